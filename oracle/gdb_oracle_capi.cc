@@ -1,0 +1,126 @@
+// gdb_oracle_capi.cc - TEST ORACLE driver + C entry points (ctypes).  NOT PRODUCT CODE.
+//
+// Restates the control flow of tools/src/gt_mpi_gather.cc:322-366 (scan_and_produce_Broad_GVCF):
+// build the operator, then for every query interval call scan_and_operate until the scan state
+// reports done, draining the output buffer after each call (the "-p <page>" batched mode when
+// buffer_limit != 0).
+#include "gdb_oracle_combine.hpp"
+
+#include <chrono>
+#include <cstdio>
+
+using namespace gdb_oracle;
+
+namespace {
+
+struct RunResult { std::string text; uint64_t num_records = 0; uint64_t num_cells = 0; double scan_seconds = 0; };
+
+RunResult run_query(const std::string& query_json_text, const uint8_t* cells, uint64_t nbytes, int64_t partition_begin, int64_t partition_end,
+                    uint64_t buffer_limit, bool with_header, const ReferenceGenome* external_ref) {
+  mini_json::Value q = mini_json::parse(query_json_text);
+  VidMapper vid;
+  if (q.HasMember("vid_mapping_file")) vid.load_vid(mini_json::parse_file(q["vid_mapping_file"].GetString()));
+  else if (q.HasMember("vid_mapping")) vid.load_vid(q["vid_mapping"]);
+  else throw OracleException("query JSON needs vid_mapping_file or vid_mapping");
+  if (q.HasMember("callset_mapping_file")) vid.load_callsets(mini_json::parse_file(q["callset_mapping_file"].GetString()));
+  else if (q.HasMember("callset_mapping") || q.HasMember("callsets")) vid.load_callsets(q);
+  else throw OracleException("query JSON needs callset_mapping_file or callset_mapping");
+  VariantArray array;
+  array.schema = build_array_schema(vid);
+  array.num_rows = (int64_t)vid.row_to_callset.size();
+  array.load(cells, nbytes, partition_begin, partition_end);
+  QueryConfig qc;
+  qc.read_query_json(q, vid, 0);
+  qc.do_query_bookkeeping(array.schema, vid, array.num_rows, 0);
+  std::string tmpl;
+  if (!qc.vcf_header_filename.empty()) tmpl = mini_json::read_text_file(qc.vcf_header_filename);
+  ReferenceGenome ref_local;
+  const ReferenceGenome* ref = external_ref;
+  if (!ref && !qc.reference_genome.empty()) { ref_local.load_fasta(qc.reference_genome); ref = &ref_local; }
+  BroadCombinedGVCFOperator op(vid, qc, tmpl, ref, qc.max_diploid_alt_alleles_that_can_be_genotyped);
+  op.buffer_limit = buffer_limit;
+  RunResult rr;
+  if (with_header) { rr.text = op.header_text; op.bytes_in_buffer = op.header_text.size(); }
+  QueryProcessor qp(&array);
+  auto t0 = std::chrono::steady_clock::now();
+  ScanState ss;
+  unsigned n_int = std::max<unsigned>(1u, (unsigned)qc.column_intervals.size());
+  for (unsigned i = 0; i < n_int; ++i) {
+    while (!ss.end()) {
+      qp.scan_and_operate(qc, op, i, true, &ss);
+      rr.text += op.out;  // do_output(); rw_buffer.m_num_valid_bytes = 0
+      op.out.clear();
+      op.bytes_in_buffer = 0;
+    }
+    ss.reset();
+  }
+  rr.scan_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  rr.num_records = op.num_records;
+  rr.num_cells = qp.stats.num_cells;
+  return rr;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Runs one produce-Broad-GVCF query.  Returns 0 on success; *out is malloc'ed (release with oracle_free).
+int oracle_run_query(const char* query_json_text, const uint8_t* cells, uint64_t nbytes, int64_t partition_begin, int64_t partition_end,
+                     uint64_t buffer_limit, int with_header, char** out, uint64_t* out_len, uint64_t* num_records, double* scan_seconds,
+                     char* err, uint64_t errlen) {
+  try {
+    RunResult rr = run_query(query_json_text, cells, nbytes, partition_begin, partition_end, buffer_limit, with_header != 0, nullptr);
+    *out = (char*)malloc(rr.text.size() + 1);
+    memcpy(*out, rr.text.data(), rr.text.size());
+    (*out)[rr.text.size()] = 0;
+    *out_len = rr.text.size();
+    if (num_records) *num_records = rr.num_records;
+    if (scan_seconds) *scan_seconds = rr.scan_seconds;
+    return 0;
+  } catch (const std::exception& e) {
+    if (err && errlen) snprintf(err, errlen, "%s", e.what());
+    return 1;
+  }
+}
+
+void oracle_free(char* p) { free(p); }
+
+// format_float exposed for the float-format unit tests
+int oracle_format_float(float v, char* buf, uint64_t buflen) {
+  std::string s;
+  format_float(s, v);
+  snprintf(buf, buflen, "%s", s.c_str());
+  return (int)s.size();
+}
+
+// genotype-order known answers (src/test/cpp/src/test_non_diploid_mapper.cc): enumerates the merged
+// genotypes for (num_alleles, ploidy) and returns, per merged genotype, the input genotype index or -1.
+// lut_m2i[k] = input allele index for merged allele k (-1 = missing).
+int oracle_genotype_map(const int64_t* lut_m2i, unsigned num_merged, int non_ref_exists, unsigned ploidy, uint64_t input_size, int64_t* out, uint64_t out_cap) {
+  CombineAllelesLUT lut;
+  lut.resize_luts_if_needed(1u, num_merged);
+  for (unsigned k = 0; k < num_merged; ++k) if (lut_m2i[k] >= 0) lut.add_input_merged_idx_pair(0u, lut_m2i[k], k);
+  uint64_t n = 0;
+  remap_based_on_genotype(input_size, 0, lut, num_merged, non_ref_exists != 0, ploidy, [&](uint64_t o, bool has, uint64_t i) {
+    if (o < out_cap) out[o] = has ? (int64_t)i : -1;
+    n = std::max(n, o + 1);
+  });
+  return (int)n;
+}
+
+}  // extern "C"
+
+#ifdef ORACLE_MAIN
+int main(int argc, char** argv) {
+  if (argc < 3) { fprintf(stderr, "usage: %s <query.json> <cells.bin> [buffer_limit]\n", argv[0]); return 2; }
+  std::string q = mini_json::read_text_file(argv[1]);
+  std::string cells = mini_json::read_text_file(argv[2]);
+  uint64_t lim = argc > 3 ? strtoull(argv[3], nullptr, 10) : 0;
+  try {
+    RunResult rr = run_query(q, (const uint8_t*)cells.data(), cells.size(), 0, INT64_MAX - 1, lim, true, nullptr);
+    fwrite(rr.text.data(), 1, rr.text.size(), stdout);
+    fprintf(stderr, "records %llu scan %.6f s\n", (unsigned long long)rr.num_records, rr.scan_seconds);
+  } catch (const std::exception& e) { fprintf(stderr, "error: %s\n", e.what()); return 1; }
+  return 0;
+}
+#endif

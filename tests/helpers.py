@@ -1,0 +1,92 @@
+"""Shared helpers for the parity tests: fixture cells, query JSON, oracle access (ctypes)."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+import vcf2cells  # noqa: E402
+from golden_cases import VCF_ATTRIBUTES_ORDER  # noqa: E402
+
+INT64_MAX = 2**63 - 1
+_cells_cache = {}
+
+
+def cells_for(callsets, vid):
+    """Begin-cells (reference binary-cell layout) for a callset mapping of the fixture tree."""
+    key = (callsets, vid)
+    if key not in _cells_cache:
+        cs = os.path.join(GOLDEN, "inputs", "callsets", callsets)
+        vd = os.path.join(GOLDEN, "inputs", vid)
+        cells = vcf2cells.build_cells(cs, vd, lambda fn: os.path.join(GOLDEN, fn))
+        _cells_cache[key] = b"".join(c[3] for c in cells)
+    return _cells_cache[key]
+
+
+def query_json(callsets, vid, overrides, mode):
+    q = {
+        "vid_mapping_file": os.path.join(GOLDEN, "inputs", vid),
+        "callset_mapping_file": os.path.join(GOLDEN, "inputs", "callsets", callsets),
+        "vcf_header_filename": os.path.join(GOLDEN, "inputs", "template_vcf_header.vcf"),
+        "reference_genome": os.path.join(GOLDEN, "inputs", "chr1_10MB.fasta.gz"),
+    }
+    ov = dict(overrides)
+    pb = ov.pop("partition_begin", 0)
+    if mode == "query":
+        q["attributes"] = VCF_ATTRIBUTES_ORDER
+        q["query_row_ranges"] = [{"range_list": [{"low": 0, "high": 3}]}]
+    else:  # loader in-line combine: every schema attribute, interval = column partition
+        q["query_column_ranges"] = [[[pb, INT64_MAX - 1]]]
+    q.update(ov)
+    return q, pb
+
+
+def golden_text(name):
+    with open(os.path.join(GOLDEN, "outputs", name), "rb") as fp:
+        return fp.read()
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    return os.path.join(ROOT, "oracle", "liboracle_gvcf.so")
+
+
+_oracle = None
+
+
+def oracle_lib():
+    global _oracle
+    if _oracle is None:
+        lib = ctypes.CDLL(build_oracle())
+        lib.oracle_run_query.restype = ctypes.c_int
+        lib.oracle_run_query.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64,
+                                         ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
+                                         ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
+                                         ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_uint64]
+        lib.oracle_free.argtypes = [ctypes.c_void_p]
+        lib.oracle_format_float.argtypes = [ctypes.c_float, ctypes.c_char_p, ctypes.c_uint64]
+        lib.oracle_genotype_map.restype = ctypes.c_int
+        lib.oracle_genotype_map.argtypes = [ctypes.POINTER(ctypes.c_int64), ctypes.c_uint, ctypes.c_int, ctypes.c_uint,
+                                            ctypes.c_uint64, ctypes.POINTER(ctypes.c_int64), ctypes.c_uint64]
+        _oracle = lib
+    return _oracle
+
+
+def oracle_run(query, cells, partition_begin=0, partition_end=INT64_MAX - 1, buffer_limit=0, with_header=True):
+    lib = oracle_lib()
+    out = ctypes.c_void_p()
+    n = ctypes.c_uint64()
+    nrec = ctypes.c_uint64()
+    secs = ctypes.c_double()
+    err = ctypes.create_string_buffer(4096)
+    rc = lib.oracle_run_query(json.dumps(query).encode(), cells, len(cells), partition_begin, partition_end, buffer_limit,
+                              1 if with_header else 0, ctypes.byref(out), ctypes.byref(n), ctypes.byref(nrec),
+                              ctypes.byref(secs), err, 4096)
+    if rc != 0:
+        raise RuntimeError("oracle: " + err.value.decode())
+    txt = ctypes.string_at(out.value, n.value)
+    lib.oracle_free(out)
+    return txt, nrec.value, secs.value
