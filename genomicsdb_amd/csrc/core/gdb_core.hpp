@@ -1,0 +1,779 @@
+// gdb_core.hpp - per-cell / per-record / per-entry device functions of the MI355X variant-combine path.
+//
+// Everything here is GDB_HD (__host__ __device__ under hipcc): the HIP kernels in
+// kernels/gdb_kernels.hip are thin grid wrappers around these functions, and tests/hostsim compiles the
+// very same functions with g++ so the index arithmetic can be debugged without a GPU.  This is NOT a CPU
+// path of the product: the shipped library only contains the HIP kernels.
+//
+// What replaces what (reference paths under /root/reference/src/main/cpp):
+//   classify_cell          gt_fill_row flags + field validity   src/genomicsdb/query_variants.cc:1014-1117,
+//                                                               include/genomicsdb/variant_field_data.h:365-384
+//   site_emit              handle_deletions + merge_reference_allele + merge_alt_alleles (+LUT) + INFO reducers +
+//                          fixed VCF columns                    src/query_operations/broad_combined_gvcf.cc:523-601,
+//                                                               :765-901, :912-1078; variant_operations.cc:73-228
+//   entry_emit             remap_GT_field / remap_data_based_on_alleles / _genotype_{haploid,diploid} +
+//                          collect_and_extend_fields + htslib FORMAT text
+//                                                               src/genomicsdb/variant_field_handler.cc:41-191, :804-871
+// The sweep itself (VariantCallEndPQ, handle_gvcf_ranges) has no per-thread counterpart: it becomes the
+// event sort + scans of the pipeline.
+#pragma once
+#include "gdb_types.h"
+
+// ---- cell flags --------------------------------------------------------------------------------------
+#define GDB_CF_REFBLOCK 1u
+#define GDB_CF_DELETION 2u
+#define GDB_CF_HAS_NR 4u
+#define GDB_CF_HEAVY 8u
+#define GDB_CF_IN_WINDOW 16u
+#define GDB_CF_NALT(f) (((f) >> 8) & 0xFFu)
+#define GDB_CF_PLOIDY(f) (((f) >> 16) & 0xFu)
+
+// ---- record flags ------------------------------------------------------------------------------------
+#define GDB_RF_NON_REF_EXISTS 1u
+#define GDB_RF_REMAPPING_NEEDED 2u
+#define GDB_RF_SKIP_G_FIELDS 4u   // too many ALT alleles for genotype-length fields
+
+// incidence flags
+#define GDB_IF_SPANNING 1u        // spanning deletion (began before this record)
+#define GDB_IF_GT_OVERRIDE 2u     // GT replaced by the min-PL genotype
+#define GDB_IF_NO_NR 4u           // call has no <NON_REF>: unmapped GT alleles become '.'
+
+struct CellMeta {       // SoA, one entry per cell of the staged fragment
+  uint64_t* vmask;      // bit f: plan field f is valid for this cell
+  uint32_t* cflags;
+  int32_t* dpval;       // INFO DP else MIN_DP else DP_FORMAT else 0 (broad_combined_gvcf.cc:696-712)
+  int64_t* eff_end;     // END truncated by the next cell of the same row (overlap override, query_variants.cc:512-543)
+  int32_t* k_lo;        // first / last record this cell is live in (-1: none)
+  int32_t* k_hi;
+};
+
+struct RecordTable {    // one entry per output record (VCF line)
+  int64_t npos;         // P
+  const int64_t* start; // column interval of the record
+  const int64_t* end;
+};
+
+struct SiteOut {        // per-record results of the site kernel
+  uint8_t* num_alleles;    // A_k, merged alleles incl. REF
+  uint8_t* rflags;
+  uint32_t* fmt_mask;      // bit i: plan.format_field[i] is emitted for this record
+  uint32_t* prefix_len;    // bytes of the fixed columns incl. trailing FORMAT keys, excl. sample columns
+};
+
+struct HeavyLists {     // incidences (record, heavy cell) sorted by (record, row)
+  const int64_t* base;       // [P+1]
+  const int64_t* cell;       // [T] cell idx
+  const uint32_t* i2m_off;   // [T+1]
+  int8_t* i2m;               // input allele idx -> merged allele idx (-1: none)
+  uint8_t* iflags;           // [T]
+  int8_t* gt_override;       // [T*2]
+};
+
+struct PresenceCounts {  // per record, from difference arrays + scan
+  const int32_t* fmt_cnt;  // [n_format][P]  #live calls with a valid value for format_field[i]
+  const int32_t* dp_sum;   // [P]
+  const int32_t* nr_cnt;   // [P]  #live calls whose ALT has <NON_REF>
+  int64_t stride;          // P
+};
+
+struct NameTables {      // small text tables in device memory
+  const char* text;
+  const int32_t* field_name_off;   // per plan field: vcf name
+  const int32_t* field_name_len;
+  const int32_t* filter_name_off;  // per vid field idx (FILTER ids); len 0 = not in header
+  const int32_t* filter_name_len;
+  int32_t n_filter_names;
+};
+
+// ---- sinks -----------------------------------------------------------------------------------------
+struct CountSink {
+  uint64_t n;
+  GDB_HD CountSink() : n(0) {}
+  GDB_HD void put(char) { ++n; }
+  GDB_HD void write(const char*, int len) { n += (uint64_t)len; }
+};
+struct ByteSink {
+  char* p;
+  GDB_HD explicit ByteSink(char* q) : p(q) {}
+  GDB_HD void put(char c) { *p++ = c; }
+  GDB_HD void write(const char* s, int len) { for (int i = 0; i < len; ++i) *p++ = s[i]; }
+};
+
+// ---- small helpers -----------------------------------------------------------------------------------
+GDB_HD uint32_t gdb_f2u(float f) { union { float f; uint32_t u; } x; x.f = f; return x.u; }
+GDB_HD bool gdb_int_valid(int32_t v) { return v != GDB_BCF_INT32_MISSING && v != GDB_BCF_INT32_VECTOR_END; }
+GDB_HD bool gdb_float_valid(float v) { uint32_t u = gdb_f2u(v); return u != GDB_BCF_FLOAT_MISSING_BITS && u != GDB_BCF_FLOAT_VECTOR_END_BITS; }
+GDB_HD int gdb_alleles2gt(int a, int b) { return a > b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; }
+
+template <class Sink> GDB_HD void put_u64(Sink& s, uint64_t v) {
+  char buf[20];
+  int n = 0;
+  do { buf[n++] = (char)('0' + (v % 10)); v /= 10; } while (v);
+  while (n) s.put(buf[--n]);
+}
+template <class Sink> GDB_HD void put_i64(Sink& s, int64_t v) {
+  if (v < 0) { s.put('-'); put_u64(s, (uint64_t)(-(v + 1)) + 1u); } else put_u64(s, (uint64_t)v);
+}
+template <class Sink> GDB_HD void put_i32(Sink& s, int32_t v) { put_i64(s, (int64_t)v); }
+
+// Float text as the goldens pin it (htslib-fork kputd flavour, see oracle/gdb_oracle_combine.hpp format_float).
+// Returns false when the value is outside the range this path reproduces exactly.
+template <class Sink> GDB_HD bool put_float(Sink& s, float f) {
+  double d = (double)f;
+  if (d == 0) { if (gdb_f2u(f) >> 31) s.put('-'); s.put('0'); return true; }
+  if (d < 0) { s.put('-'); d = -d; }
+  if (!(d >= 0.0001 && d <= 999999)) {
+    // "%g" branch: exact 6-significant-digit scientific form for 1e6 <= d < 2^63
+    if (!(d > 999999 && d < 9.2e18)) return false;
+    uint64_t I = (uint64_t)d;
+    double frac = d - (double)I;
+    int nd = 0;
+    { uint64_t t = I; while (t) { ++nd; t /= 10; } }
+    uint64_t pw = 1;
+    for (int i = 0; i < nd - 6; ++i) pw *= 10;
+    uint64_t q = I / pw, rem = I % pw, half = pw / 2;
+    bool up;
+    if (pw == 1) up = frac > 0.5 || (frac == 0.5 && (q & 1));  // exactly 6 integer digits
+    else up = rem > half || (rem == half && (frac > 0 || (q & 1)));
+    if (up) ++q;
+    int ex = nd - 1;
+    if (q >= 1000000) { q /= 10; ++ex; }
+    char dg[6];
+    for (int i = 5; i >= 0; --i) { dg[i] = (char)('0' + q % 10); q /= 10; }
+    int last = 5;
+    while (last > 0 && dg[last] == '0') --last;
+    s.put(dg[0]);
+    if (last > 0) { s.put('.'); for (int i = 1; i <= last; ++i) s.put(dg[i]); }
+    s.put('e'); s.put('+');
+    if (ex < 10) s.put('0');
+    put_u64(s, (uint64_t)ex);
+    return true;
+  }
+  uint64_t i = (uint64_t)(d * 10000000000.0);
+  if (d < 0.001) i += 5; else if (d < 0.01) i += 50; else if (d < 0.1) i += 500; else if (d < 1) i += 5000;
+  else if (d < 10) i += 50000; else if (d < 100) i += 500000; else if (d < 1000) i += 5000000;
+  else if (d < 10000) i += 50000000; else if (d < 100000) i += 500000000; else i += 5000000000ULL;
+  char dg[24];
+  int p = 0;
+  { char tmp[24]; int n = 0; do { tmp[n++] = (char)('0' + i % 10); i /= 10; } while (i); while (n) dg[p++] = tmp[--n]; }
+  char out[40];
+  int m = 0, dot = -1;
+  if (p <= 10) {
+    out[m++] = '0'; dot = m; out[m++] = '.';
+    for (int z = 0; z < 10 - p; ++z) out[m++] = '0';
+    int take = p < 6 ? p : 6;
+    for (int z = 0; z < take; ++z) out[m++] = dg[z];
+  } else {
+    int ip = p - 10;
+    for (int z = 0; z < ip; ++z) out[m++] = dg[z];
+    if (ip < 6) { dot = m; out[m++] = '.'; for (int z = ip; z < 6; ++z) out[m++] = dg[z]; }
+  }
+  if (dot >= 0) while (m > dot + 2 && out[m - 1] == '0') --m;
+  s.write(out, m);
+  return true;
+}
+
+// ---- fragment accessors --------------------------------------------------------------------------------
+template <class T> GDB_HD const T* cell_field(const FragmentView& fr, const CombinePlan& pl, int f, int64_t c, int& n) {
+  const GdbColumn& col = fr.col[f];
+  if (col.off) { uint32_t a = col.off[c], b = col.off[c + 1]; n = (int)(b - a); return (const T*)col.data + a; }
+  n = pl.field[f].fixed_num;
+  return (const T*)col.data + (int64_t)c * n;
+}
+GDB_HD bool field_valid(const CellMeta& cm, int64_t c, int f) { return (cm.vmask[c] >> f) & 1ull; }
+
+// i-th '|' separated token of an ALT string (empty tokens skipped like strtok_r); false when exhausted
+GDB_HD bool alt_token(const char* s, int len, int idx, const char*& tok, int& tlen) {
+  int i = 0, k = -1;
+  while (i < len) {
+    while (i < len && s[i] == '|') ++i;
+    if (i >= len) break;
+    int j = i;
+    while (j < len && s[j] != '|') ++j;
+    if (++k == idx) { tok = s + i; tlen = j - i; return true; }
+    i = j;
+  }
+  return false;
+}
+GDB_HD bool allele_is_symbolic(const char* a, int n) {  // VariantUtils::is_symbolic_allele
+  if (n > 0 && a[0] == '&') return true;
+  if (n == 1 && a[0] == '*') return true;
+  if (n > 0 && a[0] == '<' && a[n - 1] == '>') return true;
+  for (int i = 0; i < n; ++i) if (a[i] == '[' || a[i] == ']') return true;
+  return false;
+}
+GDB_HD bool allele_is_deletion(int ref_len, const char* a, int n) {  // VariantUtils::is_deletion
+  return ref_len > 1 && ((n == 1 && a[0] == '*') || (!allele_is_symbolic(a, n) && n < ref_len));
+}
+
+// ---- K0: per-cell classification ---------------------------------------------------------------------
+GDB_HD void classify_cell(const FragmentView& fr, const CombinePlan& pl, const CellMeta& cm, int64_t c, uint32_t* err) {
+  uint64_t vmask = 0;
+  for (int f = 0; f < pl.nfields; ++f) {
+    const GdbFieldDesc& fd = pl.field[f];
+    int n;
+    bool valid = false;
+    if (fd.elem == GDB_ET_INT) {
+      const int32_t* p = cell_field<int32_t>(fr, pl, f, c, n);
+      for (int i = 0; i < n; ++i) if (p[i] != GDB_TILEDB_NULL_INT32) { valid = true; break; }
+    } else if (fd.elem == GDB_ET_FLOAT) {
+      const float* p = cell_field<float>(fr, pl, f, c, n);
+      for (int i = 0; i < n; ++i) if (gdb_f2u(p[i]) != GDB_TILEDB_NULL_FLOAT_BITS) { valid = true; break; }
+    } else {
+      const char* p = cell_field<char>(fr, pl, f, c, n);
+      for (int i = 0; i < n; ++i) if (p[i] != GDB_TILEDB_NULL_CHAR) { valid = true; break; }
+    }
+    if (valid) vmask |= 1ull << f;
+  }
+  uint32_t flags = 0;
+  int nalt = 0, ref_len = 0;
+  if (pl.f_REF >= 0 && pl.f_ALT >= 0 && ((vmask >> pl.f_REF) & 1) && ((vmask >> pl.f_ALT) & 1)) {
+    int alt_len;
+    cell_field<char>(fr, pl, pl.f_REF, c, ref_len);
+    const char* alt = cell_field<char>(fr, pl, pl.f_ALT, c, alt_len);
+    bool deletion = false, has_nr = false;
+    const char* tok; int tl;
+    for (int i = 0; alt_token(alt, alt_len, i, tok, tl); ++i) {
+      ++nalt;
+      if (tl > 0 && tok[0] == '&') has_nr = true;
+      if (ref_len > 1 && !allele_is_symbolic(tok, tl) && tl < ref_len) deletion = true;  // contains_deletion
+    }
+    if (deletion) flags |= GDB_CF_DELETION;
+    if (has_nr) flags |= GDB_CF_HAS_NR;
+    if (ref_len == 1 && nalt == 1 && has_nr) flags |= GDB_CF_REFBLOCK;  // is_reference_block
+  }
+  if (nalt + 1 > GDB_MAX_INPUT_ALLELES) { *err |= GDB_ERR_TOO_MANY_INPUT_ALLELES; nalt = GDB_MAX_INPUT_ALLELES - 1; }
+  int ploidy = 0;
+  if (pl.f_GT >= 0 && ((vmask >> pl.f_GT) & 1)) {
+    int n;
+    cell_field<int32_t>(fr, pl, pl.f_GT, c, n);
+    ploidy = pl.field[pl.f_GT].length == GDB_VL_PP ? (n + 1) >> 1 : n;
+    if (ploidy > 15) ploidy = 15;
+  }
+  // heavy = needs the per-record site logic: not a plain reference block, or carries a value an INFO reducer /
+  // QUAL / FILTER rule would read
+  bool heavy = !(flags & GDB_CF_REFBLOCK);
+  for (int i = 0; i < pl.n_info; ++i) if ((vmask >> pl.info_field[i]) & 1) heavy = true;
+  if (pl.qual_combine_op != GDB_OP_UNKNOWN && pl.f_QUAL >= 0 && ((vmask >> pl.f_QUAL) & 1)) heavy = true;
+  if (pl.produce_FILTER_field && pl.f_FILTER >= 0 && ((vmask >> pl.f_FILTER) & 1)) heavy = true;
+  if (heavy) flags |= GDB_CF_HEAVY;
+  flags |= ((uint32_t)nalt & 0xFFu) << 8;
+  flags |= ((uint32_t)ploidy & 0xFu) << 16;
+  // DP contribution of this call to the INFO DP sum
+  int32_t dp = 0;
+  {
+    int n; bool got = false;
+    if (pl.f_DP >= 0 && ((vmask >> pl.f_DP) & 1)) { const int32_t* p = cell_field<int32_t>(fr, pl, pl.f_DP, c, n); if (n > 0 && gdb_int_valid(p[0])) { dp = p[0]; got = true; } }
+    if (!got && pl.f_MIN_DP >= 0 && ((vmask >> pl.f_MIN_DP) & 1)) { const int32_t* p = cell_field<int32_t>(fr, pl, pl.f_MIN_DP, c, n); if (n > 0 && gdb_int_valid(p[0])) { dp = p[0]; got = true; } }
+    if (!got && pl.f_DP_FORMAT >= 0 && ((vmask >> pl.f_DP_FORMAT) & 1)) { const int32_t* p = cell_field<int32_t>(fr, pl, pl.f_DP_FORMAT, c, n); if (n > 0 && gdb_int_valid(p[0])) { dp = p[0]; got = true; } }
+  }
+  cm.vmask[c] = vmask;
+  cm.cflags[c] = flags;
+  cm.dpval[c] = dp;
+}
+
+// ---- site (per record) ---------------------------------------------------------------------------------
+struct AlleleRef { const char* p; int len; int suffix_from; };  // text = p[0..len) + mergedREF[suffix_from..)
+
+GDB_HD bool allele_equal(const AlleleRef& a, const AlleleRef& b, const char* mref, int mref_len) {
+  int la = a.len + (a.suffix_from >= 0 ? mref_len - a.suffix_from : 0);
+  int lb = b.len + (b.suffix_from >= 0 ? mref_len - b.suffix_from : 0);
+  if (la != lb) return false;
+  for (int i = 0; i < la; ++i) {
+    char ca = i < a.len ? a.p[i] : mref[a.suffix_from + (i - a.len)];
+    char cb = i < b.len ? b.p[i] : mref[b.suffix_from + (i - b.len)];
+    if (ca != cb) return false;
+  }
+  return true;
+}
+
+struct SiteCtx {
+  FragmentView fr;
+  CombinePlan pl;
+  CellMeta cm;
+  RecordTable rec;
+  HeavyLists hl;
+  PresenceCounts pc;
+  NameTables names;
+  QueryWindow qw;
+  SiteOut so;
+};
+
+// value of a scalar INFO-like field over the heavy list: median / sum / mean (variant_field_handler.cc:529-607).
+// Spanning-deletion calls have their INFO fields invalidated (broad_combined_gvcf.cc:1068-1075) unless keep_spanning.
+GDB_HD bool inc_is_spanning(const SiteCtx& cx, int64_t t, int64_t s_k) {
+  int64_t c = cx.hl.cell[t];
+  return (cx.cm.cflags[c] & GDB_CF_DELETION) && s_k > cx.fr.begin[c];
+}
+template <class T> GDB_HD bool reduce_scalar(const SiteCtx& cx, int64_t k, int f, int op, bool keep_spanning, T& result) {
+  const int64_t b = cx.hl.base[k], e = cx.hl.base[k + 1];
+  const int64_t s_k = cx.rec.start[k];
+  const bool is_float = cx.pl.field[f].elem == GDB_ET_FLOAT;
+  int64_t nvalid = 0;
+  T sum = 0;
+  for (int64_t t = b; t < e; ++t) {
+    if (!keep_spanning && inc_is_spanning(cx, t, s_k)) continue;
+    int64_t c = cx.hl.cell[t];
+    if (!field_valid(cx.cm, c, f)) continue;
+    int n;
+    const T* p = cell_field<T>(cx.fr, cx.pl, f, c, n);
+    T v = p[0];
+    bool ok = is_float ? gdb_float_valid((float)v) : gdb_int_valid((int32_t)v);
+    if (!ok) continue;
+    sum += v;
+    ++nvalid;
+  }
+  if (!nvalid) return false;
+  if (op == GDB_OP_SUM) { result = sum; return true; }
+  if (op == GDB_OP_MEAN) { result = sum / (T)nvalid; return true; }
+  // median = element of rank nvalid/2 in ascending order (std::nth_element at mid_point)
+  int64_t mid = nvalid / 2;
+  for (int64_t t = b; t < e; ++t) {
+    if (!keep_spanning && inc_is_spanning(cx, t, s_k)) continue;
+    int64_t c = cx.hl.cell[t];
+    if (!field_valid(cx.cm, c, f)) continue;
+    int n;
+    const T* p = cell_field<T>(cx.fr, cx.pl, f, c, n);
+    T v = p[0];
+    if (!(is_float ? gdb_float_valid((float)v) : gdb_int_valid((int32_t)v))) continue;
+    int64_t less = 0, leq = 0;
+    for (int64_t u = b; u < e; ++u) {
+      if (!keep_spanning && inc_is_spanning(cx, u, s_k)) continue;
+      int64_t c2 = cx.hl.cell[u];
+      if (!field_valid(cx.cm, c2, f)) continue;
+      int n2;
+      const T* p2 = cell_field<T>(cx.fr, cx.pl, f, c2, n2);
+      T w = p2[0];
+      if (!(is_float ? gdb_float_valid((float)w) : gdb_int_valid((int32_t)w))) continue;
+      if (w < v) ++less;
+      if (w <= v) ++leq;
+    }
+    if (less <= mid && mid < leq) { result = v; return true; }
+  }
+  return false;
+}
+
+GDB_HD int find_contig(const QueryWindow& qw, int64_t pos) {  // VidMapper::get_contig_location
+  int lo = 0, hi = qw.ncontigs;  // last contig with offset <= pos
+  while (lo < hi) { int mid = (lo + hi) >> 1; if (qw.contigs[mid].offset <= pos) lo = mid + 1; else hi = mid; }
+  int idx = lo - 1;
+  if (idx < 0) return -1;
+  if (pos >= qw.contigs[idx].offset && pos < qw.contigs[idx].offset + qw.contigs[idx].length) return idx;
+  return -1;
+}
+
+// Per-record site logic.  PASS 0 (Sink = CountSink, write_luts = false) sizes the prefix; PASS 1 writes the prefix
+// text and the per-incidence allele LUTs / flags.  One call handles one record.
+template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& sink, bool write_luts, uint32_t* err) {
+  const CombinePlan& pl = cx.pl;
+  const int64_t s_k = cx.rec.start[k], e_k = cx.rec.end[k];
+  const int64_t hb = cx.hl.base[k], he = cx.hl.base[k + 1];
+  // -- merged REF: longest REF among calls that START here (merge_reference_allele) -------------------
+  const char* mref = nullptr;
+  int mref_len = 0;
+  char ref_base = 'N';
+  {
+    // lowest-row cell starting at s_k (cells are (col,row) sorted)
+    int64_t lo = 0, hi = cx.fr.ncells;
+    while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (cx.fr.begin[mid] < s_k) lo = mid + 1; else hi = mid; }
+    if (lo < cx.fr.ncells && cx.fr.begin[lo] == s_k && field_valid(cx.cm, lo, pl.f_REF)) {
+      int n;
+      mref = cell_field<char>(cx.fr, pl, pl.f_REF, lo, n);
+      mref_len = n;
+    }
+    for (int64_t t = hb; t < he; ++t) {
+      int64_t c = cx.hl.cell[t];
+      if (cx.fr.begin[c] != s_k || !field_valid(cx.cm, c, pl.f_REF)) continue;
+      int n;
+      const char* r = cell_field<char>(cx.fr, pl, pl.f_REF, c, n);
+      if (n > mref_len) { mref = r; mref_len = n; }
+    }
+    if (mref_len == 0 || (mref_len == 1 && mref[0] == 'N')) {
+      // nobody starts here: base from the reference genome (broad_combined_gvcf.cc:825-830)
+      int64_t off = s_k - cx.qw.ref_begin;
+      char b = (cx.qw.ref_bases && off >= 0 && off < cx.qw.ref_len) ? cx.qw.ref_bases[off] : 'N';
+      ref_base = (b == 'A' || b == 'C' || b == 'G' || b == 'T') ? b : 'N';
+      mref = &ref_base;
+      mref_len = 1;
+    }
+  }
+  // -- merged ALT list + LUTs (merge_alt_alleles), spanning deletions folded in (handle_deletions) ------
+  AlleleRef merged[GDB_MAX_MERGED_ALLELES];
+  int nmerged = 1;  // index 0 = REF
+  const char star = '*';
+  bool non_ref_exists = cx.pc.nr_cnt[k] > 0;
+  for (int64_t t = hb; t < he; ++t) {
+    int64_t c = cx.hl.cell[t];
+    uint32_t cf = cx.cm.cflags[c];
+    int ref_len = 0, alt_len = 0;
+    cell_field<char>(cx.fr, pl, pl.f_REF, c, ref_len);
+    const char* alt = cell_field<char>(cx.fr, pl, pl.f_ALT, c, alt_len);
+    int nalt = (int)GDB_CF_NALT(cf);
+    int8_t* lut = write_luts ? cx.hl.i2m + cx.hl.i2m_off[t] : nullptr;
+    bool spanning = (cf & GDB_CF_DELETION) && s_k > cx.fr.begin[c];
+    uint8_t iflag = 0;
+    if (lut) { lut[0] = 0; for (int a = 1; a <= nalt; ++a) lut[a] = -1; }
+    if (spanning) {
+      iflag |= GDB_IF_SPANNING;
+      if (!(cf & GDB_CF_HAS_NR)) iflag |= GDB_IF_NO_NR;
+      // deletion allele with the lowest hom PL maps to '*' (broad_combined_gvcf.cc:960-989)
+      int ploidy = (int)GDB_CF_PLOIDY(cf);
+      int npl = 0;
+      const int32_t* plv = nullptr;
+      bool pl_exists = pl.f_PL >= 0 && field_valid(cx.cm, c, pl.f_PL);
+      if (pl_exists) plv = cell_field<int32_t>(cx.fr, pl, pl.f_PL, c, npl);
+      int lowest = -1;
+      int lowest_pl = 0x7FFFFFFF;
+      const char* tok; int tl;
+      for (int i = 0; alt_token(alt, alt_len, i, tok, tl); ++i) {
+        int aidx = i + 1;
+        if (allele_is_deletion(ref_len, tok, tl)) {
+          if (lowest < 0) lowest = aidx;
+          if (pl_exists) {
+            int64_t gt_idx;
+            if (ploidy == 0) gt_idx = 0;
+            else if (ploidy == 1) gt_idx = aidx;
+            else if (ploidy == 2) gt_idx = gdb_alleles2gt(aidx, aidx);
+            else { *err |= GDB_ERR_UNSUPPORTED_PLOIDY; gt_idx = 0x7FFFFFFF; }
+            if (gt_idx < npl && plv[gt_idx] < lowest_pl) { lowest_pl = plv[gt_idx]; lowest = aidx; }
+          }
+        }
+      }
+      if (lowest < 0) { *err |= GDB_ERR_INTERNAL; lowest = 1; }
+      AlleleRef cand{&star, 1, -1};
+      int found = -1;
+      for (int j = 1; j < nmerged; ++j) if (allele_equal(merged[j], cand, mref, mref_len)) { found = j; break; }
+      if (found < 0) {
+        if (nmerged >= GDB_MAX_MERGED_ALLELES - 1) { *err |= GDB_ERR_TOO_MANY_MERGED_ALLELES; found = nmerged - 1; }
+        else { merged[nmerged] = cand; found = nmerged++; }
+      }
+      if (lut) lut[lowest] = (int8_t)found;
+      if (lut && pl.min_PL_GT_for_spanning_deletions && pl.produce_GT_field && pl_exists && pl.f_GT >= 0 && field_valid(cx.cm, c, pl.f_GT)) {
+        // update_GT_to_correspond_to_min_PL_value on the REDUCED PL (alleles REF,*,[<NON_REF>])
+        int nr_idx = -1;
+        for (int i = 0; alt_token(alt, alt_len, i, tok, tl); ++i) if (tl > 0 && tok[0] == '&') nr_idx = i + 1;
+        int red2in[3] = {0, lowest, nr_idx};
+        int nred = nr_idx >= 0 ? 3 : 2;
+        int best_min = 0x7FFFFFFF, best_a = -1, best_b = -1;
+        if (ploidy == 1) {
+          for (int a = 0; a < nred; ++a) {
+            int64_t gi = red2in[a];
+            int32_t v = gi < npl ? plv[gi] : GDB_BCF_INT32_MISSING;
+            if (gdb_int_valid(v) && v < best_min) { best_min = v; best_a = a; }
+          }
+        } else if (ploidy == 2) {
+          for (int a = 0; a < nred; ++a) for (int b2 = a; b2 < nred; ++b2) {
+            int64_t gi = gdb_alleles2gt(red2in[a], red2in[b2]);
+            int32_t v = gi < npl ? plv[gi] : GDB_BCF_INT32_MISSING;
+            if (gdb_int_valid(v) && v < best_min) { best_min = v; best_a = a; best_b = b2; }
+          }
+        } else *err |= GDB_ERR_UNSUPPORTED_PLOIDY;
+        if (best_a >= 0) {
+          iflag |= GDB_IF_GT_OVERRIDE;
+          cx.hl.gt_override[2 * t] = (int8_t)best_a;      // reduced allele idx: 0 REF, 1 '*', 2 <NON_REF>
+          cx.hl.gt_override[2 * t + 1] = (int8_t)best_b;
+        }
+      }
+    } else {
+      bool suffix_needed = ref_len < mref_len;
+      const char* tok; int tl;
+      for (int i = 0; alt_token(alt, alt_len, i, tok, tl); ++i) {
+        if (tl > 0 && tok[0] == '&') continue;  // <NON_REF> goes last
+        AlleleRef cand{tok, tl, (suffix_needed && !allele_is_symbolic(tok, tl)) ? ref_len : -1};
+        int found = -1;
+        for (int j = 1; j < nmerged; ++j) if (allele_equal(merged[j], cand, mref, mref_len)) { found = j; break; }
+        if (found < 0) {
+          if (nmerged >= GDB_MAX_MERGED_ALLELES - 1) { *err |= GDB_ERR_TOO_MANY_MERGED_ALLELES; found = nmerged - 1; }
+          else { merged[nmerged] = cand; found = nmerged++; }
+        }
+        if (lut && i + 1 <= nalt) lut[i + 1] = (int8_t)found;
+      }
+    }
+    if (write_luts) cx.hl.iflags[t] = iflag;
+  }
+  const int num_merged = nmerged + (non_ref_exists ? 1 : 0);
+  if (write_luts && non_ref_exists) {
+    for (int64_t t = hb; t < he; ++t) {
+      int64_t c = cx.hl.cell[t];
+      uint32_t cf = cx.cm.cflags[c];
+      if (!(cf & GDB_CF_HAS_NR)) continue;
+      int alt_len;
+      const char* alt = cell_field<char>(cx.fr, pl, pl.f_ALT, c, alt_len);
+      const char* tok; int tl;
+      for (int i = 0; alt_token(alt, alt_len, i, tok, tl); ++i)
+        if (tl > 0 && tok[0] == '&' && i + 1 <= (int)GDB_CF_NALT(cf)) cx.hl.i2m[cx.hl.i2m_off[t] + i + 1] = (int8_t)(num_merged - 1);
+    }
+  }
+  const bool ref_block_only = (mref_len == 1 && nmerged == 1 && non_ref_exists);
+  const bool skip_G = (num_merged - 1) > pl.max_diploid_alt_alleles;
+  // -- FORMAT presence -------------------------------------------------------------------------------
+  uint32_t fmt_mask = 0;
+  if (!pl.sites_only_query)
+    for (int i = 0; i < pl.n_format; ++i) {
+      int f = pl.format_field[i];
+      if (cx.pc.fmt_cnt[(int64_t)i * cx.pc.stride + k] <= 0) continue;
+      if (pl.field[f].length == GDB_VL_G && skip_G) continue;
+      fmt_mask |= 1u << i;
+    }
+  if (write_luts) {
+    cx.so.num_alleles[k] = (uint8_t)num_merged;
+    cx.so.rflags[k] = (uint8_t)((non_ref_exists ? GDB_RF_NON_REF_EXISTS : 0) | (!ref_block_only ? GDB_RF_REMAPPING_NEEDED : 0) | (skip_G ? GDB_RF_SKIP_G_FIELDS : 0));
+    cx.so.fmt_mask[k] = fmt_mask;
+  }
+  // -- fixed columns ----------------------------------------------------------------------------------
+  int ci = find_contig(cx.qw, s_k);
+  if (ci < 0) { *err |= GDB_ERR_INTERNAL; ci = 0; }
+  const GdbContig& ctg = cx.qw.contigs[ci];
+  sink.write(cx.qw.contig_names + ctg.name_off, ctg.name_len);
+  sink.put('\t');
+  put_i64(sink, s_k - ctg.offset + 1);
+  sink.put('\t'); sink.put('.'); sink.put('\t');  // ID: not produced on the device path (host rejects ID queries)
+  sink.write(mref, mref_len);
+  sink.put('\t');
+  if (num_merged == 1) sink.put('.');
+  for (int j = 1; j < nmerged; ++j) {
+    if (j > 1) sink.put(',');
+    sink.write(merged[j].p, merged[j].len);
+    if (merged[j].suffix_from >= 0) sink.write(mref + merged[j].suffix_from, mref_len - merged[j].suffix_from);
+  }
+  if (non_ref_exists) { if (nmerged > 1) sink.put(','); const char nr[] = "<NON_REF>"; sink.write(nr, 9); }
+  sink.put('\t');
+  // QUAL
+  {
+    float q;
+    if (pl.qual_combine_op != GDB_OP_UNKNOWN && pl.f_QUAL >= 0 && reduce_scalar<float>(cx, k, pl.f_QUAL, pl.qual_combine_op, true, q)) {
+      if (!put_float(sink, q)) *err |= GDB_ERR_FLOAT_RANGE;
+    } else sink.put('.');
+  }
+  sink.put('\t');
+  // FILTER (union over live calls; only single-id unions are order-pinned)
+  {
+    int first_id = -1;
+    bool multi = false;
+    if (pl.produce_FILTER_field && pl.f_FILTER >= 0)
+      for (int64_t t = hb; t < he; ++t) {
+        int64_t c = cx.hl.cell[t];
+        if (!field_valid(cx.cm, c, pl.f_FILTER)) continue;
+        int n;
+        const int32_t* p = cell_field<int32_t>(cx.fr, pl, pl.f_FILTER, c, n);
+        for (int i = 0; i < n; ++i) { if (first_id < 0) first_id = p[i]; else if (p[i] != first_id) multi = true; }
+      }
+    if (multi) *err |= GDB_ERR_INTERNAL;
+    if (first_id >= 0 && first_id < cx.names.n_filter_names && cx.names.filter_name_len[first_id] > 0)
+      sink.write(cx.names.text + cx.names.filter_name_off[first_id], cx.names.filter_name_len[first_id]);
+    else sink.put('.');
+  }
+  sink.put('\t');
+  // INFO: END, reducers in query order, DP
+  {
+    bool any = false;
+    if (e_k > s_k) { const char t[] = "END="; sink.write(t, 4); put_i64(sink, e_k - ctg.offset + 1); any = true; }
+    for (int i = 0; i < pl.n_info; ++i) {
+      int f = pl.info_field[i];
+      const GdbFieldDesc& fd = pl.field[f];
+      if (fd.elem == GDB_ET_FLOAT) {
+        float v;
+        if (!reduce_scalar<float>(cx, k, f, fd.combine_op, false, v)) continue;
+        if (any) sink.put(';');
+        sink.write(cx.names.text + cx.names.field_name_off[f], cx.names.field_name_len[f]);
+        sink.put('=');
+        if (!put_float(sink, v)) *err |= GDB_ERR_FLOAT_RANGE;
+      } else {
+        int32_t v;
+        if (!reduce_scalar<int32_t>(cx, k, f, fd.combine_op, false, v)) continue;
+        if (any) sink.put(';');
+        sink.write(cx.names.text + cx.names.field_name_off[f], cx.names.field_name_len[f]);
+        sink.put('=');
+        put_i32(sink, v);
+      }
+      any = true;
+    }
+    int32_t dp = cx.pc.dp_sum[k];
+    if ((pl.f_DP >= 0 || pl.f_DP_FORMAT >= 0) && dp > 0 && !ref_block_only) {
+      if (any) sink.put(';');
+      const char t[] = "DP="; sink.write(t, 3); put_i32(sink, dp);
+      any = true;
+    }
+    if (!any) sink.put('.');
+  }
+  // FORMAT keys
+  if (fmt_mask) {
+    sink.put('\t');
+    bool first = true;
+    for (int i = 0; i < pl.n_format; ++i) {
+      if (!((fmt_mask >> i) & 1)) continue;
+      if (!first) sink.put(':');
+      first = false;
+      int f = pl.format_field[i];
+      if (f == pl.f_DP_FORMAT || f == pl.f_DP) { sink.put('D'); sink.put('P'); }
+      else sink.write(cx.names.text + cx.names.field_name_off[f], cx.names.field_name_len[f]);
+    }
+  }
+}
+
+// ---- sample entries --------------------------------------------------------------------------------------
+struct EntryCtx {
+  FragmentView fr;
+  CombinePlan pl;
+  CellMeta cm;
+  HeavyLists hl;
+};
+struct RecordInfo { int num_merged; uint32_t rflags; uint32_t fmt_mask; int64_t hbase, hend; };
+
+template <class Sink> GDB_HD void put_int_vector(Sink& s, const int32_t* p, int n) {
+  if (n == 0) { s.put('.'); return; }
+  for (int j = 0; j < n; ++j) {
+    if (p[j] == GDB_BCF_INT32_VECTOR_END) break;
+    if (j) s.put(',');
+    if (p[j] == GDB_BCF_INT32_MISSING) s.put('.'); else put_i32(s, p[j]);
+  }
+}
+template <class Sink> GDB_HD void put_int_or_missing(Sink& s, bool has, int32_t v) {
+  if (!has || v == GDB_BCF_INT32_MISSING) s.put('.'); else put_i32(s, v);
+}
+
+// text of one (record, sample) column.  c < 0: the sample has no live call.
+template <class Sink> GDB_HD void entry_emit(const EntryCtx& cx, const RecordInfo& ri, int64_t c, Sink& s, uint32_t* err) {
+  const CombinePlan& pl = cx.pl;
+  bool first = true;
+  // allele maps of this call (only when a remap is needed)
+  const bool remap = (ri.rflags & GDB_RF_REMAPPING_NEEDED) != 0;
+  const bool nr_exists = (ri.rflags & GDB_RF_NON_REF_EXISTS) != 0;
+  int8_t m2i[GDB_MAX_MERGED_ALLELES];
+  int nr_in = -1;        // input idx of <NON_REF> in this call
+  const int8_t* i2m = nullptr;
+  int n_in = 0;
+  uint8_t iflag = 0;
+  int64_t inc = -1;
+  uint32_t cf = 0;
+  if (c >= 0) {
+    cf = cx.cm.cflags[c];
+    n_in = (int)GDB_CF_NALT(cf) + 1;
+    if (remap) {
+      for (int j = 0; j < ri.num_merged; ++j) m2i[j] = -1;
+      if (cf & GDB_CF_HEAVY) {
+        int32_t row = cx.fr.row[c];
+        int64_t lo = ri.hbase, hi = ri.hend;
+        while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (cx.fr.row[cx.hl.cell[mid]] < row) lo = mid + 1; else hi = mid; }
+        inc = lo;
+        if (inc >= ri.hend || cx.hl.cell[inc] != c) { *err |= GDB_ERR_INTERNAL; inc = -1; }
+      }
+      if (inc >= 0) {
+        i2m = cx.hl.i2m + cx.hl.i2m_off[inc];
+        iflag = cx.hl.iflags[inc];
+        for (int a = 0; a < n_in; ++a) if (i2m[a] >= 0) m2i[i2m[a]] = (int8_t)a;
+        if (nr_exists && m2i[ri.num_merged - 1] >= 0 && (cf & GDB_CF_HAS_NR)) nr_in = m2i[ri.num_merged - 1];
+      } else {  // plain reference block: REF -> 0, <NON_REF> -> last
+        m2i[0] = 0;
+        if (nr_exists) { m2i[ri.num_merged - 1] = 1; nr_in = 1; }
+      }
+    }
+  }
+  for (int i = 0; i < pl.n_format; ++i) {
+    if (!((ri.fmt_mask >> i) & 1)) continue;
+    if (!first) s.put(':');
+    first = false;
+    const int f = pl.format_field[i];
+    const GdbFieldDesc& fd = pl.field[f];
+    if (c < 0) { s.put('.'); continue; }
+    if (f == pl.f_DP && pl.f_DP_FORMAT >= 0) {  // FORMAT DP := DP_FORMAT (broad_combined_gvcf.cc:689-719)
+      int n; bool ok = field_valid(cx.cm, c, pl.f_DP_FORMAT);
+      int32_t v = GDB_BCF_INT32_MISSING;
+      if (ok) { const int32_t* p = cell_field<int32_t>(cx.fr, pl, pl.f_DP_FORMAT, c, n); if (n > 0) v = p[0]; }
+      put_int_or_missing(s, ok && gdb_int_valid(v), v);
+      continue;
+    }
+    if (!field_valid(cx.cm, c, f)) { s.put('.'); continue; }
+    if (f == pl.f_GT) {
+      int n;
+      const int32_t* g = cell_field<int32_t>(cx.fr, pl, f, c, n);
+      const bool pp = fd.length == GDB_VL_PP;
+      const int step = pp ? 2 : 1;
+      int out_i = 0;
+      for (int j = 0; j < n; j += step, ++out_i) {
+        if (out_i) s.put((pp && g[j - 1] > 0) ? '|' : '/');
+        int32_t a = g[j];
+        if (!pl.produce_GT_field) { s.put('.'); continue; }
+        if (iflag & GDB_IF_GT_OVERRIDE) {  // min-PL genotype over the reduced alleles
+          int ra = cx.hl.gt_override[2 * inc + (out_i < 2 ? out_i : 1)];
+          a = ra == 0 ? 0 : (ra == 1 ? -2 : -3);  // -2: '*' allele, -3: <NON_REF>
+        }
+        int32_t m;
+        if (a == -2 || a == -3) {
+          m = -1;
+          if (a == -3) m = ri.num_merged - 1;
+          else for (int q = 1; q < n_in; ++q) if (i2m && i2m[q] >= 0 && i2m[q] != ri.num_merged - 1) { m = i2m[q]; break; }
+        } else if (a == GDB_TILEDB_NULL_INT32 || a == -1 || a == GDB_BCF_INT32_MISSING) m = -1;
+        else if (!remap) m = a;
+        else {
+          int8_t mm = -1;
+          if (a >= 0 && a < n_in) mm = i2m ? i2m[a] : (a == 0 ? 0 : (nr_exists && a == 1 ? (int8_t)(ri.num_merged - 1) : -1));
+          if (mm >= 0) m = mm;
+          else if (iflag & GDB_IF_SPANNING) m = (iflag & GDB_IF_NO_NR) ? -1 : (nr_exists ? ri.num_merged - 1 : -1);
+          else m = nr_exists ? ri.num_merged - 1 : -1;
+        }
+        if (m < 0) s.put('.'); else put_i32(s, m);
+      }
+      if (out_i == 0) s.put('.');
+      continue;
+    }
+    if (fd.elem == GDB_ET_CHAR || fd.elem == GDB_ET_FLAG) {
+      int n;
+      const char* p = cell_field<char>(cx.fr, pl, f, c, n);
+      if (n == 0) s.put('.');
+      for (int j = 0; j < n && p[j]; ++j) s.put(p[j] == 0x07 ? '.' : p[j]);
+      continue;
+    }
+    if (fd.elem != GDB_ET_INT) { *err |= GDB_ERR_INTERNAL; s.put('.'); continue; }
+    int n;
+    const int32_t* p = cell_field<int32_t>(cx.fr, pl, f, c, n);
+    const bool allele_dep = fd.length == GDB_VL_A || fd.length == GDB_VL_R || fd.length == GDB_VL_G;
+    if (!remap || !allele_dep) { put_int_vector(s, p, n); continue; }
+    if (fd.length == GDB_VL_R || fd.length == GDB_VL_A) {  // remap_data_based_on_alleles
+      const bool alt_only = fd.length == GDB_VL_A;
+      const int length = alt_only ? ri.num_merged - 1 : ri.num_merged;
+      if (length == 0) { s.put('.'); continue; }
+      for (int j = 0; j < length; ++j) {
+        if (j) s.put(',');
+        int aj = alt_only ? j + 1 : j;
+        int in_j = m2i[aj];
+        if (in_j < 0) in_j = nr_in;
+        int idx = alt_only ? in_j - 1 : in_j;
+        bool has = in_j >= 0 && idx >= 0 && idx < n;
+        put_int_or_missing(s, has, has ? p[idx] : 0);
+      }
+      continue;
+    }
+    // genotype-length field (PL)
+    const int ploidy = (int)GDB_CF_PLOIDY(cf);
+    if (ploidy == 1) {
+      for (int j = 0; j < ri.num_merged; ++j) {
+        if (j) s.put(',');
+        int in_j = m2i[j];
+        if (in_j < 0) in_j = nr_in;
+        bool has = in_j >= 0 && in_j < n;
+        put_int_or_missing(s, has, has ? p[in_j] : 0);
+      }
+    } else if (ploidy == 2) {
+      // output order gt = k(k+1)/2 + j, j <= k  (remap_data_based_on_genotype_diploid)
+      bool firstv = true;
+      for (int kk = 0; kk < ri.num_merged; ++kk) {
+        int in_k = m2i[kk];
+        if (in_k < 0) in_k = nr_in;
+        for (int j = 0; j <= kk; ++j) {
+          if (!firstv) s.put(',');
+          firstv = false;
+          int in_j = m2i[j];
+          if (in_j < 0) in_j = nr_in;
+          bool has = in_j >= 0 && in_k >= 0;
+          int gi = has ? gdb_alleles2gt(in_j, in_k) : 0;
+          has = has && gi < n;
+          put_int_or_missing(s, has, has ? p[gi] : 0);
+        }
+      }
+    } else {
+      *err |= GDB_ERR_UNSUPPORTED_PLOIDY;
+      s.put('.');
+    }
+  }
+}

@@ -90,3 +90,36 @@ def oracle_run(query, cells, partition_begin=0, partition_end=INT64_MAX - 1, buf
     txt = ctypes.string_at(out.value, n.value)
     lib.oracle_free(out)
     return txt, nrec.value, secs.value
+
+
+# ---- hostsim (CPU harness around the kernel bodies; test infrastructure) -------------------------------
+_hostsim = None
+
+
+def hostsim_lib():
+    global _hostsim
+    if _hostsim is None:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "hostsim")])
+        lib = ctypes.CDLL(os.path.join(ROOT, "tests", "hostsim", "libhostsim.so"))
+        lib.hostsim_run_query.restype = ctypes.c_int
+        lib.hostsim_run_query.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64),
+                                          ctypes.POINTER(ctypes.c_uint32), ctypes.c_char_p, ctypes.c_uint64]
+        lib.hostsim_free.argtypes = [ctypes.c_void_p]
+        _hostsim = lib
+    return _hostsim
+
+
+def hostsim_run(query, cells, with_header=True, rows_per_chunk=2, records_per_run=3):
+    lib = hostsim_lib()
+    out = ctypes.c_void_p()
+    n = ctypes.c_uint64()
+    errbits = ctypes.c_uint32()
+    err = ctypes.create_string_buffer(4096)
+    rc = lib.hostsim_run_query(json.dumps(query).encode(), cells, len(cells), 1 if with_header else 0, rows_per_chunk,
+                               records_per_run, ctypes.byref(out), ctypes.byref(n), ctypes.byref(errbits), err, 4096)
+    if rc != 0:
+        raise RuntimeError("hostsim: " + err.value.decode())
+    txt = ctypes.string_at(out.value, n.value)
+    lib.hostsim_free(out)
+    return txt, errbits.value

@@ -1,0 +1,202 @@
+// hostsim.cc - TEST HARNESS, NOT PRODUCT CODE.
+//
+// Runs the GDB_HD stage/record/entry functions of genomicsdb_amd/csrc/core (the bodies of the HIP kernels) in
+// plain serial loops on the CPU, with std::sort / serial scans standing in for the device sorts and scans.
+// Purpose: debug the index arithmetic of the device pipeline in a container without a GPU and keep a CPU
+// regression of it next to the oracle.  The shipped library (libgenomicsdb_amd.so) contains no such path.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../genomicsdb_amd/csrc/core/gdb_stages.hpp"
+#include "../../genomicsdb_amd/csrc/host/combine_plan.h"
+#include "../../genomicsdb_amd/csrc/host/fragment.h"
+#include "../../genomicsdb_amd/csrc/host/reference_genome.h"
+
+using namespace genomicsdb_amd;
+
+namespace {
+
+FragmentView make_view(const HostFragment& fr) {
+  FragmentView v;
+  memset(&v, 0, sizeof(v));
+  v.ncells = fr.ncells();
+  v.row = fr.row.data(); v.begin = fr.begin.data(); v.end = fr.end.data();
+  for (size_t f = 0; f < fr.cols.size(); ++f) {
+    v.col[f].data = fr.cols[f].data.data();
+    v.col[f].off = fr.cols[f].var ? fr.cols[f].off.data() : nullptr;
+  }
+  return v;
+}
+
+std::string run_interval(const HostPlan& hp, const HostFragment& hf, const VidMapper& vid, const ReferenceGenomeInfo& ref, int64_t qb, int64_t qe,
+                         int rows_per_chunk, int records_per_run, uint32_t& err_out) {
+  const CombinePlan& pl = hp.plan;
+  const FragmentView fr = make_view(hf);
+  const int64_t C = fr.ncells;
+  const int64_t N = pl.num_query_rows;
+  uint32_t err = 0;
+  std::string out;
+  if (C == 0) return out;
+  // S0 classify
+  std::vector<uint64_t> vmask(C); std::vector<uint32_t> cflags(C); std::vector<int32_t> dpval(C), k_lo(C), k_hi(C); std::vector<int64_t> eff_end(C);
+  CellMeta cm{vmask.data(), cflags.data(), dpval.data(), eff_end.data(), k_lo.data(), k_hi.data()};
+  for (int64_t c = 0; c < C; ++c) classify_cell(fr, pl, cm, c, &err);
+  // S1 row index (stable sort by row)
+  std::vector<int64_t> perm(C), rm_begin(C), row_ptr(N + 1, 0);
+  std::iota(perm.begin(), perm.end(), 0);
+  std::stable_sort(perm.begin(), perm.end(), [&](int64_t a, int64_t b) { return fr.row[a] < fr.row[b]; });
+  for (int64_t c = 0; c < C; ++c) row_ptr[fr.row[c] + 1]++;
+  for (int64_t r = 0; r < N; ++r) row_ptr[r + 1] += row_ptr[r];
+  // S2 effective END
+  for (int64_t j = 0; j < C; ++j) stage_eff_end(fr, cm, perm.data(), j, qb, qe, rm_begin.data(), &err);
+  // clip the window to what the cells can reach (keeps relative positions small)
+  // S3 events
+  std::vector<uint64_t> keys(2 * C);
+  for (int64_t c = 0; c < C; ++c) stage_event_keys(fr, cm, c, qb, qe, keys.data());
+  std::sort(keys.begin(), keys.end());
+  const int64_t NE = 2 * C;
+  std::vector<int64_t> incl(NE);
+  std::vector<int32_t> run_end(NE), run_excl(NE);
+  { int64_t acc = 0; for (int64_t i = 0; i < NE; ++i) { acc = packed_add(acc, stage_event_delta(keys[i])); incl[i] = acc; } }
+  int64_t U = 0;
+  for (int64_t i = 0; i < NE; ++i) { run_end[i] = stage_is_run_end(keys.data(), NE, i); run_excl[i] = (int32_t)U; U += run_end[i]; }
+  std::vector<int64_t> bpos(U + 1), nrec(U + 1), rbase(U + 1);
+  std::vector<int32_t> bcov(U + 1), bdel(U + 1);
+  Boundaries bd{bpos.data(), bcov.data(), bdel.data(), nrec.data()};
+  for (int64_t i = 0; i < NE; ++i) stage_boundary_write(keys.data(), incl.data(), run_excl.data(), i, run_end[i], bd, qb);
+  int64_t P = 0;
+  for (int64_t u = 0; u < U; ++u) { nrec[u] = stage_boundary_nrec(bd, U, u); rbase[u] = P; P += nrec[u]; }
+  if (P == 0) { err_out |= err; return out; }
+  std::vector<int64_t> rstart(P), rend(P);
+  for (int64_t k = 0; k < P; ++k) stage_record_expand(bd, rbase.data(), U, k, rstart.data(), rend.data());
+  RecordTable rec{P, rstart.data(), rend.data()};
+  // S4 ranges + difference arrays
+  const int nf = pl.n_format;
+  std::vector<int32_t> dfmt((size_t)std::max(nf, 1) * (P + 1), 0), ddp(P + 1, 0), dnr(P + 1, 0);
+  DiffArrays da{dfmt.data(), ddp.data(), dnr.data(), P + 1};
+  std::vector<int64_t> heavy_count(C), hoff(C + 1, 0);
+  for (int64_t c = 0; c < C; ++c) stage_cell_ranges(fr, pl, cm, rec, c, qb, qe, da, heavy_count.data());
+  // S5 scans
+  for (int i = 0; i < nf; ++i) { int32_t a = 0; for (int64_t k = 0; k <= P; ++k) { a += dfmt[(size_t)i * (P + 1) + k]; dfmt[(size_t)i * (P + 1) + k] = a; } }
+  { int32_t a = 0, b = 0; for (int64_t k = 0; k <= P; ++k) { a += ddp[k]; ddp[k] = a; b += dnr[k]; dnr[k] = b; } }
+  for (int64_t c = 0; c < C; ++c) hoff[c + 1] = hoff[c] + heavy_count[c];
+  const int64_t T = hoff[C];
+  // S6 incidences
+  std::vector<uint64_t> ikeys(T); std::vector<int64_t> ivals(T);
+  for (int64_t c = 0; c < C; ++c) stage_incidence_fill(fr, cm, hoff.data(), c, N, ikeys.data(), ivals.data(), nullptr);
+  {
+    std::vector<int64_t> order(T);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return ikeys[a] < ikeys[b]; });
+    std::vector<uint64_t> k2(T); std::vector<int64_t> v2(T);
+    for (int64_t t = 0; t < T; ++t) { k2[t] = ikeys[order[t]]; v2[t] = ivals[order[t]]; }
+    ikeys.swap(k2); ivals.swap(v2);
+  }
+  std::vector<int64_t> hbase(P + 1);
+  for (int64_t k = 0; k <= P; ++k) hbase[k] = stage_heavy_base(ikeys.data(), T, N, k);
+  std::vector<uint32_t> i2m_off(T + 1, 0);
+  for (int64_t t = 0; t < T; ++t) i2m_off[t + 1] = i2m_off[t] + GDB_CF_NALT(cflags[ivals[t]]) + 1;
+  std::vector<int8_t> i2m(i2m_off[T] + 1), gto(2 * T + 2);
+  std::vector<uint8_t> iflags(T + 1);
+  HeavyLists hl{hbase.data(), ivals.data(), i2m_off.data(), i2m.data(), iflags.data(), gto.data()};
+  // S7 site pass 0
+  std::vector<uint8_t> num_alleles(P), rflags(P);
+  std::vector<uint32_t> fmt_mask(P), prefix_len(P);
+  SiteOut so{num_alleles.data(), rflags.data(), fmt_mask.data(), prefix_len.data()};
+  // name tables / window
+  std::string refwin;
+  int64_t ref_begin = rstart[0];
+  int64_t ref_len = rstart[P - 1] - rstart[0] + 1;
+  if (ref.is_initialized()) refwin = ref.window(vid, ref_begin, ref_len);
+  QueryWindow qw;
+  memset(&qw, 0, sizeof(qw));
+  qw.qb = qb; qw.qe = qe; qw.contigs = hp.contigs.data(); qw.ncontigs = (int)hp.contigs.size(); qw.contig_names = hp.contig_names.data();
+  qw.ref_bases = refwin.empty() ? nullptr : refwin.data(); qw.ref_begin = ref_begin; qw.ref_len = refwin.empty() ? 0 : ref_len;
+  NameTables nt{hp.names_text.data(), hp.field_name_off.data(), hp.field_name_len.data(), hp.filter_name_off.data(), hp.filter_name_len.data(), (int)hp.filter_name_off.size()};
+  PresenceCounts pc{dfmt.data(), ddp.data(), dnr.data(), P + 1};
+  SiteCtx sx{fr, pl, cm, rec, hl, pc, nt, qw, so};
+  for (int64_t k = 0; k < P; ++k) { CountSink cs; site_emit(sx, k, cs, true, &err); prefix_len[k] = (uint32_t)cs.n; }
+  // S8 entry sizing per (record, row chunk); rows walk runs of records
+  RowIndex ri{row_ptr.data(), perm.data(), rm_begin.data()};
+  EntryCtx ex{fr, pl, cm, hl};
+  const int64_t nchunks = (N + rows_per_chunk - 1) / rows_per_chunk;
+  std::vector<uint64_t> chunk_size((size_t)P * nchunks, 0), chunk_off((size_t)P * nchunks + 1, 0);
+  for (int64_t k0 = 0; k0 < P; k0 += records_per_run) {
+    const int64_t k1 = std::min<int64_t>(P, k0 + records_per_run);
+    for (int64_t r = 0; r < N; ++r) {
+      RowWalker w; w.init(ri, (int32_t)r, rstart[k0]);
+      for (int64_t k = k0; k < k1; ++k) {
+        const int64_t c = w.live(ri, cm, rstart[k]);
+        if (!fmt_mask[k]) continue;
+        RecordInfo rinfo = load_record_info(so, hl, k);
+        CountSink cs; entry_emit(ex, rinfo, c, cs, &err);
+        chunk_size[(size_t)k * nchunks + r / rows_per_chunk] += 1 + cs.n;
+      }
+    }
+    for (int64_t k = k0; k < k1; ++k) { chunk_size[(size_t)k * nchunks] += prefix_len[k]; chunk_size[(size_t)k * nchunks + nchunks - 1] += 1; }
+  }
+  for (size_t i = 0; i < chunk_size.size(); ++i) chunk_off[i + 1] = chunk_off[i] + chunk_size[i];
+  out.resize(chunk_off.back());
+  // S9 write: prefix (site pass 1) + entries
+  for (int64_t k = 0; k < P; ++k) { ByteSink bs(&out[chunk_off[(size_t)k * nchunks]]); site_emit(sx, k, bs, false, &err); out[chunk_off[(size_t)(k + 1) * nchunks] - 1] = '\n'; }
+  for (int64_t k0 = 0; k0 < P; k0 += records_per_run) {
+    const int64_t k1 = std::min<int64_t>(P, k0 + records_per_run);
+    std::vector<uint64_t> cursor((size_t)(k1 - k0) * nchunks);
+    for (int64_t k = k0; k < k1; ++k) for (int64_t ch = 0; ch < nchunks; ++ch) cursor[(size_t)(k - k0) * nchunks + ch] = chunk_off[(size_t)k * nchunks + ch] + (ch == 0 ? prefix_len[k] : 0);
+    for (int64_t r = 0; r < N; ++r) {
+      RowWalker w; w.init(ri, (int32_t)r, rstart[k0]);
+      for (int64_t k = k0; k < k1; ++k) {
+        const int64_t c = w.live(ri, cm, rstart[k]);
+        if (!fmt_mask[k]) continue;
+        RecordInfo rinfo = load_record_info(so, hl, k);
+        uint64_t& cur = cursor[(size_t)(k - k0) * nchunks + r / rows_per_chunk];
+        out[cur++] = '\t';
+        ByteSink bs(&out[cur]);
+        entry_emit(ex, rinfo, c, bs, &err);
+        cur = (uint64_t)(bs.p - out.data());
+      }
+    }
+  }
+  err_out |= err;
+  return out;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hostsim_run_query(const char* query_json_text, const uint8_t* cells, uint64_t nbytes, int with_header, int rows_per_chunk, int records_per_run,
+                      char** out, uint64_t* out_len, uint32_t* err_bits, char* errmsg, uint64_t errlen) {
+  try {
+    VariantQueryConfig qc;
+    qc.read_from_json(mini_json::parse(query_json_text), 0, "");
+    qc.do_query_bookkeeping(qc.get_vid_mapper().get_num_callsets(), 0);
+    std::string tmpl;
+    if (!qc.get_vcf_header_filename().empty()) tmpl = mini_json::read_text_file(qc.get_vcf_header_filename());
+    HostPlan hp = build_combine_plan(qc, tmpl);
+    HostFragment hf = fragment_from_cells(cells, nbytes, qc, hp);
+    ReferenceGenomeInfo ref;
+    if (!qc.get_reference_genome().empty()) ref.initialize(qc.get_reference_genome());
+    std::string text = with_header ? hp.header_text : std::string();
+    uint32_t err = 0;
+    unsigned nint = qc.get_num_column_intervals();
+    if (nint == 0) text += run_interval(hp, hf, qc.get_vid_mapper(), ref, 0, INT64_MAX - 1, rows_per_chunk, records_per_run, err);
+    for (unsigned i = 0; i < nint; ++i)
+      text += run_interval(hp, hf, qc.get_vid_mapper(), ref, qc.get_column_begin(i), qc.get_column_end(i), rows_per_chunk, records_per_run, err);
+    *out = (char*)malloc(text.size() + 1);
+    memcpy(*out, text.data(), text.size());
+    *out_len = text.size();
+    *err_bits = err;
+    return 0;
+  } catch (const std::exception& e) {
+    snprintf(errmsg, errlen, "%s", e.what());
+    return 1;
+  }
+}
+void hostsim_free(char* p) { free(p); }
+
+}  // extern "C"
