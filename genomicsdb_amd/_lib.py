@@ -1,0 +1,75 @@
+"""ctypes binding of libgenomicsdb_amd.so.  No fallback: a missing library is an ImportError-grade failure."""
+import ctypes
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libgenomicsdb_amd.so")
+
+
+class IntervalStats(ctypes.Structure):
+    _fields_ = [("num_cells", ctypes.c_int64), ("num_cells_in_window", ctypes.c_int64), ("num_records", ctypes.c_int64),
+                ("num_heavy_incidences", ctypes.c_int64), ("bytes_out", ctypes.c_uint64),
+                ("bytes_in_reference_cells", ctypes.c_uint64), ("pages", ctypes.c_int32), ("write_launches", ctypes.c_int32),
+                ("err_bits", ctypes.c_uint32), ("ms_sweep", ctypes.c_float), ("ms_site", ctypes.c_float),
+                ("ms_size", ctypes.c_float), ("ms_write", ctypes.c_float), ("ms_total", ctypes.c_float),
+                ("ms_write_kernel_avg", ctypes.c_float)]
+
+
+class DeviceColumn(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p), ("off", ctypes.c_void_p)]
+
+
+_lib = None
+
+# every symbol include/genomicsdb_amd.h declares
+SYMBOLS = ["gdb_mi355_last_error", "gdb_mi355_device_count", "gdb_mi355_init", "gdb_mi355_init_from_memory", "gdb_mi355_close",
+           "gdb_mi355_get_num_bytes_available", "gdb_mi355_read_next_byte", "gdb_mi355_read", "gdb_mi355_skip",
+           "gdbamd_engine_create", "gdbamd_engine_destroy", "gdbamd_engine_num_fields", "gdbamd_engine_field_name",
+           "gdbamd_engine_field_info", "gdbamd_engine_header", "gdbamd_engine_stage_cells",
+           "gdbamd_engine_adopt_device_fragment", "gdbamd_engine_set_reference", "gdbamd_engine_run_interval"]
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libgenomicsdb_amd.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                           "the variant-combine path has no Python/CPU fallback")
+    L = ctypes.CDLL(LIB_PATH)
+    c = ctypes
+    L.gdb_mi355_last_error.restype = c.c_char_p
+    L.gdb_mi355_device_count.restype = c.c_int
+    L.gdb_mi355_init.restype = c.c_void_p
+    L.gdb_mi355_init.argtypes = [c.c_char_p, c.c_char_p, c.c_char_p, c.c_int, c.c_int, c.c_int, c.c_uint64, c.c_uint64, c.c_int, c.c_int, c.c_int, c.c_int]
+    L.gdb_mi355_init_from_memory.restype = c.c_void_p
+    L.gdb_mi355_init_from_memory.argtypes = [c.c_char_p, c.c_char_p, c.c_uint64, c.c_uint64, c.c_int]
+    L.gdb_mi355_close.restype = c.c_uint64
+    L.gdb_mi355_close.argtypes = [c.c_void_p]
+    L.gdb_mi355_get_num_bytes_available.restype = c.c_uint64
+    L.gdb_mi355_get_num_bytes_available.argtypes = [c.c_void_p]
+    L.gdb_mi355_read_next_byte.restype = c.c_int
+    L.gdb_mi355_read_next_byte.argtypes = [c.c_void_p]
+    L.gdb_mi355_read.restype = c.c_int64
+    L.gdb_mi355_read.argtypes = [c.c_void_p, c.c_char_p, c.c_uint64, c.c_uint64]
+    L.gdb_mi355_skip.restype = c.c_int64
+    L.gdb_mi355_skip.argtypes = [c.c_void_p, c.c_uint64]
+    L.gdbamd_engine_create.restype = c.c_void_p
+    L.gdbamd_engine_create.argtypes = [c.c_char_p, c.c_int]
+    L.gdbamd_engine_destroy.argtypes = [c.c_void_p]
+    L.gdbamd_engine_num_fields.argtypes = [c.c_void_p]
+    L.gdbamd_engine_field_name.restype = c.c_char_p
+    L.gdbamd_engine_field_name.argtypes = [c.c_void_p, c.c_int]
+    L.gdbamd_engine_field_info.argtypes = [c.c_void_p, c.c_int, c.POINTER(c.c_int), c.POINTER(c.c_int), c.POINTER(c.c_int)]
+    L.gdbamd_engine_header.restype = c.c_uint64
+    L.gdbamd_engine_header.argtypes = [c.c_void_p, c.c_char_p, c.c_uint64]
+    L.gdbamd_engine_stage_cells.argtypes = [c.c_void_p, c.c_char_p, c.c_uint64]
+    L.gdbamd_engine_adopt_device_fragment.argtypes = [c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p, c.c_void_p, c.POINTER(DeviceColumn), c.c_int, c.c_uint64]
+    L.gdbamd_engine_set_reference.argtypes = [c.c_void_p, c.c_int64, c.c_char_p, c.c_uint64]
+    L.gdbamd_engine_run_interval.argtypes = [c.c_void_p, c.c_int64, c.c_int64, c.c_uint64, c.c_void_p, c.c_uint64, c.POINTER(c.c_uint64), c.POINTER(IntervalStats)]
+    _lib = L
+    return L
+
+
+def last_error():
+    return lib().gdb_mi355_last_error().decode(errors="replace")

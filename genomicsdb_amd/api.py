@@ -1,0 +1,138 @@
+import ctypes
+import json
+
+from . import _lib
+
+INT64_MAX = 2**63 - 1
+
+
+class GenomicsDBException(RuntimeError):
+    pass
+
+
+def _check(ok, what):
+    if not ok:
+        raise GenomicsDBException("%s: %s" % (what, _lib.last_error()))
+
+
+class GenomicsDBQueryStream:
+    """Byte stream of the combined gVCF (header first), the Python face of the six JNI entry points."""
+
+    def __init__(self, loader_json_file=None, query_json_file=None, chr="", start=0, end=0, rank=0, buffer_capacity=1048576,
+                 segment_size=1048576, is_bcf=False, produce_header_only=False, query_json=None, cells=None):
+        L = _lib.lib()
+        if query_json is not None:
+            txt = query_json if isinstance(query_json, str) else json.dumps(query_json)
+            self._cells = bytes(cells or b"")
+            self._h = L.gdb_mi355_init_from_memory(txt.encode(), self._cells, len(self._cells), buffer_capacity, int(produce_header_only))
+        else:
+            self._h = L.gdb_mi355_init((loader_json_file or "").encode(), (query_json_file or "").encode(), chr.encode(), start, end, rank,
+                                       buffer_capacity, segment_size, int(is_bcf), int(produce_header_only), 0, 1)
+        _check(self._h, "GenomicsDBQueryStream init")
+
+    def read(self, n=-1):
+        L = _lib.lib()
+        chunks = []
+        want = n if n >= 0 else None
+        while want is None or want > 0:
+            k = 1 << 20 if want is None else min(want, 1 << 20)
+            buf = ctypes.create_string_buffer(k)
+            got = L.gdb_mi355_read(self._h, buf, 0, k)
+            if got < 0:
+                raise GenomicsDBException("read: " + _lib.last_error())
+            if got == 0:
+                break
+            chunks.append(buf.raw[:got])
+            if want is not None:
+                want -= got
+        return b"".join(chunks)
+
+    def skip(self, n):
+        return _lib.lib().gdb_mi355_skip(self._h, n)
+
+    def available(self):
+        return _lib.lib().gdb_mi355_get_num_bytes_available(self._h)
+
+    def close(self):
+        if self._h:
+            _lib.lib().gdb_mi355_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CombineEngine:
+    """One column partition on one GPU: stage cells (or adopt device columns), run query intervals."""
+
+    def __init__(self, query_json, device=0):
+        L = _lib.lib()
+        txt = query_json if isinstance(query_json, str) else json.dumps(query_json)
+        self._e = L.gdbamd_engine_create(txt.encode(), device)
+        _check(self._e, "CombineEngine create")
+        self._keep = []
+
+    @property
+    def header(self):
+        L = _lib.lib()
+        n = L.gdbamd_engine_header(self._e, None, 0)
+        buf = ctypes.create_string_buffer(n)
+        L.gdbamd_engine_header(self._e, buf, n)
+        return buf.raw[:n]
+
+    def fields(self):
+        L = _lib.lib()
+        out = []
+        for f in range(L.gdbamd_engine_num_fields(self._e)):
+            et, var, num = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            L.gdbamd_engine_field_info(self._e, f, ctypes.byref(et), ctypes.byref(var), ctypes.byref(num))
+            out.append({"name": L.gdbamd_engine_field_name(self._e, f).decode(), "elem": et.value, "var": bool(var.value), "num": num.value})
+        return out
+
+    def stage_cells(self, cells):
+        cells = bytes(cells)
+        _check(_lib.lib().gdbamd_engine_stage_cells(self._e, cells, len(cells)) == 0, "stage_cells")
+
+    def adopt_device_fragment(self, ncells, row_ptr, begin_ptr, end_ptr, cols, reference_cell_bytes, keepalive=None):
+        """cols: list of (data_ptr, off_ptr_or_0) device addresses, one per plan field."""
+        arr = (_lib.DeviceColumn * len(cols))()
+        for i, (d, o) in enumerate(cols):
+            arr[i].data = d
+            arr[i].off = o or None
+        self._keep = [arr, keepalive]
+        _check(_lib.lib().gdbamd_engine_adopt_device_fragment(self._e, ncells, row_ptr, begin_ptr, end_ptr, arr, len(cols), reference_cell_bytes) == 0,
+               "adopt_device_fragment")
+
+    def set_reference(self, begin, bases):
+        _check(_lib.lib().gdbamd_engine_set_reference(self._e, begin, bases, len(bases)) == 0, "set_reference")
+
+    def run_interval(self, begin=0, end=INT64_MAX - 1, arena_bytes=1 << 30, fetch=True, host_cap=None):
+        L = _lib.lib()
+        st = _lib.IntervalStats()
+        n = ctypes.c_uint64()
+        if fetch:
+            cap = host_cap or (1 << 26)
+            while True:
+                buf = ctypes.create_string_buffer(cap)
+                rc = L.gdbamd_engine_run_interval(self._e, begin, end, arena_bytes, buf, cap, ctypes.byref(n), ctypes.byref(st))
+                _check(rc == 0, "run_interval")
+                if n.value <= cap:
+                    return buf.raw[:n.value], st
+                cap = n.value
+        rc = L.gdbamd_engine_run_interval(self._e, begin, end, arena_bytes, None, 0, ctypes.byref(n), ctypes.byref(st))
+        _check(rc == 0, "run_interval")
+        return None, st
+
+    def close(self):
+        if self._e:
+            _lib.lib().gdbamd_engine_destroy(self._e)
+            self._e = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,77 @@
+"""In-tree build of libgenomicsdb_amd.so (HIP kernels for gfx950 + host layer + C ABI) with hipcc.
+
+hipcc cross-compiles gfx950 without a GPU; the .so lands next to this file so that it travels with the
+repo snapshot to the GPU box.  Also builds the test oracle (oracle/Makefile) and the hostsim harness.
+"""
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+OBJ = os.path.join(ROOT, "build", "obj")
+LIB = os.path.join(PKG, "libgenomicsdb_amd.so")
+
+SOURCES = [
+    "kernels/gdb_pipeline.hip",
+    "host/vid_mapper.cc",
+    "host/variant_query_config.cc",
+    "host/combine_plan.cc",
+    "host/fragment.cc",
+    "host/reference_genome.cc",
+    "api/genomicsdb_bcf_generator.cc",
+    "api/capi.cc",
+]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+
+
+def _headers():
+    out = []
+    for d, _, fs in os.walk(CSRC):
+        out += [os.path.join(d, f) for f in fs if f.endswith((".h", ".hpp"))]
+    out.append(os.path.join(ROOT, "include", "genomicsdb_amd.h"))
+    return out
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_native(verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = _headers()
+    objs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ, s.replace("/", "_") + ".o")
+        objs.append(obj)
+        if _newer(obj, [src] + hdrs):
+            cmd = [HIPCC] + FLAGS + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+    if _newer(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    return os.path.join(ROOT, "oracle", "liboracle_gvcf.so")
+
+
+def build_hostsim():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "hostsim")])
+
+
+if __name__ == "__main__":
+    print(build_native(verbose=True))
+    print(build_oracle())

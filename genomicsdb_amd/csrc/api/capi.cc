@@ -1,0 +1,129 @@
+// capi.cc - extern "C" surface declared in include/genomicsdb_amd.h
+#include "../../../include/genomicsdb_amd.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstring>
+
+#include "genomicsdb_bcf_generator.h"
+
+using namespace genomicsdb_amd;
+
+namespace {
+thread_local std::string g_last_error;
+template <class F, class R> R guarded(F f, R on_error) {
+  try { g_last_error.clear(); return f(); }
+  catch (const std::exception& e) { g_last_error = e.what(); return on_error; }
+  catch (...) { g_last_error = "unknown exception"; return on_error; }
+}
+struct EngineHandle { std::unique_ptr<CombineEngine> eng; };
+}  // namespace
+
+extern "C" {
+
+const char* gdb_mi355_last_error(void) { return g_last_error.c_str(); }
+int gdb_mi355_device_count(void) { return DevicePipeline::device_count(); }
+
+void* gdb_mi355_init(const char* loader_json_file, const char* query_json_file, const char* chr, int start, int end, int rank, uint64_t buffer_capacity,
+                     uint64_t segment_size, int is_bcf, int produce_header_only, int use_missing, int keep_idx) {
+  return guarded([&]() -> void* {
+    return new GenomicsDBBCFGenerator(loader_json_file ? loader_json_file : "", query_json_file ? query_json_file : "", chr, start, end, rank, buffer_capacity,
+                                      segment_size, is_bcf ? "bu" : "", produce_header_only != 0, is_bcf && use_missing, is_bcf && keep_idx);
+  }, (void*)nullptr);
+}
+void* gdb_mi355_init_from_memory(const char* query_json_text, const uint8_t* cells, uint64_t nbytes, uint64_t buffer_capacity, int produce_header_only) {
+  return guarded([&]() -> void* { return new GenomicsDBBCFGenerator(std::string(query_json_text), cells, nbytes, buffer_capacity, produce_header_only != 0); }, (void*)nullptr);
+}
+uint64_t gdb_mi355_close(void* h) { delete (GenomicsDBBCFGenerator*)h; return 0; }
+uint64_t gdb_mi355_get_num_bytes_available(void* h) { return h ? ((GenomicsDBBCFGenerator*)h)->get_buffer_capacity() : 0; }
+int gdb_mi355_read_next_byte(void* h) {
+  if (!h) return -1;
+  return guarded([&]() -> int { auto* g = (GenomicsDBBCFGenerator*)h; if (g->end()) return -1; return (int)g->read_next_byte(); }, -1);
+}
+int64_t gdb_mi355_read(void* h, uint8_t* dst, uint64_t offset, uint64_t n) {
+  if (!h) return 0;
+  return guarded([&]() -> int64_t { return (int64_t)((GenomicsDBBCFGenerator*)h)->read_and_advance(dst, offset, n); }, (int64_t)-1);
+}
+int64_t gdb_mi355_skip(void* h, uint64_t n) {
+  if (!h) return 0;
+  return guarded([&]() -> int64_t { return (int64_t)((GenomicsDBBCFGenerator*)h)->read_and_advance(nullptr, 0, n); }, (int64_t)-1);
+}
+
+void* gdbamd_engine_create(const char* query_json_text, int device) {
+  return guarded([&]() -> void* { auto* e = new EngineHandle; e->eng.reset(new CombineEngine(mini_json::parse(query_json_text), device)); return e; }, (void*)nullptr);
+}
+void gdbamd_engine_destroy(void* e) { delete (EngineHandle*)e; }
+int gdbamd_engine_num_fields(void* e) { return e ? ((EngineHandle*)e)->eng->plan().plan.nfields : -1; }
+const char* gdbamd_engine_field_name(void* e, int f) {
+  if (!e) return nullptr;
+  const HostPlan& hp = ((EngineHandle*)e)->eng->plan();
+  return (f >= 0 && f < hp.plan.nfields) ? hp.field_names[(size_t)f].c_str() : nullptr;
+}
+int gdbamd_engine_field_info(void* e, int f, int* elem_type, int* is_var, int* fixed_num) {
+  if (!e) return -1;
+  const CombinePlan& pl = ((EngineHandle*)e)->eng->plan().plan;
+  if (f < 0 || f >= pl.nfields) return -1;
+  *elem_type = pl.field[f].elem;
+  *is_var = pl.field[f].length != GDB_VL_FIXED;
+  *fixed_num = pl.field[f].fixed_num;
+  return 0;
+}
+uint64_t gdbamd_engine_header(void* e, char* dst, uint64_t cap) {
+  if (!e) return 0;
+  const std::string& h = ((EngineHandle*)e)->eng->plan().header_text;
+  if (dst && cap) memcpy(dst, h.data(), std::min<uint64_t>(cap, h.size()));
+  return h.size();
+}
+int gdbamd_engine_stage_cells(void* e, const uint8_t* cells, uint64_t nbytes) {
+  return guarded([&]() -> int { ((EngineHandle*)e)->eng->stage_cells(cells, nbytes); return 0; }, 1);
+}
+int gdbamd_engine_adopt_device_fragment(void* e, int64_t ncells, const int32_t* row, const int64_t* begin, const int64_t* end, const gdbamd_device_column* cols,
+                                        int ncols, uint64_t reference_cell_bytes) {
+  return guarded([&]() -> int {
+    CombineEngine& eng = *((EngineHandle*)e)->eng;
+    if (ncols != eng.plan().plan.nfields) throw GenomicsDBDeviceException("adopt_device_fragment: ncols != number of plan fields");
+    FragmentView v;
+    memset(&v, 0, sizeof(v));
+    v.ncells = ncells; v.row = row; v.begin = begin; v.end = end;
+    for (int f = 0; f < ncols; ++f) { v.col[f].data = cols[f].data; v.col[f].off = cols[f].off; }
+    eng.pipeline().adopt_fragment(v);
+    eng.reference_cell_bytes = reference_cell_bytes;
+    eng.has_cells = ncells > 0;
+    return 0;
+  }, 1);
+}
+int gdbamd_engine_set_reference(void* e, int64_t begin, const char* bases, uint64_t len) {
+  return guarded([&]() -> int { ((EngineHandle*)e)->eng->pipeline().set_reference_window(begin, std::string(bases, len)); return 0; }, 1);
+}
+
+namespace {
+struct HostCopy { char* dst; uint64_t cap, len; };
+void copy_page(void* user, const char* dev, uint64_t n) {
+  HostCopy* hc = (HostCopy*)user;
+  if (hc->dst && hc->len < hc->cap) {
+    uint64_t k = std::min(n, hc->cap - hc->len);
+    if (hipMemcpy(hc->dst + hc->len, dev, k, hipMemcpyDeviceToHost) != hipSuccess) throw GenomicsDBDeviceException("page copy to host failed");
+  }
+  hc->len += n;
+}
+}  // namespace
+
+int gdbamd_engine_run_interval(void* e, int64_t qb, int64_t qe, uint64_t arena_bytes, char* host_out, uint64_t host_cap, uint64_t* host_len,
+                               gdbamd_interval_stats* out) {
+  return guarded([&]() -> int {
+    CombineEngine& eng = *((EngineHandle*)e)->eng;
+    HostCopy hc{host_out, host_cap, 0};
+    IntervalStats s = eng.pipeline().run_interval(qb, qe, arena_bytes, host_out ? copy_page : nullptr, &hc);
+    if (host_len) *host_len = host_out ? hc.len : s.bytes_out;
+    if (out) {
+      out->num_cells = s.num_cells; out->num_cells_in_window = s.num_cells_in_window; out->num_records = s.num_records;
+      out->num_heavy_incidences = s.num_heavy_incidences; out->bytes_out = s.bytes_out; out->bytes_in_reference_cells = eng.reference_cell_bytes;
+      out->pages = s.pages; out->write_launches = s.write_launches; out->err_bits = s.err_bits;
+      out->ms_sweep = s.ms_sweep; out->ms_site = s.ms_site; out->ms_size = s.ms_size; out->ms_write = s.ms_write; out->ms_total = s.ms_total;
+      out->ms_write_kernel_avg = s.ms_write_kernel_avg;
+    }
+    return 0;
+  }, 1);
+}
+
+}  // extern "C"

@@ -1,0 +1,64 @@
+// genomicsdb_bcf_generator.h - pull stream over the device pipeline, source-compatible with the reference's
+// GenomicsDBBCFGenerator (reference src/main/cpp/include/vcf/genomicsdb_bcf_generator.h:33-93): header first, then the
+// combined-gVCF body of every query column interval, produced in batches of at most buffer_capacity bytes.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../kernels/gdb_pipeline.h"
+#include "../host/reference_genome.h"
+
+namespace genomicsdb_amd {
+
+class GenomicsDBJNIException : public std::runtime_error {
+ public:
+  explicit GenomicsDBJNIException(const std::string& m) : std::runtime_error("GenomicsDBJNIException : " + m) {}
+};
+
+// what the engine needs to know about one query: configuration, plan, pipeline
+class CombineEngine {
+ public:
+  explicit CombineEngine(const mini_json::Value& query_json, int device, const GenomicsDBImportConfig* loader = nullptr, int rank = 0);
+  VariantQueryConfig& query_config() { return m_qc; }
+  const HostPlan& plan() const { return m_hp; }
+  DevicePipeline& pipeline() { return *m_pipe; }
+  void stage_cells(const uint8_t* cells, uint64_t nbytes);
+  void stage_reference_for(int64_t qb, int64_t qe);
+  uint64_t reference_cell_bytes = 0;
+  int64_t min_begin = 0, max_end = 0;
+  bool has_cells = false;
+ private:
+  VariantQueryConfig m_qc;
+  HostPlan m_hp;
+  std::unique_ptr<DevicePipeline> m_pipe;
+  ReferenceGenomeInfo m_ref;
+};
+
+class GenomicsDBBCFGenerator {
+ public:
+  GenomicsDBBCFGenerator(const std::string& loader_config_file, const std::string& query_config_file, const char* chr, const int start,
+                         const int end, int my_rank = 0, size_t buffer_capacity = 1048576u, size_t tiledb_segment_size = 1048576u,
+                         const char* output_format = "bu", const bool produce_header_only = false,
+                         const bool use_missing_values_only_not_vector_end = false, const bool keep_idx_fields_in_bcf_header = true);
+  // in-memory flavour: query JSON text + begin-cells (reference binary-cell layout)
+  GenomicsDBBCFGenerator(const std::string& query_json_text, const uint8_t* cells, uint64_t nbytes, size_t buffer_capacity, bool produce_header_only);
+  GenomicsDBBCFGenerator(const GenomicsDBBCFGenerator&) = delete;
+  GenomicsDBBCFGenerator& operator=(const GenomicsDBBCFGenerator&) = delete;
+  // n == SIZE_MAX: only produce the next batch
+  size_t read_and_advance(uint8_t* dst, size_t offset, size_t n);
+  uint8_t read_next_byte();
+  bool end() const { return m_done && m_next_read_idx >= m_buffer.size(); }
+  size_t get_buffer_capacity() const { return m_buffer_capacity; }
+ private:
+  void common_init(bool produce_header_only);
+  void produce_next_batch();
+  std::unique_ptr<CombineEngine> m_engine;
+  size_t m_buffer_capacity;
+  std::vector<uint8_t> m_buffer;  // current batch (host copy of the page drained from HBM)
+  size_t m_next_read_idx = 0;
+  bool m_done = false, m_interval_active = false, m_produce_header_only = false;
+  unsigned m_query_column_interval_idx = 0;
+};
+
+}  // namespace genomicsdb_amd

@@ -1,0 +1,65 @@
+// gdb_pipeline.h - the MI355X scan-and-combine pipeline (host-visible interface, no HIP types).
+//
+// One DevicePipeline = one column partition on one GPU: the device-side replacement of
+// VariantQueryProcessor::scan_and_operate + BroadCombinedGVCFOperator (reference
+// src/main/cpp/src/genomicsdb/query_variants.cc:334-476, src/query_operations/broad_combined_gvcf.cc:765-901).
+// run_interval() consumes a staged columnar fragment and produces the bit-exact VCF body for one query column
+// interval in pages of at most `arena_bytes` (the analogue of combined_vcf_records_buffer_size_limit / RWBuffer).
+#pragma once
+#include <cstdint>
+#include <string>
+
+#include "../core/gdb_types.h"
+#include "../host/combine_plan.h"
+#include "../host/fragment.h"
+
+namespace genomicsdb_amd {
+
+class GenomicsDBDeviceException : public std::runtime_error {
+ public:
+  explicit GenomicsDBDeviceException(const std::string& m) : std::runtime_error("GenomicsDBDeviceException : " + m) {}
+};
+
+struct IntervalStats {
+  int64_t num_cells = 0;          // begin-cells staged
+  int64_t num_cells_in_window = 0;
+  int64_t num_records = 0;        // output positions
+  int64_t num_heavy_incidences = 0;
+  uint64_t bytes_out = 0;         // VCF body bytes
+  int pages = 0;
+  uint32_t err_bits = 0;
+  // device time (hipEvent) per phase, ms
+  float ms_sweep = 0, ms_site = 0, ms_size = 0, ms_write = 0, ms_total = 0;
+  float ms_write_kernel_avg = 0;  // average duration of one entry-write launch
+  int write_launches = 0;
+};
+
+// page consumer: `dev_ptr` points to `nbytes` of VCF text in HBM, valid until the callback returns
+typedef void (*PageCallback)(void* user, const char* dev_ptr, uint64_t nbytes);
+
+class DevicePipeline {
+ public:
+  explicit DevicePipeline(const HostPlan& hp, int device = 0);
+  ~DevicePipeline();
+  DevicePipeline(const DevicePipeline&) = delete;
+  DevicePipeline& operator=(const DevicePipeline&) = delete;
+  // copy a host fragment to HBM (replaces the previously staged one)
+  void stage_fragment(const HostFragment& hf);
+  // adopt a fragment that already lives in HBM (e.g. torch tensors); the caller keeps ownership
+  void adopt_fragment(const FragmentView& device_view);
+  // reference bases for TileDB columns [begin, begin + bases.size())
+  void set_reference_window(int64_t begin, const std::string& bases);
+  // pull interface: prepare_interval() runs the sweep, the site pass and the sizing pass; next_page() then writes the
+  // next <= arena_bytes of VCF text (always whole records) into HBM and returns false when the interval is exhausted
+  void prepare_interval(int64_t qb, int64_t qe);
+  bool next_page(uint64_t arena_bytes, const char** dev_ptr, uint64_t* nbytes);
+  const IntervalStats& interval_stats() const;
+  // push interface built on the two calls above
+  IntervalStats run_interval(int64_t qb, int64_t qe, uint64_t arena_bytes, PageCallback cb, void* user);
+  static int device_count();
+  struct Impl;
+ private:
+  Impl* m_;
+};
+
+}  // namespace genomicsdb_amd

@@ -1,0 +1,610 @@
+// gdb_pipeline.hip - HIP kernels + stage orchestration of the MI355X variant-combine path (gfx950).
+//
+// Kernel bodies are the GDB_HD functions of ../core; this file adds the grid mapping, the wavefront (64-lane)
+// reductions / scans, and the device-wide sorts and scans (rocPRIM).  All of it is integer / byte work bound by
+// HBM traffic: no MFMA, no GEMM reshaping (see DESIGN.md for the per-kernel byte accounting).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "../core/gdb_stages.hpp"
+#include "gdb_pipeline.h"
+
+namespace genomicsdb_amd {
+
+#define HIP_CHECK(expr)                                                                                            \
+  do {                                                                                                             \
+    hipError_t _e = (expr);                                                                                        \
+    if (_e != hipSuccess)                                                                                          \
+      throw GenomicsDBDeviceException(std::string(#expr) + " failed: " + hipGetErrorString(_e) + " at " + __FILE__ + ":" + std::to_string(__LINE__)); \
+  } while (0)
+
+namespace {
+
+constexpr int kBlock = 256;          // threads per workgroup = 4 wavefronts of 64
+constexpr int kRun = 16;             // consecutive records one workgroup walks per row
+constexpr int kWavesPerBlock = kBlock / 64;
+
+template <class T> struct DevBuf {   // grow-only device allocation
+  T* p = nullptr;
+  size_t cap = 0;
+  void ensure(size_t n) {
+    if (n <= cap) return;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    size_t want = n + n / 8 + 16;
+    HIP_CHECK(hipMalloc((void**)&p, want * sizeof(T)));
+    cap = want;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  ~DevBuf() { release(); }
+};
+
+inline unsigned blocks_for(int64_t n, int b = kBlock) { return (unsigned)std::max<int64_t>(1, (n + b - 1) / b); }
+inline int bits_for(uint64_t max_value) { int b = 1; while (b < 64 && (max_value >> b)) ++b; return std::min(64, b + 1); }
+
+// ---- elementwise stage kernels -----------------------------------------------------------------------------
+__global__ void k_classify(FragmentView fr, CombinePlan pl, CellMeta cm, uint32_t* err) {
+  int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= fr.ncells) return;
+  uint32_t e = 0;
+  classify_cell(fr, pl, cm, c, &e);
+  if (e) atomicOr(err, e);
+}
+__global__ void k_iota_rows(FragmentView fr, int32_t* keys, int64_t* vals) {
+  int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= fr.ncells) return;
+  keys[c] = fr.row[c];
+  vals[c] = c;
+}
+__global__ void k_row_ptr(const int32_t* sorted_rows, int64_t C, int32_t N, int64_t* row_ptr) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > N) return;
+  int64_t lo = 0, hi = C;
+  while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (sorted_rows[mid] < (int32_t)r) lo = mid + 1; else hi = mid; }
+  row_ptr[r] = lo;
+}
+__global__ void k_eff_end(FragmentView fr, CellMeta cm, const int64_t* perm, int64_t qb, int64_t qe, int64_t* rm_begin, uint32_t* err) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= fr.ncells) return;
+  uint32_t e = 0;
+  stage_eff_end(fr, cm, perm, j, qb, qe, rm_begin, &e);
+  if (e) atomicOr(err, e);
+}
+__global__ void k_event_keys(FragmentView fr, CellMeta cm, int64_t qb, int64_t qe, uint64_t* keys) {
+  int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= fr.ncells) return;
+  stage_event_keys(fr, cm, c, qb, qe, keys);
+}
+__global__ void k_event_delta(const uint64_t* keys, int64_t n, int64_t* delta, int32_t* run_end) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  delta[i] = stage_event_delta(keys[i]);
+  run_end[i] = stage_is_run_end(keys, n, i);
+}
+struct PackedAdd { __host__ __device__ int64_t operator()(const int64_t& a, const int64_t& b) const { return packed_add(a, b); } };
+__global__ void k_boundary_write(const uint64_t* keys, const int64_t* incl, const int32_t* run_end, const int32_t* run_excl, int64_t n, Boundaries b, int64_t qb) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  stage_boundary_write(keys, incl, run_excl, i, run_end[i], b, qb);
+}
+__global__ void k_boundary_nrec(Boundaries b, int64_t U) {
+  int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= U) return;
+  b.nrec[u] = stage_boundary_nrec(b, U, u);
+}
+__global__ void k_record_expand(Boundaries b, const int64_t* rbase, int64_t U, int64_t P, int64_t* rstart, int64_t* rend) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= P) return;
+  stage_record_expand(b, rbase, U, k, rstart, rend);
+}
+__global__ void k_cell_ranges(FragmentView fr, CombinePlan pl, CellMeta cm, RecordTable rec, int64_t qb, int64_t qe, DiffArrays d, int64_t* heavy_count, int32_t* in_window_count) {
+  int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= fr.ncells) return;
+  stage_cell_ranges(fr, pl, cm, rec, c, qb, qe, d, heavy_count);
+  if (cm.k_lo[c] >= 0) atomicAdd(in_window_count, 1);
+}
+__global__ void k_incidence_fill(FragmentView fr, CellMeta cm, const int64_t* hoff, int64_t nrows, uint64_t* keys, int64_t* vals) {
+  int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= fr.ncells) return;
+  stage_incidence_fill(fr, cm, hoff, c, nrows, keys, vals, nullptr);
+}
+__global__ void k_heavy_base(const uint64_t* sorted_keys, int64_t T, int64_t nrows, int64_t P, int64_t* hbase) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > P) return;
+  hbase[k] = stage_heavy_base(sorted_keys, T, nrows, k);
+}
+__global__ void k_lut_len(const int64_t* inc_cell, const uint32_t* cflags, int64_t T, uint32_t* len) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  len[t] = GDB_CF_NALT(cflags[inc_cell[t]]) + 1;
+}
+
+// ---- site kernels: one thread per record -----------------------------------------------------------------------
+__global__ void k_site_size(SiteCtx sx, uint32_t* err) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= sx.rec.npos) return;
+  uint32_t e = 0;
+  CountSink cs;
+  site_emit(sx, k, cs, true, &e);
+  sx.so.prefix_len[k] = (uint32_t)cs.n;
+  if (e) atomicOr(err, e);
+}
+__global__ void k_site_write(SiteCtx sx, int64_t k_begin, int64_t k_end, const uint64_t* chunk_off, int nchunks, uint64_t page_base, char* arena, uint32_t* err) {
+  int64_t k = k_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= k_end) return;
+  uint32_t e = 0;
+  ByteSink bs(arena + (chunk_off[k * nchunks] - page_base));
+  site_emit(sx, k, bs, false, &e);
+  arena[chunk_off[(k + 1) * nchunks] - page_base - 1] = '\n';
+  if (e) atomicOr(err, e);
+}
+
+// ---- sample-column kernels: workgroup = kRun consecutive records x kBlock rows ---------------------------------------
+__device__ __forceinline__ uint32_t wave_reduce_sum(uint32_t v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
+  for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(v, off, 64); if (lane >= off) v += t; }
+  return v;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_entry_size(EntryCtx ex, RowIndex ri, SiteOut so, RecordTable rec, int32_t N, int nchunks, uint64_t* chunk_size, uint32_t* err) {
+  const int64_t k0 = (int64_t)blockIdx.x * kRun;
+  const int ch = blockIdx.y;
+  const int64_t k1 = min(rec.npos, k0 + (int64_t)kRun);
+  const int32_t r = ch * kBlock + (int32_t)threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ uint32_t wsum[kRun][kWavesPerBlock];
+  uint32_t lens[kRun];
+  uint32_t e = 0;
+#pragma unroll
+  for (int i = 0; i < kRun; ++i) lens[i] = 0;
+  if (r < N) {
+    RowWalker w;
+    w.init(ri, r, rec.start[k0]);
+    for (int i = 0; i < kRun; ++i) {
+      const int64_t k = k0 + i;
+      if (k >= k1) break;
+      const int64_t c = w.live(ri, ex.cm, rec.start[k]);
+      if (!so.fmt_mask[k]) continue;
+      RecordInfo rinfo = load_record_info(so, ex.hl, k);
+      CountSink cs;
+      entry_emit(ex, rinfo, c, cs, &e);
+      lens[i] = 1u + (uint32_t)cs.n;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kRun; ++i) { uint32_t s = wave_reduce_sum(lens[i]); if (lane == 0) wsum[i][wave] = s; }
+  __syncthreads();
+  if (threadIdx.x < kRun) {
+    const int64_t k = k0 + threadIdx.x;
+    if (k < k1) {
+      uint64_t total = 0;
+      for (int wv = 0; wv < kWavesPerBlock; ++wv) total += wsum[threadIdx.x][wv];
+      if (ch == 0) total += so.prefix_len[k];
+      if (ch == nchunks - 1) total += 1;  // '\n'
+      chunk_size[k * nchunks + ch] = total;
+    }
+  }
+  if (e) atomicOr(err, e);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_entry_write(EntryCtx ex, RowIndex ri, SiteOut so, RecordTable rec, int32_t N, int nchunks, int64_t k_begin, int64_t k_end,
+              const uint64_t* chunk_off, uint64_t page_base, char* arena, uint32_t* err) {
+  const int64_t k0 = k_begin + (int64_t)blockIdx.x * kRun;
+  const int ch = blockIdx.y;
+  const int64_t k1 = min(k_end, k0 + (int64_t)kRun);
+  const int32_t r = ch * kBlock + (int32_t)threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ uint32_t wtot[kRun][kWavesPerBlock];
+  uint32_t lens[kRun];
+  int32_t cells[kRun];
+  uint32_t e = 0;
+#pragma unroll
+  for (int i = 0; i < kRun; ++i) { lens[i] = 0; cells[i] = -1; }
+  if (r < N) {
+    RowWalker w;
+    w.init(ri, r, rec.start[k0]);
+    for (int i = 0; i < kRun; ++i) {
+      const int64_t k = k0 + i;
+      if (k >= k1) break;
+      const int64_t c = w.live(ri, ex.cm, rec.start[k]);
+      cells[i] = (int32_t)c;
+      if (!so.fmt_mask[k]) continue;
+      RecordInfo rinfo = load_record_info(so, ex.hl, k);
+      CountSink cs;
+      entry_emit(ex, rinfo, c, cs, &e);
+      lens[i] = 1u + (uint32_t)cs.n;
+    }
+  }
+  // exclusive offsets of every row inside its (record, chunk): wave scan + wave totals through LDS
+  uint32_t excl[kRun];
+#pragma unroll
+  for (int i = 0; i < kRun; ++i) {
+    uint32_t inc = wave_inclusive_scan(lens[i], lane);
+    excl[i] = inc - lens[i];
+    if (lane == 63) wtot[i][wave] = inc;
+  }
+  __syncthreads();
+  if (r < N) {
+    for (int i = 0; i < kRun; ++i) {
+      const int64_t k = k0 + i;
+      if (k >= k1) break;
+      if (!lens[i]) continue;
+      uint32_t base = 0;
+      for (int wv = 0; wv < wave; ++wv) base += wtot[i][wv];
+      char* dst = arena + (chunk_off[k * nchunks + ch] - page_base) + (ch == 0 ? so.prefix_len[k] : 0u) + base + excl[i];
+      *dst = '\t';
+      ByteSink bs(dst + 1);
+      RecordInfo rinfo = load_record_info(so, ex.hl, k);
+      entry_emit(ex, rinfo, (int64_t)cells[i], bs, &e);
+    }
+  }
+  if (e) atomicOr(err, e);
+}
+
+__global__ void k_gather_record_offsets(const uint64_t* chunk_off, int nchunks, int64_t P, uint64_t* rec_off) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > P) return;
+  rec_off[k] = chunk_off[k * nchunks];
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+struct DevicePipeline::Impl {
+  HostPlan hp;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // staged fragment
+  FragmentView fr;
+  bool owns_fragment = false;
+  std::vector<void*> owned;
+  // small tables
+  DevBuf<char> names_text, contig_names, ref_bases;
+  DevBuf<int32_t> field_name_off, field_name_len, filter_name_off, filter_name_len;
+  DevBuf<GdbContig> contigs;
+  int64_t ref_begin = 0, ref_len = 0;
+  // per-cell
+  DevBuf<uint64_t> vmask; DevBuf<uint32_t> cflags; DevBuf<int32_t> dpval, k_lo, k_hi; DevBuf<int64_t> eff_end;
+  DevBuf<int32_t> row_keys, row_keys_sorted; DevBuf<int64_t> cell_ids, perm, rm_begin, row_ptr;
+  DevBuf<uint64_t> ev_keys, ev_keys_sorted; DevBuf<int64_t> ev_delta, ev_incl; DevBuf<int32_t> run_end, run_excl;
+  DevBuf<int64_t> bpos, bnrec, rbase; DevBuf<int32_t> bcov, bdel;
+  DevBuf<int64_t> rstart, rend;
+  DevBuf<int32_t> diff; DevBuf<int64_t> heavy_count, hoff;
+  DevBuf<uint64_t> inc_keys, inc_keys_sorted; DevBuf<int64_t> inc_vals, inc_vals_sorted, hbase;
+  DevBuf<uint32_t> lut_len, i2m_off; DevBuf<int8_t> i2m, gt_override; DevBuf<uint8_t> iflags;
+  DevBuf<uint8_t> num_alleles, rflags; DevBuf<uint32_t> fmt_mask, prefix_len;
+  DevBuf<uint64_t> chunk_size, chunk_off, rec_off;
+  DevBuf<char> arena, temp;
+  DevBuf<uint32_t> err; DevBuf<int32_t> counters;
+  bool classified = false;
+  struct IntervalState {
+    bool active = false;
+    int64_t P = 0, kp = 0;
+    int nchunks = 0;
+    uint64_t max_record_bytes = 0;
+    float write_kernel_ms = 0;
+    std::vector<uint64_t> rec_off;
+    IntervalStats stats;
+    SiteCtx sx; EntryCtx ex; RowIndex ri; SiteOut so; RecordTable rec;
+  } iv;
+
+  void* temp_storage(size_t bytes) { temp.ensure(bytes + 256); return temp.p; }
+  template <class K, class V> void sort_pairs(const K* kin, K* kout, const V* vin, V* vout, size_t n, int end_bit) {
+    size_t bytes = 0;
+    HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, 0, end_bit, stream));
+    void* t = temp_storage(bytes);
+    HIP_CHECK(rocprim::radix_sort_pairs(t, bytes, kin, kout, vin, vout, n, 0, end_bit, stream));
+  }
+  template <class K> void sort_keys(const K* kin, K* kout, size_t n, int end_bit) {
+    size_t bytes = 0;
+    HIP_CHECK(rocprim::radix_sort_keys(nullptr, bytes, kin, kout, n, 0, end_bit, stream));
+    void* t = temp_storage(bytes);
+    HIP_CHECK(rocprim::radix_sort_keys(t, bytes, kin, kout, n, 0, end_bit, stream));
+  }
+  template <class T, class Op> void incl_scan(const T* in, T* out, size_t n, Op op) {
+    size_t bytes = 0;
+    HIP_CHECK(rocprim::inclusive_scan(nullptr, bytes, in, out, n, op, stream));
+    void* t = temp_storage(bytes);
+    HIP_CHECK(rocprim::inclusive_scan(t, bytes, in, out, n, op, stream));
+  }
+  template <class T> void excl_scan(const T* in, T* out, size_t n) {
+    size_t bytes = 0;
+    HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, in, out, T(0), n, rocprim::plus<T>(), stream));
+    void* t = temp_storage(bytes);
+    HIP_CHECK(rocprim::exclusive_scan(t, bytes, in, out, T(0), n, rocprim::plus<T>(), stream));
+  }
+  template <class T> T read_back(const T* p) {
+    T v;
+    HIP_CHECK(hipMemcpyAsync(&v, p, sizeof(T), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    return v;
+  }
+  void free_owned() { for (void* p : owned) (void)hipFree(p); owned.clear(); }
+};
+
+int DevicePipeline::device_count() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+DevicePipeline::DevicePipeline(const HostPlan& hp, int device) : m_(new Impl) {
+  m_->hp = hp;
+  m_->device = device;
+  if (device_count() <= 0) { delete m_; throw GenomicsDBDeviceException("no HIP device visible: the variant-combine path has no CPU fallback"); }
+  HIP_CHECK(hipSetDevice(device));
+  HIP_CHECK(hipStreamCreate(&m_->stream));
+  memset(&m_->fr, 0, sizeof(m_->fr));
+  auto up = [&](auto& buf, const auto* src, size_t n) {
+    buf.ensure(std::max<size_t>(n, 1));
+    if (n) HIP_CHECK(hipMemcpy(buf.p, src, n * sizeof(*src), hipMemcpyHostToDevice));
+  };
+  up(m_->names_text, hp.names_text.data(), hp.names_text.size());
+  up(m_->contig_names, hp.contig_names.data(), hp.contig_names.size());
+  up(m_->field_name_off, hp.field_name_off.data(), hp.field_name_off.size());
+  up(m_->field_name_len, hp.field_name_len.data(), hp.field_name_len.size());
+  up(m_->filter_name_off, hp.filter_name_off.data(), hp.filter_name_off.size());
+  up(m_->filter_name_len, hp.filter_name_len.data(), hp.filter_name_len.size());
+  up(m_->contigs, hp.contigs.data(), hp.contigs.size());
+  m_->err.ensure(4);
+  m_->counters.ensure(16);
+}
+
+DevicePipeline::~DevicePipeline() {
+  if (!m_) return;
+  m_->free_owned();
+  if (m_->stream) (void)hipStreamDestroy(m_->stream);
+  delete m_;
+}
+
+void DevicePipeline::stage_fragment(const HostFragment& hf) {
+  HIP_CHECK(hipSetDevice(m_->device));
+  m_->free_owned();
+  FragmentView v;
+  memset(&v, 0, sizeof(v));
+  v.ncells = hf.ncells();
+  auto up = [&](const void* src, size_t bytes) -> void* {
+    void* d = nullptr;
+    HIP_CHECK(hipMalloc(&d, std::max<size_t>(bytes, 16)));
+    m_->owned.push_back(d);
+    if (bytes) HIP_CHECK(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+    return d;
+  };
+  v.row = (const int32_t*)up(hf.row.data(), hf.row.size() * 4);
+  v.begin = (const int64_t*)up(hf.begin.data(), hf.begin.size() * 8);
+  v.end = (const int64_t*)up(hf.end.data(), hf.end.size() * 8);
+  for (size_t f = 0; f < hf.cols.size(); ++f) {
+    v.col[f].data = up(hf.cols[f].data.data(), hf.cols[f].data.size());
+    v.col[f].off = hf.cols[f].var ? (const uint32_t*)up(hf.cols[f].off.data(), hf.cols[f].off.size() * 4) : nullptr;
+  }
+  m_->fr = v;
+  m_->owns_fragment = true;
+  m_->classified = false;
+}
+
+void DevicePipeline::adopt_fragment(const FragmentView& v) {
+  m_->free_owned();
+  m_->fr = v;
+  m_->owns_fragment = false;
+  m_->classified = false;
+}
+
+void DevicePipeline::set_reference_window(int64_t begin, const std::string& bases) {
+  HIP_CHECK(hipSetDevice(m_->device));
+  m_->ref_bases.ensure(std::max<size_t>(bases.size(), 1));
+  if (!bases.empty()) HIP_CHECK(hipMemcpy(m_->ref_bases.p, bases.data(), bases.size(), hipMemcpyHostToDevice));
+  m_->ref_begin = begin;
+  m_->ref_len = (int64_t)bases.size();
+}
+
+void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
+  Impl& S = *m_;
+  S.iv = Impl::IntervalState();
+  HIP_CHECK(hipSetDevice(S.device));
+  hipStream_t st = S.stream;
+  const CombinePlan& pl = S.hp.plan;
+  const FragmentView& fr = S.fr;
+  const int64_t C = fr.ncells;
+  const int32_t N = pl.num_query_rows;
+  IntervalStats& stats = S.iv.stats;
+  stats.num_cells = C;
+  if (C == 0 || N == 0) return;
+  hipEvent_t ev[4];
+  for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
+  HIP_CHECK(hipMemsetAsync(S.err.p, 0, sizeof(uint32_t), st));
+  HIP_CHECK(hipMemsetAsync(S.counters.p, 0, 16 * sizeof(int32_t), st));
+  HIP_CHECK(hipEventRecord(ev[0], st));
+  // ---- S0 classify + S1 row index (independent of the query interval: once per staged fragment) ---------------------
+  S.vmask.ensure(C); S.cflags.ensure(C); S.dpval.ensure(C); S.k_lo.ensure(C); S.k_hi.ensure(C); S.eff_end.ensure(C);
+  CellMeta cm{S.vmask.p, S.cflags.p, S.dpval.p, S.eff_end.p, S.k_lo.p, S.k_hi.p};
+  S.perm.ensure(C); S.rm_begin.ensure(C); S.row_ptr.ensure((size_t)N + 2);
+  if (!S.classified) {
+    hipLaunchKernelGGL(k_classify, dim3(blocks_for(C)), dim3(kBlock), 0, st, fr, pl, cm, S.err.p);
+    S.row_keys.ensure(C); S.row_keys_sorted.ensure(C); S.cell_ids.ensure(C);
+    hipLaunchKernelGGL(k_iota_rows, dim3(blocks_for(C)), dim3(kBlock), 0, st, fr, S.row_keys.p, S.cell_ids.p);
+    S.sort_pairs(S.row_keys.p, S.row_keys_sorted.p, S.cell_ids.p, S.perm.p, (size_t)C, std::min(32, bits_for((uint64_t)N)));
+    hipLaunchKernelGGL(k_row_ptr, dim3(blocks_for((int64_t)N + 1)), dim3(kBlock), 0, st, S.row_keys_sorted.p, C, N, S.row_ptr.p);
+    S.classified = true;
+  }
+  // ---- S2 effective END ------------------------------------------------------------------------------------------
+  hipLaunchKernelGGL(k_eff_end, dim3(blocks_for(C)), dim3(kBlock), 0, st, fr, cm, S.perm.p, qb, qe, S.rm_begin.p, S.err.p);
+  // ---- S3 events -> boundaries -> records --------------------------------------------------------------------------
+  const int64_t NE = 2 * C;
+  S.ev_keys.ensure(NE); S.ev_keys_sorted.ensure(NE); S.ev_delta.ensure(NE); S.ev_incl.ensure(NE); S.run_end.ensure(NE); S.run_excl.ensure(NE + 1);
+  hipLaunchKernelGGL(k_event_keys, dim3(blocks_for(C)), dim3(kBlock), 0, st, fr, cm, qb, qe, S.ev_keys.p);
+  {
+    const uint64_t span = (uint64_t)(qe - qb) + 2u;
+    const int eb = span >= (1ull << 60) ? 64 : bits_for(span << 2);
+    S.sort_keys(S.ev_keys.p, S.ev_keys_sorted.p, (size_t)NE, eb);
+  }
+  hipLaunchKernelGGL(k_event_delta, dim3(blocks_for(NE)), dim3(kBlock), 0, st, S.ev_keys_sorted.p, NE, S.ev_delta.p, S.run_end.p);
+  S.incl_scan(S.ev_delta.p, S.ev_incl.p, (size_t)NE, PackedAdd());
+  S.excl_scan(S.run_end.p, S.run_excl.p, (size_t)NE);
+  const int64_t U = (int64_t)S.read_back(S.run_excl.p + (NE - 1)) + (int64_t)S.read_back(S.run_end.p + (NE - 1));
+  int64_t P = 0;
+  if (U > 0) {
+    S.bpos.ensure(U + 1); S.bcov.ensure(U + 1); S.bdel.ensure(U + 1); S.bnrec.ensure(U + 1); S.rbase.ensure(U + 1);
+    Boundaries bd{S.bpos.p, S.bcov.p, S.bdel.p, S.bnrec.p};
+    hipLaunchKernelGGL(k_boundary_write, dim3(blocks_for(NE)), dim3(kBlock), 0, st, S.ev_keys_sorted.p, S.ev_incl.p, S.run_end.p, S.run_excl.p, NE, bd, qb);
+    hipLaunchKernelGGL(k_boundary_nrec, dim3(blocks_for(U)), dim3(kBlock), 0, st, bd, U);
+    S.excl_scan(S.bnrec.p, S.rbase.p, (size_t)U);
+    P = S.read_back(S.rbase.p + (U - 1)) + S.read_back(S.bnrec.p + (U - 1));
+    if (P > 0) {
+      S.rstart.ensure(P); S.rend.ensure(P);
+      hipLaunchKernelGGL(k_record_expand, dim3(blocks_for(P)), dim3(kBlock), 0, st, bd, S.rbase.p, U, P, S.rstart.p, S.rend.p);
+    }
+  }
+  stats.num_records = P;
+  if (P == 0) {
+    stats.err_bits = S.read_back(S.err.p);
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    if (stats.err_bits) throw GenomicsDBDeviceException("device error bits " + std::to_string(stats.err_bits));
+    return;
+  }
+  if (P >= (1ll << 31)) throw GenomicsDBDeviceException("more than 2^31 records in one interval: split the query interval");
+  RecordTable rec{P, S.rstart.p, S.rend.p};
+  // ---- S4/S5 record ranges, difference arrays, scans --------------------------------------------------------------
+  const int nf = pl.n_format;
+  const int64_t stride = P + 1;
+  const size_t ndiff = (size_t)(nf + 2) * (size_t)stride;
+  S.diff.ensure(ndiff);
+  HIP_CHECK(hipMemsetAsync(S.diff.p, 0, ndiff * sizeof(int32_t), st));
+  int32_t* d_fmt = S.diff.p;
+  int32_t* d_dp = S.diff.p + (size_t)nf * stride;
+  int32_t* d_nr = d_dp + stride;
+  DiffArrays da{d_fmt, d_dp, d_nr, stride};
+  S.heavy_count.ensure(C + 1); S.hoff.ensure(C + 2);
+  hipLaunchKernelGGL(k_cell_ranges, dim3(blocks_for(C)), dim3(kBlock), 0, st, fr, pl, cm, rec, qb, qe, da, S.heavy_count.p, S.counters.p);
+  for (int i = 0; i < nf + 2; ++i) S.incl_scan(S.diff.p + (size_t)i * stride, S.diff.p + (size_t)i * stride, (size_t)stride, rocprim::plus<int32_t>());
+  S.excl_scan(S.heavy_count.p, S.hoff.p, (size_t)C);
+  const int64_t T = S.read_back(S.hoff.p + (C - 1)) + S.read_back(S.heavy_count.p + (C - 1));
+  stats.num_heavy_incidences = T;
+  stats.num_cells_in_window = S.read_back(S.counters.p);
+  // ---- S6 incidences sorted by (record,row) --------------------------------------------------------------------------
+  S.inc_keys.ensure(T + 1); S.inc_keys_sorted.ensure(T + 1); S.inc_vals.ensure(T + 1); S.inc_vals_sorted.ensure(T + 1);
+  S.hbase.ensure(P + 2); S.lut_len.ensure(T + 1); S.i2m_off.ensure(T + 2); S.iflags.ensure(T + 1); S.gt_override.ensure(2 * T + 2);
+  uint32_t lut_total = 0;
+  if (T > 0) {
+    hipLaunchKernelGGL(k_incidence_fill, dim3(blocks_for(C)), dim3(kBlock), 0, st, fr, cm, S.hoff.p, (int64_t)N, S.inc_keys.p, S.inc_vals.p);
+    S.sort_pairs(S.inc_keys.p, S.inc_keys_sorted.p, S.inc_vals.p, S.inc_vals_sorted.p, (size_t)T, bits_for((uint64_t)P * (uint64_t)N));
+    hipLaunchKernelGGL(k_lut_len, dim3(blocks_for(T)), dim3(kBlock), 0, st, S.inc_vals_sorted.p, S.cflags.p, T, S.lut_len.p);
+    S.excl_scan(S.lut_len.p, S.i2m_off.p, (size_t)T);
+    lut_total = S.read_back(S.i2m_off.p + (T - 1)) + S.read_back(S.lut_len.p + (T - 1));
+    HIP_CHECK(hipMemcpyAsync(S.i2m_off.p + T, &lut_total, sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+  } else {
+    HIP_CHECK(hipMemsetAsync(S.i2m_off.p, 0, 2 * sizeof(uint32_t), st));
+  }
+  hipLaunchKernelGGL(k_heavy_base, dim3(blocks_for(P + 1)), dim3(kBlock), 0, st, S.inc_keys_sorted.p, T, (int64_t)N, P, S.hbase.p);
+  S.i2m.ensure((size_t)lut_total + 16);
+  HeavyLists hl{S.hbase.p, S.inc_vals_sorted.p, S.i2m_off.p, S.i2m.p, S.iflags.p, S.gt_override.p};
+  HIP_CHECK(hipEventRecord(ev[1], st));
+  // ---- S7 site pass 0: allele merge, LUTs, prefix sizes -------------------------------------------------------------
+  S.num_alleles.ensure(P); S.rflags.ensure(P); S.fmt_mask.ensure(P); S.prefix_len.ensure(P);
+  SiteOut so{S.num_alleles.p, S.rflags.p, S.fmt_mask.p, S.prefix_len.p};
+  QueryWindow qw;
+  memset(&qw, 0, sizeof(qw));
+  qw.qb = qb; qw.qe = qe;
+  qw.contigs = S.contigs.p; qw.ncontigs = (int32_t)S.hp.contigs.size(); qw.contig_names = S.contig_names.p;
+  qw.ref_bases = S.ref_len ? S.ref_bases.p : nullptr; qw.ref_begin = S.ref_begin; qw.ref_len = S.ref_len;
+  NameTables nt{S.names_text.p, S.field_name_off.p, S.field_name_len.p, S.filter_name_off.p, S.filter_name_len.p, (int32_t)S.hp.filter_name_off.size()};
+  PresenceCounts pc{d_fmt, d_dp, d_nr, stride};
+  SiteCtx sx{fr, pl, cm, rec, hl, pc, nt, qw, so};
+  hipLaunchKernelGGL(k_site_size, dim3(blocks_for(P, 64)), dim3(64), 0, st, sx, S.err.p);
+  HIP_CHECK(hipEventRecord(ev[2], st));
+  // ---- S8 sample-column sizes + offsets ---------------------------------------------------------------------------
+  const int nchunks = (N + kBlock - 1) / kBlock;
+  const size_t nchunk_total = (size_t)P * nchunks;
+  S.chunk_size.ensure(nchunk_total + 1); S.chunk_off.ensure(nchunk_total + 2); S.rec_off.ensure(P + 2);
+  RowIndex ri{S.row_ptr.p, S.perm.p, S.rm_begin.p};
+  EntryCtx ex{fr, pl, cm, hl};
+  const unsigned run_blocks = (unsigned)((P + kRun - 1) / kRun);
+  hipLaunchKernelGGL(k_entry_size, dim3(run_blocks, nchunks), dim3(kBlock), 0, st, ex, ri, so, rec, N, nchunks, S.chunk_size.p, S.err.p);
+  HIP_CHECK(hipMemsetAsync(S.chunk_size.p + nchunk_total, 0, sizeof(uint64_t), st));
+  S.excl_scan(S.chunk_size.p, S.chunk_off.p, nchunk_total + 1);
+  hipLaunchKernelGGL(k_gather_record_offsets, dim3(blocks_for(P + 1)), dim3(kBlock), 0, st, S.chunk_off.p, nchunks, P, S.rec_off.p);
+  std::vector<uint64_t>& rec_off = S.iv.rec_off;
+  rec_off.resize((size_t)P + 1);
+  HIP_CHECK(hipMemcpyAsync(rec_off.data(), S.rec_off.p, (size_t)(P + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipEventRecord(ev[3], st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  stats.bytes_out = rec_off[(size_t)P];
+  HIP_CHECK(hipEventElapsedTime(&stats.ms_sweep, ev[0], ev[1]));
+  HIP_CHECK(hipEventElapsedTime(&stats.ms_site, ev[1], ev[2]));
+  HIP_CHECK(hipEventElapsedTime(&stats.ms_size, ev[2], ev[3]));
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  {
+    uint32_t eb = S.read_back(S.err.p);
+    if (eb) throw GenomicsDBDeviceException("device error bits " + std::to_string(eb) + " (see GdbErr in gdb_types.h)");
+  }
+  for (int64_t k = 0; k < P; ++k) S.iv.max_record_bytes = std::max<uint64_t>(S.iv.max_record_bytes, rec_off[(size_t)k + 1] - rec_off[(size_t)k]);
+  S.iv.P = P; S.iv.nchunks = nchunks; S.iv.kp = 0;
+  S.iv.sx = sx; S.iv.ex = ex; S.iv.ri = ri; S.iv.so = so; S.iv.rec = rec;
+  S.iv.active = true;
+}
+
+bool DevicePipeline::next_page(uint64_t arena_bytes, const char** dev_ptr, uint64_t* nbytes) {
+  Impl& S = *m_;
+  Impl::IntervalState& iv = S.iv;
+  if (!iv.active || iv.kp >= iv.P) { iv.active = false; return false; }
+  HIP_CHECK(hipSetDevice(S.device));
+  hipStream_t st = S.stream;
+  const int32_t N = S.hp.plan.num_query_rows;
+  const std::vector<uint64_t>& rec_off = iv.rec_off;
+  const uint64_t arena_cap = std::max<uint64_t>(arena_bytes, iv.max_record_bytes);
+  S.arena.ensure(std::min<uint64_t>(arena_cap, iv.stats.bytes_out) + 64);
+  const int64_t kp = iv.kp, P = iv.P;
+  int64_t lo = kp + 1, hi = P;  // largest k_end with rec_off[k_end] - rec_off[kp] <= arena_cap
+  while (lo < hi) { int64_t mid = (lo + hi + 1) >> 1; if (rec_off[(size_t)mid] - rec_off[(size_t)kp] <= arena_cap) lo = mid; else hi = mid - 1; }
+  const int64_t ke = lo;
+  const uint64_t page_base = rec_off[(size_t)kp], page_bytes = rec_off[(size_t)ke] - page_base;
+  const int64_t np = ke - kp;
+  hipEvent_t w0, w1, w2;
+  HIP_CHECK(hipEventCreate(&w0)); HIP_CHECK(hipEventCreate(&w1)); HIP_CHECK(hipEventCreate(&w2));
+  HIP_CHECK(hipEventRecord(w0, st));
+  hipLaunchKernelGGL(k_site_write, dim3(blocks_for(np, 64)), dim3(64), 0, st, iv.sx, kp, ke, S.chunk_off.p, iv.nchunks, page_base, S.arena.p, S.err.p);
+  HIP_CHECK(hipEventRecord(w1, st));
+  hipLaunchKernelGGL(k_entry_write, dim3((unsigned)((np + kRun - 1) / kRun), iv.nchunks), dim3(kBlock), 0, st, iv.ex, iv.ri, iv.so, iv.rec, N, iv.nchunks, kp, ke,
+                     S.chunk_off.p, page_base, S.arena.p, S.err.p);
+  HIP_CHECK(hipEventRecord(w2, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  float ms_site = 0, ms_entry = 0;
+  HIP_CHECK(hipEventElapsedTime(&ms_site, w0, w1));
+  HIP_CHECK(hipEventElapsedTime(&ms_entry, w1, w2));
+  (void)hipEventDestroy(w0); (void)hipEventDestroy(w1); (void)hipEventDestroy(w2);
+  iv.stats.ms_write += ms_site + ms_entry;
+  iv.write_kernel_ms += ms_entry;
+  iv.stats.write_launches++;
+  iv.stats.ms_write_kernel_avg = iv.write_kernel_ms / iv.stats.write_launches;
+  iv.stats.pages++;
+  iv.stats.ms_total = iv.stats.ms_sweep + iv.stats.ms_site + iv.stats.ms_size + iv.stats.ms_write;
+  iv.stats.err_bits = S.read_back(S.err.p);
+  if (iv.stats.err_bits) throw GenomicsDBDeviceException("device error bits " + std::to_string(iv.stats.err_bits) + " (see GdbErr in gdb_types.h)");
+  iv.kp = ke;
+  *dev_ptr = S.arena.p;
+  *nbytes = page_bytes;
+  return true;
+}
+
+const IntervalStats& DevicePipeline::interval_stats() const { return m_->iv.stats; }
+
+IntervalStats DevicePipeline::run_interval(int64_t qb, int64_t qe, uint64_t arena_bytes, PageCallback cb, void* user) {
+  prepare_interval(qb, qe);
+  const char* p = nullptr;
+  uint64_t n = 0;
+  while (next_page(arena_bytes, &p, &n)) if (cb) cb(user, p, n);
+  return m_->iv.stats;
+}
+
+}  // namespace genomicsdb_amd

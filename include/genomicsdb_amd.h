@@ -1,0 +1,77 @@
+/* genomicsdb_amd.h - C ABI of the MI355X variant-combine engine (libgenomicsdb_amd.so).
+ *
+ * Drop-in boundary for the scan/combine hot path of Intel-HLS/GenomicsDB v0.10.2.  Plain pointers and sizes only.
+ * Every function returns an error through gdb_mi355_last_error() (thread-local) instead of throwing across the ABI.
+ * There is NO CPU fallback: without a HIP device every engine entry point fails.
+ *
+ * (1) Query stream - the six entry points the reference exports over JNI
+ *     (reference src/main/jni/src/genomicsdb_GenomicsDBQueryStream.cc:29-111, header
+ *      src/main/jni/include/genomicsdb_GenomicsDBQueryStream.h:17-58), each a thin shim over GenomicsDBBCFGenerator
+ *     (reference src/main/cpp/include/vcf/genomicsdb_bcf_generator.h:33-93).  A JNI stub forwards 1:1.
+ * (2) Engine - explicit staging / per-interval execution with the output left in HBM, for callers that own device
+ *     memory (bench, multi-GPU drivers).  Replaces the VariantQueryProcessor::scan_and_operate +
+ *     BroadCombinedGVCFOperator pair (reference src/main/cpp/include/genomicsdb/query_variants.h:241-243,
+ *     include/query_operations/broad_combined_gvcf.h:59-61).
+ */
+#ifndef GENOMICSDB_AMD_H
+#define GENOMICSDB_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* gdb_mi355_last_error(void);
+int gdb_mi355_device_count(void);
+
+/* ---- (1) query stream ------------------------------------------------------------------------------------ */
+/* jniGenomicsDBInit: returns a handle or NULL.  chr == "" keeps the intervals of the query JSON; otherwise the
+ * interval is contig offset + start-1 .. end-1 (1-based, inclusive).  is_bcf != 0 asks for BCF2 ("bu"), which this
+ * build does not produce yet (returns NULL with an error); text VCF otherwise. */
+void* gdb_mi355_init(const char* loader_json_file, const char* query_json_file, const char* chr, int start, int end, int rank,
+                     uint64_t buffer_capacity, uint64_t segment_size, int is_bcf, int produce_header_only,
+                     int use_missing_values_only_not_vector_end, int keep_idx_fields_in_bcf_header);
+/* same stream, configuration and cells handed over in memory (tests, embedding) */
+void* gdb_mi355_init_from_memory(const char* query_json_text, const uint8_t* cells, uint64_t cells_nbytes, uint64_t buffer_capacity,
+                                 int produce_header_only);
+uint64_t gdb_mi355_close(void* handle);                         /* jniGenomicsDBClose */
+uint64_t gdb_mi355_get_num_bytes_available(void* handle);       /* jniGenomicsDBGetNumBytesAvailable: buffer capacity */
+int gdb_mi355_read_next_byte(void* handle);                     /* jniGenomicsDBReadNextByte: byte or -1 */
+int64_t gdb_mi355_read(void* handle, uint8_t* dst, uint64_t offset, uint64_t n); /* jniGenomicsDBRead: bytes copied, -1 on error */
+int64_t gdb_mi355_skip(void* handle, uint64_t n);               /* jniGenomicsDBSkip */
+
+/* ---- (2) engine ------------------------------------------------------------------------------------------ */
+typedef struct gdbamd_interval_stats {
+  int64_t num_cells, num_cells_in_window, num_records, num_heavy_incidences;
+  uint64_t bytes_out, bytes_in_reference_cells;
+  int32_t pages, write_launches;
+  uint32_t err_bits;
+  float ms_sweep, ms_site, ms_size, ms_write, ms_total, ms_write_kernel_avg;
+} gdbamd_interval_stats;
+
+/* one attribute column in device memory; off == NULL for fixed-length attributes */
+typedef struct gdbamd_device_column { const void* data; const uint32_t* off; } gdbamd_device_column;
+
+void* gdbamd_engine_create(const char* query_json_text, int device);          /* NULL on error */
+void gdbamd_engine_destroy(void* engine);
+int gdbamd_engine_num_fields(void* engine);                                     /* plan fields = staged attribute columns */
+const char* gdbamd_engine_field_name(void* engine, int f);                      /* array attribute name of plan field f */
+int gdbamd_engine_field_info(void* engine, int f, int* elem_type, int* is_var, int* fixed_num);
+uint64_t gdbamd_engine_header(void* engine, char* dst, uint64_t cap);           /* VCF header text; returns its length */
+/* stage begin-cells given in the reference binary-cell layout (host memory, column-major order) */
+int gdbamd_engine_stage_cells(void* engine, const uint8_t* cells, uint64_t nbytes);
+/* adopt a columnar fragment that already lives in HBM: row = QUERY row idx, begin/end = columns, cols[num_fields] */
+int gdbamd_engine_adopt_device_fragment(void* engine, int64_t ncells, const int32_t* row, const int64_t* begin, const int64_t* end,
+                                        const gdbamd_device_column* cols, int ncols, uint64_t reference_cell_bytes);
+/* reference bases for TileDB columns [begin, begin+len) (host pointer) */
+int gdbamd_engine_set_reference(void* engine, int64_t begin, const char* bases, uint64_t len);
+/* scan + combine one column interval.  The VCF body is produced page by page in HBM (arena_bytes per page); when
+ * host_out != NULL the pages are copied there (at most host_cap bytes, *host_len = total body bytes). */
+int gdbamd_engine_run_interval(void* engine, int64_t column_begin, int64_t column_end, uint64_t arena_bytes, char* host_out,
+                               uint64_t host_cap, uint64_t* host_len, gdbamd_interval_stats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

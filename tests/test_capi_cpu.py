@@ -1,0 +1,52 @@
+"""No-GPU checks of the product boundary: the C-ABI library loads, exports every symbol include/genomicsdb_amd.h
+declares, and refuses to run without a HIP device (no CPU fallback)."""
+import os
+import re
+
+import pytest
+
+import helpers
+from golden_cases import CASES
+
+ROOT = helpers.ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from genomicsdb_amd import build as b
+    b.build_native()
+    from genomicsdb_amd import _lib
+    return _lib.lib()
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "genomicsdb_amd.h")).read()
+    declared = set(re.findall(r"\b(gdb_mi355_\w+|gdbamd_engine_\w+)\s*\(", hdr))
+    from genomicsdb_amd import _lib
+    assert declared == set(_lib.SYMBOLS)
+    for s in declared:
+        assert getattr(lib, s) is not None
+
+
+def test_no_cpu_fallback_without_device(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    case = CASES[0]
+    q, _ = helpers.query_json(case[1], case[2], case[3], case[5])
+    import genomicsdb_amd
+    with pytest.raises(genomicsdb_amd.GenomicsDBException, match="no HIP device|HIP"):
+        genomicsdb_amd.CombineEngine(q)
+
+
+def test_product_does_not_reference_oracle():
+    """the product tree must not include / link / import anything under oracle/"""
+    bad = []
+    for d, _, fs in os.walk(os.path.join(ROOT, "genomicsdb_amd")):
+        for f in fs:
+            if f.endswith((".cc", ".h", ".hpp", ".hip", ".py")):
+                txt = open(os.path.join(d, f), errors="replace").read()
+                if re.search(r'#include\s+"[^"]*oracle', txt) or re.search(r"liboracle|import\s+oracle|from\s+oracle", txt):
+                    if f != "build.py":
+                        bad.append(f)
+    assert not bad, bad
