@@ -24,7 +24,7 @@ SOURCES = [
     "api/capi.cc",
 ]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-gline-tables-only", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 
 
 def _headers():

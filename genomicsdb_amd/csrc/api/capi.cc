@@ -113,6 +113,7 @@ int gdbamd_engine_run_interval(void* e, int64_t qb, int64_t qe, uint64_t arena_b
   return guarded([&]() -> int {
     CombineEngine& eng = *((EngineHandle*)e)->eng;
     HostCopy hc{host_out, host_cap, 0};
+    eng.stage_reference_for(qb, qe);  // no-op unless the query names a reference_genome and cells were staged from host
     IntervalStats s = eng.pipeline().run_interval(qb, qe, arena_bytes, host_out ? copy_page : nullptr, &hc);
     if (host_len) *host_len = host_out ? hc.len : s.bytes_out;
     if (out) {

@@ -632,148 +632,202 @@ template <class Sink> GDB_HD void put_int_or_missing(Sink& s, bool has, int32_t 
   if (!has || v == GDB_BCF_INT32_MISSING) s.put('.'); else put_i32(s, v);
 }
 
-// text of one (record, sample) column.  c < 0: the sample has no live call.
-template <class Sink> GDB_HD void entry_emit(const EntryCtx& cx, const RecordInfo& ri, int64_t c, Sink& s, uint32_t* err) {
+// Allele maps of one live call inside one record (built once per entry, handed to the field emitters by reference)
+struct EntryMaps {
+  int8_t m2i[GDB_MAX_MERGED_ALLELES];  // merged allele -> input allele of this call (-1: none)
+  const int8_t* i2m;                   // input -> merged (heavy calls), null for plain reference blocks
+  int nr_in;                           // input idx of <NON_REF> in this call, -1 if it has none
+  int n_in;                            // #input alleles incl. REF
+  int64_t inc;                         // incidence idx of a heavy call, -1 otherwise
+  uint32_t cf;                         // cell flags
+  uint8_t iflag;
+  bool remap, nr_exists;
+};
+
+#if defined(__HIPCC__)
+#define GDB_FIELD_FN __host__ __device__ __noinline__
+#else
+#define GDB_FIELD_FN inline
+#endif
+
+// Each field kind has its own out-of-line emitter taking and returning the sink BY VALUE: keeps every function small
+// and the cursor in registers (a char store through a by-reference sink may alias the sink itself).
+template <class Sink> GDB_FIELD_FN Sink emit_GT(Sink s, const EntryCtx& cx, const RecordInfo& ri, const EntryMaps& em, int64_t c) {
   const CombinePlan& pl = cx.pl;
-  bool first = true;
-  // allele maps of this call (only when a remap is needed)
-  const bool remap = (ri.rflags & GDB_RF_REMAPPING_NEEDED) != 0;
-  const bool nr_exists = (ri.rflags & GDB_RF_NON_REF_EXISTS) != 0;
-  int8_t m2i[GDB_MAX_MERGED_ALLELES];
-  int nr_in = -1;        // input idx of <NON_REF> in this call
-  const int8_t* i2m = nullptr;
-  int n_in = 0;
-  uint8_t iflag = 0;
-  int64_t inc = -1;
-  uint32_t cf = 0;
-  if (c >= 0) {
-    cf = cx.cm.cflags[c];
-    n_in = (int)GDB_CF_NALT(cf) + 1;
-    if (remap) {
-      for (int j = 0; j < ri.num_merged; ++j) m2i[j] = -1;
-      if (cf & GDB_CF_HEAVY) {
-        int32_t row = cx.fr.row[c];
-        int64_t lo = ri.hbase, hi = ri.hend;
-        while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (cx.fr.row[cx.hl.cell[mid]] < row) lo = mid + 1; else hi = mid; }
-        inc = lo;
-        if (inc >= ri.hend || cx.hl.cell[inc] != c) { *err |= GDB_ERR_INTERNAL; inc = -1; }
-      }
-      if (inc >= 0) {
-        i2m = cx.hl.i2m + cx.hl.i2m_off[inc];
-        iflag = cx.hl.iflags[inc];
-        for (int a = 0; a < n_in; ++a) if (i2m[a] >= 0) m2i[i2m[a]] = (int8_t)a;
-        if (nr_exists && m2i[ri.num_merged - 1] >= 0 && (cf & GDB_CF_HAS_NR)) nr_in = m2i[ri.num_merged - 1];
-      } else {  // plain reference block: REF -> 0, <NON_REF> -> last
-        m2i[0] = 0;
-        if (nr_exists) { m2i[ri.num_merged - 1] = 1; nr_in = 1; }
+  const int f = pl.f_GT;
+  int n;
+  const int32_t* g = cell_field<int32_t>(cx.fr, pl, f, c, n);
+  const bool pp = pl.field[f].length == GDB_VL_PP;
+  const int step = pp ? 2 : 1;
+  int out_i = 0;
+  for (int j = 0; j < n; j += step, ++out_i) {
+    if (out_i) s.put((pp && g[j - 1] > 0) ? '|' : '/');
+    int32_t m = -1;
+    if (pl.produce_GT_field) {
+      int32_t a = g[j];
+      if (em.iflag & GDB_IF_GT_OVERRIDE) {  // min-PL genotype over the reduced alleles: 0 REF, 1 '*', 2 <NON_REF>
+        const int ra = cx.hl.gt_override[2 * em.inc + (out_i < 2 ? out_i : 1)];
+        if (ra == 0) m = 0;
+        else if (ra == 2) m = ri.num_merged - 1;
+        else { for (int q = 1; q < em.n_in; ++q) if (em.i2m && em.i2m[q] >= 0 && em.i2m[q] != ri.num_merged - 1) { m = em.i2m[q]; break; } }
+      } else if (a == GDB_TILEDB_NULL_INT32 || a == -1 || a == GDB_BCF_INT32_MISSING) {
+        m = -1;
+      } else if (!em.remap) {
+        m = a;
+      } else {
+        int8_t mm = -1;
+        if (a >= 0 && a < em.n_in) mm = em.i2m ? em.i2m[a] : (a == 0 ? (int8_t)0 : ((em.nr_exists && a == 1) ? (int8_t)(ri.num_merged - 1) : (int8_t)-1));
+        if (mm >= 0) m = mm;
+        else if ((em.iflag & GDB_IF_SPANNING) && (em.iflag & GDB_IF_NO_NR)) m = -1;
+        else m = em.nr_exists ? ri.num_merged - 1 : -1;
       }
     }
+    if (m < 0) s.put('.'); else put_i32(s, m);
   }
-  for (int i = 0; i < pl.n_format; ++i) {
-    if (!((ri.fmt_mask >> i) & 1)) continue;
-    if (!first) s.put(':');
-    first = false;
-    const int f = pl.format_field[i];
-    const GdbFieldDesc& fd = pl.field[f];
-    if (c < 0) { s.put('.'); continue; }
-    if (f == pl.f_DP && pl.f_DP_FORMAT >= 0) {  // FORMAT DP := DP_FORMAT (broad_combined_gvcf.cc:689-719)
-      int n; bool ok = field_valid(cx.cm, c, pl.f_DP_FORMAT);
-      int32_t v = GDB_BCF_INT32_MISSING;
-      if (ok) { const int32_t* p = cell_field<int32_t>(cx.fr, pl, pl.f_DP_FORMAT, c, n); if (n > 0) v = p[0]; }
-      put_int_or_missing(s, ok && gdb_int_valid(v), v);
-      continue;
+  if (out_i == 0) s.put('.');
+  return s;
+}
+
+template <class Sink> GDB_FIELD_FN Sink emit_chars(Sink s, const EntryCtx& cx, int f, int64_t c) {
+  int n;
+  const char* p = cell_field<char>(cx.fr, cx.pl, f, c, n);
+  // htslib bcf_fmt_array, char flavour: stop at the first NUL, 0x07 (bcf_str_missing) prints as '.'
+  int len = 0;
+  while (len < n && p[len]) ++len;
+  if (n == 0) s.put('.');
+  for (int j = 0; j < len; ++j) { const char ch = p[j]; s.put(ch == 0x07 ? '.' : ch); }
+  return s;
+}
+
+template <class Sink> GDB_FIELD_FN Sink emit_int_vector(Sink s, const int32_t* p, int n) {
+  if (n == 0) { s.put('.'); return s; }
+  for (int j = 0; j < n; ++j) {
+    if (p[j] == GDB_BCF_INT32_VECTOR_END) break;
+    if (j) s.put(',');
+    if (p[j] == GDB_BCF_INT32_MISSING) s.put('.'); else put_i32(s, p[j]);
+  }
+  return s;
+}
+
+// remap_data_based_on_alleles: R- and A-length fields
+template <class Sink> GDB_FIELD_FN Sink emit_remap_alleles(Sink s, const int32_t* p, int n, const EntryMaps& em, int num_merged, bool alt_only) {
+  const int length = alt_only ? num_merged - 1 : num_merged;
+  if (length == 0) { s.put('.'); return s; }
+  for (int j = 0; j < length; ++j) {
+    if (j) s.put(',');
+    const int aj = alt_only ? j + 1 : j;
+    int in_j = em.m2i[aj];
+    if (in_j < 0) in_j = em.nr_in;
+    const int idx = alt_only ? in_j - 1 : in_j;
+    const bool has = in_j >= 0 && idx >= 0 && idx < n;
+    const int32_t v = has ? p[idx] : GDB_BCF_INT32_MISSING;
+    if (v == GDB_BCF_INT32_MISSING) s.put('.'); else put_i32(s, v);
+  }
+  return s;
+}
+
+// remap_data_based_on_genotype_{haploid,diploid}: G-length fields (PL)
+template <class Sink> GDB_FIELD_FN Sink emit_remap_genotypes(Sink s, const int32_t* p, int n, const EntryMaps& em, int num_merged, int ploidy, uint32_t* err) {
+  if (ploidy == 1) {
+    for (int j = 0; j < num_merged; ++j) {
+      if (j) s.put(',');
+      int in_j = em.m2i[j];
+      if (in_j < 0) in_j = em.nr_in;
+      const bool has = in_j >= 0 && in_j < n;
+      const int32_t v = has ? p[in_j] : GDB_BCF_INT32_MISSING;
+      if (v == GDB_BCF_INT32_MISSING) s.put('.'); else put_i32(s, v);
     }
-    if (!field_valid(cx.cm, c, f)) { s.put('.'); continue; }
-    if (f == pl.f_GT) {
-      int n;
-      const int32_t* g = cell_field<int32_t>(cx.fr, pl, f, c, n);
-      const bool pp = fd.length == GDB_VL_PP;
-      const int step = pp ? 2 : 1;
-      int out_i = 0;
-      for (int j = 0; j < n; j += step, ++out_i) {
-        if (out_i) s.put((pp && g[j - 1] > 0) ? '|' : '/');
-        int32_t a = g[j];
-        if (!pl.produce_GT_field) { s.put('.'); continue; }
-        if (iflag & GDB_IF_GT_OVERRIDE) {  // min-PL genotype over the reduced alleles
-          int ra = cx.hl.gt_override[2 * inc + (out_i < 2 ? out_i : 1)];
-          a = ra == 0 ? 0 : (ra == 1 ? -2 : -3);  // -2: '*' allele, -3: <NON_REF>
-        }
-        int32_t m;
-        if (a == -2 || a == -3) {
-          m = -1;
-          if (a == -3) m = ri.num_merged - 1;
-          else for (int q = 1; q < n_in; ++q) if (i2m && i2m[q] >= 0 && i2m[q] != ri.num_merged - 1) { m = i2m[q]; break; }
-        } else if (a == GDB_TILEDB_NULL_INT32 || a == -1 || a == GDB_BCF_INT32_MISSING) m = -1;
-        else if (!remap) m = a;
-        else {
-          int8_t mm = -1;
-          if (a >= 0 && a < n_in) mm = i2m ? i2m[a] : (a == 0 ? 0 : (nr_exists && a == 1 ? (int8_t)(ri.num_merged - 1) : -1));
-          if (mm >= 0) m = mm;
-          else if (iflag & GDB_IF_SPANNING) m = (iflag & GDB_IF_NO_NR) ? -1 : (nr_exists ? ri.num_merged - 1 : -1);
-          else m = nr_exists ? ri.num_merged - 1 : -1;
-        }
-        if (m < 0) s.put('.'); else put_i32(s, m);
+  } else if (ploidy == 2) {
+    // output order gt = k(k+1)/2 + j, j <= k
+    for (int kk = 0; kk < num_merged; ++kk) {
+      int in_k = em.m2i[kk];
+      if (in_k < 0) in_k = em.nr_in;
+      for (int j = 0; j <= kk; ++j) {
+        if (kk | j) s.put(',');
+        int in_j = em.m2i[j];
+        if (in_j < 0) in_j = em.nr_in;
+        const bool both = in_j >= 0 && in_k >= 0;
+        const int gi = both ? gdb_alleles2gt(in_j, in_k) : 0;
+        const bool has = both && gi < n;
+        const int32_t v = has ? p[gi] : GDB_BCF_INT32_MISSING;
+        if (v == GDB_BCF_INT32_MISSING) s.put('.'); else put_i32(s, v);
       }
-      if (out_i == 0) s.put('.');
-      continue;
     }
-    if (fd.elem == GDB_ET_CHAR || fd.elem == GDB_ET_FLAG) {
-      int n;
-      const char* p = cell_field<char>(cx.fr, pl, f, c, n);
-      if (n == 0) s.put('.');
-      for (int j = 0; j < n && p[j]; ++j) s.put(p[j] == 0x07 ? '.' : p[j]);
-      continue;
-    }
-    if (fd.elem != GDB_ET_INT) { *err |= GDB_ERR_INTERNAL; s.put('.'); continue; }
+  } else {
+    *err |= GDB_ERR_UNSUPPORTED_PLOIDY;
+    s.put('.');
+  }
+  return s;
+}
+
+GDB_FIELD_FN void build_entry_maps(const EntryCtx& cx, const RecordInfo& ri, int64_t c, EntryMaps& em, uint32_t* err) {
+  em.remap = (ri.rflags & GDB_RF_REMAPPING_NEEDED) != 0;
+  em.nr_exists = (ri.rflags & GDB_RF_NON_REF_EXISTS) != 0;
+  em.nr_in = -1; em.i2m = nullptr; em.n_in = 0; em.iflag = 0; em.inc = -1; em.cf = 0;
+  if (c < 0) return;
+  em.cf = cx.cm.cflags[c];
+  em.n_in = (int)GDB_CF_NALT(em.cf) + 1;
+  if (!em.remap) return;
+  for (int j = 0; j < ri.num_merged; ++j) em.m2i[j] = -1;
+  if (em.cf & GDB_CF_HEAVY) {
+    const int32_t row = cx.fr.row[c];
+    int64_t lo = ri.hbase, hi = ri.hend;
+    while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (cx.fr.row[cx.hl.cell[mid]] < row) lo = mid + 1; else hi = mid; }
+    if (lo < ri.hend && cx.hl.cell[lo] == c) em.inc = lo; else *err |= GDB_ERR_INTERNAL;
+  }
+  if (em.inc >= 0) {
+    em.i2m = cx.hl.i2m + cx.hl.i2m_off[em.inc];
+    em.iflag = cx.hl.iflags[em.inc];
+    for (int a = 0; a < em.n_in; ++a) { const int8_t t = em.i2m[a]; if (t >= 0) em.m2i[t] = (int8_t)a; }
+    if (em.nr_exists && (em.cf & GDB_CF_HAS_NR) && em.m2i[ri.num_merged - 1] >= 0) em.nr_in = em.m2i[ri.num_merged - 1];
+  } else {  // plain reference block: REF -> 0, <NON_REF> -> last
+    em.m2i[0] = 0;
+    if (em.nr_exists) { em.m2i[ri.num_merged - 1] = 1; em.nr_in = 1; }
+  }
+}
+
+// text of one FORMAT field of a live call
+template <class Sink> GDB_HD Sink emit_field(Sink s, const EntryCtx& cx, const RecordInfo& ri, const EntryMaps& em, int i, int64_t c, uint32_t* err) {
+  const CombinePlan& pl = cx.pl;
+  const int f = pl.format_field[i];
+  const GdbFieldDesc& fd = pl.field[f];
+  if (f == pl.f_DP && pl.f_DP_FORMAT >= 0) {  // FORMAT DP := DP_FORMAT (broad_combined_gvcf.cc:689-719)
+    int32_t v = GDB_BCF_INT32_MISSING;
+    if (field_valid(cx.cm, c, pl.f_DP_FORMAT)) { int n; const int32_t* p = cell_field<int32_t>(cx.fr, pl, pl.f_DP_FORMAT, c, n); if (n > 0) v = p[0]; }
+    if (gdb_int_valid(v)) put_i32(s, v); else s.put('.');
+  } else if (!field_valid(cx.cm, c, f)) {
+    s.put('.');
+  } else if (f == pl.f_GT) {
+    s = emit_GT(s, cx, ri, em, c);
+  } else if (fd.elem == GDB_ET_CHAR || fd.elem == GDB_ET_FLAG) {
+    s = emit_chars(s, cx, f, c);
+  } else if (fd.elem != GDB_ET_INT) {
+    *err |= GDB_ERR_INTERNAL;
+    s.put('.');
+  } else {
     int n;
     const int32_t* p = cell_field<int32_t>(cx.fr, pl, f, c, n);
     const bool allele_dep = fd.length == GDB_VL_A || fd.length == GDB_VL_R || fd.length == GDB_VL_G;
-    if (!remap || !allele_dep) { put_int_vector(s, p, n); continue; }
-    if (fd.length == GDB_VL_R || fd.length == GDB_VL_A) {  // remap_data_based_on_alleles
-      const bool alt_only = fd.length == GDB_VL_A;
-      const int length = alt_only ? ri.num_merged - 1 : ri.num_merged;
-      if (length == 0) { s.put('.'); continue; }
-      for (int j = 0; j < length; ++j) {
-        if (j) s.put(',');
-        int aj = alt_only ? j + 1 : j;
-        int in_j = m2i[aj];
-        if (in_j < 0) in_j = nr_in;
-        int idx = alt_only ? in_j - 1 : in_j;
-        bool has = in_j >= 0 && idx >= 0 && idx < n;
-        put_int_or_missing(s, has, has ? p[idx] : 0);
-      }
-      continue;
-    }
-    // genotype-length field (PL)
-    const int ploidy = (int)GDB_CF_PLOIDY(cf);
-    if (ploidy == 1) {
-      for (int j = 0; j < ri.num_merged; ++j) {
-        if (j) s.put(',');
-        int in_j = m2i[j];
-        if (in_j < 0) in_j = nr_in;
-        bool has = in_j >= 0 && in_j < n;
-        put_int_or_missing(s, has, has ? p[in_j] : 0);
-      }
-    } else if (ploidy == 2) {
-      // output order gt = k(k+1)/2 + j, j <= k  (remap_data_based_on_genotype_diploid)
-      bool firstv = true;
-      for (int kk = 0; kk < ri.num_merged; ++kk) {
-        int in_k = m2i[kk];
-        if (in_k < 0) in_k = nr_in;
-        for (int j = 0; j <= kk; ++j) {
-          if (!firstv) s.put(',');
-          firstv = false;
-          int in_j = m2i[j];
-          if (in_j < 0) in_j = nr_in;
-          bool has = in_j >= 0 && in_k >= 0;
-          int gi = has ? gdb_alleles2gt(in_j, in_k) : 0;
-          has = has && gi < n;
-          put_int_or_missing(s, has, has ? p[gi] : 0);
-        }
-      }
-    } else {
-      *err |= GDB_ERR_UNSUPPORTED_PLOIDY;
-      s.put('.');
+    if (!em.remap || !allele_dep) s = emit_int_vector(s, p, n);
+    else if (fd.length == GDB_VL_G) s = emit_remap_genotypes(s, p, n, em, ri.num_merged, (int)GDB_CF_PLOIDY(em.cf), err);
+    else s = emit_remap_alleles(s, p, n, em, ri.num_merged, fd.length == GDB_VL_A);
+  }
+  return s;
+}
+
+// text of one (record, sample) column.  c < 0: the sample has no live call.
+template <class Sink> GDB_HD Sink entry_emit(const EntryCtx& cx, const RecordInfo& ri, int64_t c, Sink s, uint32_t* err) {
+  const CombinePlan& pl = cx.pl;
+  EntryMaps em;
+  build_entry_maps(cx, ri, c, em, err);
+  bool first = true;
+  for (int i = 0; i < pl.n_format; ++i) {
+    if ((ri.fmt_mask >> i) & 1) {
+      if (!first) s.put(':');
+      first = false;
+      if (c < 0) s.put('.');
+      else s = emit_field(s, cx, ri, em, i, c, err);
     }
   }
+  return s;
 }

@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -45,6 +47,8 @@ template <class T> struct DevBuf {   // grow-only device allocation
   ~DevBuf() { release(); }
 };
 
+inline bool debug_sync() { static int v = -1; if (v < 0) { const char* e = getenv("GDBAMD_DEBUG_SYNC"); v = (e && *e && *e != '0') ? 1 : 0; } return v == 1; }
+#define STAGE(name) do { if (debug_sync()) { HIP_CHECK(hipStreamSynchronize(st)); fprintf(stderr, "[gdbamd] stage %s\n", name); fflush(stderr); } } while (0)
 inline unsigned blocks_for(int64_t n, int b = kBlock) { return (unsigned)std::max<int64_t>(1, (n + b - 1) / b); }
 inline int bits_for(uint64_t max_value) { int b = 1; while (b < 64 && (max_value >> b)) ++b; return std::min(64, b + 1); }
 
@@ -155,6 +159,14 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
   return v;
 }
 
+// the two instantiations are kept out of line: one copy each instead of one per call site
+__device__ __noinline__ uint32_t entry_length(const EntryCtx& ex, const RecordInfo& ri, int64_t c, uint32_t* e) {
+  return (uint32_t)entry_emit(ex, ri, c, CountSink(), e).n;
+}
+__device__ __noinline__ void entry_store(const EntryCtx& ex, const RecordInfo& ri, int64_t c, char* dst, uint32_t* e) {
+  (void)entry_emit(ex, ri, c, ByteSink(dst), e);
+}
+
 __global__ void __launch_bounds__(kBlock)
 k_entry_size(EntryCtx ex, RowIndex ri, SiteOut so, RecordTable rec, int32_t N, int nchunks, uint64_t* chunk_size, uint32_t* err) {
   const int64_t k0 = (int64_t)blockIdx.x * kRun;
@@ -176,9 +188,7 @@ k_entry_size(EntryCtx ex, RowIndex ri, SiteOut so, RecordTable rec, int32_t N, i
       const int64_t c = w.live(ri, ex.cm, rec.start[k]);
       if (!so.fmt_mask[k]) continue;
       RecordInfo rinfo = load_record_info(so, ex.hl, k);
-      CountSink cs;
-      entry_emit(ex, rinfo, c, cs, &e);
-      lens[i] = 1u + (uint32_t)cs.n;
+      lens[i] = 1u + entry_length(ex, rinfo, c, &e);
     }
   }
 #pragma unroll
@@ -221,9 +231,7 @@ k_entry_write(EntryCtx ex, RowIndex ri, SiteOut so, RecordTable rec, int32_t N, 
       cells[i] = (int32_t)c;
       if (!so.fmt_mask[k]) continue;
       RecordInfo rinfo = load_record_info(so, ex.hl, k);
-      CountSink cs;
-      entry_emit(ex, rinfo, c, cs, &e);
-      lens[i] = 1u + (uint32_t)cs.n;
+      lens[i] = 1u + entry_length(ex, rinfo, c, &e);
     }
   }
   // exclusive offsets of every row inside its (record, chunk): wave scan + wave totals through LDS
@@ -244,9 +252,8 @@ k_entry_write(EntryCtx ex, RowIndex ri, SiteOut so, RecordTable rec, int32_t N, 
       for (int wv = 0; wv < wave; ++wv) base += wtot[i][wv];
       char* dst = arena + (chunk_off[k * nchunks + ch] - page_base) + (ch == 0 ? so.prefix_len[k] : 0u) + base + excl[i];
       *dst = '\t';
-      ByteSink bs(dst + 1);
       RecordInfo rinfo = load_record_info(so, ex.hl, k);
-      entry_emit(ex, rinfo, (int64_t)cells[i], bs, &e);
+      entry_store(ex, rinfo, (int64_t)cells[i], dst + 1, &e);
     }
   }
   if (e) atomicOr(err, e);
@@ -430,24 +437,30 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   CellMeta cm{S.vmask.p, S.cflags.p, S.dpval.p, S.eff_end.p, S.k_lo.p, S.k_hi.p};
   S.perm.ensure(C); S.rm_begin.ensure(C); S.row_ptr.ensure((size_t)N + 2);
   if (!S.classified) {
+    STAGE("k_classify");
     hipLaunchKernelGGL(k_classify, dim3(blocks_for(C)), dim3(kBlock), 0, st, fr, pl, cm, S.err.p);
     S.row_keys.ensure(C); S.row_keys_sorted.ensure(C); S.cell_ids.ensure(C);
+    STAGE("k_iota_rows");
     hipLaunchKernelGGL(k_iota_rows, dim3(blocks_for(C)), dim3(kBlock), 0, st, fr, S.row_keys.p, S.cell_ids.p);
     S.sort_pairs(S.row_keys.p, S.row_keys_sorted.p, S.cell_ids.p, S.perm.p, (size_t)C, std::min(32, bits_for((uint64_t)N)));
+    STAGE("k_row_ptr");
     hipLaunchKernelGGL(k_row_ptr, dim3(blocks_for((int64_t)N + 1)), dim3(kBlock), 0, st, S.row_keys_sorted.p, C, N, S.row_ptr.p);
     S.classified = true;
   }
   // ---- S2 effective END ------------------------------------------------------------------------------------------
+  STAGE("k_eff_end");
   hipLaunchKernelGGL(k_eff_end, dim3(blocks_for(C)), dim3(kBlock), 0, st, fr, cm, S.perm.p, qb, qe, S.rm_begin.p, S.err.p);
   // ---- S3 events -> boundaries -> records --------------------------------------------------------------------------
   const int64_t NE = 2 * C;
   S.ev_keys.ensure(NE); S.ev_keys_sorted.ensure(NE); S.ev_delta.ensure(NE); S.ev_incl.ensure(NE); S.run_end.ensure(NE); S.run_excl.ensure(NE + 1);
+  STAGE("k_event_keys");
   hipLaunchKernelGGL(k_event_keys, dim3(blocks_for(C)), dim3(kBlock), 0, st, fr, cm, qb, qe, S.ev_keys.p);
   {
     const uint64_t span = (uint64_t)(qe - qb) + 2u;
     const int eb = span >= (1ull << 60) ? 64 : bits_for(span << 2);
     S.sort_keys(S.ev_keys.p, S.ev_keys_sorted.p, (size_t)NE, eb);
   }
+  STAGE("k_event_delta");
   hipLaunchKernelGGL(k_event_delta, dim3(blocks_for(NE)), dim3(kBlock), 0, st, S.ev_keys_sorted.p, NE, S.ev_delta.p, S.run_end.p);
   S.incl_scan(S.ev_delta.p, S.ev_incl.p, (size_t)NE, PackedAdd());
   S.excl_scan(S.run_end.p, S.run_excl.p, (size_t)NE);
@@ -456,12 +469,15 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   if (U > 0) {
     S.bpos.ensure(U + 1); S.bcov.ensure(U + 1); S.bdel.ensure(U + 1); S.bnrec.ensure(U + 1); S.rbase.ensure(U + 1);
     Boundaries bd{S.bpos.p, S.bcov.p, S.bdel.p, S.bnrec.p};
+    STAGE("k_boundary_write");
     hipLaunchKernelGGL(k_boundary_write, dim3(blocks_for(NE)), dim3(kBlock), 0, st, S.ev_keys_sorted.p, S.ev_incl.p, S.run_end.p, S.run_excl.p, NE, bd, qb);
+    STAGE("k_boundary_nrec");
     hipLaunchKernelGGL(k_boundary_nrec, dim3(blocks_for(U)), dim3(kBlock), 0, st, bd, U);
     S.excl_scan(S.bnrec.p, S.rbase.p, (size_t)U);
     P = S.read_back(S.rbase.p + (U - 1)) + S.read_back(S.bnrec.p + (U - 1));
     if (P > 0) {
       S.rstart.ensure(P); S.rend.ensure(P);
+      STAGE("k_record_expand");
       hipLaunchKernelGGL(k_record_expand, dim3(blocks_for(P)), dim3(kBlock), 0, st, bd, S.rbase.p, U, P, S.rstart.p, S.rend.p);
     }
   }
@@ -485,6 +501,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   int32_t* d_nr = d_dp + stride;
   DiffArrays da{d_fmt, d_dp, d_nr, stride};
   S.heavy_count.ensure(C + 1); S.hoff.ensure(C + 2);
+  STAGE("k_cell_ranges");
   hipLaunchKernelGGL(k_cell_ranges, dim3(blocks_for(C)), dim3(kBlock), 0, st, fr, pl, cm, rec, qb, qe, da, S.heavy_count.p, S.counters.p);
   for (int i = 0; i < nf + 2; ++i) S.incl_scan(S.diff.p + (size_t)i * stride, S.diff.p + (size_t)i * stride, (size_t)stride, rocprim::plus<int32_t>());
   S.excl_scan(S.heavy_count.p, S.hoff.p, (size_t)C);
@@ -496,8 +513,10 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   S.hbase.ensure(P + 2); S.lut_len.ensure(T + 1); S.i2m_off.ensure(T + 2); S.iflags.ensure(T + 1); S.gt_override.ensure(2 * T + 2);
   uint32_t lut_total = 0;
   if (T > 0) {
+    STAGE("k_incidence_fill");
     hipLaunchKernelGGL(k_incidence_fill, dim3(blocks_for(C)), dim3(kBlock), 0, st, fr, cm, S.hoff.p, (int64_t)N, S.inc_keys.p, S.inc_vals.p);
     S.sort_pairs(S.inc_keys.p, S.inc_keys_sorted.p, S.inc_vals.p, S.inc_vals_sorted.p, (size_t)T, bits_for((uint64_t)P * (uint64_t)N));
+    STAGE("k_lut_len");
     hipLaunchKernelGGL(k_lut_len, dim3(blocks_for(T)), dim3(kBlock), 0, st, S.inc_vals_sorted.p, S.cflags.p, T, S.lut_len.p);
     S.excl_scan(S.lut_len.p, S.i2m_off.p, (size_t)T);
     lut_total = S.read_back(S.i2m_off.p + (T - 1)) + S.read_back(S.lut_len.p + (T - 1));
@@ -506,6 +525,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   } else {
     HIP_CHECK(hipMemsetAsync(S.i2m_off.p, 0, 2 * sizeof(uint32_t), st));
   }
+  STAGE("k_heavy_base");
   hipLaunchKernelGGL(k_heavy_base, dim3(blocks_for(P + 1)), dim3(kBlock), 0, st, S.inc_keys_sorted.p, T, (int64_t)N, P, S.hbase.p);
   S.i2m.ensure((size_t)lut_total + 16);
   HeavyLists hl{S.hbase.p, S.inc_vals_sorted.p, S.i2m_off.p, S.i2m.p, S.iflags.p, S.gt_override.p};
@@ -521,6 +541,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   NameTables nt{S.names_text.p, S.field_name_off.p, S.field_name_len.p, S.filter_name_off.p, S.filter_name_len.p, (int32_t)S.hp.filter_name_off.size()};
   PresenceCounts pc{d_fmt, d_dp, d_nr, stride};
   SiteCtx sx{fr, pl, cm, rec, hl, pc, nt, qw, so};
+  STAGE("k_site_size");
   hipLaunchKernelGGL(k_site_size, dim3(blocks_for(P, 64)), dim3(64), 0, st, sx, S.err.p);
   HIP_CHECK(hipEventRecord(ev[2], st));
   // ---- S8 sample-column sizes + offsets ---------------------------------------------------------------------------
@@ -530,13 +551,16 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   RowIndex ri{S.row_ptr.p, S.perm.p, S.rm_begin.p};
   EntryCtx ex{fr, pl, cm, hl};
   const unsigned run_blocks = (unsigned)((P + kRun - 1) / kRun);
+  STAGE("k_entry_size");
   hipLaunchKernelGGL(k_entry_size, dim3(run_blocks, nchunks), dim3(kBlock), 0, st, ex, ri, so, rec, N, nchunks, S.chunk_size.p, S.err.p);
   HIP_CHECK(hipMemsetAsync(S.chunk_size.p + nchunk_total, 0, sizeof(uint64_t), st));
   S.excl_scan(S.chunk_size.p, S.chunk_off.p, nchunk_total + 1);
+  STAGE("k_gather_record_offsets");
   hipLaunchKernelGGL(k_gather_record_offsets, dim3(blocks_for(P + 1)), dim3(kBlock), 0, st, S.chunk_off.p, nchunks, P, S.rec_off.p);
   std::vector<uint64_t>& rec_off = S.iv.rec_off;
   rec_off.resize((size_t)P + 1);
   HIP_CHECK(hipMemcpyAsync(rec_off.data(), S.rec_off.p, (size_t)(P + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  STAGE("before-sync-offsets");
   HIP_CHECK(hipEventRecord(ev[3], st));
   HIP_CHECK(hipStreamSynchronize(st));
   stats.bytes_out = rec_off[(size_t)P];
@@ -573,8 +597,10 @@ bool DevicePipeline::next_page(uint64_t arena_bytes, const char** dev_ptr, uint6
   hipEvent_t w0, w1, w2;
   HIP_CHECK(hipEventCreate(&w0)); HIP_CHECK(hipEventCreate(&w1)); HIP_CHECK(hipEventCreate(&w2));
   HIP_CHECK(hipEventRecord(w0, st));
+  STAGE("k_site_write");
   hipLaunchKernelGGL(k_site_write, dim3(blocks_for(np, 64)), dim3(64), 0, st, iv.sx, kp, ke, S.chunk_off.p, iv.nchunks, page_base, S.arena.p, S.err.p);
   HIP_CHECK(hipEventRecord(w1, st));
+  STAGE("k_entry_write");
   hipLaunchKernelGGL(k_entry_write, dim3((unsigned)((np + kRun - 1) / kRun), iv.nchunks), dim3(kBlock), 0, st, iv.ex, iv.ri, iv.so, iv.rec, N, iv.nchunks, kp, ke,
                      S.chunk_off.p, page_base, S.arena.p, S.err.p);
   HIP_CHECK(hipEventRecord(w2, st));

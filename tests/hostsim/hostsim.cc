@@ -133,7 +133,7 @@ std::string run_interval(const HostPlan& hp, const HostFragment& hf, const VidMa
         const int64_t c = w.live(ri, cm, rstart[k]);
         if (!fmt_mask[k]) continue;
         RecordInfo rinfo = load_record_info(so, hl, k);
-        CountSink cs; entry_emit(ex, rinfo, c, cs, &err);
+        CountSink cs = entry_emit(ex, rinfo, c, CountSink(), &err);
         chunk_size[(size_t)k * nchunks + r / rows_per_chunk] += 1 + cs.n;
       }
     }
@@ -155,8 +155,7 @@ std::string run_interval(const HostPlan& hp, const HostFragment& hf, const VidMa
         RecordInfo rinfo = load_record_info(so, hl, k);
         uint64_t& cur = cursor[(size_t)(k - k0) * nchunks + r / rows_per_chunk];
         out[cur++] = '\t';
-        ByteSink bs(&out[cur]);
-        entry_emit(ex, rinfo, c, bs, &err);
+        ByteSink bs = entry_emit(ex, rinfo, c, ByteSink(&out[cur]), &err);
         cur = (uint64_t)(bs.p - out.data());
       }
     }
