@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py - combined-gVCF positions/sec of the scan+combine hot path on MI355X.
+
+Workload (BASELINE.json configs[1], "c2"): 1 000 synthetic-gVCF samples x 10 Mb column interval (generator of
+SURVEY.md 8(d), genomicsdb_amd/synth), staged once in HBM as a columnar fragment.  A STEP is one pass of the hot path
+over one batch = one --window-bp wide column window of that array (sweep -> site merge -> sizing -> bit-exact VCF text
+written into HBM pages); successive steps take successive windows.  `value` = output records (positions) per second
+with the input resident in HBM; nothing is copied to the host inside the timed region.
+
+N > 1 (torch.distributed.run, one rank per GPU): every rank owns its own column partition of the same shape
+(weak scaling, no data-path collective - the reference's ranks do not communicate either, gt_mpi_gather.cc:322-366);
+value = records of all ranks / max-over-ranks time.
+
+Also on the JSON line: "roofline" for the dominant kernel (k_entry_write, HBM-bound byte emission) and "cpu_baseline"
+(the CPU oracle = port of the reference algorithm, single thread, on a bounded sample of the same workload).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--samples", type=int, default=1000)
+    ap.add_argument("--interval-bp", type=int, default=10_000_000)
+    ap.add_argument("--window-bp", type=int, default=100_000, help="columns per step (one batch)")
+    ap.add_argument("--arena-mb", type=int, default=4096, help="HBM page for the output text")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-bp", type=int, default=5000)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+
+    import genomicsdb_amd
+    from genomicsdb_amd import synth
+    import helpers
+
+    N, Lbp, W = args.samples, args.interval_bp, args.window_bp
+    B = 10_000_000 + rank * Lbp  # every rank scans its own column partition of the same shape
+    nwin = max(1, Lbp // W)
+    total_steps = args.steps + args.warmup
+    need_bp = min(Lbp, W * min(nwin, total_steps))  # stage only the windows the run will touch
+    tmp = tempfile.mkdtemp(prefix="gdbamd_bench_")
+    q = helpers.synth_query(tmp, N, B, B + Lbp - 1)
+    eng = genomicsdb_amd.CombineEngine(q, device=local_rank)
+
+    # ---- generate + stage (not timed): cells -> columnar fragment in HBM, in 1 Mb parts ---------------------------------
+    t0 = time.time()
+    gen = synth.Generator(N, B, Lbp)
+    eng.stage_cells_begin()
+    ncells = 0
+    col = B
+    while col < B + need_bp:
+        col = min(B + need_bp, col + 1_000_000)
+        ptr, nbytes, nc = gen.next_chunk(col)
+        eng.stage_cells_append(ptr, nbytes)
+        ncells += nc
+    eng.stage_cells_end()
+    ref = synth.reference(B, need_bp + 4096)
+    eng.set_reference(B, ref)
+    t_stage = time.time() - t0
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    arena = args.arena_mb << 20
+    windows = [(B + (i % (need_bp // W)) * W, B + (i % (need_bp // W)) * W + W - 1) for i in range(total_steps)]
+    for i in range(args.warmup):
+        eng.run_interval(windows[i][0], windows[i][1], arena_bytes=arena, fetch=False)
+    barrier()
+    t1 = time.time()
+    recs = cells_in = bytes_out = bytes_in = 0
+    ms = {"sweep": 0.0, "site": 0.0, "size": 0.0, "write": 0.0}
+    wk_ms = wk_launches = 0.0
+    for i in range(args.warmup, total_steps):
+        _, st = eng.run_interval(windows[i][0], windows[i][1], arena_bytes=arena, fetch=False)
+        recs += st.num_records
+        cells_in += st.num_cells_in_window
+        bytes_out += st.bytes_out
+        ms["sweep"] += st.ms_sweep; ms["site"] += st.ms_site; ms["size"] += st.ms_size; ms["write"] += st.ms_write
+        wk_ms += st.ms_write_kernel_avg * st.write_launches
+        wk_launches += st.write_launches
+    barrier()
+    dt = time.time() - t1
+    # bytes_in: reference binary-cell bytes of the begin-cells consumed (pro rata of the staged total)
+    st_total_cells = max(1, ncells)
+    bytes_in = int(eng_reference_bytes(eng) * (cells_in / st_total_cells))
+
+    if world > 1:
+        t = torch.tensor([dt], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        agg = torch.tensor([recs, cells_in, bytes_out, bytes_in], dtype=torch.float64, device="cuda")
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        recs_all, cells_all, bo_all, bi_all = [float(x) for x in agg.tolist()]
+    else:
+        recs_all, cells_all, bo_all, bi_all = float(recs), float(cells_in), float(bytes_out), float(bytes_in)
+
+    out = None
+    if rank == 0:
+        # roofline of the dominant kernel: algorithmic bytes of one k_entry_write launch / its average duration
+        launches = max(1.0, wk_launches)
+        alg_bytes_per_launch = (bytes_out + bytes_in) / launches
+        avg_ms = wk_ms / launches
+        achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "combined-gVCF positions/sec",
+            "value": recs_all / dt,
+            "unit": "positions/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/int32", "data": "synthetic",
+            "config": {"workload": "c2: %d synthetic-gVCF samples x %d bp (BASELINE.json configs[1]); step = one %d bp column window"
+                       % (N, Lbp, W), "samples": N, "interval_bp": Lbp, "window_bp": W, "output": "VCF text, bit-exact",
+                       "partition_per_gpu": True},
+            "cells_per_sec": cells_all / dt,
+            "bytes_out_per_position": bo_all / max(1.0, recs_all),
+            "bytes_in_per_cell": bi_all / max(1.0, cells_all),
+            "whole_path_GBps": (bo_all + bi_all) / dt / 1e9,
+            "phase_ms": {k: v / args.steps for k, v in ms.items()},
+            "stage_seconds_untimed": t_stage,
+            "roofline": {"bound": "hbm", "kernel": "k_entry_write", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "alg_bytes_per_launch": alg_bytes_per_launch, "avg_launch_ms": avg_ms, "launches": int(launches)},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(N, args.cpu_sample_bp, tmp)
+    if out is not None:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def eng_reference_bytes(eng):
+    """sum of the reference binary-cell sizes of everything staged ("bytes_in")"""
+    return eng.staged_info()[1]
+
+
+def cpu_baseline(N, sample_bp, tmp):
+    """the CPU oracle (single-threaded restatement of the reference algorithm) on a bounded sample of the same workload"""
+    import helpers
+    from genomicsdb_amd import synth
+    B = 10_000_000
+    g = synth.Generator(N, B, sample_bp + 3000)
+    cells, nc = g.chunk_bytes(B + sample_bp + 3000)
+    q = helpers.synth_query(tmp, N, B + 1000, B + 1000 + sample_bp - 1)
+    txt, nrec, secs = helpers.oracle_run_synth(q, cells, synth.SEED, with_header=False)
+    return {"value": nrec / secs, "unit": "positions/s", "cores": 1, "kind": "port",
+            "sample": "%d samples x %d bp window of the same generator; %d records, %.1f s, %d output bytes"
+                      % (N, sample_bp, nrec, secs, len(txt)),
+            "host_cpus": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

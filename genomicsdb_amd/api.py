@@ -96,6 +96,16 @@ class CombineEngine:
         cells = bytes(cells)
         _check(_lib.lib().gdbamd_engine_stage_cells(self._e, cells, len(cells)) == 0, "stage_cells")
 
+    def stage_cells_begin(self):
+        _check(_lib.lib().gdbamd_engine_stage_cells_begin(self._e) == 0, "stage_cells_begin")
+
+    def stage_cells_append(self, ptr, nbytes):
+        """ptr: host address (int / ctypes pointer) of `nbytes` of cells continuing the column-major order"""
+        _check(_lib.lib().gdbamd_engine_stage_cells_append(self._e, ptr, nbytes) == 0, "stage_cells_append")
+
+    def stage_cells_end(self):
+        _check(_lib.lib().gdbamd_engine_stage_cells_end(self._e) == 0, "stage_cells_end")
+
     def adopt_device_fragment(self, ncells, row_ptr, begin_ptr, end_ptr, cols, reference_cell_bytes, keepalive=None):
         """cols: list of (data_ptr, off_ptr_or_0) device addresses, one per plan field."""
         arr = (_lib.DeviceColumn * len(cols))()
@@ -105,6 +115,11 @@ class CombineEngine:
         self._keep = [arr, keepalive]
         _check(_lib.lib().gdbamd_engine_adopt_device_fragment(self._e, ncells, row_ptr, begin_ptr, end_ptr, arr, len(cols), reference_cell_bytes) == 0,
                "adopt_device_fragment")
+
+    def staged_info(self):
+        n, b = ctypes.c_int64(), ctypes.c_uint64()
+        _check(_lib.lib().gdbamd_engine_staged_info(self._e, ctypes.byref(n), ctypes.byref(b)) == 0, "staged_info")
+        return n.value, b.value
 
     def set_reference(self, begin, bases):
         _check(_lib.lib().gdbamd_engine_set_reference(self._e, begin, bases, len(bases)) == 0, "set_reference")

@@ -77,6 +77,11 @@ uint64_t gdbamd_engine_header(void* e, char* dst, uint64_t cap) {
 int gdbamd_engine_stage_cells(void* e, const uint8_t* cells, uint64_t nbytes) {
   return guarded([&]() -> int { ((EngineHandle*)e)->eng->stage_cells(cells, nbytes); return 0; }, 1);
 }
+int gdbamd_engine_stage_cells_begin(void* e) { return guarded([&]() -> int { ((EngineHandle*)e)->eng->stage_cells_begin(); return 0; }, 1); }
+int gdbamd_engine_stage_cells_append(void* e, const uint8_t* cells, uint64_t nbytes) {
+  return guarded([&]() -> int { ((EngineHandle*)e)->eng->stage_cells_append(cells, nbytes); return 0; }, 1);
+}
+int gdbamd_engine_stage_cells_end(void* e) { return guarded([&]() -> int { ((EngineHandle*)e)->eng->stage_cells_end(); return 0; }, 1); }
 int gdbamd_engine_adopt_device_fragment(void* e, int64_t ncells, const int32_t* row, const int64_t* begin, const int64_t* end, const gdbamd_device_column* cols,
                                         int ncols, uint64_t reference_cell_bytes) {
   return guarded([&]() -> int {
@@ -89,8 +94,16 @@ int gdbamd_engine_adopt_device_fragment(void* e, int64_t ncells, const int32_t* 
     eng.pipeline().adopt_fragment(v);
     eng.reference_cell_bytes = reference_cell_bytes;
     eng.has_cells = ncells > 0;
+    eng.num_cells = ncells;
     return 0;
   }, 1);
+}
+int gdbamd_engine_staged_info(void* e, int64_t* ncells, uint64_t* reference_cell_bytes) {
+  if (!e) return 1;
+  CombineEngine& eng = *((EngineHandle*)e)->eng;
+  if (ncells) *ncells = eng.num_cells;
+  if (reference_cell_bytes) *reference_cell_bytes = eng.reference_cell_bytes;
+  return 0;
 }
 int gdbamd_engine_set_reference(void* e, int64_t begin, const char* bases, uint64_t len) {
   return guarded([&]() -> int { ((EngineHandle*)e)->eng->pipeline().set_reference_window(begin, std::string(bases, len)); return 0; }, 1);

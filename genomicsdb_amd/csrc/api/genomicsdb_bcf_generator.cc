@@ -22,9 +22,26 @@ void CombineEngine::stage_cells(const uint8_t* cells, uint64_t nbytes) {
   HostFragment hf = fragment_from_cells(cells, nbytes, m_qc, m_hp);
   reference_cell_bytes = hf.reference_cell_bytes;
   has_cells = hf.ncells() > 0;
+  num_cells = hf.ncells();
   min_begin = INT64_MAX; max_end = 0;
   for (int64_t c = 0; c < hf.ncells(); ++c) { min_begin = std::min(min_begin, hf.begin[(size_t)c]); max_end = std::max(max_end, hf.end[(size_t)c]); }
   m_pipe->stage_fragment(hf);
+}
+
+void CombineEngine::stage_cells_begin() {
+  reference_cell_bytes = 0; num_cells = 0; has_cells = false; min_begin = INT64_MAX; max_end = 0;
+  m_pipe->begin_staging();
+}
+void CombineEngine::stage_cells_append(const uint8_t* cells, uint64_t nbytes) {
+  HostFragment hf = fragment_from_cells(cells, nbytes, m_qc, m_hp);
+  reference_cell_bytes += hf.reference_cell_bytes;
+  num_cells += hf.ncells();
+  for (int64_t c = 0; c < hf.ncells(); ++c) { min_begin = std::min(min_begin, hf.begin[(size_t)c]); max_end = std::max(max_end, hf.end[(size_t)c]); }
+  m_pipe->append_fragment(hf);
+}
+void CombineEngine::stage_cells_end() {
+  has_cells = num_cells > 0;
+  m_pipe->finish_staging();
 }
 
 void CombineEngine::stage_reference_for(int64_t qb, int64_t qe) {

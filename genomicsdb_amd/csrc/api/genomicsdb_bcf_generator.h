@@ -24,6 +24,11 @@ class CombineEngine {
   const HostPlan& plan() const { return m_hp; }
   DevicePipeline& pipeline() { return *m_pipe; }
   void stage_cells(const uint8_t* cells, uint64_t nbytes);
+  // staging in parts: cells of successive calls must continue the column-major order
+  void stage_cells_begin();
+  void stage_cells_append(const uint8_t* cells, uint64_t nbytes);
+  void stage_cells_end();
+  int64_t num_cells = 0;
   void stage_reference_for(int64_t qb, int64_t qe);
   uint64_t reference_cell_bytes = 0;
   int64_t min_begin = 0, max_end = 0;

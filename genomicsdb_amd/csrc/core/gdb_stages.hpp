@@ -23,8 +23,7 @@
 #define GDB_EVENT_SENTINEL 0xFFFFFFFFFFFFFFFFull
 
 // ---- S2: effective END (row-major walk).  perm = cells stably sorted by row ---------------------------------
-GDB_HD void stage_eff_end(const FragmentView& fr, const CellMeta& cm, const int64_t* perm, int64_t j, int64_t qb, int64_t qe,
-                          int64_t* rm_begin, uint32_t* err) {
+GDB_HD void stage_eff_end(const FragmentView& fr, const CellMeta& cm, const int64_t* perm, int64_t j, int64_t* rm_begin, int64_t* span, uint32_t* err) {
   const int64_t C = fr.ncells;
   const int64_t c = perm[j];
   int64_t eff = fr.end[c];
@@ -36,16 +35,19 @@ GDB_HD void stage_eff_end(const FragmentView& fr, const CellMeta& cm, const int6
     }
   }
   cm.eff_end[c] = eff;
-  uint32_t f = cm.cflags[c] & ~GDB_CF_IN_WINDOW;
-  if (fr.begin[c] <= qe && eff >= qb && eff >= fr.begin[c]) f |= GDB_CF_IN_WINDOW;
-  cm.cflags[c] = f;
+  span[c] = eff - fr.begin[c];  // its maximum bounds how far back a query window has to look for live cells
   rm_begin[j] = fr.begin[c];
+}
+GDB_HD bool cell_in_window(const FragmentView& fr, const CellMeta& cm, int64_t c, int64_t qb, int64_t qe) {
+  return fr.begin[c] <= qe && cm.eff_end[c] >= qb && cm.eff_end[c] >= fr.begin[c];
 }
 
 // ---- S3a: two event keys per cell: (position << 2) | (is_end << 1) | is_deletion ---------------------------
-GDB_HD void stage_event_keys(const FragmentView& fr, const CellMeta& cm, int64_t c, int64_t qb, int64_t qe, uint64_t* keys) {
+// (keys are indexed relative to c_base: only the cells that can reach the window take part in an interval)
+GDB_HD void stage_event_keys(const FragmentView& fr, const CellMeta& cm, int64_t c, int64_t c_base, int64_t qb, int64_t qe, uint64_t* keys) {
   const uint32_t f = cm.cflags[c];
-  if (!(f & GDB_CF_IN_WINDOW)) { keys[2 * c] = GDB_EVENT_SENTINEL; keys[2 * c + 1] = GDB_EVENT_SENTINEL; return; }
+  keys += 2 * (c - c_base) - 2 * c;
+  if (!cell_in_window(fr, cm, c, qb, qe)) { keys[2 * c] = GDB_EVENT_SENTINEL; keys[2 * c + 1] = GDB_EVENT_SENTINEL; return; }
   const int64_t b = fr.begin[c] > qb ? fr.begin[c] : qb;
   const int64_t e = cm.eff_end[c] < qe ? cm.eff_end[c] : qe;
   const uint64_t del = (f & GDB_CF_DELETION) ? 1u : 0u;
@@ -102,11 +104,11 @@ GDB_HD int presence_field(const CombinePlan& pl, int i) {  // field whose validi
 }
 struct DiffArrays { int32_t* fmt; int32_t* dp; int32_t* nr; int64_t stride; };  // stride = P + 1
 
-GDB_HD void stage_cell_ranges(const FragmentView& fr, const CombinePlan& pl, const CellMeta& cm, const RecordTable& rec, int64_t c,
+GDB_HD void stage_cell_ranges(const FragmentView& fr, const CombinePlan& pl, const CellMeta& cm, const RecordTable& rec, int64_t c, int64_t c_base,
                               int64_t qb, int64_t qe, const DiffArrays& d, int64_t* heavy_count) {
   const uint32_t f = cm.cflags[c];
-  cm.k_lo[c] = -1; cm.k_hi[c] = -1; heavy_count[c] = 0;
-  if (!(f & GDB_CF_IN_WINDOW) || rec.npos == 0) return;
+  cm.k_lo[c] = -1; cm.k_hi[c] = -1; heavy_count[c - c_base] = 0;
+  if (!cell_in_window(fr, cm, c, qb, qe) || rec.npos == 0) return;
   const int64_t b = fr.begin[c] > qb ? fr.begin[c] : qb;
   const int64_t e = cm.eff_end[c] < qe ? cm.eff_end[c] : qe;
   int64_t lo = 0, hi = rec.npos;
@@ -127,14 +129,14 @@ GDB_HD void stage_cell_ranges(const FragmentView& fr, const CombinePlan& pl, con
   const int32_t dp = cm.dpval[c];
   if (dp) { GDB_ATOMIC_ADD_I32(d.dp + klo, dp); GDB_ATOMIC_ADD_I32(d.dp + khi + 1, -dp); }
   if (f & GDB_CF_HAS_NR) { GDB_ATOMIC_ADD_I32(d.nr + klo, 1); GDB_ATOMIC_ADD_I32(d.nr + khi + 1, -1); }
-  if (f & GDB_CF_HEAVY) heavy_count[c] = khi - klo + 1;
+  if (f & GDB_CF_HEAVY) heavy_count[c - c_base] = khi - klo + 1;
 }
 
 // ---- S6: incidence keys: record * N + row, value = cell ----------------------------------------------------
-GDB_HD void stage_incidence_fill(const FragmentView& fr, const CellMeta& cm, const int64_t* hoff, int64_t c, int64_t nrows,
+GDB_HD void stage_incidence_fill(const FragmentView& fr, const CellMeta& cm, const int64_t* hoff, int64_t c, int64_t c_base, int64_t nrows,
                                  uint64_t* keys, int64_t* vals, uint32_t* lut_len) {
   if (!(cm.cflags[c] & GDB_CF_HEAVY) || cm.k_lo[c] < 0) return;
-  const int64_t base = hoff[c];
+  const int64_t base = hoff[c - c_base];
   const int64_t klo = cm.k_lo[c], khi = cm.k_hi[c];
   for (int64_t k = klo; k <= khi; ++k) {
     keys[base + (k - klo)] = (uint64_t)k * (uint64_t)nrows + (uint64_t)fr.row[c];

@@ -45,6 +45,10 @@ class DevicePipeline {
   DevicePipeline& operator=(const DevicePipeline&) = delete;
   // copy a host fragment to HBM (replaces the previously staged one)
   void stage_fragment(const HostFragment& hf);
+  // staging in parts (column-major order across parts): begin, append host fragments, finish = one contiguous fragment in HBM
+  void begin_staging();
+  void append_fragment(const HostFragment& hf);
+  void finish_staging();
   // adopt a fragment that already lives in HBM (e.g. torch tensors); the caller keeps ownership
   void adopt_fragment(const FragmentView& device_view);
   // reference bases for TileDB columns [begin, begin + bases.size())

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_reduce.hpp>
 #include <rocprim/device/device_scan.hpp>
 
 #include "../core/gdb_stages.hpp"
@@ -73,17 +74,27 @@ __global__ void k_row_ptr(const int32_t* sorted_rows, int64_t C, int32_t N, int6
   while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (sorted_rows[mid] < (int32_t)r) lo = mid + 1; else hi = mid; }
   row_ptr[r] = lo;
 }
-__global__ void k_eff_end(FragmentView fr, CellMeta cm, const int64_t* perm, int64_t qb, int64_t qe, int64_t* rm_begin, uint32_t* err) {
+__global__ void k_eff_end(FragmentView fr, CellMeta cm, const int64_t* perm, int64_t* rm_begin, int64_t* span, uint32_t* err) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= fr.ncells) return;
   uint32_t e = 0;
-  stage_eff_end(fr, cm, perm, j, qb, qe, rm_begin, &e);
+  stage_eff_end(fr, cm, perm, j, rm_begin, span, &e);
   if (e) atomicOr(err, e);
 }
-__global__ void k_event_keys(FragmentView fr, CellMeta cm, int64_t qb, int64_t qe, uint64_t* keys) {
-  int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= fr.ncells) return;
-  stage_event_keys(fr, cm, c, qb, qe, keys);
+// cells that can intersect [qb,qe]: begin in [qb - max_span, qe]  (cells are sorted by begin)
+__global__ void k_cell_window(const int64_t* begin, int64_t C, int64_t lo_pos, int64_t hi_pos, int64_t* out) {
+  if (blockIdx.x || threadIdx.x) return;
+  int64_t lo = 0, hi = C;
+  while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (begin[mid] < lo_pos) lo = mid + 1; else hi = mid; }
+  out[0] = lo;
+  hi = C;
+  while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (begin[mid] <= hi_pos) lo = mid + 1; else hi = mid; }
+  out[1] = lo;
+}
+__global__ void k_event_keys(FragmentView fr, CellMeta cm, int64_t c_base, int64_t n, int64_t qb, int64_t qe, uint64_t* keys) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  stage_event_keys(fr, cm, c_base + i, c_base, qb, qe, keys);
 }
 __global__ void k_event_delta(const uint64_t* keys, int64_t n, int64_t* delta, int32_t* run_end) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -107,16 +118,18 @@ __global__ void k_record_expand(Boundaries b, const int64_t* rbase, int64_t U, i
   if (k >= P) return;
   stage_record_expand(b, rbase, U, k, rstart, rend);
 }
-__global__ void k_cell_ranges(FragmentView fr, CombinePlan pl, CellMeta cm, RecordTable rec, int64_t qb, int64_t qe, DiffArrays d, int64_t* heavy_count, int32_t* in_window_count) {
-  int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= fr.ncells) return;
-  stage_cell_ranges(fr, pl, cm, rec, c, qb, qe, d, heavy_count);
+__global__ void k_cell_ranges(FragmentView fr, CombinePlan pl, CellMeta cm, RecordTable rec, int64_t c_base, int64_t n, int64_t qb, int64_t qe, DiffArrays d,
+                              int64_t* heavy_count, int32_t* in_window_count) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t c = c_base + i;
+  stage_cell_ranges(fr, pl, cm, rec, c, c_base, qb, qe, d, heavy_count);
   if (cm.k_lo[c] >= 0) atomicAdd(in_window_count, 1);
 }
-__global__ void k_incidence_fill(FragmentView fr, CellMeta cm, const int64_t* hoff, int64_t nrows, uint64_t* keys, int64_t* vals) {
-  int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= fr.ncells) return;
-  stage_incidence_fill(fr, cm, hoff, c, nrows, keys, vals, nullptr);
+__global__ void k_incidence_fill(FragmentView fr, CellMeta cm, const int64_t* hoff, int64_t c_base, int64_t n, int64_t nrows, uint64_t* keys, int64_t* vals) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  stage_incidence_fill(fr, cm, hoff, c_base + i, c_base, nrows, keys, vals, nullptr);
 }
 __global__ void k_heavy_base(const uint64_t* sorted_keys, int64_t T, int64_t nrows, int64_t P, int64_t* hbase) {
   int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -259,6 +272,10 @@ k_entry_write(EntryCtx ex, RowIndex ri, SiteOut so, RecordTable rec, int32_t N, 
   if (e) atomicOr(err, e);
 }
 
+__global__ void k_copy_offsets(const uint32_t* src, int64_t n, uint32_t base, uint32_t* dst) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i] + base;
+}
 __global__ void k_gather_record_offsets(const uint64_t* chunk_off, int nchunks, int64_t P, uint64_t* rec_off) {
   int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k > P) return;
@@ -283,7 +300,8 @@ struct DevicePipeline::Impl {
   int64_t ref_begin = 0, ref_len = 0;
   // per-cell
   DevBuf<uint64_t> vmask; DevBuf<uint32_t> cflags; DevBuf<int32_t> dpval, k_lo, k_hi; DevBuf<int64_t> eff_end;
-  DevBuf<int32_t> row_keys, row_keys_sorted; DevBuf<int64_t> cell_ids, perm, rm_begin, row_ptr;
+  DevBuf<int32_t> row_keys, row_keys_sorted; DevBuf<int64_t> cell_ids, perm, rm_begin, row_ptr, span, span_max, cwin;
+  int64_t max_span = 0;
   DevBuf<uint64_t> ev_keys, ev_keys_sorted; DevBuf<int64_t> ev_delta, ev_incl; DevBuf<int32_t> run_end, run_excl;
   DevBuf<int64_t> bpos, bnrec, rbase; DevBuf<int32_t> bcov, bdel;
   DevBuf<int64_t> rstart, rend;
@@ -295,6 +313,9 @@ struct DevicePipeline::Impl {
   DevBuf<char> arena, temp;
   DevBuf<uint32_t> err; DevBuf<int32_t> counters;
   bool classified = false;
+  struct Part { FragmentView v; std::vector<size_t> data_bytes; std::vector<void*> bufs; };
+  std::vector<Part> parts;
+  std::vector<int> col_elem_size; std::vector<bool> col_var; std::vector<int> col_fixed_num;
   struct IntervalState {
     bool active = false;
     int64_t P = 0, kp = 0;
@@ -400,6 +421,85 @@ void DevicePipeline::stage_fragment(const HostFragment& hf) {
   m_->classified = false;
 }
 
+void DevicePipeline::begin_staging() {
+  for (auto& p : m_->parts) for (void* b : p.bufs) (void)hipFree(b);
+  m_->parts.clear();
+}
+
+void DevicePipeline::append_fragment(const HostFragment& hf) {
+  HIP_CHECK(hipSetDevice(m_->device));
+  if (hf.ncells() == 0) return;
+  Impl::Part part;
+  memset(&part.v, 0, sizeof(part.v));
+  part.v.ncells = hf.ncells();
+  auto up = [&](const void* src, size_t bytes) -> void* {
+    void* d = nullptr;
+    HIP_CHECK(hipMalloc(&d, std::max<size_t>(bytes, 16)));
+    part.bufs.push_back(d);
+    if (bytes) HIP_CHECK(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+    return d;
+  };
+  part.v.row = (const int32_t*)up(hf.row.data(), hf.row.size() * 4);
+  part.v.begin = (const int64_t*)up(hf.begin.data(), hf.begin.size() * 8);
+  part.v.end = (const int64_t*)up(hf.end.data(), hf.end.size() * 8);
+  m_->col_elem_size.resize(hf.cols.size()); m_->col_var.resize(hf.cols.size()); m_->col_fixed_num.resize(hf.cols.size());
+  for (size_t f = 0; f < hf.cols.size(); ++f) {
+    part.v.col[f].data = up(hf.cols[f].data.data(), hf.cols[f].data.size());
+    part.v.col[f].off = hf.cols[f].var ? (const uint32_t*)up(hf.cols[f].off.data(), hf.cols[f].off.size() * 4) : nullptr;
+    part.data_bytes.push_back(hf.cols[f].data.size());
+    m_->col_elem_size[f] = hf.cols[f].elem_size; m_->col_var[f] = hf.cols[f].var; m_->col_fixed_num[f] = hf.cols[f].fixed_num;
+  }
+  m_->parts.push_back(part);
+}
+
+void DevicePipeline::finish_staging() {
+  Impl& S = *m_;
+  HIP_CHECK(hipSetDevice(S.device));
+  S.free_owned();
+  FragmentView v;
+  memset(&v, 0, sizeof(v));
+  int64_t C = 0;
+  for (auto& p : S.parts) C += p.v.ncells;
+  v.ncells = C;
+  auto alloc = [&](size_t bytes) -> void* { void* d = nullptr; HIP_CHECK(hipMalloc(&d, std::max<size_t>(bytes, 16))); S.owned.push_back(d); return d; };
+  int32_t* row = (int32_t*)alloc((size_t)C * 4); int64_t* begin = (int64_t*)alloc((size_t)C * 8); int64_t* end = (int64_t*)alloc((size_t)C * 8);
+  int64_t at = 0;
+  for (auto& p : S.parts) {
+    HIP_CHECK(hipMemcpy(row + at, p.v.row, (size_t)p.v.ncells * 4, hipMemcpyDeviceToDevice));
+    HIP_CHECK(hipMemcpy(begin + at, p.v.begin, (size_t)p.v.ncells * 8, hipMemcpyDeviceToDevice));
+    HIP_CHECK(hipMemcpy(end + at, p.v.end, (size_t)p.v.ncells * 8, hipMemcpyDeviceToDevice));
+    at += p.v.ncells;
+  }
+  v.row = row; v.begin = begin; v.end = end;
+  const size_t nf = S.col_elem_size.size();
+  for (size_t f = 0; f < nf; ++f) {
+    size_t total = 0;
+    for (auto& p : S.parts) total += p.data_bytes[f];
+    char* data = (char*)alloc(total);
+    uint32_t* off = S.col_var[f] ? (uint32_t*)alloc((size_t)(C + 1) * 4) : nullptr;
+    size_t byte_at = 0;
+    int64_t cell_at = 0;
+    for (auto& p : S.parts) {
+      if (p.data_bytes[f]) HIP_CHECK(hipMemcpy(data + byte_at, p.v.col[f].data, p.data_bytes[f], hipMemcpyDeviceToDevice));
+      if (off) {
+        const uint64_t base_elems = byte_at / (size_t)S.col_elem_size[f];
+        if (base_elems + p.data_bytes[f] / (size_t)S.col_elem_size[f] >= (1ull << 32)) throw GenomicsDBDeviceException("variable-length column exceeds 2^32 elements: stage a narrower column interval");
+        hipLaunchKernelGGL(k_copy_offsets, dim3(blocks_for(p.v.ncells + 1)), dim3(kBlock), 0, S.stream, p.v.col[f].off, p.v.ncells + 1, (uint32_t)base_elems, off + cell_at);
+      }
+      byte_at += p.data_bytes[f];
+      cell_at += p.v.ncells;
+    }
+    v.col[f].data = data;
+    v.col[f].off = off;
+  }
+  HIP_CHECK(hipStreamSynchronize(S.stream));
+  for (auto& p : S.parts) for (void* b : p.bufs) (void)hipFree(b);
+  S.parts.clear();
+  S.fr = v;
+  S.owns_fragment = true;
+  S.classified = false;
+}
+
 void DevicePipeline::adopt_fragment(const FragmentView& v) {
   m_->free_owned();
   m_->fr = v;
@@ -445,16 +545,31 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
     S.sort_pairs(S.row_keys.p, S.row_keys_sorted.p, S.cell_ids.p, S.perm.p, (size_t)C, std::min(32, bits_for((uint64_t)N)));
     STAGE("k_row_ptr");
     hipLaunchKernelGGL(k_row_ptr, dim3(blocks_for((int64_t)N + 1)), dim3(kBlock), 0, st, S.row_keys_sorted.p, C, N, S.row_ptr.p);
+    // S2 effective END of every cell (next cell of the same sample overrides) + the longest live span
+    S.span.ensure(C); S.span_max.ensure(2);
+    STAGE("k_eff_end");
+    hipLaunchKernelGGL(k_eff_end, dim3(blocks_for(C)), dim3(kBlock), 0, st, fr, cm, S.perm.p, S.rm_begin.p, S.span.p, S.err.p);
+    {
+      size_t bytes = 0;
+      HIP_CHECK(rocprim::reduce(nullptr, bytes, S.span.p, S.span_max.p, (int64_t)0, (size_t)C, rocprim::maximum<int64_t>(), st));
+      void* t = S.temp_storage(bytes);
+      HIP_CHECK(rocprim::reduce(t, bytes, S.span.p, S.span_max.p, (int64_t)0, (size_t)C, rocprim::maximum<int64_t>(), st));
+    }
+    S.max_span = S.read_back(S.span_max.p);
     S.classified = true;
   }
-  // ---- S2 effective END ------------------------------------------------------------------------------------------
-  STAGE("k_eff_end");
-  hipLaunchKernelGGL(k_eff_end, dim3(blocks_for(C)), dim3(kBlock), 0, st, fr, cm, S.perm.p, qb, qe, S.rm_begin.p, S.err.p);
+  // ---- cells that can reach the window -----------------------------------------------------------------------------
+  S.cwin.ensure(2);
+  STAGE("k_cell_window");
+  hipLaunchKernelGGL(k_cell_window, dim3(1), dim3(64), 0, st, fr.begin, C, qb > INT64_MIN + S.max_span ? qb - S.max_span : INT64_MIN, qe, S.cwin.p);
+  const int64_t c_base = S.read_back(S.cwin.p), c_end = S.read_back(S.cwin.p + 1);
+  const int64_t CW = c_end - c_base;
+  if (CW <= 0) return;
   // ---- S3 events -> boundaries -> records --------------------------------------------------------------------------
-  const int64_t NE = 2 * C;
+  const int64_t NE = 2 * CW;
   S.ev_keys.ensure(NE); S.ev_keys_sorted.ensure(NE); S.ev_delta.ensure(NE); S.ev_incl.ensure(NE); S.run_end.ensure(NE); S.run_excl.ensure(NE + 1);
   STAGE("k_event_keys");
-  hipLaunchKernelGGL(k_event_keys, dim3(blocks_for(C)), dim3(kBlock), 0, st, fr, cm, qb, qe, S.ev_keys.p);
+  hipLaunchKernelGGL(k_event_keys, dim3(blocks_for(CW)), dim3(kBlock), 0, st, fr, cm, c_base, CW, qb, qe, S.ev_keys.p);
   {
     const uint64_t span = (uint64_t)(qe - qb) + 2u;
     const int eb = span >= (1ull << 60) ? 64 : bits_for(span << 2);
@@ -500,12 +615,12 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   int32_t* d_dp = S.diff.p + (size_t)nf * stride;
   int32_t* d_nr = d_dp + stride;
   DiffArrays da{d_fmt, d_dp, d_nr, stride};
-  S.heavy_count.ensure(C + 1); S.hoff.ensure(C + 2);
+  S.heavy_count.ensure(CW + 1); S.hoff.ensure(CW + 2);
   STAGE("k_cell_ranges");
-  hipLaunchKernelGGL(k_cell_ranges, dim3(blocks_for(C)), dim3(kBlock), 0, st, fr, pl, cm, rec, qb, qe, da, S.heavy_count.p, S.counters.p);
+  hipLaunchKernelGGL(k_cell_ranges, dim3(blocks_for(CW)), dim3(kBlock), 0, st, fr, pl, cm, rec, c_base, CW, qb, qe, da, S.heavy_count.p, S.counters.p);
   for (int i = 0; i < nf + 2; ++i) S.incl_scan(S.diff.p + (size_t)i * stride, S.diff.p + (size_t)i * stride, (size_t)stride, rocprim::plus<int32_t>());
-  S.excl_scan(S.heavy_count.p, S.hoff.p, (size_t)C);
-  const int64_t T = S.read_back(S.hoff.p + (C - 1)) + S.read_back(S.heavy_count.p + (C - 1));
+  S.excl_scan(S.heavy_count.p, S.hoff.p, (size_t)CW);
+  const int64_t T = S.read_back(S.hoff.p + (CW - 1)) + S.read_back(S.heavy_count.p + (CW - 1));
   stats.num_heavy_incidences = T;
   stats.num_cells_in_window = S.read_back(S.counters.p);
   // ---- S6 incidences sorted by (record,row) --------------------------------------------------------------------------
@@ -514,7 +629,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   uint32_t lut_total = 0;
   if (T > 0) {
     STAGE("k_incidence_fill");
-    hipLaunchKernelGGL(k_incidence_fill, dim3(blocks_for(C)), dim3(kBlock), 0, st, fr, cm, S.hoff.p, (int64_t)N, S.inc_keys.p, S.inc_vals.p);
+    hipLaunchKernelGGL(k_incidence_fill, dim3(blocks_for(CW)), dim3(kBlock), 0, st, fr, cm, S.hoff.p, c_base, CW, (int64_t)N, S.inc_keys.p, S.inc_vals.p);
     S.sort_pairs(S.inc_keys.p, S.inc_keys_sorted.p, S.inc_vals.p, S.inc_vals_sorted.p, (size_t)T, bits_for((uint64_t)P * (uint64_t)N));
     STAGE("k_lut_len");
     hipLaunchKernelGGL(k_lut_len, dim3(blocks_for(T)), dim3(kBlock), 0, st, S.inc_vals_sorted.p, S.cflags.p, T, S.lut_len.p);

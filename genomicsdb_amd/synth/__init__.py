@@ -1,0 +1,75 @@
+"""Synthetic gVCF input for bench.py and the parity tests: builds libgdbsynth.so (g++) on demand."""
+import ctypes
+import json
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libgdbsynth.so")
+SEED = 20260928
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        src = os.path.join(HERE, "gvcf_synth.cc")
+        if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", LIB, src])
+        L = ctypes.CDLL(LIB)
+        L.gdbsynth_create.restype = ctypes.c_void_p
+        L.gdbsynth_create.argtypes = [ctypes.c_uint64, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64]
+        L.gdbsynth_destroy.argtypes = [ctypes.c_void_p]
+        L.gdbsynth_next_chunk.restype = ctypes.c_int64
+        L.gdbsynth_next_chunk.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64)]
+        L.gdbsynth_reference.argtypes = [ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64, ctypes.c_char_p]
+        _lib = L
+    return _lib
+
+
+class Generator:
+    """cells of N samples over [B, B+L), handed out in column chunks (column-major order inside and across chunks)"""
+
+    def __init__(self, n_samples, B, L, seed=SEED):
+        self.n_samples, self.B, self.L, self.seed = n_samples, B, L, seed
+        self._h = lib().gdbsynth_create(seed, n_samples, B, L)
+
+    def next_chunk(self, col_end, nthreads=None):
+        """returns (host address, nbytes, ncells) valid until the next call"""
+        p = ctypes.c_void_p()
+        n = ctypes.c_uint64()
+        nc = lib().gdbsynth_next_chunk(self._h, col_end, nthreads or min(16, os.cpu_count() or 1), ctypes.byref(p), ctypes.byref(n))
+        return p.value, n.value, nc
+
+    def chunk_bytes(self, col_end, nthreads=None):
+        p, n, nc = self.next_chunk(col_end, nthreads)
+        return ctypes.string_at(p, n), nc
+
+    def close(self):
+        if self._h:
+            lib().gdbsynth_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def reference(begin, length, seed=SEED):
+    buf = ctypes.create_string_buffer(length)
+    lib().gdbsynth_reference(seed, begin, length, buf)
+    return buf.raw[:length]
+
+
+def write_metadata(dirname, n_samples, vid_template_path):
+    """vid mapping (schema of the reference's tests/inputs/vid.json, contig '1' only) + callsets S%06d; returns the paths"""
+    vid = json.load(open(vid_template_path))
+    vid["contigs"] = {"1": {"length": 249250621, "tiledb_column_offset": 0}}
+    cs = {"callsets": {"S%06d" % i: {"row_idx": i, "idx_in_file": 0, "filename": "synthetic"} for i in range(n_samples)}}
+    vp = os.path.join(dirname, "vid_synth.json")
+    cp = os.path.join(dirname, "callsets_synth_%d.json" % n_samples)
+    json.dump(vid, open(vp, "w"))
+    json.dump(cs, open(cp, "w"))
+    return vp, cp

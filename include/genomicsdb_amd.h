@@ -61,9 +61,15 @@ int gdbamd_engine_field_info(void* engine, int f, int* elem_type, int* is_var, i
 uint64_t gdbamd_engine_header(void* engine, char* dst, uint64_t cap);           /* VCF header text; returns its length */
 /* stage begin-cells given in the reference binary-cell layout (host memory, column-major order) */
 int gdbamd_engine_stage_cells(void* engine, const uint8_t* cells, uint64_t nbytes);
+/* the same in parts (successive calls continue the column-major order); _end() makes one contiguous fragment in HBM */
+int gdbamd_engine_stage_cells_begin(void* engine);
+int gdbamd_engine_stage_cells_append(void* engine, const uint8_t* cells, uint64_t nbytes);
+int gdbamd_engine_stage_cells_end(void* engine);
 /* adopt a columnar fragment that already lives in HBM: row = QUERY row idx, begin/end = columns, cols[num_fields] */
 int gdbamd_engine_adopt_device_fragment(void* engine, int64_t ncells, const int32_t* row, const int64_t* begin, const int64_t* end,
                                         const gdbamd_device_column* cols, int ncols, uint64_t reference_cell_bytes);
+/* what is staged: #begin-cells and the sum of their reference binary-cell sizes ("bytes_in" of the byte accounting) */
+int gdbamd_engine_staged_info(void* engine, int64_t* ncells, uint64_t* reference_cell_bytes);
 /* reference bases for TileDB columns [begin, begin+len) (host pointer) */
 int gdbamd_engine_set_reference(void* engine, int64_t begin, const char* bases, uint64_t len);
 /* scan + combine one column interval.  The VCF body is produced page by page in HBM (arena_bytes per page); when

@@ -83,6 +83,36 @@ int oracle_run_query(const char* query_json_text, const uint8_t* cells, uint64_t
   }
 }
 
+// Same query, but REF bases of "nobody starts here" records come from the synthetic reference of the bench generator
+// (genomicsdb_amd/synth/gvcf_synth.cc: base(pos) = "ACGT"[hash2(seed ^ 0x5bd1e9955bd1e995, pos) & 3]; single contig at offset 0).
+static inline uint64_t synth_splitmix64(uint64_t& s) {
+  uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+int oracle_run_query_synthetic_reference(const char* query_json_text, const uint8_t* cells, uint64_t nbytes, uint64_t seed, uint64_t buffer_limit, int with_header,
+                                         char** out, uint64_t* out_len, uint64_t* num_records, double* scan_seconds, char* err, uint64_t errlen) {
+  try {
+    ReferenceGenome ref;
+    ref.custom = [seed](const std::string&, int64_t pos) -> char {
+      uint64_t s = (seed ^ 0x5bd1e9955bd1e995ull) ^ ((uint64_t)pos * 0xD6E8FEB86659FD93ull);
+      return "ACGT"[synth_splitmix64(s) & 3];
+    };
+    RunResult rr = run_query(query_json_text, cells, nbytes, 0, INT64_MAX - 1, buffer_limit, with_header != 0, &ref);
+    *out = (char*)malloc(rr.text.size() + 1);
+    memcpy(*out, rr.text.data(), rr.text.size());
+    (*out)[rr.text.size()] = 0;
+    *out_len = rr.text.size();
+    if (num_records) *num_records = rr.num_records;
+    if (scan_seconds) *scan_seconds = rr.scan_seconds;
+    return 0;
+  } catch (const std::exception& e) {
+    if (err && errlen) snprintf(err, errlen, "%s", e.what());
+    return 1;
+  }
+}
+
 void oracle_free(char* p) { free(p); }
 
 // format_float exposed for the float-format unit tests

@@ -123,3 +123,36 @@ def hostsim_run(query, cells, with_header=True, rows_per_chunk=2, records_per_ru
     txt = ctypes.string_at(out.value, n.value)
     lib.hostsim_free(out)
     return txt, errbits.value
+
+
+def oracle_run_synth(query, cells, seed, buffer_limit=0, with_header=True):
+    lib = oracle_lib()
+    fn = lib.oracle_run_query_synthetic_reference
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int,
+                   ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
+                   ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_uint64]
+    out = ctypes.c_void_p()
+    n = ctypes.c_uint64()
+    nrec = ctypes.c_uint64()
+    secs = ctypes.c_double()
+    err = ctypes.create_string_buffer(4096)
+    rc = fn(json.dumps(query).encode(), cells, len(cells), seed, buffer_limit, 1 if with_header else 0, ctypes.byref(out),
+            ctypes.byref(n), ctypes.byref(nrec), ctypes.byref(secs), err, 4096)
+    if rc != 0:
+        raise RuntimeError("oracle: " + err.value.decode())
+    txt = ctypes.string_at(out.value, n.value)
+    lib.oracle_free(out)
+    return txt, nrec.value, secs.value
+
+
+def synth_query(tmpdir, n_samples, begin, end):
+    """query JSON for the synthetic workload (vcf_attributes_order, vid.json schema, one contig)"""
+    from genomicsdb_amd import synth
+    vp, cp = synth.write_metadata(str(tmpdir), n_samples, os.path.join(GOLDEN, "inputs", "vid.json"))
+    return {
+        "vid_mapping_file": vp, "callset_mapping_file": cp,
+        "vcf_header_filename": os.path.join(GOLDEN, "inputs", "template_vcf_header.vcf"),
+        "attributes": VCF_ATTRIBUTES_ORDER,
+        "query_column_ranges": [[[begin, end]]],
+    }

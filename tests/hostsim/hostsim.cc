@@ -52,11 +52,12 @@ std::string run_interval(const HostPlan& hp, const HostFragment& hf, const VidMa
   for (int64_t c = 0; c < C; ++c) row_ptr[fr.row[c] + 1]++;
   for (int64_t r = 0; r < N; ++r) row_ptr[r + 1] += row_ptr[r];
   // S2 effective END
-  for (int64_t j = 0; j < C; ++j) stage_eff_end(fr, cm, perm.data(), j, qb, qe, rm_begin.data(), &err);
+  std::vector<int64_t> span(C);
+  for (int64_t j = 0; j < C; ++j) stage_eff_end(fr, cm, perm.data(), j, rm_begin.data(), span.data(), &err);
   // clip the window to what the cells can reach (keeps relative positions small)
   // S3 events
   std::vector<uint64_t> keys(2 * C);
-  for (int64_t c = 0; c < C; ++c) stage_event_keys(fr, cm, c, qb, qe, keys.data());
+  for (int64_t c = 0; c < C; ++c) stage_event_keys(fr, cm, c, 0, qb, qe, keys.data());
   std::sort(keys.begin(), keys.end());
   const int64_t NE = 2 * C;
   std::vector<int64_t> incl(NE);
@@ -79,7 +80,7 @@ std::string run_interval(const HostPlan& hp, const HostFragment& hf, const VidMa
   std::vector<int32_t> dfmt((size_t)std::max(nf, 1) * (P + 1), 0), ddp(P + 1, 0), dnr(P + 1, 0);
   DiffArrays da{dfmt.data(), ddp.data(), dnr.data(), P + 1};
   std::vector<int64_t> heavy_count(C), hoff(C + 1, 0);
-  for (int64_t c = 0; c < C; ++c) stage_cell_ranges(fr, pl, cm, rec, c, qb, qe, da, heavy_count.data());
+  for (int64_t c = 0; c < C; ++c) stage_cell_ranges(fr, pl, cm, rec, c, 0, qb, qe, da, heavy_count.data());
   // S5 scans
   for (int i = 0; i < nf; ++i) { int32_t a = 0; for (int64_t k = 0; k <= P; ++k) { a += dfmt[(size_t)i * (P + 1) + k]; dfmt[(size_t)i * (P + 1) + k] = a; } }
   { int32_t a = 0, b = 0; for (int64_t k = 0; k <= P; ++k) { a += ddp[k]; ddp[k] = a; b += dnr[k]; dnr[k] = b; } }
@@ -87,7 +88,7 @@ std::string run_interval(const HostPlan& hp, const HostFragment& hf, const VidMa
   const int64_t T = hoff[C];
   // S6 incidences
   std::vector<uint64_t> ikeys(T); std::vector<int64_t> ivals(T);
-  for (int64_t c = 0; c < C; ++c) stage_incidence_fill(fr, cm, hoff.data(), c, N, ikeys.data(), ivals.data(), nullptr);
+  for (int64_t c = 0; c < C; ++c) stage_incidence_fill(fr, cm, hoff.data(), c, 0, N, ikeys.data(), ivals.data(), nullptr);
   {
     std::vector<int64_t> order(T);
     std::iota(order.begin(), order.end(), 0);

@@ -72,3 +72,50 @@ def test_engine_stats_and_header(gdb):
     assert st.num_records == 4 and st.num_cells == 5 and st.bytes_out == len(body)
     assert st.bytes_in_reference_cells == len(cells)
     e.close()
+
+
+def test_synthetic_matches_oracle(gdb, tmp_path):
+    """generator of SURVEY 8(d): 300 samples x 6 kb (SNVs, insertions, deletions with per-bp stepping), staged in two parts"""
+    from genomicsdb_amd import synth
+    N, B, L = 300, 10_000_000, 6000
+    g = synth.Generator(N, B, L)
+    c1, _ = g.chunk_bytes(B + 2500)
+    c2, _ = g.chunk_bytes(B + L)
+    q = helpers.synth_query(tmp_path, N, B + 700, B + L - 900)
+    want, nrec, _ = helpers.oracle_run_synth(q, c1 + c2, synth.SEED, with_header=False)
+    e = gdb.CombineEngine(q)
+    e.stage_cells_begin()
+    import ctypes
+    for part in (c1, c2):
+        buf = ctypes.create_string_buffer(part, len(part))
+        e.stage_cells_append(ctypes.addressof(buf), len(part))
+    e.stage_cells_end()
+    e.set_reference(B, synth.reference(B, L + 16))
+    body, st = e.run_interval(B + 700, B + L - 900, arena_bytes=1 << 20)   # many pages
+    assert st.num_records == nrec and st.pages > 5
+    assert body == want
+    body2, st2 = e.run_interval(B + 700, B + L - 900, arena_bytes=1 << 30)  # one page
+    assert st2.pages == 1 and body2 == want
+    e.close()
+
+
+def test_synthetic_window_split_equals_whole(gdb, tmp_path):
+    """size-independent property: the records of two adjacent windows = the records of their union, except that an
+    interval crossing the cut is split there (END of the first part = cut, same rule as the reference's partitions)"""
+    from genomicsdb_amd import synth
+    N, B, L = 500, 10_000_000, 30_000
+    g = synth.Generator(N, B, L)
+    cells, _ = g.chunk_bytes(B + L)
+    q = helpers.synth_query(tmp_path, N, B, B + L - 1)
+    e = gdb.CombineEngine(q)
+    e.stage_cells(cells)
+    e.set_reference(B, synth.reference(B, L + 16))
+    whole, sw = e.run_interval(B + 1000, B + 20_999, arena_bytes=1 << 28)
+    a, sa = e.run_interval(B + 1000, B + 10_999, arena_bytes=1 << 28)
+    b, sb = e.run_interval(B + 11_000, B + 20_999, arena_bytes=1 << 28)
+    assert sa.num_records + sb.num_records in (sw.num_records, sw.num_records + 1)
+    pos_whole = [l.split(b"\t", 2)[1] for l in whole.splitlines()]
+    pos_split = [l.split(b"\t", 2)[1] for l in (a + b).splitlines()]
+    assert set(pos_whole) <= set(pos_split) and len(pos_split) - len(pos_whole) <= 1
+    assert pos_split == sorted(pos_split, key=int)
+    e.close()

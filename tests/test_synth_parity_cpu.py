@@ -1,0 +1,42 @@
+"""Synthetic workload (SURVEY 8(d) generator): CPU-side checks - the generator is deterministic, and the kernel bodies
+(hostsim) agree with the oracle on it byte for byte."""
+import helpers
+
+
+def test_generator_deterministic_and_chunk_invariant():
+    from genomicsdb_amd import synth
+    g1 = synth.Generator(20, 10_000_000, 6000)
+    a, na = g1.chunk_bytes(10_006_000)
+    g2 = synth.Generator(20, 10_000_000, 6000)
+    b1, n1 = g2.chunk_bytes(10_002_000)
+    b2, n2 = g2.chunk_bytes(10_006_000)
+    assert na == n1 + n2 and na > 20
+    assert sorted_cells(a) == sorted_cells(b1 + b2)
+    assert len(a) >= 150 * na
+
+
+def sorted_cells(buf):
+    import struct
+    out, off = [], 0
+    while off < len(buf):
+        sz = struct.unpack_from("<Q", buf, off + 16)[0]
+        out.append(buf[off:off + sz])
+        off += sz
+    return sorted(out)
+
+
+def test_hostsim_matches_oracle_on_synthetic(tmp_path):
+    from genomicsdb_amd import synth
+    N, B, L = 37, 10_000_000, 4000
+    g = synth.Generator(N, B, L)
+    cells, nc = g.chunk_bytes(B + L)
+    q = helpers.synth_query(tmp_path, N, B + 100, B + L - 300)
+    want, nrec, _ = helpers.oracle_run_synth(q, cells, synth.SEED)
+    assert nrec > 500
+    # hostsim has no synthetic-reference hook: compare on a query whose records all start at a cell begin is not
+    # possible in general, so give both the same FASTA-less setup and mask REF of 'N' records via the oracle without seed
+    want_n, _, _ = helpers.oracle_run(q, cells)
+    got, errbits = helpers.hostsim_run(q, cells, rows_per_chunk=16, records_per_run=7)
+    assert errbits == 0
+    assert got == want_n
+    assert want != want_n  # the synthetic reference does change REF of mid-block records
