@@ -99,6 +99,16 @@ struct ByteSink {
   GDB_HD void write(const char* s, int len) { for (int i = 0; i < len; ++i) *p++ = s[i]; }
 };
 
+#if defined(__HIPCC__)
+typedef __attribute__((address_space(3))) char gdb_lds_char;
+struct LdsSink {  // same as ByteSink but the cursor is an LDS (address space 3) pointer: ds_write_b8 instead of flat stores
+  gdb_lds_char* p;
+  __device__ __forceinline__ explicit LdsSink(gdb_lds_char* q) : p(q) {}
+  __device__ __forceinline__ void put(char c) { *p++ = c; }
+  __device__ __forceinline__ void write(const char* s, int len) { for (int i = 0; i < len; ++i) *p++ = s[i]; }
+};
+#endif
+
 // ---- small helpers -----------------------------------------------------------------------------------
 GDB_HD uint32_t gdb_f2u(float f) { union { float f; uint32_t u; } x; x.f = f; return x.u; }
 GDB_HD bool gdb_int_valid(int32_t v) { return v != GDB_BCF_INT32_MISSING && v != GDB_BCF_INT32_VECTOR_END; }
@@ -114,7 +124,18 @@ template <class Sink> GDB_HD void put_u64(Sink& s, uint64_t v) {
 template <class Sink> GDB_HD void put_i64(Sink& s, int64_t v) {
   if (v < 0) { s.put('-'); put_u64(s, (uint64_t)(-(v + 1)) + 1u); } else put_u64(s, (uint64_t)v);
 }
-template <class Sink> GDB_HD void put_i32(Sink& s, int32_t v) { put_i64(s, (int64_t)v); }
+// 32-bit only (no 64-bit division on the hot path): every FORMAT integer goes through here
+template <class Sink> GDB_HD void put_u32(Sink& s, uint32_t v) {
+  if (v < 10u) { s.put((char)('0' + v)); return; }
+  if (v < 100u) { const uint32_t q = v / 10u; s.put((char)('0' + q)); s.put((char)('0' + (v - q * 10u))); return; }
+  char buf[10];
+  int n = 0;
+  do { const uint32_t q = v / 10u; buf[n++] = (char)('0' + (v - q * 10u)); v = q; } while (v);
+  while (n) s.put(buf[--n]);
+}
+template <class Sink> GDB_HD void put_i32(Sink& s, int32_t v) {
+  if (v < 0) { s.put('-'); put_u32(s, 0u - (uint32_t)v); } else put_u32(s, (uint32_t)v);
+}
 
 // Float text as the goldens pin it (htslib-fork kputd flavour, see oracle/gdb_oracle_combine.hpp format_float).
 // Returns false when the value is outside the range this path reproduces exactly.
@@ -642,13 +663,18 @@ struct EntryMaps {
   uint32_t cf;                         // cell flags
   uint8_t iflag;
   bool remap, nr_exists;
+  bool light;                          // plain reference block (REF,<NON_REF>): REF -> 0, every other merged allele <- <NON_REF>
+  // input allele feeding merged allele j, with the <NON_REF> fallback of the reference's remap loops; -1 = missing
+  GDB_HD int lookup(int j) const {
+    if (light) return j == 0 ? 0 : nr_in;
+    const int v = m2i[j];
+    return v >= 0 ? v : nr_in;
+  }
 };
 
-#if defined(__HIPCC__)
-#define GDB_FIELD_FN __host__ __device__ __noinline__
-#else
-#define GDB_FIELD_FN inline
-#endif
+// The field emitters inline into the two out-of-line wrappers of the kernels file (entry_length / entry_store*), which
+// read the EntryCtx from __constant__ memory: every plan / column-pointer access is then a scalar (SGPR) load.
+#define GDB_FIELD_FN GDB_HD
 
 // Each field kind has its own out-of-line emitter taking and returning the sink BY VALUE: keeps every function small
 // and the cursor in registers (a char store through a by-reference sink may alias the sink itself).
@@ -716,8 +742,7 @@ template <class Sink> GDB_FIELD_FN Sink emit_remap_alleles(Sink s, const int32_t
   for (int j = 0; j < length; ++j) {
     if (j) s.put(',');
     const int aj = alt_only ? j + 1 : j;
-    int in_j = em.m2i[aj];
-    if (in_j < 0) in_j = em.nr_in;
+    const int in_j = em.lookup(aj);
     const int idx = alt_only ? in_j - 1 : in_j;
     const bool has = in_j >= 0 && idx >= 0 && idx < n;
     const int32_t v = has ? p[idx] : GDB_BCF_INT32_MISSING;
@@ -731,8 +756,7 @@ template <class Sink> GDB_FIELD_FN Sink emit_remap_genotypes(Sink s, const int32
   if (ploidy == 1) {
     for (int j = 0; j < num_merged; ++j) {
       if (j) s.put(',');
-      int in_j = em.m2i[j];
-      if (in_j < 0) in_j = em.nr_in;
+      const int in_j = em.lookup(j);
       const bool has = in_j >= 0 && in_j < n;
       const int32_t v = has ? p[in_j] : GDB_BCF_INT32_MISSING;
       if (v == GDB_BCF_INT32_MISSING) s.put('.'); else put_i32(s, v);
@@ -740,12 +764,10 @@ template <class Sink> GDB_FIELD_FN Sink emit_remap_genotypes(Sink s, const int32
   } else if (ploidy == 2) {
     // output order gt = k(k+1)/2 + j, j <= k
     for (int kk = 0; kk < num_merged; ++kk) {
-      int in_k = em.m2i[kk];
-      if (in_k < 0) in_k = em.nr_in;
+      const int in_k = em.lookup(kk);
       for (int j = 0; j <= kk; ++j) {
         if (kk | j) s.put(',');
-        int in_j = em.m2i[j];
-        if (in_j < 0) in_j = em.nr_in;
+        const int in_j = em.lookup(j);
         const bool both = in_j >= 0 && in_k >= 0;
         const int gi = both ? gdb_alleles2gt(in_j, in_k) : 0;
         const bool has = both && gi < n;
@@ -763,11 +785,12 @@ template <class Sink> GDB_FIELD_FN Sink emit_remap_genotypes(Sink s, const int32
 GDB_FIELD_FN void build_entry_maps(const EntryCtx& cx, const RecordInfo& ri, int64_t c, EntryMaps& em, uint32_t* err) {
   em.remap = (ri.rflags & GDB_RF_REMAPPING_NEEDED) != 0;
   em.nr_exists = (ri.rflags & GDB_RF_NON_REF_EXISTS) != 0;
-  em.nr_in = -1; em.i2m = nullptr; em.n_in = 0; em.iflag = 0; em.inc = -1; em.cf = 0;
+  em.nr_in = -1; em.i2m = nullptr; em.n_in = 0; em.iflag = 0; em.inc = -1; em.cf = 0; em.light = false;
   if (c < 0) return;
   em.cf = cx.cm.cflags[c];
   em.n_in = (int)GDB_CF_NALT(em.cf) + 1;
   if (!em.remap) return;
+  if (!(em.cf & GDB_CF_HEAVY)) { em.light = true; em.nr_in = em.nr_exists ? 1 : -1; return; }
   for (int j = 0; j < ri.num_merged; ++j) em.m2i[j] = -1;
   if (em.cf & GDB_CF_HEAVY) {
     const int32_t row = cx.fr.row[c];
@@ -780,9 +803,6 @@ GDB_FIELD_FN void build_entry_maps(const EntryCtx& cx, const RecordInfo& ri, int
     em.iflag = cx.hl.iflags[em.inc];
     for (int a = 0; a < em.n_in; ++a) { const int8_t t = em.i2m[a]; if (t >= 0) em.m2i[t] = (int8_t)a; }
     if (em.nr_exists && (em.cf & GDB_CF_HAS_NR) && em.m2i[ri.num_merged - 1] >= 0) em.nr_in = em.m2i[ri.num_merged - 1];
-  } else {  // plain reference block: REF -> 0, <NON_REF> -> last
-    em.m2i[0] = 0;
-    if (em.nr_exists) { em.m2i[ri.num_merged - 1] = 1; em.nr_in = 1; }
   }
 }
 

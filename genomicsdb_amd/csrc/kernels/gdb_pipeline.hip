@@ -50,6 +50,12 @@ template <class T> struct DevBuf {   // grow-only device allocation
 
 inline bool debug_sync() { static int v = -1; if (v < 0) { const char* e = getenv("GDBAMD_DEBUG_SYNC"); v = (e && *e && *e != '0') ? 1 : 0; } return v == 1; }
 #define STAGE(name) do { if (debug_sync()) { HIP_CHECK(hipStreamSynchronize(st)); fprintf(stderr, "[gdbamd] stage %s\n", name); fflush(stderr); } } while (0)
+// records one workgroup walks: long runs amortise the per-lane cell cache, but keep >= ~8 workgroups per CU in flight
+inline int run_length(int64_t nrec, int nchunks) {
+  int64_t run = 256;
+  while (run > kRun && (nrec / run) * nchunks < 2048) run >>= 1;
+  return (int)run;
+}
 inline unsigned blocks_for(int64_t n, int b = kBlock) { return (unsigned)std::max<int64_t>(1, (n + b - 1) / b); }
 inline int bits_for(uint64_t max_value) { int b = 1; while (b < 64 && (max_value >> b)) ++b; return std::min(64, b + 1); }
 
@@ -143,7 +149,8 @@ __global__ void k_lut_len(const int64_t* inc_cell, const uint32_t* cflags, int64
 }
 
 // ---- site kernels: one thread per record -----------------------------------------------------------------------
-__global__ void k_site_size(SiteCtx sx, uint32_t* err) {
+__global__ void k_site_size(const SiteCtx* __restrict__ sxp, uint32_t* err) {
+  const SiteCtx& sx = *sxp;
   int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= sx.rec.npos) return;
   uint32_t e = 0;
@@ -152,7 +159,8 @@ __global__ void k_site_size(SiteCtx sx, uint32_t* err) {
   sx.so.prefix_len[k] = (uint32_t)cs.n;
   if (e) atomicOr(err, e);
 }
-__global__ void k_site_write(SiteCtx sx, int64_t k_begin, int64_t k_end, const uint64_t* chunk_off, int nchunks, uint64_t page_base, char* arena, uint32_t* err) {
+__global__ void k_site_write(const SiteCtx* __restrict__ sxp, int64_t k_begin, int64_t k_end, const uint64_t* chunk_off, int nchunks, uint64_t page_base, char* arena, uint32_t* err) {
+  const SiteCtx& sx = *sxp;
   int64_t k = k_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= k_end) return;
   uint32_t e = 0;
@@ -172,102 +180,228 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
   return v;
 }
 
-// the two instantiations are kept out of line: one copy each instead of one per call site
-__device__ __noinline__ uint32_t entry_length(const EntryCtx& ex, const RecordInfo& ri, int64_t c, uint32_t* e) {
-  return (uint32_t)entry_emit(ex, ri, c, CountSink(), e).n;
+// Per-interval context in constant memory: plan, column pointers, per-cell metadata pointers.  Uniform accesses to it are
+// scalar loads through the scalar cache (a by-reference argument would turn each of them into a vector memory instruction).
+__constant__ EntryCtx c_ex;
+
+// the instantiations are kept out of line: one copy each instead of one per call site
+__device__ __noinline__ uint32_t entry_length(RecordInfo ri, int64_t c, uint32_t* e) {
+  return (uint32_t)entry_emit(c_ex, ri, c, CountSink(), e).n;
 }
-__device__ __noinline__ void entry_store(const EntryCtx& ex, const RecordInfo& ri, int64_t c, char* dst, uint32_t* e) {
-  (void)entry_emit(ex, ri, c, ByteSink(dst), e);
+__device__ __noinline__ void entry_store(RecordInfo ri, int64_t c, char* dst, uint32_t* e) {
+  (void)entry_emit(c_ex, ri, c, ByteSink(dst), e);
+}
+__device__ __noinline__ void entry_store_lds(RecordInfo ri, int64_t c, gdb_lds_char* dst, uint32_t* e) {
+  (void)entry_emit(c_ex, ri, c, LdsSink(dst), e);
 }
 
+// ---- per-lane entry cache -------------------------------------------------------------------------------------------
+// A lane walks consecutive records of one sample; its live cell changes every ~100 bp while records are ~1 bp apart, and
+// the text of a plain reference-block call depends only on (cell, record type) with type = (FORMAT mask, remap flags,
+// #merged alleles).  So each lane keeps the last kSlots (type -> length [, text in LDS]) results of its current cell and
+// re-runs the field emitters only on a miss.  Calls that take part in the allele merge ("heavy") are never cached.
+constexpr int kSlots = 3;
+constexpr int kSlotBytes = 64;
+
+struct LaneLenCache {
+  int64_t cell;
+  uint64_t key[kSlots];
+  uint32_t len[kSlots];
+  int next;
+  __device__ __forceinline__ void reset(int64_t c) { cell = c; next = 0;
+#pragma unroll
+    for (int t = 0; t < kSlots; ++t) key[t] = ~0ull; }
+  __device__ __forceinline__ int find(uint64_t k) const {
+    int hit = -1;
+#pragma unroll
+    for (int t = 0; t < kSlots; ++t) if (key[t] == k) hit = t;
+    return hit;
+  }
+  // victim = round-robin slot not in `busy` (slots whose text is still waiting to be copied out); -1 if all are busy
+  __device__ __forceinline__ int insert(uint64_t k, uint32_t l, uint32_t busy = 0u) {
+    int t = -1;
+#pragma unroll
+    for (int u = 0; u < kSlots; ++u) { const int cand = (next + u) % kSlots; if (t < 0 && !((busy >> cand) & 1u)) t = cand; }
+    if (t < 0) return -1;
+    next = (t + 1 == kSlots) ? 0 : t + 1;
+#pragma unroll
+    for (int u = 0; u < kSlots; ++u) if (u == t) { key[u] = k; len[u] = l; }
+    return t;
+  }
+  __device__ __forceinline__ uint32_t length(int t) const {
+    uint32_t l = 0;
+#pragma unroll
+    for (int u = 0; u < kSlots; ++u) if (u == t) l = len[u];
+    return l;
+  }
+};
+__device__ __forceinline__ uint64_t record_type_key(const RecordInfo& ri) {
+  return (uint64_t)ri.fmt_mask | ((uint64_t)(uint32_t)ri.num_merged << 32) | ((uint64_t)ri.rflags << 40);
+}
+__device__ __forceinline__ bool cacheable(const EntryCtx& ex, int64_t c) { return c < 0 || !(ex.cm.cflags[c] & GDB_CF_HEAVY); }
+
 __global__ void __launch_bounds__(kBlock)
-k_entry_size(EntryCtx ex, RowIndex ri, SiteOut so, RecordTable rec, int32_t N, int nchunks, uint64_t* chunk_size, uint32_t* err) {
-  const int64_t k0 = (int64_t)blockIdx.x * kRun;
+k_entry_size(RowIndex ri, SiteOut so, RecordTable rec, int32_t N, int nchunks, int run, uint64_t* chunk_size, uint32_t* err) {
+  const EntryCtx& ex = c_ex;
+  const int64_t kb = (int64_t)blockIdx.x * run;
+  const int64_t ke = min(rec.npos, kb + (int64_t)run);
   const int ch = blockIdx.y;
-  const int64_t k1 = min(rec.npos, k0 + (int64_t)kRun);
   const int32_t r = ch * kBlock + (int32_t)threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __shared__ uint32_t wsum[kRun][kWavesPerBlock];
-  uint32_t lens[kRun];
   uint32_t e = 0;
+  RowWalker w;
+  LaneLenCache cache;
+  cache.reset(-2);
+  if (r < N) w.init(ri, r, rec.start[kb]);
+  for (int64_t k0 = kb; k0 < ke; k0 += kRun) {        // uniform
+    const int64_t k1 = min(ke, k0 + (int64_t)kRun);
+    uint32_t lens[kRun];
 #pragma unroll
-  for (int i = 0; i < kRun; ++i) lens[i] = 0;
-  if (r < N) {
-    RowWalker w;
-    w.init(ri, r, rec.start[k0]);
-    for (int i = 0; i < kRun; ++i) {
-      const int64_t k = k0 + i;
-      if (k >= k1) break;
-      const int64_t c = w.live(ri, ex.cm, rec.start[k]);
-      if (!so.fmt_mask[k]) continue;
-      RecordInfo rinfo = load_record_info(so, ex.hl, k);
-      lens[i] = 1u + entry_length(ex, rinfo, c, &e);
+    for (int i = 0; i < kRun; ++i) lens[i] = 0;
+    if (r < N) {
+      for (int i = 0; i < kRun; ++i) {
+        const int64_t k = k0 + i;
+        if (k >= k1) break;
+        const int64_t c = w.live(ri, ex.cm, rec.start[k]);
+        if (!so.fmt_mask[k]) continue;
+        RecordInfo rinfo = load_record_info(so, ex.hl, k);
+        if (c != cache.cell) cache.reset(c);
+        uint32_t l;
+        if (cacheable(ex, c)) {
+          const uint64_t key = record_type_key(rinfo);
+          const int t = cache.find(key);
+          if (t >= 0) l = cache.length(t);
+          else { l = entry_length(rinfo, c, &e); cache.insert(key, l); }
+        } else l = entry_length(rinfo, c, &e);
+        lens[i] = 1u + l;
+      }
     }
-  }
 #pragma unroll
-  for (int i = 0; i < kRun; ++i) { uint32_t s = wave_reduce_sum(lens[i]); if (lane == 0) wsum[i][wave] = s; }
-  __syncthreads();
-  if (threadIdx.x < kRun) {
-    const int64_t k = k0 + threadIdx.x;
-    if (k < k1) {
-      uint64_t total = 0;
-      for (int wv = 0; wv < kWavesPerBlock; ++wv) total += wsum[threadIdx.x][wv];
-      if (ch == 0) total += so.prefix_len[k];
-      if (ch == nchunks - 1) total += 1;  // '\n'
-      chunk_size[k * nchunks + ch] = total;
+    for (int i = 0; i < kRun; ++i) { uint32_t s = wave_reduce_sum(lens[i]); if (lane == 0) wsum[i][wave] = s; }
+    __syncthreads();
+    if (threadIdx.x < kRun) {
+      const int64_t k = k0 + threadIdx.x;
+      if (k < k1) {
+        uint64_t total = 0;
+        for (int wv = 0; wv < kWavesPerBlock; ++wv) total += wsum[threadIdx.x][wv];
+        if (ch == 0) total += so.prefix_len[k];
+        if (ch == nchunks - 1) total += 1;  // '\n'
+        chunk_size[k * nchunks + ch] = total;
+      }
     }
+    __syncthreads();
   }
   if (e) atomicOr(err, e);
 }
 
+// Sample columns of `run` consecutive records x kBlock rows.  Every (record, row-chunk) is assembled in LDS at the byte
+// offsets a wavefront scan of the entry lengths gives, then flushed to HBM with 16-byte stores (the LDS image sits at the
+// same offset modulo 16 as its destination, so whole aligned words move as uint4; only the <16-byte head/tail go bytewise).
+constexpr int kLdsBytes = 24 * 1024;
+
 __global__ void __launch_bounds__(kBlock)
-k_entry_write(EntryCtx ex, RowIndex ri, SiteOut so, RecordTable rec, int32_t N, int nchunks, int64_t k_begin, int64_t k_end,
+k_entry_write(RowIndex ri, SiteOut so, RecordTable rec, int32_t N, int nchunks, int run, int64_t k_begin, int64_t k_end,
               const uint64_t* chunk_off, uint64_t page_base, char* arena, uint32_t* err) {
-  const int64_t k0 = k_begin + (int64_t)blockIdx.x * kRun;
+  const EntryCtx& ex = c_ex;
+  const int64_t kb = k_begin + (int64_t)blockIdx.x * run;
+  const int64_t ke = min(k_end, kb + (int64_t)run);
   const int ch = blockIdx.y;
-  const int64_t k1 = min(k_end, k0 + (int64_t)kRun);
   const int32_t r = ch * kBlock + (int32_t)threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __shared__ uint32_t wtot[kRun][kWavesPerBlock];
-  uint32_t lens[kRun];
-  int32_t cells[kRun];
+  __shared__ __attribute__((aligned(16))) char lds_buf[kLdsBytes];
+  __shared__ __attribute__((aligned(16))) char slots[kBlock * kSlots * kSlotBytes];
+  gdb_lds_char* my_slots = (gdb_lds_char*)slots + (size_t)threadIdx.x * (kSlots * kSlotBytes);
   uint32_t e = 0;
+  RowWalker w;
+  LaneLenCache cache;
+  cache.reset(-2);
+  if (r < N) w.init(ri, r, rec.start[kb]);
+  for (int64_t k0 = kb; k0 < ke; k0 += kRun) {        // uniform
+    const int64_t k1 = min(ke, k0 + (int64_t)kRun);
+    uint32_t lens[kRun];
+    int32_t cells[kRun];
+    int8_t slot_of[kRun];                             // cache slot holding the text, -1: not cached
+    uint32_t busy = 0;                                // slots referenced by records of this batch
 #pragma unroll
-  for (int i = 0; i < kRun; ++i) { lens[i] = 0; cells[i] = -1; }
-  if (r < N) {
-    RowWalker w;
-    w.init(ri, r, rec.start[k0]);
+    for (int i = 0; i < kRun; ++i) { lens[i] = 0; cells[i] = -1; slot_of[i] = -1; }
+    if (r < N) {
+      for (int i = 0; i < kRun; ++i) {
+        const int64_t k = k0 + i;
+        if (k >= k1) break;
+        const int64_t c = w.live(ri, ex.cm, rec.start[k]);
+        cells[i] = (int32_t)c;
+        if (!so.fmt_mask[k]) continue;
+        RecordInfo rinfo = load_record_info(so, ex.hl, k);
+        uint32_t l;
+        if (cacheable(ex, c)) {
+          // a cell change may only recycle the cache once no earlier record of this batch still points into it
+          if (c != cache.cell && busy == 0u) cache.reset(c);
+          const uint64_t key = record_type_key(rinfo);
+          int t = (c == cache.cell) ? cache.find(key) : -1;
+          if (t >= 0) l = cache.length(t);
+          else {
+            l = entry_length(rinfo, c, &e);
+            if (c == cache.cell && l <= (uint32_t)kSlotBytes) {
+              t = cache.insert(key, l, busy);
+              if (t >= 0) entry_store_lds(rinfo, c, my_slots + t * kSlotBytes, &e);
+            }
+          }
+          if (t >= 0) busy |= 1u << t;
+          slot_of[i] = (int8_t)t;
+        } else l = entry_length(rinfo, c, &e);
+        lens[i] = 1u + l;
+      }
+    }
+    uint32_t excl[kRun];
+#pragma unroll
+    for (int i = 0; i < kRun; ++i) {
+      uint32_t inc = wave_inclusive_scan(lens[i], lane);
+      excl[i] = inc - lens[i];
+      if (lane == 63) wtot[i][wave] = inc;
+    }
+    __syncthreads();
     for (int i = 0; i < kRun; ++i) {
       const int64_t k = k0 + i;
-      if (k >= k1) break;
-      const int64_t c = w.live(ri, ex.cm, rec.start[k]);
-      cells[i] = (int32_t)c;
-      if (!so.fmt_mask[k]) continue;
-      RecordInfo rinfo = load_record_info(so, ex.hl, k);
-      lens[i] = 1u + entry_length(ex, rinfo, c, &e);
+      if (k >= k1) break;                       // uniform
+      uint32_t base = 0, total = 0;
+      for (int wv = 0; wv < kWavesPerBlock; ++wv) { const uint32_t t = wtot[i][wv]; if (wv < wave) base += t; total += t; }
+      if (total == 0) continue;                 // uniform: no FORMAT columns in this record
+      char* gdst = arena + (chunk_off[k * nchunks + ch] - page_base) + (ch == 0 ? so.prefix_len[k] : 0u);
+      const uint32_t a = (uint32_t)((uintptr_t)gdst & 15u);
+      if (a + total <= (uint32_t)kLdsBytes) {   // uniform
+        if (lens[i]) {
+          gdb_lds_char* ldst = (gdb_lds_char*)lds_buf + a + base + excl[i];
+          *ldst = '\t';
+          if (slot_of[i] >= 0) {
+            const gdb_lds_char* src = my_slots + slot_of[i] * kSlotBytes;
+            const uint32_t n = lens[i] - 1u;
+            for (uint32_t j = 0; j < n; ++j) ldst[1 + j] = src[j];
+          } else {
+            RecordInfo rinfo = load_record_info(so, ex.hl, k);
+            entry_store_lds(rinfo, (int64_t)cells[i], ldst + 1, &e);
+          }
+        }
+        __syncthreads();
+        uint32_t head = (16u - a) & 15u;
+        if (head > total) head = total;
+        const uint32_t nwords = (total - head) >> 4;
+        const uint32_t tail_at = head + (nwords << 4);
+        if (threadIdx.x < head) gdst[threadIdx.x] = lds_buf[a + threadIdx.x];
+        const uint4* lsrc = reinterpret_cast<const uint4*>(lds_buf + a + head);
+        uint4* gw = reinterpret_cast<uint4*>(gdst + head);
+        for (uint32_t wq = threadIdx.x; wq < nwords; wq += kBlock) gw[wq] = lsrc[wq];
+        if (threadIdx.x < total - tail_at) gdst[tail_at + threadIdx.x] = lds_buf[a + tail_at + threadIdx.x];
+        __syncthreads();
+      } else if (lens[i]) {                     // oversize chunk (very long PL vectors): straight to HBM
+        char* dst = gdst + base + excl[i];
+        *dst = '\t';
+        RecordInfo rinfo = load_record_info(so, ex.hl, k);
+        entry_store(rinfo, (int64_t)cells[i], dst + 1, &e);
+      }
     }
-  }
-  // exclusive offsets of every row inside its (record, chunk): wave scan + wave totals through LDS
-  uint32_t excl[kRun];
-#pragma unroll
-  for (int i = 0; i < kRun; ++i) {
-    uint32_t inc = wave_inclusive_scan(lens[i], lane);
-    excl[i] = inc - lens[i];
-    if (lane == 63) wtot[i][wave] = inc;
-  }
-  __syncthreads();
-  if (r < N) {
-    for (int i = 0; i < kRun; ++i) {
-      const int64_t k = k0 + i;
-      if (k >= k1) break;
-      if (!lens[i]) continue;
-      uint32_t base = 0;
-      for (int wv = 0; wv < wave; ++wv) base += wtot[i][wv];
-      char* dst = arena + (chunk_off[k * nchunks + ch] - page_base) + (ch == 0 ? so.prefix_len[k] : 0u) + base + excl[i];
-      *dst = '\t';
-      RecordInfo rinfo = load_record_info(so, ex.hl, k);
-      entry_store(ex, rinfo, (int64_t)cells[i], dst + 1, &e);
-    }
+    __syncthreads();
   }
   if (e) atomicOr(err, e);
 }
@@ -312,6 +446,7 @@ struct DevicePipeline::Impl {
   DevBuf<uint64_t> chunk_size, chunk_off, rec_off;
   DevBuf<char> arena, temp;
   DevBuf<uint32_t> err; DevBuf<int32_t> counters;
+  DevBuf<SiteCtx> d_sx; DevBuf<EntryCtx> d_ex;
   bool classified = false;
   struct Part { FragmentView v; std::vector<size_t> data_bytes; std::vector<void*> bufs; };
   std::vector<Part> parts;
@@ -656,8 +791,11 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   NameTables nt{S.names_text.p, S.field_name_off.p, S.field_name_len.p, S.filter_name_off.p, S.filter_name_len.p, (int32_t)S.hp.filter_name_off.size()};
   PresenceCounts pc{d_fmt, d_dp, d_nr, stride};
   SiteCtx sx{fr, pl, cm, rec, hl, pc, nt, qw, so};
+  S.d_sx.ensure(1);
+  HIP_CHECK(hipMemcpyAsync(S.d_sx.p, &sx, sizeof(SiteCtx), hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipStreamSynchronize(st));
   STAGE("k_site_size");
-  hipLaunchKernelGGL(k_site_size, dim3(blocks_for(P, 64)), dim3(64), 0, st, sx, S.err.p);
+  hipLaunchKernelGGL(k_site_size, dim3(blocks_for(P, 64)), dim3(64), 0, st, S.d_sx.p, S.err.p);
   HIP_CHECK(hipEventRecord(ev[2], st));
   // ---- S8 sample-column sizes + offsets ---------------------------------------------------------------------------
   const int nchunks = (N + kBlock - 1) / kBlock;
@@ -665,9 +803,12 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   S.chunk_size.ensure(nchunk_total + 1); S.chunk_off.ensure(nchunk_total + 2); S.rec_off.ensure(P + 2);
   RowIndex ri{S.row_ptr.p, S.perm.p, S.rm_begin.p};
   EntryCtx ex{fr, pl, cm, hl};
-  const unsigned run_blocks = (unsigned)((P + kRun - 1) / kRun);
+  HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_ex), &ex, sizeof(EntryCtx), 0, hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  const int run = run_length(P, nchunks);
+  const unsigned run_blocks = (unsigned)((P + run - 1) / run);
   STAGE("k_entry_size");
-  hipLaunchKernelGGL(k_entry_size, dim3(run_blocks, nchunks), dim3(kBlock), 0, st, ex, ri, so, rec, N, nchunks, S.chunk_size.p, S.err.p);
+  hipLaunchKernelGGL(k_entry_size, dim3(run_blocks, nchunks), dim3(kBlock), 0, st, ri, so, rec, N, nchunks, run, S.chunk_size.p, S.err.p);
   HIP_CHECK(hipMemsetAsync(S.chunk_size.p + nchunk_total, 0, sizeof(uint64_t), st));
   S.excl_scan(S.chunk_size.p, S.chunk_off.p, nchunk_total + 1);
   STAGE("k_gather_record_offsets");
@@ -713,10 +854,11 @@ bool DevicePipeline::next_page(uint64_t arena_bytes, const char** dev_ptr, uint6
   HIP_CHECK(hipEventCreate(&w0)); HIP_CHECK(hipEventCreate(&w1)); HIP_CHECK(hipEventCreate(&w2));
   HIP_CHECK(hipEventRecord(w0, st));
   STAGE("k_site_write");
-  hipLaunchKernelGGL(k_site_write, dim3(blocks_for(np, 64)), dim3(64), 0, st, iv.sx, kp, ke, S.chunk_off.p, iv.nchunks, page_base, S.arena.p, S.err.p);
+  hipLaunchKernelGGL(k_site_write, dim3(blocks_for(np, 64)), dim3(64), 0, st, S.d_sx.p, kp, ke, S.chunk_off.p, iv.nchunks, page_base, S.arena.p, S.err.p);
   HIP_CHECK(hipEventRecord(w1, st));
   STAGE("k_entry_write");
-  hipLaunchKernelGGL(k_entry_write, dim3((unsigned)((np + kRun - 1) / kRun), iv.nchunks), dim3(kBlock), 0, st, iv.ex, iv.ri, iv.so, iv.rec, N, iv.nchunks, kp, ke,
+  const int wrun = run_length(np, iv.nchunks);
+  hipLaunchKernelGGL(k_entry_write, dim3((unsigned)((np + wrun - 1) / wrun), iv.nchunks), dim3(kBlock), 0, st, iv.ri, iv.so, iv.rec, N, iv.nchunks, wrun, kp, ke,
                      S.chunk_off.p, page_base, S.arena.p, S.err.p);
   HIP_CHECK(hipEventRecord(w2, st));
   HIP_CHECK(hipStreamSynchronize(st));
