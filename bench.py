@@ -11,7 +11,7 @@ N > 1 (torch.distributed.run, one rank per GPU): every rank owns its own column 
 (weak scaling, no data-path collective - the reference's ranks do not communicate either, gt_mpi_gather.cc:322-366);
 value = records of all ranks / max-over-ranks time.
 
-Also on the JSON line: "roofline" for the dominant kernel (k_entry_write, HBM-bound byte emission) and "cpu_baseline"
+Also on the JSON line: "roofline" for the dominant kernel (k_assemble_write, the HBM-bound gather-copy of entry texts into pages) and "cpu_baseline"
 (the CPU oracle = port of the reference algorithm, single thread, on a bounded sample of the same workload).
 """
 import argparse
@@ -120,7 +120,7 @@ def main():
 
     out = None
     if rank == 0:
-        # roofline of the dominant kernel: algorithmic bytes of one k_entry_write launch / its average duration
+        # roofline of the dominant kernel: algorithmic bytes of one k_assemble_write launch / its average duration
         launches = max(1.0, wk_launches)
         alg_bytes_per_launch = (bytes_out + bytes_in) / launches
         avg_ms = wk_ms / launches
@@ -142,7 +142,7 @@ def main():
             "whole_path_GBps": (bo_all + bi_all) / dt / 1e9,
             "phase_ms": {k: v / args.steps for k, v in ms.items()},
             "stage_seconds_untimed": t_stage,
-            "roofline": {"bound": "hbm", "kernel": "k_entry_write", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_assemble_write", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "alg_bytes_per_launch": alg_bytes_per_launch, "avg_launch_ms": avg_ms, "launches": int(launches)},
         }

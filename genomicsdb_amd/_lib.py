@@ -12,7 +12,9 @@ class IntervalStats(ctypes.Structure):
                 ("bytes_in_reference_cells", ctypes.c_uint64), ("pages", ctypes.c_int32), ("write_launches", ctypes.c_int32),
                 ("err_bits", ctypes.c_uint32), ("ms_sweep", ctypes.c_float), ("ms_site", ctypes.c_float),
                 ("ms_size", ctypes.c_float), ("ms_write", ctypes.c_float), ("ms_total", ctypes.c_float),
-                ("ms_write_kernel_avg", ctypes.c_float)]
+                ("ms_write_kernel_avg", ctypes.c_float),
+                ("num_record_types", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+                ("num_text_slots", ctypes.c_int64), ("text_pool_bytes", ctypes.c_int64)]
 
 
 class DeviceColumn(ctypes.Structure):

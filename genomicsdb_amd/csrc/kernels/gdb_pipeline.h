@@ -32,6 +32,10 @@ struct IntervalStats {
   float ms_sweep = 0, ms_site = 0, ms_size = 0, ms_write = 0, ms_total = 0;
   float ms_write_kernel_avg = 0;  // average duration of one entry-write launch
   int write_launches = 0;
+  // entry text table of the interval
+  int num_record_types = 0;       // distinct (FORMAT mask, #merged alleles, remap flags)
+  int64_t num_text_slots = 0;     // (cell, type) + (record, variant call) + no-call texts
+  int64_t text_pool_bytes = 0;
 };
 
 // page consumer: `dev_ptr` points to `nbytes` of VCF text in HBM, valid until the callback returns

@@ -56,6 +56,11 @@ inline int run_length(int64_t nrec, int nchunks) {
   while (run > kRun && (nrec / run) * nchunks < 2048) run >>= 1;
   return (int)run;
 }
+// record types that get text-table slots (GDBAMD_MAX_TYPES < 64 forces the direct path in tests)
+inline int max_tabled_types() {
+  const char* e = getenv("GDBAMD_MAX_TYPES");   // read per interval: tests flip it in-process
+  return e && *e ? std::max(0, std::min(64, atoi(e))) : 64;
+}
 inline unsigned blocks_for(int64_t n, int b = kBlock) { return (unsigned)std::max<int64_t>(1, (n + b - 1) / b); }
 inline int bits_for(uint64_t max_value) { int b = 1; while (b < 64 && (max_value >> b)) ++b; return std::min(64, b + 1); }
 
@@ -195,86 +200,217 @@ __device__ __noinline__ void entry_store_lds(RecordInfo ri, int64_t c, gdb_lds_c
   (void)entry_emit(c_ex, ri, c, LdsSink(dst), e);
 }
 
-// ---- per-lane entry cache -------------------------------------------------------------------------------------------
-// A lane walks consecutive records of one sample; its live cell changes every ~100 bp while records are ~1 bp apart, and
-// the text of a plain reference-block call depends only on (cell, record type) with type = (FORMAT mask, remap flags,
-// #merged alleles).  So each lane keeps the last kSlots (type -> length [, text in LDS]) results of its current cell and
-// re-runs the field emitters only on a miss.  Calls that take part in the allele merge ("heavy") are never cached.
-constexpr int kSlots = 3;
-constexpr int kSlotBytes = 64;
+// ---- entry text table ---------------------------------------------------------------------------------------------
+// The sample columns are >99 % of the output bytes, and almost all of them repeat: a reference-block call is live in ~100
+// consecutive records and its text depends only on (cell, record type) with type = (FORMAT mask, remap flags, #merged
+// alleles).  So the field emitters run once per distinct (cell, type) pair, once per (record, heavy call) incidence and once
+// per type for the no-call column, into a text pool in HBM ("slots", 16-byte aligned); the P x N assembly pass that follows
+// is a pure gather-copy: slot id -> (offset, length) -> LDS -> page.
+constexpr int kTypeHash = 4096;           // open-addressing table of record type keys
+constexpr int kMaxTypes = 64;             // types with a slot bitmask position; the rest take the direct (untabled) path
+constexpr uint32_t kUntabledType = 255u;
+constexpr uint32_t kDirectSlot = 0xFFFFFFFFu;
+constexpr uint64_t kEmptyKey = ~0ull;
 
-struct LaneLenCache {
-  int64_t cell;
-  uint64_t key[kSlots];
-  uint32_t len[kSlots];
-  int next;
-  __device__ __forceinline__ void reset(int64_t c) { cell = c; next = 0;
-#pragma unroll
-    for (int t = 0; t < kSlots; ++t) key[t] = ~0ull; }
-  __device__ __forceinline__ int find(uint64_t k) const {
-    int hit = -1;
-#pragma unroll
-    for (int t = 0; t < kSlots; ++t) if (key[t] == k) hit = t;
-    return hit;
+__device__ __forceinline__ uint64_t record_type_key(uint32_t fmt_mask, uint32_t num_merged, uint32_t rflags) {
+  return (uint64_t)fmt_mask | ((uint64_t)num_merged << 32) | ((uint64_t)rflags << 40);
+}
+__device__ __forceinline__ uint32_t type_hash(uint64_t k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 29;
+  return (uint32_t)k & (kTypeHash - 1);
+}
+__global__ void k_type_insert(SiteOut so, int64_t P, unsigned long long* hkeys, int32_t* hrep) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= P) return;
+  const uint64_t key = record_type_key(so.fmt_mask[k], so.num_alleles[k], so.rflags[k]);
+  uint32_t h = type_hash(key);
+  for (int probe = 0; probe < kTypeHash; ++probe, h = (h + 1) & (kTypeHash - 1)) {
+    unsigned long long cur = __atomic_load_n(&hkeys[h], __ATOMIC_RELAXED);
+    if (cur == kEmptyKey) cur = atomicCAS(&hkeys[h], (unsigned long long)kEmptyKey, (unsigned long long)key);
+    if (cur == kEmptyKey || cur == key) { atomicMin(&hrep[h], (int32_t)k); return; }
   }
-  // victim = round-robin slot not in `busy` (slots whose text is still waiting to be copied out); -1 if all are busy
-  __device__ __forceinline__ int insert(uint64_t k, uint32_t l, uint32_t busy = 0u) {
-    int t = -1;
-#pragma unroll
-    for (int u = 0; u < kSlots; ++u) { const int cand = (next + u) % kSlots; if (t < 0 && !((busy >> cand) & 1u)) t = cand; }
-    if (t < 0) return -1;
-    next = (t + 1 == kSlots) ? 0 : t + 1;
-#pragma unroll
-    for (int u = 0; u < kSlots; ++u) if (u == t) { key[u] = k; len[u] = l; }
-    return t;
+}
+// dense ids for the first max_types occupied buckets; later ones are "untabled"
+__global__ void k_type_assign(const unsigned long long* hkeys, const int32_t* hrep, int max_types, uint8_t* hid, int32_t* type_rep, int32_t* ntypes) {
+  if (blockIdx.x || threadIdx.x) return;
+  int n = 0;
+  for (int h = 0; h < kTypeHash; ++h) {
+    if (hkeys[h] == kEmptyKey) continue;
+    if (n < max_types) { hid[h] = (uint8_t)n; type_rep[n] = hrep[h]; ++n; } else hid[h] = (uint8_t)kUntabledType;
   }
-  __device__ __forceinline__ uint32_t length(int t) const {
-    uint32_t l = 0;
-#pragma unroll
-    for (int u = 0; u < kSlots; ++u) if (u == t) l = len[u];
-    return l;
+  *ntypes = n;
+}
+__global__ void k_type_lookup(SiteOut so, int64_t P, const unsigned long long* hkeys, const uint8_t* hid, uint8_t* rtype) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= P) return;
+  const uint64_t key = record_type_key(so.fmt_mask[k], so.num_alleles[k], so.rflags[k]);
+  uint32_t h = type_hash(key);
+  uint8_t t = (uint8_t)kUntabledType;
+  for (int probe = 0; probe < kTypeHash; ++probe, h = (h + 1) & (kTypeHash - 1)) {
+    const unsigned long long cur = hkeys[h];
+    if (cur == key) { t = hid[h]; break; }
+    if (cur == kEmptyKey) break;
+  }
+  rtype[k] = t;
+}
+// which record types does every plain (non-heavy) cell of the window meet?
+__global__ void k_cell_types(const uint32_t* cflags, const int32_t* k_lo, const int32_t* k_hi, const uint8_t* rtype, int64_t c_base, int64_t n,
+                             uint64_t* tmask, uint32_t* nslots) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t c = c_base + i;
+  uint64_t m = 0;
+  if (!(cflags[c] & GDB_CF_HEAVY) && k_lo[c] >= 0) {
+    const int32_t hi = k_hi[c];
+    for (int32_t k = k_lo[c]; k <= hi; ++k) { const uint32_t t = rtype[k]; if (t != kUntabledType) m |= 1ull << t; }
+  }
+  tmask[i] = m;
+  nslots[i] = (uint32_t)__popcll(m);
+}
+__global__ void k_inc_pos(const uint64_t* inc_keys_sorted, const int64_t* inc_cell, const int64_t* hoff, const int32_t* k_lo, int64_t c_base, int64_t T,
+                          int64_t nrows, uint32_t* inc_pos) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= T) return;
+  const int64_t c = inc_cell[i];
+  const int64_t k = (int64_t)(inc_keys_sorted[i] / (uint64_t)nrows);
+  inc_pos[hoff[c - c_base] + (k - k_lo[c])] = (uint32_t)i;
+}
+
+struct SlotTable {
+  uint32_t* len;          // [S]  entry bytes incl. the leading tab; 0: the record has no FORMAT columns
+  const uint32_t* off16;  // [S]  pool offset in 16-byte units (exclusive scan of ceil(len/16))
+  char* pool;
+  uint32_t light_base;    // = kMaxTypes: slots [0,kMaxTypes) are the no-call texts per type
+  uint32_t heavy_base;
+};
+// pass 0: lengths; pass 1: text.  One template, three enumerations (types / plain cells x met types / heavy incidences).
+template <int PASS> __device__ __forceinline__ void slot_fill(const SlotTable& st, uint32_t s, const RecordInfo& rinfo, int64_t c, uint32_t* e) {
+  if (PASS == 0) st.len[s] = rinfo.fmt_mask ? 1u + entry_length(rinfo, c, e) : 0u;
+  else if (rinfo.fmt_mask) { char* dst = st.pool + (size_t)st.off16[s] * 16; *dst = '\t'; entry_store(rinfo, c, dst + 1, e); }
+}
+template <int PASS> __global__ void k_slots_nocall(SlotTable st, SiteOut so, const int32_t* type_rep, int ntypes, uint32_t* err) {
+  const int t = threadIdx.x;
+  if (blockIdx.x || t >= kMaxTypes) return;
+  uint32_t e = 0;
+  if (t < ntypes) slot_fill<PASS>(st, (uint32_t)t, load_record_info(so, c_ex.hl, type_rep[t]), -1, &e);
+  else if (PASS == 0) st.len[t] = 0;
+  if (e) atomicOr(err, e);
+}
+template <int PASS> __global__ void k_slots_light(SlotTable st, SiteOut so, const int32_t* type_rep, const uint64_t* tmask, const uint32_t* tbase,
+                                                 int64_t c_base, int64_t n, uint32_t* err) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t m = tmask[i];
+  uint32_t s = st.light_base + tbase[i];
+  uint32_t e = 0;
+  while (m) {
+    const int t = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    slot_fill<PASS>(st, s++, load_record_info(so, c_ex.hl, type_rep[t]), c_base + i, &e);
+  }
+  if (e) atomicOr(err, e);
+}
+template <int PASS> __global__ void k_slots_heavy(SlotTable st, SiteOut so, const uint64_t* inc_keys_sorted, const int64_t* inc_cell, int64_t T, int64_t nrows,
+                                                 uint32_t* err) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= T) return;
+  uint32_t e = 0;
+  const int64_t k = (int64_t)(inc_keys_sorted[i] / (uint64_t)nrows);
+  slot_fill<PASS>(st, st.heavy_base + (uint32_t)i, load_record_info(so, c_ex.hl, k), inc_cell[i], &e);
+  if (e) atomicOr(err, e);
+}
+__global__ void k_slot_units(const uint32_t* len, int64_t S, uint32_t* units) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < S) units[s] = (len[s] + 15u) >> 4;
+}
+__global__ void k_slot_desc(const uint32_t* len, const uint32_t* off16, int64_t S, uint2* desc) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < S) desc[s] = make_uint2(off16[s], len[s]);
+}
+
+// ---- assembly: workgroup = `run` consecutive records x kBlock rows ------------------------------------------------------
+struct AsmCtx {
+  RowIndex ri;
+  RecordTable rec;
+  SiteOut so;
+  const uint8_t* rtype;    // [P]
+  const uint2* desc;       // [S] (off16, len)
+  const char* pool;
+  const uint32_t* tbase;   // [CW] first slot of a plain cell (relative to light_base)
+  const uint64_t* tmask;   // [CW] types the cell has slots for
+  const int64_t* hoff;     // [CW] first incidence (fill order) of a heavy cell
+  const uint32_t* inc_pos; // [T]  fill order -> (record,row) order
+  const int64_t* eff_end;
+  const uint32_t* cflags;
+  const int32_t* k_lo;
+  int64_t c_base, c_end;
+  uint32_t light_base, heavy_base;
+};
+
+// A lane follows one sample through consecutive records.  The live cell and what is needed to name its slot stay in
+// registers; memory is touched only when the sample moves to its next cell (every ~100 records).
+struct SlotWalker {
+  int64_t j, j_end, next_begin, cur_end;
+  int64_t c;
+  uint64_t mask;
+  uint32_t base;
+  int32_t klo;
+  bool heavy;
+  __device__ __forceinline__ void load(const AsmCtx& a) {
+    next_begin = (j + 1 < j_end) ? a.ri.rm_begin[j + 1] : INT64_MAX;
+    const int64_t cc = a.ri.rm_cell[j];
+    c = -1; cur_end = INT64_MIN; heavy = false; mask = 0; base = 0; klo = 0;
+    if (cc < a.c_base || cc >= a.c_end) return;   // cannot reach the window
+    c = cc;
+    cur_end = a.eff_end[cc];
+    heavy = (a.cflags[cc] & GDB_CF_HEAVY) != 0;
+    const int64_t i = cc - a.c_base;
+    if (heavy) { base = (uint32_t)a.hoff[i]; klo = a.k_lo[cc]; }
+    else { base = a.tbase[i]; mask = a.tmask[i]; }
+  }
+  __device__ __forceinline__ void init(const AsmCtx& a, int32_t row, int64_t s0) {
+    const int64_t j_begin = a.ri.row_ptr[row];
+    j_end = a.ri.row_ptr[row + 1];
+    int64_t lo = j_begin, hi = j_end;  // last j with rm_begin[j] <= s0
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a.ri.rm_begin[mid] <= s0) lo = mid + 1; else hi = mid; }
+    j = lo - 1;
+    if (j >= j_begin) load(a);
+    else { c = -1; cur_end = INT64_MIN; heavy = false; mask = 0; base = 0; klo = 0; next_begin = (j + 1 < j_end) ? a.ri.rm_begin[j + 1] : INT64_MAX; }
+  }
+  __device__ __forceinline__ void advance(const AsmCtx& a, int64_t s) { while (next_begin <= s) { ++j; load(a); } }
+  __device__ __forceinline__ int64_t live(int64_t s) const { return (c >= 0 && s <= cur_end) ? c : -1; }
+  __device__ __forceinline__ uint32_t slot(const AsmCtx& a, int64_t k, int64_t s, uint32_t t) const {
+    if (c < 0 || s > cur_end) return t == kUntabledType ? kDirectSlot : t;
+    if (heavy) return a.heavy_base + a.inc_pos[base + (uint32_t)(k - klo)];
+    if (t == kUntabledType) return kDirectSlot;
+    return a.light_base + base + (uint32_t)__popcll(mask & ((1ull << t) - 1ull));
   }
 };
-__device__ __forceinline__ uint64_t record_type_key(const RecordInfo& ri) {
-  return (uint64_t)ri.fmt_mask | ((uint64_t)(uint32_t)ri.num_merged << 32) | ((uint64_t)ri.rflags << 40);
-}
-__device__ __forceinline__ bool cacheable(const EntryCtx& ex, int64_t c) { return c < 0 || !(ex.cm.cflags[c] & GDB_CF_HEAVY); }
 
 __global__ void __launch_bounds__(kBlock)
-k_entry_size(RowIndex ri, SiteOut so, RecordTable rec, int32_t N, int nchunks, int run, uint64_t* chunk_size, uint32_t* err) {
-  const EntryCtx& ex = c_ex;
+k_assemble_size(AsmCtx a, int32_t N, int nchunks, int run, uint64_t* chunk_size, uint32_t* err) {
   const int64_t kb = (int64_t)blockIdx.x * run;
-  const int64_t ke = min(rec.npos, kb + (int64_t)run);
+  const int64_t ke = min(a.rec.npos, kb + (int64_t)run);
   const int ch = blockIdx.y;
   const int32_t r = ch * kBlock + (int32_t)threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __shared__ uint32_t wsum[kRun][kWavesPerBlock];
   uint32_t e = 0;
-  RowWalker w;
-  LaneLenCache cache;
-  cache.reset(-2);
-  if (r < N) w.init(ri, r, rec.start[kb]);
+  SlotWalker w;
+  if (r < N) w.init(a, r, a.rec.start[kb]);
   for (int64_t k0 = kb; k0 < ke; k0 += kRun) {        // uniform
     const int64_t k1 = min(ke, k0 + (int64_t)kRun);
     uint32_t lens[kRun];
 #pragma unroll
-    for (int i = 0; i < kRun; ++i) lens[i] = 0;
-    if (r < N) {
-      for (int i = 0; i < kRun; ++i) {
-        const int64_t k = k0 + i;
-        if (k >= k1) break;
-        const int64_t c = w.live(ri, ex.cm, rec.start[k]);
-        if (!so.fmt_mask[k]) continue;
-        RecordInfo rinfo = load_record_info(so, ex.hl, k);
-        if (c != cache.cell) cache.reset(c);
-        uint32_t l;
-        if (cacheable(ex, c)) {
-          const uint64_t key = record_type_key(rinfo);
-          const int t = cache.find(key);
-          if (t >= 0) l = cache.length(t);
-          else { l = entry_length(rinfo, c, &e); cache.insert(key, l); }
-        } else l = entry_length(rinfo, c, &e);
-        lens[i] = 1u + l;
+    for (int i = 0; i < kRun; ++i) {
+      lens[i] = 0;
+      const int64_t k = k0 + i;
+      if (k < k1 && r < N) {
+        const int64_t s = a.rec.start[k];
+        w.advance(a, s);
+        const uint32_t sl = w.slot(a, k, s, a.rtype[k]);
+        if (sl != kDirectSlot) lens[i] = a.desc[sl].y;
+        else if (a.so.fmt_mask[k]) lens[i] = 1u + entry_length(load_record_info(a.so, c_ex.hl, k), w.live(s), &e);
       }
     }
 #pragma unroll
@@ -285,7 +421,7 @@ k_entry_size(RowIndex ri, SiteOut so, RecordTable rec, int32_t N, int nchunks, i
       if (k < k1) {
         uint64_t total = 0;
         for (int wv = 0; wv < kWavesPerBlock; ++wv) total += wsum[threadIdx.x][wv];
-        if (ch == 0) total += so.prefix_len[k];
+        if (ch == 0) total += a.so.prefix_len[k];
         if (ch == nchunks - 1) total += 1;  // '\n'
         chunk_size[k * nchunks + ch] = total;
       }
@@ -295,113 +431,155 @@ k_entry_size(RowIndex ri, SiteOut so, RecordTable rec, int32_t N, int nchunks, i
   if (e) atomicOr(err, e);
 }
 
-// Sample columns of `run` consecutive records x kBlock rows.  Every (record, row-chunk) is assembled in LDS at the byte
-// offsets a wavefront scan of the entry lengths gives, then flushed to HBM with 16-byte stores (the LDS image sits at the
-// same offset modulo 16 as its destination, so whole aligned words move as uint4; only the <16-byte head/tail go bytewise).
-constexpr int kLdsBytes = 24 * 1024;
+// Copy n bytes of a 16-byte aligned pool slot to an arbitrary LDS byte address: head bytes up to the next LDS word, then
+// whole words funnel-shifted out of consecutive source words (v_alignbyte), then the <4 tail bytes.  Executed by all lanes
+// of a wavefront with per-lane n (0: idle lane); the loop count is the wavefront maximum.
+__device__ __forceinline__ void copy_slot_to_lds(const char* __restrict__ src, gdb_lds_char* dst, uint32_t n) {
+  const uint32_t d = (uint32_t)(uintptr_t)dst;
+  uint32_t h = (4u - (d & 3u)) & 3u;
+  if (h > n) h = n;
+  const uint32_t nbody = (n - h) >> 2;                 // whole destination words
+  const uint32_t tb = h + (nbody << 2);                // first tail byte (source position)
+  __attribute__((address_space(3))) uint32_t* dw = (__attribute__((address_space(3))) uint32_t*)(dst + h);
+  uint32_t carry = 0;
+  // (the last destination word of a word-aligned copy takes only the carry: one more round without a load)
+  for (uint32_t q = 0; __any((int)((q << 4) < n || (q << 2) <= nbody)); ++q) {
+    uint4 x = make_uint4(0, 0, 0, 0);
+    if ((q << 4) < n) x = *reinterpret_cast<const uint4*>(src + (q << 4));
+    if (q == 0) {
+      if (h > 0) dst[0] = (char)(x.x & 0xFFu);
+      if (h > 1) dst[1] = (char)((x.x >> 8) & 0xFFu);
+      if (h > 2) dst[2] = (char)((x.x >> 16) & 0xFFu);
+    }
+    // destination word m takes source bytes [h+4m, h+4m+4): low part in source word m, high part in word m+1
+    const int32_t m0 = (int32_t)(q << 2) - 1;
+    const uint32_t v0 = __builtin_amdgcn_alignbyte(x.x, carry, h);
+    const uint32_t v1 = __builtin_amdgcn_alignbyte(x.y, x.x, h);
+    const uint32_t v2 = __builtin_amdgcn_alignbyte(x.z, x.y, h);
+    const uint32_t v3 = __builtin_amdgcn_alignbyte(x.w, x.z, h);
+    if (m0 >= 0 && (uint32_t)m0 < nbody) dw[m0] = v0;
+    if ((uint32_t)(m0 + 1) < nbody) dw[m0 + 1] = v1;
+    if ((uint32_t)(m0 + 2) < nbody) dw[m0 + 2] = v2;
+    if ((uint32_t)(m0 + 3) < nbody) dw[m0 + 3] = v3;
+    carry = x.w;
+    // tail bytes living in this source chunk
+#pragma unroll
+    for (uint32_t u = 0; u < 3; ++u) {
+      const uint32_t p = tb + u;
+      if (p < n && (p >> 4) == q) {
+        const uint32_t wsel = (p >> 2) & 3u;
+        const uint32_t word = wsel == 0 ? x.x : wsel == 1 ? x.y : wsel == 2 ? x.z : x.w;
+        dst[p] = (char)((word >> ((p & 3u) << 3)) & 0xFFu);
+      }
+    }
+  }
+}
+
+constexpr int kLdsBytes = 40 * 1024;
 
 __global__ void __launch_bounds__(kBlock)
-k_entry_write(RowIndex ri, SiteOut so, RecordTable rec, int32_t N, int nchunks, int run, int64_t k_begin, int64_t k_end,
-              const uint64_t* chunk_off, uint64_t page_base, char* arena, uint32_t* err) {
-  const EntryCtx& ex = c_ex;
+k_assemble_write(AsmCtx a, int32_t N, int nchunks, int run, int64_t k_begin, int64_t k_end, const uint64_t* chunk_off, uint64_t page_base,
+                 char* arena, uint32_t* err) {
   const int64_t kb = k_begin + (int64_t)blockIdx.x * run;
   const int64_t ke = min(k_end, kb + (int64_t)run);
   const int ch = blockIdx.y;
   const int32_t r = ch * kBlock + (int32_t)threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __shared__ uint32_t wtot[kRun][kWavesPerBlock];
+  __shared__ uint32_t s_total[kRun], s_lbase[kRun];
+  __shared__ int32_t s_group[kRun], s_ngroups;
+  __shared__ uint64_t s_gdst[kRun];
   __shared__ __attribute__((aligned(16))) char lds_buf[kLdsBytes];
-  __shared__ __attribute__((aligned(16))) char slots[kBlock * kSlots * kSlotBytes];
-  gdb_lds_char* my_slots = (gdb_lds_char*)slots + (size_t)threadIdx.x * (kSlots * kSlotBytes);
   uint32_t e = 0;
-  RowWalker w;
-  LaneLenCache cache;
-  cache.reset(-2);
-  if (r < N) w.init(ri, r, rec.start[kb]);
+  SlotWalker w;
+  if (r < N) w.init(a, r, a.rec.start[kb]);
   for (int64_t k0 = kb; k0 < ke; k0 += kRun) {        // uniform
     const int64_t k1 = min(ke, k0 + (int64_t)kRun);
-    uint32_t lens[kRun];
-    int32_t cells[kRun];
-    int8_t slot_of[kRun];                             // cache slot holding the text, -1: not cached
-    uint32_t busy = 0;                                // slots referenced by records of this batch
+    const int nb = (int)(k1 - k0);
+    uint32_t lens[kRun], off16[kRun];
+    int32_t cells[kRun];                              // only read on the direct path
 #pragma unroll
-    for (int i = 0; i < kRun; ++i) { lens[i] = 0; cells[i] = -1; slot_of[i] = -1; }
-    if (r < N) {
-      for (int i = 0; i < kRun; ++i) {
-        const int64_t k = k0 + i;
-        if (k >= k1) break;
-        const int64_t c = w.live(ri, ex.cm, rec.start[k]);
-        cells[i] = (int32_t)c;
-        if (!so.fmt_mask[k]) continue;
-        RecordInfo rinfo = load_record_info(so, ex.hl, k);
-        uint32_t l;
-        if (cacheable(ex, c)) {
-          // a cell change may only recycle the cache once no earlier record of this batch still points into it
-          if (c != cache.cell && busy == 0u) cache.reset(c);
-          const uint64_t key = record_type_key(rinfo);
-          int t = (c == cache.cell) ? cache.find(key) : -1;
-          if (t >= 0) l = cache.length(t);
-          else {
-            l = entry_length(rinfo, c, &e);
-            if (c == cache.cell && l <= (uint32_t)kSlotBytes) {
-              t = cache.insert(key, l, busy);
-              if (t >= 0) entry_store_lds(rinfo, c, my_slots + t * kSlotBytes, &e);
-            }
-          }
-          if (t >= 0) busy |= 1u << t;
-          slot_of[i] = (int8_t)t;
-        } else l = entry_length(rinfo, c, &e);
-        lens[i] = 1u + l;
+    for (int i = 0; i < kRun; ++i) {
+      lens[i] = 0; off16[i] = 0; cells[i] = -1;
+      const int64_t k = k0 + i;
+      if (k < k1 && r < N) {
+        const int64_t s = a.rec.start[k];
+        w.advance(a, s);
+        const uint32_t sl = w.slot(a, k, s, a.rtype[k]);
+        if (sl != kDirectSlot) { const uint2 dsc = a.desc[sl]; off16[i] = dsc.x; lens[i] = dsc.y; }
+        else if (a.so.fmt_mask[k]) {
+          cells[i] = (int32_t)w.live(s);
+          off16[i] = kDirectSlot;
+          lens[i] = 1u + entry_length(load_record_info(a.so, c_ex.hl, k), (int64_t)cells[i], &e);
+        }
       }
     }
     uint32_t excl[kRun];
 #pragma unroll
     for (int i = 0; i < kRun; ++i) {
-      uint32_t inc = wave_inclusive_scan(lens[i], lane);
+      const uint32_t inc = wave_inclusive_scan(lens[i], lane);
       excl[i] = inc - lens[i];
       if (lane == 63) wtot[i][wave] = inc;
     }
     __syncthreads();
-    for (int i = 0; i < kRun; ++i) {
-      const int64_t k = k0 + i;
-      if (k >= k1) break;                       // uniform
-      uint32_t base = 0, total = 0;
-      for (int wv = 0; wv < kWavesPerBlock; ++wv) { const uint32_t t = wtot[i][wv]; if (wv < wave) base += t; total += t; }
-      if (total == 0) continue;                 // uniform: no FORMAT columns in this record
-      char* gdst = arena + (chunk_off[k * nchunks + ch] - page_base) + (ch == 0 ? so.prefix_len[k] : 0u);
-      const uint32_t a = (uint32_t)((uintptr_t)gdst & 15u);
-      if (a + total <= (uint32_t)kLdsBytes) {   // uniform
-        if (lens[i]) {
-          gdb_lds_char* ldst = (gdb_lds_char*)lds_buf + a + base + excl[i];
-          *ldst = '\t';
-          if (slot_of[i] >= 0) {
-            const gdb_lds_char* src = my_slots + slot_of[i] * kSlotBytes;
-            const uint32_t n = lens[i] - 1u;
-            for (uint32_t j = 0; j < n; ++j) ldst[1 + j] = src[j];
-          } else {
-            RecordInfo rinfo = load_record_info(so, ex.hl, k);
-            entry_store_lds(rinfo, (int64_t)cells[i], ldst + 1, &e);
-          }
+    // one thread lays the batch out: records are packed into LDS groups, each image at its destination's offset mod 16
+    if (threadIdx.x == 0) {
+      uint32_t cur = 0;
+      int grp = 0;
+      for (int i = 0; i < nb; ++i) {
+        uint32_t total = 0;
+        for (int wv = 0; wv < kWavesPerBlock; ++wv) total += wtot[i][wv];
+        const int64_t k = k0 + i;
+        const uint64_t g = (uint64_t)(uintptr_t)arena + (chunk_off[k * nchunks + ch] - page_base) + (ch == 0 ? a.so.prefix_len[k] : 0u);
+        const uint32_t sp = (((uint32_t)(g & 15u) + total + 15u) & ~15u);
+        s_total[i] = total; s_gdst[i] = g;
+        if (sp > (uint32_t)kLdsBytes) { if (cur) { ++grp; cur = 0; } s_group[i] = grp++; s_lbase[i] = 0xFFFFFFFFu; continue; }   // oversize: own group, direct
+        if (cur + sp > (uint32_t)kLdsBytes) { ++grp; cur = 0; }
+        s_group[i] = grp; s_lbase[i] = cur;
+        cur += sp;
+      }
+      s_ngroups = nb ? s_group[nb - 1] + 1 : 0;
+    }
+    __syncthreads();
+    const int ngroups = s_ngroups;
+    for (int g = 0; g < ngroups; ++g) {               // uniform
+#pragma unroll
+      for (int i = 0; i < kRun; ++i) {
+        if (i >= nb || s_group[i] != g || s_total[i] == 0) continue;   // uniform
+        uint32_t base = 0;
+        for (int wv = 0; wv < wave; ++wv) base += wtot[i][wv];
+        char* gdst = (char*)(uintptr_t)s_gdst[i];
+        const uint32_t lbase = s_lbase[i];
+        if (lbase != 0xFFFFFFFFu) {
+          gdb_lds_char* ldst = (gdb_lds_char*)lds_buf + lbase + (uint32_t)((uintptr_t)gdst & 15u) + base + excl[i];
+          const bool direct = off16[i] == kDirectSlot;
+          copy_slot_to_lds(a.pool + (size_t)(direct ? 0u : off16[i]) * 16, ldst, direct ? 0u : lens[i]);
+          if (direct && lens[i]) { *ldst = '\t'; entry_store_lds(load_record_info(a.so, c_ex.hl, k0 + i), (int64_t)cells[i], ldst + 1, &e); }
+        } else if (lens[i]) {                         // chunk larger than the LDS image (very long PL vectors): straight to HBM
+          char* dst = gdst + base + excl[i];
+          if (off16[i] == kDirectSlot) { *dst = '\t'; entry_store(load_record_info(a.so, c_ex.hl, k0 + i), (int64_t)cells[i], dst + 1, &e); }
+          else { const char* src = a.pool + (size_t)off16[i] * 16; for (uint32_t b = 0; b < lens[i]; ++b) dst[b] = src[b]; }
         }
-        __syncthreads();
-        uint32_t head = (16u - a) & 15u;
+      }
+      __syncthreads();
+      for (int i = 0; i < nb; ++i) {
+        if (s_group[i] != g || s_total[i] == 0 || s_lbase[i] == 0xFFFFFFFFu) continue;   // uniform
+        char* gdst = (char*)(uintptr_t)s_gdst[i];
+        const uint32_t total = s_total[i];
+        const uint32_t al = (uint32_t)((uintptr_t)gdst & 15u);
+        const char* img = lds_buf + s_lbase[i] + al;
+        uint32_t head = (16u - al) & 15u;
         if (head > total) head = total;
         const uint32_t nwords = (total - head) >> 4;
         const uint32_t tail_at = head + (nwords << 4);
-        if (threadIdx.x < head) gdst[threadIdx.x] = lds_buf[a + threadIdx.x];
-        const uint4* lsrc = reinterpret_cast<const uint4*>(lds_buf + a + head);
+        if (threadIdx.x < head) gdst[threadIdx.x] = img[threadIdx.x];
+        const uint4* lsrc = reinterpret_cast<const uint4*>(img + head);
         uint4* gw = reinterpret_cast<uint4*>(gdst + head);
         for (uint32_t wq = threadIdx.x; wq < nwords; wq += kBlock) gw[wq] = lsrc[wq];
-        if (threadIdx.x < total - tail_at) gdst[tail_at + threadIdx.x] = lds_buf[a + tail_at + threadIdx.x];
-        __syncthreads();
-      } else if (lens[i]) {                     // oversize chunk (very long PL vectors): straight to HBM
-        char* dst = gdst + base + excl[i];
-        *dst = '\t';
-        RecordInfo rinfo = load_record_info(so, ex.hl, k);
-        entry_store(rinfo, (int64_t)cells[i], dst + 1, &e);
+        if (threadIdx.x < total - tail_at) gdst[tail_at + threadIdx.x] = img[tail_at + threadIdx.x];
       }
+      __syncthreads();
     }
-    __syncthreads();
   }
   if (e) atomicOr(err, e);
 }
@@ -446,7 +624,10 @@ struct DevicePipeline::Impl {
   DevBuf<uint64_t> chunk_size, chunk_off, rec_off;
   DevBuf<char> arena, temp;
   DevBuf<uint32_t> err; DevBuf<int32_t> counters;
-  DevBuf<SiteCtx> d_sx; DevBuf<EntryCtx> d_ex;
+  DevBuf<SiteCtx> d_sx;
+  // entry text table
+  DevBuf<unsigned long long> type_hkeys; DevBuf<int32_t> type_hrep, type_rep; DevBuf<uint8_t> type_hid, rtype;
+  DevBuf<uint64_t> tmask; DevBuf<uint32_t> nslots, tbase, inc_pos, slot_len, slot_units, slot_off; DevBuf<uint2> slot_desc; DevBuf<char> pool;
   bool classified = false;
   struct Part { FragmentView v; std::vector<size_t> data_bytes; std::vector<void*> bufs; };
   std::vector<Part> parts;
@@ -459,7 +640,7 @@ struct DevicePipeline::Impl {
     float write_kernel_ms = 0;
     std::vector<uint64_t> rec_off;
     IntervalStats stats;
-    SiteCtx sx; EntryCtx ex; RowIndex ri; SiteOut so; RecordTable rec;
+    SiteCtx sx; EntryCtx ex; RowIndex ri; SiteOut so; RecordTable rec; AsmCtx ac;
   } iv;
 
   void* temp_storage(size_t bytes) { temp.ensure(bytes + 256); return temp.p; }
@@ -805,10 +986,54 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   EntryCtx ex{fr, pl, cm, hl};
   HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_ex), &ex, sizeof(EntryCtx), 0, hipMemcpyHostToDevice, st));
   HIP_CHECK(hipStreamSynchronize(st));
+  // ---- S8a entry text table: record types, slots of (plain cell, type) / (record, heavy call) / no-call, text pool ------------
+  if (T >= (1ll << 32)) throw GenomicsDBDeviceException("more than 2^32 (record, variant call) incidences in one interval: split the query interval");
+  S.type_hkeys.ensure(kTypeHash); S.type_hrep.ensure(kTypeHash); S.type_hid.ensure(kTypeHash); S.type_rep.ensure(kMaxTypes); S.rtype.ensure(P);
+  HIP_CHECK(hipMemsetAsync(S.type_hkeys.p, 0xFF, kTypeHash * sizeof(unsigned long long), st));
+  HIP_CHECK(hipMemsetAsync(S.type_hrep.p, 0x7F, kTypeHash * sizeof(int32_t), st));
+  HIP_CHECK(hipMemsetAsync(S.type_hid.p, 0xFF, kTypeHash, st));
+  HIP_CHECK(hipMemsetAsync(S.type_rep.p, 0, kMaxTypes * sizeof(int32_t), st));
+  STAGE("k_type_insert");
+  hipLaunchKernelGGL(k_type_insert, dim3(blocks_for(P)), dim3(kBlock), 0, st, so, P, S.type_hkeys.p, S.type_hrep.p);
+  hipLaunchKernelGGL(k_type_assign, dim3(1), dim3(1), 0, st, S.type_hkeys.p, S.type_hrep.p, max_tabled_types(), S.type_hid.p, S.type_rep.p, S.counters.p + 1);
+  hipLaunchKernelGGL(k_type_lookup, dim3(blocks_for(P)), dim3(kBlock), 0, st, so, P, S.type_hkeys.p, S.type_hid.p, S.rtype.p);
+  S.tmask.ensure(CW); S.nslots.ensure(CW + 1); S.tbase.ensure(CW + 1);
+  STAGE("k_cell_types");
+  hipLaunchKernelGGL(k_cell_types, dim3(blocks_for(CW)), dim3(kBlock), 0, st, S.cflags.p, S.k_lo.p, S.k_hi.p, S.rtype.p, c_base, CW, S.tmask.p, S.nslots.p);
+  S.excl_scan(S.nslots.p, S.tbase.p, (size_t)CW);
+  const uint64_t SL = (uint64_t)S.read_back(S.tbase.p + (CW - 1)) + S.read_back(S.nslots.p + (CW - 1));
+  const int ntypes = S.read_back(S.counters.p + 1);
+  const uint64_t NS = (uint64_t)kMaxTypes + SL + (uint64_t)T;
+  if (NS >= (1ull << 32)) throw GenomicsDBDeviceException("entry text table exceeds 2^32 slots: split the query interval");
+  S.inc_pos.ensure(T + 1);
+  if (T > 0) hipLaunchKernelGGL(k_inc_pos, dim3(blocks_for(T)), dim3(kBlock), 0, st, S.inc_keys_sorted.p, S.inc_vals_sorted.p, S.hoff.p, S.k_lo.p, c_base, T, (int64_t)N, S.inc_pos.p);
+  S.slot_len.ensure(NS + 1); S.slot_units.ensure(NS + 1); S.slot_off.ensure(NS + 1); S.slot_desc.ensure(NS + 1);
+  SlotTable stt{S.slot_len.p, S.slot_off.p, nullptr, (uint32_t)kMaxTypes, (uint32_t)(kMaxTypes + SL)};
+  STAGE("k_slots<0>");
+  hipLaunchKernelGGL(k_slots_nocall<0>, dim3(1), dim3(kMaxTypes), 0, st, stt, so, S.type_rep.p, ntypes, S.err.p);
+  hipLaunchKernelGGL(k_slots_light<0>, dim3(blocks_for(CW, 64)), dim3(64), 0, st, stt, so, S.type_rep.p, S.tmask.p, S.tbase.p, c_base, CW, S.err.p);
+  if (T > 0) hipLaunchKernelGGL(k_slots_heavy<0>, dim3(blocks_for(T, 64)), dim3(64), 0, st, stt, so, S.inc_keys_sorted.p, S.inc_vals_sorted.p, T, (int64_t)N, S.err.p);
+  hipLaunchKernelGGL(k_slot_units, dim3(blocks_for((int64_t)NS)), dim3(kBlock), 0, st, S.slot_len.p, (int64_t)NS, S.slot_units.p);
+  S.excl_scan(S.slot_units.p, S.slot_off.p, (size_t)NS);
+  const uint64_t pool_units = (uint64_t)S.read_back(S.slot_off.p + (NS - 1)) + S.read_back(S.slot_units.p + (NS - 1));
+  if (pool_units >= (1ull << 32)) throw GenomicsDBDeviceException("entry text pool exceeds 64 GiB: split the query interval");
+  S.pool.ensure((size_t)pool_units * 16 + 64);
+  stt.pool = S.pool.p;
+  STAGE("k_slots<1>");
+  hipLaunchKernelGGL(k_slots_nocall<1>, dim3(1), dim3(kMaxTypes), 0, st, stt, so, S.type_rep.p, ntypes, S.err.p);
+  hipLaunchKernelGGL(k_slots_light<1>, dim3(blocks_for(CW, 64)), dim3(64), 0, st, stt, so, S.type_rep.p, S.tmask.p, S.tbase.p, c_base, CW, S.err.p);
+  if (T > 0) hipLaunchKernelGGL(k_slots_heavy<1>, dim3(blocks_for(T, 64)), dim3(64), 0, st, stt, so, S.inc_keys_sorted.p, S.inc_vals_sorted.p, T, (int64_t)N, S.err.p);
+  hipLaunchKernelGGL(k_slot_desc, dim3(blocks_for((int64_t)NS)), dim3(kBlock), 0, st, S.slot_len.p, S.slot_off.p, (int64_t)NS, S.slot_desc.p);
+  stats.num_record_types = ntypes;
+  stats.num_text_slots = (int64_t)NS;
+  stats.text_pool_bytes = (int64_t)(pool_units * 16);
+  AsmCtx ac{ri, rec, so, S.rtype.p, S.slot_desc.p, S.pool.p, S.tbase.p, S.tmask.p, S.hoff.p, S.inc_pos.p, S.eff_end.p, S.cflags.p, S.k_lo.p,
+            c_base, c_end, (uint32_t)kMaxTypes, (uint32_t)(kMaxTypes + SL)};
+  // ---- S8b sample-column sizes + offsets ---------------------------------------------------------------------------
   const int run = run_length(P, nchunks);
   const unsigned run_blocks = (unsigned)((P + run - 1) / run);
-  STAGE("k_entry_size");
-  hipLaunchKernelGGL(k_entry_size, dim3(run_blocks, nchunks), dim3(kBlock), 0, st, ri, so, rec, N, nchunks, run, S.chunk_size.p, S.err.p);
+  STAGE("k_assemble_size");
+  hipLaunchKernelGGL(k_assemble_size, dim3(run_blocks, nchunks), dim3(kBlock), 0, st, ac, N, nchunks, run, S.chunk_size.p, S.err.p);
   HIP_CHECK(hipMemsetAsync(S.chunk_size.p + nchunk_total, 0, sizeof(uint64_t), st));
   S.excl_scan(S.chunk_size.p, S.chunk_off.p, nchunk_total + 1);
   STAGE("k_gather_record_offsets");
@@ -830,7 +1055,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   }
   for (int64_t k = 0; k < P; ++k) S.iv.max_record_bytes = std::max<uint64_t>(S.iv.max_record_bytes, rec_off[(size_t)k + 1] - rec_off[(size_t)k]);
   S.iv.P = P; S.iv.nchunks = nchunks; S.iv.kp = 0;
-  S.iv.sx = sx; S.iv.ex = ex; S.iv.ri = ri; S.iv.so = so; S.iv.rec = rec;
+  S.iv.sx = sx; S.iv.ex = ex; S.iv.ri = ri; S.iv.so = so; S.iv.rec = rec; S.iv.ac = ac;
   S.iv.active = true;
 }
 
@@ -856,9 +1081,9 @@ bool DevicePipeline::next_page(uint64_t arena_bytes, const char** dev_ptr, uint6
   STAGE("k_site_write");
   hipLaunchKernelGGL(k_site_write, dim3(blocks_for(np, 64)), dim3(64), 0, st, S.d_sx.p, kp, ke, S.chunk_off.p, iv.nchunks, page_base, S.arena.p, S.err.p);
   HIP_CHECK(hipEventRecord(w1, st));
-  STAGE("k_entry_write");
+  STAGE("k_assemble_write");
   const int wrun = run_length(np, iv.nchunks);
-  hipLaunchKernelGGL(k_entry_write, dim3((unsigned)((np + wrun - 1) / wrun), iv.nchunks), dim3(kBlock), 0, st, iv.ri, iv.so, iv.rec, N, iv.nchunks, wrun, kp, ke,
+  hipLaunchKernelGGL(k_assemble_write, dim3((unsigned)((np + wrun - 1) / wrun), iv.nchunks), dim3(kBlock), 0, st, iv.ac, N, iv.nchunks, wrun, kp, ke,
                      S.chunk_off.p, page_base, S.arena.p, S.err.p);
   HIP_CHECK(hipEventRecord(w2, st));
   HIP_CHECK(hipStreamSynchronize(st));

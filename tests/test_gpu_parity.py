@@ -119,3 +119,34 @@ def test_synthetic_window_split_equals_whole(gdb, tmp_path):
     assert set(pos_whole) <= set(pos_split) and len(pos_split) - len(pos_whole) <= 1
     assert pos_split == sorted(pos_split, key=int)
     e.close()
+
+
+@pytest.mark.parametrize("max_types", ["0", "1", "2"])
+def test_untabled_record_types_take_the_direct_path(gdb, tmp_path, monkeypatch, max_types):
+    """Record types beyond the text-table capacity (64) are emitted per (record, sample) by the field emitters instead of
+    copied from the pool; GDBAMD_MAX_TYPES shrinks the capacity so that both paths mix in one page."""
+    monkeypatch.setenv("GDBAMD_MAX_TYPES", max_types)
+    for name in ("t0_1_2_vcf_at_0", "t6_7_8_vcf_at_0", "t0_overlapping_at_12202"):
+        case = [c for c in CASES if c[0] == name]
+        if not case:
+            continue
+        _, callsets, vid, ov, golden, mode = case[0]
+        cells = helpers.cells_for(callsets, vid)
+        q, pb = helpers.query_json(callsets, vid, ov, mode)
+        s = gdb.GenomicsDBQueryStream(query_json=q, cells=cells, buffer_capacity=1 << 16)
+        got = s.read()
+        s.close()
+        assert got == helpers.golden_text(golden)
+    from genomicsdb_amd import synth
+    N, B, L = 100, 10_000_000, 3000
+    g = synth.Generator(N, B, L + 2500)
+    cells, nc = g.chunk_bytes(B + L + 2500)
+    q = helpers.synth_query(tmp_path, N, B + 500, B + 500 + L - 1)
+    want, nrec, _ = helpers.oracle_run_synth(q, cells, synth.SEED, with_header=False)
+    eng = gdb.CombineEngine(q)
+    eng.stage_cells(cells)
+    eng.set_reference(B, synth.reference(B, L + 4096))
+    got, st = eng.run_interval(B + 500, B + 500 + L - 1, arena_bytes=1 << 20)
+    assert st.num_record_types == int(max_types)
+    assert got == want
+    eng.close()
