@@ -30,8 +30,6 @@ namespace genomicsdb_amd {
 namespace {
 
 constexpr int kBlock = 256;          // threads per workgroup = 4 wavefronts of 64
-constexpr int kRun = 16;             // consecutive records one workgroup walks per row
-constexpr int kWavesPerBlock = kBlock / 64;
 
 template <class T> struct DevBuf {   // grow-only device allocation
   T* p = nullptr;
@@ -53,7 +51,7 @@ inline bool debug_sync() { static int v = -1; if (v < 0) { const char* e = geten
 // records one workgroup walks: long runs amortise the per-lane cell cache, but keep >= ~8 workgroups per CU in flight
 inline int run_length(int64_t nrec, int nchunks) {
   int64_t run = 256;
-  while (run > kRun && (nrec / run) * nchunks < 2048) run >>= 1;
+  while (run > 16 && (nrec / run) * nchunks < 16384) run >>= 1;
   return (int)run;
 }
 // record types that get text-table slots (GDBAMD_MAX_TYPES < 64 forces the direct path in tests)
@@ -175,7 +173,7 @@ __global__ void k_site_write(const SiteCtx* __restrict__ sxp, int64_t k_begin, i
   if (e) atomicOr(err, e);
 }
 
-// ---- sample-column kernels: workgroup = kRun consecutive records x kBlock rows ---------------------------------------
+// ---- sample columns -------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t wave_reduce_sum(uint32_t v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   return v;
@@ -207,9 +205,8 @@ __device__ __noinline__ void entry_store_lds(RecordInfo ri, int64_t c, gdb_lds_c
 // per type for the no-call column, into a text pool in HBM ("slots", 16-byte aligned); the P x N assembly pass that follows
 // is a pure gather-copy: slot id -> (offset, length) -> LDS -> page.
 constexpr int kTypeHash = 4096;           // open-addressing table of record type keys
-constexpr int kMaxTypes = 64;             // types with a slot bitmask position; the rest take the direct (untabled) path
+constexpr int kMaxTypes = 64;             // types with a slot bitmask position; records of further types get one slot per sample
 constexpr uint32_t kUntabledType = 255u;
-constexpr uint32_t kDirectSlot = 0xFFFFFFFFu;
 constexpr uint64_t kEmptyKey = ~0ull;
 
 __device__ __forceinline__ uint64_t record_type_key(uint32_t fmt_mask, uint32_t num_merged, uint32_t rflags) {
@@ -227,20 +224,31 @@ __global__ void k_type_insert(SiteOut so, int64_t P, unsigned long long* hkeys, 
   for (int probe = 0; probe < kTypeHash; ++probe, h = (h + 1) & (kTypeHash - 1)) {
     unsigned long long cur = __atomic_load_n(&hkeys[h], __ATOMIC_RELAXED);
     if (cur == kEmptyKey) cur = atomicCAS(&hkeys[h], (unsigned long long)kEmptyKey, (unsigned long long)key);
-    if (cur == kEmptyKey || cur == key) { atomicMin(&hrep[h], (int32_t)k); return; }
+    if (cur == kEmptyKey || cur == key) {   // representative record: the smallest index (read first: nearly every thread loses)
+      if (__atomic_load_n(&hrep[h], __ATOMIC_RELAXED) > (int32_t)k) atomicMin(&hrep[h], (int32_t)k);
+      return;
+    }
   }
 }
-// dense ids for the first max_types occupied buckets; later ones are "untabled"
+// dense ids for the first max_types occupied buckets (bucket order); later ones are "untabled".  One wavefront: every lane
+// counts its kTypeHash/64 consecutive buckets, a wavefront scan gives its first id.
 __global__ void k_type_assign(const unsigned long long* hkeys, const int32_t* hrep, int max_types, uint8_t* hid, int32_t* type_rep, int32_t* ntypes) {
-  if (blockIdx.x || threadIdx.x) return;
-  int n = 0;
-  for (int h = 0; h < kTypeHash; ++h) {
+  if (blockIdx.x) return;
+  constexpr int per = kTypeHash / 64;
+  const int lane = threadIdx.x;
+  uint32_t cnt = 0;
+  for (int j = 0; j < per; ++j) cnt += hkeys[lane * per + j] != kEmptyKey;
+  const uint32_t incl = wave_inclusive_scan(cnt, lane);
+  int n = (int)(incl - cnt);
+  for (int j = 0; j < per; ++j) {
+    const int h = lane * per + j;
     if (hkeys[h] == kEmptyKey) continue;
-    if (n < max_types) { hid[h] = (uint8_t)n; type_rep[n] = hrep[h]; ++n; } else hid[h] = (uint8_t)kUntabledType;
+    if (n < max_types) { hid[h] = (uint8_t)n; type_rep[n] = hrep[h]; } else hid[h] = (uint8_t)kUntabledType;
+    ++n;
   }
-  *ntypes = n;
+  if (lane == 63) *ntypes = min((int)incl, max_types);
 }
-__global__ void k_type_lookup(SiteOut so, int64_t P, const unsigned long long* hkeys, const uint8_t* hid, uint8_t* rtype) {
+__global__ void k_type_lookup(SiteOut so, int64_t P, const unsigned long long* hkeys, const uint8_t* hid, uint8_t* rtype, uint32_t* untabled) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= P) return;
   const uint64_t key = record_type_key(so.fmt_mask[k], so.num_alleles[k], so.rflags[k]);
@@ -252,6 +260,11 @@ __global__ void k_type_lookup(SiteOut so, int64_t P, const unsigned long long* h
     if (cur == kEmptyKey) break;
   }
   rtype[k] = t;
+  untabled[k] = t == (uint8_t)kUntabledType ? 1u : 0u;
+}
+__global__ void k_untabled_records(const uint32_t* untabled, const uint32_t* ubase, int64_t P, int32_t* urec) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < P && untabled[k]) urec[ubase[k]] = (int32_t)k;
 }
 // which record types does every plain (non-heavy) cell of the window meet?
 __global__ void k_cell_types(const uint32_t* cflags, const int32_t* k_lo, const int32_t* k_hi, const uint8_t* rtype, int64_t c_base, int64_t n,
@@ -276,17 +289,34 @@ __global__ void k_inc_pos(const uint64_t* inc_keys_sorted, const int64_t* inc_ce
   inc_pos[hoff[c - c_base] + (k - k_lo[c])] = (uint32_t)i;
 }
 
+constexpr int kSlotBlock = 64;     // threads per workgroup of the slot kernels
+constexpr int kStripWords = 33;    // LDS words per lane (132 bytes)
 struct SlotTable {
   uint32_t* len;          // [S]  entry bytes incl. the leading tab; 0: the record has no FORMAT columns
   const uint32_t* off16;  // [S]  pool offset in 16-byte units (exclusive scan of ceil(len/16))
   char* pool;
   uint32_t light_base;    // = kMaxTypes: slots [0,kMaxTypes) are the no-call texts per type
   uint32_t heavy_base;
+  uint32_t row_base;      // slots of (untabled record, sample): row_base + u * N + row
 };
-// pass 0: lengths; pass 1: text.  One template, three enumerations (types / plain cells x met types / heavy incidences).
+// pass 0: lengths; pass 1: text.  One template, four enumerations (types / plain cells x met types / heavy incidences /
+// samples of records whose type has no bitmask position).
 template <int PASS> __device__ __forceinline__ void slot_fill(const SlotTable& st, uint32_t s, const RecordInfo& rinfo, int64_t c, uint32_t* e) {
   if (PASS == 0) st.len[s] = rinfo.fmt_mask ? 1u + entry_length(rinfo, c, e) : 0u;
-  else if (rinfo.fmt_mask) { char* dst = st.pool + (size_t)st.off16[s] * 16; *dst = '\t'; entry_store(rinfo, c, dst + 1, e); }
+  else if (rinfo.fmt_mask) {
+    // the text is formatted into a lane-private LDS strip (odd word stride: no bank conflicts between lanes) and leaves as
+    // 16-byte stores into the lane's 16-byte aligned pool slot; only texts longer than the strip go out bytewise
+    __shared__ uint32_t strip[kSlotBlock * kStripWords];
+    char* dst = st.pool + (size_t)st.off16[s] * 16;
+    const uint32_t len = st.len[s];
+    if (len <= (uint32_t)(kStripWords - 1) * 4u) {
+      uint32_t* mine = strip + threadIdx.x * kStripWords;
+      gdb_lds_char* txt = (gdb_lds_char*)mine;
+      *txt = '\t';
+      entry_store_lds(rinfo, c, txt + 1, e);
+      for (uint32_t q = 0; (q << 4) < len; ++q) reinterpret_cast<uint4*>(dst)[q] = make_uint4(mine[4 * q], mine[4 * q + 1], mine[4 * q + 2], mine[4 * q + 3]);
+    } else { *dst = '\t'; entry_store(rinfo, c, dst + 1, e); }
+  }
 }
 template <int PASS> __global__ void k_slots_nocall(SlotTable st, SiteOut so, const int32_t* type_rep, int ntypes, uint32_t* err) {
   const int t = threadIdx.x;
@@ -319,6 +349,21 @@ template <int PASS> __global__ void k_slots_heavy(SlotTable st, SiteOut so, cons
   slot_fill<PASS>(st, st.heavy_base + (uint32_t)i, load_record_info(so, c_ex.hl, k), inc_cell[i], &e);
   if (e) atomicOr(err, e);
 }
+template <int PASS> __global__ void k_slots_untabled(SlotTable st, SiteOut so, RowIndex ri, RecordTable rec, const int32_t* urec, int64_t U, int32_t N, uint32_t* err) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= U * (int64_t)N) return;
+  const int64_t u = i / N;
+  const int32_t row = (int32_t)(i - u * N);
+  const int64_t k = urec[u];
+  uint32_t e = 0;
+  RowWalker w;
+  w.init(ri, row, rec.start[k]);
+  const int64_t c = w.live(ri, c_ex.cm, rec.start[k]);
+  const uint32_t s = st.row_base + (uint32_t)i;
+  if (c >= 0 && (c_ex.cm.cflags[c] & GDB_CF_HEAVY)) { if (PASS == 0) st.len[s] = 0; }   // heavy calls have their incidence slot
+  else slot_fill<PASS>(st, s, load_record_info(so, c_ex.hl, k), c, &e);
+  if (e) atomicOr(err, e);
+}
 __global__ void k_slot_units(const uint32_t* len, int64_t S, uint32_t* units) {
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s < S) units[s] = (len[s] + 15u) >> 4;
@@ -328,141 +373,112 @@ __global__ void k_slot_desc(const uint32_t* len, const uint32_t* off16, int64_t 
   if (s < S) desc[s] = make_uint2(off16[s], len[s]);
 }
 
-// ---- assembly: workgroup = `run` consecutive records x kBlock rows ------------------------------------------------------
+// ---- assembly ------------------------------------------------------------------------------------------------------
+// Row-major walk list: what a lane needs when its sample moves to the next cell, in ONE 32-byte element.  begin / eff_end /
+// heavy are properties of the staged fragment; base / aux are refreshed per interval for the cells of the window.
+struct __attribute__((aligned(16))) WalkCell {
+  int64_t begin;
+  int64_t eff_end;
+  uint64_t aux;     // plain cell: bitmask of the record types it has slots for; heavy cell: its first record (k_lo)
+  uint32_t base;    // plain cell: first slot (relative to light_base); heavy cell: first incidence in fill order
+  uint32_t heavy;
+};
+__global__ void k_walk_static(const int64_t* perm, const int64_t* rm_begin, const int64_t* eff_end, const uint32_t* cflags, int64_t C, WalkCell* walk, int64_t* inv) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= C) return;
+  const int64_t c = perm[j];
+  WalkCell w;
+  w.begin = rm_begin[j]; w.eff_end = eff_end[c]; w.aux = 0; w.base = 0; w.heavy = (cflags[c] & GDB_CF_HEAVY) ? 1u : 0u;
+  walk[j] = w;
+  inv[c] = j;
+}
+__global__ void k_walk_window(const int64_t* inv, const uint32_t* cflags, const int64_t* hoff, const int32_t* k_lo, const uint32_t* tbase, const uint64_t* tmask,
+                              int64_t c_base, int64_t n, WalkCell* walk) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t c = c_base + i;
+  WalkCell* w = walk + inv[c];
+  if (cflags[c] & GDB_CF_HEAVY) { w->base = (uint32_t)hoff[i]; w->aux = (uint64_t)(int64_t)k_lo[c]; }
+  else { w->base = tbase[i]; w->aux = tmask[i]; }
+}
+
 struct AsmCtx {
-  RowIndex ri;
-  RecordTable rec;
-  SiteOut so;
-  const uint8_t* rtype;    // [P]
-  const uint2* desc;       // [S] (off16, len)
+  const int64_t* row_ptr;   // [N+1] row-major ranges
+  const int64_t* rm_begin;  // [C]   begin column in row-major order (binary search at the start of a run)
+  const WalkCell* walk;     // [C]
+  const int64_t* rec_start; // [P]
+  const uint8_t* rtype;     // [P]
+  const uint32_t* prefix_len; // [P] bytes of the fixed columns of a record (chunk 0 starts behind them)
+  const uint2* desc;        // [S] (off16, len)
   const char* pool;
-  const uint32_t* tbase;   // [CW] first slot of a plain cell (relative to light_base)
-  const uint64_t* tmask;   // [CW] types the cell has slots for
-  const int64_t* hoff;     // [CW] first incidence (fill order) of a heavy cell
-  const uint32_t* inc_pos; // [T]  fill order -> (record,row) order
-  const int64_t* eff_end;
-  const uint32_t* cflags;
-  const int32_t* k_lo;
-  int64_t c_base, c_end;
-  uint32_t light_base, heavy_base;
+  const uint32_t* inc_pos;  // [T]  fill order -> (record,row) order
+  const uint32_t* ubase;    // [P]  rank of a record among those with an untabled type
+  uint32_t light_base, heavy_base, row_base;
+  int32_t nrows;
 };
 
-// A lane follows one sample through consecutive records.  The live cell and what is needed to name its slot stay in
-// registers; memory is touched only when the sample moves to its next cell (every ~100 records).
+// A lane follows one sample through increasing records.  The live cell and what is needed to name its slot stay in
+// registers; memory is touched only when the sample moves to its next cell: one WalkCell plus the begin of the one behind.
 struct SlotWalker {
   int64_t j, j_end, next_begin, cur_end;
-  int64_t c;
-  uint64_t mask;
+  uint64_t aux;
   uint32_t base;
-  int32_t klo;
   bool heavy;
   __device__ __forceinline__ void load(const AsmCtx& a) {
-    next_begin = (j + 1 < j_end) ? a.ri.rm_begin[j + 1] : INT64_MAX;
-    const int64_t cc = a.ri.rm_cell[j];
-    c = -1; cur_end = INT64_MIN; heavy = false; mask = 0; base = 0; klo = 0;
-    if (cc < a.c_base || cc >= a.c_end) return;   // cannot reach the window
-    c = cc;
-    cur_end = a.eff_end[cc];
-    heavy = (a.cflags[cc] & GDB_CF_HEAVY) != 0;
-    const int64_t i = cc - a.c_base;
-    if (heavy) { base = (uint32_t)a.hoff[i]; klo = a.k_lo[cc]; }
-    else { base = a.tbase[i]; mask = a.tmask[i]; }
+    const WalkCell w = a.walk[j];
+    next_begin = (j + 1 < j_end) ? a.walk[j + 1].begin : INT64_MAX;
+    cur_end = w.eff_end; aux = w.aux; base = w.base; heavy = w.heavy != 0;
   }
   __device__ __forceinline__ void init(const AsmCtx& a, int32_t row, int64_t s0) {
-    const int64_t j_begin = a.ri.row_ptr[row];
-    j_end = a.ri.row_ptr[row + 1];
+    const int64_t j_begin = a.row_ptr[row];
+    j_end = a.row_ptr[row + 1];
     int64_t lo = j_begin, hi = j_end;  // last j with rm_begin[j] <= s0
-    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a.ri.rm_begin[mid] <= s0) lo = mid + 1; else hi = mid; }
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a.rm_begin[mid] <= s0) lo = mid + 1; else hi = mid; }
     j = lo - 1;
     if (j >= j_begin) load(a);
-    else { c = -1; cur_end = INT64_MIN; heavy = false; mask = 0; base = 0; klo = 0; next_begin = (j + 1 < j_end) ? a.ri.rm_begin[j + 1] : INT64_MAX; }
+    else { cur_end = INT64_MIN; heavy = false; aux = 0; base = 0; next_begin = (j + 1 < j_end) ? a.rm_begin[j + 1] : INT64_MAX; }
   }
   __device__ __forceinline__ void advance(const AsmCtx& a, int64_t s) { while (next_begin <= s) { ++j; load(a); } }
-  __device__ __forceinline__ int64_t live(int64_t s) const { return (c >= 0 && s <= cur_end) ? c : -1; }
-  __device__ __forceinline__ uint32_t slot(const AsmCtx& a, int64_t k, int64_t s, uint32_t t) const {
-    if (c < 0 || s > cur_end) return t == kUntabledType ? kDirectSlot : t;
-    if (heavy) return a.heavy_base + a.inc_pos[base + (uint32_t)(k - klo)];
-    if (t == kUntabledType) return kDirectSlot;
-    return a.light_base + base + (uint32_t)__popcll(mask & ((1ull << t) - 1ull));
+  // (a cell that ended before the window keeps stale base/aux, but it is dead for every record of the window)
+  __device__ __forceinline__ uint32_t slot(const AsmCtx& a, int64_t k, int64_t s, uint32_t t, int32_t row) const {
+    const bool dead = s > cur_end;
+    if (!dead && heavy) return a.heavy_base + a.inc_pos[base + (uint32_t)(k - (int64_t)aux)];
+    if (t == kUntabledType) return a.row_base + a.ubase[k] * (uint32_t)a.nrows + (uint32_t)row;
+    if (dead) return t;
+    return a.light_base + base + (uint32_t)__popcll(aux & ((1ull << t) - 1ull));
   }
 };
-
-__global__ void __launch_bounds__(kBlock)
-k_assemble_size(AsmCtx a, int32_t N, int nchunks, int run, uint64_t* chunk_size, uint32_t* err) {
-  const int64_t kb = (int64_t)blockIdx.x * run;
-  const int64_t ke = min(a.rec.npos, kb + (int64_t)run);
-  const int ch = blockIdx.y;
-  const int32_t r = ch * kBlock + (int32_t)threadIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __shared__ uint32_t wsum[kRun][kWavesPerBlock];
-  uint32_t e = 0;
-  SlotWalker w;
-  if (r < N) w.init(a, r, a.rec.start[kb]);
-  for (int64_t k0 = kb; k0 < ke; k0 += kRun) {        // uniform
-    const int64_t k1 = min(ke, k0 + (int64_t)kRun);
-    uint32_t lens[kRun];
-#pragma unroll
-    for (int i = 0; i < kRun; ++i) {
-      lens[i] = 0;
-      const int64_t k = k0 + i;
-      if (k < k1 && r < N) {
-        const int64_t s = a.rec.start[k];
-        w.advance(a, s);
-        const uint32_t sl = w.slot(a, k, s, a.rtype[k]);
-        if (sl != kDirectSlot) lens[i] = a.desc[sl].y;
-        else if (a.so.fmt_mask[k]) lens[i] = 1u + entry_length(load_record_info(a.so, c_ex.hl, k), w.live(s), &e);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < kRun; ++i) { uint32_t s = wave_reduce_sum(lens[i]); if (lane == 0) wsum[i][wave] = s; }
-    __syncthreads();
-    if (threadIdx.x < kRun) {
-      const int64_t k = k0 + threadIdx.x;
-      if (k < k1) {
-        uint64_t total = 0;
-        for (int wv = 0; wv < kWavesPerBlock; ++wv) total += wsum[threadIdx.x][wv];
-        if (ch == 0) total += a.so.prefix_len[k];
-        if (ch == nchunks - 1) total += 1;  // '\n'
-        chunk_size[k * nchunks + ch] = total;
-      }
-    }
-    __syncthreads();
-  }
-  if (e) atomicOr(err, e);
-}
 
 // Copy n bytes of a 16-byte aligned pool slot to an arbitrary LDS byte address: head bytes up to the next LDS word, then
 // whole words funnel-shifted out of consecutive source words (v_alignbyte), then the <4 tail bytes.  Executed by all lanes
-// of a wavefront with per-lane n (0: idle lane); the loop count is the wavefront maximum.
-__device__ __forceinline__ void copy_slot_to_lds(const char* __restrict__ src, gdb_lds_char* dst, uint32_t n) {
-  const uint32_t d = (uint32_t)(uintptr_t)dst;
-  uint32_t h = (4u - (d & 3u)) & 3u;
-  if (h > n) h = n;
-  const uint32_t nbody = (n - h) >> 2;                 // whole destination words
-  const uint32_t tb = h + (nbody << 2);                // first tail byte (source position)
-  __attribute__((address_space(3))) uint32_t* dw = (__attribute__((address_space(3))) uint32_t*)(dst + h);
-  uint32_t carry = 0;
-  // (the last destination word of a word-aligned copy takes only the carry: one more round without a load)
-  for (uint32_t q = 0; __any((int)((q << 4) < n || (q << 2) <= nbody)); ++q) {
-    uint4 x = make_uint4(0, 0, 0, 0);
-    if ((q << 4) < n) x = *reinterpret_cast<const uint4*>(src + (q << 4));
+// of a wavefront with per-lane n (0: idle lane).  The first 64 bytes are fetched with four independent loads before any
+// of them is consumed (one memory latency per entry, not one per 16 bytes); longer entries continue chunk by chunk.
+struct SlotCopy {
+  gdb_lds_char* dst;
+  __attribute__((address_space(3))) uint32_t* dw;
+  uint32_t n, h, nbody, tb, carry;
+  __device__ __forceinline__ void begin(gdb_lds_char* d, uint32_t len) {
+    dst = d; n = len;
+    h = (4u - ((uint32_t)(uintptr_t)d & 3u)) & 3u;
+    if (h > n) h = n;
+    nbody = (n - h) >> 2;            // whole destination words
+    tb = h + (nbody << 2);           // first tail byte (source position)
+    dw = (__attribute__((address_space(3))) uint32_t*)(d + h);
+    carry = 0;
+  }
+  // source chunk q (bytes [16q, 16q+16)) -> destination words 4q-1 .. 4q+2, head bytes (q = 0) and the tail bytes it holds
+  __device__ __forceinline__ void chunk(uint32_t q, const uint4& x) {
     if (q == 0) {
       if (h > 0) dst[0] = (char)(x.x & 0xFFu);
       if (h > 1) dst[1] = (char)((x.x >> 8) & 0xFFu);
       if (h > 2) dst[2] = (char)((x.x >> 16) & 0xFFu);
     }
-    // destination word m takes source bytes [h+4m, h+4m+4): low part in source word m, high part in word m+1
-    const int32_t m0 = (int32_t)(q << 2) - 1;
-    const uint32_t v0 = __builtin_amdgcn_alignbyte(x.x, carry, h);
-    const uint32_t v1 = __builtin_amdgcn_alignbyte(x.y, x.x, h);
-    const uint32_t v2 = __builtin_amdgcn_alignbyte(x.z, x.y, h);
-    const uint32_t v3 = __builtin_amdgcn_alignbyte(x.w, x.z, h);
-    if (m0 >= 0 && (uint32_t)m0 < nbody) dw[m0] = v0;
-    if ((uint32_t)(m0 + 1) < nbody) dw[m0 + 1] = v1;
-    if ((uint32_t)(m0 + 2) < nbody) dw[m0 + 2] = v2;
-    if ((uint32_t)(m0 + 3) < nbody) dw[m0 + 3] = v3;
+    const uint32_t m1 = q << 2;      // word m takes source bytes [h+4m, h+4m+4): low part in source word m, high part in m+1
+    if (m1 >= 1 && m1 - 1 < nbody) dw[m1 - 1] = __builtin_amdgcn_alignbyte(x.x, carry, h);
+    if (m1 < nbody) dw[m1] = __builtin_amdgcn_alignbyte(x.y, x.x, h);
+    if (m1 + 1 < nbody) dw[m1 + 1] = __builtin_amdgcn_alignbyte(x.z, x.y, h);
+    if (m1 + 2 < nbody) dw[m1 + 2] = __builtin_amdgcn_alignbyte(x.w, x.z, h);
     carry = x.w;
-    // tail bytes living in this source chunk
 #pragma unroll
     for (uint32_t u = 0; u < 3; ++u) {
       const uint32_t p = tb + u;
@@ -473,115 +489,170 @@ __device__ __forceinline__ void copy_slot_to_lds(const char* __restrict__ src, g
       }
     }
   }
+  // rounds needed: chunks holding source bytes, plus one carry-only round when the last body word ends a chunk exactly
+  __device__ __forceinline__ bool needs(uint32_t q) const { return (q << 4) < n || ((q << 2) <= nbody && nbody > 0 && q > 0); }
+};
+__device__ __forceinline__ uint4 load_chunk(const char* __restrict__ src, uint32_t q, uint32_t n) {
+  uint4 x = make_uint4(0, 0, 0, 0);
+  if ((q << 4) < n) x = *reinterpret_cast<const uint4*>(src + (q << 4));
+  return x;
+}
+// ---- wavefront scan / reduce on DPP (no LDS traffic) --------------------------------------------------------------------
+__device__ __forceinline__ uint32_t dpp_row_shr(uint32_t v, int n) {   // lane i <- lane i-n of the same 16-lane row, else 0
+  switch (n) {
+    case 1: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    case 2: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    case 4: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    default: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+  }
+}
+__device__ __forceinline__ uint32_t wave_inclusive_scan_dpp(uint32_t v) {
+  v += dpp_row_shr(v, 1);
+  v += dpp_row_shr(v, 2);
+  v += dpp_row_shr(v, 4);
+  v += dpp_row_shr(v, 8);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_total(uint32_t inclusive) { return (uint32_t)__builtin_amdgcn_readlane((int)inclusive, 63); }
+
+// ---- assembly kernels: one wavefront = `run` records of one type x 64 samples, no workgroup barriers ---------------------
+// Records are visited in (type, position) order (`order`): along such a run a sample keeps the same slot until its live
+// cell changes, so the slot descriptor and the first 80 text bytes stay in registers and memory is read only when the slot
+// id changes.  The per-record scalars (index, start, type, destination) are fetched 64 records at a time, one per lane, and
+// broadcast with v_readlane: no dependent scalar memory access inside the record loop.
+constexpr int kAsmRows = 64;         // samples per (record, chunk): one wavefront
+constexpr int kWaveLds = 8 * 1024;   // LDS image of one (record, chunk)
+constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
+
+__device__ __forceinline__ int64_t readlane64(int64_t v, int l) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)v, l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), l);
+  return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
-constexpr int kLdsBytes = 40 * 1024;
-
-__global__ void __launch_bounds__(kBlock)
-k_assemble_write(AsmCtx a, int32_t N, int nchunks, int run, int64_t k_begin, int64_t k_end, const uint64_t* chunk_off, uint64_t page_base,
-                 char* arena, uint32_t* err) {
-  const int64_t kb = k_begin + (int64_t)blockIdx.x * run;
-  const int64_t ke = min(k_end, kb + (int64_t)run);
+__global__ void __launch_bounds__(kAsmRows)
+k_assemble_size(AsmCtx a, const int32_t* __restrict__ order, int64_t n, int32_t N, int nchunks, int run, uint64_t* __restrict__ chunk_size) {
+  const int64_t ib = (int64_t)blockIdx.x * run;
+  const int64_t ie = min(n, ib + (int64_t)run);
   const int ch = blockIdx.y;
-  const int32_t r = ch * kBlock + (int32_t)threadIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __shared__ uint32_t wtot[kRun][kWavesPerBlock];
-  __shared__ uint32_t s_total[kRun], s_lbase[kRun];
-  __shared__ int32_t s_group[kRun], s_ngroups;
-  __shared__ uint64_t s_gdst[kRun];
-  __shared__ __attribute__((aligned(16))) char lds_buf[kLdsBytes];
-  uint32_t e = 0;
+  const int lane = threadIdx.x;
+  const int32_t r = ch * kAsmRows + lane;
   SlotWalker w;
-  if (r < N) w.init(a, r, a.rec.start[kb]);
-  for (int64_t k0 = kb; k0 < ke; k0 += kRun) {        // uniform
-    const int64_t k1 = min(ke, k0 + (int64_t)kRun);
-    const int nb = (int)(k1 - k0);
-    uint32_t lens[kRun], off16[kRun];
-    int32_t cells[kRun];                              // only read on the direct path
+  int64_t prev_k = INT64_MAX;
+  uint32_t cur_slot = kNoSlot, cur_len = 0;
+  for (int64_t i0 = ib; i0 < ie; i0 += 64) {                // uniform
+    const int cnt = (int)min((int64_t)64, ie - i0);
+    int32_t my_k = 0; int64_t my_s = 0; uint32_t my_t = 0; uint64_t my_total = 0;
+    if (lane < cnt) {
+      my_k = order[i0 + lane];
+      my_s = a.rec_start[my_k];
+      my_t = a.rtype[my_k];
+      if (ch == 0) my_total = a.prefix_len[my_k];
+      if (ch == nchunks - 1) my_total += 1;                 // '\n'
+    }
+    for (int jj = 0; jj < cnt; ++jj) {                      // uniform
+      const int64_t k = __builtin_amdgcn_readlane(my_k, jj);
+      const int64_t s = readlane64(my_s, jj);
+      const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)my_t, jj);
+      uint32_t len = 0;
+      if (r < N) {
+        if (k < prev_k) w.init(a, r, s); else w.advance(a, s);  // uniform branch: a new type restarts at its first record
+        const uint32_t sl = w.slot(a, k, s, t, r);
+        if (sl != cur_slot) { cur_slot = sl; cur_len = a.desc[sl].y; }
+        len = cur_len;
+      }
+      prev_k = k;
+      const uint32_t total = wave_total(wave_inclusive_scan_dpp(len));
+      if (lane == jj) my_total += total;
+    }
+    if (lane < cnt) chunk_size[(int64_t)my_k * nchunks + ch] = my_total;
+  }
+}
+
+constexpr int kTextChunks = 5;       // 16-byte chunks of a slot kept in registers
+struct SlotText { uint4 x[kTextChunks]; };
+
+__global__ void __launch_bounds__(kAsmRows)
+k_assemble_write(AsmCtx a, const int32_t* __restrict__ order, int64_t n, int32_t N, int nchunks, int run, const uint64_t* __restrict__ chunk_off,
+                 uint64_t page_base, char* __restrict__ arena) {
+  const int64_t ib = (int64_t)blockIdx.x * run;
+  const int64_t ie = min(n, ib + (int64_t)run);
+  const int ch = blockIdx.y;
+  const int lane = threadIdx.x;
+  const int32_t r = ch * kAsmRows + lane;
+  __shared__ __attribute__((aligned(16))) char lds_buf[kWaveLds + 16];
+  SlotWalker w;
+  int64_t prev_k = INT64_MAX;
+  uint32_t cur_slot = kNoSlot, cur_len = 0;
+  const char* cur_src = a.pool;
+  SlotText txt;
 #pragma unroll
-    for (int i = 0; i < kRun; ++i) {
-      lens[i] = 0; off16[i] = 0; cells[i] = -1;
-      const int64_t k = k0 + i;
-      if (k < k1 && r < N) {
-        const int64_t s = a.rec.start[k];
-        w.advance(a, s);
-        const uint32_t sl = w.slot(a, k, s, a.rtype[k]);
-        if (sl != kDirectSlot) { const uint2 dsc = a.desc[sl]; off16[i] = dsc.x; lens[i] = dsc.y; }
-        else if (a.so.fmt_mask[k]) {
-          cells[i] = (int32_t)w.live(s);
-          off16[i] = kDirectSlot;
-          lens[i] = 1u + entry_length(load_record_info(a.so, c_ex.hl, k), (int64_t)cells[i], &e);
+  for (int q = 0; q < kTextChunks; ++q) txt.x[q] = make_uint4(0, 0, 0, 0);
+  for (int64_t i0 = ib; i0 < ie; i0 += 64) {                // uniform
+    const int cnt = (int)min((int64_t)64, ie - i0);
+    int32_t my_k = 0; int64_t my_s = 0; uint32_t my_t = 0; int64_t my_dst = 0;
+    if (lane < cnt) {
+      my_k = order[i0 + lane];
+      my_s = a.rec_start[my_k];
+      my_t = a.rtype[my_k];
+      my_dst = (int64_t)(chunk_off[(int64_t)my_k * nchunks + ch] - page_base) + (ch == 0 ? a.prefix_len[my_k] : 0u);
+    }
+    for (int jj = 0; jj < cnt; ++jj) {                      // uniform
+      const int64_t k = __builtin_amdgcn_readlane(my_k, jj);
+      const int64_t s = readlane64(my_s, jj);
+      const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)my_t, jj);
+      uint32_t len = 0;
+      if (r < N) {
+        if (k < prev_k) w.init(a, r, s); else w.advance(a, s);  // uniform branch
+        const uint32_t sl = w.slot(a, k, s, t, r);
+        if (sl != cur_slot) {
+          cur_slot = sl;
+          const uint2 dsc = a.desc[sl];
+          cur_len = dsc.y;
+          cur_src = a.pool + (size_t)dsc.x * 16;
+#pragma unroll
+          for (int q = 0; q < kTextChunks; ++q) txt.x[q] = load_chunk(cur_src, q, cur_len);
         }
+        len = cur_len;
       }
-    }
-    uint32_t excl[kRun];
+      prev_k = k;
+      const uint32_t inc = wave_inclusive_scan_dpp(len);
+      const uint32_t excl = inc - len;
+      const uint32_t total = wave_total(inc);
+      if (total == 0) continue;                             // uniform: no FORMAT columns in this record
+      char* gdst = arena + readlane64(my_dst, jj);
+      const uint32_t al = (uint32_t)((uintptr_t)gdst & 15u);
+      if (al + total <= (uint32_t)kWaveLds) {               // uniform
+        SlotCopy cp;
+        cp.begin((gdb_lds_char*)lds_buf + al + excl, len);
+        cp.chunk(0, txt.x[0]);
 #pragma unroll
-    for (int i = 0; i < kRun; ++i) {
-      const uint32_t inc = wave_inclusive_scan(lens[i], lane);
-      excl[i] = inc - lens[i];
-      if (lane == 63) wtot[i][wave] = inc;
-    }
-    __syncthreads();
-    // one thread lays the batch out: records are packed into LDS groups, each image at its destination's offset mod 16
-    if (threadIdx.x == 0) {
-      uint32_t cur = 0;
-      int grp = 0;
-      for (int i = 0; i < nb; ++i) {
-        uint32_t total = 0;
-        for (int wv = 0; wv < kWavesPerBlock; ++wv) total += wtot[i][wv];
-        const int64_t k = k0 + i;
-        const uint64_t g = (uint64_t)(uintptr_t)arena + (chunk_off[k * nchunks + ch] - page_base) + (ch == 0 ? a.so.prefix_len[k] : 0u);
-        const uint32_t sp = (((uint32_t)(g & 15u) + total + 15u) & ~15u);
-        s_total[i] = total; s_gdst[i] = g;
-        if (sp > (uint32_t)kLdsBytes) { if (cur) { ++grp; cur = 0; } s_group[i] = grp++; s_lbase[i] = 0xFFFFFFFFu; continue; }   // oversize: own group, direct
-        if (cur + sp > (uint32_t)kLdsBytes) { ++grp; cur = 0; }
-        s_group[i] = grp; s_lbase[i] = cur;
-        cur += sp;
-      }
-      s_ngroups = nb ? s_group[nb - 1] + 1 : 0;
-    }
-    __syncthreads();
-    const int ngroups = s_ngroups;
-    for (int g = 0; g < ngroups; ++g) {               // uniform
-#pragma unroll
-      for (int i = 0; i < kRun; ++i) {
-        if (i >= nb || s_group[i] != g || s_total[i] == 0) continue;   // uniform
-        uint32_t base = 0;
-        for (int wv = 0; wv < wave; ++wv) base += wtot[i][wv];
-        char* gdst = (char*)(uintptr_t)s_gdst[i];
-        const uint32_t lbase = s_lbase[i];
-        if (lbase != 0xFFFFFFFFu) {
-          gdb_lds_char* ldst = (gdb_lds_char*)lds_buf + lbase + (uint32_t)((uintptr_t)gdst & 15u) + base + excl[i];
-          const bool direct = off16[i] == kDirectSlot;
-          copy_slot_to_lds(a.pool + (size_t)(direct ? 0u : off16[i]) * 16, ldst, direct ? 0u : lens[i]);
-          if (direct && lens[i]) { *ldst = '\t'; entry_store_lds(load_record_info(a.so, c_ex.hl, k0 + i), (int64_t)cells[i], ldst + 1, &e); }
-        } else if (lens[i]) {                         // chunk larger than the LDS image (very long PL vectors): straight to HBM
-          char* dst = gdst + base + excl[i];
-          if (off16[i] == kDirectSlot) { *dst = '\t'; entry_store(load_record_info(a.so, c_ex.hl, k0 + i), (int64_t)cells[i], dst + 1, &e); }
-          else { const char* src = a.pool + (size_t)off16[i] * 16; for (uint32_t b = 0; b < lens[i]; ++b) dst[b] = src[b]; }
-        }
-      }
-      __syncthreads();
-      for (int i = 0; i < nb; ++i) {
-        if (s_group[i] != g || s_total[i] == 0 || s_lbase[i] == 0xFFFFFFFFu) continue;   // uniform
-        char* gdst = (char*)(uintptr_t)s_gdst[i];
-        const uint32_t total = s_total[i];
-        const uint32_t al = (uint32_t)((uintptr_t)gdst & 15u);
-        const char* img = lds_buf + s_lbase[i] + al;
+        for (int q = 1; q < kTextChunks; ++q) if (__any((int)cp.needs(q))) cp.chunk(q, txt.x[q]);
+        for (uint32_t q = kTextChunks; __any((int)cp.needs(q)); ++q) cp.chunk(q, load_chunk(cur_src, q, len));
+        __syncthreads();                                    // one wavefront per workgroup: orders the LDS image, no s_barrier wait
+        const char* img = lds_buf + al;
         uint32_t head = (16u - al) & 15u;
         if (head > total) head = total;
         const uint32_t nwords = (total - head) >> 4;
         const uint32_t tail_at = head + (nwords << 4);
-        if (threadIdx.x < head) gdst[threadIdx.x] = img[threadIdx.x];
+        if ((uint32_t)lane < head) gdst[lane] = img[lane];
         const uint4* lsrc = reinterpret_cast<const uint4*>(img + head);
         uint4* gw = reinterpret_cast<uint4*>(gdst + head);
-        for (uint32_t wq = threadIdx.x; wq < nwords; wq += kBlock) gw[wq] = lsrc[wq];
-        if (threadIdx.x < total - tail_at) gdst[tail_at + threadIdx.x] = img[tail_at + threadIdx.x];
+        for (uint32_t wq = lane; wq < nwords; wq += kAsmRows) gw[wq] = lsrc[wq];
+        if ((uint32_t)lane < total - tail_at) gdst[tail_at + lane] = img[tail_at + lane];
+        __syncthreads();
+      } else {                                              // longer than the LDS image (very long PL vectors): straight to HBM
+        char* dst = gdst + excl;
+        for (uint32_t b = 0; b < len; ++b) dst[b] = cur_src[b];
       }
-      __syncthreads();
     }
   }
-  if (e) atomicOr(err, e);
+}
+__global__ void k_iota32(int32_t base, int64_t n, int32_t* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = base + (int32_t)i;
 }
 
 __global__ void k_copy_offsets(const uint32_t* src, int64_t n, uint32_t base, uint32_t* dst) {
@@ -627,6 +698,8 @@ struct DevicePipeline::Impl {
   DevBuf<SiteCtx> d_sx;
   // entry text table
   DevBuf<unsigned long long> type_hkeys; DevBuf<int32_t> type_hrep, type_rep; DevBuf<uint8_t> type_hid, rtype;
+  DevBuf<WalkCell> walk; DevBuf<int64_t> walk_inv;
+  DevBuf<uint32_t> untabled, ubase; DevBuf<int32_t> urec, iota, order; DevBuf<uint8_t> rtype_sorted;
   DevBuf<uint64_t> tmask; DevBuf<uint32_t> nslots, tbase, inc_pos, slot_len, slot_units, slot_off; DevBuf<uint2> slot_desc; DevBuf<char> pool;
   bool classified = false;
   struct Part { FragmentView v; std::vector<size_t> data_bytes; std::vector<void*> bufs; };
@@ -673,6 +746,12 @@ struct DevicePipeline::Impl {
     HIP_CHECK(hipMemcpyAsync(&v, p, sizeof(T), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
     return v;
+  }
+  // records [k0, k0+n) in (type, position) order -> order[]
+  void order_by_type(int64_t k0, int64_t n) {
+    iota.ensure(n); order.ensure(n); rtype_sorted.ensure(n);
+    hipLaunchKernelGGL(k_iota32, dim3(blocks_for(n)), dim3(kBlock), 0, stream, (int32_t)k0, n, iota.p);
+    sort_pairs(rtype.p + k0, rtype_sorted.p, iota.p, order.p, (size_t)n, 8);
   }
   void free_owned() { for (void* p : owned) (void)hipFree(p); owned.clear(); }
 };
@@ -871,6 +950,9 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
       void* t = S.temp_storage(bytes);
       HIP_CHECK(rocprim::reduce(t, bytes, S.span.p, S.span_max.p, (int64_t)0, (size_t)C, rocprim::maximum<int64_t>(), st));
     }
+    S.walk.ensure(C); S.walk_inv.ensure(C);
+    STAGE("k_walk_static");
+    hipLaunchKernelGGL(k_walk_static, dim3(blocks_for(C)), dim3(kBlock), 0, st, S.perm.p, S.rm_begin.p, S.eff_end.p, S.cflags.p, C, S.walk.p, S.walk_inv.p);
     S.max_span = S.read_back(S.span_max.p);
     S.classified = true;
   }
@@ -979,7 +1061,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   hipLaunchKernelGGL(k_site_size, dim3(blocks_for(P, 64)), dim3(64), 0, st, S.d_sx.p, S.err.p);
   HIP_CHECK(hipEventRecord(ev[2], st));
   // ---- S8 sample-column sizes + offsets ---------------------------------------------------------------------------
-  const int nchunks = (N + kBlock - 1) / kBlock;
+  const int nchunks = (N + kAsmRows - 1) / kAsmRows;
   const size_t nchunk_total = (size_t)P * nchunks;
   S.chunk_size.ensure(nchunk_total + 1); S.chunk_off.ensure(nchunk_total + 2); S.rec_off.ensure(P + 2);
   RowIndex ri{S.row_ptr.p, S.perm.p, S.rm_begin.p};
@@ -995,24 +1077,29 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   HIP_CHECK(hipMemsetAsync(S.type_rep.p, 0, kMaxTypes * sizeof(int32_t), st));
   STAGE("k_type_insert");
   hipLaunchKernelGGL(k_type_insert, dim3(blocks_for(P)), dim3(kBlock), 0, st, so, P, S.type_hkeys.p, S.type_hrep.p);
-  hipLaunchKernelGGL(k_type_assign, dim3(1), dim3(1), 0, st, S.type_hkeys.p, S.type_hrep.p, max_tabled_types(), S.type_hid.p, S.type_rep.p, S.counters.p + 1);
-  hipLaunchKernelGGL(k_type_lookup, dim3(blocks_for(P)), dim3(kBlock), 0, st, so, P, S.type_hkeys.p, S.type_hid.p, S.rtype.p);
+  hipLaunchKernelGGL(k_type_assign, dim3(1), dim3(64), 0, st, S.type_hkeys.p, S.type_hrep.p, max_tabled_types(), S.type_hid.p, S.type_rep.p, S.counters.p + 1);
+  S.untabled.ensure(P + 1); S.ubase.ensure(P + 1); S.urec.ensure(P + 1);
+  hipLaunchKernelGGL(k_type_lookup, dim3(blocks_for(P)), dim3(kBlock), 0, st, so, P, S.type_hkeys.p, S.type_hid.p, S.rtype.p, S.untabled.p);
+  S.excl_scan(S.untabled.p, S.ubase.p, (size_t)P);
+  const int64_t UR = (int64_t)S.read_back(S.ubase.p + (P - 1)) + S.read_back(S.untabled.p + (P - 1));
+  if (UR > 0) hipLaunchKernelGGL(k_untabled_records, dim3(blocks_for(P)), dim3(kBlock), 0, st, S.untabled.p, S.ubase.p, P, S.urec.p);
   S.tmask.ensure(CW); S.nslots.ensure(CW + 1); S.tbase.ensure(CW + 1);
   STAGE("k_cell_types");
   hipLaunchKernelGGL(k_cell_types, dim3(blocks_for(CW)), dim3(kBlock), 0, st, S.cflags.p, S.k_lo.p, S.k_hi.p, S.rtype.p, c_base, CW, S.tmask.p, S.nslots.p);
   S.excl_scan(S.nslots.p, S.tbase.p, (size_t)CW);
   const uint64_t SL = (uint64_t)S.read_back(S.tbase.p + (CW - 1)) + S.read_back(S.nslots.p + (CW - 1));
   const int ntypes = S.read_back(S.counters.p + 1);
-  const uint64_t NS = (uint64_t)kMaxTypes + SL + (uint64_t)T;
+  const uint64_t NS = (uint64_t)kMaxTypes + SL + (uint64_t)T + (uint64_t)UR * (uint64_t)N;
   if (NS >= (1ull << 32)) throw GenomicsDBDeviceException("entry text table exceeds 2^32 slots: split the query interval");
   S.inc_pos.ensure(T + 1);
   if (T > 0) hipLaunchKernelGGL(k_inc_pos, dim3(blocks_for(T)), dim3(kBlock), 0, st, S.inc_keys_sorted.p, S.inc_vals_sorted.p, S.hoff.p, S.k_lo.p, c_base, T, (int64_t)N, S.inc_pos.p);
   S.slot_len.ensure(NS + 1); S.slot_units.ensure(NS + 1); S.slot_off.ensure(NS + 1); S.slot_desc.ensure(NS + 1);
-  SlotTable stt{S.slot_len.p, S.slot_off.p, nullptr, (uint32_t)kMaxTypes, (uint32_t)(kMaxTypes + SL)};
+  SlotTable stt{S.slot_len.p, S.slot_off.p, nullptr, (uint32_t)kMaxTypes, (uint32_t)(kMaxTypes + SL), (uint32_t)(kMaxTypes + SL + (uint64_t)T)};
   STAGE("k_slots<0>");
   hipLaunchKernelGGL(k_slots_nocall<0>, dim3(1), dim3(kMaxTypes), 0, st, stt, so, S.type_rep.p, ntypes, S.err.p);
-  hipLaunchKernelGGL(k_slots_light<0>, dim3(blocks_for(CW, 64)), dim3(64), 0, st, stt, so, S.type_rep.p, S.tmask.p, S.tbase.p, c_base, CW, S.err.p);
+  hipLaunchKernelGGL(k_slots_light<0>, dim3(blocks_for(CW, kSlotBlock)), dim3(kSlotBlock), 0, st, stt, so, S.type_rep.p, S.tmask.p, S.tbase.p, c_base, CW, S.err.p);
   if (T > 0) hipLaunchKernelGGL(k_slots_heavy<0>, dim3(blocks_for(T, 64)), dim3(64), 0, st, stt, so, S.inc_keys_sorted.p, S.inc_vals_sorted.p, T, (int64_t)N, S.err.p);
+  if (UR > 0) hipLaunchKernelGGL(k_slots_untabled<0>, dim3(blocks_for(UR * N, 64)), dim3(64), 0, st, stt, so, ri, rec, S.urec.p, UR, N, S.err.p);
   hipLaunchKernelGGL(k_slot_units, dim3(blocks_for((int64_t)NS)), dim3(kBlock), 0, st, S.slot_len.p, (int64_t)NS, S.slot_units.p);
   S.excl_scan(S.slot_units.p, S.slot_off.p, (size_t)NS);
   const uint64_t pool_units = (uint64_t)S.read_back(S.slot_off.p + (NS - 1)) + S.read_back(S.slot_units.p + (NS - 1));
@@ -1021,19 +1108,29 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   stt.pool = S.pool.p;
   STAGE("k_slots<1>");
   hipLaunchKernelGGL(k_slots_nocall<1>, dim3(1), dim3(kMaxTypes), 0, st, stt, so, S.type_rep.p, ntypes, S.err.p);
-  hipLaunchKernelGGL(k_slots_light<1>, dim3(blocks_for(CW, 64)), dim3(64), 0, st, stt, so, S.type_rep.p, S.tmask.p, S.tbase.p, c_base, CW, S.err.p);
+  hipLaunchKernelGGL(k_slots_light<1>, dim3(blocks_for(CW, kSlotBlock)), dim3(kSlotBlock), 0, st, stt, so, S.type_rep.p, S.tmask.p, S.tbase.p, c_base, CW, S.err.p);
   if (T > 0) hipLaunchKernelGGL(k_slots_heavy<1>, dim3(blocks_for(T, 64)), dim3(64), 0, st, stt, so, S.inc_keys_sorted.p, S.inc_vals_sorted.p, T, (int64_t)N, S.err.p);
+  if (UR > 0) hipLaunchKernelGGL(k_slots_untabled<1>, dim3(blocks_for(UR * N, 64)), dim3(64), 0, st, stt, so, ri, rec, S.urec.p, UR, N, S.err.p);
   hipLaunchKernelGGL(k_slot_desc, dim3(blocks_for((int64_t)NS)), dim3(kBlock), 0, st, S.slot_len.p, S.slot_off.p, (int64_t)NS, S.slot_desc.p);
   stats.num_record_types = ntypes;
   stats.num_text_slots = (int64_t)NS;
   stats.text_pool_bytes = (int64_t)(pool_units * 16);
-  AsmCtx ac{ri, rec, so, S.rtype.p, S.slot_desc.p, S.pool.p, S.tbase.p, S.tmask.p, S.hoff.p, S.inc_pos.p, S.eff_end.p, S.cflags.p, S.k_lo.p,
-            c_base, c_end, (uint32_t)kMaxTypes, (uint32_t)(kMaxTypes + SL)};
+  STAGE("k_walk_window");
+  hipLaunchKernelGGL(k_walk_window, dim3(blocks_for(CW)), dim3(kBlock), 0, st, S.walk_inv.p, S.cflags.p, S.hoff.p, S.k_lo.p, S.tbase.p, S.tmask.p, c_base, CW, S.walk.p);
+  AsmCtx ac{S.row_ptr.p, S.rm_begin.p, S.walk.p, S.rstart.p, S.rtype.p, S.prefix_len.p, S.slot_desc.p, S.pool.p, S.inc_pos.p, S.ubase.p,
+            (uint32_t)kMaxTypes, (uint32_t)(kMaxTypes + SL), (uint32_t)(kMaxTypes + SL + (uint64_t)T), N};
   // ---- S8b sample-column sizes + offsets ---------------------------------------------------------------------------
   const int run = run_length(P, nchunks);
   const unsigned run_blocks = (unsigned)((P + run - 1) / run);
   STAGE("k_assemble_size");
-  hipLaunchKernelGGL(k_assemble_size, dim3(run_blocks, nchunks), dim3(kBlock), 0, st, ac, N, nchunks, run, S.chunk_size.p, S.err.p);
+  if (getenv("GDBAMD_DEBUG_OCC")) {
+    int nb1 = 0, nb2 = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, k_assemble_size, kAsmRows, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, k_assemble_write, kAsmRows, 0);
+    fprintf(stderr, "[gdbamd] occupancy blocks/CU: size %d write %d; grid %u x %d run %d\n", nb1, nb2, run_blocks, nchunks, run);
+  }
+  S.order_by_type(0, P);
+  hipLaunchKernelGGL(k_assemble_size, dim3(run_blocks, nchunks), dim3(kAsmRows), 0, st, ac, S.order.p, P, N, nchunks, run, S.chunk_size.p);
   HIP_CHECK(hipMemsetAsync(S.chunk_size.p + nchunk_total, 0, sizeof(uint64_t), st));
   S.excl_scan(S.chunk_size.p, S.chunk_off.p, nchunk_total + 1);
   STAGE("k_gather_record_offsets");
@@ -1083,8 +1180,9 @@ bool DevicePipeline::next_page(uint64_t arena_bytes, const char** dev_ptr, uint6
   HIP_CHECK(hipEventRecord(w1, st));
   STAGE("k_assemble_write");
   const int wrun = run_length(np, iv.nchunks);
-  hipLaunchKernelGGL(k_assemble_write, dim3((unsigned)((np + wrun - 1) / wrun), iv.nchunks), dim3(kBlock), 0, st, iv.ac, N, iv.nchunks, wrun, kp, ke,
-                     S.chunk_off.p, page_base, S.arena.p, S.err.p);
+  S.order_by_type(kp, np);
+  hipLaunchKernelGGL(k_assemble_write, dim3((unsigned)((np + wrun - 1) / wrun), iv.nchunks), dim3(kAsmRows), 0, st, iv.ac, S.order.p, np, N, iv.nchunks, wrun,
+                     S.chunk_off.p, page_base, S.arena.p);
   HIP_CHECK(hipEventRecord(w2, st));
   HIP_CHECK(hipStreamSynchronize(st));
   float ms_site = 0, ms_entry = 0;
