@@ -59,6 +59,22 @@ inline int max_tabled_types() {
   const char* e = getenv("GDBAMD_MAX_TYPES");   // read per interval: tests flip it in-process
   return e && *e ? std::max(0, std::min(64, atoi(e))) : 64;
 }
+// HBM the resolved (record, sample) matrix of a whole interval may take (8 bytes x records x samples rounded up to 64);
+// wider intervals resolve page by page.  GDBAMD_RESOLVED_MB overrides (tests use 0 to force the per-page path).
+inline uint64_t resolved_budget_bytes() {
+  const char* e = getenv("GDBAMD_RESOLVED_MB");
+  return e && *e ? (uint64_t)atoll(e) << 20 : (uint64_t)32 << 30;
+}
+// chunks (x 64 samples) one wavefront of the write kernel assembles in lock step
+inline int assemble_group() {
+  const char* e = getenv("GDBAMD_ASM_GROUP");
+  const int g = e && *e ? atoi(e) : 1;
+  return g >= 4 ? 4 : g >= 2 ? 2 : 1;
+}
+inline int order_block_log2() {
+  const char* e = getenv("GDBAMD_ORDER_BLOCK_LOG2");
+  return e && *e ? std::max(0, std::min(30, atoi(e))) : 7;
+}
 inline unsigned blocks_for(int64_t n, int b = kBlock) { return (unsigned)std::max<int64_t>(1, (n + b - 1) / b); }
 inline int bits_for(uint64_t max_value) { int b = 1; while (b < 64 && (max_value >> b)) ++b; return std::min(64, b + 1); }
 
@@ -449,48 +465,39 @@ struct SlotWalker {
   }
 };
 
-// Copy n bytes of a 16-byte aligned pool slot to an arbitrary LDS byte address: head bytes up to the next LDS word, then
-// whole words funnel-shifted out of consecutive source words (v_alignbyte), then the <4 tail bytes.  Executed by all lanes
-// of a wavefront with per-lane n (0: idle lane).  The first 64 bytes are fetched with four independent loads before any
-// of them is consumed (one memory latency per entry, not one per 16 bytes); longer entries continue chunk by chunk.
+// Copy n bytes of a 16-byte aligned pool slot to an arbitrary LDS byte address, executed by all lanes of a wavefront
+// with per-lane n (0: idle lane).  Destination words are funnel-shifted out of consecutive source words (v_alignbyte).
+// The last, partial word is stored whole: it spills at most 3 bytes past the entry, and every spilled byte is a HEAD byte
+// (the bytes before the first word boundary) of one of the following entries.  The head bytes are therefore written by
+// finish(), after the words of all lanes (LDS executes a wavefront's instructions in order), which repairs the spill.
 struct SlotCopy {
   gdb_lds_char* dst;
   __attribute__((address_space(3))) uint32_t* dw;
-  uint32_t n, h, nbody, tb, carry;
+  uint32_t n, h, nw, carry, head_word;
   __device__ __forceinline__ void begin(gdb_lds_char* d, uint32_t len) {
     dst = d; n = len;
     h = (4u - ((uint32_t)(uintptr_t)d & 3u)) & 3u;
     if (h > n) h = n;
-    nbody = (n - h) >> 2;            // whole destination words
-    tb = h + (nbody << 2);           // first tail byte (source position)
+    nw = (n - h + 3u) >> 2;          // destination words, the last one possibly partial
     dw = (__attribute__((address_space(3))) uint32_t*)(d + h);
-    carry = 0;
+    carry = 0; head_word = 0;
   }
-  // source chunk q (bytes [16q, 16q+16)) -> destination words 4q-1 .. 4q+2, head bytes (q = 0) and the tail bytes it holds
+  // source chunk q (bytes [16q, 16q+16)) -> destination words 4q-1 .. 4q+2
   __device__ __forceinline__ void chunk(uint32_t q, const uint4& x) {
-    if (q == 0) {
-      if (h > 0) dst[0] = (char)(x.x & 0xFFu);
-      if (h > 1) dst[1] = (char)((x.x >> 8) & 0xFFu);
-      if (h > 2) dst[2] = (char)((x.x >> 16) & 0xFFu);
-    }
+    if (q == 0) head_word = x.x;
     const uint32_t m1 = q << 2;      // word m takes source bytes [h+4m, h+4m+4): low part in source word m, high part in m+1
-    if (m1 >= 1 && m1 - 1 < nbody) dw[m1 - 1] = __builtin_amdgcn_alignbyte(x.x, carry, h);
-    if (m1 < nbody) dw[m1] = __builtin_amdgcn_alignbyte(x.y, x.x, h);
-    if (m1 + 1 < nbody) dw[m1 + 1] = __builtin_amdgcn_alignbyte(x.z, x.y, h);
-    if (m1 + 2 < nbody) dw[m1 + 2] = __builtin_amdgcn_alignbyte(x.w, x.z, h);
+    if (m1 >= 1 && m1 - 1 < nw) dw[m1 - 1] = __builtin_amdgcn_alignbyte(x.x, carry, h);
+    if (m1 < nw) dw[m1] = __builtin_amdgcn_alignbyte(x.y, x.x, h);
+    if (m1 + 1 < nw) dw[m1 + 1] = __builtin_amdgcn_alignbyte(x.z, x.y, h);
+    if (m1 + 2 < nw) dw[m1 + 2] = __builtin_amdgcn_alignbyte(x.w, x.z, h);
     carry = x.w;
-#pragma unroll
-    for (uint32_t u = 0; u < 3; ++u) {
-      const uint32_t p = tb + u;
-      if (p < n && (p >> 4) == q) {
-        const uint32_t wsel = (p >> 2) & 3u;
-        const uint32_t word = wsel == 0 ? x.x : wsel == 1 ? x.y : wsel == 2 ? x.z : x.w;
-        dst[p] = (char)((word >> ((p & 3u) << 3)) & 0xFFu);
-      }
-    }
   }
-  // rounds needed: chunks holding source bytes, plus one carry-only round when the last body word ends a chunk exactly
-  __device__ __forceinline__ bool needs(uint32_t q) const { return (q << 4) < n || ((q << 2) <= nbody && nbody > 0 && q > 0); }
+  __device__ __forceinline__ bool needs(uint32_t q) const { return (q << 2) <= nw && nw > 0; }   // q >= 1
+  __device__ __forceinline__ void finish() const {
+    if (h > 0) dst[0] = (char)(head_word & 0xFFu);
+    if (h > 1) dst[1] = (char)((head_word >> 8) & 0xFFu);
+    if (h > 2) dst[2] = (char)((head_word >> 16) & 0xFFu);
+  }
 };
 __device__ __forceinline__ uint4 load_chunk(const char* __restrict__ src, uint32_t q, uint32_t n) {
   uint4 x = make_uint4(0, 0, 0, 0);
@@ -519,9 +526,11 @@ __device__ __forceinline__ uint32_t wave_total(uint32_t inclusive) { return (uin
 
 // ---- assembly kernels: one wavefront = `run` records of one type x 64 samples, no workgroup barriers ---------------------
 // Records are visited in (type, position) order (`order`): along such a run a sample keeps the same slot until its live
-// cell changes, so the slot descriptor and the first 80 text bytes stay in registers and memory is read only when the slot
-// id changes.  The per-record scalars (index, start, type, destination) are fetched 64 records at a time, one per lane, and
-// broadcast with v_readlane: no dependent scalar memory access inside the record loop.
+// cell changes.  k_assemble_size walks the samples (the only pass with dependent loads: walk list -> incidence -> slot
+// descriptor), adds up the chunk sizes and leaves the resolved (pool offset, length) of every (record, sample) in a
+// matrix; k_assemble_write streams that matrix (coalesced, prefetched one record ahead), keeps the current text of each
+// sample in registers, and reads the pool only when a sample's slot changes.  The per-record scalars (index, start, type,
+// destination) are fetched 64 records at a time, one per lane, and broadcast with v_readlane.
 constexpr int kAsmRows = 64;         // samples per (record, chunk): one wavefront
 constexpr int kWaveLds = 8 * 1024;   // LDS image of one (record, chunk)
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
@@ -532,16 +541,21 @@ __device__ __forceinline__ int64_t readlane64(int64_t v, int l) {
   return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
+// chunk_size == nullptr: resolve only (per-page matrix when the whole interval's matrix would not fit the budget)
 __global__ void __launch_bounds__(kAsmRows)
-k_assemble_size(AsmCtx a, const int32_t* __restrict__ order, int64_t n, int32_t N, int nchunks, int run, uint64_t* __restrict__ chunk_size) {
-  const int64_t ib = (int64_t)blockIdx.x * run;
+k_assemble_size(AsmCtx a, const int32_t* __restrict__ order, int64_t n, int32_t N, int nchunks, int run, uint64_t* __restrict__ chunk_size,
+                uint2* __restrict__ resolved, int64_t resolved_base) {
+  // chunk is the fast grid dimension: the wavefronts in flight work on the same few records (one 44 KB line is written
+  // by its 16 chunk wavefronts at about the same time: DRAM pages, TLB entries and shared boundary lines stay hot)
+  const int64_t ib = (int64_t)(blockIdx.x / (unsigned)nchunks) * run;
   const int64_t ie = min(n, ib + (int64_t)run);
-  const int ch = blockIdx.y;
+  const int ch = (int)(blockIdx.x % (unsigned)nchunks);
   const int lane = threadIdx.x;
   const int32_t r = ch * kAsmRows + lane;
   SlotWalker w;
   int64_t prev_k = INT64_MAX;
-  uint32_t cur_slot = kNoSlot, cur_len = 0;
+  uint32_t cur_slot = kNoSlot;
+  uint2 cur = make_uint2(0, 0);
   for (int64_t i0 = ib; i0 < ie; i0 += 64) {                // uniform
     const int cnt = (int)min((int64_t)64, ie - i0);
     int32_t my_k = 0; int64_t my_s = 0; uint32_t my_t = 0; uint64_t my_total = 0;
@@ -556,103 +570,137 @@ k_assemble_size(AsmCtx a, const int32_t* __restrict__ order, int64_t n, int32_t 
       const int64_t k = __builtin_amdgcn_readlane(my_k, jj);
       const int64_t s = readlane64(my_s, jj);
       const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)my_t, jj);
-      uint32_t len = 0;
+      uint2 d = make_uint2(0, 0);
       if (r < N) {
         if (k < prev_k) w.init(a, r, s); else w.advance(a, s);  // uniform branch: a new type restarts at its first record
         const uint32_t sl = w.slot(a, k, s, t, r);
-        if (sl != cur_slot) { cur_slot = sl; cur_len = a.desc[sl].y; }
-        len = cur_len;
+        if (sl != cur_slot) { cur_slot = sl; cur = a.desc[sl]; }
+        d = cur;
       }
       prev_k = k;
-      const uint32_t total = wave_total(wave_inclusive_scan_dpp(len));
+      if (resolved) resolved[((k - resolved_base) * nchunks + ch) * kAsmRows + lane] = d;
+      const uint32_t total = wave_total(wave_inclusive_scan_dpp(d.y));
       if (lane == jj) my_total += total;
     }
-    if (lane < cnt) chunk_size[(int64_t)my_k * nchunks + ch] = my_total;
+    if (chunk_size && lane < cnt) chunk_size[(int64_t)my_k * nchunks + ch] = my_total;
   }
 }
 
 constexpr int kTextChunks = 5;       // 16-byte chunks of a slot kept in registers
 struct SlotText { uint4 x[kTextChunks]; };
 
+// One wavefront assembles G adjacent chunks (G x 64 samples) of the same records in lock step: the matrix loads, the
+// text fetches and the page stores of the G chunks are independent, so each of the wavefront's memory waits (gfx9 has one
+// in-order vmcnt for loads and stores: every wait for a load also waits for the acknowledgement of the stores before it)
+// is paid once per G x 64 entries instead of once per 64.
+template <int G>
 __global__ void __launch_bounds__(kAsmRows)
-k_assemble_write(AsmCtx a, const int32_t* __restrict__ order, int64_t n, int32_t N, int nchunks, int run, const uint64_t* __restrict__ chunk_off,
-                 uint64_t page_base, char* __restrict__ arena) {
-  const int64_t ib = (int64_t)blockIdx.x * run;
+k_assemble_write(const char* __restrict__ pool, const uint32_t* __restrict__ prefix_len, const uint2* __restrict__ resolved, int64_t resolved_base,
+                 const int32_t* __restrict__ order, int64_t n, int nchunks, int run, const uint64_t* __restrict__ chunk_off, uint64_t page_base,
+                 char* __restrict__ arena) {
+  const unsigned ngroups = (unsigned)((nchunks + G - 1) / G);
+  const int64_t ib = (int64_t)(blockIdx.x / ngroups) * run;
   const int64_t ie = min(n, ib + (int64_t)run);
-  const int ch = blockIdx.y;
+  const int ch0 = (int)(blockIdx.x % ngroups) * G;
   const int lane = threadIdx.x;
-  const int32_t r = ch * kAsmRows + lane;
-  __shared__ __attribute__((aligned(16))) char lds_buf[kWaveLds + 16];
-  SlotWalker w;
-  int64_t prev_k = INT64_MAX;
-  uint32_t cur_slot = kNoSlot, cur_len = 0;
-  const char* cur_src = a.pool;
-  SlotText txt;
+  __shared__ __attribute__((aligned(16))) char lds_buf[G][kWaveLds + 16];
+  uint2 cur[G];
+  const char* cur_src[G];
+  SlotText txt[G];
 #pragma unroll
-  for (int q = 0; q < kTextChunks; ++q) txt.x[q] = make_uint4(0, 0, 0, 0);
+  for (int g = 0; g < G; ++g) {
+    cur[g] = make_uint2(0xFFFFFFFFu, 0); cur_src[g] = pool;
+#pragma unroll
+    for (int q = 0; q < kTextChunks; ++q) txt[g].x[q] = make_uint4(0, 0, 0, 0);
+  }
   for (int64_t i0 = ib; i0 < ie; i0 += 64) {                // uniform
     const int cnt = (int)min((int64_t)64, ie - i0);
-    int32_t my_k = 0; int64_t my_s = 0; uint32_t my_t = 0; int64_t my_dst = 0;
+    int32_t my_k = 0; int64_t my_dst[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) my_dst[g] = 0;
     if (lane < cnt) {
       my_k = order[i0 + lane];
-      my_s = a.rec_start[my_k];
-      my_t = a.rtype[my_k];
-      my_dst = (int64_t)(chunk_off[(int64_t)my_k * nchunks + ch] - page_base) + (ch == 0 ? a.prefix_len[my_k] : 0u);
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        if (ch0 + g < nchunks) my_dst[g] = (int64_t)(chunk_off[(int64_t)my_k * nchunks + ch0 + g] - page_base) + (ch0 + g == 0 ? prefix_len[my_k] : 0u);
+    }
+    uint2 d_next[G];
+    {
+      const int64_t row0 = ((int64_t)__builtin_amdgcn_readlane(my_k, 0) - resolved_base) * nchunks;
+#pragma unroll
+      for (int g = 0; g < G; ++g) d_next[g] = ch0 + g < nchunks ? resolved[(row0 + ch0 + g) * kAsmRows + lane] : make_uint2(0, 0);
     }
     for (int jj = 0; jj < cnt; ++jj) {                      // uniform
-      const int64_t k = __builtin_amdgcn_readlane(my_k, jj);
-      const int64_t s = readlane64(my_s, jj);
-      const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)my_t, jj);
-      uint32_t len = 0;
-      if (r < N) {
-        if (k < prev_k) w.init(a, r, s); else w.advance(a, s);  // uniform branch
-        const uint32_t sl = w.slot(a, k, s, t, r);
-        if (sl != cur_slot) {
-          cur_slot = sl;
-          const uint2 dsc = a.desc[sl];
-          cur_len = dsc.y;
-          cur_src = a.pool + (size_t)dsc.x * 16;
+      uint2 d[G];
 #pragma unroll
-          for (int q = 0; q < kTextChunks; ++q) txt.x[q] = load_chunk(cur_src, q, cur_len);
+      for (int g = 0; g < G; ++g) d[g] = d_next[g];
+      if (jj + 1 < cnt) {
+        const int64_t row1 = ((int64_t)__builtin_amdgcn_readlane(my_k, jj + 1) - resolved_base) * nchunks;
+#pragma unroll
+        for (int g = 0; g < G; ++g) if (ch0 + g < nchunks) d_next[g] = resolved[(row1 + ch0 + g) * kAsmRows + lane];
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const uint32_t len = d[g].y;
+        if (len && (d[g].x != cur[g].x || len != cur[g].y)) {   // the sample moved to another slot: fetch its text
+          cur[g] = d[g];
+          cur_src[g] = pool + (size_t)d[g].x * 16;
+#pragma unroll
+          for (int q = 0; q < kTextChunks; ++q) txt[g].x[q] = load_chunk(cur_src[g], q, len);
         }
-        len = cur_len;
       }
-      prev_k = k;
-      const uint32_t inc = wave_inclusive_scan_dpp(len);
-      const uint32_t excl = inc - len;
-      const uint32_t total = wave_total(inc);
-      if (total == 0) continue;                             // uniform: no FORMAT columns in this record
-      char* gdst = arena + readlane64(my_dst, jj);
-      const uint32_t al = (uint32_t)((uintptr_t)gdst & 15u);
-      if (al + total <= (uint32_t)kWaveLds) {               // uniform
-        SlotCopy cp;
-        cp.begin((gdb_lds_char*)lds_buf + al + excl, len);
-        cp.chunk(0, txt.x[0]);
+      uint32_t total[G], al[G];
+      char* gdst[G];
 #pragma unroll
-        for (int q = 1; q < kTextChunks; ++q) if (__any((int)cp.needs(q))) cp.chunk(q, txt.x[q]);
-        for (uint32_t q = kTextChunks; __any((int)cp.needs(q)); ++q) cp.chunk(q, load_chunk(cur_src, q, len));
-        __syncthreads();                                    // one wavefront per workgroup: orders the LDS image, no s_barrier wait
-        const char* img = lds_buf + al;
-        uint32_t head = (16u - al) & 15u;
-        if (head > total) head = total;
-        const uint32_t nwords = (total - head) >> 4;
-        const uint32_t tail_at = head + (nwords << 4);
-        if ((uint32_t)lane < head) gdst[lane] = img[lane];
-        const uint4* lsrc = reinterpret_cast<const uint4*>(img + head);
-        uint4* gw = reinterpret_cast<uint4*>(gdst + head);
-        for (uint32_t wq = lane; wq < nwords; wq += kAsmRows) gw[wq] = lsrc[wq];
-        if ((uint32_t)lane < total - tail_at) gdst[tail_at + lane] = img[tail_at + lane];
-        __syncthreads();
-      } else {                                              // longer than the LDS image (very long PL vectors): straight to HBM
-        char* dst = gdst + excl;
-        for (uint32_t b = 0; b < len; ++b) dst[b] = cur_src[b];
+      for (int g = 0; g < G; ++g) {
+        const uint32_t len = d[g].y;
+        const uint32_t inc = wave_inclusive_scan_dpp(len);
+        const uint32_t excl = inc - len;
+        total[g] = wave_total(inc);
+        gdst[g] = arena + readlane64(my_dst[g], jj);
+        al[g] = (uint32_t)((uintptr_t)gdst[g] & 15u);
+        if (total[g] == 0) continue;                        // uniform: no FORMAT columns in this record (or chunk beyond N)
+        if (al[g] + total[g] <= (uint32_t)kWaveLds) {       // uniform
+          SlotCopy cp;
+          cp.begin((gdb_lds_char*)lds_buf[g] + al[g] + excl, len);
+          cp.chunk(0, txt[g].x[0]);
+#pragma unroll
+          for (int q = 1; q < kTextChunks; ++q) if (__any((int)cp.needs(q))) cp.chunk(q, txt[g].x[q]);
+          for (uint32_t q = kTextChunks; __any((int)cp.needs(q)); ++q) cp.chunk(q, load_chunk(cur_src[g], q, len));
+          cp.finish();
+        } else {                                            // longer than the LDS image (very long PL vectors): straight to HBM
+          char* dst = gdst[g] + excl;
+          for (uint32_t b = 0; b < len; ++b) dst[b] = cur_src[g][b];
+          total[g] = 0;
+        }
       }
+      // One wavefront per workgroup: the LDS unit runs its instructions in order, so the images only need a compiler-level
+      // fence (wavefront scope emits no s_waitcnt).
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        if (total[g] == 0) continue;                        // uniform
+        const char* img = lds_buf[g] + al[g];
+        uint32_t head = (16u - al[g]) & 15u;
+        if (head > total[g]) head = total[g];
+        const uint32_t nwords = (total[g] - head) >> 4;
+        const uint32_t tail_at = head + (nwords << 4);
+        if ((uint32_t)lane < head) gdst[g][lane] = img[lane];
+        const uint4* lsrc = reinterpret_cast<const uint4*>(img + head);
+        uint4* gw = reinterpret_cast<uint4*>(gdst[g] + head);
+        for (uint32_t wq = lane; wq < nwords; wq += kAsmRows) gw[wq] = lsrc[wq];
+        if ((uint32_t)lane < total[g] - tail_at) gdst[g][tail_at + lane] = img[tail_at + lane];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
   }
 }
-__global__ void k_iota32(int32_t base, int64_t n, int32_t* out) {
+// sort key of the assembly order: (block of 2^block_log2 consecutive records, record type); the value is the record index
+__global__ void k_order_keys(const uint8_t* rtype, int32_t base, int64_t n, int block_log2, uint32_t* keys, int32_t* vals) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = base + (int32_t)i;
+  if (i >= n) return;
+  keys[i] = ((uint32_t)(i >> block_log2) << 8) | rtype[base + i];
+  vals[i] = base + (int32_t)i;
 }
 
 __global__ void k_copy_offsets(const uint32_t* src, int64_t n, uint32_t base, uint32_t* dst) {
@@ -699,7 +747,8 @@ struct DevicePipeline::Impl {
   // entry text table
   DevBuf<unsigned long long> type_hkeys; DevBuf<int32_t> type_hrep, type_rep; DevBuf<uint8_t> type_hid, rtype;
   DevBuf<WalkCell> walk; DevBuf<int64_t> walk_inv;
-  DevBuf<uint32_t> untabled, ubase; DevBuf<int32_t> urec, iota, order; DevBuf<uint8_t> rtype_sorted;
+  DevBuf<uint2> resolved;          // (pool offset, length) of every (record, sample): whole interval, or one page when that exceeds the budget
+  DevBuf<uint32_t> untabled, ubase; DevBuf<int32_t> urec, iota, order; DevBuf<uint32_t> order_keys, order_keys_sorted;
   DevBuf<uint64_t> tmask; DevBuf<uint32_t> nslots, tbase, inc_pos, slot_len, slot_units, slot_off; DevBuf<uint2> slot_desc; DevBuf<char> pool;
   bool classified = false;
   struct Part { FragmentView v; std::vector<size_t> data_bytes; std::vector<void*> bufs; };
@@ -714,6 +763,7 @@ struct DevicePipeline::Impl {
     std::vector<uint64_t> rec_off;
     IntervalStats stats;
     SiteCtx sx; EntryCtx ex; RowIndex ri; SiteOut so; RecordTable rec; AsmCtx ac;
+    bool resolved_whole = false;
   } iv;
 
   void* temp_storage(size_t bytes) { temp.ensure(bytes + 256); return temp.p; }
@@ -749,9 +799,12 @@ struct DevicePipeline::Impl {
   }
   // records [k0, k0+n) in (type, position) order -> order[]
   void order_by_type(int64_t k0, int64_t n) {
-    iota.ensure(n); order.ensure(n); rtype_sorted.ensure(n);
-    hipLaunchKernelGGL(k_iota32, dim3(blocks_for(n)), dim3(kBlock), 0, stream, (int32_t)k0, n, iota.p);
-    sort_pairs(rtype.p + k0, rtype_sorted.p, iota.p, order.p, (size_t)n, 8);
+    // Types are grouped inside blocks of consecutive records, not over the whole range: a wavefront still walks ~100
+    // same-type records, but the page stores and matrix reads in flight stay within a few tens of MB (TLB reach, DRAM pages).
+    const int block_log2 = order_block_log2();
+    iota.ensure(n); order.ensure(n); order_keys.ensure(n); order_keys_sorted.ensure(n);
+    hipLaunchKernelGGL(k_order_keys, dim3(blocks_for(n)), dim3(kBlock), 0, stream, (const uint8_t*)rtype.p, (int32_t)k0, n, block_log2, order_keys.p, iota.p);
+    sort_pairs(order_keys.p, order_keys_sorted.p, iota.p, order.p, (size_t)n, std::min(32, 8 + bits_for((uint64_t)(n >> block_log2))));
   }
   void free_owned() { for (void* p : owned) (void)hipFree(p); owned.clear(); }
 };
@@ -1123,14 +1176,12 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   const int run = run_length(P, nchunks);
   const unsigned run_blocks = (unsigned)((P + run - 1) / run);
   STAGE("k_assemble_size");
-  if (getenv("GDBAMD_DEBUG_OCC")) {
-    int nb1 = 0, nb2 = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, k_assemble_size, kAsmRows, 0);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, k_assemble_write, kAsmRows, 0);
-    fprintf(stderr, "[gdbamd] occupancy blocks/CU: size %d write %d; grid %u x %d run %d\n", nb1, nb2, run_blocks, nchunks, run);
-  }
   S.order_by_type(0, P);
-  hipLaunchKernelGGL(k_assemble_size, dim3(run_blocks, nchunks), dim3(kAsmRows), 0, st, ac, S.order.p, P, N, nchunks, run, S.chunk_size.p);
+  const uint64_t resolved_bytes = (uint64_t)P * nchunks * kAsmRows * sizeof(uint2);
+  const bool resolved_whole = resolved_bytes <= resolved_budget_bytes();
+  if (resolved_whole) S.resolved.ensure((size_t)P * nchunks * kAsmRows);
+  hipLaunchKernelGGL(k_assemble_size, dim3(run_blocks * (unsigned)nchunks), dim3(kAsmRows), 0, st, ac, S.order.p, P, N, nchunks, run, S.chunk_size.p,
+                     resolved_whole ? S.resolved.p : nullptr, (int64_t)0);
   HIP_CHECK(hipMemsetAsync(S.chunk_size.p + nchunk_total, 0, sizeof(uint64_t), st));
   S.excl_scan(S.chunk_size.p, S.chunk_off.p, nchunk_total + 1);
   STAGE("k_gather_record_offsets");
@@ -1152,7 +1203,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   }
   for (int64_t k = 0; k < P; ++k) S.iv.max_record_bytes = std::max<uint64_t>(S.iv.max_record_bytes, rec_off[(size_t)k + 1] - rec_off[(size_t)k]);
   S.iv.P = P; S.iv.nchunks = nchunks; S.iv.kp = 0;
-  S.iv.sx = sx; S.iv.ex = ex; S.iv.ri = ri; S.iv.so = so; S.iv.rec = rec; S.iv.ac = ac;
+  S.iv.sx = sx; S.iv.ex = ex; S.iv.ri = ri; S.iv.so = so; S.iv.rec = rec; S.iv.ac = ac; S.iv.resolved_whole = resolved_whole;
   S.iv.active = true;
 }
 
@@ -1181,8 +1232,21 @@ bool DevicePipeline::next_page(uint64_t arena_bytes, const char** dev_ptr, uint6
   STAGE("k_assemble_write");
   const int wrun = run_length(np, iv.nchunks);
   S.order_by_type(kp, np);
-  hipLaunchKernelGGL(k_assemble_write, dim3((unsigned)((np + wrun - 1) / wrun), iv.nchunks), dim3(kAsmRows), 0, st, iv.ac, S.order.p, np, N, iv.nchunks, wrun,
-                     S.chunk_off.p, page_base, S.arena.p);
+  const unsigned wruns = (unsigned)((np + wrun - 1) / wrun);
+  const dim3 wgrid(wruns * (unsigned)iv.nchunks);
+  if (!iv.resolved_whole) {   // the interval's matrix exceeded the budget: resolve this page's records now
+    S.resolved.ensure((size_t)np * iv.nchunks * kAsmRows);
+    hipLaunchKernelGGL(k_assemble_size, wgrid, dim3(kAsmRows), 0, st, iv.ac, S.order.p, np, N, iv.nchunks, wrun, (uint64_t*)nullptr, S.resolved.p, kp);
+  }
+  {
+    const int G = assemble_group();
+    const dim3 ggrid(wruns * (unsigned)((iv.nchunks + G - 1) / G));
+    auto launch = [&](auto kernel) {
+      hipLaunchKernelGGL(kernel, ggrid, dim3(kAsmRows), 0, st, (const char*)S.pool.p, (const uint32_t*)S.prefix_len.p, (const uint2*)S.resolved.p,
+                         iv.resolved_whole ? (int64_t)0 : kp, (const int32_t*)S.order.p, np, iv.nchunks, wrun, (const uint64_t*)S.chunk_off.p, page_base, S.arena.p);
+    };
+    if (G == 4) launch(k_assemble_write<4>); else if (G == 2) launch(k_assemble_write<2>); else launch(k_assemble_write<1>);
+  }
   HIP_CHECK(hipEventRecord(w2, st));
   HIP_CHECK(hipStreamSynchronize(st));
   float ms_site = 0, ms_entry = 0;

@@ -74,7 +74,7 @@ def test_engine_stats_and_header(gdb):
     e.close()
 
 
-def test_synthetic_matches_oracle(gdb, tmp_path):
+def test_synthetic_matches_oracle(gdb, tmp_path, monkeypatch):
     """generator of SURVEY 8(d): 300 samples x 6 kb (SNVs, insertions, deletions with per-bp stepping), staged in two parts"""
     from genomicsdb_amd import synth
     N, B, L = 300, 10_000_000, 6000
@@ -96,6 +96,9 @@ def test_synthetic_matches_oracle(gdb, tmp_path):
     assert body == want
     body2, st2 = e.run_interval(B + 700, B + L - 900, arena_bytes=1 << 30)  # one page
     assert st2.pages == 1 and body2 == want
+    monkeypatch.setenv("GDBAMD_RESOLVED_MB", "0")   # (record, sample) matrix over budget: resolved page by page
+    body3, st3 = e.run_interval(B + 700, B + L - 900, arena_bytes=1 << 20)
+    assert st3.pages > 5 and body3 == want
     e.close()
 
 
