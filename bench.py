@@ -36,8 +36,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--samples", type=int, default=1000)
     ap.add_argument("--interval-bp", type=int, default=10_000_000)
-    ap.add_argument("--window-bp", type=int, default=100_000, help="columns per step (one batch)")
-    ap.add_argument("--arena-mb", type=int, default=4096, help="HBM page for the output text")
+    ap.add_argument("--window-bp", type=int, default=200_000, help="columns per step (one batch)")
+    ap.add_argument("--arena-mb", type=int, default=16384, help="HBM page for the output text")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-bp", type=int, default=5000)
     args = ap.parse_args()
@@ -56,7 +56,8 @@ def main():
     import helpers
 
     N, Lbp, W = args.samples, args.interval_bp, args.window_bp
-    B = 10_000_000 + rank * Lbp  # every rank scans its own column partition of the same shape
+    from genomicsdb_amd import dist as gdist
+    B, _ = gdist.synthetic_partition(rank, 10_000_000, Lbp)  # every rank scans its own column partition of the same shape
     nwin = max(1, Lbp // W)
     total_steps = args.steps + args.warmup
     need_bp = min(Lbp, W * min(nwin, total_steps))  # stage only the windows the run will touch
@@ -108,15 +109,7 @@ def main():
     st_total_cells = max(1, ncells)
     bytes_in = int(eng_reference_bytes(eng) * (cells_in / st_total_cells))
 
-    if world > 1:
-        t = torch.tensor([dt], device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        agg = torch.tensor([recs, cells_in, bytes_out, bytes_in], dtype=torch.float64, device="cuda")
-        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        recs_all, cells_all, bo_all, bi_all = [float(x) for x in agg.tolist()]
-    else:
-        recs_all, cells_all, bo_all, bi_all = float(recs), float(cells_in), float(bytes_out), float(bytes_in)
+    dt, (recs_all, cells_all, bo_all, bi_all) = gdist.aggregate(dt, [recs, cells_in, bytes_out, bytes_in], device="cuda")
 
     out = None
     if rank == 0:
@@ -143,7 +136,7 @@ def main():
             "phase_ms": {k: v / args.steps for k, v in ms.items()},
             "stage_seconds_untimed": t_stage,
             "roofline": {"bound": "hbm", "kernel": "k_assemble_write", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(N, W, arena),
                          "alg_bytes_per_launch": alg_bytes_per_launch, "avg_launch_ms": avg_ms, "launches": int(launches)},
         }
         if not args.no_cpu_baseline:
@@ -152,6 +145,21 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(N, W, arena):
+    """HBM bytes per k_assemble_write launch from the rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate passes,
+    MI355X_MICROARCH.md 'HBM'): measured with tests/tools/prof_traffic.sh on this very configuration and committed under
+    profiles/; null for any other configuration."""
+    path = os.path.join(ROOT, "profiles", "r1_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if t.get("samples") == N and t.get("window_bp") == W and t.get("arena_bytes") == arena:
+            return t["k_assemble_write"]["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
 
 
 def eng_reference_bytes(eng):

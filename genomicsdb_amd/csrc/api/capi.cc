@@ -142,4 +142,15 @@ int gdbamd_engine_run_interval(void* e, int64_t qb, int64_t qe, uint64_t arena_b
   }, 1);
 }
 
+int gdbamd_column_partition(const char* loader_json_text, int rank, int64_t* begin, int64_t* end) {
+  try {
+    GenomicsDBImportConfig cfg;
+    cfg.read_from_json(mini_json::parse(std::string(loader_json_text ? loader_json_text : "")), rank);
+    const ColumnRange r = cfg.get_column_partition(rank);
+    if (begin) *begin = r.first;
+    if (end) *end = r.second;
+    return 0;
+  } catch (const std::exception& e) { g_last_error = e.what(); return -1; }
+}
+
 }  // extern "C"

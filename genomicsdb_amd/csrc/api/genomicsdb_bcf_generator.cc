@@ -3,6 +3,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <climits>
+#include <cstdlib>
 #include <cstring>
 
 namespace genomicsdb_amd {
@@ -59,7 +60,11 @@ GenomicsDBBCFGenerator::GenomicsDBBCFGenerator(const std::string& loader_config_
     throw UnsupportedOnDeviceException(std::string("VCF output format \"") + output_format + "\": only text VCF (\"\") is produced by this build (SURVEY 8f-2)");
   GenomicsDBImportConfig loader;
   if (!loader_config_file.empty()) loader.read_from_file(loader_config_file, my_rank);
-  m_engine.reset(new CombineEngine(mini_json::parse_file(query_config_file), 0, loader_config_file.empty() ? nullptr : &loader, my_rank));
+  // one process per GPU: the device is the launcher's LOCAL_RANK (torchrun / mpirun wrappers export it), else GDBAMD_DEVICE, else 0
+  int device = 0;
+  if (const char* e = getenv("GDBAMD_DEVICE")) device = atoi(e);
+  else if (const char* e2 = getenv("LOCAL_RANK")) device = atoi(e2);
+  m_engine.reset(new CombineEngine(mini_json::parse_file(query_config_file), device, loader_config_file.empty() ? nullptr : &loader, my_rank));
   VariantQueryConfig& qc = m_engine->query_config();
   if (chr && strlen(chr) > 0u) {
     ContigInfo ci;

@@ -1,0 +1,50 @@
+"""Multi-GPU side of the path: one process per GPU, one column partition per rank, no collective in the data path.
+
+The reference shards the scan the same way: rank r of `mpirun -n P gt_mpi_gather` reads column_partitions[r] of the loader
+JSON, scans it on its own and writes its own output (src/main/cpp/src/config/json_config.cc:340-417,
+tools/gt_mpi_gather.cc:322-366).  The only cross-rank steps are bookkeeping: the reduction of the benchmark counters
+(max time, summed counts) and, for callers that want ONE stream, an ordered concatenation of the per-rank bodies.
+Works over any torch.distributed backend ("nccl" = RCCL on the GPUs, "gloo" in the CPU tests)."""
+import ctypes
+
+from . import _lib
+
+
+def column_partition(loader_json_text, rank):
+    """(begin, end) of rank's column partition, by the loader-JSON rules of the reference"""
+    b, e = ctypes.c_int64(), ctypes.c_int64()
+    if isinstance(loader_json_text, str):
+        loader_json_text = loader_json_text.encode()
+    if _lib.lib().gdbamd_column_partition(loader_json_text, rank, ctypes.byref(b), ctypes.byref(e)) != 0:
+        raise RuntimeError(_lib.lib().gdb_mi355_last_error().decode())
+    return b.value, e.value
+
+
+def synthetic_partition(rank, begin, length):
+    """bench.py's weak-scaling layout: every rank owns its own `length` columns, back to back"""
+    b = begin + rank * length
+    return b, b + length - 1
+
+
+def aggregate(seconds, counters, device=None):
+    """(max over ranks of seconds, per-counter sum over ranks); identity when torch.distributed is not initialised"""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(seconds), [float(c) for c in counters]
+    t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    c = torch.tensor([float(x) for x in counters], dtype=torch.float64, device=device)
+    dist.all_reduce(c, op=dist.ReduceOp.SUM)
+    return float(t.item()), [float(x) for x in c.tolist()]
+
+
+def ordered_concat(body, dst=0):
+    """bodies of all ranks in rank (= column) order on rank `dst`, None elsewhere: the single-stream view of P partition
+    outputs.  Host-side utility (bytes objects); the per-rank pages stay where they are."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return body
+    parts = [None] * dist.get_world_size() if dist.get_rank() == dst else None
+    dist.gather_object(body, parts, dst=dst)
+    return b"".join(parts) if parts is not None else None

@@ -79,6 +79,11 @@ int gdbamd_engine_set_reference(void* engine, int64_t begin, const char* bases, 
 int gdbamd_engine_run_interval(void* engine, int64_t column_begin, int64_t column_end, uint64_t arena_bytes, char* host_out,
                                uint64_t host_cap, uint64_t* host_len, gdbamd_interval_stats* stats);
 
+/* ---- (3) host-only helpers (no device needed) ----------------------------------------------------------- */
+/* column partition of `rank` as the loader JSON defines it: begin from "column_partitions"[rank], end = next sorted begin - 1
+ * (reference: GenomicsDBImportConfig::get_column_partition, src/main/cpp/src/config/json_config.cc:340-417) */
+int gdbamd_column_partition(const char* loader_json_text, int rank, int64_t* begin, int64_t* end);
+
 #ifdef __cplusplus
 }
 #endif

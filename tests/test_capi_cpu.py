@@ -21,7 +21,7 @@ def lib():
 
 def test_header_symbols_exported(lib):
     hdr = open(os.path.join(ROOT, "include", "genomicsdb_amd.h")).read()
-    declared = set(re.findall(r"\b(gdb_mi355_\w+|gdbamd_engine_\w+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(gdb_mi355_\w+|gdbamd_\w+)\s*\(", hdr))
     from genomicsdb_amd import _lib
     assert declared == set(_lib.SYMBOLS)
     for s in declared:

@@ -1,0 +1,75 @@
+"""N > 1 on CPU (gloo, world_size 2): the column-partition arithmetic, the reduction bench.py uses, and the ordered concat.
+The device path itself needs a GPU; what is shared between ranks is only this bookkeeping - the reference's ranks do not
+talk to each other during the scan either (gt_mpi_gather.cc:322-366)."""
+import json
+import os
+import socket
+import sys
+
+import pytest
+
+import helpers
+from golden_cases import CASES
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+LOADER = {"column_partitions": [{"begin": 0, "workspace": "/tmp/ws", "array": "a0"}, {"begin": 12202, "workspace": "/tmp/ws", "array": "a1"}],
+          "vid_mapping_file": "vid.json", "callset_mapping_file": "callsets.json"}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from genomicsdb_amd import dist as gdist
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        begin, end = gdist.column_partition(json.dumps(LOADER), rank)
+        sb, se = gdist.synthetic_partition(rank, 10_000_000, 1_000_000)
+        # each rank "scans" its partition of the reference's overlapping-intervals fixture with the CPU oracle (checker only)
+        case = [c for c in CASES if c[0] == "t0_overlapping_at_12202"][0]
+        _, callsets, vid, ov, golden, mode = case
+        cells = helpers.cells_for(callsets, vid)
+        ov = dict(ov)
+        ov["query_column_ranges"] = [[[begin, min(end, 1_000_000_000)]]]
+        qj, _ = helpers.query_json(callsets, vid, ov, mode)
+        body, nrec, _ = helpers.oracle_run(qj, cells, partition_begin=begin, with_header=False)
+        dt, (recs,) = gdist.aggregate(1.0 + rank, [nrec])
+        whole = gdist.ordered_concat(body)
+        q.put((rank, begin, end, sb, se, nrec, dt, recs, whole))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_partition_reduce_concat():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, b0, e0, sb0, se0, n0, dt0, recs0, whole0), (r1, b1, e1, sb1, se1, n1, dt1, recs1, whole1) = res
+    assert (b0, e0) == (0, 12201) and b1 == 12202 and e1 >= 10**12          # ends derive from the next sorted begin
+    assert (sb0, se0) == (10_000_000, 10_999_999) and (sb1, se1) == (11_000_000, 11_999_999)
+    assert dt0 == dt1 == 2.0 and recs0 == recs1 == n0 + n1                  # max over ranks, sum over ranks
+    assert whole1 is None and whole0 is not None
+    # the second partition starts inside an interval: it is clipped to the partition and equals the reference's golden for
+    # the query at 12202; the concat is the two bodies in column order
+    golden = helpers.golden_text([c for c in CASES if c[0] == "t0_overlapping_at_12202"][0][4])
+    body_golden = b"".join(l for l in golden.splitlines(True) if not l.startswith(b"#"))
+    assert whole0.endswith(body_golden) and n1 == body_golden.count(b"\n")
+    assert whole0.count(b"\n") == n0 + n1
