@@ -65,12 +65,6 @@ inline uint64_t resolved_budget_bytes() {
   const char* e = getenv("GDBAMD_RESOLVED_MB");
   return e && *e ? (uint64_t)atoll(e) << 20 : (uint64_t)32 << 30;
 }
-// chunks (x 64 samples) one wavefront of the write kernel assembles in lock step
-inline int assemble_group() {
-  const char* e = getenv("GDBAMD_ASM_GROUP");
-  const int g = e && *e ? atoi(e) : 1;
-  return g >= 4 ? 4 : g >= 2 ? 2 : 1;
-}
 inline int order_block_log2() {
   const char* e = getenv("GDBAMD_ORDER_BLOCK_LOG2");
   return e && *e ? std::max(0, std::min(30, atoi(e))) : 7;
@@ -146,10 +140,14 @@ __global__ void k_record_expand(Boundaries b, const int64_t* rbase, int64_t U, i
 __global__ void k_cell_ranges(FragmentView fr, CombinePlan pl, CellMeta cm, RecordTable rec, int64_t c_base, int64_t n, int64_t qb, int64_t qe, DiffArrays d,
                               int64_t* heavy_count, int32_t* in_window_count) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int64_t c = c_base + i;
-  stage_cell_ranges(fr, pl, cm, rec, c, c_base, qb, qe, d, heavy_count);
-  if (cm.k_lo[c] >= 0) atomicAdd(in_window_count, 1);
+  bool in_window = false;
+  if (i < n) {
+    const int64_t c = c_base + i;
+    stage_cell_ranges(fr, pl, cm, rec, c, c_base, qb, qe, d, heavy_count);
+    in_window = cm.k_lo[c] >= 0;
+  }
+  const uint64_t m = __ballot(in_window);                 // one atomic per wavefront, not per cell
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(in_window_count, (int32_t)__popcll(m));
 }
 __global__ void k_incidence_fill(FragmentView fr, CellMeta cm, const int64_t* hoff, int64_t c_base, int64_t n, int64_t nrows, uint64_t* keys, int64_t* vals) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -232,19 +230,39 @@ __device__ __forceinline__ uint32_t type_hash(uint64_t k) {
   k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 29;
   return (uint32_t)k & (kTypeHash - 1);
 }
-__global__ void k_type_insert(SiteOut so, int64_t P, unsigned long long* hkeys, int32_t* hrep) {
-  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= P) return;
-  const uint64_t key = record_type_key(so.fmt_mask[k], so.num_alleles[k], so.rflags[k]);
+__device__ __forceinline__ void type_insert_global(uint64_t key, int32_t k, unsigned long long* hkeys, int32_t* hrep) {
   uint32_t h = type_hash(key);
   for (int probe = 0; probe < kTypeHash; ++probe, h = (h + 1) & (kTypeHash - 1)) {
     unsigned long long cur = __atomic_load_n(&hkeys[h], __ATOMIC_RELAXED);
     if (cur == kEmptyKey) cur = atomicCAS(&hkeys[h], (unsigned long long)kEmptyKey, (unsigned long long)key);
-    if (cur == kEmptyKey || cur == key) {   // representative record: the smallest index (read first: nearly every thread loses)
-      if (__atomic_load_n(&hrep[h], __ATOMIC_RELAXED) > (int32_t)k) atomicMin(&hrep[h], (int32_t)k);
+    if (cur == kEmptyKey || cur == key) {   // representative record: the smallest index
+      if (__atomic_load_n(&hrep[h], __ATOMIC_RELAXED) > k) atomicMin(&hrep[h], k);
       return;
     }
   }
+}
+// A workgroup first folds its 256 records into a small LDS table (a window has ~10 distinct types), then only the
+// occupied LDS buckets go to the global table: a few thousand global atomics per interval instead of one per record.
+__global__ void __launch_bounds__(kBlock) k_type_insert(SiteOut so, int64_t P, unsigned long long* hkeys, int32_t* hrep) {
+  constexpr int kLocal = 128;
+  __shared__ unsigned long long lkey[kLocal];
+  __shared__ int32_t lrep[kLocal];
+  if (threadIdx.x < kLocal) { lkey[threadIdx.x] = kEmptyKey; lrep[threadIdx.x] = INT32_MAX; }
+  __syncthreads();
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < P) {
+    const uint64_t key = record_type_key(so.fmt_mask[k], so.num_alleles[k], so.rflags[k]);
+    uint32_t h = type_hash(key) & (kLocal - 1);
+    bool placed = false;
+    for (int probe = 0; probe < kLocal && !placed; ++probe, h = (h + 1) & (kLocal - 1)) {
+      unsigned long long cur = lkey[h];
+      if (cur == kEmptyKey) cur = atomicCAS(&lkey[h], (unsigned long long)kEmptyKey, (unsigned long long)key);
+      if (cur == kEmptyKey || cur == key) { atomicMin(&lrep[h], (int32_t)k); placed = true; }
+    }
+    if (!placed) type_insert_global(key, (int32_t)k, hkeys, hrep);   // more than 128 types inside one workgroup
+  }
+  __syncthreads();
+  if (threadIdx.x < kLocal && lkey[threadIdx.x] != kEmptyKey) type_insert_global(lkey[threadIdx.x], lrep[threadIdx.x], hkeys, hrep);
 }
 // dense ids for the first max_types occupied buckets (bucket order); later ones are "untabled".  One wavefront: every lane
 // counts its kTypeHash/64 consecutive buckets, a wavefront scan gives its first id.
@@ -589,112 +607,80 @@ k_assemble_size(AsmCtx a, const int32_t* __restrict__ order, int64_t n, int32_t 
 constexpr int kTextChunks = 5;       // 16-byte chunks of a slot kept in registers
 struct SlotText { uint4 x[kTextChunks]; };
 
-// One wavefront assembles G adjacent chunks (G x 64 samples) of the same records in lock step: the matrix loads, the
-// text fetches and the page stores of the G chunks are independent, so each of the wavefront's memory waits (gfx9 has one
-// in-order vmcnt for loads and stores: every wait for a load also waits for the acknowledgement of the stores before it)
-// is paid once per G x 64 entries instead of once per 64.
-template <int G>
+// Page assembly: one wavefront = `run` records x 64 samples (one chunk), one wavefront per workgroup (no s_barrier).
+// Variants measured on MI355X this round and dropped because they were slower (c2, 200 kb window, ms per launch, this
+// kernel = 3.0-3.2): 2 / 4 chunks per wavefront in lock step 3.3 / 4.7; 2 / 4 records built before one flush 3.9 / 5.4;
+// builder + flusher wavefront pairs 5.6; skewed software pipeline with two LDS images 4.2.  All of them trade resident
+// wavefronts for fewer exposed waits, and lose: the kernel is bound by (resident wavefronts) / (per-record latency).
 __global__ void __launch_bounds__(kAsmRows)
 k_assemble_write(const char* __restrict__ pool, const uint32_t* __restrict__ prefix_len, const uint2* __restrict__ resolved, int64_t resolved_base,
                  const int32_t* __restrict__ order, int64_t n, int nchunks, int run, const uint64_t* __restrict__ chunk_off, uint64_t page_base,
                  char* __restrict__ arena) {
-  const unsigned ngroups = (unsigned)((nchunks + G - 1) / G);
-  const int64_t ib = (int64_t)(blockIdx.x / ngroups) * run;
+  // chunk is the fast grid dimension: the 16 chunk wavefronts of a record run are in flight together
+  const int64_t ib = (int64_t)(blockIdx.x / (unsigned)nchunks) * run;
   const int64_t ie = min(n, ib + (int64_t)run);
-  const int ch0 = (int)(blockIdx.x % ngroups) * G;
+  const int ch = (int)(blockIdx.x % (unsigned)nchunks);
   const int lane = threadIdx.x;
-  __shared__ __attribute__((aligned(16))) char lds_buf[G][kWaveLds + 16];
-  uint2 cur[G];
-  const char* cur_src[G];
-  SlotText txt[G];
+  __shared__ __attribute__((aligned(16))) char lds_buf[kWaveLds + 16];
+  uint2 cur = make_uint2(0xFFFFFFFFu, 0);
+  const char* cur_src = pool;
+  SlotText txt;
 #pragma unroll
-  for (int g = 0; g < G; ++g) {
-    cur[g] = make_uint2(0xFFFFFFFFu, 0); cur_src[g] = pool;
-#pragma unroll
-    for (int q = 0; q < kTextChunks; ++q) txt[g].x[q] = make_uint4(0, 0, 0, 0);
-  }
+  for (int q = 0; q < kTextChunks; ++q) txt.x[q] = make_uint4(0, 0, 0, 0);
   for (int64_t i0 = ib; i0 < ie; i0 += 64) {                // uniform
     const int cnt = (int)min((int64_t)64, ie - i0);
-    int32_t my_k = 0; int64_t my_dst[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) my_dst[g] = 0;
+    int32_t my_k = 0; int64_t my_dst = 0;
     if (lane < cnt) {
       my_k = order[i0 + lane];
-#pragma unroll
-      for (int g = 0; g < G; ++g)
-        if (ch0 + g < nchunks) my_dst[g] = (int64_t)(chunk_off[(int64_t)my_k * nchunks + ch0 + g] - page_base) + (ch0 + g == 0 ? prefix_len[my_k] : 0u);
+      my_dst = (int64_t)(chunk_off[(int64_t)my_k * nchunks + ch] - page_base) + (ch == 0 ? prefix_len[my_k] : 0u);
     }
-    uint2 d_next[G];
-    {
-      const int64_t row0 = ((int64_t)__builtin_amdgcn_readlane(my_k, 0) - resolved_base) * nchunks;
-#pragma unroll
-      for (int g = 0; g < G; ++g) d_next[g] = ch0 + g < nchunks ? resolved[(row0 + ch0 + g) * kAsmRows + lane] : make_uint2(0, 0);
-    }
+    uint2 d_next = resolved[(((int64_t)__builtin_amdgcn_readlane(my_k, 0) - resolved_base) * nchunks + ch) * kAsmRows + lane];
     for (int jj = 0; jj < cnt; ++jj) {                      // uniform
-      uint2 d[G];
+      const uint2 d = d_next;
+      if (jj + 1 < cnt) d_next = resolved[(((int64_t)__builtin_amdgcn_readlane(my_k, jj + 1) - resolved_base) * nchunks + ch) * kAsmRows + lane];
+      const uint32_t len = d.y;
+      if (len && (d.x != cur.x || len != cur.y)) {          // the sample moved to another slot: fetch its text
+        cur = d;
+        cur_src = pool + (size_t)d.x * 16;
 #pragma unroll
-      for (int g = 0; g < G; ++g) d[g] = d_next[g];
-      if (jj + 1 < cnt) {
-        const int64_t row1 = ((int64_t)__builtin_amdgcn_readlane(my_k, jj + 1) - resolved_base) * nchunks;
-#pragma unroll
-        for (int g = 0; g < G; ++g) if (ch0 + g < nchunks) d_next[g] = resolved[(row1 + ch0 + g) * kAsmRows + lane];
+        for (int q = 0; q < kTextChunks; ++q) txt.x[q] = load_chunk(cur_src, q, len);
       }
+      const uint32_t inc = wave_inclusive_scan_dpp(len);
+      const uint32_t excl = inc - len;
+      const uint32_t total = wave_total(inc);
+      if (total == 0) continue;                             // uniform: no FORMAT columns in this record
+      char* gdst = arena + readlane64(my_dst, jj);
+      const uint32_t al = (uint32_t)((uintptr_t)gdst & 15u);
+      if (al + total <= (uint32_t)kWaveLds) {               // uniform
+        SlotCopy cp;
+        cp.begin((gdb_lds_char*)lds_buf + al + excl, len);
+        cp.chunk(0, txt.x[0]);
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const uint32_t len = d[g].y;
-        if (len && (d[g].x != cur[g].x || len != cur[g].y)) {   // the sample moved to another slot: fetch its text
-          cur[g] = d[g];
-          cur_src[g] = pool + (size_t)d[g].x * 16;
-#pragma unroll
-          for (int q = 0; q < kTextChunks; ++q) txt[g].x[q] = load_chunk(cur_src[g], q, len);
-        }
-      }
-      uint32_t total[G], al[G];
-      char* gdst[G];
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const uint32_t len = d[g].y;
-        const uint32_t inc = wave_inclusive_scan_dpp(len);
-        const uint32_t excl = inc - len;
-        total[g] = wave_total(inc);
-        gdst[g] = arena + readlane64(my_dst[g], jj);
-        al[g] = (uint32_t)((uintptr_t)gdst[g] & 15u);
-        if (total[g] == 0) continue;                        // uniform: no FORMAT columns in this record (or chunk beyond N)
-        if (al[g] + total[g] <= (uint32_t)kWaveLds) {       // uniform
-          SlotCopy cp;
-          cp.begin((gdb_lds_char*)lds_buf[g] + al[g] + excl, len);
-          cp.chunk(0, txt[g].x[0]);
-#pragma unroll
-          for (int q = 1; q < kTextChunks; ++q) if (__any((int)cp.needs(q))) cp.chunk(q, txt[g].x[q]);
-          for (uint32_t q = kTextChunks; __any((int)cp.needs(q)); ++q) cp.chunk(q, load_chunk(cur_src[g], q, len));
-          cp.finish();
-        } else {                                            // longer than the LDS image (very long PL vectors): straight to HBM
-          char* dst = gdst[g] + excl;
-          for (uint32_t b = 0; b < len; ++b) dst[b] = cur_src[g][b];
-          total[g] = 0;
-        }
-      }
-      // One wavefront per workgroup: the LDS unit runs its instructions in order, so the images only need a compiler-level
-      // fence (wavefront scope emits no s_waitcnt).
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        if (total[g] == 0) continue;                        // uniform
-        const char* img = lds_buf[g] + al[g];
-        uint32_t head = (16u - al[g]) & 15u;
-        if (head > total[g]) head = total[g];
-        const uint32_t nwords = (total[g] - head) >> 4;
+        for (int q = 1; q < kTextChunks; ++q) if (__any((int)cp.needs(q))) cp.chunk(q, txt.x[q]);
+        for (uint32_t q = kTextChunks; __any((int)cp.needs(q)); ++q) cp.chunk(q, load_chunk(cur_src, q, len));
+        cp.finish();
+        // One wavefront per workgroup: the LDS unit runs its instructions in order, so the image only needs a compiler-level
+        // fence (wavefront scope emits no s_waitcnt: outstanding matrix loads and page stores keep flying across records).
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        const char* img = lds_buf + al;
+        uint32_t head = (16u - al) & 15u;
+        if (head > total) head = total;
+        const uint32_t nwords = (total - head) >> 4;
         const uint32_t tail_at = head + (nwords << 4);
-        if ((uint32_t)lane < head) gdst[g][lane] = img[lane];
+        if ((uint32_t)lane < head) gdst[lane] = img[lane];
         const uint4* lsrc = reinterpret_cast<const uint4*>(img + head);
-        uint4* gw = reinterpret_cast<uint4*>(gdst[g] + head);
+        uint4* gw = reinterpret_cast<uint4*>(gdst + head);
         for (uint32_t wq = lane; wq < nwords; wq += kAsmRows) gw[wq] = lsrc[wq];
-        if ((uint32_t)lane < total[g] - tail_at) gdst[g][tail_at + lane] = img[tail_at + lane];
+        if ((uint32_t)lane < total - tail_at) gdst[tail_at + lane] = img[tail_at + lane];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      } else {                                              // longer than the LDS image (very long PL vectors): straight to HBM
+        char* dst = gdst + excl;
+        for (uint32_t b = 0; b < len; ++b) dst[b] = cur_src[b];
       }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
   }
 }
+
 // sort key of the assembly order: (block of 2^block_log2 consecutive records, record type); the value is the record index
 __global__ void k_order_keys(const uint8_t* rtype, int32_t base, int64_t n, int block_log2, uint32_t* keys, int32_t* vals) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -790,6 +776,14 @@ struct DevicePipeline::Impl {
     HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, in, out, T(0), n, rocprim::plus<T>(), stream));
     void* t = temp_storage(bytes);
     HIP_CHECK(rocprim::exclusive_scan(t, bytes, in, out, T(0), n, rocprim::plus<T>(), stream));
+  }
+  // a + b with one stream synchronisation (the usual "last exclusive-scan element + last count" total)
+  template <class A, class B> int64_t read_back_sum(const A* pa, const B* pb) {
+    A a; B b;
+    HIP_CHECK(hipMemcpyAsync(&a, pa, sizeof(A), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(&b, pb, sizeof(B), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    return (int64_t)a + (int64_t)b;
   }
   template <class T> T read_back(const T* p) {
     T v;
@@ -1013,7 +1007,10 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   S.cwin.ensure(2);
   STAGE("k_cell_window");
   hipLaunchKernelGGL(k_cell_window, dim3(1), dim3(64), 0, st, fr.begin, C, qb > INT64_MIN + S.max_span ? qb - S.max_span : INT64_MIN, qe, S.cwin.p);
-  const int64_t c_base = S.read_back(S.cwin.p), c_end = S.read_back(S.cwin.p + 1);
+  int64_t cw[2];
+  HIP_CHECK(hipMemcpyAsync(cw, S.cwin.p, sizeof(cw), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  const int64_t c_base = cw[0], c_end = cw[1];
   const int64_t CW = c_end - c_base;
   if (CW <= 0) return;
   // ---- S3 events -> boundaries -> records --------------------------------------------------------------------------
@@ -1030,7 +1027,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   hipLaunchKernelGGL(k_event_delta, dim3(blocks_for(NE)), dim3(kBlock), 0, st, S.ev_keys_sorted.p, NE, S.ev_delta.p, S.run_end.p);
   S.incl_scan(S.ev_delta.p, S.ev_incl.p, (size_t)NE, PackedAdd());
   S.excl_scan(S.run_end.p, S.run_excl.p, (size_t)NE);
-  const int64_t U = (int64_t)S.read_back(S.run_excl.p + (NE - 1)) + (int64_t)S.read_back(S.run_end.p + (NE - 1));
+  const int64_t U = S.read_back_sum(S.run_excl.p + (NE - 1), S.run_end.p + (NE - 1));
   int64_t P = 0;
   if (U > 0) {
     S.bpos.ensure(U + 1); S.bcov.ensure(U + 1); S.bdel.ensure(U + 1); S.bnrec.ensure(U + 1); S.rbase.ensure(U + 1);
@@ -1040,7 +1037,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
     STAGE("k_boundary_nrec");
     hipLaunchKernelGGL(k_boundary_nrec, dim3(blocks_for(U)), dim3(kBlock), 0, st, bd, U);
     S.excl_scan(S.bnrec.p, S.rbase.p, (size_t)U);
-    P = S.read_back(S.rbase.p + (U - 1)) + S.read_back(S.bnrec.p + (U - 1));
+    P = S.read_back_sum(S.rbase.p + (U - 1), S.bnrec.p + (U - 1));
     if (P > 0) {
       S.rstart.ensure(P); S.rend.ensure(P);
       STAGE("k_record_expand");
@@ -1069,9 +1066,10 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   S.heavy_count.ensure(CW + 1); S.hoff.ensure(CW + 2);
   STAGE("k_cell_ranges");
   hipLaunchKernelGGL(k_cell_ranges, dim3(blocks_for(CW)), dim3(kBlock), 0, st, fr, pl, cm, rec, c_base, CW, qb, qe, da, S.heavy_count.p, S.counters.p);
-  for (int i = 0; i < nf + 2; ++i) S.incl_scan(S.diff.p + (size_t)i * stride, S.diff.p + (size_t)i * stride, (size_t)stride, rocprim::plus<int32_t>());
+  // every difference array sums to zero over its P+1 elements, so ONE scan over the concatenation equals nf+2 separate scans
+  S.incl_scan(S.diff.p, S.diff.p, ndiff, rocprim::plus<int32_t>());
   S.excl_scan(S.heavy_count.p, S.hoff.p, (size_t)CW);
-  const int64_t T = S.read_back(S.hoff.p + (CW - 1)) + S.read_back(S.heavy_count.p + (CW - 1));
+  const int64_t T = S.read_back_sum(S.hoff.p + (CW - 1), S.heavy_count.p + (CW - 1));
   stats.num_heavy_incidences = T;
   stats.num_cells_in_window = S.read_back(S.counters.p);
   // ---- S6 incidences sorted by (record,row) --------------------------------------------------------------------------
@@ -1085,7 +1083,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
     STAGE("k_lut_len");
     hipLaunchKernelGGL(k_lut_len, dim3(blocks_for(T)), dim3(kBlock), 0, st, S.inc_vals_sorted.p, S.cflags.p, T, S.lut_len.p);
     S.excl_scan(S.lut_len.p, S.i2m_off.p, (size_t)T);
-    lut_total = S.read_back(S.i2m_off.p + (T - 1)) + S.read_back(S.lut_len.p + (T - 1));
+    lut_total = (uint32_t)S.read_back_sum(S.i2m_off.p + (T - 1), S.lut_len.p + (T - 1));
     HIP_CHECK(hipMemcpyAsync(S.i2m_off.p + T, &lut_total, sizeof(uint32_t), hipMemcpyHostToDevice, st));
     HIP_CHECK(hipStreamSynchronize(st));
   } else {
@@ -1134,13 +1132,13 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   S.untabled.ensure(P + 1); S.ubase.ensure(P + 1); S.urec.ensure(P + 1);
   hipLaunchKernelGGL(k_type_lookup, dim3(blocks_for(P)), dim3(kBlock), 0, st, so, P, S.type_hkeys.p, S.type_hid.p, S.rtype.p, S.untabled.p);
   S.excl_scan(S.untabled.p, S.ubase.p, (size_t)P);
-  const int64_t UR = (int64_t)S.read_back(S.ubase.p + (P - 1)) + S.read_back(S.untabled.p + (P - 1));
+  const int64_t UR = S.read_back_sum(S.ubase.p + (P - 1), S.untabled.p + (P - 1));
   if (UR > 0) hipLaunchKernelGGL(k_untabled_records, dim3(blocks_for(P)), dim3(kBlock), 0, st, S.untabled.p, S.ubase.p, P, S.urec.p);
   S.tmask.ensure(CW); S.nslots.ensure(CW + 1); S.tbase.ensure(CW + 1);
   STAGE("k_cell_types");
   hipLaunchKernelGGL(k_cell_types, dim3(blocks_for(CW)), dim3(kBlock), 0, st, S.cflags.p, S.k_lo.p, S.k_hi.p, S.rtype.p, c_base, CW, S.tmask.p, S.nslots.p);
   S.excl_scan(S.nslots.p, S.tbase.p, (size_t)CW);
-  const uint64_t SL = (uint64_t)S.read_back(S.tbase.p + (CW - 1)) + S.read_back(S.nslots.p + (CW - 1));
+  const uint64_t SL = (uint64_t)S.read_back_sum(S.tbase.p + (CW - 1), S.nslots.p + (CW - 1));
   const int ntypes = S.read_back(S.counters.p + 1);
   const uint64_t NS = (uint64_t)kMaxTypes + SL + (uint64_t)T + (uint64_t)UR * (uint64_t)N;
   if (NS >= (1ull << 32)) throw GenomicsDBDeviceException("entry text table exceeds 2^32 slots: split the query interval");
@@ -1155,7 +1153,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   if (UR > 0) hipLaunchKernelGGL(k_slots_untabled<0>, dim3(blocks_for(UR * N, 64)), dim3(64), 0, st, stt, so, ri, rec, S.urec.p, UR, N, S.err.p);
   hipLaunchKernelGGL(k_slot_units, dim3(blocks_for((int64_t)NS)), dim3(kBlock), 0, st, S.slot_len.p, (int64_t)NS, S.slot_units.p);
   S.excl_scan(S.slot_units.p, S.slot_off.p, (size_t)NS);
-  const uint64_t pool_units = (uint64_t)S.read_back(S.slot_off.p + (NS - 1)) + S.read_back(S.slot_units.p + (NS - 1));
+  const uint64_t pool_units = (uint64_t)S.read_back_sum(S.slot_off.p + (NS - 1), S.slot_units.p + (NS - 1));
   if (pool_units >= (1ull << 32)) throw GenomicsDBDeviceException("entry text pool exceeds 64 GiB: split the query interval");
   S.pool.ensure((size_t)pool_units * 16 + 64);
   stt.pool = S.pool.p;
@@ -1238,15 +1236,8 @@ bool DevicePipeline::next_page(uint64_t arena_bytes, const char** dev_ptr, uint6
     S.resolved.ensure((size_t)np * iv.nchunks * kAsmRows);
     hipLaunchKernelGGL(k_assemble_size, wgrid, dim3(kAsmRows), 0, st, iv.ac, S.order.p, np, N, iv.nchunks, wrun, (uint64_t*)nullptr, S.resolved.p, kp);
   }
-  {
-    const int G = assemble_group();
-    const dim3 ggrid(wruns * (unsigned)((iv.nchunks + G - 1) / G));
-    auto launch = [&](auto kernel) {
-      hipLaunchKernelGGL(kernel, ggrid, dim3(kAsmRows), 0, st, (const char*)S.pool.p, (const uint32_t*)S.prefix_len.p, (const uint2*)S.resolved.p,
-                         iv.resolved_whole ? (int64_t)0 : kp, (const int32_t*)S.order.p, np, iv.nchunks, wrun, (const uint64_t*)S.chunk_off.p, page_base, S.arena.p);
-    };
-    if (G == 4) launch(k_assemble_write<4>); else if (G == 2) launch(k_assemble_write<2>); else launch(k_assemble_write<1>);
-  }
+  hipLaunchKernelGGL(k_assemble_write, wgrid, dim3(kAsmRows), 0, st, (const char*)S.pool.p, (const uint32_t*)S.prefix_len.p, (const uint2*)S.resolved.p,
+                     iv.resolved_whole ? (int64_t)0 : kp, (const int32_t*)S.order.p, np, iv.nchunks, wrun, (const uint64_t*)S.chunk_off.p, page_base, S.arena.p);
   HIP_CHECK(hipEventRecord(w2, st));
   HIP_CHECK(hipStreamSynchronize(st));
   float ms_site = 0, ms_entry = 0;
