@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--window-bp", type=int, default=200_000, help="columns per step (one batch)")
     ap.add_argument("--arena-mb", type=int, default=16384, help="HBM page for the output text")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-bp", type=int, default=5000)
+    ap.add_argument("--cpu-sample-bp", type=int, default=12000, help="columns of the bounded CPU-baseline sample (~15 s of oracle time)")
     args = ap.parse_args()
 
     import torch

@@ -66,7 +66,7 @@ struct HeavyLists {     // incidences (record, heavy cell) sorted by (record, ro
   const uint32_t* i2m_off;   // [T+1]
   int8_t* i2m;               // input allele idx -> merged allele idx (-1: none)
   uint8_t* iflags;           // [T]
-  int8_t* gt_override;       // [T*2]
+  int8_t* gt_override;       // [T*GDB_MAX_PLOIDY] min-PL genotype of a spanning deletion (reduced allele indices)
 };
 
 struct PresenceCounts {  // per record, from difference arrays + scan
@@ -114,6 +114,33 @@ GDB_HD uint32_t gdb_f2u(float f) { union { float f; uint32_t u; } x; x.f = f; re
 GDB_HD bool gdb_int_valid(int32_t v) { return v != GDB_BCF_INT32_MISSING && v != GDB_BCF_INT32_VECTOR_END; }
 GDB_HD bool gdb_float_valid(float v) { uint32_t u = gdb_f2u(v); return u != GDB_BCF_FLOAT_MISSING_BITS && u != GDB_BCF_FLOAT_VECTOR_END_BITS; }
 GDB_HD int gdb_alleles2gt(int a, int b) { return a > b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; }
+// General ploidy (KnownFieldInfo::get_number_of_genotypes / VariantOperations::get_genotype_index,
+// src/main/cpp/src/utils/known_field_info.cc:130-162, variant_operations.cc:300-321): genotypes are the non-decreasing
+// allele tuples a[0] <= ... <= a[p-1] in colexicographic order; index = sum_i C(a[i] + i, i + 1).
+GDB_HD int64_t gdb_choose(int n, int k) {
+  if (k < 0 || k > n) return 0;
+  int64_t r = 1;
+  for (int i = 1; i <= k; ++i) r = r * (n - k + i) / i;
+  return r;
+}
+GDB_HD int64_t gdb_genotype_index_sorted(const int* a, int p) {
+  int64_t g = 0;
+  for (int i = 0; i < p; ++i) g += gdb_choose(a[i] + i, i + 1);
+  return g;
+}
+GDB_HD int64_t gdb_genotype_index(const int* a, int p) {  // a[] in any order, p <= GDB_MAX_PLOIDY
+  int t[GDB_MAX_PLOIDY];
+  for (int i = 0; i < p; ++i) { int v = a[i], j = i; while (j > 0 && t[j - 1] > v) { t[j] = t[j - 1]; --j; } t[j] = v; }
+  return gdb_genotype_index_sorted(t, p);
+}
+// next tuple in VCF (colex) order over alleles 0..nalleles-1; false after the last one
+GDB_HD bool gdb_next_genotype(int* a, int p, int nalleles) {
+  for (int i = 0; i < p; ++i) {
+    const int bound = i + 1 < p ? a[i + 1] : nalleles - 1;
+    if (a[i] < bound) { ++a[i]; for (int j = 0; j < i; ++j) a[j] = 0; return true; }
+  }
+  return false;
+}
 
 template <class Sink> GDB_HD void put_u64(Sink& s, uint64_t v) {
   char buf[20];
@@ -277,6 +304,7 @@ GDB_HD void classify_cell(const FragmentView& fr, const CombinePlan& pl, const C
   for (int i = 0; i < pl.n_info; ++i) if ((vmask >> pl.info_field[i]) & 1) heavy = true;
   if (pl.qual_combine_op != GDB_OP_UNKNOWN && pl.f_QUAL >= 0 && ((vmask >> pl.f_QUAL) & 1)) heavy = true;
   if (pl.produce_FILTER_field && pl.f_FILTER >= 0 && ((vmask >> pl.f_FILTER) & 1)) heavy = true;
+  if (pl.f_ID >= 0 && ((vmask >> pl.f_ID) & 1)) heavy = true;   // ID union (broad_combined_gvcf.cc:730-763)
   if (heavy) flags |= GDB_CF_HEAVY;
   flags |= ((uint32_t)nalt & 0xFFu) << 8;
   flags |= ((uint32_t)ploidy & 0xFu) << 16;
@@ -455,6 +483,7 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
             if (ploidy == 0) gt_idx = 0;
             else if (ploidy == 1) gt_idx = aidx;
             else if (ploidy == 2) gt_idx = gdb_alleles2gt(aidx, aidx);
+            else if (ploidy <= GDB_MAX_PLOIDY) { int hom[GDB_MAX_PLOIDY]; for (int q = 0; q < ploidy; ++q) hom[q] = aidx; gt_idx = gdb_genotype_index_sorted(hom, ploidy); }
             else { *err |= GDB_ERR_UNSUPPORTED_PLOIDY; gt_idx = 0x7FFFFFFF; }
             if (gt_idx < npl && plv[gt_idx] < lowest_pl) { lowest_pl = plv[gt_idx]; lowest = aidx; }
           }
@@ -488,11 +517,25 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
             int32_t v = gi < npl ? plv[gi] : GDB_BCF_INT32_MISSING;
             if (gdb_int_valid(v) && v < best_min) { best_min = v; best_a = a; best_b = b2; }
           }
+        } else if (ploidy <= GDB_MAX_PLOIDY) {   // general ploidy: VCF (colex) genotype order, first minimum wins (remap_..._general + tracker)
+          int g[GDB_MAX_PLOIDY], in[GDB_MAX_PLOIDY];
+          for (int q = 0; q < ploidy; ++q) g[q] = 0;
+          do {
+            for (int q = 0; q < ploidy; ++q) in[q] = red2in[g[q]];
+            const int64_t gi = gdb_genotype_index(in, ploidy);
+            const int32_t v = gi < npl ? plv[gi] : GDB_BCF_INT32_MISSING;
+            if (gdb_int_valid(v) && v < best_min) {
+              best_min = v; best_a = g[0];
+              for (int q = 0; q < ploidy; ++q) cx.hl.gt_override[GDB_MAX_PLOIDY * t + q] = (int8_t)g[q];
+            }
+          } while (gdb_next_genotype(g, ploidy, nred));
         } else *err |= GDB_ERR_UNSUPPORTED_PLOIDY;
         if (best_a >= 0) {
           iflag |= GDB_IF_GT_OVERRIDE;
-          cx.hl.gt_override[2 * t] = (int8_t)best_a;      // reduced allele idx: 0 REF, 1 '*', 2 <NON_REF>
-          cx.hl.gt_override[2 * t + 1] = (int8_t)best_b;
+          if (ploidy <= 2) {
+            cx.hl.gt_override[GDB_MAX_PLOIDY * t] = (int8_t)best_a;      // reduced allele idx: 0 REF, 1 '*', 2 <NON_REF>
+            cx.hl.gt_override[GDB_MAX_PLOIDY * t + 1] = (int8_t)best_b;
+          }
         }
       }
     } else {
@@ -548,7 +591,41 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
   sink.write(cx.qw.contig_names + ctg.name_off, ctg.name_len);
   sink.put('\t');
   put_i64(sink, s_k - ctg.offset + 1);
-  sink.put('\t'); sink.put('.'); sink.put('\t');  // ID: not produced on the device path (host rejects ID queries)
+  sink.put('\t');
+  // ID: union of the ';'-separated tokens of the live calls, in sorted order (merge_ID_field, broad_combined_gvcf.cc:730-763;
+  // the reference's DEBUG build - the one the goldens come from - keeps them in a std::set)
+  {
+    const char* tp[GDB_MAX_ID_TOKENS]; int tn[GDB_MAX_ID_TOKENS]; int nt = 0;
+    if (pl.f_ID >= 0)
+      for (int64_t t = hb; t < he; ++t) {
+        const int64_t c = cx.hl.cell[t];
+        if (!field_valid(cx.cm, c, pl.f_ID)) continue;
+        int n;
+        const char* p = cell_field<char>(cx.fr, pl, pl.f_ID, c, n);
+        int last = 0;
+        for (int i = 0; i <= n; ++i) {
+          if (i < n && p[i] != ';') continue;
+          const int len = i - last;
+          if (i == n && len == 0) break;                    // nothing behind a trailing ';'
+          int pos = 0, cmp = 1;                             // insertion point in the sorted token list
+          for (; pos < nt; ++pos) {
+            const int m = len < tn[pos] ? len : tn[pos];
+            cmp = 0;
+            for (int j = 0; j < m && cmp == 0; ++j) cmp = (int)(unsigned char)p[last + j] - (int)(unsigned char)tp[pos][j];
+            if (cmp == 0) cmp = len - tn[pos];
+            if (cmp <= 0) break;
+          }
+          if (pos == nt || cmp != 0) {
+            if (nt >= GDB_MAX_ID_TOKENS) { *err |= GDB_ERR_TOO_MANY_ID_TOKENS; }
+            else { for (int j = nt; j > pos; --j) { tp[j] = tp[j - 1]; tn[j] = tn[j - 1]; } tp[pos] = p + last; tn[pos] = len; ++nt; }
+          }
+          last = i + 1;
+        }
+      }
+    if (nt == 0) sink.put('.');
+    for (int i = 0; i < nt; ++i) { if (i) sink.put(';'); sink.write(tp[i], tn[i]); }
+  }
+  sink.put('\t');
   sink.write(mref, mref_len);
   sink.put('\t');
   if (num_merged == 1) sink.put('.');
@@ -692,7 +769,7 @@ template <class Sink> GDB_FIELD_FN Sink emit_GT(Sink s, const EntryCtx& cx, cons
     if (pl.produce_GT_field) {
       int32_t a = g[j];
       if (em.iflag & GDB_IF_GT_OVERRIDE) {  // min-PL genotype over the reduced alleles: 0 REF, 1 '*', 2 <NON_REF>
-        const int ra = cx.hl.gt_override[2 * em.inc + (out_i < 2 ? out_i : 1)];
+        const int ra = cx.hl.gt_override[GDB_MAX_PLOIDY * em.inc + (out_i < GDB_MAX_PLOIDY ? out_i : GDB_MAX_PLOIDY - 1)];
         if (ra == 0) m = 0;
         else if (ra == 2) m = ri.num_merged - 1;
         else { for (int q = 1; q < em.n_in; ++q) if (em.i2m && em.i2m[q] >= 0 && em.i2m[q] != ri.num_merged - 1) { m = em.i2m[q]; break; } }
@@ -775,6 +852,20 @@ template <class Sink> GDB_FIELD_FN Sink emit_remap_genotypes(Sink s, const int32
         if (v == GDB_BCF_INT32_MISSING) s.put('.'); else put_i32(s, v);
       }
     }
+  } else if (ploidy >= 3 && ploidy <= GDB_MAX_PLOIDY) {
+    // remap_data_based_on_genotype_general (variant_field_handler.cc:198-297): merged genotypes in VCF order
+    int g[GDB_MAX_PLOIDY], in[GDB_MAX_PLOIDY];
+    for (int q = 0; q < ploidy; ++q) g[q] = 0;
+    bool first = true;
+    do {
+      if (!first) s.put(',');
+      first = false;
+      bool missing = false;
+      for (int q = 0; q < ploidy; ++q) { in[q] = em.lookup(g[q]); if (in[q] < 0) missing = true; }
+      int32_t v = GDB_BCF_INT32_MISSING;
+      if (!missing) { const int64_t gi = gdb_genotype_index(in, ploidy); if (gi < n) v = p[gi]; }
+      if (v == GDB_BCF_INT32_MISSING) s.put('.'); else put_i32(s, v);
+    } while (gdb_next_genotype(g, ploidy, num_merged));
   } else {
     *err |= GDB_ERR_UNSUPPORTED_PLOIDY;
     s.put('.');

@@ -26,6 +26,8 @@
 #define GDB_MAX_FORMAT_FIELDS 24
 #define GDB_MAX_MERGED_ALLELES 128  // per record (REF included)
 #define GDB_MAX_INPUT_ALLELES 32    // per cell (REF included)
+#define GDB_MAX_PLOIDY 8            // general-ploidy genotype enumeration (G-length fields, min-PL genotype)
+#define GDB_MAX_ID_TOKENS 16        // distinct ';'-separated ID tokens per output record
 
 // htslib / TileDB sentinels (reference include/vcf/vcf.h:59-218)
 #define GDB_BCF_INT32_MISSING ((int32_t)0x80000000)
@@ -48,10 +50,11 @@ enum GdbErr {
   GDB_ERR_OVERLAP_NOT_REFBLOCK_OR_DELETION = 1u << 0,  // query_variants.cc:533-535
   GDB_ERR_TOO_MANY_MERGED_ALLELES = 1u << 1,
   GDB_ERR_TOO_MANY_INPUT_ALLELES = 1u << 2,
-  GDB_ERR_UNSUPPORTED_PLOIDY = 1u << 3,               // device path handles ploidy 1 and 2
+  GDB_ERR_UNSUPPORTED_PLOIDY = 1u << 3,               // ploidy above GDB_MAX_PLOIDY
   GDB_ERR_FLOAT_RANGE = 1u << 4,                      // float text outside the pinned kputd range
   GDB_ERR_ARENA_OVERFLOW = 1u << 5,
-  GDB_ERR_INTERNAL = 1u << 6
+  GDB_ERR_INTERNAL = 1u << 6,
+  GDB_ERR_TOO_MANY_ID_TOKENS = 1u << 7                // more than GDB_MAX_ID_TOKENS distinct ID tokens in one record
 };
 
 struct GdbFieldDesc {

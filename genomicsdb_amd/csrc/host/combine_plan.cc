@@ -48,7 +48,6 @@ HostPlan build_combine_plan(const VariantQueryConfig& qc, const std::string& tmp
     }
   }
   if (pl.f_REF < 0 || pl.f_ALT < 0) throw BroadCombinedGVCFException("REF and ALT must be part of the query");
-  if (pl.f_ID >= 0) throw UnsupportedOnDeviceException("ID field merge is not implemented on the device path yet");
   if (pl.f_GT >= 0 && !(pl.field[pl.f_GT].length == GDB_VL_P || pl.field[pl.f_GT].length == GDB_VL_PP))
     throw BroadCombinedGVCFException("GT must have length descriptor P or PP");
   // ---- header lines -----------------------------------------------------------------------------------

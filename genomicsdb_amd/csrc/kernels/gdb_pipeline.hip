@@ -1074,7 +1074,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   stats.num_cells_in_window = S.read_back(S.counters.p);
   // ---- S6 incidences sorted by (record,row) --------------------------------------------------------------------------
   S.inc_keys.ensure(T + 1); S.inc_keys_sorted.ensure(T + 1); S.inc_vals.ensure(T + 1); S.inc_vals_sorted.ensure(T + 1);
-  S.hbase.ensure(P + 2); S.lut_len.ensure(T + 1); S.i2m_off.ensure(T + 2); S.iflags.ensure(T + 1); S.gt_override.ensure(2 * T + 2);
+  S.hbase.ensure(P + 2); S.lut_len.ensure(T + 1); S.i2m_off.ensure(T + 2); S.iflags.ensure(T + 1); S.gt_override.ensure((size_t)GDB_MAX_PLOIDY * T + 2);
   uint32_t lut_total = 0;
   if (T > 0) {
     STAGE("k_incidence_fill");

@@ -101,7 +101,7 @@ std::string run_interval(const HostPlan& hp, const HostFragment& hf, const VidMa
   for (int64_t k = 0; k <= P; ++k) hbase[k] = stage_heavy_base(ikeys.data(), T, N, k);
   std::vector<uint32_t> i2m_off(T + 1, 0);
   for (int64_t t = 0; t < T; ++t) i2m_off[t + 1] = i2m_off[t] + GDB_CF_NALT(cflags[ivals[t]]) + 1;
-  std::vector<int8_t> i2m(i2m_off[T] + 1), gto(2 * T + 2);
+  std::vector<int8_t> i2m(i2m_off[T] + 1), gto((size_t)GDB_MAX_PLOIDY * T + 2);
   std::vector<uint8_t> iflags(T + 1);
   HeavyLists hl{hbase.data(), ivals.data(), i2m_off.data(), i2m.data(), iflags.data(), gto.data()};
   // S7 site pass 0

@@ -153,3 +153,71 @@ def test_untabled_record_types_take_the_direct_path(gdb, tmp_path, monkeypatch, 
     assert st.num_record_types == int(max_types)
     assert got == want
     eng.close()
+
+
+def _c2_engine(gdb, tmp_path, N, B, L, slack=2500):
+    from genomicsdb_amd import synth
+    g = synth.Generator(N, B, L + slack)
+    cells, nc = g.chunk_bytes(B + L + slack)
+    q = helpers.synth_query(tmp_path, N, B, B + L - 1)
+    eng = gdb.CombineEngine(q)
+    eng.stage_cells(cells)
+    eng.set_reference(B, synth.reference(B, L + slack + 4096))
+    return eng, q, cells
+
+
+def test_c2_width_1000_samples_matches_oracle(gdb, tmp_path):
+    """BASELINE.json configs[1] at its full sample count (1 000) on a column window the oracle finishes in seconds"""
+    from genomicsdb_amd import synth
+    N, B, L = 1000, 10_000_000, 1500
+    eng, q, cells = _c2_engine(gdb, tmp_path, N, B, L)
+    want, nrec, _ = helpers.oracle_run_synth(q, cells, synth.SEED, with_header=False)
+    got, st = eng.run_interval(B, B + L - 1, arena_bytes=8 << 20)
+    assert st.num_records == nrec and st.pages > 3
+    assert got == want
+    eng.close()
+
+
+def test_c2_scale_properties(gdb, tmp_path, monkeypatch):
+    """1 000 samples x 60 kb (2.7 GB of VCF text): properties that do not need the oracle at this size -
+    (1) the bytes do not depend on paging, on the resolved-matrix mode, on the record visiting order or on the type-table
+        capacity;  (2) every record line has 9 + N tab-separated columns, positions ascend, END >= POS;
+    (3) the first 1 200 columns equal the oracle's output for that window (records are independent of what follows them)."""
+    import hashlib
+    from genomicsdb_amd import synth
+    N, B, L = 1000, 10_000_000, 60_000
+    eng, q, cells = _c2_engine(gdb, tmp_path, N, B, L)
+    ref, st = eng.run_interval(B, B + L - 1, arena_bytes=4 << 30)
+    assert st.pages == 1 and st.num_records > 50_000
+    h_ref = hashlib.sha256(ref).hexdigest()
+    for env, arena in (({"GDBAMD_RESOLVED_MB": "0"}, 256 << 20), ({"GDBAMD_ORDER_BLOCK_LOG2": "30"}, 1 << 30),
+                       ({"GDBAMD_ORDER_BLOCK_LOG2": "0", "GDBAMD_MAX_TYPES": "3"}, 700 << 20)):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got, st2 = eng.run_interval(B, B + L - 1, arena_bytes=arena)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert st2.num_records == st.num_records and len(got) == len(ref)
+        assert hashlib.sha256(got).hexdigest() == h_ref, env
+    lines = ref.split(b"\n")
+    assert lines[-1] == b"" and len(lines) - 1 == st.num_records
+    prev = 0
+    for ln in lines[:-1:97]:                      # every 97th record: column count, order, END
+        cols = ln.split(b"\t")
+        assert len(cols) == 9 + N
+        pos = int(cols[1])
+        assert pos > prev
+        prev = pos
+        info = cols[7]
+        if info.startswith(b"END="):
+            assert int(info[4:].split(b";")[0]) >= pos
+    # window prefix against the oracle
+    n_small = 1200
+    g = synth.Generator(N, B, n_small + 2500)
+    small_cells, _ = g.chunk_bytes(B + n_small + 2500)
+    q_small = helpers.synth_query(tmp_path, N, B, B + n_small - 1)
+    want, nrec, _ = helpers.oracle_run_synth(q_small, small_cells, synth.SEED, with_header=False)
+    want_lines = want.split(b"\n")[:-1]
+    # the last oracle record may be clipped by the smaller query window: compare all but the last
+    assert lines[:len(want_lines) - 1] == want_lines[:-1]
+    eng.close()

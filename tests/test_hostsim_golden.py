@@ -10,11 +10,7 @@ DEVICE_UNSUPPORTED = {
     "t6_7_8_new_field_gatk": "move_to_FORMAT",
     "info_ops0": "combine operation",
     "info_ops1": "combine operation",
-    "t0_1_2_DS_ID_vcf_at_0": "ID field",
 }
-HT = "t0_haploid_triploid_1_2_3_triploid_deletion"
-for suffix in ("_loading", "_vcf", "_vcf_produce_GT", "_vcf_produce_GT_for_min_value_PL"):
-    DEVICE_UNSUPPORTED[HT + suffix] = "ID field"   # vid_DS_ID_phased_GT.json declares ID; triploid needs general ploidy too
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
