@@ -402,6 +402,86 @@ template <class T> GDB_HD bool reduce_scalar(const SiteCtx& cx, int64_t k, int f
   return false;
 }
 
+// element helpers shared by the int32 and float flavours of the vector emitters
+GDB_HD bool elem_is_vector_end(int32_t v) { return v == GDB_BCF_INT32_VECTOR_END; }
+GDB_HD bool elem_is_vector_end(float v) { return gdb_f2u(v) == GDB_BCF_FLOAT_VECTOR_END_BITS; }
+GDB_HD bool elem_is_missing(int32_t v) { return v == GDB_BCF_INT32_MISSING; }
+GDB_HD bool elem_is_missing(float v) { return gdb_f2u(v) == GDB_BCF_FLOAT_MISSING_BITS; }
+GDB_HD void elem_set_missing(int32_t& v) { v = GDB_BCF_INT32_MISSING; }
+GDB_HD void elem_set_missing(float& v) { union { uint32_t u; float f; } x; x.u = GDB_BCF_FLOAT_MISSING_BITS; v = x.f; }
+template <class Sink> GDB_HD void put_elem(Sink& s, int32_t v, uint32_t*) { if (elem_is_missing(v)) s.put('.'); else put_i32(s, v); }
+template <class Sink> GDB_HD void put_elem(Sink& s, float v, uint32_t* err) {
+  if (elem_is_missing(v)) s.put('.');
+  else if (!put_float(s, v)) *err |= GDB_ERR_FLOAT_RANGE;
+}
+
+// element_wise_sum / concatenate INFO combiners (handle_VCF_field_combine_operation, broad_combined_gvcf.cc:374-429;
+// compute_valid_element_wise_sum, variant_field_handler.cc:618-664).  Allele-dependent fields (A / R length) are read
+// through the call's allele LUT, i.e. in merged-allele order with the <NON_REF> fallback, like the reference reads them from
+// its remapped variant.  Values live in a small per-record array: more than GDB_MAX_INFO_VECTOR elements raise an error bit.
+template <class T, class Sink> GDB_HD bool info_vector_combine(const SiteCtx& cx, int64_t k, int f, int op, int num_merged, bool non_ref_exists, bool remapping_needed,
+                                                             Sink& sink, bool& any, uint32_t* err) {
+  const CombinePlan& pl = cx.pl;
+  const GdbFieldDesc& fd = pl.field[f];
+  const int64_t b = cx.hl.base[k], e = cx.hl.base[k + 1];
+  const int64_t s_k = cx.rec.start[k];
+  const bool allele_dep = remapping_needed && (fd.length == GDB_VL_A || fd.length == GDB_VL_R);
+  const bool alt_only = fd.length == GDB_VL_A;
+  T r[GDB_MAX_INFO_VECTOR];
+  int num_valid = 0, nconcat = 0;
+  bool name_written = false;
+  for (int64_t t = b; t < e; ++t) {
+    if (inc_is_spanning(cx, t, s_k)) continue;           // INFO of spanning deletions is invalidated
+    const int64_t c = cx.hl.cell[t];
+    if (!field_valid(cx.cm, c, f)) continue;
+    int n_in;
+    const T* p = cell_field<T>(cx.fr, pl, f, c, n_in);
+    int n = n_in;
+    const int8_t* lut = cx.hl.i2m + cx.hl.i2m_off[t];
+    const int nal = (int)GDB_CF_NALT(cx.cm.cflags[c]) + 1;
+    int nr_in = -1;
+    if (allele_dep) {
+      n = alt_only ? num_merged - 1 : num_merged;
+      if (non_ref_exists) for (int a = 0; a < nal; ++a) if (lut[a] == num_merged - 1) nr_in = a;
+    }
+    for (int i = 0; i < n; ++i) {
+      T v;
+      if (allele_dep) {
+        const int aj = alt_only ? i + 1 : i;
+        int in = -1;
+        for (int a = 0; a < nal; ++a) if (lut[a] == aj) { in = a; break; }
+        if (in < 0) in = nr_in;
+        const int idx = alt_only ? in - 1 : in;
+        if (in >= 0 && idx >= 0 && idx < n_in) v = p[idx]; else elem_set_missing(v);
+      } else v = p[i];
+      if (op == GDB_OP_CONCATENATE) {
+        if (!name_written) {
+          if (any) sink.put(';');
+          sink.write(cx.names.text + cx.names.field_name_off[f], cx.names.field_name_len[f]);
+          sink.put('=');
+          name_written = true; any = true;
+        }
+        if (elem_is_vector_end(v)) return true;           // htslib stops printing a vector at vector_end
+        if (nconcat++) sink.put(',');
+        put_elem(sink, v, err);
+        continue;
+      }
+      if (elem_is_missing(v) || elem_is_vector_end(v)) continue;
+      if (i >= GDB_MAX_INFO_VECTOR) { *err |= GDB_ERR_INFO_VECTOR_TOO_LONG; break; }
+      if (i < num_valid && !elem_is_missing(r[i])) r[i] += v;
+      else { r[i] = v; if (i >= num_valid) { for (int j = num_valid; j < i; ++j) elem_set_missing(r[j]); num_valid = i + 1; } }
+    }
+  }
+  if (op == GDB_OP_CONCATENATE) return name_written;
+  if (num_valid == 0) return false;
+  if (any) sink.put(';');
+  sink.write(cx.names.text + cx.names.field_name_off[f], cx.names.field_name_len[f]);
+  sink.put('=');
+  for (int i = 0; i < num_valid; ++i) { if (i) sink.put(','); put_elem(sink, r[i], err); }
+  any = true;
+  return true;
+}
+
 GDB_HD int find_contig(const QueryWindow& qw, int64_t pos) {  // VidMapper::get_contig_location
   int lo = 0, hi = qw.ncontigs;  // last contig with offset <= pos
   while (lo < hi) { int mid = (lo + hi) >> 1; if (qw.contigs[mid].offset <= pos) lo = mid + 1; else hi = mid; }
@@ -669,6 +749,11 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
     for (int i = 0; i < pl.n_info; ++i) {
       int f = pl.info_field[i];
       const GdbFieldDesc& fd = pl.field[f];
+      if (fd.combine_op == GDB_OP_ELEMENT_WISE_SUM || fd.combine_op == GDB_OP_CONCATENATE) {
+        if (fd.elem == GDB_ET_FLOAT) info_vector_combine<float>(cx, k, f, fd.combine_op, num_merged, non_ref_exists, !ref_block_only, sink, any, err);
+        else info_vector_combine<int32_t>(cx, k, f, fd.combine_op, num_merged, non_ref_exists, !ref_block_only, sink, any, err);
+        continue;
+      }
       if (fd.elem == GDB_ET_FLOAT) {
         float v;
         if (!reduce_scalar<float>(cx, k, f, fd.combine_op, false, v)) continue;
@@ -802,18 +887,18 @@ template <class Sink> GDB_FIELD_FN Sink emit_chars(Sink s, const EntryCtx& cx, i
   return s;
 }
 
-template <class Sink> GDB_FIELD_FN Sink emit_int_vector(Sink s, const int32_t* p, int n) {
+template <class Sink, class T> GDB_FIELD_FN Sink emit_vector(Sink s, const T* p, int n, uint32_t* err) {
   if (n == 0) { s.put('.'); return s; }
   for (int j = 0; j < n; ++j) {
-    if (p[j] == GDB_BCF_INT32_VECTOR_END) break;
+    if (elem_is_vector_end(p[j])) break;
     if (j) s.put(',');
-    if (p[j] == GDB_BCF_INT32_MISSING) s.put('.'); else put_i32(s, p[j]);
+    put_elem(s, p[j], err);
   }
   return s;
 }
 
 // remap_data_based_on_alleles: R- and A-length fields
-template <class Sink> GDB_FIELD_FN Sink emit_remap_alleles(Sink s, const int32_t* p, int n, const EntryMaps& em, int num_merged, bool alt_only) {
+template <class Sink, class T> GDB_FIELD_FN Sink emit_remap_alleles(Sink s, const T* p, int n, const EntryMaps& em, int num_merged, bool alt_only, uint32_t* err) {
   const int length = alt_only ? num_merged - 1 : num_merged;
   if (length == 0) { s.put('.'); return s; }
   for (int j = 0; j < length; ++j) {
@@ -822,21 +907,23 @@ template <class Sink> GDB_FIELD_FN Sink emit_remap_alleles(Sink s, const int32_t
     const int in_j = em.lookup(aj);
     const int idx = alt_only ? in_j - 1 : in_j;
     const bool has = in_j >= 0 && idx >= 0 && idx < n;
-    const int32_t v = has ? p[idx] : GDB_BCF_INT32_MISSING;
-    if (v == GDB_BCF_INT32_MISSING) s.put('.'); else put_i32(s, v);
+    T v;
+    if (has) v = p[idx]; else elem_set_missing(v);
+    put_elem(s, v, err);
   }
   return s;
 }
 
 // remap_data_based_on_genotype_{haploid,diploid}: G-length fields (PL)
-template <class Sink> GDB_FIELD_FN Sink emit_remap_genotypes(Sink s, const int32_t* p, int n, const EntryMaps& em, int num_merged, int ploidy, uint32_t* err) {
+template <class Sink, class T> GDB_FIELD_FN Sink emit_remap_genotypes(Sink s, const T* p, int n, const EntryMaps& em, int num_merged, int ploidy, uint32_t* err) {
   if (ploidy == 1) {
     for (int j = 0; j < num_merged; ++j) {
       if (j) s.put(',');
       const int in_j = em.lookup(j);
       const bool has = in_j >= 0 && in_j < n;
-      const int32_t v = has ? p[in_j] : GDB_BCF_INT32_MISSING;
-      if (v == GDB_BCF_INT32_MISSING) s.put('.'); else put_i32(s, v);
+      T v;
+      if (has) v = p[in_j]; else elem_set_missing(v);
+      put_elem(s, v, err);
     }
   } else if (ploidy == 2) {
     // output order gt = k(k+1)/2 + j, j <= k
@@ -848,8 +935,9 @@ template <class Sink> GDB_FIELD_FN Sink emit_remap_genotypes(Sink s, const int32
         const bool both = in_j >= 0 && in_k >= 0;
         const int gi = both ? gdb_alleles2gt(in_j, in_k) : 0;
         const bool has = both && gi < n;
-        const int32_t v = has ? p[gi] : GDB_BCF_INT32_MISSING;
-        if (v == GDB_BCF_INT32_MISSING) s.put('.'); else put_i32(s, v);
+        T v;
+        if (has) v = p[gi]; else elem_set_missing(v);
+        put_elem(s, v, err);
       }
     }
   } else if (ploidy >= 3 && ploidy <= GDB_MAX_PLOIDY) {
@@ -862,9 +950,10 @@ template <class Sink> GDB_FIELD_FN Sink emit_remap_genotypes(Sink s, const int32
       first = false;
       bool missing = false;
       for (int q = 0; q < ploidy; ++q) { in[q] = em.lookup(g[q]); if (in[q] < 0) missing = true; }
-      int32_t v = GDB_BCF_INT32_MISSING;
+      T v;
+      elem_set_missing(v);
       if (!missing) { const int64_t gi = gdb_genotype_index(in, ploidy); if (gi < n) v = p[gi]; }
-      if (v == GDB_BCF_INT32_MISSING) s.put('.'); else put_i32(s, v);
+      put_elem(s, v, err);
     } while (gdb_next_genotype(g, ploidy, num_merged));
   } else {
     *err |= GDB_ERR_UNSUPPORTED_PLOIDY;
@@ -912,6 +1001,13 @@ template <class Sink> GDB_HD Sink emit_field(Sink s, const EntryCtx& cx, const R
     s = emit_GT(s, cx, ri, em, c);
   } else if (fd.elem == GDB_ET_CHAR || fd.elem == GDB_ET_FLAG) {
     s = emit_chars(s, cx, f, c);
+  } else if (fd.elem == GDB_ET_FLOAT) {
+    int n;
+    const float* p = cell_field<float>(cx.fr, pl, f, c, n);
+    const bool allele_dep = fd.length == GDB_VL_A || fd.length == GDB_VL_R || fd.length == GDB_VL_G;
+    if (!em.remap || !allele_dep) s = emit_vector(s, p, n, err);
+    else if (fd.length == GDB_VL_G) s = emit_remap_genotypes(s, p, n, em, ri.num_merged, (int)GDB_CF_PLOIDY(em.cf), err);
+    else s = emit_remap_alleles(s, p, n, em, ri.num_merged, fd.length == GDB_VL_A, err);
   } else if (fd.elem != GDB_ET_INT) {
     *err |= GDB_ERR_INTERNAL;
     s.put('.');
@@ -919,9 +1015,9 @@ template <class Sink> GDB_HD Sink emit_field(Sink s, const EntryCtx& cx, const R
     int n;
     const int32_t* p = cell_field<int32_t>(cx.fr, pl, f, c, n);
     const bool allele_dep = fd.length == GDB_VL_A || fd.length == GDB_VL_R || fd.length == GDB_VL_G;
-    if (!em.remap || !allele_dep) s = emit_int_vector(s, p, n);
+    if (!em.remap || !allele_dep) s = emit_vector(s, p, n, err);
     else if (fd.length == GDB_VL_G) s = emit_remap_genotypes(s, p, n, em, ri.num_merged, (int)GDB_CF_PLOIDY(em.cf), err);
-    else s = emit_remap_alleles(s, p, n, em, ri.num_merged, fd.length == GDB_VL_A);
+    else s = emit_remap_alleles(s, p, n, em, ri.num_merged, fd.length == GDB_VL_A, err);
   }
   return s;
 }

@@ -27,6 +27,7 @@
 #define GDB_MAX_MERGED_ALLELES 128  // per record (REF included)
 #define GDB_MAX_INPUT_ALLELES 32    // per cell (REF included)
 #define GDB_MAX_PLOIDY 8            // general-ploidy genotype enumeration (G-length fields, min-PL genotype)
+#define GDB_MAX_INFO_VECTOR 64       // elements of an element_wise_sum INFO vector
 #define GDB_MAX_ID_TOKENS 16        // distinct ';'-separated ID tokens per output record
 
 // htslib / TileDB sentinels (reference include/vcf/vcf.h:59-218)
@@ -54,7 +55,8 @@ enum GdbErr {
   GDB_ERR_FLOAT_RANGE = 1u << 4,                      // float text outside the pinned kputd range
   GDB_ERR_ARENA_OVERFLOW = 1u << 5,
   GDB_ERR_INTERNAL = 1u << 6,
-  GDB_ERR_TOO_MANY_ID_TOKENS = 1u << 7                // more than GDB_MAX_ID_TOKENS distinct ID tokens in one record
+  GDB_ERR_TOO_MANY_ID_TOKENS = 1u << 7,               // more than GDB_MAX_ID_TOKENS distinct ID tokens in one record
+  GDB_ERR_INFO_VECTOR_TOO_LONG = 1u << 8              // element_wise_sum over more than GDB_MAX_INFO_VECTOR elements
 };
 
 struct GdbFieldDesc {

@@ -115,8 +115,10 @@ HostPlan build_combine_plan(const VariantQueryConfig& qc, const std::string& tmp
     bool add_FORMAT = (fi->m_is_vcf_FORMAT_field && (!sites_only || ke == GVCF_DP_FORMAT_IDX || ke == GVCF_MIN_DP_IDX)) ||
                       (fi->m_is_vcf_INFO_field && ((ke == GVCF_DP_IDX && op == GDB_OP_DP) || (op == GDB_OP_MOVE_TO_FORMAT && !sites_only)));
     if (add_INFO && op != GDB_OP_UNKNOWN) {  // UNKNOWN: "field will NOT be part of INFO fields" warning in the reference
-      if (op != GDB_OP_SUM && op != GDB_OP_MEAN && op != GDB_OP_MEDIAN)
-        throw UnsupportedOnDeviceException("INFO combine operation of field " + fi->m_name + " (element_wise_sum / concatenate / histogram_sum) is not on the device path yet");
+      if (op != GDB_OP_SUM && op != GDB_OP_MEAN && op != GDB_OP_MEDIAN && op != GDB_OP_ELEMENT_WISE_SUM && op != GDB_OP_CONCATENATE)
+        throw UnsupportedOnDeviceException("INFO combine operation of field " + fi->m_name + " (histogram_sum) is not on the device path yet");
+      if ((op == GDB_OP_ELEMENT_WISE_SUM || op == GDB_OP_CONCATENATE) && fi->m_length_descriptor == GDB_VL_G)
+        throw UnsupportedOnDeviceException("genotype-length INFO vector " + fi->m_name + " is not on the device path yet");
       if (fi->m_element_type != GDB_ET_INT && fi->m_element_type != GDB_ET_FLOAT)
         throw UnsupportedOnDeviceException("INFO reducer on non-numeric field " + fi->m_name);
       if (pl.n_info >= GDB_MAX_INFO_FIELDS) throw UnsupportedOnDeviceException("too many INFO fields");
@@ -125,9 +127,8 @@ HostPlan build_combine_plan(const VariantQueryConfig& qc, const std::string& tmp
     }
     if (add_FORMAT) {
       if (fi->m_is_vcf_FORMAT_field || op == GDB_OP_MOVE_TO_FORMAT) {
-        if (op == GDB_OP_MOVE_TO_FORMAT) throw UnsupportedOnDeviceException("move_to_FORMAT field " + fi->m_name + " is not on the device path yet");
-        if (fi->m_element_type == GDB_ET_FLOAT) throw UnsupportedOnDeviceException("float FORMAT field " + fi->m_name + " is not on the device path yet");
-        if (fi->is_length_allele_dependent() && fi->m_element_type != GDB_ET_INT) throw UnsupportedOnDeviceException("allele-dependent non-int FORMAT field " + fi->m_name);
+        if (fi->is_length_allele_dependent() && fi->m_element_type != GDB_ET_INT && fi->m_element_type != GDB_ET_FLOAT)
+          throw UnsupportedOnDeviceException("allele-dependent non-numeric FORMAT field " + fi->m_name);
         fmt_list.push_back(f);
         add_field_to_hdr_if_missing(fi->m_vcf_name, 2);
       } else {  // INFO DP handled with the FORMAT fields

@@ -50,3 +50,12 @@ def test_product_does_not_reference_oracle():
                     if f != "build.py":
                         bad.append(f)
     assert not bad, bad
+
+
+def test_unsupported_configurations_are_rejected_by_name():
+    """what the device path does not implement is refused when the plan is built (before any device work), with the
+    reference-facing exception text: allele-specific (2-D) annotation fields + histogram_sum"""
+    import genomicsdb_amd
+    q, _ = helpers.query_json("t0_1_2_all_asa.json", "vid_all_asa.json", {}, "load")
+    with pytest.raises(genomicsdb_amd.GenomicsDBException, match="UnsupportedOnDevice|not on the device path|multi-dimensional"):
+        genomicsdb_amd.CombineEngine(q)

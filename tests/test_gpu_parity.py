@@ -49,15 +49,19 @@ def test_stream_small_pages(gdb, case):
     assert got == helpers.golden_text(golden)
 
 
-@pytest.mark.parametrize("name", sorted(DEVICE_UNSUPPORTED))
-def test_unsupported_configurations_fail_loudly(gdb, name):
-    case = [c for c in CASES if c[0] == name][0]
-    _, callsets, vid, ov, golden, mode = case
-    cells = helpers.cells_for(callsets, vid)
-    q, pb = helpers.query_json(callsets, vid, ov, mode)
+def test_unsupported_configurations_fail_loudly(gdb, tmp_path):
+    """BCF output and allele-specific annotation fields are not produced by this build: errors, never silent fallbacks"""
+    q, _ = helpers.query_json("t0_1_2_all_asa.json", "vid_all_asa.json", {}, "load")
     with pytest.raises(gdb.GenomicsDBException):
-        s = gdb.GenomicsDBQueryStream(query_json=q, cells=cells)
-        s.read()
+        gdb.CombineEngine(q)
+    from genomicsdb_amd import _lib
+    import json as _json
+    case = CASES[0]
+    qj, _ = helpers.query_json(case[1], case[2], case[3], case[5])
+    qf = tmp_path / "q.json"
+    qf.write_text(_json.dumps(qj))
+    h = _lib.lib().gdb_mi355_init(b"", str(qf).encode(), b"", 0, 0, 0, 1 << 20, 1 << 20, 1, 0, 0, 1)   # is_bcf = 1
+    assert not h and b"bu" in _lib.lib().gdb_mi355_last_error()
 
 
 def test_engine_stats_and_header(gdb):

@@ -6,11 +6,7 @@ import helpers
 from golden_cases import CASES
 
 # golden cases whose configuration the device path rejects today, with the reason it reports
-DEVICE_UNSUPPORTED = {
-    "t6_7_8_new_field_gatk": "move_to_FORMAT",
-    "info_ops0": "combine operation",
-    "info_ops1": "combine operation",
-}
+DEVICE_UNSUPPORTED = {}   # every C++-path golden of the reference that the oracle covers now runs on the device path
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
