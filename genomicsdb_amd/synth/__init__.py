@@ -19,6 +19,8 @@ def lib():
         L = ctypes.CDLL(LIB)
         L.gdbsynth_create.restype = ctypes.c_void_p
         L.gdbsynth_create.argtypes = [ctypes.c_uint64, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64]
+        L.gdbsynth_create_dense.restype = ctypes.c_void_p
+        L.gdbsynth_create_dense.argtypes = [ctypes.c_uint64, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32]
         L.gdbsynth_destroy.argtypes = [ctypes.c_void_p]
         L.gdbsynth_next_chunk.restype = ctypes.c_int64
         L.gdbsynth_next_chunk.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64)]
@@ -30,9 +32,14 @@ def lib():
 class Generator:
     """cells of N samples over [B, B+L), handed out in column chunks (column-major order inside and across chunks)"""
 
-    def __init__(self, n_samples, B, L, seed=SEED):
+    def __init__(self, n_samples, B, L, seed=SEED, dense=None):
+        """dense = (begin, length, hot_stride, K): BASELINE.json configs[4]-style region where every sample starts an
+        insertion, drawn from a pool of K alleles, at every multiple of hot_stride"""
         self.n_samples, self.B, self.L, self.seed = n_samples, B, L, seed
-        self._h = lib().gdbsynth_create(seed, n_samples, B, L)
+        if dense:
+            self._h = lib().gdbsynth_create_dense(seed, n_samples, B, L, dense[0], dense[1], dense[2], dense[3])
+        else:
+            self._h = lib().gdbsynth_create(seed, n_samples, B, L)
 
     def next_chunk(self, col_end, nthreads=None):
         """returns (host address, nbytes, ncells) valid until the next call"""

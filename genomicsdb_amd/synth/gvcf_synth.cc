@@ -63,6 +63,13 @@ struct Synth {
   std::vector<uint8_t> cells;  // last chunk
   int64_t last_ncells = 0;
 
+  // c5 of BASELINE.json (high-ALT stress): inside [dense_begin, dense_begin + dense_len) every sample starts a variant at
+  // every position that is a multiple of hot_stride, with its ALT drawn from a site pool of dense_K insertion alleles
+  int64_t dense_begin = 0, dense_len = 0, hot_stride = 50;
+  int dense_K = 0;
+  bool in_dense(int64_t p) const { return dense_len > 0 && p >= dense_begin && p < dense_begin + dense_len; }
+  bool is_hot(int64_t p) const { return in_dense(p) && (p % hot_stride) == 0; }
+
   char base(int64_t p) const { return "ACGT"[hash2(seed ^ 0x5bd1e9955bd1e995ull, (uint64_t)p) & 3]; }
 
   void next_record(int32_t row, Rec& r) {
@@ -70,11 +77,16 @@ struct Synth {
     memset(&r, 0, sizeof(r));
     r.row = row;
     r.begin = pos[row];
-    if (g.below(8) != 0) {  // reference block
+    const bool hot = is_hot(r.begin);
+    if (!hot && g.below(8) != 0) {  // reference block
       double u = g.unit();
       int64_t len = 1 + (int64_t)std::floor(std::log(u) / std::log(1.0 - 1.0 / 120.0));
       if (len > 2000) len = 2000;
       if (len < 1) len = 1;
+      if (dense_len > 0) {  // a block must not run over the next hot position
+        int64_t nh = ((r.begin / hot_stride) + 1) * hot_stride;
+        if (in_dense(nh) && r.begin + len > nh) len = nh - r.begin;
+      }
       r.kind = 0;
       r.end = r.begin + len - 1;
       r.reflen = 1; r.ref[0] = base(r.begin);
@@ -88,6 +100,7 @@ struct Synth {
       uint32_t t = g.below(100);
       uint64_t site = hash2(seed, (uint64_t)r.begin);
       int K = (site % 100) < 90 ? 1 : 2 + (int)((site >> 8) & 1);
+      if (hot) { K = dense_K; t = 99; }   // insertion from the dense pool
       int pick = (int)g.below((uint32_t)K);
       uint64_t ah = hash2(site, (uint64_t)pick + 17);
       char rb = base(r.begin);
@@ -103,9 +116,10 @@ struct Synth {
         r.altlen = 1; r.alt[0] = rb;
       } else {  // insertion
         int ins = 1 + (int)(ah % 5);
+        if (hot) { ins = 5; ah = (uint64_t)pick * 0x9E3779B97F4A7C15ull + 12345; }   // K distinct 5-mers
         r.kind = 3; r.end = r.begin; r.reflen = 1; r.ref[0] = rb;
         r.altlen = (uint8_t)(1 + ins); r.alt[0] = rb;
-        for (int i = 0; i < ins; ++i) r.alt[1 + i] = "ACGT"[(ah >> (8 + 2 * i)) & 3];
+        for (int i = 0; i < ins; ++i) r.alt[1 + i] = "ACGT"[hot ? ((pick >> (2 * i)) & 3) : ((ah >> (8 + 2 * i)) & 3)];
       }
       r.hom = g.below(3) == 0;
       r.dp = g.range(10, 60);
@@ -194,6 +208,12 @@ struct Synth {
 
 extern "C" {
 
+void* gdbsynth_create(uint64_t seed, int32_t n_samples, int64_t B, int64_t L);
+void* gdbsynth_create_dense(uint64_t seed, int32_t n_samples, int64_t B, int64_t L, int64_t dense_begin, int64_t dense_len, int64_t hot_stride, int32_t K) {
+  Synth* s = (Synth*)gdbsynth_create(seed, n_samples, B, L);
+  s->dense_begin = dense_begin; s->dense_len = dense_len; s->hot_stride = hot_stride > 0 ? hot_stride : 50; s->dense_K = K > 0 ? (K > 1024 ? 1024 : K) : 1;
+  return s;
+}
 void* gdbsynth_create(uint64_t seed, int32_t n_samples, int64_t B, int64_t L) {
   Synth* s = new Synth;
   s->seed = seed; s->n_samples = n_samples; s->B = B; s->L = L; s->chunk_begin = B;

@@ -225,3 +225,25 @@ def test_c2_scale_properties(gdb, tmp_path, monkeypatch):
     # the last oracle record may be clipped by the smaller query window: compare all but the last
     assert lines[:len(want_lines) - 1] == want_lines[:-1]
     eng.close()
+
+
+@pytest.mark.parametrize("max_alt", [50, 64])
+def test_high_alt_dense_region_matches_oracle(gdb, tmp_path, max_alt):
+    """BASELINE.json configs[4]-style stress at test size (see tests/test_synth_parity_cpu.py): ~50 merged alleles per hot
+    site, entries of several KB each - the text-pool strips, the LDS images and the pages all take their oversize paths"""
+    from genomicsdb_amd import synth
+    N, B, L = 150, 10_000_000, 330
+    g = synth.Generator(N, B, L + 500, dense=(B + 100, 200, 50, 64))
+    cells, nc = g.chunk_bytes(B + L + 500)
+    q = helpers.synth_query(tmp_path, N, B, B + L - 1)
+    q["max_diploid_alt_alleles_that_can_be_genotyped"] = max_alt
+    want, nrec, _ = helpers.oracle_run_synth(q, cells, synth.SEED, with_header=False)
+    eng = gdb.CombineEngine(q)
+    eng.stage_cells(cells)
+    eng.set_reference(B, synth.reference(B, L + 4096))
+    got, st = eng.run_interval(B, B + L - 1, arena_bytes=1 << 20)
+    assert st.num_records == nrec
+    assert got == want
+    widest = max(len(l.split(b"\t")[4].split(b",")) for l in want.split(b"\n") if l)
+    assert widest >= 45
+    eng.close()

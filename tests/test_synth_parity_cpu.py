@@ -1,5 +1,7 @@
 """Synthetic workload (SURVEY 8(d) generator): CPU-side checks - the generator is deterministic, and the kernel bodies
 (hostsim) agree with the oracle on it byte for byte."""
+import pytest
+
 import helpers
 
 
@@ -40,3 +42,22 @@ def test_hostsim_matches_oracle_on_synthetic(tmp_path):
     assert errbits == 0
     assert got == want_n
     assert want != want_n  # the synthetic reference does change REF of mid-block records
+
+
+@pytest.mark.parametrize("max_alt", [50, 64])
+def test_high_alt_dense_region_kernel_bodies_match_oracle(tmp_path, max_alt):
+    """BASELINE.json configs[4]-style stress at test size: 80 samples all starting an insertion from a pool of 64 alleles at
+    the same positions -> ~45-55 merged alleles per hot site, PL re-indexing over ~1 500 genotypes per sample; with the default
+    limit (50 ALT alleles) the widest sites drop their genotype-length fields, with 64 none does."""
+    from genomicsdb_amd import synth
+    N, B, L = 80, 10_000_000, 330
+    g = synth.Generator(N, B, L + 500, dense=(B + 100, 200, 50, 64))
+    cells, nc = g.chunk_bytes(B + L + 500)
+    q = helpers.synth_query(tmp_path, N, B, B + L - 1)
+    q["max_diploid_alt_alleles_that_can_be_genotyped"] = max_alt
+    want, nrec, _ = helpers.oracle_run(q, cells, with_header=False)   # (no FASTA hook in hostsim: 'N' for mid-block REF on both sides)
+    got, errbits = helpers.hostsim_run(q, cells, with_header=False, rows_per_chunk=16, records_per_run=7)
+    assert errbits == 0
+    assert got == want
+    widest = max(len(l.split(b"\t")[4].split(b",")) for l in want.split(b"\n") if l)
+    assert widest >= 40
