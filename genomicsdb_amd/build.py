@@ -12,6 +12,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(ROOT, "build", "obj")
 LIB = os.path.join(PKG, "libgenomicsdb_amd.so")
+TOOL = os.path.join(PKG, "gt_mpi_gather")
 
 SOURCES = [
     "kernels/gdb_pipeline.hip",
@@ -57,6 +58,13 @@ def build_native(verbose=False):
             subprocess.check_call(cmd)
     if _newer(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    # command line of the reference's query tool (--produce-Broad-GVCF mode), linked against the library
+    tool_src = os.path.join(CSRC, "tools", "gt_mpi_gather.cc")
+    if _newer(TOOL, [tool_src, LIB] + hdrs):
+        cmd = [HIPCC, "-O2", "-std=c++17", "-Wall", "-Wno-unused-function", tool_src, "-o", TOOL, "-L" + PKG, "-lgenomicsdb_amd", "-Wl,-rpath,$ORIGIN", "-lz"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

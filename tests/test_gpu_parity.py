@@ -247,3 +247,31 @@ def test_high_alt_dense_region_matches_oracle(gdb, tmp_path, max_alt):
     widest = max(len(l.split(b"\t")[4].split(b",")) for l in want.split(b"\n") if l)
     assert widest >= 45
     eng.close()
+
+
+def test_gt_mpi_gather_cli_produces_the_golden(gdb, tmp_path):
+    """the reference's command line (tools/src/gt_mpi_gather.cc:437-531, mode --produce-Broad-GVCF) on an array directory:
+    stdout must be the reference's golden for the same query, for two paging sizes"""
+    import json
+    import os
+    import subprocess
+    tool = os.path.join(helpers.ROOT, "genomicsdb_amd", "gt_mpi_gather")
+    assert os.path.exists(tool), "build() must produce the tool"
+    case = [c for c in CASES if c[0] == "t0_1_2_vcf_at_0"][0]
+    _, callsets, vid, ov, golden, mode = case
+    cells = helpers.cells_for(callsets, vid)
+    q, _ = helpers.query_json(callsets, vid, ov, mode)
+    ws = tmp_path / "ws"
+    (ws / "t0_1_2").mkdir(parents=True)
+    (ws / "t0_1_2" / "cells.bin").write_bytes(cells)
+    q["workspace"] = str(ws)
+    q["array"] = "t0_1_2"
+    qf = tmp_path / "query.json"
+    qf.write_text(json.dumps(q))
+    for page in ("0", "128"):
+        r = subprocess.run([tool, "-j", str(qf), "-p", page, "--produce-Broad-GVCF"], capture_output=True, timeout=120)
+        assert r.returncode == 0, r.stderr.decode()
+        assert r.stdout == helpers.golden_text(golden)
+        assert b"scan_and_produce_Broad_GVCF" in r.stderr
+    r = subprocess.run([tool, "-j", str(qf), "--print-calls"], capture_output=True, timeout=60)
+    assert r.returncode != 0
