@@ -101,6 +101,13 @@ struct ByteSink {
 
 #if defined(__HIPCC__)
 typedef __attribute__((address_space(3))) char gdb_lds_char;
+struct LdsCapSink {  // counts every byte, stores the first `cap` of them in LDS: length and (short) text in ONE emitter pass
+  gdb_lds_char* p;
+  uint32_t n, cap;
+  __device__ __forceinline__ LdsCapSink(gdb_lds_char* q, uint32_t c) : p(q), n(0), cap(c) {}
+  __device__ __forceinline__ void put(char c) { if (n < cap) p[n] = c; ++n; }
+  __device__ __forceinline__ void write(const char* s, int len) { for (int i = 0; i < len; ++i) put(s[i]); }
+};
 struct LdsSink {  // same as ByteSink but the cursor is an LDS (address space 3) pointer: ds_write_b8 instead of flat stores
   gdb_lds_char* p;
   __device__ __forceinline__ explicit LdsSink(gdb_lds_char* q) : p(q) {}

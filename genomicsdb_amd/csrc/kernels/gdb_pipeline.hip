@@ -208,8 +208,9 @@ __device__ __noinline__ uint32_t entry_length(RecordInfo ri, int64_t c, uint32_t
 __device__ __noinline__ void entry_store(RecordInfo ri, int64_t c, char* dst, uint32_t* e) {
   (void)entry_emit(c_ex, ri, c, ByteSink(dst), e);
 }
-__device__ __noinline__ void entry_store_lds(RecordInfo ri, int64_t c, gdb_lds_char* dst, uint32_t* e) {
-  (void)entry_emit(c_ex, ri, c, LdsSink(dst), e);
+// length of the text; its first `cap` bytes are left at dst (LDS)
+__device__ __noinline__ uint32_t entry_store_lds_capped(RecordInfo ri, int64_t c, gdb_lds_char* dst, uint32_t cap, uint32_t* e) {
+  return entry_emit(c_ex, ri, c, LdsCapSink(dst, cap), e).n;
 }
 
 // ---- entry text table ---------------------------------------------------------------------------------------------
@@ -324,32 +325,41 @@ __global__ void k_inc_pos(const uint64_t* inc_keys_sorted, const int64_t* inc_ce
 }
 
 constexpr int kSlotBlock = 64;     // threads per workgroup of the slot kernels
-constexpr int kStripWords = 33;    // LDS words per lane (132 bytes)
+constexpr int kSlotStride = 128;   // bytes of an inline slot: slot s lives at pool + s * kSlotStride; longer texts go to the overflow pool
+constexpr int kStripWords = kSlotStride / 4 + 1;   // LDS words per lane: odd stride, no bank conflicts between lanes
+constexpr uint32_t kOverflowBit = 0x80000000u;     // descriptor offsets with this bit are 16-byte units into the overflow pool
 struct SlotTable {
   uint32_t* len;          // [S]  entry bytes incl. the leading tab; 0: the record has no FORMAT columns
-  const uint32_t* off16;  // [S]  pool offset in 16-byte units (exclusive scan of ceil(len/16))
-  char* pool;
+  const uint32_t* ovf16;  // [S]  overflow-pool offset in 16-byte units (exclusive scan; only meaningful for len > kSlotStride)
+  char* pool;             // inline texts, fixed stride
+  char* pool_ovf;
   uint32_t light_base;    // = kMaxTypes: slots [0,kMaxTypes) are the no-call texts per type
   uint32_t heavy_base;
   uint32_t row_base;      // slots of (untabled record, sample): row_base + u * N + row
 };
-// pass 0: lengths; pass 1: text.  One template, four enumerations (types / plain cells x met types / heavy incidences /
-// samples of records whose type has no bitmask position).
+// PASS 0: ONE run of the field emitters gives the length of the text and, when it fits kSlotStride bytes (nearly always),
+// the text itself: formatted into a lane-private LDS strip, it leaves as 16-byte stores into the lane's inline slot.
+// PASS 1: only the texts longer than an inline slot are formatted again, straight into the overflow pool.
+// One template, four enumerations (types / plain cells x met types / heavy incidences / samples of untabled records).
 template <int PASS> __device__ __forceinline__ void slot_fill(const SlotTable& st, uint32_t s, const RecordInfo& rinfo, int64_t c, uint32_t* e) {
-  if (PASS == 0) st.len[s] = rinfo.fmt_mask ? 1u + entry_length(rinfo, c, e) : 0u;
-  else if (rinfo.fmt_mask) {
-    // the text is formatted into a lane-private LDS strip (odd word stride: no bank conflicts between lanes) and leaves as
-    // 16-byte stores into the lane's 16-byte aligned pool slot; only texts longer than the strip go out bytewise
-    __shared__ uint32_t strip[kSlotBlock * kStripWords];
-    char* dst = st.pool + (size_t)st.off16[s] * 16;
-    const uint32_t len = st.len[s];
-    if (len <= (uint32_t)(kStripWords - 1) * 4u) {
+  if (PASS == 0) {
+    uint32_t len = 0;
+    if (rinfo.fmt_mask) {
+      __shared__ uint32_t strip[kSlotBlock * kStripWords];
       uint32_t* mine = strip + threadIdx.x * kStripWords;
       gdb_lds_char* txt = (gdb_lds_char*)mine;
       *txt = '\t';
-      entry_store_lds(rinfo, c, txt + 1, e);
-      for (uint32_t q = 0; (q << 4) < len; ++q) reinterpret_cast<uint4*>(dst)[q] = make_uint4(mine[4 * q], mine[4 * q + 1], mine[4 * q + 2], mine[4 * q + 3]);
-    } else { *dst = '\t'; entry_store(rinfo, c, dst + 1, e); }
+      len = 1u + entry_store_lds_capped(rinfo, c, txt + 1, (uint32_t)kSlotStride - 1u, e);
+      if (len <= (uint32_t)kSlotStride) {
+        uint4* dst = reinterpret_cast<uint4*>(st.pool + (size_t)s * kSlotStride);
+        for (uint32_t q = 0; (q << 4) < len; ++q) dst[q] = make_uint4(mine[4 * q], mine[4 * q + 1], mine[4 * q + 2], mine[4 * q + 3]);
+      }
+    }
+    st.len[s] = len;
+  } else if (st.len[s] > (uint32_t)kSlotStride) {
+    char* dst = st.pool_ovf + (size_t)st.ovf16[s] * 16;
+    *dst = '\t';
+    entry_store(rinfo, c, dst + 1, e);
   }
 }
 template <int PASS> __global__ void k_slots_nocall(SlotTable st, SiteOut so, const int32_t* type_rep, int ntypes, uint32_t* err) {
@@ -398,13 +408,13 @@ template <int PASS> __global__ void k_slots_untabled(SlotTable st, SiteOut so, R
   else slot_fill<PASS>(st, s, load_record_info(so, c_ex.hl, k), c, &e);
   if (e) atomicOr(err, e);
 }
-__global__ void k_slot_units(const uint32_t* len, int64_t S, uint32_t* units) {
+__global__ void k_slot_units(const uint32_t* len, int64_t S, uint32_t* units) {   // overflow-pool units of every slot
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s < S) units[s] = (len[s] + 15u) >> 4;
+  if (s < S) units[s] = len[s] > (uint32_t)kSlotStride ? (len[s] + 15u) >> 4 : 0u;
 }
-__global__ void k_slot_desc(const uint32_t* len, const uint32_t* off16, int64_t S, uint2* desc) {
+__global__ void k_slot_desc(const uint32_t* len, const uint32_t* ovf16, int64_t S, uint2* desc) {
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s < S) desc[s] = make_uint2(off16[s], len[s]);
+  if (s < S) desc[s] = len[s] > (uint32_t)kSlotStride ? make_uint2(kOverflowBit | ovf16[s], len[s]) : make_uint2((uint32_t)s * (kSlotStride / 16), len[s]);
 }
 
 // ---- assembly ------------------------------------------------------------------------------------------------------
@@ -613,7 +623,7 @@ struct SlotText { uint4 x[kTextChunks]; };
 // builder + flusher wavefront pairs 5.6; skewed software pipeline with two LDS images 4.2.  All of them trade resident
 // wavefronts for fewer exposed waits, and lose: the kernel is bound by (resident wavefronts) / (per-record latency).
 __global__ void __launch_bounds__(kAsmRows)
-k_assemble_write(const char* __restrict__ pool, const uint32_t* __restrict__ prefix_len, const uint2* __restrict__ resolved, int64_t resolved_base,
+k_assemble_write(const char* __restrict__ pool, const char* __restrict__ pool_ovf, const uint32_t* __restrict__ prefix_len, const uint2* __restrict__ resolved, int64_t resolved_base,
                  const int32_t* __restrict__ order, int64_t n, int nchunks, int run, const uint64_t* __restrict__ chunk_off, uint64_t page_base,
                  char* __restrict__ arena) {
   // chunk is the fast grid dimension: the 16 chunk wavefronts of a record run are in flight together
@@ -641,7 +651,7 @@ k_assemble_write(const char* __restrict__ pool, const uint32_t* __restrict__ pre
       const uint32_t len = d.y;
       if (len && (d.x != cur.x || len != cur.y)) {          // the sample moved to another slot: fetch its text
         cur = d;
-        cur_src = pool + (size_t)d.x * 16;
+        cur_src = ((d.x & kOverflowBit) ? pool_ovf : pool) + (size_t)(d.x & ~kOverflowBit) * 16;
 #pragma unroll
         for (int q = 0; q < kTextChunks; ++q) txt.x[q] = load_chunk(cur_src, q, len);
       }
@@ -735,7 +745,7 @@ struct DevicePipeline::Impl {
   DevBuf<WalkCell> walk; DevBuf<int64_t> walk_inv;
   DevBuf<uint2> resolved;          // (pool offset, length) of every (record, sample): whole interval, or one page when that exceeds the budget
   DevBuf<uint32_t> untabled, ubase; DevBuf<int32_t> urec, iota, order; DevBuf<uint32_t> order_keys, order_keys_sorted;
-  DevBuf<uint64_t> tmask; DevBuf<uint32_t> nslots, tbase, inc_pos, slot_len, slot_units, slot_off; DevBuf<uint2> slot_desc; DevBuf<char> pool;
+  DevBuf<uint64_t> tmask; DevBuf<uint32_t> nslots, tbase, inc_pos, slot_len, slot_units, slot_off; DevBuf<uint2> slot_desc; DevBuf<char> pool, pool_ovf;
   bool classified = false;
   struct Part { FragmentView v; std::vector<size_t> data_bytes; std::vector<void*> bufs; };
   std::vector<Part> parts;
@@ -784,6 +794,12 @@ struct DevicePipeline::Impl {
     HIP_CHECK(hipMemcpyAsync(&b, pb, sizeof(B), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
     return (int64_t)a + (int64_t)b;
+  }
+  // several scalars, one stream synchronisation
+  struct Pending { void* dst; const void* src; size_t bytes; };
+  void read_back_many(std::initializer_list<Pending> items) {
+    for (const Pending& it : items) HIP_CHECK(hipMemcpyAsync(it.dst, it.src, it.bytes, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
   }
   template <class T> T read_back(const T* p) {
     T v;
@@ -1069,12 +1085,15 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   // every difference array sums to zero over its P+1 elements, so ONE scan over the concatenation equals nf+2 separate scans
   S.incl_scan(S.diff.p, S.diff.p, ndiff, rocprim::plus<int32_t>());
   S.excl_scan(S.heavy_count.p, S.hoff.p, (size_t)CW);
-  const int64_t T = S.read_back_sum(S.hoff.p + (CW - 1), S.heavy_count.p + (CW - 1));
+  int64_t T_a = 0, T_b = 0;
+  int32_t n_in_window = 0;
+  S.read_back_many({{&T_a, S.hoff.p + (CW - 1), sizeof(int64_t)}, {&T_b, S.heavy_count.p + (CW - 1), sizeof(int64_t)}, {&n_in_window, S.counters.p, sizeof(int32_t)}});
+  const int64_t T = T_a + T_b;
   stats.num_heavy_incidences = T;
-  stats.num_cells_in_window = S.read_back(S.counters.p);
+  stats.num_cells_in_window = n_in_window;
   // ---- S6 incidences sorted by (record,row) --------------------------------------------------------------------------
   S.inc_keys.ensure(T + 1); S.inc_keys_sorted.ensure(T + 1); S.inc_vals.ensure(T + 1); S.inc_vals_sorted.ensure(T + 1);
-  S.hbase.ensure(P + 2); S.lut_len.ensure(T + 1); S.i2m_off.ensure(T + 2); S.iflags.ensure(T + 1); S.gt_override.ensure((size_t)GDB_MAX_PLOIDY * T + 2);
+  S.hbase.ensure(P + 2); S.lut_len.ensure(T + 2); S.i2m_off.ensure(T + 2); S.iflags.ensure(T + 1); S.gt_override.ensure((size_t)GDB_MAX_PLOIDY * T + 2);
   uint32_t lut_total = 0;
   if (T > 0) {
     STAGE("k_incidence_fill");
@@ -1082,10 +1101,10 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
     S.sort_pairs(S.inc_keys.p, S.inc_keys_sorted.p, S.inc_vals.p, S.inc_vals_sorted.p, (size_t)T, bits_for((uint64_t)P * (uint64_t)N));
     STAGE("k_lut_len");
     hipLaunchKernelGGL(k_lut_len, dim3(blocks_for(T)), dim3(kBlock), 0, st, S.inc_vals_sorted.p, S.cflags.p, T, S.lut_len.p);
-    S.excl_scan(S.lut_len.p, S.i2m_off.p, (size_t)T);
-    lut_total = (uint32_t)S.read_back_sum(S.i2m_off.p + (T - 1), S.lut_len.p + (T - 1));
-    HIP_CHECK(hipMemcpyAsync(S.i2m_off.p + T, &lut_total, sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipMemsetAsync(S.lut_len.p + T, 0, sizeof(uint32_t), st));
+    S.excl_scan(S.lut_len.p, S.i2m_off.p, (size_t)T + 1);   // i2m_off[T] = total, no host round trip
+    if ((uint64_t)T * GDB_MAX_INPUT_ALLELES >= (1ull << 32)) throw GenomicsDBDeviceException("allele LUT storage exceeds 2^32 entries: split the query interval");
+    lut_total = (uint32_t)((uint64_t)T * GDB_MAX_INPUT_ALLELES);   // capacity bound (a cell has at most GDB_MAX_INPUT_ALLELES alleles)
   } else {
     HIP_CHECK(hipMemsetAsync(S.i2m_off.p, 0, 2 * sizeof(uint32_t), st));
   }
@@ -1106,8 +1125,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   PresenceCounts pc{d_fmt, d_dp, d_nr, stride};
   SiteCtx sx{fr, pl, cm, rec, hl, pc, nt, qw, so};
   S.d_sx.ensure(1);
-  HIP_CHECK(hipMemcpyAsync(S.d_sx.p, &sx, sizeof(SiteCtx), hipMemcpyHostToDevice, st));
-  HIP_CHECK(hipStreamSynchronize(st));
+  HIP_CHECK(hipMemcpyAsync(S.d_sx.p, &sx, sizeof(SiteCtx), hipMemcpyHostToDevice, st));   // (sx outlives the copy: the function synchronises before it returns)
   STAGE("k_site_size");
   hipLaunchKernelGGL(k_site_size, dim3(blocks_for(P, 64)), dim3(64), 0, st, S.d_sx.p, S.err.p);
   HIP_CHECK(hipEventRecord(ev[2], st));
@@ -1118,7 +1136,6 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   RowIndex ri{S.row_ptr.p, S.perm.p, S.rm_begin.p};
   EntryCtx ex{fr, pl, cm, hl};
   HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_ex), &ex, sizeof(EntryCtx), 0, hipMemcpyHostToDevice, st));
-  HIP_CHECK(hipStreamSynchronize(st));
   // ---- S8a entry text table: record types, slots of (plain cell, type) / (record, heavy call) / no-call, text pool ------------
   if (T >= (1ll << 32)) throw GenomicsDBDeviceException("more than 2^32 (record, variant call) incidences in one interval: split the query interval");
   S.type_hkeys.ensure(kTypeHash); S.type_hrep.ensure(kTypeHash); S.type_hid.ensure(kTypeHash); S.type_rep.ensure(kMaxTypes); S.rtype.ensure(P);
@@ -1132,20 +1149,25 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   S.untabled.ensure(P + 1); S.ubase.ensure(P + 1); S.urec.ensure(P + 1);
   hipLaunchKernelGGL(k_type_lookup, dim3(blocks_for(P)), dim3(kBlock), 0, st, so, P, S.type_hkeys.p, S.type_hid.p, S.rtype.p, S.untabled.p);
   S.excl_scan(S.untabled.p, S.ubase.p, (size_t)P);
-  const int64_t UR = S.read_back_sum(S.ubase.p + (P - 1), S.untabled.p + (P - 1));
-  if (UR > 0) hipLaunchKernelGGL(k_untabled_records, dim3(blocks_for(P)), dim3(kBlock), 0, st, S.untabled.p, S.ubase.p, P, S.urec.p);
   S.tmask.ensure(CW); S.nslots.ensure(CW + 1); S.tbase.ensure(CW + 1);
   STAGE("k_cell_types");
   hipLaunchKernelGGL(k_cell_types, dim3(blocks_for(CW)), dim3(kBlock), 0, st, S.cflags.p, S.k_lo.p, S.k_hi.p, S.rtype.p, c_base, CW, S.tmask.p, S.nslots.p);
   S.excl_scan(S.nslots.p, S.tbase.p, (size_t)CW);
-  const uint64_t SL = (uint64_t)S.read_back_sum(S.tbase.p + (CW - 1), S.nslots.p + (CW - 1));
-  const int ntypes = S.read_back(S.counters.p + 1);
+  uint32_t ur_a = 0, ur_b = 0, sl_a = 0, sl_b = 0;
+  int32_t ntypes = 0;
+  S.read_back_many({{&ur_a, S.ubase.p + (P - 1), 4}, {&ur_b, S.untabled.p + (P - 1), 4}, {&sl_a, S.tbase.p + (CW - 1), 4}, {&sl_b, S.nslots.p + (CW - 1), 4},
+                    {&ntypes, S.counters.p + 1, 4}});
+  const int64_t UR = (int64_t)ur_a + ur_b;
+  const uint64_t SL = (uint64_t)sl_a + sl_b;
+  if (UR > 0) hipLaunchKernelGGL(k_untabled_records, dim3(blocks_for(P)), dim3(kBlock), 0, st, S.untabled.p, S.ubase.p, P, S.urec.p);
   const uint64_t NS = (uint64_t)kMaxTypes + SL + (uint64_t)T + (uint64_t)UR * (uint64_t)N;
   if (NS >= (1ull << 32)) throw GenomicsDBDeviceException("entry text table exceeds 2^32 slots: split the query interval");
   S.inc_pos.ensure(T + 1);
   if (T > 0) hipLaunchKernelGGL(k_inc_pos, dim3(blocks_for(T)), dim3(kBlock), 0, st, S.inc_keys_sorted.p, S.inc_vals_sorted.p, S.hoff.p, S.k_lo.p, c_base, T, (int64_t)N, S.inc_pos.p);
   S.slot_len.ensure(NS + 1); S.slot_units.ensure(NS + 1); S.slot_off.ensure(NS + 1); S.slot_desc.ensure(NS + 1);
-  SlotTable stt{S.slot_len.p, S.slot_off.p, nullptr, (uint32_t)kMaxTypes, (uint32_t)(kMaxTypes + SL), (uint32_t)(kMaxTypes + SL + (uint64_t)T)};
+  if (NS * (uint64_t)(kSlotStride / 16) >= (uint64_t)kOverflowBit) throw GenomicsDBDeviceException("entry text table exceeds 32 GiB: split the query interval");
+  S.pool.ensure((size_t)NS * kSlotStride + 64);
+  SlotTable stt{S.slot_len.p, S.slot_off.p, S.pool.p, nullptr, (uint32_t)kMaxTypes, (uint32_t)(kMaxTypes + SL), (uint32_t)(kMaxTypes + SL + (uint64_t)T)};
   STAGE("k_slots<0>");
   hipLaunchKernelGGL(k_slots_nocall<0>, dim3(1), dim3(kMaxTypes), 0, st, stt, so, S.type_rep.p, ntypes, S.err.p);
   hipLaunchKernelGGL(k_slots_light<0>, dim3(blocks_for(CW, kSlotBlock)), dim3(kSlotBlock), 0, st, stt, so, S.type_rep.p, S.tmask.p, S.tbase.p, c_base, CW, S.err.p);
@@ -1154,18 +1176,20 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   hipLaunchKernelGGL(k_slot_units, dim3(blocks_for((int64_t)NS)), dim3(kBlock), 0, st, S.slot_len.p, (int64_t)NS, S.slot_units.p);
   S.excl_scan(S.slot_units.p, S.slot_off.p, (size_t)NS);
   const uint64_t pool_units = (uint64_t)S.read_back_sum(S.slot_off.p + (NS - 1), S.slot_units.p + (NS - 1));
-  if (pool_units >= (1ull << 32)) throw GenomicsDBDeviceException("entry text pool exceeds 64 GiB: split the query interval");
-  S.pool.ensure((size_t)pool_units * 16 + 64);
-  stt.pool = S.pool.p;
+  if (pool_units >= (uint64_t)kOverflowBit) throw GenomicsDBDeviceException("entry text overflow pool exceeds 32 GiB: split the query interval");
+  S.pool_ovf.ensure((size_t)pool_units * 16 + 64);
+  stt.pool_ovf = S.pool_ovf.p;
   STAGE("k_slots<1>");
+  if (pool_units > 0) {   // some text is longer than an inline slot
   hipLaunchKernelGGL(k_slots_nocall<1>, dim3(1), dim3(kMaxTypes), 0, st, stt, so, S.type_rep.p, ntypes, S.err.p);
   hipLaunchKernelGGL(k_slots_light<1>, dim3(blocks_for(CW, kSlotBlock)), dim3(kSlotBlock), 0, st, stt, so, S.type_rep.p, S.tmask.p, S.tbase.p, c_base, CW, S.err.p);
   if (T > 0) hipLaunchKernelGGL(k_slots_heavy<1>, dim3(blocks_for(T, 64)), dim3(64), 0, st, stt, so, S.inc_keys_sorted.p, S.inc_vals_sorted.p, T, (int64_t)N, S.err.p);
   if (UR > 0) hipLaunchKernelGGL(k_slots_untabled<1>, dim3(blocks_for(UR * N, 64)), dim3(64), 0, st, stt, so, ri, rec, S.urec.p, UR, N, S.err.p);
+  }
   hipLaunchKernelGGL(k_slot_desc, dim3(blocks_for((int64_t)NS)), dim3(kBlock), 0, st, S.slot_len.p, S.slot_off.p, (int64_t)NS, S.slot_desc.p);
   stats.num_record_types = ntypes;
   stats.num_text_slots = (int64_t)NS;
-  stats.text_pool_bytes = (int64_t)(pool_units * 16);
+  stats.text_pool_bytes = (int64_t)(NS * kSlotStride + pool_units * 16);
   STAGE("k_walk_window");
   hipLaunchKernelGGL(k_walk_window, dim3(blocks_for(CW)), dim3(kBlock), 0, st, S.walk_inv.p, S.cflags.p, S.hoff.p, S.k_lo.p, S.tbase.p, S.tmask.p, c_base, CW, S.walk.p);
   AsmCtx ac{S.row_ptr.p, S.rm_begin.p, S.walk.p, S.rstart.p, S.rtype.p, S.prefix_len.p, S.slot_desc.p, S.pool.p, S.inc_pos.p, S.ubase.p,
@@ -1189,16 +1213,15 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   HIP_CHECK(hipMemcpyAsync(rec_off.data(), S.rec_off.p, (size_t)(P + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   STAGE("before-sync-offsets");
   HIP_CHECK(hipEventRecord(ev[3], st));
+  uint32_t eb = 0;
+  HIP_CHECK(hipMemcpyAsync(&eb, S.err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
   stats.bytes_out = rec_off[(size_t)P];
   HIP_CHECK(hipEventElapsedTime(&stats.ms_sweep, ev[0], ev[1]));
   HIP_CHECK(hipEventElapsedTime(&stats.ms_site, ev[1], ev[2]));
   HIP_CHECK(hipEventElapsedTime(&stats.ms_size, ev[2], ev[3]));
   for (auto& e : ev) (void)hipEventDestroy(e);
-  {
-    uint32_t eb = S.read_back(S.err.p);
-    if (eb) throw GenomicsDBDeviceException("device error bits " + std::to_string(eb) + " (see GdbErr in gdb_types.h)");
-  }
+  if (eb) throw GenomicsDBDeviceException("device error bits " + std::to_string(eb) + " (see GdbErr in gdb_types.h)");
   for (int64_t k = 0; k < P; ++k) S.iv.max_record_bytes = std::max<uint64_t>(S.iv.max_record_bytes, rec_off[(size_t)k + 1] - rec_off[(size_t)k]);
   S.iv.P = P; S.iv.nchunks = nchunks; S.iv.kp = 0;
   S.iv.sx = sx; S.iv.ex = ex; S.iv.ri = ri; S.iv.so = so; S.iv.rec = rec; S.iv.ac = ac; S.iv.resolved_whole = resolved_whole;
@@ -1236,9 +1259,10 @@ bool DevicePipeline::next_page(uint64_t arena_bytes, const char** dev_ptr, uint6
     S.resolved.ensure((size_t)np * iv.nchunks * kAsmRows);
     hipLaunchKernelGGL(k_assemble_size, wgrid, dim3(kAsmRows), 0, st, iv.ac, S.order.p, np, N, iv.nchunks, wrun, (uint64_t*)nullptr, S.resolved.p, kp);
   }
-  hipLaunchKernelGGL(k_assemble_write, wgrid, dim3(kAsmRows), 0, st, (const char*)S.pool.p, (const uint32_t*)S.prefix_len.p, (const uint2*)S.resolved.p,
+  hipLaunchKernelGGL(k_assemble_write, wgrid, dim3(kAsmRows), 0, st, (const char*)S.pool.p, (const char*)S.pool_ovf.p, (const uint32_t*)S.prefix_len.p, (const uint2*)S.resolved.p,
                      iv.resolved_whole ? (int64_t)0 : kp, (const int32_t*)S.order.p, np, iv.nchunks, wrun, (const uint64_t*)S.chunk_off.p, page_base, S.arena.p);
   HIP_CHECK(hipEventRecord(w2, st));
+  HIP_CHECK(hipMemcpyAsync(&iv.stats.err_bits, S.err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
   float ms_site = 0, ms_entry = 0;
   HIP_CHECK(hipEventElapsedTime(&ms_site, w0, w1));
@@ -1250,7 +1274,6 @@ bool DevicePipeline::next_page(uint64_t arena_bytes, const char** dev_ptr, uint6
   iv.stats.ms_write_kernel_avg = iv.write_kernel_ms / iv.stats.write_launches;
   iv.stats.pages++;
   iv.stats.ms_total = iv.stats.ms_sweep + iv.stats.ms_site + iv.stats.ms_size + iv.stats.ms_write;
-  iv.stats.err_bits = S.read_back(S.err.p);
   if (iv.stats.err_bits) throw GenomicsDBDeviceException("device error bits " + std::to_string(iv.stats.err_bits) + " (see GdbErr in gdb_types.h)");
   iv.kp = ke;
   *dev_ptr = S.arena.p;
