@@ -370,17 +370,23 @@ template <int PASS> __global__ void k_slots_nocall(SlotTable st, SiteOut so, con
   else if (PASS == 0) st.len[t] = 0;
   if (e) atomicOr(err, e);
 }
-template <int PASS> __global__ void k_slots_light(SlotTable st, SiteOut so, const int32_t* type_rep, const uint64_t* tmask, const uint32_t* tbase,
+// Types are visited in the same (uniform) order by all lanes: the lanes that are active in a round format texts of ONE
+// record type - same number of merged alleles, same FORMAT mask - so the PL / AD loops of a wavefront have one trip count.
+template <int PASS> __global__ void k_slots_light(SlotTable st, SiteOut so, const int32_t* type_rep, int ntypes, const uint64_t* tmask, const uint32_t* tbase,
                                                  int64_t c_base, int64_t n, uint32_t* err) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint64_t m = tmask[i];
-  uint32_t s = st.light_base + tbase[i];
+  const uint64_t m = i < n ? tmask[i] : 0ull;
+  const uint32_t s0 = i < n ? st.light_base + tbase[i] : 0u;
   uint32_t e = 0;
-  while (m) {
-    const int t = __ffsll((long long)m) - 1;
-    m &= m - 1;
-    slot_fill<PASS>(st, s++, load_record_info(so, c_ex.hl, type_rep[t]), c_base + i, &e);
+  if (PASS == 1) {   // overflow pass: most wavefronts have nothing to do
+    bool any = false;
+    for (uint64_t r = m, s = s0; r; r &= r - 1, ++s) any = any || st.len[s] > (uint32_t)kSlotStride;
+    if (!__any((int)any)) return;
+  }
+  for (int t = 0; t < ntypes; ++t) {                       // uniform
+    if (!((m >> t) & 1ull)) continue;
+    const uint32_t s = s0 + (uint32_t)__popcll(m & ((1ull << t) - 1ull));
+    slot_fill<PASS>(st, s, load_record_info(so, c_ex.hl, type_rep[t]), c_base + i, &e);
   }
   if (e) atomicOr(err, e);
 }
@@ -1170,7 +1176,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   SlotTable stt{S.slot_len.p, S.slot_off.p, S.pool.p, nullptr, (uint32_t)kMaxTypes, (uint32_t)(kMaxTypes + SL), (uint32_t)(kMaxTypes + SL + (uint64_t)T)};
   STAGE("k_slots<0>");
   hipLaunchKernelGGL(k_slots_nocall<0>, dim3(1), dim3(kMaxTypes), 0, st, stt, so, S.type_rep.p, ntypes, S.err.p);
-  hipLaunchKernelGGL(k_slots_light<0>, dim3(blocks_for(CW, kSlotBlock)), dim3(kSlotBlock), 0, st, stt, so, S.type_rep.p, S.tmask.p, S.tbase.p, c_base, CW, S.err.p);
+  hipLaunchKernelGGL(k_slots_light<0>, dim3(blocks_for(CW, kSlotBlock)), dim3(kSlotBlock), 0, st, stt, so, S.type_rep.p, ntypes, S.tmask.p, S.tbase.p, c_base, CW, S.err.p);
   if (T > 0) hipLaunchKernelGGL(k_slots_heavy<0>, dim3(blocks_for(T, 64)), dim3(64), 0, st, stt, so, S.inc_keys_sorted.p, S.inc_vals_sorted.p, T, (int64_t)N, S.err.p);
   if (UR > 0) hipLaunchKernelGGL(k_slots_untabled<0>, dim3(blocks_for(UR * N, 64)), dim3(64), 0, st, stt, so, ri, rec, S.urec.p, UR, N, S.err.p);
   hipLaunchKernelGGL(k_slot_units, dim3(blocks_for((int64_t)NS)), dim3(kBlock), 0, st, S.slot_len.p, (int64_t)NS, S.slot_units.p);
@@ -1182,7 +1188,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   STAGE("k_slots<1>");
   if (pool_units > 0) {   // some text is longer than an inline slot
   hipLaunchKernelGGL(k_slots_nocall<1>, dim3(1), dim3(kMaxTypes), 0, st, stt, so, S.type_rep.p, ntypes, S.err.p);
-  hipLaunchKernelGGL(k_slots_light<1>, dim3(blocks_for(CW, kSlotBlock)), dim3(kSlotBlock), 0, st, stt, so, S.type_rep.p, S.tmask.p, S.tbase.p, c_base, CW, S.err.p);
+  hipLaunchKernelGGL(k_slots_light<1>, dim3(blocks_for(CW, kSlotBlock)), dim3(kSlotBlock), 0, st, stt, so, S.type_rep.p, ntypes, S.tmask.p, S.tbase.p, c_base, CW, S.err.p);
   if (T > 0) hipLaunchKernelGGL(k_slots_heavy<1>, dim3(blocks_for(T, 64)), dim3(64), 0, st, stt, so, S.inc_keys_sorted.p, S.inc_vals_sorted.p, T, (int64_t)N, S.err.p);
   if (UR > 0) hipLaunchKernelGGL(k_slots_untabled<1>, dim3(blocks_for(UR * N, 64)), dim3(64), 0, st, stt, so, ri, rec, S.urec.p, UR, N, S.err.p);
   }
