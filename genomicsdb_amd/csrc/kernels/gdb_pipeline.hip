@@ -626,7 +626,8 @@ struct SlotText { uint4 x[kTextChunks]; };
 // Page assembly: one wavefront = `run` records x 64 samples (one chunk), one wavefront per workgroup (no s_barrier).
 // Variants measured on MI355X this round and dropped because they were slower (c2, 200 kb window, ms per launch, this
 // kernel = 3.0-3.2): 2 / 4 chunks per wavefront in lock step 3.3 / 4.7; 2 / 4 records built before one flush 3.9 / 5.4;
-// builder + flusher wavefront pairs 5.6; skewed software pipeline with two LDS images 4.2.  All of them trade resident
+// builder + flusher wavefront pairs 5.6; skewed software pipeline with two LDS images 4.2; unaligned ds_write_b128 of whole
+// chunks instead of the funnel-shifted words (gfx950 accepts any byte alignment, but it costs 3.8 vs 2.9).  All of them trade resident
 // wavefronts for fewer exposed waits, and lose: the kernel is bound by (resident wavefronts) / (per-record latency).
 __global__ void __launch_bounds__(kAsmRows)
 k_assemble_write(const char* __restrict__ pool, const char* __restrict__ pool_ovf, const uint32_t* __restrict__ prefix_len, const uint2* __restrict__ resolved, int64_t resolved_base,
