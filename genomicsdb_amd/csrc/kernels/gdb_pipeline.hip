@@ -67,7 +67,7 @@ inline uint64_t resolved_budget_bytes() {
 }
 inline int order_block_log2() {
   const char* e = getenv("GDBAMD_ORDER_BLOCK_LOG2");
-  return e && *e ? std::max(0, std::min(30, atoi(e))) : 7;
+  return e && *e ? std::max(0, std::min(30, atoi(e))) : 12;
 }
 inline unsigned blocks_for(int64_t n, int b = kBlock) { return (unsigned)std::max<int64_t>(1, (n + b - 1) / b); }
 inline int bits_for(uint64_t max_value) { int b = 1; while (b < 64 && (max_value >> b)) ++b; return std::min(64, b + 1); }
@@ -166,23 +166,49 @@ __global__ void k_lut_len(const int64_t* inc_cell, const uint32_t* cflags, int64
 }
 
 // ---- site kernels: one thread per record -----------------------------------------------------------------------
-__global__ void k_site_size(const SiteCtx* __restrict__ sxp, uint32_t* err) {
+// Pass 0 runs the record logic ONCE: allele merge, LUTs, per-record flags - and the text of the fixed columns, formatted
+// through a capped LDS sink into a lane-private strip and parked in a fixed-stride staging slot.  The page pass then only
+// copies the parked text (records whose fixed columns exceed the slot - long allele lists - are formatted again).
+constexpr int kSiteStride = 256;                   // staging bytes per record
+constexpr int kSiteStripWords = kSiteStride / 4 + 1;
+__global__ void __launch_bounds__(64) k_site_size(const SiteCtx* __restrict__ sxp, char* __restrict__ staging, uint32_t* err) {
   const SiteCtx& sx = *sxp;
+  __shared__ uint32_t strip[64 * kSiteStripWords];
   int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= sx.rec.npos) return;
   uint32_t e = 0;
-  CountSink cs;
+  uint32_t* mine = strip + threadIdx.x * kSiteStripWords;
+  LdsCapSink cs((gdb_lds_char*)mine, (uint32_t)kSiteStride);
   site_emit(sx, k, cs, true, &e);
-  sx.so.prefix_len[k] = (uint32_t)cs.n;
+  sx.so.prefix_len[k] = cs.n;
+  if (cs.n <= (uint32_t)kSiteStride) {
+    uint4* dst = reinterpret_cast<uint4*>(staging + (size_t)k * kSiteStride);
+    for (uint32_t q = 0; (q << 4) < cs.n; ++q) dst[q] = make_uint4(mine[4 * q], mine[4 * q + 1], mine[4 * q + 2], mine[4 * q + 3]);
+  }
   if (e) atomicOr(err, e);
 }
-__global__ void k_site_write(const SiteCtx* __restrict__ sxp, int64_t k_begin, int64_t k_end, const uint64_t* chunk_off, int nchunks, uint64_t page_base, char* arena, uint32_t* err) {
+__global__ void k_site_write(const SiteCtx* __restrict__ sxp, const char* __restrict__ staging, int64_t k_begin, int64_t k_end, const uint64_t* chunk_off, int nchunks,
+                             uint64_t page_base, char* arena, uint32_t* err) {
   const SiteCtx& sx = *sxp;
   int64_t k = k_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= k_end) return;
   uint32_t e = 0;
-  ByteSink bs(arena + (chunk_off[k * nchunks] - page_base));
-  site_emit(sx, k, bs, false, &e);
+  char* dst = arena + (chunk_off[k * nchunks] - page_base);
+  const uint32_t n = sx.so.prefix_len[k];
+  if (n <= (uint32_t)kSiteStride) {
+    const char* src = staging + (size_t)k * kSiteStride;
+    uint32_t i = 0;
+    for (; i < n && ((uintptr_t)(dst + i) & 3u); ++i) dst[i] = src[i];        // to the first destination word
+    for (; i + 4 <= n; i += 4) {                                              // whole destination words (source bytewise-assembled)
+      const uint32_t w = (uint32_t)(unsigned char)src[i] | ((uint32_t)(unsigned char)src[i + 1] << 8) | ((uint32_t)(unsigned char)src[i + 2] << 16) |
+                         ((uint32_t)(unsigned char)src[i + 3] << 24);
+      *reinterpret_cast<uint32_t*>(dst + i) = w;
+    }
+    for (; i < n; ++i) dst[i] = src[i];
+  } else {
+    ByteSink bs(dst);
+    site_emit(sx, k, bs, false, &e);
+  }
   arena[chunk_off[(k + 1) * nchunks] - page_base - 1] = '\n';
   if (e) atomicOr(err, e);
 }
@@ -742,7 +768,7 @@ struct DevicePipeline::Impl {
   DevBuf<int32_t> diff; DevBuf<int64_t> heavy_count, hoff;
   DevBuf<uint64_t> inc_keys, inc_keys_sorted; DevBuf<int64_t> inc_vals, inc_vals_sorted, hbase;
   DevBuf<uint32_t> lut_len, i2m_off; DevBuf<int8_t> i2m, gt_override; DevBuf<uint8_t> iflags;
-  DevBuf<uint8_t> num_alleles, rflags; DevBuf<uint32_t> fmt_mask, prefix_len;
+  DevBuf<uint8_t> num_alleles, rflags; DevBuf<uint32_t> fmt_mask, prefix_len; DevBuf<char> site_staging;
   DevBuf<uint64_t> chunk_size, chunk_off, rec_off;
   DevBuf<char> arena, temp;
   DevBuf<uint32_t> err; DevBuf<int32_t> counters;
@@ -1134,7 +1160,8 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   S.d_sx.ensure(1);
   HIP_CHECK(hipMemcpyAsync(S.d_sx.p, &sx, sizeof(SiteCtx), hipMemcpyHostToDevice, st));   // (sx outlives the copy: the function synchronises before it returns)
   STAGE("k_site_size");
-  hipLaunchKernelGGL(k_site_size, dim3(blocks_for(P, 64)), dim3(64), 0, st, S.d_sx.p, S.err.p);
+  S.site_staging.ensure((size_t)P * kSiteStride + 64);
+  hipLaunchKernelGGL(k_site_size, dim3(blocks_for(P, 64)), dim3(64), 0, st, S.d_sx.p, S.site_staging.p, S.err.p);
   HIP_CHECK(hipEventRecord(ev[2], st));
   // ---- S8 sample-column sizes + offsets ---------------------------------------------------------------------------
   const int nchunks = (N + kAsmRows - 1) / kAsmRows;
@@ -1255,7 +1282,7 @@ bool DevicePipeline::next_page(uint64_t arena_bytes, const char** dev_ptr, uint6
   HIP_CHECK(hipEventCreate(&w0)); HIP_CHECK(hipEventCreate(&w1)); HIP_CHECK(hipEventCreate(&w2));
   HIP_CHECK(hipEventRecord(w0, st));
   STAGE("k_site_write");
-  hipLaunchKernelGGL(k_site_write, dim3(blocks_for(np, 64)), dim3(64), 0, st, S.d_sx.p, kp, ke, S.chunk_off.p, iv.nchunks, page_base, S.arena.p, S.err.p);
+  hipLaunchKernelGGL(k_site_write, dim3(blocks_for(np, 64)), dim3(64), 0, st, S.d_sx.p, (const char*)S.site_staging.p, kp, ke, S.chunk_off.p, iv.nchunks, page_base, S.arena.p, S.err.p);
   HIP_CHECK(hipEventRecord(w1, st));
   STAGE("k_assemble_write");
   const int wrun = run_length(np, iv.nchunks);
