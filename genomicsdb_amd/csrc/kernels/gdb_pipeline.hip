@@ -692,33 +692,48 @@ k_assemble_write(const char* __restrict__ pool, const char* __restrict__ pool_ov
       const uint32_t excl = inc - len;
       const uint32_t total = wave_total(inc);
       if (total == 0) continue;                             // uniform: no FORMAT columns in this record
-      char* gdst = arena + readlane64(my_dst, jj);
-      const uint32_t al = (uint32_t)((uintptr_t)gdst & 15u);
-      if (al + total <= (uint32_t)kWaveLds) {               // uniform
+      char* const grec = arena + readlane64(my_dst, jj);
+      // The chunk normally fits one LDS image.  Wider chunks (long PL vectors) go out in passes over consecutive lane
+      // ranges that fit; only a single entry larger than the image is copied straight from the pool.
+      uint32_t l0 = 0, base_off = 0;
+      while (base_off < total) {                            // uniform
+        char* gdst = grec + base_off;
+        const uint32_t al = (uint32_t)((uintptr_t)gdst & 15u);
+        const bool fits = (uint32_t)lane >= l0 && al + (inc - base_off) <= (uint32_t)kWaveLds;
+        const uint64_t fit_mask = __ballot(fits) >> l0;     // inc is non-decreasing: the fitting lanes are a run starting at l0
+        if (!(fit_mask & 1ull)) {                           // lane l0 alone exceeds the image
+          if ((uint32_t)lane == l0) { char* dst = gdst; for (uint32_t b = 0; b < len; ++b) dst[b] = cur_src[b]; }
+          base_off = (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)l0);
+          ++l0;
+          continue;
+        }
+        const uint32_t nfit = fit_mask == ~0ull ? 64u - l0 : (uint32_t)__builtin_ctzll(~fit_mask);
+        const uint32_t l1 = l0 + nfit;
+        const uint32_t pass_total = (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)(l1 - 1)) - base_off;
+        const bool mine = (uint32_t)lane >= l0 && (uint32_t)lane < l1;
         SlotCopy cp;
-        cp.begin((gdb_lds_char*)lds_buf + al + excl, len);
+        cp.begin((gdb_lds_char*)lds_buf + al + (excl - base_off), mine ? len : 0u);
         cp.chunk(0, txt.x[0]);
 #pragma unroll
         for (int q = 1; q < kTextChunks; ++q) if (__any((int)cp.needs(q))) cp.chunk(q, txt.x[q]);
-        for (uint32_t q = kTextChunks; __any((int)cp.needs(q)); ++q) cp.chunk(q, load_chunk(cur_src, q, len));
+        for (uint32_t q = kTextChunks; __any((int)cp.needs(q)); ++q) cp.chunk(q, load_chunk(cur_src, q, mine ? len : 0u));
         cp.finish();
         // One wavefront per workgroup: the LDS unit runs its instructions in order, so the image only needs a compiler-level
         // fence (wavefront scope emits no s_waitcnt: outstanding matrix loads and page stores keep flying across records).
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         const char* img = lds_buf + al;
         uint32_t head = (16u - al) & 15u;
-        if (head > total) head = total;
-        const uint32_t nwords = (total - head) >> 4;
+        if (head > pass_total) head = pass_total;
+        const uint32_t nwords = (pass_total - head) >> 4;
         const uint32_t tail_at = head + (nwords << 4);
         if ((uint32_t)lane < head) gdst[lane] = img[lane];
         const uint4* lsrc = reinterpret_cast<const uint4*>(img + head);
         uint4* gw = reinterpret_cast<uint4*>(gdst + head);
         for (uint32_t wq = lane; wq < nwords; wq += kAsmRows) gw[wq] = lsrc[wq];
-        if ((uint32_t)lane < total - tail_at) gdst[tail_at + lane] = img[tail_at + lane];
+        if ((uint32_t)lane < pass_total - tail_at) gdst[tail_at + lane] = img[tail_at + lane];
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      } else {                                              // longer than the LDS image (very long PL vectors): straight to HBM
-        char* dst = gdst + excl;
-        for (uint32_t b = 0; b < len; ++b) dst[b] = cur_src[b];
+        l0 = l1;
+        base_off += pass_total;
       }
     }
   }
