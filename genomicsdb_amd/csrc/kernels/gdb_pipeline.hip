@@ -48,12 +48,11 @@ template <class T> struct DevBuf {   // grow-only device allocation
 
 inline bool debug_sync() { static int v = -1; if (v < 0) { const char* e = getenv("GDBAMD_DEBUG_SYNC"); v = (e && *e && *e != '0') ? 1 : 0; } return v == 1; }
 #define STAGE(name) do { if (debug_sync()) { HIP_CHECK(hipStreamSynchronize(st)); fprintf(stderr, "[gdbamd] stage %s\n", name); fflush(stderr); } } while (0)
-// records one workgroup walks: long runs amortise the per-lane cell cache, but keep >= ~8 workgroups per CU in flight
-inline int run_length(int64_t nrec, int nchunks) {
-  int64_t run = 256;
-  while (run > 16 && (nrec / run) * nchunks < 16384) run >>= 1;
-  return (int)run;
-}
+// Records one wavefront takes in a row.  Measured on c2 (200 kb windows): the sizing pass, which starts every run with a
+// binary search per sample, is fastest at 64; the page pass (no per-run set-up beyond one 64-lane scalar fetch) at 32 -
+// more, shorter runs balance better across the 256 CUs than longer ones amortise.  GDBAMD_RUN / GDBAMD_RUN_W override.
+inline int size_run_length() { const char* e = getenv("GDBAMD_RUN"); return e && *e ? std::max(1, atoi(e)) : 64; }
+inline int write_run_length() { const char* e = getenv("GDBAMD_RUN_W"); return e && *e ? std::max(1, atoi(e)) : 32; }
 // record types that get text-table slots (GDBAMD_MAX_TYPES < 64 forces the direct path in tests)
 inline int max_tabled_types() {
   const char* e = getenv("GDBAMD_MAX_TYPES");   // read per interval: tests flip it in-process
@@ -1244,7 +1243,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   AsmCtx ac{S.row_ptr.p, S.rm_begin.p, S.walk.p, S.rstart.p, S.rtype.p, S.prefix_len.p, S.slot_desc.p, S.pool.p, S.inc_pos.p, S.ubase.p,
             (uint32_t)kMaxTypes, (uint32_t)(kMaxTypes + SL), (uint32_t)(kMaxTypes + SL + (uint64_t)T), N};
   // ---- S8b sample-column sizes + offsets ---------------------------------------------------------------------------
-  const int run = run_length(P, nchunks);
+  const int run = size_run_length();
   const unsigned run_blocks = (unsigned)((P + run - 1) / run);
   STAGE("k_assemble_size");
   S.order_by_type(0, P);
@@ -1300,7 +1299,7 @@ bool DevicePipeline::next_page(uint64_t arena_bytes, const char** dev_ptr, uint6
   hipLaunchKernelGGL(k_site_write, dim3(blocks_for(np, 64)), dim3(64), 0, st, S.d_sx.p, (const char*)S.site_staging.p, kp, ke, S.chunk_off.p, iv.nchunks, page_base, S.arena.p, S.err.p);
   HIP_CHECK(hipEventRecord(w1, st));
   STAGE("k_assemble_write");
-  const int wrun = run_length(np, iv.nchunks);
+  const int wrun = write_run_length();
   S.order_by_type(kp, np);
   const unsigned wruns = (unsigned)((np + wrun - 1) / wrun);
   const dim3 wgrid(wruns * (unsigned)iv.nchunks);
