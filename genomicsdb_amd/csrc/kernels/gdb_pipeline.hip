@@ -14,6 +14,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_reduce.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/reverse_iterator.hpp>
 
 #include "../core/gdb_stages.hpp"
 #include "gdb_pipeline.h"
@@ -30,6 +31,7 @@ namespace genomicsdb_amd {
 namespace {
 
 constexpr int kBlock = 256;          // threads per workgroup = 4 wavefronts of 64
+constexpr int kCountSpread = 64;     // addresses a device-wide counter is spread over
 
 template <class T> struct DevBuf {   // grow-only device allocation
   T* p = nullptr;
@@ -136,17 +138,40 @@ __global__ void k_record_expand(Boundaries b, const int64_t* rbase, int64_t U, i
   if (k >= P) return;
   stage_record_expand(b, rbase, U, k, rstart, rend);
 }
+// first_record_at[p] := k for the record starting at qb + p (the starts are distinct and ascending); the suffix-minimum scan
+// that follows turns the marks into "first record starting at or behind qb + p"
+__global__ void k_mark_record_starts(const int64_t* rstart, int64_t P, int64_t qb, int32_t* first_record_at) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < P) first_record_at[rstart[k] - qb] = (int32_t)k;
+}
+__global__ void k_fill_i32(int32_t* p, int64_t n, int32_t v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+// packed prefix sums -> the int32 arrays the site kernels read (PresenceCounts)
+__global__ void k_unpack_counts(DiffPacked pk, int n_format, int64_t n, DiffArrays d) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const uint64_t mask = pk.width >= 64 ? ~0ull : ((1ull << pk.width) - 1ull);
+  for (int j = 0; j <= n_format; ++j) {
+    const uint64_t w = pk.w[(int64_t)(j / pk.per_word) * pk.stride + k];
+    const int32_t v = (int32_t)((w >> ((j % pk.per_word) * pk.width)) & mask);
+    if (j < n_format) d.fmt[(int64_t)j * d.stride + k] = v; else d.nr[k] = v;
+  }
+  d.dp[k] = (int32_t)(int64_t)pk.w[(int64_t)(pk.nwords - 1) * pk.stride + k];
+}
 __global__ void k_cell_ranges(FragmentView fr, CombinePlan pl, CellMeta cm, RecordTable rec, int64_t c_base, int64_t n, int64_t qb, int64_t qe, DiffArrays d,
-                              int64_t* heavy_count, int32_t* in_window_count) {
+                              int64_t* heavy_count, int32_t* in_window_count, const int32_t* first_record_at, DiffPacked pk) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool in_window = false;
   if (i < n) {
     const int64_t c = c_base + i;
-    stage_cell_ranges(fr, pl, cm, rec, c, c_base, qb, qe, d, heavy_count);
+    stage_cell_ranges(fr, pl, cm, rec, c, c_base, qb, qe, d, heavy_count, first_record_at, pk.w ? &pk : nullptr);
     in_window = cm.k_lo[c] >= 0;
   }
-  const uint64_t m = __ballot(in_window);                 // one atomic per wavefront, not per cell
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(in_window_count, (int32_t)__popcll(m));
+  // one atomic per wavefront, spread over kCountSpread addresses (same-address atomics serialise in L2: ~10 ns each)
+  const uint64_t m = __ballot(in_window);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(in_window_count + 16 + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & (kCountSpread - 1)), (int32_t)__popcll(m));
 }
 __global__ void k_incidence_fill(FragmentView fr, CellMeta cm, const int64_t* hoff, int64_t c_base, int64_t n, int64_t nrows, uint64_t* keys, int64_t* vals) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -779,7 +804,7 @@ struct DevicePipeline::Impl {
   DevBuf<uint64_t> ev_keys, ev_keys_sorted; DevBuf<int64_t> ev_delta, ev_incl; DevBuf<int32_t> run_end, run_excl;
   DevBuf<int64_t> bpos, bnrec, rbase; DevBuf<int32_t> bcov, bdel;
   DevBuf<int64_t> rstart, rend;
-  DevBuf<int32_t> diff; DevBuf<int64_t> heavy_count, hoff;
+  DevBuf<int32_t> diff, first_record_at; DevBuf<uint64_t> diff_packed; DevBuf<int64_t> heavy_count, hoff;
   DevBuf<uint64_t> inc_keys, inc_keys_sorted; DevBuf<int64_t> inc_vals, inc_vals_sorted, hbase;
   DevBuf<uint32_t> lut_len, i2m_off; DevBuf<int8_t> i2m, gt_override; DevBuf<uint8_t> iflags;
   DevBuf<uint8_t> num_alleles, rflags; DevBuf<uint32_t> fmt_mask, prefix_len; DevBuf<char> site_staging;
@@ -891,7 +916,7 @@ DevicePipeline::DevicePipeline(const HostPlan& hp, int device) : m_(new Impl) {
   up(m_->filter_name_len, hp.filter_name_len.data(), hp.filter_name_len.size());
   up(m_->contigs, hp.contigs.data(), hp.contigs.size());
   m_->err.ensure(4);
-  m_->counters.ensure(16);
+  m_->counters.ensure(16 + kCountSpread);
 }
 
 DevicePipeline::~DevicePipeline() {
@@ -1035,7 +1060,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   hipEvent_t ev[4];
   for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
   HIP_CHECK(hipMemsetAsync(S.err.p, 0, sizeof(uint32_t), st));
-  HIP_CHECK(hipMemsetAsync(S.counters.p, 0, 16 * sizeof(int32_t), st));
+  HIP_CHECK(hipMemsetAsync(S.counters.p, 0, (16 + kCountSpread) * sizeof(int32_t), st));
   HIP_CHECK(hipEventRecord(ev[0], st));
   // ---- S0 classify + S1 row index (independent of the query interval: once per staged fragment) ---------------------
   S.vmask.ensure(C); S.cflags.ensure(C); S.dpval.ensure(C); S.k_lo.ensure(C); S.k_hi.ensure(C); S.eff_end.ensure(C);
@@ -1121,20 +1146,46 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   const int64_t stride = P + 1;
   const size_t ndiff = (size_t)(nf + 2) * (size_t)stride;
   S.diff.ensure(ndiff);
-  HIP_CHECK(hipMemsetAsync(S.diff.p, 0, ndiff * sizeof(int32_t), st));
+  // counters packed into 64-bit words for the atomics (width = bits of the sample count; fmt fields + <NON_REF> count, DP last)
+  DiffPacked pk;
+  pk.width = 1; while (pk.width < 32 && (1ll << pk.width) <= (int64_t)N) ++pk.width;
+  pk.per_word = 64 / pk.width;
+  pk.nwords = (nf + 1 + pk.per_word - 1) / pk.per_word + 1;
+  pk.stride = stride;
+  S.diff_packed.ensure((size_t)pk.nwords * stride);
+  pk.w = S.diff_packed.p;
+  HIP_CHECK(hipMemsetAsync(pk.w, 0, (size_t)pk.nwords * stride * sizeof(uint64_t), st));
   int32_t* d_fmt = S.diff.p;
   int32_t* d_dp = S.diff.p + (size_t)nf * stride;
   int32_t* d_nr = d_dp + stride;
   DiffArrays da{d_fmt, d_dp, d_nr, stride};
   S.heavy_count.ensure(CW + 1); S.hoff.ensure(CW + 2);
+  // position -> first record table (windows up to 2^27 columns; wider ones keep the binary searches)
+  const int32_t* first_record_at = nullptr;
+  if ((uint64_t)(qe - qb) + 2u <= (1ull << 27)) {
+    const int64_t W = qe - qb + 2;
+    S.first_record_at.ensure(W);
+    hipLaunchKernelGGL(k_fill_i32, dim3(blocks_for(W)), dim3(kBlock), 0, st, S.first_record_at.p, W, (int32_t)P);
+    hipLaunchKernelGGL(k_mark_record_starts, dim3(blocks_for(P)), dim3(kBlock), 0, st, S.rstart.p, P, qb, S.first_record_at.p);
+    {
+      auto rin = rocprim::make_reverse_iterator(S.first_record_at.p + W);
+      size_t bytes = 0;
+      HIP_CHECK(rocprim::inclusive_scan(nullptr, bytes, rin, rin, (size_t)W, rocprim::minimum<int32_t>(), st));
+      void* t = S.temp_storage(bytes);
+      HIP_CHECK(rocprim::inclusive_scan(t, bytes, rin, rin, (size_t)W, rocprim::minimum<int32_t>(), st));
+    }
+    first_record_at = S.first_record_at.p;
+  }
   STAGE("k_cell_ranges");
-  hipLaunchKernelGGL(k_cell_ranges, dim3(blocks_for(CW)), dim3(kBlock), 0, st, fr, pl, cm, rec, c_base, CW, qb, qe, da, S.heavy_count.p, S.counters.p);
-  // every difference array sums to zero over its P+1 elements, so ONE scan over the concatenation equals nf+2 separate scans
-  S.incl_scan(S.diff.p, S.diff.p, ndiff, rocprim::plus<int32_t>());
+  hipLaunchKernelGGL(k_cell_ranges, dim3(blocks_for(CW)), dim3(kBlock), 0, st, fr, pl, cm, rec, c_base, CW, qb, qe, da, S.heavy_count.p, S.counters.p, first_record_at, pk);
+  // every difference array sums to zero over its P+1 elements, so ONE scan over the concatenation equals separate scans
+  S.incl_scan(pk.w, pk.w, (size_t)pk.nwords * stride, rocprim::plus<uint64_t>());
+  hipLaunchKernelGGL(k_unpack_counts, dim3(blocks_for(stride)), dim3(kBlock), 0, st, pk, nf, stride, da);
   S.excl_scan(S.heavy_count.p, S.hoff.p, (size_t)CW);
   int64_t T_a = 0, T_b = 0;
-  int32_t n_in_window = 0;
-  S.read_back_many({{&T_a, S.hoff.p + (CW - 1), sizeof(int64_t)}, {&T_b, S.heavy_count.p + (CW - 1), sizeof(int64_t)}, {&n_in_window, S.counters.p, sizeof(int32_t)}});
+  int32_t n_in_window = 0, spread[kCountSpread];
+  S.read_back_many({{&T_a, S.hoff.p + (CW - 1), sizeof(int64_t)}, {&T_b, S.heavy_count.p + (CW - 1), sizeof(int64_t)}, {spread, S.counters.p + 16, sizeof(spread)}});
+  for (int i = 0; i < kCountSpread; ++i) n_in_window += spread[i];
   const int64_t T = T_a + T_b;
   stats.num_heavy_incidences = T;
   stats.num_cells_in_window = n_in_window;
