@@ -111,17 +111,15 @@ struct DiffArrays { int32_t* fmt; int32_t* dp; int32_t* nr; int64_t stride; };  
 // sum of a field is >= 0 the modulo-2^64 sums never borrow across fields.  The DP sum has a word of its own (last).
 struct DiffPacked { uint64_t* w; int64_t stride; int32_t width, per_word, nwords; };
 
-GDB_HD void stage_cell_ranges(const FragmentView& fr, const CombinePlan& pl, const CellMeta& cm, const RecordTable& rec, int64_t c, int64_t c_base,
-                              int64_t qb, int64_t qe, const DiffArrays& d, int64_t* heavy_count, const int32_t* first_record_at = nullptr,
-                              const DiffPacked* pk = nullptr) {
-  // first_record_at (optional): [qe - qb + 2] table, entry p = first record whose start is >= qb + p (P if none); it replaces
-  // the two binary searches over the record starts by two loads
-  const uint32_t f = cm.cflags[c];
+// record range [klo, khi] a cell is live in (false: none); also k_lo / k_hi / heavy_count of the cell.
+// first_record_at (optional): [qe - qb + 2] table, entry p = first record whose start is >= qb + p (P if none); it replaces
+// the two binary searches over the record starts by two loads
+GDB_HD bool stage_cell_range(const FragmentView& fr, const CellMeta& cm, const RecordTable& rec, int64_t c, int64_t c_base, int64_t qb, int64_t qe,
+                             int64_t* heavy_count, const int32_t* first_record_at, int64_t& klo, int64_t& khi) {
   cm.k_lo[c] = -1; cm.k_hi[c] = -1; heavy_count[c - c_base] = 0;
-  if (!cell_in_window(fr, cm, c, qb, qe) || rec.npos == 0) return;
+  if (!cell_in_window(fr, cm, c, qb, qe) || rec.npos == 0) return false;
   const int64_t b = fr.begin[c] > qb ? fr.begin[c] : qb;
   const int64_t e = cm.eff_end[c] < qe ? cm.eff_end[c] : qe;
-  int64_t klo, khi;
   if (first_record_at) {
     klo = first_record_at[b - qb];
     khi = (int64_t)first_record_at[e + 1 - qb] - 1;
@@ -133,42 +131,39 @@ GDB_HD void stage_cell_ranges(const FragmentView& fr, const CombinePlan& pl, con
     while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (rec.start[mid] <= e) lo = mid + 1; else hi = mid; }
     khi = lo - 1;
   }
-  if (khi < klo) return;
+  if (khi < klo) return false;
   cm.k_lo[c] = (int32_t)klo; cm.k_hi[c] = (int32_t)khi;
-  const uint64_t vm = cm.vmask[c];
-  const int32_t dp = cm.dpval[c];
-  if (pk) {
-    uint64_t acc = 0;
-    int word = 0;
-    for (int j = 0; j <= pl.n_format; ++j) {
-      const int wj = j / pk->per_word;
-      if (wj != word) {
-        if (acc) { GDB_ATOMIC_ADD_U64(pk->w + (int64_t)word * pk->stride + klo, acc); GDB_ATOMIC_ADD_U64(pk->w + (int64_t)word * pk->stride + khi + 1, 0 - acc); }
-        acc = 0; word = wj;
-      }
-      bool on;
-      if (j < pl.n_format) { const int pf = presence_field(pl, j); on = pf >= 0 && ((vm >> pf) & 1); }
-      else on = (f & GDB_CF_HAS_NR) != 0;
-      if (on) acc |= 1ull << ((j % pk->per_word) * pk->width);
-    }
-    if (acc) { GDB_ATOMIC_ADD_U64(pk->w + (int64_t)word * pk->stride + klo, acc); GDB_ATOMIC_ADD_U64(pk->w + (int64_t)word * pk->stride + khi + 1, 0 - acc); }
-    if (dp) {
-      uint64_t* dw = pk->w + (int64_t)(pk->nwords - 1) * pk->stride;
-      GDB_ATOMIC_ADD_U64(dw + klo, (uint64_t)(int64_t)dp);
-      GDB_ATOMIC_ADD_U64(dw + khi + 1, (uint64_t)(-(int64_t)dp));
-    }
-    if (f & GDB_CF_HEAVY) heavy_count[c - c_base] = khi - klo + 1;
-    return;
+  if (cm.cflags[c] & GDB_CF_HEAVY) heavy_count[c - c_base] = khi - klo + 1;
+  return true;
+}
+// contribution of a cell to packed word `word` (presence of FORMAT fields / <NON_REF>)
+GDB_HD uint64_t stage_packed_word(const CombinePlan& pl, const DiffPacked& pk, uint64_t vmask, uint32_t cflags, int word) {
+  uint64_t acc = 0;
+  const int j0 = word * pk.per_word;
+  for (int j = j0; j < j0 + pk.per_word && j <= pl.n_format; ++j) {
+    bool on;
+    if (j < pl.n_format) { const int pf = presence_field(pl, j); on = pf >= 0 && ((vmask >> pf) & 1); }
+    else on = (cflags & GDB_CF_HAS_NR) != 0;
+    if (on) acc |= 1ull << ((j - j0) * pk.width);
   }
+  return acc;
+}
+// serial flavour (CPU harness): +v at klo, -v at khi + 1 in the int32 difference arrays
+GDB_HD void stage_cell_ranges(const FragmentView& fr, const CombinePlan& pl, const CellMeta& cm, const RecordTable& rec, int64_t c, int64_t c_base,
+                              int64_t qb, int64_t qe, const DiffArrays& d, int64_t* heavy_count) {
+  int64_t klo, khi;
+  if (!stage_cell_range(fr, cm, rec, c, c_base, qb, qe, heavy_count, nullptr, klo, khi)) return;
+  const uint32_t f = cm.cflags[c];
+  const uint64_t vm = cm.vmask[c];
   for (int i = 0; i < pl.n_format; ++i) {
     const int pf = presence_field(pl, i);
     if (pf < 0 || !((vm >> pf) & 1)) continue;
     GDB_ATOMIC_ADD_I32(d.fmt + (int64_t)i * d.stride + klo, 1);
     GDB_ATOMIC_ADD_I32(d.fmt + (int64_t)i * d.stride + khi + 1, -1);
   }
+  const int32_t dp = cm.dpval[c];
   if (dp) { GDB_ATOMIC_ADD_I32(d.dp + klo, dp); GDB_ATOMIC_ADD_I32(d.dp + khi + 1, -dp); }
   if (f & GDB_CF_HAS_NR) { GDB_ATOMIC_ADD_I32(d.nr + klo, 1); GDB_ATOMIC_ADD_I32(d.nr + khi + 1, -1); }
-  if (f & GDB_CF_HEAVY) heavy_count[c - c_base] = khi - klo + 1;
 }
 
 // ---- S6: incidence keys: record * N + row, value = cell ----------------------------------------------------

@@ -73,6 +73,26 @@ inline int order_block_log2() {
 inline unsigned blocks_for(int64_t n, int b = kBlock) { return (unsigned)std::max<int64_t>(1, (n + b - 1) / b); }
 inline int bits_for(uint64_t max_value) { int b = 1; while (b < 64 && (max_value >> b)) ++b; return std::min(64, b + 1); }
 
+// ---- wavefront scan / reduce on DPP (no LDS traffic) --------------------------------------------------------------------
+__device__ __forceinline__ uint32_t dpp_row_shr(uint32_t v, int n) {   // lane i <- lane i-n of the same 16-lane row, else 0
+  switch (n) {
+    case 1: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    case 2: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    case 4: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    default: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+  }
+}
+__device__ __forceinline__ uint32_t wave_inclusive_scan_dpp(uint32_t v) {
+  v += dpp_row_shr(v, 1);
+  v += dpp_row_shr(v, 2);
+  v += dpp_row_shr(v, 4);
+  v += dpp_row_shr(v, 8);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_total(uint32_t inclusive) { return (uint32_t)__builtin_amdgcn_readlane((int)inclusive, 63); }
+
 // ---- elementwise stage kernels -----------------------------------------------------------------------------
 __global__ void k_classify(FragmentView fr, CombinePlan pl, CellMeta cm, uint32_t* err) {
   int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -160,18 +180,43 @@ __global__ void k_unpack_counts(DiffPacked pk, int n_format, int64_t n, DiffArra
   }
   d.dp[k] = (int32_t)(int64_t)pk.w[(int64_t)(pk.nwords - 1) * pk.stride + k];
 }
-__global__ void k_cell_ranges(FragmentView fr, CombinePlan pl, CellMeta cm, RecordTable rec, int64_t c_base, int64_t n, int64_t qb, int64_t qe, DiffArrays d,
+// Cells arrive sorted by begin, so neighbouring lanes mostly share klo (about ten cells start per record): the +words of a
+// wavefront are first summed per run of equal klo (segmented suffix sum over the sorted key), and only the first lane of a
+// run issues the atomic.  The -words at khi + 1 are scattered and go out one per lane.
+__device__ __forceinline__ uint64_t wave_run_sum(uint32_t key, uint64_t v, int lane) {   // key = run id: equal ids are contiguous
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t ok = __shfl_down(key, off, 64);
+    const uint64_t ov = __shfl_down(v, off, 64);
+    if (lane + off < 64 && ok == key) v += ov;
+  }
+  return v;
+}
+__global__ void k_cell_ranges(FragmentView fr, CombinePlan pl, CellMeta cm, RecordTable rec, int64_t c_base, int64_t n, int64_t qb, int64_t qe,
                               int64_t* heavy_count, int32_t* in_window_count, const int32_t* first_record_at, DiffPacked pk) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  bool in_window = false;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  bool live = false;
+  int64_t klo = -1 - (int64_t)lane, khi = -1;      // dead lanes: distinct keys, never merged with anything
+  uint64_t vm = 0; uint32_t cf = 0; int32_t dp = 0;
   if (i < n) {
     const int64_t c = c_base + i;
-    stage_cell_ranges(fr, pl, cm, rec, c, c_base, qb, qe, d, heavy_count, first_record_at, pk.w ? &pk : nullptr);
-    in_window = cm.k_lo[c] >= 0;
+    live = stage_cell_range(fr, cm, rec, c, c_base, qb, qe, heavy_count, first_record_at, klo, khi);
+    if (live) { vm = cm.vmask[c]; cf = cm.cflags[c]; dp = cm.dpval[c]; } else klo = -1 - (int64_t)lane;
+  }
+  const int64_t prev_key = __shfl_up(klo, 1, 64);
+  const bool head = lane == 0 || prev_key != klo;
+  const uint32_t run_id = wave_inclusive_scan_dpp(head ? 1u : 0u);   // runs of equal klo (dead lanes are runs of their own)
+  for (int word = 0; word < pk.nwords; ++word) {           // uniform
+    uint64_t acc = 0;
+    if (live) acc = word + 1 < pk.nwords ? stage_packed_word(pl, pk, vm, cf, word) : (uint64_t)(int64_t)dp;
+    const uint64_t run = wave_run_sum(run_id, acc, lane);
+    uint64_t* w = pk.w + (int64_t)word * pk.stride;
+    if (live && head && run) atomicAdd((unsigned long long*)(w + klo), (unsigned long long)run);
+    if (live && acc) atomicAdd((unsigned long long*)(w + khi + 1), (unsigned long long)(0 - acc));
   }
   // one atomic per wavefront, spread over kCountSpread addresses (same-address atomics serialise in L2: ~10 ns each)
-  const uint64_t m = __ballot(in_window);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(in_window_count + 16 + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & (kCountSpread - 1)), (int32_t)__popcll(m));
+  const uint64_t m = __ballot(live);
+  if (lane == 0 && m) atomicAdd(in_window_count + 16 + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & (kCountSpread - 1)), (int32_t)__popcll(m));
 }
 __global__ void k_incidence_fill(FragmentView fr, CellMeta cm, const int64_t* hoff, int64_t c_base, int64_t n, int64_t nrows, uint64_t* keys, int64_t* vals) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -588,25 +633,6 @@ __device__ __forceinline__ uint4 load_chunk(const char* __restrict__ src, uint32
   if ((q << 4) < n) x = *reinterpret_cast<const uint4*>(src + (q << 4));
   return x;
 }
-// ---- wavefront scan / reduce on DPP (no LDS traffic) --------------------------------------------------------------------
-__device__ __forceinline__ uint32_t dpp_row_shr(uint32_t v, int n) {   // lane i <- lane i-n of the same 16-lane row, else 0
-  switch (n) {
-    case 1: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
-    case 2: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
-    case 4: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
-    default: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
-  }
-}
-__device__ __forceinline__ uint32_t wave_inclusive_scan_dpp(uint32_t v) {
-  v += dpp_row_shr(v, 1);
-  v += dpp_row_shr(v, 2);
-  v += dpp_row_shr(v, 4);
-  v += dpp_row_shr(v, 8);
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
-  return v;
-}
-__device__ __forceinline__ uint32_t wave_total(uint32_t inclusive) { return (uint32_t)__builtin_amdgcn_readlane((int)inclusive, 63); }
 
 // ---- assembly kernels: one wavefront = `run` records of one type x 64 samples, no workgroup barriers ---------------------
 // Records are visited in (type, position) order (`order`): along such a run a sample keeps the same slot until its live
@@ -1177,7 +1203,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
     first_record_at = S.first_record_at.p;
   }
   STAGE("k_cell_ranges");
-  hipLaunchKernelGGL(k_cell_ranges, dim3(blocks_for(CW)), dim3(kBlock), 0, st, fr, pl, cm, rec, c_base, CW, qb, qe, da, S.heavy_count.p, S.counters.p, first_record_at, pk);
+  hipLaunchKernelGGL(k_cell_ranges, dim3(blocks_for(CW)), dim3(kBlock), 0, st, fr, pl, cm, rec, c_base, CW, qb, qe, S.heavy_count.p, S.counters.p, first_record_at, pk);
   // every difference array sums to zero over its P+1 elements, so ONE scan over the concatenation equals separate scans
   S.incl_scan(pk.w, pk.w, (size_t)pk.nwords * stride, rocprim::plus<uint64_t>());
   hipLaunchKernelGGL(k_unpack_counts, dim3(blocks_for(stride)), dim3(kBlock), 0, st, pk, nf, stride, da);
