@@ -397,15 +397,29 @@ __global__ void k_untabled_records(const uint32_t* untabled, const uint32_t* uba
   if (k < P && untabled[k]) urec[ubase[k]] = (int32_t)k;
 }
 // which record types does every plain (non-heavy) cell of the window meet?
-__global__ void k_cell_types(const uint32_t* cflags, const int32_t* k_lo, const int32_t* k_hi, const uint8_t* rtype, int64_t c_base, int64_t n,
-                             uint64_t* tmask, uint32_t* nslots) {
+// Which record types does every plain (non-heavy) cell of the window meet?  A cell is live in ~100 records, so instead of
+// reading their types one by one the kernel asks per type "is there a record of this type in [k_lo, k_hi]?" of a prefix
+// count table: occ[t][k] = #records of type t before k (one exclusive scan over the 64 x (P+1) one-hot matrix; differences
+// inside a row do not care about the row's starting value).
+__global__ void k_type_onehot(const uint8_t* rtype, int64_t P, uint32_t* occ) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= P) return;
+  const uint32_t t = rtype[k];
+  if (t != kUntabledType) occ[(int64_t)t * (P + 1) + k] = 1u;
+}
+__global__ void k_cell_types(const uint32_t* cflags, const int32_t* k_lo, const int32_t* k_hi, const uint32_t* occ, int64_t P, const int32_t* ntypes_p,
+                             int64_t c_base, int64_t n, uint64_t* tmask, uint32_t* nslots) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int64_t c = c_base + i;
   uint64_t m = 0;
   if (!(cflags[c] & GDB_CF_HEAVY) && k_lo[c] >= 0) {
-    const int32_t hi = k_hi[c];
-    for (int32_t k = k_lo[c]; k <= hi; ++k) { const uint32_t t = rtype[k]; if (t != kUntabledType) m |= 1ull << t; }
+    const int64_t lo = k_lo[c], hi1 = (int64_t)k_hi[c] + 1;
+    const int ntypes = *ntypes_p;
+    for (int t = 0; t < ntypes; ++t) {
+      const uint32_t* row = occ + (int64_t)t * (P + 1);
+      if (row[hi1] != row[lo]) m |= 1ull << t;
+    }
   }
   tmask[i] = m;
   nslots[i] = (uint32_t)__popcll(m);
@@ -842,6 +856,7 @@ struct DevicePipeline::Impl {
   DevBuf<unsigned long long> type_hkeys; DevBuf<int32_t> type_hrep, type_rep; DevBuf<uint8_t> type_hid, rtype;
   DevBuf<WalkCell> walk; DevBuf<int64_t> walk_inv;
   DevBuf<uint2> resolved;          // (pool offset, length) of every (record, sample): whole interval, or one page when that exceeds the budget
+  DevBuf<uint32_t> type_occ;
   DevBuf<uint32_t> untabled, ubase; DevBuf<int32_t> urec, iota, order; DevBuf<uint32_t> order_keys, order_keys_sorted;
   DevBuf<uint64_t> tmask; DevBuf<uint32_t> nslots, tbase, inc_pos, slot_len, slot_units, slot_off; DevBuf<uint2> slot_desc; DevBuf<char> pool, pool_ovf;
   bool classified = false;
@@ -1276,7 +1291,15 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   S.excl_scan(S.untabled.p, S.ubase.p, (size_t)P);
   S.tmask.ensure(CW); S.nslots.ensure(CW + 1); S.tbase.ensure(CW + 1);
   STAGE("k_cell_types");
-  hipLaunchKernelGGL(k_cell_types, dim3(blocks_for(CW)), dim3(kBlock), 0, st, S.cflags.p, S.k_lo.p, S.k_hi.p, S.rtype.p, c_base, CW, S.tmask.p, S.nslots.p);
+  {
+    const size_t nocc = (size_t)kMaxTypes * (size_t)(P + 1);
+    S.type_occ.ensure(nocc);
+    HIP_CHECK(hipMemsetAsync(S.type_occ.p, 0, nocc * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(k_type_onehot, dim3(blocks_for(P)), dim3(kBlock), 0, st, (const uint8_t*)S.rtype.p, P, S.type_occ.p);
+    S.excl_scan(S.type_occ.p, S.type_occ.p, nocc);
+  }
+  hipLaunchKernelGGL(k_cell_types, dim3(blocks_for(CW)), dim3(kBlock), 0, st, S.cflags.p, S.k_lo.p, S.k_hi.p, (const uint32_t*)S.type_occ.p, P,
+                     (const int32_t*)(S.counters.p + 1), c_base, CW, S.tmask.p, S.nslots.p);
   S.excl_scan(S.nslots.p, S.tbase.p, (size_t)CW);
   uint32_t ur_a = 0, ur_b = 0, sl_a = 0, sl_b = 0;
   int32_t ntypes = 0;
