@@ -158,14 +158,32 @@ template <class Sink> GDB_HD void put_u64(Sink& s, uint64_t v) {
 template <class Sink> GDB_HD void put_i64(Sink& s, int64_t v) {
   if (v < 0) { s.put('-'); put_u64(s, (uint64_t)(-(v + 1)) + 1u); } else put_u64(s, (uint64_t)v);
 }
-// 32-bit only (no 64-bit division on the hot path): every FORMAT integer goes through here
+// 32-bit only (no 64-bit division on the hot path): every FORMAT integer goes through here.  The digits are gathered in
+// a register (8 characters in a 64-bit word, first character in the low byte) - no private-memory array.
+GDB_HD uint64_t gdb_pack_digits(uint32_t v, int& n) {   // v < 10^8
+  uint64_t w = 0;
+  n = 0;
+  do { const uint32_t q = v / 10u; w = (w << 8) | (uint64_t)('0' + (v - q * 10u)); v = q; ++n; } while (v);
+  return w;
+}
+template <class Sink> GDB_HD void put_packed(Sink& s, uint64_t w, int n) {
+  for (int i = 0; i < n; ++i) { s.put((char)(w & 0xFFu)); w >>= 8; }
+}
 template <class Sink> GDB_HD void put_u32(Sink& s, uint32_t v) {
   if (v < 10u) { s.put((char)('0' + v)); return; }
   if (v < 100u) { const uint32_t q = v / 10u; s.put((char)('0' + q)); s.put((char)('0' + (v - q * 10u))); return; }
-  char buf[10];
-  int n = 0;
-  do { const uint32_t q = v / 10u; buf[n++] = (char)('0' + (v - q * 10u)); v = q; } while (v);
-  while (n) s.put(buf[--n]);
+  int n;
+  if (v >= 100000000u) {   // 9 or 10 digits: leading one or two, then exactly eight
+    const uint32_t hi = v / 100000000u;
+    v -= hi * 100000000u;
+    put_packed(s, gdb_pack_digits(hi, n), n);
+    uint64_t w = gdb_pack_digits(v, n);
+    for (; n < 8; ++n) w = (w << 8) | (uint64_t)'0';
+    put_packed(s, w, 8);
+    return;
+  }
+  const uint64_t w = gdb_pack_digits(v, n);
+  put_packed(s, w, n);
 }
 template <class Sink> GDB_HD void put_i32(Sink& s, int32_t v) {
   if (v < 0) { s.put('-'); put_u32(s, 0u - (uint32_t)v); } else put_u32(s, (uint32_t)v);
@@ -416,6 +434,15 @@ GDB_HD bool elem_is_missing(int32_t v) { return v == GDB_BCF_INT32_MISSING; }
 GDB_HD bool elem_is_missing(float v) { return gdb_f2u(v) == GDB_BCF_FLOAT_MISSING_BITS; }
 GDB_HD void elem_set_missing(int32_t& v) { v = GDB_BCF_INT32_MISSING; }
 GDB_HD void elem_set_missing(float& v) { union { uint32_t u; float f; } x; x.u = GDB_BCF_FLOAT_MISSING_BITS; v = x.f; }
+// text of an element in a register (first character in the low byte), or 0 when it does not fit the packed form
+GDB_HD int elem_pack_text(int32_t v, uint64_t& w) {
+  if (v == GDB_BCF_INT32_MISSING) { w = (uint64_t)'.'; return 1; }
+  if (v < 0 || v >= 100000000) return 0;
+  int n;
+  w = gdb_pack_digits((uint32_t)v, n);
+  return n;
+}
+GDB_HD int elem_pack_text(float, uint64_t&) { return 0; }
 template <class Sink> GDB_HD void put_elem(Sink& s, int32_t v, uint32_t*) { if (elem_is_missing(v)) s.put('.'); else put_i32(s, v); }
 template <class Sink> GDB_HD void put_elem(Sink& s, float v, uint32_t* err) {
   if (elem_is_missing(v)) s.put('.');
@@ -932,6 +959,24 @@ template <class Sink, class T> GDB_FIELD_FN Sink emit_remap_genotypes(Sink s, co
       if (has) v = p[in_j]; else elem_set_missing(v);
       put_elem(s, v, err);
     }
+  } else if (ploidy == 2 && em.light) {
+    // plain reference block: every merged ALT reads the call's <NON_REF>, so the whole vector repeats three values -
+    // PL[REF/REF], PL[REF/NR], PL[NR/NR] - which are formatted once
+    T v3[3];
+    uint64_t w3[3];
+    int n3[3];
+    const int nr = em.nr_in;
+    for (int q = 0; q < 3; ++q) {
+      const int gi = q == 0 ? 0 : q == 1 ? (nr >= 0 ? gdb_alleles2gt(0, nr) : -1) : (nr >= 0 ? gdb_alleles2gt(nr, nr) : -1);
+      if (gi >= 0 && gi < n) v3[q] = p[gi]; else elem_set_missing(v3[q]);
+      n3[q] = elem_pack_text(v3[q], w3[q]);   // 0: not packable (float, negative, 9+ digits) -> generic formatter
+    }
+    for (int kk = 0; kk < num_merged; ++kk)
+      for (int j = 0; j <= kk; ++j) {
+        if (kk | j) s.put(',');
+        const int q = kk == 0 ? 0 : (j == 0 ? 1 : 2);
+        if (n3[q]) put_packed(s, w3[q], n3[q]); else put_elem(s, v3[q], err);
+      }
   } else if (ploidy == 2) {
     // output order gt = k(k+1)/2 + j, j <= k
     for (int kk = 0; kk < num_merged; ++kk) {
