@@ -1397,7 +1397,6 @@ bool DevicePipeline::next_page(uint64_t arena_bytes, const char** dev_ptr, uint6
   HIP_CHECK(hipEventRecord(w0, st));
   STAGE("k_site_write");
   hipLaunchKernelGGL(k_site_write, dim3(blocks_for(np, 64)), dim3(64), 0, st, S.d_sx.p, (const char*)S.site_staging.p, kp, ke, S.chunk_off.p, iv.nchunks, page_base, S.arena.p, S.err.p);
-  HIP_CHECK(hipEventRecord(w1, st));
   STAGE("k_assemble_write");
   const int wrun = write_run_length();
   S.order_by_type(kp, np);
@@ -1407,6 +1406,7 @@ bool DevicePipeline::next_page(uint64_t arena_bytes, const char** dev_ptr, uint6
     S.resolved.ensure((size_t)np * iv.nchunks * kAsmRows);
     hipLaunchKernelGGL(k_assemble_size, wgrid, dim3(kAsmRows), 0, st, iv.ac, S.order.p, np, N, iv.nchunks, wrun, (uint64_t*)nullptr, S.resolved.p, kp);
   }
+  HIP_CHECK(hipEventRecord(w1, st));   // [w1, w2] brackets the page-assembly kernel alone (its duration feeds the roofline figure)
   hipLaunchKernelGGL(k_assemble_write, wgrid, dim3(kAsmRows), 0, st, (const char*)S.pool.p, (const char*)S.pool_ovf.p, (const uint32_t*)S.prefix_len.p, (const uint2*)S.resolved.p,
                      iv.resolved_whole ? (int64_t)0 : kp, (const int32_t*)S.order.p, np, iv.nchunks, wrun, (const uint64_t*)S.chunk_off.p, page_base, S.arena.p);
   HIP_CHECK(hipEventRecord(w2, st));
