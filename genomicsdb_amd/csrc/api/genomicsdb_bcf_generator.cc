@@ -20,13 +20,9 @@ CombineEngine::CombineEngine(const mini_json::Value& query_json, int device, con
 }
 
 void CombineEngine::stage_cells(const uint8_t* cells, uint64_t nbytes) {
-  HostFragment hf = fragment_from_cells(cells, nbytes, m_qc, m_hp);
-  reference_cell_bytes = hf.reference_cell_bytes;
-  has_cells = hf.ncells() > 0;
-  num_cells = hf.ncells();
-  min_begin = INT64_MAX; max_end = 0;
-  for (int64_t c = 0; c < hf.ncells(); ++c) { min_begin = std::min(min_begin, hf.begin[(size_t)c]); max_end = std::max(max_end, hf.end[(size_t)c]); }
-  m_pipe->stage_fragment(hf);
+  stage_cells_begin();
+  stage_cells_append(cells, nbytes);
+  stage_cells_end();
 }
 
 void CombineEngine::stage_cells_begin() {
@@ -34,11 +30,12 @@ void CombineEngine::stage_cells_begin() {
   m_pipe->begin_staging();
 }
 void CombineEngine::stage_cells_append(const uint8_t* cells, uint64_t nbytes) {
-  HostFragment hf = fragment_from_cells(cells, nbytes, m_qc, m_hp);
-  reference_cell_bytes += hf.reference_cell_bytes;
-  num_cells += hf.ncells();
-  for (int64_t c = 0; c < hf.ncells(); ++c) { min_begin = std::min(min_begin, hf.begin[(size_t)c]); max_end = std::max(max_end, hf.end[(size_t)c]); }
-  m_pipe->append_fragment(hf);
+  if (!m_layout) m_layout.reset(new CellStreamLayout(m_qc, m_hp));
+  // the stream goes to HBM as it is and is taken apart there (DevicePipeline::append_cells)
+  const DevicePipeline::CellStreamInfo info = m_pipe->append_cells(cells, nbytes, m_layout->schema, m_layout->attr_to_field, m_layout->row_map);
+  reference_cell_bytes += info.reference_cell_bytes;
+  num_cells += info.ncells;
+  if (info.ncells > 0) { min_begin = std::min(min_begin, info.min_begin); max_end = std::max(max_end, info.max_end); }
 }
 void CombineEngine::stage_cells_end() {
   has_cells = num_cells > 0;

@@ -37,6 +37,7 @@ class CombineEngine {
   VariantQueryConfig m_qc;
   HostPlan m_hp;
   std::unique_ptr<DevicePipeline> m_pipe;
+  std::unique_ptr<CellStreamLayout> m_layout;   // attribute order, plan-field map, row map of the binary cell stream
   ReferenceGenomeInfo m_ref;
 };
 

@@ -172,7 +172,7 @@ template <class Sink> GDB_HD void put_packed(Sink& s, uint64_t w, int n) {
 template <class Sink> GDB_HD void put_u32(Sink& s, uint32_t v) {
   if (v < 10u) { s.put((char)('0' + v)); return; }
   if (v < 100u) { const uint32_t q = v / 10u; s.put((char)('0' + q)); s.put((char)('0' + (v - q * 10u))); return; }
-  int n;
+  int n = 0;
   if (v >= 100000000u) {   // 9 or 10 digits: leading one or two, then exactly eight
     const uint32_t hi = v / 100000000u;
     v -= hi * 100000000u;

@@ -56,6 +56,13 @@ GDB_HD void stage_event_keys(const FragmentView& fr, const CellMeta& cm, int64_t
   keys[2 * c] = ((uint64_t)(b - qb) << 2) | del;
   keys[2 * c + 1] = ((uint64_t)(e + 1 - qb) << 2) | 2u | del;
 }
+// a boundary marker = a begin and an end event at the same position: a boundary with no change of coverage
+GDB_HD void stage_marker_keys(const FragmentView& fr, int64_t m, int64_t qb, int64_t qe, uint64_t* two_keys) {
+  const int64_t p = fr.marker_begin[m];
+  if (p < qb || p > qe) { two_keys[0] = GDB_EVENT_SENTINEL; two_keys[1] = GDB_EVENT_SENTINEL; return; }
+  two_keys[0] = (uint64_t)(p - qb) << 2;
+  two_keys[1] = ((uint64_t)(p - qb) << 2) | 2u;
+}
 // S3b: deltas of a sorted key: packed (coverage delta << 32) + deletion-coverage delta, both as wrapped int32 lanes
 GDB_HD int64_t stage_event_delta(uint64_t key) {
   if (key == GDB_EVENT_SENTINEL) return 0;

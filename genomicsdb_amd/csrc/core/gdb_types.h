@@ -56,7 +56,8 @@ enum GdbErr {
   GDB_ERR_ARENA_OVERFLOW = 1u << 5,
   GDB_ERR_INTERNAL = 1u << 6,
   GDB_ERR_TOO_MANY_ID_TOKENS = 1u << 7,               // more than GDB_MAX_ID_TOKENS distinct ID tokens in one record
-  GDB_ERR_INFO_VECTOR_TOO_LONG = 1u << 8              // element_wise_sum over more than GDB_MAX_INFO_VECTOR elements
+  GDB_ERR_INFO_VECTOR_TOO_LONG = 1u << 8,             // element_wise_sum over more than GDB_MAX_INFO_VECTOR elements
+  GDB_ERR_CELL_STREAM = 1u << 9                       // malformed / unsorted binary cell stream at staging
 };
 
 struct GdbFieldDesc {
@@ -80,6 +81,11 @@ struct FragmentView {
   const int64_t* begin;  // column (genomic position) of the cell
   const int64_t* end;    // END attribute
   GdbColumn col[GDB_MAX_FIELDS];  // indexed by plan field idx
+  // begin columns (ascending) of the cells of array rows the query does NOT ask for: the reference's scan still sees those
+  // cells and closes the current interval at each of their begins (query_variants.cc:478-505 runs before the row filter of
+  // :507), so they survive staging as position-only boundary markers
+  int64_t nmarkers;
+  const int64_t* marker_begin;
 };
 
 struct CombinePlan {

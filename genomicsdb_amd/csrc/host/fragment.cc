@@ -24,6 +24,20 @@ int VariantArraySchemaLite::find(const std::string& n) const {
   return -1;
 }
 
+CellStreamLayout::CellStreamLayout(const VariantQueryConfig& qc, const HostPlan& hp) : schema(qc.get_vid_mapper()) {
+  attr_to_field.assign(schema.attrs.size(), -1);
+  for (int f = 0; f < hp.plan.nfields; ++f) {
+    int ai = schema.find(hp.field_names[(size_t)f]);
+    if (ai < 0) throw UnknownQueryAttributeException("Invalid query attribute : " + hp.field_names[(size_t)f]);
+    attr_to_field[(size_t)ai] = f;
+  }
+  row_map.assign((size_t)std::max<int64_t>(qc.get_num_rows_in_array(), 1), -1);
+  for (uint64_t q = 0; q < qc.get_num_rows_to_query(); ++q) {
+    int64_t r = qc.get_array_row_idx_for_query_row_idx(q);
+    if (r >= 0 && (size_t)r < row_map.size()) row_map[(size_t)r] = (int32_t)q;
+  }
+}
+
 HostFragment fragment_from_cells(const uint8_t* cells, size_t nbytes, const VariantQueryConfig& qc, const HostPlan& hp) {
   const VidMapper& vid = qc.get_vid_mapper();
   VariantArraySchemaLite schema(vid);
@@ -82,6 +96,7 @@ HostFragment fragment_from_cells(const uint8_t* cells, size_t nbytes, const Vari
       p += bytes;
     }
     if ((uint64_t)(p - (cells + off)) != cell_size) throw std::runtime_error("cell size mismatch while parsing the cell stream");
+    if (qrow < 0 && row >= 0 && (size_t)row < row_map.size()) fr.marker_begin.push_back(col);
     if (qrow >= 0) {
       fr.row.push_back(qrow);
       fr.begin.push_back(col);

@@ -52,6 +52,11 @@ class DevicePipeline {
   // staging in parts (column-major order across parts): begin, append host fragments, finish = one contiguous fragment in HBM
   void begin_staging();
   void append_fragment(const HostFragment& hf);
+  // the same from the reference's binary cell stream: the bytes are copied to HBM as they are and taken apart there
+  // (one thread per cell); the host only walks the cell sizes.  row_map: array row -> query row (-1: not queried)
+  struct CellStreamInfo { int64_t ncells = 0; uint64_t reference_cell_bytes = 0; int64_t min_begin = INT64_MAX, max_end = 0; };
+  CellStreamInfo append_cells(const uint8_t* cells, uint64_t nbytes, const VariantArraySchemaLite& schema, const std::vector<int>& attr_to_field,
+                              const std::vector<int32_t>& row_map);
   void finish_staging();
   // adopt a fragment that already lives in HBM (e.g. torch tensors); the caller keeps ownership
   void adopt_fragment(const FragmentView& device_view);

@@ -136,6 +136,10 @@ __global__ void k_event_keys(FragmentView fr, CellMeta cm, int64_t c_base, int64
   if (i >= n) return;
   stage_event_keys(fr, cm, c_base + i, c_base, qb, qe, keys);
 }
+__global__ void k_marker_keys(FragmentView fr, int64_t m_base, int64_t n, int64_t qb, int64_t qe, uint64_t* keys) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) stage_marker_keys(fr, m_base + i, qb, qe, keys + 2 * i);
+}
 __global__ void k_event_delta(const uint64_t* keys, int64_t n, int64_t* delta, int32_t* run_end) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -811,6 +815,77 @@ __global__ void k_order_keys(const uint8_t* rtype, int32_t base, int64_t n, int 
   vals[i] = base + (int32_t)i;
 }
 
+// ---- S-1: the reference's binary cell stream -> columnar fragment, on the device ---------------------------------------
+// Cell = [row i64][col i64][size u64] then the attributes in schema order, each fixed (num x elem) or var ([len i32] +
+// len x elem)  (vcf2binary.cc:991-1196, variant_cell.cc:79-117).  One thread per cell walks the ~20 attributes twice:
+// pass 1 measures (keep flag, coordinates, element counts of the variable-length plan fields), scans turn the counts into
+// column offsets, pass 2 copies the payloads.  Unaligned sources: everything is read bytewise.
+constexpr int kMaxSchemaAttrs = 96;
+struct CellAttrDesc { int16_t var, elem_size; int32_t num; int32_t field; };   // field: plan field fed by this attribute or -1
+struct CellSchemaDev { int32_t nattrs; CellAttrDesc a[kMaxSchemaAttrs]; };
+struct CellColumnsDev { char* data[GDB_MAX_FIELDS]; uint32_t* len[GDB_MAX_FIELDS]; const uint32_t* off[GDB_MAX_FIELDS]; uint32_t* frag_off[GDB_MAX_FIELDS]; };
+
+__device__ __forceinline__ int64_t load_i64_unaligned(const uint8_t* p) { int64_t v = 0; for (int i = 7; i >= 0; --i) v = (v << 8) | p[i]; return v; }
+__device__ __forceinline__ int32_t load_i32_unaligned(const uint8_t* p) { return (int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)); }
+
+__global__ void k_cells_measure(const uint8_t* __restrict__ cells, const uint64_t* __restrict__ cell_off, int64_t n, CellSchemaDev sch, const int32_t* __restrict__ row_map,
+                                int64_t nrows_array, int nfields, uint32_t* keep, uint32_t* is_marker, int32_t* qrow, int64_t* begin, int64_t* end, CellColumnsDev cols,
+                                uint32_t* err) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* c = cells + cell_off[i];
+  const int64_t row = load_i64_unaligned(c);
+  const int64_t size = (int64_t)(cell_off[i + 1] - cell_off[i]);
+  const int32_t q = (row >= 0 && row < nrows_array) ? row_map[row] : -1;
+  keep[i] = q >= 0 ? 1u : 0u;
+  is_marker[i] = (q < 0 && row >= 0 && row < nrows_array) ? 1u : 0u;   // an array row outside the query: boundary marker
+  qrow[i] = q;
+  begin[i] = load_i64_unaligned(c + 8);
+  const uint8_t* p = c + 24;
+  for (int ai = 0; ai < sch.nattrs; ++ai) {
+    const CellAttrDesc a = sch.a[ai];
+    uint32_t cnt = (uint32_t)a.num;
+    if (a.var) { cnt = (uint32_t)load_i32_unaligned(p); p += 4; }
+    if (ai == 0) end[i] = load_i64_unaligned(p);
+    if (a.field >= 0 && a.var) cols.len[a.field][i] = q >= 0 ? cnt : 0u;
+    p += (size_t)cnt * (size_t)a.elem_size;
+    if (p - c > size) break;
+  }
+  if (p - c != size) atomicOr(err, (uint32_t)GDB_ERR_CELL_STREAM);
+  (void)nfields;
+}
+__global__ void k_cells_scatter(const uint8_t* __restrict__ cells, const uint64_t* __restrict__ cell_off, int64_t n, CellSchemaDev sch, const uint32_t* __restrict__ keep,
+                                const uint32_t* __restrict__ dest, const int32_t* __restrict__ qrow, const int64_t* __restrict__ begin, const int64_t* __restrict__ end,
+                                int32_t* row_out, int64_t* begin_out, int64_t* end_out, CellColumnsDev cols) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !keep[i]) return;
+  const uint32_t d = dest[i];
+  row_out[d] = qrow[i]; begin_out[d] = begin[i]; end_out[d] = end[i];
+  const uint8_t* p = cells + cell_off[i] + 24;
+  for (int ai = 0; ai < sch.nattrs; ++ai) {
+    const CellAttrDesc a = sch.a[ai];
+    uint32_t cnt = (uint32_t)a.num;
+    if (a.var) { cnt = (uint32_t)load_i32_unaligned(p); p += 4; }
+    const size_t bytes = (size_t)cnt * (size_t)a.elem_size;
+    if (a.field >= 0) {
+      char* dst;
+      if (a.var) { const uint32_t o = cols.off[a.field][i]; cols.frag_off[a.field][d] = o; dst = cols.data[a.field] + (size_t)o * a.elem_size; }
+      else dst = cols.data[a.field] + (size_t)d * bytes;
+      for (size_t b = 0; b < bytes; ++b) dst[b] = (char)p[b];
+    }
+    p += bytes;
+  }
+}
+__global__ void k_cells_markers(const uint32_t* is_marker, const uint32_t* mdest, const int64_t* begin, int64_t n, int64_t* marker_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && is_marker[i]) marker_out[mdest[i]] = begin[i];
+}
+__global__ void k_cells_order_check(const int32_t* row, const int64_t* begin, int64_t n, uint32_t* err) {
+  const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (d < 1 || d >= n) return;
+  if (begin[d] < begin[d - 1] || (begin[d] == begin[d - 1] && row[d] <= row[d - 1])) atomicOr(err, (uint32_t)GDB_ERR_CELL_STREAM);
+}
+
 __global__ void k_copy_offsets(const uint32_t* src, int64_t n, uint32_t base, uint32_t* dst) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[i] + base;
@@ -855,6 +930,9 @@ struct DevicePipeline::Impl {
   // entry text table
   DevBuf<unsigned long long> type_hkeys; DevBuf<int32_t> type_hrep, type_rep; DevBuf<uint8_t> type_hid, rtype;
   DevBuf<WalkCell> walk; DevBuf<int64_t> walk_inv;
+  // cell-stream staging (append_cells)
+  DevBuf<uint8_t> raw_cells; DevBuf<uint64_t> raw_off; DevBuf<int32_t> raw_row_map, raw_qrow; DevBuf<uint32_t> raw_keep, raw_dest, raw_len, raw_voff, raw_mark, raw_mdest;
+  DevBuf<int64_t> raw_begin, raw_end;
   DevBuf<uint2> resolved;          // (pool offset, length) of every (record, sample): whole interval, or one page when that exceeds the budget
   DevBuf<uint32_t> type_occ;
   DevBuf<uint32_t> untabled, ubase; DevBuf<int32_t> urec, iota, order; DevBuf<uint32_t> order_keys, order_keys_sorted;
@@ -987,6 +1065,8 @@ void DevicePipeline::stage_fragment(const HostFragment& hf) {
     v.col[f].data = up(hf.cols[f].data.data(), hf.cols[f].data.size());
     v.col[f].off = hf.cols[f].var ? (const uint32_t*)up(hf.cols[f].off.data(), hf.cols[f].off.size() * 4) : nullptr;
   }
+  v.nmarkers = (int64_t)hf.marker_begin.size();
+  v.marker_begin = (const int64_t*)up(hf.marker_begin.data(), hf.marker_begin.size() * 8);
   m_->fr = v;
   m_->owns_fragment = true;
   m_->classified = false;
@@ -1020,7 +1100,132 @@ void DevicePipeline::append_fragment(const HostFragment& hf) {
     part.data_bytes.push_back(hf.cols[f].data.size());
     m_->col_elem_size[f] = hf.cols[f].elem_size; m_->col_var[f] = hf.cols[f].var; m_->col_fixed_num[f] = hf.cols[f].fixed_num;
   }
+  part.v.nmarkers = (int64_t)hf.marker_begin.size();
+  part.v.marker_begin = (const int64_t*)up(hf.marker_begin.data(), hf.marker_begin.size() * 8);
   m_->parts.push_back(part);
+}
+
+DevicePipeline::CellStreamInfo DevicePipeline::append_cells(const uint8_t* cells, uint64_t nbytes, const VariantArraySchemaLite& schema,
+                                                          const std::vector<int>& attr_to_field, const std::vector<int32_t>& row_map) {
+  Impl& S = *m_;
+  CellStreamInfo info;
+  HIP_CHECK(hipSetDevice(S.device));
+  hipStream_t st = S.stream;
+  if (nbytes == 0) return info;
+  if (schema.attrs.size() > (size_t)kMaxSchemaAttrs) throw UnsupportedOnDeviceException("more than 96 attributes in the array schema");
+  // ---- host: walk the cell sizes (the only sequential dependency of the format) --------------------------------------
+  std::vector<uint64_t> offs;
+  offs.reserve((size_t)(nbytes / 128) + 16);
+  int64_t nkept = 0, nmark = 0;
+  for (uint64_t off = 0; off < nbytes;) {
+    if (off + 32 > nbytes) throw std::runtime_error("truncated cell stream");
+    int64_t row; uint64_t sz;
+    memcpy(&row, cells + off, 8);
+    memcpy(&sz, cells + off + 16, 8);
+    if (sz < 32 || off + sz > nbytes) throw std::runtime_error("truncated cell stream");
+    offs.push_back(off);
+    if (row >= 0 && (size_t)row < row_map.size()) { if (row_map[(size_t)row] >= 0) { ++nkept; info.reference_cell_bytes += sz; } else ++nmark; }
+    off += sz;
+  }
+  const int64_t n = (int64_t)offs.size();
+  offs.push_back(nbytes);
+  info.ncells = nkept;
+  if (nkept == 0 && nmark == 0) return info;
+  if (nkept >= (1ll << 32)) throw GenomicsDBDeviceException("more than 2^32 cells in one part: stage in smaller parts");
+  const int nf = S.hp.plan.nfields;
+  CellSchemaDev sch;
+  memset(&sch, 0, sizeof(sch));
+  sch.nattrs = (int32_t)schema.attrs.size();
+  S.col_elem_size.assign((size_t)nf, 4); S.col_var.assign((size_t)nf, false); S.col_fixed_num.assign((size_t)nf, 1);
+  for (size_t ai = 0; ai < schema.attrs.size(); ++ai) {
+    const auto& a = schema.attrs[ai];
+    sch.a[ai].var = a.var ? 1 : 0; sch.a[ai].elem_size = (int16_t)a.elem_size; sch.a[ai].num = a.num; sch.a[ai].field = attr_to_field[ai];
+    const int f = attr_to_field[ai];
+    if (f >= 0) { S.col_elem_size[(size_t)f] = a.elem_size; S.col_var[(size_t)f] = a.var; S.col_fixed_num[(size_t)f] = a.num; }
+  }
+  // ---- device: raw bytes, offsets, row map ------------------------------------------------------------------------------
+  S.raw_cells.ensure(nbytes + 16); S.raw_off.ensure((size_t)n + 1); S.raw_row_map.ensure(std::max<size_t>(row_map.size(), 1));
+  HIP_CHECK(hipMemcpyAsync(S.raw_cells.p, cells, nbytes, hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipMemcpyAsync(S.raw_off.p, offs.data(), (size_t)(n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+  if (!row_map.empty()) HIP_CHECK(hipMemcpyAsync(S.raw_row_map.p, row_map.data(), row_map.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  S.raw_keep.ensure((size_t)n + 1); S.raw_dest.ensure((size_t)n + 1); S.raw_mark.ensure((size_t)n + 1); S.raw_mdest.ensure((size_t)n + 1); S.raw_qrow.ensure((size_t)n); S.raw_begin.ensure((size_t)n); S.raw_end.ensure((size_t)n);
+  HIP_CHECK(hipMemsetAsync(S.err.p, 0, sizeof(uint32_t), st));
+  CellColumnsDev cols;
+  memset(&cols, 0, sizeof(cols));
+  int nvar = 0;
+  for (int f = 0; f < nf; ++f) if (S.col_var[(size_t)f]) ++nvar;
+  S.raw_len.ensure((size_t)std::max(nvar, 1) * ((size_t)n + 1)); S.raw_voff.ensure((size_t)std::max(nvar, 1) * ((size_t)n + 1));
+  {
+    int v = 0;
+    for (int f = 0; f < nf; ++f) if (S.col_var[(size_t)f]) { cols.len[f] = S.raw_len.p + (size_t)v * ((size_t)n + 1); cols.off[f] = S.raw_voff.p + (size_t)v * ((size_t)n + 1); ++v; }
+  }
+  hipLaunchKernelGGL(k_cells_measure, dim3(blocks_for(n)), dim3(kBlock), 0, st, (const uint8_t*)S.raw_cells.p, (const uint64_t*)S.raw_off.p, n, sch,
+                     (const int32_t*)S.raw_row_map.p, (int64_t)row_map.size(), nf, S.raw_keep.p, S.raw_mark.p, S.raw_qrow.p, S.raw_begin.p, S.raw_end.p, cols, S.err.p);
+  HIP_CHECK(hipMemsetAsync(S.raw_keep.p + n, 0, sizeof(uint32_t), st));
+  S.excl_scan(S.raw_keep.p, S.raw_dest.p, (size_t)n + 1);
+  if (nmark > 0) { HIP_CHECK(hipMemsetAsync(S.raw_mark.p + n, 0, sizeof(uint32_t), st)); S.excl_scan(S.raw_mark.p, S.raw_mdest.p, (size_t)n + 1); }
+  std::vector<uint32_t> totals((size_t)nf, 0);
+  for (int f = 0; f < nf; ++f) if (S.col_var[(size_t)f]) {
+    HIP_CHECK(hipMemsetAsync(cols.len[f] + n, 0, sizeof(uint32_t), st));
+    S.excl_scan((const uint32_t*)cols.len[f], const_cast<uint32_t*>(cols.off[f]), (size_t)n + 1);
+  }
+  for (int f = 0; f < nf; ++f) if (S.col_var[(size_t)f]) HIP_CHECK(hipMemcpyAsync(&totals[(size_t)f], cols.off[f] + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  uint32_t eb = 0;
+  HIP_CHECK(hipMemcpyAsync(&eb, S.err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  if (eb) throw std::runtime_error("cell size mismatch while parsing the cell stream");
+  // ---- the part's columns ----------------------------------------------------------------------------------------------
+  Impl::Part part;
+  memset(&part.v, 0, sizeof(part.v));
+  part.v.ncells = nkept;
+  if (nkept == 0) {   // markers only (no cell of a queried row in this part)
+    void* d = nullptr;
+    HIP_CHECK(hipMalloc(&d, (size_t)nmark * 8));
+    part.bufs.push_back(d);
+    hipLaunchKernelGGL(k_cells_markers, dim3(blocks_for(n)), dim3(kBlock), 0, st, (const uint32_t*)S.raw_mark.p, (const uint32_t*)S.raw_mdest.p, (const int64_t*)S.raw_begin.p, n, (int64_t*)d);
+    HIP_CHECK(hipStreamSynchronize(st));
+    part.v.nmarkers = nmark; part.v.marker_begin = (const int64_t*)d;
+    part.data_bytes.assign((size_t)nf, 0);
+    S.parts.push_back(part);
+    return info;
+  }
+  auto alloc = [&](size_t bytes) -> void* { void* d = nullptr; HIP_CHECK(hipMalloc(&d, std::max<size_t>(bytes, 16))); part.bufs.push_back(d); return d; };
+  int32_t* row = (int32_t*)alloc((size_t)nkept * 4); int64_t* begin = (int64_t*)alloc((size_t)nkept * 8); int64_t* end = (int64_t*)alloc((size_t)nkept * 8);
+  part.v.row = row; part.v.begin = begin; part.v.end = end;
+  if (nmark > 0) {
+    int64_t* mk = (int64_t*)alloc((size_t)nmark * 8);
+    hipLaunchKernelGGL(k_cells_markers, dim3(blocks_for(n)), dim3(kBlock), 0, st, (const uint32_t*)S.raw_mark.p, (const uint32_t*)S.raw_mdest.p, (const int64_t*)S.raw_begin.p, n, mk);
+    part.v.nmarkers = nmark; part.v.marker_begin = mk;
+  }
+  for (int f = 0; f < nf; ++f) {
+    const size_t es = (size_t)S.col_elem_size[(size_t)f];
+    size_t bytes;
+    if (S.col_var[(size_t)f]) {
+      bytes = (size_t)totals[(size_t)f] * es;
+      uint32_t* fo = (uint32_t*)alloc(((size_t)nkept + 1) * 4);
+      cols.frag_off[f] = fo;
+      HIP_CHECK(hipMemcpyAsync(fo + nkept, &totals[(size_t)f], sizeof(uint32_t), hipMemcpyHostToDevice, st));
+      part.v.col[f].off = fo;
+    } else bytes = (size_t)nkept * (size_t)S.col_fixed_num[(size_t)f] * es;
+    cols.data[f] = (char*)alloc(bytes);
+    part.v.col[f].data = cols.data[f];
+    part.data_bytes.push_back(bytes);
+  }
+  hipLaunchKernelGGL(k_cells_scatter, dim3(blocks_for(n)), dim3(kBlock), 0, st, (const uint8_t*)S.raw_cells.p, (const uint64_t*)S.raw_off.p, n, sch, (const uint32_t*)S.raw_keep.p,
+                     (const uint32_t*)S.raw_dest.p, (const int32_t*)S.raw_qrow.p, (const int64_t*)S.raw_begin.p, (const int64_t*)S.raw_end.p, row, begin, end, cols);
+  hipLaunchKernelGGL(k_cells_order_check, dim3(blocks_for(nkept)), dim3(kBlock), 0, st, (const int32_t*)row, (const int64_t*)begin, nkept, S.err.p);
+  // first begin (the stream is sorted) and the largest END: what the FASTA window of the engine needs
+  S.span_max.ensure(2);
+  {
+    size_t bytes = 0;
+    HIP_CHECK(rocprim::reduce(nullptr, bytes, end, S.span_max.p, (int64_t)INT64_MIN, (size_t)nkept, rocprim::maximum<int64_t>(), st));
+    void* t = S.temp_storage(bytes);
+    HIP_CHECK(rocprim::reduce(t, bytes, end, S.span_max.p, (int64_t)INT64_MIN, (size_t)nkept, rocprim::maximum<int64_t>(), st));
+  }
+  S.read_back_many({{&info.min_begin, begin, sizeof(int64_t)}, {&info.max_end, S.span_max.p, sizeof(int64_t)}, {&eb, S.err.p, sizeof(uint32_t)}});
+  if (eb) { for (void* b : part.bufs) (void)hipFree(b); throw std::runtime_error("cells are not in column-major (col,row) order"); }
+  S.parts.push_back(part);
+  return info;
 }
 
 void DevicePipeline::finish_staging() {
@@ -1052,7 +1257,7 @@ void DevicePipeline::finish_staging() {
     int64_t cell_at = 0;
     for (auto& p : S.parts) {
       if (p.data_bytes[f]) HIP_CHECK(hipMemcpy(data + byte_at, p.v.col[f].data, p.data_bytes[f], hipMemcpyDeviceToDevice));
-      if (off) {
+      if (off && p.v.ncells > 0) {
         const uint64_t base_elems = byte_at / (size_t)S.col_elem_size[f];
         if (base_elems + p.data_bytes[f] / (size_t)S.col_elem_size[f] >= (1ull << 32)) throw GenomicsDBDeviceException("variable-length column exceeds 2^32 elements: stage a narrower column interval");
         hipLaunchKernelGGL(k_copy_offsets, dim3(blocks_for(p.v.ncells + 1)), dim3(kBlock), 0, S.stream, p.v.col[f].off, p.v.ncells + 1, (uint32_t)base_elems, off + cell_at);
@@ -1062,6 +1267,14 @@ void DevicePipeline::finish_staging() {
     }
     v.col[f].data = data;
     v.col[f].off = off;
+  }
+  {
+    int64_t M = 0;
+    for (auto& p : S.parts) M += p.v.nmarkers;
+    int64_t* mk = (int64_t*)alloc((size_t)M * 8);
+    int64_t at_m = 0;
+    for (auto& p : S.parts) { if (p.v.nmarkers) HIP_CHECK(hipMemcpy(mk + at_m, p.v.marker_begin, (size_t)p.v.nmarkers * 8, hipMemcpyDeviceToDevice)); at_m += p.v.nmarkers; }
+    v.nmarkers = M; v.marker_begin = mk;
   }
   HIP_CHECK(hipStreamSynchronize(S.stream));
   for (auto& p : S.parts) for (void* b : p.bufs) (void)hipFree(b);
@@ -1133,20 +1346,23 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
     S.classified = true;
   }
   // ---- cells that can reach the window -----------------------------------------------------------------------------
-  S.cwin.ensure(2);
+  S.cwin.ensure(4);
   STAGE("k_cell_window");
   hipLaunchKernelGGL(k_cell_window, dim3(1), dim3(64), 0, st, fr.begin, C, qb > INT64_MIN + S.max_span ? qb - S.max_span : INT64_MIN, qe, S.cwin.p);
-  int64_t cw[2];
-  HIP_CHECK(hipMemcpyAsync(cw, S.cwin.p, sizeof(cw), hipMemcpyDeviceToHost, st));
+  if (fr.nmarkers > 0) hipLaunchKernelGGL(k_cell_window, dim3(1), dim3(64), 0, st, fr.marker_begin, fr.nmarkers, qb, qe, S.cwin.p + 2);   // boundary markers in [qb, qe]
+  int64_t cw[4] = {0, 0, 0, 0};
+  HIP_CHECK(hipMemcpyAsync(cw, S.cwin.p, (fr.nmarkers > 0 ? 4 : 2) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
   const int64_t c_base = cw[0], c_end = cw[1];
   const int64_t CW = c_end - c_base;
   if (CW <= 0) return;
+  const int64_t m_base = cw[2], MW = std::max<int64_t>(0, cw[3] - cw[2]);
   // ---- S3 events -> boundaries -> records --------------------------------------------------------------------------
-  const int64_t NE = 2 * CW;
+  const int64_t NE = 2 * CW + 2 * MW;
   S.ev_keys.ensure(NE); S.ev_keys_sorted.ensure(NE); S.ev_delta.ensure(NE); S.ev_incl.ensure(NE); S.run_end.ensure(NE); S.run_excl.ensure(NE + 1);
   STAGE("k_event_keys");
   hipLaunchKernelGGL(k_event_keys, dim3(blocks_for(CW)), dim3(kBlock), 0, st, fr, cm, c_base, CW, qb, qe, S.ev_keys.p);
+  if (MW > 0) hipLaunchKernelGGL(k_marker_keys, dim3(blocks_for(MW)), dim3(kBlock), 0, st, fr, m_base, MW, qb, qe, S.ev_keys.p + 2 * CW);
   {
     const uint64_t span = (uint64_t)(qe - qb) + 2u;
     const int eb = span >= (1ull << 60) ? 64 : bits_for(span << 2);

@@ -25,6 +25,7 @@ FragmentView make_view(const HostFragment& fr) {
   memset(&v, 0, sizeof(v));
   v.ncells = fr.ncells();
   v.row = fr.row.data(); v.begin = fr.begin.data(); v.end = fr.end.data();
+  v.nmarkers = (int64_t)fr.marker_begin.size(); v.marker_begin = fr.marker_begin.data();
   for (size_t f = 0; f < fr.cols.size(); ++f) {
     v.col[f].data = fr.cols[f].data.data();
     v.col[f].off = fr.cols[f].var ? fr.cols[f].off.data() : nullptr;
@@ -56,10 +57,11 @@ std::string run_interval(const HostPlan& hp, const HostFragment& hf, const VidMa
   for (int64_t j = 0; j < C; ++j) stage_eff_end(fr, cm, perm.data(), j, rm_begin.data(), span.data(), &err);
   // clip the window to what the cells can reach (keeps relative positions small)
   // S3 events
-  std::vector<uint64_t> keys(2 * C);
+  std::vector<uint64_t> keys(2 * C + 2 * fr.nmarkers);
   for (int64_t c = 0; c < C; ++c) stage_event_keys(fr, cm, c, 0, qb, qe, keys.data());
+  for (int64_t m = 0; m < fr.nmarkers; ++m) stage_marker_keys(fr, m, qb, qe, keys.data() + 2 * C + 2 * m);
   std::sort(keys.begin(), keys.end());
-  const int64_t NE = 2 * C;
+  const int64_t NE = 2 * C + 2 * fr.nmarkers;
   std::vector<int64_t> incl(NE);
   std::vector<int32_t> run_end(NE), run_excl(NE);
   { int64_t acc = 0; for (int64_t i = 0; i < NE; ++i) { acc = packed_add(acc, stage_event_delta(keys[i])); incl[i] = acc; } }

@@ -275,3 +275,19 @@ def test_gt_mpi_gather_cli_produces_the_golden(gdb, tmp_path):
         assert b"scan_and_produce_Broad_GVCF" in r.stderr
     r = subprocess.run([tool, "-j", str(qf), "--print-calls"], capture_output=True, timeout=60)
     assert r.returncode != 0
+
+
+def test_row_subset_query_drops_cells_at_staging(gdb):
+    """query_row_ranges selecting samples 0 and 2 only: the device-side cell-stream parser drops the cells of sample 1 and
+    renumbers the rest; the result must be what the oracle gives for the same query"""
+    case = [c for c in CASES if c[0] == "t0_1_2_vcf_at_0"][0]
+    _, callsets, vid, ov, golden, mode = case
+    cells = helpers.cells_for(callsets, vid)
+    q, pb = helpers.query_json(callsets, vid, ov, mode)
+    q["query_row_ranges"] = [{"range_list": [{"low": 0, "high": 0}, {"low": 2, "high": 2}]}]
+    want, nrec, _ = helpers.oracle_run(q, cells, partition_begin=pb)
+    s = gdb.GenomicsDBQueryStream(query_json=q, cells=cells, buffer_capacity=1 << 20)
+    got = s.read()
+    s.close()
+    assert got == want
+    assert got != helpers.golden_text(golden) and b"HG00141" in want and b"HG01958" not in want.split(b"#CHROM")[1].split(b"\n")[0]

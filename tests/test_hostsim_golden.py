@@ -26,3 +26,18 @@ def test_hostsim_matches_reference_golden(case):
     txt, errbits = helpers.hostsim_run(q, cells)
     assert errbits == 0
     assert txt == helpers.golden_text(golden)
+
+
+def test_unqueried_rows_still_split_intervals():
+    """The reference's scan iterates ALL array rows and closes the current interval at every cell begin before it checks whether
+    the row is queried (query_variants.cc:478-507).  A query for samples 0 and 2 therefore gets the interval splits caused by
+    sample 1's cells: staging keeps those cells as position-only boundary markers."""
+    case = [c for c in CASES if c[0] == "t0_1_2_vcf_at_0"][0]
+    _, callsets, vid, ov, golden, mode = case
+    cells = helpers.cells_for(callsets, vid)
+    q, pb = helpers.query_json(callsets, vid, ov, mode)
+    q["query_row_ranges"] = [{"range_list": [{"low": 0, "high": 0}, {"low": 2, "high": 2}]}]
+    want, nrec, _ = helpers.oracle_run(q, cells, partition_begin=pb)
+    got, errbits = helpers.hostsim_run(q, cells)
+    assert errbits == 0 and got == want
+    assert b"END=12144" in want    # the split at 12145 comes from the unqueried sample's cell
