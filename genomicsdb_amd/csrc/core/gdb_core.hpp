@@ -361,6 +361,24 @@ GDB_HD bool allele_equal(const AlleleRef& a, const AlleleRef& b, const char* mre
   return true;
 }
 
+// Median fields through a device-wide sort: key = record << 33 | invalid << 32 | order-preserving value bits, value = incidence.
+// After the (stable) sort the valid values of record k are the first n_valid entries of [base[k], base[k+1]) in ascending
+// order, equal values in row order.  slot[f] = index of plan field f among the sorted fields or -1; arrays of slot s start at
+// s * stride.
+struct MedianOrder {
+  const uint64_t* keys;      // sorted
+  const uint32_t* inc;       // incidence index per sorted key
+  int64_t stride;            // T
+  int8_t slot[GDB_MAX_FIELDS];
+  int32_t enabled;
+};
+GDB_HD uint32_t gdb_orderable_bits(float v) {
+  uint32_t u = gdb_f2u(v);
+  if (u == 0x80000000u) u = 0;               // -0.0 and +0.0 compare equal: same key, row order decides
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+GDB_HD uint32_t gdb_orderable_bits(int32_t v) { return (uint32_t)v ^ 0x80000000u; }
+
 struct SiteCtx {
   FragmentView fr;
   CombinePlan pl;
@@ -371,6 +389,8 @@ struct SiteCtx {
   NameTables names;
   QueryWindow qw;
   SiteOut so;
+  // optional (records with many variant calls): per median field, the incidences of every record ordered by value
+  MedianOrder med;
 };
 
 // value of a scalar INFO-like field over the heavy list: median / sum / mean (variant_field_handler.cc:529-607).
@@ -400,6 +420,19 @@ template <class T> GDB_HD bool reduce_scalar(const SiteCtx& cx, int64_t k, int f
   if (!nvalid) return false;
   if (op == GDB_OP_SUM) { result = sum; return true; }
   if (op == GDB_OP_MEAN) { result = sum / (T)nvalid; return true; }
+  if (cx.med.enabled && cx.med.slot[f] >= 0) {
+    // sorted flavour: entry of rank nvalid/2 among the valid ones; among equal values the first in row order, like the scan below
+    const uint64_t* keys = cx.med.keys + (int64_t)cx.med.slot[f] * cx.med.stride;
+    const uint32_t* inc = cx.med.inc + (int64_t)cx.med.slot[f] * cx.med.stride;
+    const uint64_t want = keys[b + nvalid / 2];
+    int64_t lo = b, hi = b + nvalid / 2;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (keys[mid] < want) lo = mid + 1; else hi = mid; }
+    const int64_t t = inc[lo];
+    int n;
+    const T* p = cell_field<T>(cx.fr, cx.pl, f, cx.hl.cell[t], n);
+    result = p[0];
+    return true;
+  }
   // median = element of rank nvalid/2 in ascending order (std::nth_element at mid_point)
   int64_t mid = nvalid / 2;
   for (int64_t t = b; t < e; ++t) {

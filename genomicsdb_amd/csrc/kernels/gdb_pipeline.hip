@@ -238,6 +238,29 @@ __global__ void k_lut_len(const int64_t* inc_cell, const uint32_t* cflags, int64
   len[t] = GDB_CF_NALT(cflags[inc_cell[t]]) + 1;
 }
 
+// ---- sorted medians (records with many variant calls) ------------------------------------------------------------------
+// reduce_scalar's median scan is quadratic in the number of variant calls of a record: fine for ~10, ruinous for the
+// thousands that tens of thousands of samples bring.  When the interval averages more than kSortedMedianThreshold calls per
+// record every median field is ordered once by a device-wide radix sort (key layout at MedianOrder).
+constexpr int kSortedMedianThreshold = 16;
+__global__ void k_median_keys(FragmentView fr, CombinePlan pl, CellMeta cm, RecordTable rec, const uint64_t* inc_keys_sorted, const int64_t* inc_cell, int64_t T,
+                              int64_t nrows, int f, int keep_spanning, uint64_t* keys, uint32_t* idx) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const int64_t k = (int64_t)(inc_keys_sorted[t] / (uint64_t)nrows);
+  const int64_t c = inc_cell[t];
+  bool valid = field_valid(cm, c, f);
+  if (valid && !keep_spanning && (cm.cflags[c] & GDB_CF_DELETION) && rec.start[k] > fr.begin[c]) valid = false;   // inc_is_spanning
+  uint32_t bits = 0;
+  if (valid) {
+    int n;
+    if (pl.field[f].elem == GDB_ET_FLOAT) { const float v = cell_field<float>(fr, pl, f, c, n)[0]; valid = gdb_float_valid(v); bits = gdb_orderable_bits(v); }
+    else { const int32_t v = cell_field<int32_t>(fr, pl, f, c, n)[0]; valid = gdb_int_valid(v); bits = gdb_orderable_bits(v); }
+  }
+  keys[t] = ((uint64_t)k << 33) | (valid ? 0ull : 1ull << 32) | (valid ? bits : 0u);
+  idx[t] = (uint32_t)t;
+}
+
 // ---- site kernels: one thread per record -----------------------------------------------------------------------
 // Pass 0 runs the record logic ONCE: allele merge, LUTs, per-record flags - and the text of the fixed columns, formatted
 // through a capped LDS sink into a lane-private strip and parked in a fixed-stride staging slot.  The page pass then only
@@ -927,6 +950,7 @@ struct DevicePipeline::Impl {
   DevBuf<char> arena, temp;
   DevBuf<uint32_t> err; DevBuf<int32_t> counters;
   DevBuf<SiteCtx> d_sx;
+  DevBuf<uint64_t> med_keys, med_keys_sorted; DevBuf<uint32_t> med_idx, med_idx_sorted;
   // entry text table
   DevBuf<unsigned long long> type_hkeys; DevBuf<int32_t> type_hrep, type_rep; DevBuf<uint8_t> type_hid, rtype;
   DevBuf<WalkCell> walk; DevBuf<int64_t> walk_inv;
@@ -1478,7 +1502,26 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   qw.ref_bases = S.ref_len ? S.ref_bases.p : nullptr; qw.ref_begin = S.ref_begin; qw.ref_len = S.ref_len;
   NameTables nt{S.names_text.p, S.field_name_off.p, S.field_name_len.p, S.filter_name_off.p, S.filter_name_len.p, (int32_t)S.hp.filter_name_off.size()};
   PresenceCounts pc{d_fmt, d_dp, d_nr, stride};
-  SiteCtx sx{fr, pl, cm, rec, hl, pc, nt, qw, so};
+  MedianOrder med;
+  memset(&med, 0, sizeof(med));
+  for (int f = 0; f < GDB_MAX_FIELDS; ++f) med.slot[f] = -1;
+  if (T > (int64_t)kSortedMedianThreshold * P || getenv("GDBAMD_SORTED_MEDIAN")) {
+    std::vector<std::pair<int, int>> fields;   // (plan field, keep_spanning)
+    for (int i = 0; i < pl.n_info; ++i) if (pl.field[pl.info_field[i]].combine_op == GDB_OP_MEDIAN) fields.push_back(std::make_pair(pl.info_field[i], 0));
+    if (pl.qual_combine_op == GDB_OP_MEDIAN && pl.f_QUAL >= 0) fields.push_back(std::make_pair(pl.f_QUAL, 1));
+    if (!fields.empty() && T > 0 && P < (1ll << 31)) {
+      S.med_keys.ensure((size_t)T); S.med_idx.ensure((size_t)T);
+      S.med_keys_sorted.ensure(fields.size() * (size_t)T); S.med_idx_sorted.ensure(fields.size() * (size_t)T);
+      for (size_t s = 0; s < fields.size(); ++s) {
+        hipLaunchKernelGGL(k_median_keys, dim3(blocks_for(T)), dim3(kBlock), 0, st, fr, pl, cm, rec, (const uint64_t*)S.inc_keys_sorted.p, (const int64_t*)S.inc_vals_sorted.p, T,
+                           (int64_t)N, fields[s].first, fields[s].second, S.med_keys.p, S.med_idx.p);
+        S.sort_pairs(S.med_keys.p, S.med_keys_sorted.p + s * (size_t)T, S.med_idx.p, S.med_idx_sorted.p + s * (size_t)T, (size_t)T, std::min(64, 33 + bits_for((uint64_t)P)));
+        med.slot[fields[s].first] = (int8_t)s;
+      }
+      med.keys = S.med_keys_sorted.p; med.inc = S.med_idx_sorted.p; med.stride = T; med.enabled = 1;
+    }
+  }
+  SiteCtx sx{fr, pl, cm, rec, hl, pc, nt, qw, so, med};
   S.d_sx.ensure(1);
   HIP_CHECK(hipMemcpyAsync(S.d_sx.p, &sx, sizeof(SiteCtx), hipMemcpyHostToDevice, st));   // (sx outlives the copy: the function synchronises before it returns)
   STAGE("k_site_size");

@@ -291,3 +291,24 @@ def test_row_subset_query_drops_cells_at_staging(gdb):
     s.close()
     assert got == want
     assert got != helpers.golden_text(golden) and b"HG00141" in want and b"HG01958" not in want.split(b"#CHROM")[1].split(b"\n")[0]
+
+
+def test_sorted_median_path_gives_the_same_bytes(gdb, tmp_path, monkeypatch):
+    """intervals that average more than 16 variant calls per record order their median fields with a device-wide sort instead
+    of the per-record quadratic scan; GDBAMD_SORTED_MEDIAN forces that path on small inputs"""
+    monkeypatch.setenv("GDBAMD_SORTED_MEDIAN", "1")
+    for name in ("info_ops0", "t0_1_2_vcf_at_0", "min_PL_spanning_deletion_vcf", "t6_7_8_vcf_at_0"):
+        _, callsets, vid, ov, golden, mode = [c for c in CASES if c[0] == name][0]
+        cells = helpers.cells_for(callsets, vid)
+        q, pb = helpers.query_json(callsets, vid, ov, mode)
+        s = gdb.GenomicsDBQueryStream(query_json=q, cells=cells, buffer_capacity=1 << 16)
+        got = s.read()
+        s.close()
+        assert got == helpers.golden_text(golden), name
+    from genomicsdb_amd import synth
+    N, B, L = 400, 10_000_000, 2500
+    eng, q, cells = _c2_engine(gdb, tmp_path, N, B, L)
+    want, nrec, _ = helpers.oracle_run_synth(q, cells, synth.SEED, with_header=False)
+    got, st = eng.run_interval(B, B + L - 1, arena_bytes=4 << 20)
+    assert st.num_records == nrec and got == want
+    eng.close()
