@@ -108,12 +108,6 @@ struct LdsCapSink {  // counts every byte, stores the first `cap` of them in LDS
   __device__ __forceinline__ void put(char c) { if (n < cap) p[n] = c; ++n; }
   __device__ __forceinline__ void write(const char* s, int len) { for (int i = 0; i < len; ++i) put(s[i]); }
 };
-struct LdsSink {  // same as ByteSink but the cursor is an LDS (address space 3) pointer: ds_write_b8 instead of flat stores
-  gdb_lds_char* p;
-  __device__ __forceinline__ explicit LdsSink(gdb_lds_char* q) : p(q) {}
-  __device__ __forceinline__ void put(char c) { *p++ = c; }
-  __device__ __forceinline__ void write(const char* s, int len) { for (int i = 0; i < len; ++i) *p++ = s[i]; }
-};
 #endif
 
 // ---- small helpers -----------------------------------------------------------------------------------

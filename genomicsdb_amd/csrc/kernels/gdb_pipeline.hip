@@ -310,23 +310,11 @@ __global__ void k_site_write(const SiteCtx* __restrict__ sxp, const char* __rest
 }
 
 // ---- sample columns -------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_reduce_sum(uint32_t v) {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
-}
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
-  for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(v, off, 64); if (lane >= off) v += t; }
-  return v;
-}
-
 // Per-interval context in constant memory: plan, column pointers, per-cell metadata pointers.  Uniform accesses to it are
 // scalar loads through the scalar cache (a by-reference argument would turn each of them into a vector memory instruction).
 __constant__ EntryCtx c_ex;
 
 // the instantiations are kept out of line: one copy each instead of one per call site
-__device__ __noinline__ uint32_t entry_length(RecordInfo ri, int64_t c, uint32_t* e) {
-  return (uint32_t)entry_emit(c_ex, ri, c, CountSink(), e).n;
-}
 __device__ __noinline__ void entry_store(RecordInfo ri, int64_t c, char* dst, uint32_t* e) {
   (void)entry_emit(c_ex, ri, c, ByteSink(dst), e);
 }
@@ -395,7 +383,7 @@ __global__ void k_type_assign(const unsigned long long* hkeys, const int32_t* hr
   const int lane = threadIdx.x;
   uint32_t cnt = 0;
   for (int j = 0; j < per; ++j) cnt += hkeys[lane * per + j] != kEmptyKey;
-  const uint32_t incl = wave_inclusive_scan(cnt, lane);
+  const uint32_t incl = wave_inclusive_scan_dpp(cnt);
   int n = (int)(incl - cnt);
   for (int j = 0; j < per; ++j) {
     const int h = lane * per + j;
@@ -1023,7 +1011,10 @@ struct DevicePipeline::Impl {
     return v;
   }
   // records [k0, k0+n) in (type, position) order -> order[]
+  int64_t order_k0 = -1, order_n = -1;   // what `order` currently holds
   void order_by_type(int64_t k0, int64_t n) {
+    if (k0 == order_k0 && n == order_n) return;   // a page that is the whole interval reuses the sizing pass's order
+    order_k0 = k0; order_n = n;
     // Types are grouped inside blocks of consecutive records, not over the whole range: a wavefront still walks ~100
     // same-type records, but the page stores and matrix reads in flight stay within a few tens of MB (TLB reach, DRAM pages).
     const int block_log2 = order_block_log2();
@@ -1326,6 +1317,7 @@ void DevicePipeline::set_reference_window(int64_t begin, const std::string& base
 void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   Impl& S = *m_;
   S.iv = Impl::IntervalState();
+  S.order_k0 = S.order_n = -1;
   HIP_CHECK(hipSetDevice(S.device));
   hipStream_t st = S.stream;
   const CombinePlan& pl = S.hp.plan;
