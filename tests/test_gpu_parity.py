@@ -312,3 +312,46 @@ def test_sorted_median_path_gives_the_same_bytes(gdb, tmp_path, monkeypatch):
     got, st = eng.run_interval(B, B + L - 1, arena_bytes=4 << 20)
     assert st.num_records == nrec and got == want
     eng.close()
+
+
+@pytest.mark.parametrize("n_samples,seed", [(1, 11), (2, 12), (63, 13), (64, 14), (65, 15), (127, 16), (128, 17), (129, 18), (257, 19), (640, 20)])
+def test_sample_counts_around_the_wavefront_width(gdb, tmp_path, n_samples, seed):
+    """the sample axis is cut into chunks of 64 (one wavefront each): counts just below / at / above the multiples, other
+    generator seeds, and a query window that starts and ends inside cells"""
+    from genomicsdb_amd import synth
+    B, L = 10_000_000, 1800 if n_samples < 300 else 900
+    g = synth.Generator(n_samples, B, L + 2500, seed=seed)
+    cells, nc = g.chunk_bytes(B + L + 2500)
+    q = helpers.synth_query(tmp_path, n_samples, B + 333, B + 333 + L - 1)
+    want, nrec, _ = helpers.oracle_run_synth(q, cells, seed, with_header=False)
+    eng = gdb.CombineEngine(q)
+    eng.stage_cells(cells)
+    eng.set_reference(B, synth.reference(B, L + 4096, seed=seed))
+    got, st = eng.run_interval(B + 333, B + 333 + L - 1, arena_bytes=256 << 10)
+    assert st.num_records == nrec
+    assert got == want
+    eng.close()
+
+
+@pytest.mark.parametrize("options", [
+    {"sites_only_query": True},
+    {"produce_GT_field": True},
+    {"produce_GT_field": True, "produce_GT_with_min_PL_value_for_spanning_deletions": True},
+    {"produce_FILTER_field": True, "max_diploid_alt_alleles_that_can_be_genotyped": 2},
+    {"combined_vcf_records_buffer_size_limit": 4096, "produce_GT_field": True},
+], ids=["sites_only", "GT", "GT_minPL", "FILTER_maxalt2", "small_buffer_GT"])
+def test_query_options_on_synthetic_input(gdb, tmp_path, options):
+    """the query-JSON switches of BroadCombinedGVCFOperator on an input with deletions, insertions and spanning calls"""
+    from genomicsdb_amd import synth
+    N, B, L = 120, 10_000_000, 3000
+    g = synth.Generator(N, B, L + 2500, seed=77)
+    cells, nc = g.chunk_bytes(B + L + 2500)
+    q = helpers.synth_query(tmp_path, N, B + 100, B + 100 + L - 1)
+    q.update(options)
+    want, nrec, _ = helpers.oracle_run_synth(q, cells, 77, with_header=False)
+    eng = gdb.CombineEngine(q)
+    eng.stage_cells(cells)
+    eng.set_reference(B, synth.reference(B, L + 4096, seed=77))
+    got, st = eng.run_interval(B + 100, B + 100 + L - 1, arena_bytes=1 << 20)
+    assert st.num_records == nrec and got == want
+    eng.close()
