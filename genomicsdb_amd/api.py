@@ -124,6 +124,13 @@ class CombineEngine:
     def set_reference(self, begin, bases):
         _check(_lib.lib().gdbamd_engine_set_reference(self._e, begin, bases, len(bases)) == 0, "set_reference")
 
+    def save_fragment(self, path):
+        """the staged fragment as a columnar file (file -> HBM copies on load, no parsing)"""
+        _check(_lib.lib().gdbamd_engine_save_fragment(self._e, str(path).encode()) == 0, "save_fragment")
+
+    def load_fragment(self, path):
+        _check(_lib.lib().gdbamd_engine_load_fragment(self._e, str(path).encode()) == 0, "load_fragment")
+
     def run_interval(self, begin=0, end=INT64_MAX - 1, arena_bytes=1 << 30, fetch=True, host_cap=None):
         L = _lib.lib()
         st = _lib.IntervalStats()

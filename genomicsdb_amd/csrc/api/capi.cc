@@ -142,6 +142,13 @@ int gdbamd_engine_run_interval(void* e, int64_t qb, int64_t qe, uint64_t arena_b
   }, 1);
 }
 
+int gdbamd_engine_save_fragment(void* engine, const char* path) {
+  try { ((EngineHandle*)engine)->eng->save_fragment(path); return 0; } catch (const std::exception& e) { g_last_error = e.what(); return -1; }
+}
+int gdbamd_engine_load_fragment(void* engine, const char* path) {
+  try { ((EngineHandle*)engine)->eng->load_fragment(path); return 0; } catch (const std::exception& e) { g_last_error = e.what(); return -1; }
+}
+
 int gdbamd_column_partition(const char* loader_json_text, int rank, int64_t* begin, int64_t* end) {
   try {
     GenomicsDBImportConfig cfg;

@@ -42,6 +42,20 @@ void CombineEngine::stage_cells_end() {
   m_pipe->finish_staging();
 }
 
+void CombineEngine::save_fragment(const std::string& path) {
+  FragmentFileMeta meta;
+  meta.reference_cell_bytes = reference_cell_bytes; meta.min_begin = min_begin; meta.max_end = max_end; meta.ncells = num_cells;
+  m_pipe->save_fragment(path, meta);
+}
+void CombineEngine::load_fragment(const std::string& path) {
+  // the file holds QUERY row indices: it only fits a query over all rows of the array in callset order
+  const VariantQueryConfig& qc = m_qc;
+  for (uint64_t q = 0; q < qc.get_num_rows_to_query(); ++q)
+    if (qc.get_array_row_idx_for_query_row_idx(q) != (int64_t)q) throw GenomicsDBConfigException("a columnar fragment file serves queries over all rows only");
+  const FragmentFileMeta meta = m_pipe->load_fragment(path);
+  reference_cell_bytes = meta.reference_cell_bytes; min_begin = meta.min_begin; max_end = meta.max_end; num_cells = meta.ncells; has_cells = num_cells > 0;
+}
+
 void CombineEngine::stage_reference_for(int64_t qb, int64_t qe) {
   if (!m_ref.is_initialized() || !has_cells) return;
   int64_t b = std::max(qb, min_begin), e = std::min(qe, max_end);
@@ -70,9 +84,19 @@ GenomicsDBBCFGenerator::GenomicsDBBCFGenerator(const std::string& loader_config_
   }
   // array storage of this build: <workspace>/<array>/cells.bin = begin-cells in the reference binary-cell layout
   // (the Intel TileDB fork's on-disk format is not available: SURVEY 8(f) rank 1)
-  std::string path = qc.get_workspace(my_rank) + "/" + qc.get_array_name(my_rank) + "/cells.bin";
-  std::vector<uint8_t> cells = read_binary_file(path);
-  m_engine->stage_cells(cells.data(), cells.size());
+  const std::string dir = qc.get_workspace(my_rank) + "/" + qc.get_array_name(my_rank);
+  bool loaded = false;
+  {  // columnar fragment first: file -> HBM copies, no parsing
+    const std::string frag = dir + "/fragment.gdbamd";
+    if (FILE* fp = fopen(frag.c_str(), "rb")) {
+      fclose(fp);
+      try { m_engine->load_fragment(frag); loaded = true; } catch (const GenomicsDBConfigException&) { loaded = false; }   // row subset: take the cells
+    }
+  }
+  if (!loaded) {
+    std::vector<uint8_t> cells = read_binary_file(dir + "/cells.bin");
+    m_engine->stage_cells(cells.data(), cells.size());
+  }
   common_init(produce_header_only);
 }
 

@@ -28,6 +28,9 @@ class CombineEngine {
   void stage_cells_begin();
   void stage_cells_append(const uint8_t* cells, uint64_t nbytes);
   void stage_cells_end();
+  // the staged fragment as a columnar file (<workspace>/<array>/fragment.gdbamd is what the query stream opens first)
+  void save_fragment(const std::string& path);
+  void load_fragment(const std::string& path);
   int64_t num_cells = 0;
   void stage_reference_for(int64_t qb, int64_t qe);
   uint64_t reference_cell_bytes = 0;

@@ -38,6 +38,9 @@ struct IntervalStats {
   int64_t text_pool_bytes = 0;
 };
 
+// what the engine needs to know about a staged fragment besides the columns
+struct FragmentFileMeta { uint64_t reference_cell_bytes = 0; int64_t min_begin = INT64_MAX, max_end = 0, ncells = 0; };
+
 // page consumer: `dev_ptr` points to `nbytes` of VCF text in HBM, valid until the callback returns
 typedef void (*PageCallback)(void* user, const char* dev_ptr, uint64_t nbytes);
 
@@ -58,6 +61,9 @@ class DevicePipeline {
   CellStreamInfo append_cells(const uint8_t* cells, uint64_t nbytes, const VariantArraySchemaLite& schema, const std::vector<int>& attr_to_field,
                               const std::vector<int32_t>& row_map);
   void finish_staging();
+  // the staged fragment as a columnar file / a columnar file straight into HBM (format: gdb_pipeline.hip, 'columnar fragment file')
+  void save_fragment(const std::string& path, const FragmentFileMeta& meta);
+  FragmentFileMeta load_fragment(const std::string& path);
   // adopt a fragment that already lives in HBM (e.g. torch tensors); the caller keeps ownership
   void adopt_fragment(const FragmentView& device_view);
   // reference bases for TileDB columns [begin, begin + bases.size())

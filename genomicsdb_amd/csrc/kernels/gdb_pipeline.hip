@@ -1299,6 +1299,125 @@ void DevicePipeline::finish_staging() {
   S.classified = false;
 }
 
+// ---- columnar fragment file: the staged fragment as it lies in HBM, so that opening an array is file -> HBM copies ------
+// (the build's own fragment format; the Intel TileDB fork's on-disk format is not available.)
+// Layout, little endian: "GDBAMDF1", u32 version, u32 nfields, i64 ncells, i64 nmarkers, i32 num_rows, i32 pad,
+// u64 reference_cell_bytes, i64 min_begin, i64 max_end; per field: u8 var, u8 elem_size, u16 name_len, i32 fixed_num,
+// u64 data_bytes, name; then, each 64-byte aligned: row[], begin[], end[], marker_begin[], per field off[] (var only), data[].
+namespace {
+const char kFragMagic[8] = {'G', 'D', 'B', 'A', 'M', 'D', 'F', '1'};
+struct FragFieldHdr { uint8_t var, elem_size; uint16_t name_len; int32_t fixed_num; uint64_t data_bytes; };
+void put_bytes(std::vector<uint8_t>& o, const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; o.insert(o.end(), b, b + n); }
+void pad64(FILE* f, uint64_t& at) { static const char z[64] = {0}; const size_t r = (size_t)((64 - (at & 63)) & 63); if (r) { fwrite(z, 1, r, f); at += r; } }
+}  // namespace
+
+void DevicePipeline::save_fragment(const std::string& path, const FragmentFileMeta& meta) {
+  Impl& S = *m_;
+  HIP_CHECK(hipSetDevice(S.device));
+  const FragmentView& fr = S.fr;
+  const int nf = S.hp.plan.nfields;
+  if ((int)S.col_elem_size.size() < nf) throw GenomicsDBDeviceException("save_fragment: no fragment staged from a cell stream");
+  const int64_t C = fr.ncells;
+  std::vector<uint64_t> data_bytes((size_t)nf, 0);
+  for (int f = 0; f < nf; ++f) {
+    if (S.col_var[(size_t)f]) {
+      uint32_t last = 0;
+      if (C > 0) HIP_CHECK(hipMemcpy(&last, fr.col[f].off + C, sizeof(uint32_t), hipMemcpyDeviceToHost));
+      data_bytes[(size_t)f] = (uint64_t)last * (uint64_t)S.col_elem_size[(size_t)f];
+    } else data_bytes[(size_t)f] = (uint64_t)C * (uint64_t)S.col_fixed_num[(size_t)f] * (uint64_t)S.col_elem_size[(size_t)f];
+  }
+  std::vector<uint8_t> hdr;
+  put_bytes(hdr, kFragMagic, 8);
+  const uint32_t version = 1, nfields = (uint32_t)nf;
+  const int32_t num_rows = S.hp.plan.num_query_rows, pad = 0;
+  put_bytes(hdr, &version, 4); put_bytes(hdr, &nfields, 4); put_bytes(hdr, &C, 8); put_bytes(hdr, &fr.nmarkers, 8); put_bytes(hdr, &num_rows, 4); put_bytes(hdr, &pad, 4);
+  put_bytes(hdr, &meta.reference_cell_bytes, 8); put_bytes(hdr, &meta.min_begin, 8); put_bytes(hdr, &meta.max_end, 8);
+  for (int f = 0; f < nf; ++f) {
+    const std::string& name = S.hp.field_names[(size_t)f];
+    FragFieldHdr h{(uint8_t)(S.col_var[(size_t)f] ? 1 : 0), (uint8_t)S.col_elem_size[(size_t)f], (uint16_t)name.size(), (int32_t)S.col_fixed_num[(size_t)f], data_bytes[(size_t)f]};
+    put_bytes(hdr, &h, sizeof(h)); put_bytes(hdr, name.data(), name.size());
+  }
+  FILE* fp = fopen(path.c_str(), "wb");
+  if (!fp) throw std::runtime_error("cannot create " + path);
+  uint64_t at = 0;
+  fwrite(hdr.data(), 1, hdr.size(), fp); at += hdr.size();
+  std::vector<uint8_t> host;
+  auto dump = [&](const void* dev, uint64_t bytes) {
+    pad64(fp, at);
+    host.resize((size_t)bytes);
+    if (bytes) { HIP_CHECK(hipMemcpy(host.data(), dev, (size_t)bytes, hipMemcpyDeviceToHost)); if (fwrite(host.data(), 1, (size_t)bytes, fp) != bytes) { fclose(fp); throw std::runtime_error("short write to " + path); } }
+    at += bytes;
+  };
+  dump(fr.row, (uint64_t)C * 4); dump(fr.begin, (uint64_t)C * 8); dump(fr.end, (uint64_t)C * 8); dump(fr.marker_begin, (uint64_t)fr.nmarkers * 8);
+  for (int f = 0; f < nf; ++f) {
+    if (S.col_var[(size_t)f]) dump(fr.col[f].off, (uint64_t)(C + 1) * 4);
+    dump(fr.col[f].data, data_bytes[(size_t)f]);
+  }
+  fclose(fp);
+}
+
+FragmentFileMeta DevicePipeline::load_fragment(const std::string& path) {
+  Impl& S = *m_;
+  HIP_CHECK(hipSetDevice(S.device));
+  FILE* fp = fopen(path.c_str(), "rb");
+  if (!fp) throw std::runtime_error("cannot open " + path);
+  auto fail = [&](const std::string& why) { fclose(fp); throw std::runtime_error(path + ": " + why); };
+  uint64_t at = 0;
+  auto rd = [&](void* p, size_t n) { if (fread(p, 1, n, fp) != n) fail("truncated fragment file"); at += n; };
+  char magic[8];
+  rd(magic, 8);
+  if (memcmp(magic, kFragMagic, 8) != 0) fail("not a genomicsdb_amd fragment file");
+  uint32_t version, nfields; int64_t C, M; int32_t num_rows, pad;
+  FragmentFileMeta meta;
+  rd(&version, 4); rd(&nfields, 4); rd(&C, 8); rd(&M, 8); rd(&num_rows, 4); rd(&pad, 4);
+  rd(&meta.reference_cell_bytes, 8); rd(&meta.min_begin, 8); rd(&meta.max_end, 8);
+  if (version != 1) fail("unsupported fragment file version");
+  if (num_rows != S.hp.plan.num_query_rows) fail("fragment file was written for another set of query rows");
+  struct FileField { FragFieldHdr h; std::string name; };
+  std::vector<FileField> ff(nfields);
+  for (auto& x : ff) { rd(&x.h, sizeof(x.h)); x.name.resize(x.h.name_len); if (x.h.name_len) rd(&x.name[0], x.h.name_len); }
+  const int nf = S.hp.plan.nfields;
+  std::vector<int> file_to_plan(nfields, -1);
+  for (int f = 0; f < nf; ++f) {
+    int found = -1;
+    for (uint32_t i = 0; i < nfields; ++i) if (ff[i].name == S.hp.field_names[(size_t)f]) found = (int)i;
+    if (found < 0) fail("attribute " + S.hp.field_names[(size_t)f] + " of the query is not in the fragment file");
+    file_to_plan[(size_t)found] = f;
+  }
+  S.free_owned();
+  FragmentView v;
+  memset(&v, 0, sizeof(v));
+  v.ncells = C; v.nmarkers = M;
+  meta.ncells = C;
+  std::vector<uint8_t> host;
+  auto skip_pad = [&]() { const size_t r = (size_t)((64 - (at & 63)) & 63); if (r) { if (fseek(fp, (long)r, SEEK_CUR) != 0) fail("truncated fragment file"); at += r; } };
+  auto load = [&](uint64_t bytes, bool keep) -> void* {
+    skip_pad();
+    void* d = nullptr;
+    if (keep) { HIP_CHECK(hipMalloc(&d, std::max<size_t>((size_t)bytes, 16))); S.owned.push_back(d); }
+    if (bytes) {
+      if (keep) { host.resize((size_t)bytes); rd(host.data(), (size_t)bytes); HIP_CHECK(hipMemcpy(d, host.data(), (size_t)bytes, hipMemcpyHostToDevice)); }
+      else { if (fseek(fp, (long)bytes, SEEK_CUR) != 0) fail("truncated fragment file"); at += bytes; }
+    }
+    return d;
+  };
+  v.row = (const int32_t*)load((uint64_t)C * 4, true); v.begin = (const int64_t*)load((uint64_t)C * 8, true); v.end = (const int64_t*)load((uint64_t)C * 8, true);
+  v.marker_begin = (const int64_t*)load((uint64_t)M * 8, true);
+  S.col_elem_size.assign((size_t)nf, 4); S.col_var.assign((size_t)nf, false); S.col_fixed_num.assign((size_t)nf, 1);
+  for (uint32_t i = 0; i < nfields; ++i) {
+    const int f = file_to_plan[i];
+    const bool keep = f >= 0;
+    const uint32_t* off = ff[i].h.var ? (const uint32_t*)load((uint64_t)(C + 1) * 4, keep) : nullptr;
+    const void* data = load(ff[i].h.data_bytes, keep);
+    if (keep) { v.col[f].off = off; v.col[f].data = data; S.col_elem_size[(size_t)f] = ff[i].h.elem_size; S.col_var[(size_t)f] = ff[i].h.var != 0; S.col_fixed_num[(size_t)f] = ff[i].h.fixed_num; }
+  }
+  fclose(fp);
+  S.fr = v;
+  S.owns_fragment = true;
+  S.classified = false;
+  return meta;
+}
+
 void DevicePipeline::adopt_fragment(const FragmentView& v) {
   m_->free_owned();
   m_->fr = v;

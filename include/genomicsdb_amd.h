@@ -70,6 +70,11 @@ int gdbamd_engine_stage_cells_end(void* engine);
 /* adopt a columnar fragment that already lives in HBM: row = QUERY row idx, begin/end = columns, cols[num_fields] */
 int gdbamd_engine_adopt_device_fragment(void* engine, int64_t ncells, const int32_t* row, const int64_t* begin, const int64_t* end,
                                         const gdbamd_device_column* cols, int ncols, uint64_t reference_cell_bytes);
+/* the staged fragment as a columnar file, and back: file -> HBM copies without parsing.  gdb_mi355_init opens
+ * <workspace>/<array>/fragment.gdbamd when present (else cells.bin).  This is the build's own format (the
+ * Intel TileDB fork's on-disk format of the reference, variant_storage_manager.cc:61-153, is not available). */
+int gdbamd_engine_save_fragment(void* engine, const char* path);
+int gdbamd_engine_load_fragment(void* engine, const char* path);
 /* what is staged: #begin-cells and the sum of their reference binary-cell sizes ("bytes_in" of the byte accounting) */
 int gdbamd_engine_staged_info(void* engine, int64_t* ncells, uint64_t* reference_cell_bytes);
 /* reference bases for TileDB columns [begin, begin+len) (host pointer) */

@@ -355,3 +355,38 @@ def test_query_options_on_synthetic_input(gdb, tmp_path, options):
     got, st = eng.run_interval(B + 100, B + 100 + L - 1, arena_bytes=1 << 20)
     assert st.num_records == nrec and got == want
     eng.close()
+
+
+def test_columnar_fragment_file_round_trip(gdb, tmp_path):
+    """stage from the cell stream, save the fragment as it lies in HBM, open it again (file -> HBM copies, no parsing) in a
+    new engine and through the query stream / command line: identical bytes"""
+    import json
+    import os
+    import subprocess
+    case = [c for c in CASES if c[0] == "t6_7_8_vcf_at_0"][0]
+    _, callsets, vid, ov, golden, mode = case
+    cells = helpers.cells_for(callsets, vid)
+    q, _ = helpers.query_json(callsets, vid, ov, mode)
+    ws = tmp_path / "ws"
+    (ws / "arr").mkdir(parents=True)
+    e1 = gdb.CombineEngine(q)
+    e1.stage_cells(cells)
+    body1, st1 = e1.run_interval(0, 10**9, arena_bytes=1 << 20)
+    e1.save_fragment(ws / "arr" / "fragment.gdbamd")
+    e1.close()
+    e2 = gdb.CombineEngine(q)
+    e2.load_fragment(ws / "arr" / "fragment.gdbamd")
+    assert e2.staged_info()[0] == st1.num_cells
+    body2, st2 = e2.run_interval(0, 10**9, arena_bytes=1 << 20)
+    e2.close()
+    assert body2 == body1 and st2.num_records == st1.num_records
+    # the query stream / gt_mpi_gather open fragment.gdbamd when it is there (no cells.bin in this directory)
+    q2 = dict(q)
+    q2["workspace"] = str(ws)
+    q2["array"] = "arr"
+    qf = tmp_path / "query.json"
+    qf.write_text(json.dumps(q2))
+    tool = os.path.join(helpers.ROOT, "genomicsdb_amd", "gt_mpi_gather")
+    r = subprocess.run([tool, "-j", str(qf), "--produce-Broad-GVCF"], capture_output=True, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout == helpers.golden_text(golden)
