@@ -3,7 +3,7 @@
 
 Workload (BASELINE.json configs[1], "c2"): 1 000 synthetic-gVCF samples x 10 Mb column interval (generator of
 SURVEY.md 8(d), genomicsdb_amd/synth), staged once in HBM as a columnar fragment.  A STEP is one pass of the hot path
-over one batch = one --window-bp wide column window of that array (sweep -> site merge -> sizing -> bit-exact VCF text
+over one batch = one --window-bp wide column window (default 1 Mb: the batch is sized for the 288 GB of HBM) of that array (sweep -> site merge -> sizing -> bit-exact VCF text
 written into HBM pages); successive steps take successive windows.  `value` = output records (positions) per second
 with the input resident in HBM; nothing is copied to the host inside the timed region.
 
@@ -36,8 +36,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--samples", type=int, default=1000)
     ap.add_argument("--interval-bp", type=int, default=10_000_000)
-    ap.add_argument("--window-bp", type=int, default=200_000, help="columns per step (one batch)")
-    ap.add_argument("--arena-mb", type=int, default=16384, help="HBM page for the output text")
+    ap.add_argument("--window-bp", type=int, default=1_000_000, help="columns per step (one batch); 1 Mb = 44.6 GB of VCF text at 1 000 samples")
+    ap.add_argument("--arena-mb", type=int, default=49152, help="HBM page for the output text (one page per window at the defaults)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-bp", type=int, default=12000, help="columns of the bounded CPU-baseline sample (~15 s of oracle time)")
     args = ap.parse_args()

@@ -373,6 +373,18 @@ GDB_HD uint32_t gdb_orderable_bits(float v) {
 }
 GDB_HD uint32_t gdb_orderable_bits(int32_t v) { return (uint32_t)v ^ 0x80000000u; }
 
+// Medians of the few records with very many variant calls (the first record of a partition: every sample has a cell starting
+// there), computed by one workgroup each before the site pass; index[k] = row of the table or -1; tables of field slot s
+// start at s * stride.
+struct BigMedians {
+  const int32_t* index;      // [P]
+  const uint32_t* value;     // raw 32-bit pattern of the median element
+  const uint8_t* ok;         // 0: no valid value in the record
+  int64_t stride;
+  int8_t slot[GDB_MAX_FIELDS];
+  int32_t enabled;
+};
+
 struct SiteCtx {
   FragmentView fr;
   CombinePlan pl;
@@ -385,6 +397,7 @@ struct SiteCtx {
   SiteOut so;
   // optional (records with many variant calls): per median field, the incidences of every record ordered by value
   MedianOrder med;
+  BigMedians big;
 };
 
 // value of a scalar INFO-like field over the heavy list: median / sum / mean (variant_field_handler.cc:529-607).
@@ -395,6 +408,14 @@ GDB_HD bool inc_is_spanning(const SiteCtx& cx, int64_t t, int64_t s_k) {
 }
 template <class T> GDB_HD bool reduce_scalar(const SiteCtx& cx, int64_t k, int f, int op, bool keep_spanning, T& result) {
   const int64_t b = cx.hl.base[k], e = cx.hl.base[k + 1];
+  if (op == GDB_OP_MEDIAN && cx.big.enabled && cx.big.slot[f] >= 0 && cx.big.index[k] >= 0) {
+    const int64_t at = (int64_t)cx.big.slot[f] * cx.big.stride + cx.big.index[k];
+    if (!cx.big.ok[at]) return false;
+    union { uint32_t u; T v; } x;
+    x.u = cx.big.value[at];
+    result = x.v;
+    return true;
+  }
   const int64_t s_k = cx.rec.start[k];
   const bool is_float = cx.pl.field[f].elem == GDB_ET_FLOAT;
   int64_t nvalid = 0;

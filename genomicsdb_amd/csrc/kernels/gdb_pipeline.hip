@@ -261,6 +261,65 @@ __global__ void k_median_keys(FragmentView fr, CombinePlan pl, CellMeta cm, Reco
   idx[t] = (uint32_t)t;
 }
 
+// ---- medians of records with very many variant calls: one workgroup per (big record, median field) ------------------------
+constexpr int kBigRecord = 48;          // variant calls from which a record counts as big
+constexpr int kBigCapacity = 4096;      // values a workgroup holds in LDS; larger records keep the per-thread scan
+constexpr int kMaxBigRecords = 4096;
+__global__ void k_big_records(const int64_t* hbase, int64_t P, int32_t* big_index, int32_t* big_list, int32_t* counter) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= P) return;
+  const int64_t n = hbase[k + 1] - hbase[k];
+  int32_t idx = -1;
+  if (n > kBigRecord && n <= kBigCapacity) { idx = atomicAdd(counter, 1); if (idx < kMaxBigRecords) big_list[idx] = (int32_t)k; else idx = -1; }
+  big_index[k] = idx;
+}
+// The rule of reduce_scalar: the median is the value v with #less <= n_valid/2 < #less-or-equal; among equal values the
+// first call in row order supplies the bits.
+__global__ void __launch_bounds__(kBlock) k_big_medians(FragmentView fr, CombinePlan pl, CellMeta cm, RecordTable rec, HeavyLists hl, const int32_t* big_list,
+                                                        const int32_t* counter, int f, int slot, int keep_spanning, int64_t stride, uint32_t* value, uint8_t* ok) {
+  __shared__ uint32_t s_bits[kBigCapacity];     // order-preserving keys of the valid values
+  __shared__ uint32_t s_raw[kBigCapacity];      // their raw bit patterns, in row order
+  __shared__ int32_t s_n, s_best;
+  const int count = min(*counter, kMaxBigRecords);
+  for (int bi = blockIdx.x; bi < count; bi += gridDim.x) {   // uniform
+    const int64_t k = big_list[bi];
+    const int64_t b = hl.base[k], e = hl.base[k + 1];
+    const int64_t s_k = rec.start[k];
+    if (threadIdx.x == 0) { s_n = 0; s_best = 0x7FFFFFFF; }
+    __syncthreads();
+    // gather the valid values in row order: one thread walks the (sorted) incidences - a few hundred to a few thousand
+    if (threadIdx.x == 0) {
+      int n = 0;
+      for (int64_t t = b; t < e; ++t) {
+        const int64_t c = hl.cell[t];
+        if (!keep_spanning && (cm.cflags[c] & GDB_CF_DELETION) && s_k > fr.begin[c]) continue;
+        if (!field_valid(cm, c, f)) continue;
+        int nn;
+        if (pl.field[f].elem == GDB_ET_FLOAT) { const float v = cell_field<float>(fr, pl, f, c, nn)[0]; if (!gdb_float_valid(v)) continue; s_bits[n] = gdb_orderable_bits(v); s_raw[n] = gdb_f2u(v); }
+        else { const int32_t v = cell_field<int32_t>(fr, pl, f, c, nn)[0]; if (!gdb_int_valid(v)) continue; s_bits[n] = gdb_orderable_bits(v); s_raw[n] = (uint32_t)v; }
+        ++n;
+      }
+      s_n = n;
+    }
+    __syncthreads();
+    const int n = s_n;
+    const int mid = n / 2;
+    for (int i = threadIdx.x; i < n; i += kBlock) {
+      const uint32_t v = s_bits[i];
+      int less = 0, leq = 0;
+      for (int j = 0; j < n; ++j) { const uint32_t w = s_bits[j]; less += w < v; leq += w <= v; }
+      if (less <= mid && mid < leq) atomicMin(&s_best, i);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int64_t at = (int64_t)slot * stride + bi;
+      ok[at] = n > 0 ? 1 : 0;
+      value[at] = n > 0 ? s_raw[s_best] : 0u;
+    }
+    __syncthreads();
+  }
+}
+
 // ---- site kernels: one thread per record -----------------------------------------------------------------------
 // Pass 0 runs the record logic ONCE: allele merge, LUTs, per-record flags - and the text of the fixed columns, formatted
 // through a capped LDS sink into a lane-private strip and parked in a fixed-stride staging slot.  The page pass then only
@@ -939,6 +998,7 @@ struct DevicePipeline::Impl {
   DevBuf<uint32_t> err; DevBuf<int32_t> counters;
   DevBuf<SiteCtx> d_sx;
   DevBuf<uint64_t> med_keys, med_keys_sorted; DevBuf<uint32_t> med_idx, med_idx_sorted;
+  DevBuf<int32_t> big_index, big_list; DevBuf<uint32_t> big_value; DevBuf<uint8_t> big_ok;
   // entry text table
   DevBuf<unsigned long long> type_hkeys; DevBuf<int32_t> type_hrep, type_rep; DevBuf<uint8_t> type_hid, rtype;
   DevBuf<WalkCell> walk; DevBuf<int64_t> walk_inv;
@@ -1632,7 +1692,27 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
       med.keys = S.med_keys_sorted.p; med.inc = S.med_idx_sorted.p; med.stride = T; med.enabled = 1;
     }
   }
-  SiteCtx sx{fr, pl, cm, rec, hl, pc, nt, qw, so, med};
+  // records with very many variant calls get their medians from one workgroup each (no host round trip: the list is built
+  // and consumed on the device; counters[2] = how many)
+  BigMedians big;
+  memset(&big, 0, sizeof(big));
+  for (int f = 0; f < GDB_MAX_FIELDS; ++f) big.slot[f] = -1;
+  if (!med.enabled && T > 0) {
+    std::vector<std::pair<int, int>> fields;
+    for (int i = 0; i < pl.n_info; ++i) if (pl.field[pl.info_field[i]].combine_op == GDB_OP_MEDIAN) fields.push_back(std::make_pair(pl.info_field[i], 0));
+    if (pl.qual_combine_op == GDB_OP_MEDIAN && pl.f_QUAL >= 0) fields.push_back(std::make_pair(pl.f_QUAL, 1));
+    if (!fields.empty()) {
+      S.big_index.ensure((size_t)P); S.big_list.ensure(kMaxBigRecords); S.big_value.ensure(fields.size() * (size_t)kMaxBigRecords); S.big_ok.ensure(fields.size() * (size_t)kMaxBigRecords);
+      hipLaunchKernelGGL(k_big_records, dim3(blocks_for(P)), dim3(kBlock), 0, st, (const int64_t*)S.hbase.p, P, S.big_index.p, S.big_list.p, S.counters.p + 2);
+      for (size_t s = 0; s < fields.size(); ++s) {
+        hipLaunchKernelGGL(k_big_medians, dim3(64), dim3(kBlock), 0, st, fr, pl, cm, rec, hl, (const int32_t*)S.big_list.p, (const int32_t*)(S.counters.p + 2), fields[s].first, (int)s,
+                           fields[s].second, (int64_t)kMaxBigRecords, S.big_value.p, S.big_ok.p);
+        big.slot[fields[s].first] = (int8_t)s;
+      }
+      big.index = S.big_index.p; big.value = S.big_value.p; big.ok = S.big_ok.p; big.stride = kMaxBigRecords; big.enabled = 1;
+    }
+  }
+  SiteCtx sx{fr, pl, cm, rec, hl, pc, nt, qw, so, med, big};
   S.d_sx.ensure(1);
   HIP_CHECK(hipMemcpyAsync(S.d_sx.p, &sx, sizeof(SiteCtx), hipMemcpyHostToDevice, st));   // (sx outlives the copy: the function synchronises before it returns)
   STAGE("k_site_size");
