@@ -124,6 +124,12 @@ class CombineEngine:
     def set_reference(self, begin, bases):
         _check(_lib.lib().gdbamd_engine_set_reference(self._e, begin, bases, len(bases)) == 0, "set_reference")
 
+    def split_point(self, begin, end, max_columns):
+        """last column of the first piece of [begin, end] that can be run on its own with byte-identical output"""
+        pe = ctypes.c_int64()
+        _check(_lib.lib().gdbamd_engine_split_point(self._e, begin, end, max_columns, ctypes.byref(pe)) == 0, "split_point")
+        return pe.value
+
     def save_fragment(self, path):
         """the staged fragment as a columnar file (file -> HBM copies on load, no parsing)"""
         _check(_lib.lib().gdbamd_engine_save_fragment(self._e, str(path).encode()) == 0, "save_fragment")

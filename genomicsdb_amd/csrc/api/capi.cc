@@ -142,6 +142,9 @@ int gdbamd_engine_run_interval(void* e, int64_t qb, int64_t qe, uint64_t arena_b
   }, 1);
 }
 
+int gdbamd_engine_split_point(void* engine, int64_t qb, int64_t qe, int64_t max_columns, int64_t* piece_end) {
+  try { *piece_end = ((EngineHandle*)engine)->eng->pipeline().split_point(qb, qe, max_columns); return 0; } catch (const std::exception& e) { g_last_error = e.what(); return -1; }
+}
 int gdbamd_engine_save_fragment(void* engine, const char* path) {
   try { ((EngineHandle*)engine)->eng->save_fragment(path); return 0; } catch (const std::exception& e) { g_last_error = e.what(); return -1; }
 }

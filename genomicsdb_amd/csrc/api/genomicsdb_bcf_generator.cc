@@ -115,6 +115,13 @@ void GenomicsDBBCFGenerator::common_init(bool produce_header_only) {
   if (produce_header_only) m_done = true;
 }
 
+int64_t GenomicsDBBCFGenerator::max_window_columns() const {
+  if (const char* e = getenv("GDBAMD_MAX_WINDOW_COLUMNS")) return std::max<int64_t>(1, atoll(e));
+  // ~64 bytes of HBM per (column, sample) for text, resolved matrix and tables: keep a piece under ~48 GB
+  const int64_t n = std::max<int64_t>(1, (int64_t)m_engine->plan().plan.num_query_rows);
+  return std::max<int64_t>(1000, (int64_t)(48ll << 30) / (n * 64));
+}
+
 void GenomicsDBBCFGenerator::produce_next_batch() {
   m_buffer.clear();
   m_next_read_idx = 0;
@@ -124,10 +131,16 @@ void GenomicsDBBCFGenerator::produce_next_batch() {
   while (m_buffer.empty()) {
     if (!m_interval_active) {
       if (m_query_column_interval_idx >= nint) { m_done = true; return; }
-      int64_t qb = qc.get_num_column_intervals() ? qc.get_column_begin(m_query_column_interval_idx) : 0;
-      int64_t qe = qc.get_num_column_intervals() ? qc.get_column_end(m_query_column_interval_idx) : INT64_MAX - 1;
-      m_engine->stage_reference_for(qb, qe);
-      m_engine->pipeline().prepare_interval(qb, qe);
+      const int64_t qb = qc.get_num_column_intervals() ? qc.get_column_begin(m_query_column_interval_idx) : 0;
+      const int64_t qe = qc.get_num_column_intervals() ? qc.get_column_end(m_query_column_interval_idx) : INT64_MAX - 1;
+      // a wide interval (a whole chromosome) is worked off in pieces whose buffers fit HBM; the cuts sit right before cell
+      // begins, where the sweep closes its interval anyway, so the stream is byte-identical to the unsplit one
+      if (m_piece_begin < qb || m_piece_begin > qe) m_piece_begin = qb;
+      const int64_t pe = m_engine->pipeline().split_point(m_piece_begin, qe, max_window_columns());
+      m_engine->stage_reference_for(m_piece_begin, pe);
+      m_engine->pipeline().prepare_interval(m_piece_begin, pe);
+      m_piece_end = pe;
+      m_interval_end = qe;
       m_interval_active = true;
     }
     const char* dev = nullptr;
@@ -137,7 +150,8 @@ void GenomicsDBBCFGenerator::produce_next_batch() {
       if (n && hipMemcpy(m_buffer.data(), dev, n, hipMemcpyDeviceToHost) != hipSuccess) throw GenomicsDBDeviceException("page copy to host failed");
     } else {
       m_interval_active = false;
-      ++m_query_column_interval_idx;
+      if (m_piece_end >= m_interval_end) { ++m_query_column_interval_idx; m_piece_begin = INT64_MIN; }
+      else m_piece_begin = m_piece_end + 1;
     }
   }
 }

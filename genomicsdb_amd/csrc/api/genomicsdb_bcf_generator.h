@@ -68,6 +68,8 @@ class GenomicsDBBCFGenerator {
   size_t m_next_read_idx = 0;
   bool m_done = false, m_interval_active = false, m_produce_header_only = false;
   unsigned m_query_column_interval_idx = 0;
+  int64_t m_piece_begin = INT64_MIN, m_piece_end = 0, m_interval_end = 0;   // current piece of the current query interval
+  int64_t max_window_columns() const;
 };
 
 }  // namespace genomicsdb_amd

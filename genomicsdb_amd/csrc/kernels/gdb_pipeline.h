@@ -71,6 +71,8 @@ class DevicePipeline {
   // pull interface: prepare_interval() runs the sweep, the site pass and the sizing pass; next_page() then writes the
   // next <= arena_bytes of VCF text (always whole records) into HBM and returns false when the interval is exhausted
   void prepare_interval(int64_t qb, int64_t qe);
+  // last column of the first piece of [qb, qe] that can be processed on its own with byte-identical output (cut before a cell begin)
+  int64_t split_point(int64_t qb, int64_t qe, int64_t max_columns);
   bool next_page(uint64_t arena_bytes, const char** dev_ptr, uint64_t* nbytes);
   const IntervalStats& interval_stats() const;
   // push interface built on the two calls above

@@ -131,6 +131,13 @@ __global__ void k_cell_window(const int64_t* begin, int64_t C, int64_t lo_pos, i
   while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (begin[mid] <= hi_pos) lo = mid + 1; else hi = mid; }
   out[1] = lo;
 }
+// smallest begin >= pos of a sorted begin array (INT64_MAX: none): candidate split point of a wide query interval
+__global__ void k_first_begin_at_or_after(const int64_t* begin, int64_t C, int64_t pos, int64_t* out) {
+  if (blockIdx.x || threadIdx.x) return;
+  int64_t lo = 0, hi = C;
+  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (begin[mid] < pos) lo = mid + 1; else hi = mid; }
+  *out = lo < C ? begin[lo] : INT64_MAX;
+}
 __global__ void k_event_keys(FragmentView fr, CellMeta cm, int64_t c_base, int64_t n, int64_t qb, int64_t qe, uint64_t* keys) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -1491,6 +1498,24 @@ void DevicePipeline::set_reference_window(int64_t begin, const std::string& base
   if (!bases.empty()) HIP_CHECK(hipMemcpy(m_->ref_bases.p, bases.data(), bases.size(), hipMemcpyHostToDevice));
   m_->ref_begin = begin;
   m_->ref_len = (int64_t)bases.size();
+}
+
+// Every cell begin closes the current interval of the sweep (query_variants.cc:478-505), so a query interval can be cut right
+// before any cell begin without changing a single output byte.  Returns the last column of the first piece of [qb, qe] that
+// is at most max_columns wide where the data allows it (wider only if no cell begins in between).
+int64_t DevicePipeline::split_point(int64_t qb, int64_t qe, int64_t max_columns) {
+  Impl& S = *m_;
+  if (max_columns <= 0 || qe - qb < max_columns || S.fr.ncells == 0) return qe;
+  HIP_CHECK(hipSetDevice(S.device));
+  S.cwin.ensure(4);
+  const int64_t pos = qb + max_columns;
+  hipLaunchKernelGGL(k_first_begin_at_or_after, dim3(1), dim3(64), 0, S.stream, S.fr.begin, S.fr.ncells, pos, S.cwin.p);
+  int64_t p[2] = {INT64_MAX, INT64_MAX};
+  if (S.fr.nmarkers > 0) hipLaunchKernelGGL(k_first_begin_at_or_after, dim3(1), dim3(64), 0, S.stream, S.fr.marker_begin, S.fr.nmarkers, pos, S.cwin.p + 1);
+  HIP_CHECK(hipMemcpyAsync(p, S.cwin.p, (S.fr.nmarkers > 0 ? 2 : 1) * sizeof(int64_t), hipMemcpyDeviceToHost, S.stream));
+  HIP_CHECK(hipStreamSynchronize(S.stream));
+  const int64_t cut = std::min(p[0], p[1]);
+  return (cut == INT64_MAX || cut > qe) ? qe : cut - 1;
 }
 
 void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {

@@ -70,6 +70,10 @@ int gdbamd_engine_stage_cells_end(void* engine);
 /* adopt a columnar fragment that already lives in HBM: row = QUERY row idx, begin/end = columns, cols[num_fields] */
 int gdbamd_engine_adopt_device_fragment(void* engine, int64_t ncells, const int32_t* row, const int64_t* begin, const int64_t* end,
                                         const gdbamd_device_column* cols, int ncols, uint64_t reference_cell_bytes);
+/* Last column of the first piece of [column_begin, column_end] that can be run on its own with byte-identical output: the cut
+ * sits right before a cell begin >= column_begin + max_columns (the reference's sweep closes its interval at every cell
+ * begin, query_variants.cc:478-505).  *piece_end = column_end when the interval is narrow enough or no cell begins in between. */
+int gdbamd_engine_split_point(void* engine, int64_t column_begin, int64_t column_end, int64_t max_columns, int64_t* piece_end);
 /* the staged fragment as a columnar file, and back: file -> HBM copies without parsing.  gdb_mi355_init opens
  * <workspace>/<array>/fragment.gdbamd when present (else cells.bin).  This is the build's own format (the
  * Intel TileDB fork's on-disk format of the reference, variant_storage_manager.cc:61-153, is not available). */

@@ -401,3 +401,19 @@ def test_differential_fuzz_against_the_oracle(gdb):
     r = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "tests", "tools", "fuzz.py"), "40", "4242"], capture_output=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr).decode()[-2000:]
     assert b"40 cases, 0 mismatches" in r.stdout
+
+
+@pytest.mark.parametrize("max_columns", ["1", "40", "5000"])
+def test_wide_intervals_are_worked_off_in_pieces(gdb, monkeypatch, max_columns):
+    """the query stream cuts a wide interval right before cell begins (where the sweep closes its interval anyway):
+    GDBAMD_MAX_WINDOW_COLUMNS forces many pieces on the golden inputs - same bytes"""
+    monkeypatch.setenv("GDBAMD_MAX_WINDOW_COLUMNS", max_columns)
+    for name in ("t0_1_2_vcf_at_0", "t0_overlapping_loading", "t6_7_8_vcf_at_0", "min_PL_spanning_deletion_vcf", "t0_1_2_vcf_at_multiple_positions",
+                 "t0_haploid_triploid_1_2_3_triploid_deletion_vcf"):
+        _, callsets, vid, ov, golden, mode = [c for c in CASES if c[0] == name][0]
+        cells = helpers.cells_for(callsets, vid)
+        q, pb = helpers.query_json(callsets, vid, ov, mode)
+        s = gdb.GenomicsDBQueryStream(query_json=q, cells=cells, buffer_capacity=1 << 16)
+        got = s.read()
+        s.close()
+        assert got == helpers.golden_text(golden), name

@@ -53,8 +53,17 @@ for case in range(ncases):
         eng.stage_cells_end()
     eng.set_reference(B, synth.reference(B, off + L + 4096, seed=gseed))
     got, st = eng.run_interval(qb, qe, arena_bytes=arena)
-    eng.close()
     ok = got == want and st.num_records == nrec
+    if rnd.random() < 0.3:   # the same interval in pieces cut before cell begins: byte-identical by construction
+        maxc = rnd.choice([25, 100, 400])
+        pieces, cur = [], qb
+        while cur <= qe:
+            pe = eng.split_point(cur, qe, maxc)
+            body, _ = eng.run_interval(cur, pe, arena_bytes=arena)
+            pieces.append(body)
+            cur = pe + 1
+        ok = ok and b"".join(pieces) == want
+    eng.close()
     if not ok:
         bad += 1
         print("MISMATCH case %d: N=%d L=%d B=%d off=%d seed=%d dense=%s opts=%s arena=%d parts=%d records %d/%d" % (case, N, L, B, off, gseed, dense, opts, arena, nparts, st.num_records, nrec), flush=True)
