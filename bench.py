@@ -46,10 +46,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    ndev = max(1, torch.cuda.device_count())
+    device_index = local_rank % ndev   # one GPU per rank on a full node; wraps only in the single-GPU smoke run (gloo)
+    backend = os.environ.get("GDBAMD_DIST_BACKEND", "nccl")   # "nccl" = RCCL; "gloo" lets two ranks share one GPU in a smoke test
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend=backend)
+    torch.cuda.set_device(device_index)
 
     import genomicsdb_amd
     from genomicsdb_amd import synth
@@ -63,7 +69,7 @@ def main():
     need_bp = min(Lbp, W * min(nwin, total_steps))  # stage only the windows the run will touch
     tmp = tempfile.mkdtemp(prefix="gdbamd_bench_")
     q = helpers.synth_query(tmp, N, B, B + Lbp - 1)
-    eng = genomicsdb_amd.CombineEngine(q, device=local_rank)
+    eng = genomicsdb_amd.CombineEngine(q, device=device_index)
 
     # ---- generate + stage (not timed): cells -> columnar fragment in HBM, in 1 Mb parts ---------------------------------
     t0 = time.time()
@@ -109,7 +115,7 @@ def main():
     st_total_cells = max(1, ncells)
     bytes_in = int(eng_reference_bytes(eng) * (cells_in / st_total_cells))
 
-    dt, (recs_all, cells_all, bo_all, bi_all) = gdist.aggregate(dt, [recs, cells_in, bytes_out, bytes_in], device="cuda")
+    dt, (recs_all, cells_all, bo_all, bi_all) = gdist.aggregate(dt, [recs, cells_in, bytes_out, bytes_in], device="cuda" if backend == "nccl" else None)
 
     out = None
     if rank == 0:
