@@ -107,6 +107,12 @@ struct LdsCapSink {  // counts every byte, stores the first `cap` of them in LDS
   __device__ __forceinline__ LdsCapSink(gdb_lds_char* q, uint32_t c) : p(q), n(0), cap(c) {}
   __device__ __forceinline__ void put(char c) { if (n < cap) p[n] = c; ++n; }
   __device__ __forceinline__ void write(const char* s, int len) { for (int i = 0; i < len; ++i) put(s[i]); }
+  // up to 8 characters held in a register (first character in the low byte) with ONE unaligned 8-byte LDS store: the bytes
+  // behind the len valid ones are overwritten by what is emitted next (gfx950 executes DS accesses at any byte address)
+  __device__ __forceinline__ void put_word(uint64_t w, int len) {
+    if (n + 8u <= cap) { const uint32_t a = (uint32_t)(uintptr_t)p + n; asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(w) : "memory"); n += (uint32_t)len; }
+    else for (int i = 0; i < len; ++i) { put((char)(w & 0xFFu)); w >>= 8; }
+  }
 };
 #endif
 
@@ -163,6 +169,9 @@ GDB_HD uint64_t gdb_pack_digits(uint32_t v, int& n) {   // v < 10^8
 template <class Sink> GDB_HD void put_packed(Sink& s, uint64_t w, int n) {
   for (int i = 0; i < n; ++i) { s.put((char)(w & 0xFFu)); w >>= 8; }
 }
+#if defined(__HIPCC__)
+__device__ __forceinline__ void put_packed(LdsCapSink& s, uint64_t w, int n) { s.put_word(w, n); }
+#endif
 template <class Sink> GDB_HD void put_u32(Sink& s, uint32_t v) {
   if (v < 10u) { s.put((char)('0' + v)); return; }
   if (v < 100u) { const uint32_t q = v / 10u; s.put((char)('0' + q)); s.put((char)('0' + (v - q * 10u))); return; }
@@ -1021,8 +1030,8 @@ template <class Sink, class T> GDB_FIELD_FN Sink emit_remap_genotypes(Sink s, co
     }
     for (int kk = 0; kk < num_merged; ++kk)
       for (int j = 0; j <= kk; ++j) {
-        if (kk | j) s.put(',');
         const int q = kk == 0 ? 0 : (j == 0 ? 1 : 2);
+        if (kk | j) s.put(',');
         if (n3[q]) put_packed(s, w3[q], n3[q]); else put_elem(s, v3[q], err);
       }
   } else if (ploidy == 2) {
