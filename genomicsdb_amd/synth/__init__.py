@@ -15,7 +15,9 @@ def lib():
     if _lib is None:
         src = os.path.join(HERE, "gvcf_synth.cc")
         if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", LIB, src])
+            tmp = "%s.%d.tmp" % (LIB, os.getpid())   # several ranks may get here at once: build aside, then rename atomically
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", tmp, src])
+            os.replace(tmp, LIB)
         L = ctypes.CDLL(LIB)
         L.gdbsynth_create.restype = ctypes.c_void_p
         L.gdbsynth_create.argtypes = [ctypes.c_uint64, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64]
