@@ -925,7 +925,7 @@ struct EntryMaps {
   }
 };
 
-// The field emitters inline into the two out-of-line wrappers of the kernels file (entry_length / entry_store*), which
+// The field emitters inline into the out-of-line wrappers of the kernels file (entry_store / entry_store_lds_capped), which
 // read the EntryCtx from __constant__ memory: every plan / column-pointer access is then a scalar (SGPR) load.
 #define GDB_FIELD_FN GDB_HD
 
