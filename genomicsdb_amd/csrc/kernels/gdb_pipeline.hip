@@ -739,6 +739,7 @@ __device__ __forceinline__ uint4 load_chunk(const char* __restrict__ src, uint32
 constexpr int kAsmRows = 64;         // samples per (record, chunk): one wavefront
 constexpr int kWaveLds = 8 * 1024;   // LDS image of one (record, chunk)
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
+constexpr int kCooperativeEntry = 512;   // entry texts longer than this are copied pool -> page by the whole wavefront, not through the LDS image
 
 __device__ __forceinline__ int64_t readlane64(int64_t v, int l) {
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)v, l);
@@ -846,8 +847,31 @@ k_assemble_write(const char* __restrict__ pool, const char* __restrict__ pool_ov
         const uint32_t al = (uint32_t)((uintptr_t)gdst & 15u);
         const bool fits = (uint32_t)lane >= l0 && al + (inc - base_off) <= (uint32_t)kWaveLds;
         const uint64_t fit_mask = __ballot(fits) >> l0;     // inc is non-decreasing: the fitting lanes are a run starting at l0
-        if (!(fit_mask & 1ull)) {                           // lane l0 alone exceeds the image
-          if ((uint32_t)lane == l0) { char* dst = gdst; for (uint32_t b = 0; b < len; ++b) dst[b] = cur_src[b]; }
+        const uint32_t len_l0 = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)(l0 < 64u ? l0 : 63u));
+        if (!(fit_mask & 1ull) || len_l0 > (uint32_t)kCooperativeEntry) {   // a long text (or one that exceeds the image): the whole wavefront copies it
+          const char* big_src = (const char*)(uintptr_t)readlane64((int64_t)(uintptr_t)cur_src, (int)l0);   // (pool slots are 16-byte aligned)
+          const uint32_t big_len = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)l0);
+          uint32_t head = (16u - al) & 15u;                 // bytes up to the first 16-byte boundary of the destination
+          if (head > big_len) head = big_len;
+          if ((uint32_t)lane < head) gdst[lane] = big_src[lane];
+          const uint32_t nwords = (big_len - head) >> 4;
+          uint4* gw = reinterpret_cast<uint4*>(gdst + head);
+          for (uint32_t wq = lane; wq < nwords; wq += kAsmRows) {   // aligned 16-byte stores, source words assembled from two aligned loads
+            const char* sp = big_src + head + ((size_t)wq << 4);
+            const uint4 lo = *reinterpret_cast<const uint4*>((uintptr_t)sp & ~(uintptr_t)15);
+            const uint4 hi = *reinterpret_cast<const uint4*>(((uintptr_t)sp & ~(uintptr_t)15) + 16);
+            const uint32_t sh = (uint32_t)((uintptr_t)sp & 15u);
+            const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            uint32_t o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const uint32_t a = w[(sh >> 2) + q], b = w[(sh >> 2) + q + 1 < 8 ? (sh >> 2) + q + 1 : 7];
+              o[q] = __builtin_amdgcn_alignbyte(b, a, sh & 3u);
+            }
+            gw[wq] = make_uint4(o[0], o[1], o[2], o[3]);
+          }
+          const uint32_t tail_at = head + (nwords << 4);
+          if ((uint32_t)lane < big_len - tail_at) gdst[tail_at + lane] = big_src[tail_at + lane];
           base_off = (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)l0);
           ++l0;
           continue;
