@@ -350,9 +350,18 @@ GDB_HD void classify_cell(const FragmentView& fr, const CombinePlan& pl, const C
 }
 
 // ---- site (per record) ---------------------------------------------------------------------------------
-struct AlleleRef { const char* p; int len; int suffix_from; };  // text = p[0..len) + mergedREF[suffix_from..)
+struct AlleleRef { const char* p; int len; int suffix_from; uint32_t hash; };  // text = p[0..len) + mergedREF[suffix_from..)
+// hash of the text an AlleleRef stands for (FNV-1a): the merge compares hashes first, strings only on a hash match - a site
+// with thousands of variant calls would otherwise re-read every merged allele string for every call
+GDB_HD uint32_t allele_hash(const char* p, int len, int suffix_from, const char* mref, int mref_len) {
+  uint32_t h = 2166136261u;
+  for (int i = 0; i < len; ++i) h = (h ^ (uint32_t)(unsigned char)p[i]) * 16777619u;
+  if (suffix_from >= 0) for (int i = suffix_from; i < mref_len; ++i) h = (h ^ (uint32_t)(unsigned char)mref[i]) * 16777619u;
+  return h;
+}
 
 GDB_HD bool allele_equal(const AlleleRef& a, const AlleleRef& b, const char* mref, int mref_len) {
+  if (a.hash != b.hash) return false;
   int la = a.len + (a.suffix_from >= 0 ? mref_len - a.suffix_from : 0);
   int lb = b.len + (b.suffix_from >= 0 ? mref_len - b.suffix_from : 0);
   if (la != lb) return false;
@@ -661,7 +670,8 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
         }
       }
       if (lowest < 0) { *err |= GDB_ERR_INTERNAL; lowest = 1; }
-      AlleleRef cand{&star, 1, -1};
+      AlleleRef cand{&star, 1, -1, 0u};
+      cand.hash = allele_hash(cand.p, cand.len, cand.suffix_from, mref, mref_len);
       int found = -1;
       for (int j = 1; j < nmerged; ++j) if (allele_equal(merged[j], cand, mref, mref_len)) { found = j; break; }
       if (found < 0) {
@@ -714,7 +724,8 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
       const char* tok; int tl;
       for (int i = 0; alt_token(alt, alt_len, i, tok, tl); ++i) {
         if (tl > 0 && tok[0] == '&') continue;  // <NON_REF> goes last
-        AlleleRef cand{tok, tl, (suffix_needed && !allele_is_symbolic(tok, tl)) ? ref_len : -1};
+        AlleleRef cand{tok, tl, (suffix_needed && !allele_is_symbolic(tok, tl)) ? ref_len : -1, 0u};
+        cand.hash = allele_hash(cand.p, cand.len, cand.suffix_from, mref, mref_len);
         int found = -1;
         for (int j = 1; j < nmerged; ++j) if (allele_equal(merged[j], cand, mref, mref_len)) { found = j; break; }
         if (found < 0) {
