@@ -19,6 +19,14 @@
 #pragma once
 #include "gdb_types.h"
 
+// fetch-and-add on a 64-bit counter (device: atomic; serial host harness: plain)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GDB_FETCH_ADD_U64(p, v) atomicAdd((unsigned long long*)(p), (unsigned long long)(v))
+#else
+static inline unsigned long long gdb_fetch_add_u64(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p = o + v; return o; }
+#define GDB_FETCH_ADD_U64(p, v) gdb_fetch_add_u64((unsigned long long*)(p), (unsigned long long)(v))
+#endif
+
 // ---- cell flags --------------------------------------------------------------------------------------
 #define GDB_CF_REFBLOCK 1u
 #define GDB_CF_DELETION 2u
@@ -403,6 +411,82 @@ struct BigMedians {
   int32_t enabled;
 };
 
+// std::nth_element as the reference's C++ library (libstdc++, bits/stl_algo.h: __introselect) runs it, restated on a plain
+// float array: the reference takes medians with it (variant_field_handler.cc:529-607) and prints the selected element with
+// "%g", so when -0 and +0 tie at the middle WHICH of them is selected shows in the VCF ("-0" / "0") and depends on the
+// permutation the algorithm leaves behind, not only on the order of the values.  a[0..n) = valid values in call (row) order.
+GDB_HD void gdb_swapf(float* a, int64_t i, int64_t j) { const float t = a[i]; a[i] = a[j]; a[j] = t; }
+GDB_HD void gdb_heap_adjust(float* a, int64_t hole, int64_t len, float value) {   // __adjust_heap + __push_heap
+  const int64_t top = hole;
+  int64_t child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (a[child] < a[child - 1]) --child;
+    a[hole] = a[child];
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    a[hole] = a[child - 1];
+    hole = child - 1;
+  }
+  int64_t parent = (hole - 1) / 2;
+  while (hole > top && a[parent] < value) { a[hole] = a[parent]; hole = parent; parent = (hole - 1) / 2; }
+  a[hole] = value;
+}
+GDB_HD float gdb_introselect_libstdcxx(float* a, int64_t n, int64_t nth, int depth) {
+  int64_t first = 0, last = n;
+  while (last - first > 3) {
+    if (depth == 0) {                                // __heap_select(first, nth + 1, last), then swap(first, nth)
+      const int64_t middle = nth + 1, len = middle - first;
+      if (len >= 2) for (int64_t parent = (len - 2) / 2;; --parent) { gdb_heap_adjust(a + first, parent, len, a[first + parent]); if (parent == 0) break; }
+      for (int64_t i = middle; i < last; ++i)
+        if (a[i] < a[first]) { const float v = a[i]; a[i] = a[first]; gdb_heap_adjust(a + first, 0, len, v); }
+      gdb_swapf(a, first, nth);
+      return a[nth];
+    }
+    --depth;
+    // __unguarded_partition_pivot: median of (first + 1, mid, last - 1) to first, then partition (first + 1, last) around it
+    const int64_t mid = first + (last - first) / 2, x = first + 1, y = mid, z = last - 1;
+    if (a[x] < a[y]) {
+      if (a[y] < a[z]) gdb_swapf(a, first, y);
+      else if (a[x] < a[z]) gdb_swapf(a, first, z);
+      else gdb_swapf(a, first, x);
+    } else if (a[x] < a[z]) gdb_swapf(a, first, x);
+    else if (a[y] < a[z]) gdb_swapf(a, first, z);
+    else gdb_swapf(a, first, y);
+    int64_t lo = first + 1, hi = last;
+    const float pivot = a[first];                    // (the pivot slot is outside [first + 1, last): its value does not move)
+    for (;;) {
+      while (a[lo] < pivot) ++lo;
+      --hi;
+      while (pivot < a[hi]) --hi;
+      if (!(lo < hi)) break;
+      gdb_swapf(a, lo, hi);
+      ++lo;
+    }
+    if (lo <= nth) first = lo; else last = lo;
+  }
+  for (int64_t i = first + 1; i < last; ++i) {       // __insertion_sort
+    const float v = a[i];
+    if (v < a[first]) { for (int64_t j = i; j > first; --j) a[j] = a[j - 1]; a[first] = v; }
+    else { int64_t j = i; while (v < a[j - 1]) { a[j] = a[j - 1]; --j; } a[j] = v; }
+  }
+  return a[nth];
+}
+GDB_HD float gdb_nth_element_libstdcxx(float* a, int64_t n, int64_t nth) {
+  int depth = 0;
+  for (int64_t m = n; m > 1; m >>= 1) ++depth;     // std::__lg(n) * 2
+  return gdb_introselect_libstdcxx(a, n, nth, 2 * depth);
+}
+// scratch of the (rare) tied-zero medians: reduce_scalar takes n_valid floats per use; capacity = passes x float median
+// fields x heavy incidences, so it cannot run out
+struct TieScratch {
+  float* buf;
+  unsigned long long* used;
+  uint64_t capacity;
+};
+
 struct SiteCtx {
   FragmentView fr;
   CombinePlan pl;
@@ -416,6 +500,7 @@ struct SiteCtx {
   // optional (records with many variant calls): per median field, the incidences of every record ordered by value
   MedianOrder med;
   BigMedians big;
+  TieScratch tie;
 };
 
 // value of a scalar INFO-like field over the heavy list: median / sum / mean (variant_field_handler.cc:529-607).
@@ -424,19 +509,21 @@ GDB_HD bool inc_is_spanning(const SiteCtx& cx, int64_t t, int64_t s_k) {
   int64_t c = cx.hl.cell[t];
   return (cx.cm.cflags[c] & GDB_CF_DELETION) && s_k > cx.fr.begin[c];
 }
-template <class T> GDB_HD bool reduce_scalar(const SiteCtx& cx, int64_t k, int f, int op, bool keep_spanning, T& result) {
+template <class T> GDB_HD bool reduce_scalar(const SiteCtx& cx, int64_t k, int f, int op, bool keep_spanning, T& result, uint32_t* err) {
   const int64_t b = cx.hl.base[k], e = cx.hl.base[k + 1];
   if (op == GDB_OP_MEDIAN && cx.big.enabled && cx.big.slot[f] >= 0 && cx.big.index[k] >= 0) {
     const int64_t at = (int64_t)cx.big.slot[f] * cx.big.stride + cx.big.index[k];
     if (!cx.big.ok[at]) return false;
-    union { uint32_t u; T v; } x;
-    x.u = cx.big.value[at];
-    result = x.v;
-    return true;
+    if (cx.big.ok[at] == 1) {                       // (2: -0 and +0 tie at the middle, resolved below)
+      union { uint32_t u; T v; } x;
+      x.u = cx.big.value[at];
+      result = x.v;
+      return true;
+    }
   }
   const int64_t s_k = cx.rec.start[k];
   const bool is_float = cx.pl.field[f].elem == GDB_ET_FLOAT;
-  int64_t nvalid = 0;
+  int64_t nvalid = 0, nbelow = 0, nneg0 = 0, npos0 = 0;
   T sum = 0;
   for (int64_t t = b; t < e; ++t) {
     if (!keep_spanning && inc_is_spanning(cx, t, s_k)) continue;
@@ -449,10 +536,33 @@ template <class T> GDB_HD bool reduce_scalar(const SiteCtx& cx, int64_t k, int f
     if (!ok) continue;
     sum += v;
     ++nvalid;
+    if (is_float) {
+      const uint32_t u = gdb_f2u((float)v);
+      nneg0 += u == 0x80000000u;
+      npos0 += u == 0u;
+      nbelow += v < (T)0;
+    }
   }
   if (!nvalid) return false;
   if (op == GDB_OP_SUM) { result = sum; return true; }
   if (op == GDB_OP_MEAN) { result = sum / (T)nvalid; return true; }
+  if (is_float && nneg0 && npos0 && nbelow <= nvalid / 2 && nvalid / 2 < nbelow + nneg0 + npos0) {
+    // the median is a zero and both signs are present: which one the reference prints is decided by its nth_element
+    const uint64_t at = cx.tie.buf ? GDB_FETCH_ADD_U64(cx.tie.used, (uint64_t)nvalid) : 0;
+    if (!cx.tie.buf || at + (uint64_t)nvalid > cx.tie.capacity) { *err |= GDB_ERR_INTERNAL; return false; }
+    float* a = cx.tie.buf + at;
+    int64_t m = 0;
+    for (int64_t t = b; t < e; ++t) {
+      if (!keep_spanning && inc_is_spanning(cx, t, s_k)) continue;
+      int64_t c = cx.hl.cell[t];
+      if (!field_valid(cx.cm, c, f)) continue;
+      int n;
+      const float v = cell_field<float>(cx.fr, cx.pl, f, c, n)[0];
+      if (gdb_float_valid(v)) a[m++] = v;
+    }
+    result = (T)gdb_nth_element_libstdcxx(a, m, m / 2);
+    return true;
+  }
   if (cx.med.enabled && cx.med.slot[f] >= 0) {
     // sorted flavour: entry of rank nvalid/2 among the valid ones; among equal values the first in row order, like the scan below
     const uint64_t* keys = cx.med.keys + (int64_t)cx.med.slot[f] * cx.med.stride;
@@ -821,7 +931,7 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
   // QUAL
   {
     float q;
-    if (pl.qual_combine_op != GDB_OP_UNKNOWN && pl.f_QUAL >= 0 && reduce_scalar<float>(cx, k, pl.f_QUAL, pl.qual_combine_op, true, q)) {
+    if (pl.qual_combine_op != GDB_OP_UNKNOWN && pl.f_QUAL >= 0 && reduce_scalar<float>(cx, k, pl.f_QUAL, pl.qual_combine_op, true, q, err)) {
       if (!put_float(sink, q)) *err |= GDB_ERR_FLOAT_RANGE;
     } else sink.put('.');
   }
@@ -858,14 +968,14 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
       }
       if (fd.elem == GDB_ET_FLOAT) {
         float v;
-        if (!reduce_scalar<float>(cx, k, f, fd.combine_op, false, v)) continue;
+        if (!reduce_scalar<float>(cx, k, f, fd.combine_op, false, v, err)) continue;
         if (any) sink.put(';');
         sink.write(cx.names.text + cx.names.field_name_off[f], cx.names.field_name_len[f]);
         sink.put('=');
         if (!put_float(sink, v)) *err |= GDB_ERR_FLOAT_RANGE;
       } else {
         int32_t v;
-        if (!reduce_scalar<int32_t>(cx, k, f, fd.combine_op, false, v)) continue;
+        if (!reduce_scalar<int32_t>(cx, k, f, fd.combine_op, false, v, err)) continue;
         if (any) sink.put(';');
         sink.write(cx.names.text + cx.names.field_name_off[f], cx.names.field_name_len[f]);
         sink.put('=');

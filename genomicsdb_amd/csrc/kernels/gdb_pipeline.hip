@@ -287,12 +287,13 @@ __global__ void __launch_bounds__(kBlock) k_big_medians(FragmentView fr, Combine
   __shared__ uint32_t s_bits[kBigCapacity];     // order-preserving keys of the valid values
   __shared__ uint32_t s_raw[kBigCapacity];      // their raw bit patterns, in row order
   __shared__ int32_t s_n, s_best;
+  __shared__ uint32_t s_zero_signs;             // bit 0: a +0 among the values, bit 1: a -0
   const int count = min(*counter, kMaxBigRecords);
   for (int bi = blockIdx.x; bi < count; bi += gridDim.x) {   // uniform
     const int64_t k = big_list[bi];
     const int64_t b = hl.base[k], e = hl.base[k + 1];
     const int64_t s_k = rec.start[k];
-    if (threadIdx.x == 0) { s_n = 0; s_best = 0x7FFFFFFF; }
+    if (threadIdx.x == 0) { s_n = 0; s_best = 0x7FFFFFFF; s_zero_signs = 0; }
     __syncthreads();
     // gather the valid values in row order: one thread walks the (sorted) incidences - a few hundred to a few thousand
     if (threadIdx.x == 0) {
@@ -311,16 +312,21 @@ __global__ void __launch_bounds__(kBlock) k_big_medians(FragmentView fr, Combine
     __syncthreads();
     const int n = s_n;
     const int mid = n / 2;
+    const bool is_float = pl.field[f].elem == GDB_ET_FLOAT;
     for (int i = threadIdx.x; i < n; i += kBlock) {
       const uint32_t v = s_bits[i];
       int less = 0, leq = 0;
       for (int j = 0; j < n; ++j) { const uint32_t w = s_bits[j]; less += w < v; leq += w <= v; }
       if (less <= mid && mid < leq) atomicMin(&s_best, i);
+      if (is_float && (s_raw[i] << 1) == 0u) atomicOr(&s_zero_signs, s_raw[i] ? 2u : 1u);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
       const int64_t at = (int64_t)slot * stride + bi;
-      ok[at] = n > 0 ? 1 : 0;
+      // a zero median with both signs present: which zero the reference's nth_element leaves in the middle is worked out by
+      // reduce_scalar (gdb_nth_element_libstdcxx) - ok = 2 sends the site thread there
+      const bool tie = n > 0 && is_float && s_zero_signs == 3u && (s_raw[s_best] << 1) == 0u;
+      ok[at] = n > 0 ? (tie ? 2 : 1) : 0;
       value[at] = n > 0 ? s_raw[s_best] : 0u;
     }
     __syncthreads();
@@ -1030,6 +1036,7 @@ struct DevicePipeline::Impl {
   DevBuf<SiteCtx> d_sx;
   DevBuf<uint64_t> med_keys, med_keys_sorted; DevBuf<uint32_t> med_idx, med_idx_sorted;
   DevBuf<int32_t> big_index, big_list; DevBuf<uint32_t> big_value; DevBuf<uint8_t> big_ok;
+  DevBuf<float> tie_buf; DevBuf<unsigned long long> tie_used;
   // entry text table
   DevBuf<unsigned long long> type_hkeys; DevBuf<int32_t> type_hrep, type_rep; DevBuf<uint8_t> type_hid, rtype;
   DevBuf<WalkCell> walk; DevBuf<int64_t> walk_inv;
@@ -1761,7 +1768,19 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
       big.index = S.big_index.p; big.value = S.big_value.p; big.ok = S.big_ok.p; big.stride = kMaxBigRecords; big.enabled = 1;
     }
   }
-  SiteCtx sx{fr, pl, cm, rec, hl, pc, nt, qw, so, med, big};
+  // scratch of the tied-zero medians (gdb_core.hpp: TieScratch): 2 passes x float median fields x incidences
+  TieScratch tie{nullptr, nullptr, 0};
+  {
+    int nf = (pl.qual_combine_op == GDB_OP_MEDIAN && pl.f_QUAL >= 0) ? 1 : 0;
+    for (int i = 0; i < pl.n_info; ++i) if (pl.field[pl.info_field[i]].combine_op == GDB_OP_MEDIAN && pl.field[pl.info_field[i]].elem == GDB_ET_FLOAT) ++nf;
+    if (nf && T > 0) {
+      tie.capacity = 2ull * (uint64_t)nf * (uint64_t)T;
+      S.tie_buf.ensure((size_t)tie.capacity + 4); S.tie_used.ensure(1);
+      HIP_CHECK(hipMemsetAsync(S.tie_used.p, 0, sizeof(unsigned long long), st));
+      tie.buf = S.tie_buf.p; tie.used = S.tie_used.p;
+    }
+  }
+  SiteCtx sx{fr, pl, cm, rec, hl, pc, nt, qw, so, med, big, tie};
   S.d_sx.ensure(1);
   HIP_CHECK(hipMemcpyAsync(S.d_sx.p, &sx, sizeof(SiteCtx), hipMemcpyHostToDevice, st));   // (sx outlives the copy: the function synchronises before it returns)
   STAGE("k_site_size");

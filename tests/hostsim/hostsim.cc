@@ -122,6 +122,9 @@ std::string run_interval(const HostPlan& hp, const HostFragment& hf, const VidMa
   NameTables nt{hp.names_text.data(), hp.field_name_off.data(), hp.field_name_len.data(), hp.filter_name_off.data(), hp.filter_name_len.data(), (int)hp.filter_name_off.size()};
   PresenceCounts pc{dfmt.data(), ddp.data(), dnr.data(), P + 1};
   SiteCtx sx{fr, pl, cm, rec, hl, pc, nt, qw, so};
+  std::vector<float> tie_buf((size_t)16 * (T + 1));
+  unsigned long long tie_used = 0;
+  sx.tie.buf = tie_buf.data(); sx.tie.used = &tie_used; sx.tie.capacity = tie_buf.size();
   for (int64_t k = 0; k < P; ++k) { CountSink cs; site_emit(sx, k, cs, true, &err); prefix_len[k] = (uint32_t)cs.n; }
   // S8 entry sizing per (record, row chunk); rows walk runs of records
   RowIndex ri{row_ptr.data(), perm.data(), rm_begin.data()};
@@ -200,5 +203,19 @@ int hostsim_run_query(const char* query_json_text, const uint8_t* cells, uint64_
   }
 }
 void hostsim_free(char* p) { free(p); }
+
+// the restated libstdc++ selection against the library itself: 1 when the whole array ends up bit-identical
+// depth_limit < 0: the public entry point; >= 0: the library's internal loop with that depth budget (reaches its heap-select branch)
+int hostsim_nth_element_same(const float* values, int64_t n, int64_t nth, int depth_limit) {
+  std::vector<float> a(values, values + n), b(values, values + n);
+  if (depth_limit < 0) {
+    gdb_nth_element_libstdcxx(a.data(), n, nth);
+    std::nth_element(b.begin(), b.begin() + nth, b.end());
+  } else {
+    gdb_introselect_libstdcxx(a.data(), n, nth, depth_limit);
+    std::__introselect(b.begin(), b.begin() + nth, b.end(), (long)depth_limit, __gnu_cxx::__ops::__iter_less_iter());
+  }
+  return memcmp(a.data(), b.data(), (size_t)n * sizeof(float)) == 0 ? 1 : 0;
+}
 
 }  // extern "C"

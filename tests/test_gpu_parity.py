@@ -417,3 +417,43 @@ def test_wide_intervals_are_worked_off_in_pieces(gdb, monkeypatch, max_columns):
         got = s.read()
         s.close()
         assert got == helpers.golden_text(golden), name
+
+
+def test_c3_width_10000_samples_matches_oracle(gdb, tmp_path, monkeypatch):
+    """BASELINE.json configs[2] at its full sample count (10 000 rows: 157 wavefront-wide sample chunks per record, records of
+    ~0.9 MB) on a window the oracle finishes in seconds; pages smaller than some records.  With this many calls per record
+    the rank-sum medians land on zeros of both signs: which one is printed ("-0" / "0") follows the reference's
+    std::nth_element, through the workgroup medians and through the sorted medians alike."""
+    from genomicsdb_amd import synth
+    N, B, L = 10_000, 10_000_000, 40
+    eng, q, cells = _c2_engine(gdb, tmp_path, N, B, L)
+    want, nrec, _ = helpers.oracle_run_synth(q, cells, synth.SEED, with_header=False)
+    assert b"=-0;" in want and b"=0;" in want
+    got, st = eng.run_interval(B, B + L - 1, arena_bytes=4 << 20)
+    assert st.num_records == nrec and st.pages > 5
+    assert got == want
+    monkeypatch.setenv("GDBAMD_SORTED_MEDIAN", "1")
+    got, st = eng.run_interval(B, B + L - 1, arena_bytes=64 << 20)
+    assert got == want
+    eng.close()
+
+
+def test_c5_width_12000_samples_dense_site_matches_oracle(gdb, tmp_path):
+    """BASELINE.json configs[4]-style site at 12 000 rows: every sample starts an insertion from a pool of 64 alleles at one
+    column - the allele merge of that record sees 12 000 variant calls, each PL vector is re-indexed over ~2 000 genotypes"""
+    from genomicsdb_amd import synth
+    N, B, L = 12_000, 10_000_000, 56
+    g = synth.Generator(N, B, L + 2500, dense=(B + 40, 20, 50, 64))      # the hot column is B + 50
+    cells, nc = g.chunk_bytes(B + L + 2500)
+    q = helpers.synth_query(tmp_path, N, B + 30, B + L - 1)
+    q["max_diploid_alt_alleles_that_can_be_genotyped"] = 64
+    want, nrec, _ = helpers.oracle_run_synth(q, cells, synth.SEED, with_header=False)
+    eng = gdb.CombineEngine(q)
+    eng.stage_cells(cells)
+    eng.set_reference(B, synth.reference(B, L + 4096))
+    got, st = eng.run_interval(B + 30, B + L - 1, arena_bytes=64 << 20)
+    assert st.num_records == nrec
+    assert got == want
+    widest = max(len(l.split(b"\t")[4].split(b",")) for l in want.split(b"\n") if l)
+    assert widest >= 60
+    eng.close()

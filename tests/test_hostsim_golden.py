@@ -41,3 +41,31 @@ def test_unqueried_rows_still_split_intervals():
     got, errbits = helpers.hostsim_run(q, cells)
     assert errbits == 0 and got == want
     assert b"END=12144" in want    # the split at 12145 comes from the unqueried sample's cell
+
+
+def test_median_selection_is_the_c_library_selection():
+    """The reference takes medians with std::nth_element and prints the selected float: with -0 and +0 tied at the middle the
+    printed sign depends on the permutation libstdc++'s introselect leaves.  The restatement the kernels use must leave the
+    same permutation as the library for random, tie-heavy, sorted and adversarial (depth-limit -> heap select) inputs."""
+    import ctypes
+    import numpy as np
+    lib = helpers.hostsim_lib()
+    lib.hostsim_nth_element_same.restype = ctypes.c_int
+    lib.hostsim_nth_element_same.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int]
+    rng = np.random.default_rng(7)
+
+    def check(a, nth=None):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        nth = len(a) // 2 if nth is None else nth
+        assert lib.hostsim_nth_element_same(a.ctypes.data, len(a), nth, -1) == 1, (len(a), nth)
+        for depth in (0, 1, 3):        # the library's loop with a tiny depth budget: its heap-select branch
+            assert lib.hostsim_nth_element_same(a.ctypes.data, len(a), nth, depth) == 1, (len(a), nth, depth)
+
+    for n in list(range(1, 40)) + [63, 64, 65, 100, 257, 1000, 4097, 20000]:
+        for rep in range(6):
+            check(rng.standard_normal(n))
+            z = rng.choice(np.array([-0.0, 0.0, -0.5, 0.25, 1.0], dtype=np.float32), size=n)          # many tied zeros of both signs
+            check(z)
+            check(np.round(rng.standard_normal(n), 1) + np.float32(0.0) * rng.choice([-1.0, 1.0], size=n))
+            check(rng.standard_normal(n), nth=int(rng.integers(0, n)))
+        check(np.arange(n)); check(np.arange(n)[::-1]); check(np.zeros(n)); check(np.concatenate([np.arange(n // 2), np.arange(n - n // 2)[::-1]]))

@@ -61,3 +61,18 @@ def test_high_alt_dense_region_kernel_bodies_match_oracle(tmp_path, max_alt):
     assert got == want
     widest = max(len(l.split(b"\t")[4].split(b",")) for l in want.split(b"\n") if l)
     assert widest >= 40
+
+
+def test_tied_zero_medians_follow_the_library_selection(tmp_path):
+    """10 000 samples: records with hundreds of variant calls whose rank-sum medians are zeros of both signs - the printed sign
+    ("-0" / "0") is the one std::nth_element leaves in the middle (gdb_core.hpp: gdb_nth_element_libstdcxx)"""
+    from genomicsdb_amd import synth
+    N, B, L = 10_000, 10_000_000, 6
+    g = synth.Generator(N, B, L + 2500)
+    cells, nc = g.chunk_bytes(B + L + 2500)
+    q = helpers.synth_query(tmp_path, N, B, B + L - 1)
+    want, nrec, _ = helpers.oracle_run(q, cells, with_header=False)
+    assert b"=-0;" in want and b"=0;" in want
+    got, errbits = helpers.hostsim_run(q, cells, with_header=False, rows_per_chunk=64, records_per_run=8)
+    assert errbits == 0
+    assert got == want
