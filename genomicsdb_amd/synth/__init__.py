@@ -24,6 +24,7 @@ def lib():
         L.gdbsynth_create_dense.restype = ctypes.c_void_p
         L.gdbsynth_create_dense.argtypes = [ctypes.c_uint64, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32]
         L.gdbsynth_destroy.argtypes = [ctypes.c_void_p]
+        L.gdbsynth_set_rank_sum_scale.argtypes = [ctypes.c_void_p, ctypes.c_double]
         L.gdbsynth_next_chunk.restype = ctypes.c_int64
         L.gdbsynth_next_chunk.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64)]
         L.gdbsynth_reference.argtypes = [ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64, ctypes.c_char_p]
@@ -34,7 +35,7 @@ def lib():
 class Generator:
     """cells of N samples over [B, B+L), handed out in column chunks (column-major order inside and across chunks)"""
 
-    def __init__(self, n_samples, B, L, seed=SEED, dense=None):
+    def __init__(self, n_samples, B, L, seed=SEED, dense=None, rank_sum_scale=None):
         """dense = (begin, length, hot_stride, K): BASELINE.json configs[4]-style region where every sample starts an
         insertion, drawn from a pool of K alleles, at every multiple of hot_stride"""
         self.n_samples, self.B, self.L, self.seed = n_samples, B, L, seed
@@ -42,6 +43,8 @@ class Generator:
             self._h = lib().gdbsynth_create_dense(seed, n_samples, B, L, dense[0], dense[1], dense[2], dense[3])
         else:
             self._h = lib().gdbsynth_create(seed, n_samples, B, L)
+        if rank_sum_scale:      # rank sums rounded to 1 / scale instead of 1 / 1000: many tied medians, -0 and +0 included
+            lib().gdbsynth_set_rank_sum_scale(self._h, float(rank_sum_scale))
 
     def next_chunk(self, col_end, nthreads=None):
         """returns (host address, nbytes, ncells) valid until the next call"""

@@ -67,6 +67,7 @@ struct Synth {
   // every position that is a multiple of hot_stride, with its ALT drawn from a site pool of dense_K insertion alleles
   int64_t dense_begin = 0, dense_len = 0, hot_stride = 50;
   int dense_K = 0;
+  double rs_scale = 1000.0;   // rank sums are rounded to 1 / rs_scale (coarse scales make tied medians, zeros of both signs included)
   bool in_dense(int64_t p) const { return dense_len > 0 && p >= dense_begin && p < dense_begin + dense_len; }
   bool is_hot(int64_t p) const { return in_dense(p) && (p % hot_stride) == 0; }
 
@@ -124,7 +125,7 @@ struct Synth {
       r.hom = g.below(3) == 0;
       r.dp = g.range(10, 60);
       r.min_dp = NULL_I32;
-      for (int i = 0; i < 4; ++i) r.rs[i] = (float)(std::round(g.normal() * 1000.0) / 1000.0);
+      for (int i = 0; i < 4; ++i) r.rs[i] = (float)(std::round(g.normal() * rs_scale) / rs_scale);
       r.mq = (float)(std::round((40.0 + 20.0 * g.unit()) * 100.0) / 100.0);
       r.raw_mq = r.mq * r.mq * (float)r.dp;
       r.qual = (float)(std::round((30.0 + 2970.0 * g.unit()) * 100.0) / 100.0);
@@ -222,6 +223,7 @@ void* gdbsynth_create(uint64_t seed, int32_t n_samples, int64_t B, int64_t L) {
   return s;
 }
 void gdbsynth_destroy(void* h) { delete (Synth*)h; }
+void gdbsynth_set_rank_sum_scale(void* h, double scale) { ((Synth*)h)->rs_scale = scale > 0 ? scale : 1000.0; }
 // generates the next chunk (cells beginning before col_end); returns #cells, *cells / *nbytes valid until the next call
 int64_t gdbsynth_next_chunk(void* h, int64_t col_end, int nthreads, const uint8_t** cells, uint64_t* nbytes) {
   Synth* s = (Synth*)h;

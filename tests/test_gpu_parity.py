@@ -457,3 +457,26 @@ def test_c5_width_12000_samples_dense_site_matches_oracle(gdb, tmp_path):
     widest = max(len(l.split(b"\t")[4].split(b",")) for l in want.split(b"\n") if l)
     assert widest >= 60
     eng.close()
+
+
+@pytest.mark.parametrize("n_samples,scale", [(40, 1.0), (333, 2.0), (333, 1.0)])
+def test_tied_medians_print_the_zero_the_reference_selects(gdb, tmp_path, monkeypatch, n_samples, scale):
+    """rank sums rounded to 1 / scale: most medians are ties and many of them zeros of both signs.  The per-thread medians
+    (<= 48 calls), the workgroup medians (hot sites: 333 calls) and the sorted medians must all print the zero that
+    std::nth_element leaves in the middle."""
+    from genomicsdb_amd import synth
+    N, B, L = n_samples, 10_000_000, 500
+    g = synth.Generator(N, B, L + 2500, dense=(B + 100, 200, 50, 20), rank_sum_scale=scale)
+    cells, nc = g.chunk_bytes(B + L + 2500)
+    q = helpers.synth_query(tmp_path, N, B, B + L - 1)
+    want, nrec, _ = helpers.oracle_run_synth(q, cells, synth.SEED, with_header=False)
+    assert want.count(b"=-0;") > 3 and want.count(b"=0;") > 3
+    eng = gdb.CombineEngine(q)
+    eng.stage_cells(cells)
+    eng.set_reference(B, synth.reference(B, L + 4096))
+    got, st = eng.run_interval(B, B + L - 1, arena_bytes=1 << 20)
+    assert got == want
+    monkeypatch.setenv("GDBAMD_SORTED_MEDIAN", "1")
+    got, st = eng.run_interval(B, B + L - 1, arena_bytes=1 << 20)
+    assert got == want
+    eng.close()

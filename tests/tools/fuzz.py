@@ -13,8 +13,8 @@ bad = 0
 t00 = time.time()
 for case in range(ncases):
     rnd = random.Random(seed0 + case)
-    N = rnd.choice([1, 2, 3, 7, 31, 64, 65, 100, 130, 200, 333])
-    L = rnd.randint(300, 3500) if N < 150 else rnd.randint(300, 1500)
+    N = rnd.choice([1, 2, 3, 7, 31, 64, 65, 100, 130, 200, 333, 1500])
+    L = rnd.randint(300, 3500) if N < 150 else rnd.randint(300, 1500) if N < 1000 else rnd.randint(100, 300)
     B = 10_000_000 + rnd.randint(0, 5) * 1000
     gseed = rnd.randint(1, 10**6)
     dense = None
@@ -29,7 +29,8 @@ for case in range(ncases):
     if rnd.random() < 0.2: opts["max_diploid_alt_alleles_that_can_be_genotyped"] = rnd.choice([1, 2, 5, 64])
     arena = rnd.choice([1 << 12, 1 << 16, 1 << 20, 1 << 26])
     tmp = tempfile.mkdtemp()
-    g = synth.Generator(N, B, off + L + 2500, seed=gseed, dense=dense)
+    rs_scale = rnd.choice([None, None, 1.0, 2.0, 10.0])      # coarse rank sums: tied medians, zeros of both signs
+    g = synth.Generator(N, B, off + L + 2500, seed=gseed, dense=dense, rank_sum_scale=rs_scale)
     cells, nc = g.chunk_bytes(B + off + L + 2500)
     q = helpers.synth_query(tmp, N, qb, qe)
     q.update(opts)
@@ -66,6 +67,6 @@ for case in range(ncases):
     eng.close()
     if not ok:
         bad += 1
-        print("MISMATCH case %d: N=%d L=%d B=%d off=%d seed=%d dense=%s opts=%s arena=%d parts=%d records %d/%d" % (case, N, L, B, off, gseed, dense, opts, arena, nparts, st.num_records, nrec), flush=True)
+        print("MISMATCH case %d: N=%d L=%d B=%d off=%d seed=%d dense=%s rs_scale=%s opts=%s arena=%d parts=%d records %d/%d" % (case, N, L, B, off, gseed, dense, rs_scale, opts, arena, nparts, st.num_records, nrec), flush=True)
 print("fuzz: %d cases, %d mismatches, %.0f s" % (ncases, bad, time.time() - t00))
 sys.exit(1 if bad else 0)
