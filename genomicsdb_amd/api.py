@@ -1,5 +1,6 @@
 import ctypes
 import json
+import os
 
 from . import _lib
 
@@ -164,3 +165,19 @@ class CombineEngine:
             self.close()
         except Exception:
             pass
+
+
+def import_cells(vid_mapping_file, callset_mapping_file, file_root="", treat_deletions_as_intervals=True, column_begin=0, column_end=2**63 - 2):
+    """(g)VCFs of a callset mapping -> begin-cells (bytes, reference binary cell layout, column-major) of one column partition:
+    the conversion step of the reference's vcf2tiledb (vcf2binary.cc:991-1196).  Host code, no device needed."""
+    L = _lib.lib()
+    p = ctypes.c_void_p()
+    n = ctypes.c_uint64()
+    nc = ctypes.c_int64()
+    rc = L.gdbamd_import_cells(os.fsencode(vid_mapping_file), os.fsencode(callset_mapping_file), os.fsencode(file_root or ""), 1 if treat_deletions_as_intervals else 0,
+                               column_begin, column_end, ctypes.byref(p), ctypes.byref(n), ctypes.byref(nc))
+    _check(rc == 0, "import_cells")
+    try:
+        return ctypes.string_at(p.value, n.value), nc.value
+    finally:
+        L.gdbamd_free(p)

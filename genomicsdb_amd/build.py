@@ -13,6 +13,7 @@ CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(ROOT, "build", "obj")
 LIB = os.path.join(PKG, "libgenomicsdb_amd.so")
 TOOL = os.path.join(PKG, "gt_mpi_gather")
+TOOLS = {"gt_mpi_gather": TOOL, "vcf2tiledb": os.path.join(PKG, "vcf2tiledb")}
 
 SOURCES = [
     "kernels/gdb_pipeline.hip",
@@ -21,6 +22,7 @@ SOURCES = [
     "host/combine_plan.cc",
     "host/fragment.cc",
     "host/reference_genome.cc",
+    "host/vcf_importer.cc",
     "api/genomicsdb_bcf_generator.cc",
     "api/capi.cc",
 ]
@@ -61,13 +63,14 @@ def build_native(verbose=False):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    # command line of the reference's query tool (--produce-Broad-GVCF mode), linked against the library
-    tool_src = os.path.join(CSRC, "tools", "gt_mpi_gather.cc")
-    if _newer(TOOL, [tool_src, LIB] + hdrs):
-        cmd = [HIPCC, "-O2", "-std=c++17", "-Wall", "-Wno-unused-function", tool_src, "-o", TOOL, "-L" + PKG, "-lgenomicsdb_amd", "-Wl,-rpath,$ORIGIN", "-lz"]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+    # command lines of the reference's query tool (--produce-Broad-GVCF mode) and import tool, linked against the library
+    for name, exe in TOOLS.items():
+        tool_src = os.path.join(CSRC, "tools", name + ".cc")
+        if _newer(exe, [tool_src, LIB] + hdrs):
+            cmd = [HIPCC, "-O2", "-std=c++17", "-Wall", "-Wno-unused-function", tool_src, "-o", exe, "-L" + PKG, "-lgenomicsdb_amd", "-Wl,-rpath,$ORIGIN", "-lz"]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
     return LIB
 
 

@@ -3,9 +3,11 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "genomicsdb_bcf_generator.h"
+#include "../host/vcf_importer.h"
 
 using namespace genomicsdb_amd;
 
@@ -162,5 +164,30 @@ int gdbamd_column_partition(const char* loader_json_text, int rank, int64_t* beg
     return 0;
   } catch (const std::exception& e) { g_last_error = e.what(); return -1; }
 }
+
+int gdbamd_import_cells(const char* vid_mapping_file, const char* callset_mapping_file, const char* file_root, int treat_deletions_as_intervals,
+                        int64_t column_begin, int64_t column_end, uint8_t** cells, uint64_t* nbytes, int64_t* ncells) {
+  try {
+    if (!vid_mapping_file || !callset_mapping_file || !cells || !nbytes) throw GenomicsDBConfigException("gdbamd_import_cells: null argument");
+    VidMapper vid;
+    vid.parse_vid_json(mini_json::parse_file(vid_mapping_file));
+    vid.parse_callsets_json(mini_json::parse_file(callset_mapping_file));
+    ImportOptions opt;
+    opt.treat_deletions_as_intervals = treat_deletions_as_intervals != 0;
+    opt.column_begin = column_begin;
+    opt.column_end = column_end;
+    if (file_root) opt.file_root = file_root;
+    ImportStats st;
+    const std::vector<uint8_t> out = import_callsets_to_cells(vid, opt, &st);
+    *cells = (uint8_t*)malloc(out.size() ? out.size() : 1);
+    if (!*cells) throw GenomicsDBConfigException("out of memory");
+    if (!out.empty()) memcpy(*cells, out.data(), out.size());
+    *nbytes = out.size();
+    if (ncells) *ncells = st.num_cells;
+    g_last_error.clear();
+    return 0;
+  } catch (const std::exception& e) { g_last_error = e.what(); return -1; }
+}
+void gdbamd_free(void* p) { free(p); }
 
 }  // extern "C"

@@ -221,6 +221,11 @@ void VidMapper::parse_callsets_json(const mini_json::Value& doc) {
     if (row < 0) throw VidMapperException("negative row_idx for callset " + name);
     if ((size_t)row >= m_row_idx_to_name.size()) m_row_idx_to_name.resize((size_t)row + 1);
     m_row_idx_to_name[(size_t)row] = name;
+    CallSetInfo ci;
+    ci.m_name = name; ci.m_row_idx = row;
+    if (d.HasMember("idx_in_file")) ci.m_idx_in_file = d["idx_in_file"].GetInt64();
+    if (d.HasMember("filename")) ci.m_filename = d["filename"].GetString();
+    m_callsets.push_back(ci);
   }
   m_is_callset_mapping_initialized = true;
 }

@@ -42,6 +42,8 @@ struct FieldInfo {
 };
 
 struct ContigInfo { std::string m_name; int64_t m_tiledb_column_offset = 0, m_length = 0; };
+// one entry of the callset mapping (reference vid_mapper.cc:88-146 CallSetInfo: row, file, index of the sample in the file)
+struct CallSetInfo { std::string m_name; int64_t m_row_idx = -1, m_idx_in_file = 0; std::string m_filename; };
 
 class VidMapper {
  public:
@@ -58,6 +60,7 @@ class VidMapper {
   bool get_contig_location(int64_t position, std::string& contig_name, int64_t& contig_position) const;
   bool get_callset_name(int64_t row_idx, std::string& name) const;
   int64_t get_num_callsets() const { return (int64_t)m_row_idx_to_name.size(); }
+  const std::vector<CallSetInfo>& get_callsets() const { return m_callsets; }   // mapping order
   // attribute order of the array schema (reference vid_mapper.cc:354-442): END, REF, ALT, [ID], QUAL, FILTER, INFO.., FORMAT..
   std::vector<std::string> schema_attribute_names() const;
  private:
@@ -67,6 +70,7 @@ class VidMapper {
   std::vector<ContigInfo> m_contig_idx_to_info;
   std::vector<std::pair<int64_t, int>> m_contig_begin_2_idx;
   std::vector<std::string> m_row_idx_to_name;
+  std::vector<CallSetInfo> m_callsets;
   bool m_is_initialized = false, m_is_callset_mapping_initialized = false;
 };
 

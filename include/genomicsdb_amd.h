@@ -93,6 +93,15 @@ int gdbamd_engine_run_interval(void* engine, int64_t column_begin, int64_t colum
  * (reference: GenomicsDBImportConfig::get_column_partition, src/main/cpp/src/config/json_config.cc:340-417) */
 int gdbamd_column_partition(const char* loader_json_text, int rank, int64_t* begin, int64_t* end);
 
+/* (g)VCF import: the files of the callset mapping -> begin-cells (reference binary cell layout, column-major) whose begin
+ * column lies in [column_begin, column_end]; what vcf2tiledb's conversion step produces for one column partition
+ * (reference: VCF2Binary::convert_VCF_to_binary_for_callset, src/main/cpp/src/vcf/vcf2binary.cc:991-1196, fields :715-989;
+ * hand-over order of VCF2TileDBLoader, src/main/cpp/src/loader/tiledb_loader.cc:845-965).  file_root prefixes relative
+ * "filename" entries (NULL / "": as they are).  *cells is malloc'ed: release with gdbamd_free.  0 on success. */
+int gdbamd_import_cells(const char* vid_mapping_file, const char* callset_mapping_file, const char* file_root, int treat_deletions_as_intervals,
+                        int64_t column_begin, int64_t column_end, uint8_t** cells, uint64_t* nbytes, int64_t* ncells);
+void gdbamd_free(void* p);
+
 #ifdef __cplusplus
 }
 #endif

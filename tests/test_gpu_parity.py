@@ -480,3 +480,46 @@ def test_tied_medians_print_the_zero_the_reference_selects(gdb, tmp_path, monkey
     got, st = eng.run_interval(B, B + L - 1, arena_bytes=1 << 20)
     assert got == want
     eng.close()
+
+
+@pytest.mark.parametrize("name", ["t0_1_2_loading", "t6_7_8_loading", "t0_overlapping_at_12202_partition_loading", "info_ops1"])
+def test_vcf2tiledb_cli_imports_and_combines_in_line(gdb, tmp_path, name):
+    """the reference's import command line (tools/src/vcf2tiledb.cc) on the reference's own test gVCFs, run from the fixture
+    tree like run.py runs it from tests/: with produce_combined_vcf the loader's stdout is the '*_loading' golden; with
+    produce_tiledb_array the array it leaves behind answers gt_mpi_gather queries with the query goldens."""
+    import json
+    import os
+    import subprocess
+    tool = os.path.join(helpers.ROOT, "genomicsdb_amd", "vcf2tiledb")
+    assert os.path.exists(tool), "build() must produce the tool"
+    _, callsets, vid, ov, golden, mode = [c for c in CASES if c[0] == name][0]
+    assert mode == "load"
+    ov = dict(ov)
+    pb = ov.pop("partition_begin", 0)
+    loader = {
+        "row_based_partitioning": False, "produce_combined_vcf": True, "produce_tiledb_array": True,
+        "column_partitions": [{"begin": pb, "workspace": str(tmp_path / "ws"), "array": "arr"}],
+        "callset_mapping_file": os.path.join("inputs", "callsets", callsets), "vid_mapping_file": os.path.join("inputs", vid),
+        "treat_deletions_as_intervals": True, "vcf_header_filename": os.path.join("inputs", "template_vcf_header.vcf"),
+        "reference_genome": os.path.join("inputs", "chr1_10MB.fasta.gz"), "num_parallel_vcf_files": 1, "do_ping_pong_buffering": False,
+        "size_per_column_partition": 3000, "offload_vcf_output_processing": False, "discard_vcf_index": True, "segment_size": 40,
+    }
+    loader.update(ov)
+    lf = tmp_path / "loader.json"
+    lf.write_text(json.dumps(loader))
+    r = subprocess.run([tool, str(lf)], capture_output=True, timeout=120, cwd=helpers.GOLDEN)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout == helpers.golden_text(golden)
+    assert b"vcf2binary" in r.stderr and b"produce_combined_vcf" in r.stderr
+    cells = (tmp_path / "ws" / "arr" / "cells.bin").read_bytes()
+    if pb == 0:
+        assert cells == helpers.cells_for(callsets, vid)
+    if name == "t0_1_2_loading":      # query the imported array with the reference's query tool
+        q, _ = helpers.query_json(callsets, vid, {"query_column_ranges": [{"range_list": [{"low": 0, "high": 1000000000}]}]}, "query")
+        q["workspace"] = str(tmp_path / "ws")
+        q["array"] = "arr"
+        qf = tmp_path / "query.json"
+        qf.write_text(json.dumps(q))
+        r = subprocess.run([os.path.join(helpers.ROOT, "genomicsdb_amd", "gt_mpi_gather"), "-j", str(qf), "--produce-Broad-GVCF"], capture_output=True, timeout=120)
+        assert r.returncode == 0, r.stderr.decode()
+        assert r.stdout == helpers.golden_text("t0_1_2_vcf_at_0")
