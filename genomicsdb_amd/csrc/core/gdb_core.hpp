@@ -122,6 +122,31 @@ struct LdsCapSink {  // counts every byte, stores the first `cap` of them in LDS
     else for (int i = 0; i < len; ++i) { put((char)(w & 0xFFu)); w >>= 8; }
   }
 };
+// The same with a second tier for the few long texts (records with very many ALT alleles): what does not fit the LDS strip goes
+// to one fixed-size chunk of a global pool, taken with an atomic when the first byte overflows.  n counts every byte; the text
+// is complete when n <= cap + kSpillChunk and a chunk was available (chunk >= 0).
+constexpr uint32_t kSpillChunk = 2048;
+struct SpillPool { char* buf; unsigned int* next; uint32_t nchunks; };
+struct LdsSpillSink {
+  gdb_lds_char* p;
+  uint32_t n, cap;
+  int32_t chunk;          // -1: none taken yet, -2: the pool is exhausted
+  SpillPool pool;
+  __device__ __forceinline__ LdsSpillSink(gdb_lds_char* q, uint32_t c, const SpillPool& sp) : p(q), n(0), cap(c), chunk(-1), pool(sp) {}
+  // (by value and out of line: the sink itself stays in registers, the rare path costs one call)
+  __device__ __noinline__ static int32_t spill(SpillPool pool, int32_t chunk, uint32_t at, char c) {
+    if (chunk == -1) { const unsigned int i = atomicAdd(pool.next, 1u); chunk = i < pool.nchunks ? (int32_t)i : -2; }
+    if (chunk >= 0 && at < kSpillChunk) pool.buf[(size_t)chunk * kSpillChunk + at] = c;
+    return chunk;
+  }
+  __device__ __forceinline__ void put(char c) { if (n < cap) p[n] = c; else chunk = spill(pool, chunk, n - cap, c); ++n; }
+  __device__ __forceinline__ void write(const char* s, int len) { for (int i = 0; i < len; ++i) put(s[i]); }
+  __device__ __forceinline__ void put_word(uint64_t w, int len) {
+    if (n + 8u <= cap) { const uint32_t a = (uint32_t)(uintptr_t)p + n; asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(w) : "memory"); n += (uint32_t)len; }
+    else for (int i = 0; i < len; ++i) { put((char)(w & 0xFFu)); w >>= 8; }
+  }
+  __device__ __forceinline__ bool complete() const { return n <= cap || (chunk >= 0 && n - cap <= kSpillChunk); }
+};
 #endif
 
 // ---- small helpers -----------------------------------------------------------------------------------
@@ -179,6 +204,7 @@ template <class Sink> GDB_HD void put_packed(Sink& s, uint64_t w, int n) {
 }
 #if defined(__HIPCC__)
 __device__ __forceinline__ void put_packed(LdsCapSink& s, uint64_t w, int n) { s.put_word(w, n); }
+__device__ __forceinline__ void put_packed(LdsSpillSink& s, uint64_t w, int n) { s.put_word(w, n); }
 #endif
 template <class Sink> GDB_HD void put_u32(Sink& s, uint32_t v) {
   if (v < 10u) { s.put((char)('0' + v)); return; }

@@ -339,23 +339,25 @@ __global__ void __launch_bounds__(kBlock) k_big_medians(FragmentView fr, Combine
 // copies the parked text (records whose fixed columns exceed the slot - long allele lists - are formatted again).
 constexpr int kSiteStride = 256;                   // staging bytes per record
 constexpr int kSiteStripWords = kSiteStride / 4 + 1;
-__global__ void __launch_bounds__(64) k_site_size(const SiteCtx* __restrict__ sxp, char* __restrict__ staging, uint32_t* err) {
+constexpr int kSpillChunks = 32768;                 // spill pool: 64 MB of 2 KB chunks for the tails of longer fixed columns
+__global__ void __launch_bounds__(64) k_site_size(const SiteCtx* __restrict__ sxp, char* __restrict__ staging, SpillPool spill, int32_t* __restrict__ spill_chunk, uint32_t* err) {
   const SiteCtx& sx = *sxp;
   __shared__ uint32_t strip[64 * kSiteStripWords];
   int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= sx.rec.npos) return;
   uint32_t e = 0;
   uint32_t* mine = strip + threadIdx.x * kSiteStripWords;
-  LdsCapSink cs((gdb_lds_char*)mine, (uint32_t)kSiteStride);
+  LdsSpillSink cs((gdb_lds_char*)mine, (uint32_t)kSiteStride, spill);
   site_emit(sx, k, cs, true, &e);
   sx.so.prefix_len[k] = cs.n;
-  if (cs.n <= (uint32_t)kSiteStride) {
-    uint4* dst = reinterpret_cast<uint4*>(staging + (size_t)k * kSiteStride);
-    for (uint32_t q = 0; (q << 4) < cs.n; ++q) dst[q] = make_uint4(mine[4 * q], mine[4 * q + 1], mine[4 * q + 2], mine[4 * q + 3]);
-  }
+  // longer texts: the tail lies in a chunk of the spill pool (or, when that did not work out, the page pass formats the record again)
+  spill_chunk[k] = (cs.n > (uint32_t)kSiteStride && cs.complete()) ? cs.chunk : -1;
+  const uint32_t nstaged = min(cs.n, (uint32_t)kSiteStride);
+  uint4* dst = reinterpret_cast<uint4*>(staging + (size_t)k * kSiteStride);
+  for (uint32_t q = 0; (q << 4) < nstaged; ++q) dst[q] = make_uint4(mine[4 * q], mine[4 * q + 1], mine[4 * q + 2], mine[4 * q + 3]);
   if (e) atomicOr(err, e);
 }
-__global__ void k_site_write(const SiteCtx* __restrict__ sxp, const char* __restrict__ staging, int64_t k_begin, int64_t k_end, const uint64_t* chunk_off, int nchunks,
+__global__ void k_site_write(const SiteCtx* __restrict__ sxp, const char* __restrict__ staging, const char* __restrict__ spill_buf, const int32_t* __restrict__ spill_chunk, int64_t k_begin, int64_t k_end, const uint64_t* chunk_off, int nchunks,
                              uint64_t page_base, char* arena, uint32_t* err) {
   const SiteCtx& sx = *sxp;
   int64_t k = k_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -373,6 +375,11 @@ __global__ void k_site_write(const SiteCtx* __restrict__ sxp, const char* __rest
       *reinterpret_cast<uint32_t*>(dst + i) = w;
     }
     for (; i < n; ++i) dst[i] = src[i];
+  } else if (spill_chunk[k] >= 0) {
+    const char* src = staging + (size_t)k * kSiteStride;
+    for (uint32_t i = 0; i < (uint32_t)kSiteStride; ++i) dst[i] = src[i];
+    const char* tail = spill_buf + (size_t)spill_chunk[k] * kSpillChunk;
+    for (uint32_t i = kSiteStride; i < n; ++i) dst[i] = tail[i - kSiteStride];
   } else {
     ByteSink bs(dst);
     site_emit(sx, k, bs, false, &e);
@@ -1029,7 +1036,7 @@ struct DevicePipeline::Impl {
   DevBuf<int32_t> diff, first_record_at; DevBuf<uint64_t> diff_packed; DevBuf<int64_t> heavy_count, hoff;
   DevBuf<uint64_t> inc_keys, inc_keys_sorted; DevBuf<int64_t> inc_vals, inc_vals_sorted, hbase;
   DevBuf<uint32_t> lut_len, i2m_off; DevBuf<int8_t> i2m, gt_override; DevBuf<uint8_t> iflags;
-  DevBuf<uint8_t> num_alleles, rflags; DevBuf<uint32_t> fmt_mask, prefix_len; DevBuf<char> site_staging;
+  DevBuf<uint8_t> num_alleles, rflags; DevBuf<uint32_t> fmt_mask, prefix_len; DevBuf<char> site_staging, spill_buf; DevBuf<int32_t> spill_chunk; DevBuf<unsigned int> spill_next;
   DevBuf<uint64_t> chunk_size, chunk_off, rec_off;
   DevBuf<char> arena, temp;
   DevBuf<uint32_t> err; DevBuf<int32_t> counters;
@@ -1785,7 +1792,9 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   HIP_CHECK(hipMemcpyAsync(S.d_sx.p, &sx, sizeof(SiteCtx), hipMemcpyHostToDevice, st));   // (sx outlives the copy: the function synchronises before it returns)
   STAGE("k_site_size");
   S.site_staging.ensure((size_t)P * kSiteStride + 64);
-  hipLaunchKernelGGL(k_site_size, dim3(blocks_for(P, 64)), dim3(64), 0, st, S.d_sx.p, S.site_staging.p, S.err.p);
+  S.spill_buf.ensure((size_t)kSpillChunks * kSpillChunk); S.spill_chunk.ensure((size_t)P); S.spill_next.ensure(1);
+  HIP_CHECK(hipMemsetAsync(S.spill_next.p, 0, sizeof(unsigned int), st));
+  hipLaunchKernelGGL(k_site_size, dim3(blocks_for(P, 64)), dim3(64), 0, st, S.d_sx.p, S.site_staging.p, SpillPool{S.spill_buf.p, S.spill_next.p, (uint32_t)kSpillChunks}, S.spill_chunk.p, S.err.p);
   HIP_CHECK(hipEventRecord(ev[2], st));
   // ---- S8 sample-column sizes + offsets ---------------------------------------------------------------------------
   const int nchunks = (N + kAsmRows - 1) / kAsmRows;
@@ -1914,7 +1923,7 @@ bool DevicePipeline::next_page(uint64_t arena_bytes, const char** dev_ptr, uint6
   HIP_CHECK(hipEventCreate(&w0)); HIP_CHECK(hipEventCreate(&w1)); HIP_CHECK(hipEventCreate(&w2));
   HIP_CHECK(hipEventRecord(w0, st));
   STAGE("k_site_write");
-  hipLaunchKernelGGL(k_site_write, dim3(blocks_for(np, 64)), dim3(64), 0, st, S.d_sx.p, (const char*)S.site_staging.p, kp, ke, S.chunk_off.p, iv.nchunks, page_base, S.arena.p, S.err.p);
+  hipLaunchKernelGGL(k_site_write, dim3(blocks_for(np, 64)), dim3(64), 0, st, S.d_sx.p, (const char*)S.site_staging.p, (const char*)S.spill_buf.p, (const int32_t*)S.spill_chunk.p, kp, ke, S.chunk_off.p, iv.nchunks, page_base, S.arena.p, S.err.p);
   STAGE("k_assemble_write");
   const int wrun = write_run_length();
   S.order_by_type(kp, np);
