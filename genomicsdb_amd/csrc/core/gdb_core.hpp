@@ -513,6 +513,16 @@ struct TieScratch {
   uint64_t capacity;
 };
 
+// scalar INFO-like values per (record, variant call) incidence, gathered once by a kernel before the site pass:
+// val[slot * stride + t] = raw 32 bits of the value call t contributes to the field, or the bcf missing pattern of the field's
+// type when the call does not count (field absent, value missing / vector end, spanning deletion for the INFO fields)
+struct ScalarPre {
+  const uint32_t* val;
+  int64_t stride;
+  int8_t slot[GDB_MAX_FIELDS];
+  int32_t enabled;
+};
+
 struct SiteCtx {
   FragmentView fr;
   CombinePlan pl;
@@ -527,6 +537,7 @@ struct SiteCtx {
   MedianOrder med;
   BigMedians big;
   TieScratch tie;
+  ScalarPre pre;
 };
 
 // value of a scalar INFO-like field over the heavy list: median / sum / mean (variant_field_handler.cc:529-607).
@@ -534,6 +545,24 @@ struct SiteCtx {
 GDB_HD bool inc_is_spanning(const SiteCtx& cx, int64_t t, int64_t s_k) {
   int64_t c = cx.hl.cell[t];
   return (cx.cm.cflags[c] & GDB_CF_DELETION) && s_k > cx.fr.begin[c];
+}
+// the value call t of record k contributes to scalar field f, false when it does not count (field absent, value missing,
+// spanning deletion unless keep_spanning).  With the gathered table (ScalarPre) this is one load from a contiguous array;
+// without it (CPU harness) the cell is consulted.
+template <class T> GDB_HD bool scalar_at(const SiteCtx& cx, const uint32_t* pre, int64_t t, int64_t s_k, int f, bool keep_spanning, bool is_float, T& v) {
+  if (pre) {
+    union { uint32_t u; T v; } x;
+    x.u = pre[t];
+    if (is_float ? x.u == GDB_BCF_FLOAT_MISSING_BITS : x.u == (uint32_t)GDB_BCF_INT32_MISSING) return false;
+    v = x.v;
+    return true;
+  }
+  if (!keep_spanning && inc_is_spanning(cx, t, s_k)) return false;
+  const int64_t c = cx.hl.cell[t];
+  if (!field_valid(cx.cm, c, f)) return false;
+  int n;
+  v = cell_field<T>(cx.fr, cx.pl, f, c, n)[0];
+  return is_float ? gdb_float_valid((float)v) : gdb_int_valid((int32_t)v);
 }
 template <class T> GDB_HD bool reduce_scalar(const SiteCtx& cx, int64_t k, int f, int op, bool keep_spanning, T& result, uint32_t* err) {
   const int64_t b = cx.hl.base[k], e = cx.hl.base[k + 1];
@@ -549,17 +578,12 @@ template <class T> GDB_HD bool reduce_scalar(const SiteCtx& cx, int64_t k, int f
   }
   const int64_t s_k = cx.rec.start[k];
   const bool is_float = cx.pl.field[f].elem == GDB_ET_FLOAT;
+  const uint32_t* pre = (cx.pre.enabled && cx.pre.slot[f] >= 0) ? cx.pre.val + (int64_t)cx.pre.slot[f] * cx.pre.stride : nullptr;
   int64_t nvalid = 0, nbelow = 0, nneg0 = 0, npos0 = 0;
   T sum = 0;
   for (int64_t t = b; t < e; ++t) {
-    if (!keep_spanning && inc_is_spanning(cx, t, s_k)) continue;
-    int64_t c = cx.hl.cell[t];
-    if (!field_valid(cx.cm, c, f)) continue;
-    int n;
-    const T* p = cell_field<T>(cx.fr, cx.pl, f, c, n);
-    T v = p[0];
-    bool ok = is_float ? gdb_float_valid((float)v) : gdb_int_valid((int32_t)v);
-    if (!ok) continue;
+    T v;
+    if (!scalar_at<T>(cx, pre, t, s_k, f, keep_spanning, is_float, v)) continue;
     sum += v;
     ++nvalid;
     if (is_float) {
@@ -579,12 +603,8 @@ template <class T> GDB_HD bool reduce_scalar(const SiteCtx& cx, int64_t k, int f
     float* a = cx.tie.buf + at;
     int64_t m = 0;
     for (int64_t t = b; t < e; ++t) {
-      if (!keep_spanning && inc_is_spanning(cx, t, s_k)) continue;
-      int64_t c = cx.hl.cell[t];
-      if (!field_valid(cx.cm, c, f)) continue;
-      int n;
-      const float v = cell_field<float>(cx.fr, cx.pl, f, c, n)[0];
-      if (gdb_float_valid(v)) a[m++] = v;
+      T v;
+      if (scalar_at<T>(cx, pre, t, s_k, f, keep_spanning, is_float, v)) a[m++] = (float)v;
     }
     result = (T)gdb_nth_element_libstdcxx(a, m, m / 2);
     return true;
@@ -605,22 +625,12 @@ template <class T> GDB_HD bool reduce_scalar(const SiteCtx& cx, int64_t k, int f
   // median = element of rank nvalid/2 in ascending order (std::nth_element at mid_point)
   int64_t mid = nvalid / 2;
   for (int64_t t = b; t < e; ++t) {
-    if (!keep_spanning && inc_is_spanning(cx, t, s_k)) continue;
-    int64_t c = cx.hl.cell[t];
-    if (!field_valid(cx.cm, c, f)) continue;
-    int n;
-    const T* p = cell_field<T>(cx.fr, cx.pl, f, c, n);
-    T v = p[0];
-    if (!(is_float ? gdb_float_valid((float)v) : gdb_int_valid((int32_t)v))) continue;
+    T v;
+    if (!scalar_at<T>(cx, pre, t, s_k, f, keep_spanning, is_float, v)) continue;
     int64_t less = 0, leq = 0;
     for (int64_t u = b; u < e; ++u) {
-      if (!keep_spanning && inc_is_spanning(cx, u, s_k)) continue;
-      int64_t c2 = cx.hl.cell[u];
-      if (!field_valid(cx.cm, c2, f)) continue;
-      int n2;
-      const T* p2 = cell_field<T>(cx.fr, cx.pl, f, c2, n2);
-      T w = p2[0];
-      if (!(is_float ? gdb_float_valid((float)w) : gdb_int_valid((int32_t)w))) continue;
+      T w;
+      if (!scalar_at<T>(cx, pre, u, s_k, f, keep_spanning, is_float, w)) continue;
       if (w < v) ++less;
       if (w <= v) ++leq;
     }
@@ -729,6 +739,30 @@ GDB_HD int find_contig(const QueryWindow& qw, int64_t pos) {  // VidMapper::get_
 
 // Per-record site logic.  PASS 0 (Sink = CountSink, write_luts = false) sizes the prefix; PASS 1 writes the prefix
 // text and the per-incidence allele LUTs / flags.  One call handles one record.
+// Position of `cand` in the merged allele list, appended when it is new (CombineAllelesLUT / merge_alt_alleles order: first
+// appearance).  Short lists are scanned; from kMergeScan entries on a 256-entry open-addressing index over the allele hashes
+// (built when the list first grows past the limit) replaces the scan - sites where thousands of calls share a few dozen
+// alleles would otherwise spend their time walking the list once per call.
+constexpr int kMergeScan = 8;
+struct MergeIndex { uint8_t slot[256]; bool built; };
+GDB_HD int merged_find_or_add(AlleleRef* merged, int& nmerged, MergeIndex& ix, const AlleleRef& cand, const char* mref, int mref_len, uint32_t* err) {
+  if (nmerged <= kMergeScan) {
+    for (int j = 1; j < nmerged; ++j) if (allele_equal(merged[j], cand, mref, mref_len)) return j;
+  } else {
+    if (!ix.built) {
+      for (int h = 0; h < 256; ++h) ix.slot[h] = 0;
+      for (int j = 1; j < nmerged; ++j) { uint32_t h = merged[j].hash & 255u; while (ix.slot[h]) h = (h + 1) & 255u; ix.slot[h] = (uint8_t)j; }
+      ix.built = true;
+    }
+    for (uint32_t h = cand.hash & 255u; ix.slot[h]; h = (h + 1) & 255u)
+      if (allele_equal(merged[ix.slot[h]], cand, mref, mref_len)) return ix.slot[h];
+  }
+  if (nmerged >= GDB_MAX_MERGED_ALLELES - 1) { *err |= GDB_ERR_TOO_MANY_MERGED_ALLELES; return nmerged - 1; }
+  merged[nmerged] = cand;
+  if (ix.built) { uint32_t h = cand.hash & 255u; while (ix.slot[h]) h = (h + 1) & 255u; ix.slot[h] = (uint8_t)nmerged; }
+  return nmerged++;
+}
+
 template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& sink, bool write_luts, uint32_t* err) {
   const CombinePlan& pl = cx.pl;
   const int64_t s_k = cx.rec.start[k], e_k = cx.rec.end[k];
@@ -764,6 +798,8 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
   }
   // -- merged ALT list + LUTs (merge_alt_alleles), spanning deletions folded in (handle_deletions) ------
   AlleleRef merged[GDB_MAX_MERGED_ALLELES];
+  MergeIndex mix;
+  mix.built = false;
   int nmerged = 1;  // index 0 = REF
   const char star = '*';
   bool non_ref_exists = cx.pc.nr_cnt[k] > 0;
@@ -808,12 +844,7 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
       if (lowest < 0) { *err |= GDB_ERR_INTERNAL; lowest = 1; }
       AlleleRef cand{&star, 1, -1, 0u};
       cand.hash = allele_hash(cand.p, cand.len, cand.suffix_from, mref, mref_len);
-      int found = -1;
-      for (int j = 1; j < nmerged; ++j) if (allele_equal(merged[j], cand, mref, mref_len)) { found = j; break; }
-      if (found < 0) {
-        if (nmerged >= GDB_MAX_MERGED_ALLELES - 1) { *err |= GDB_ERR_TOO_MANY_MERGED_ALLELES; found = nmerged - 1; }
-        else { merged[nmerged] = cand; found = nmerged++; }
-      }
+      const int found = merged_find_or_add(merged, nmerged, mix, cand, mref, mref_len, err);
       if (lut) lut[lowest] = (int8_t)found;
       if (lut && pl.min_PL_GT_for_spanning_deletions && pl.produce_GT_field && pl_exists && pl.f_GT >= 0 && field_valid(cx.cm, c, pl.f_GT)) {
         // update_GT_to_correspond_to_min_PL_value on the REDUCED PL (alleles REF,*,[<NON_REF>])
@@ -862,12 +893,7 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
         if (tl > 0 && tok[0] == '&') continue;  // <NON_REF> goes last
         AlleleRef cand{tok, tl, (suffix_needed && !allele_is_symbolic(tok, tl)) ? ref_len : -1, 0u};
         cand.hash = allele_hash(cand.p, cand.len, cand.suffix_from, mref, mref_len);
-        int found = -1;
-        for (int j = 1; j < nmerged; ++j) if (allele_equal(merged[j], cand, mref, mref_len)) { found = j; break; }
-        if (found < 0) {
-          if (nmerged >= GDB_MAX_MERGED_ALLELES - 1) { *err |= GDB_ERR_TOO_MANY_MERGED_ALLELES; found = nmerged - 1; }
-          else { merged[nmerged] = cand; found = nmerged++; }
-        }
+        const int found = merged_find_or_add(merged, nmerged, mix, cand, mref, mref_len, err);
         if (lut && i + 1 <= nalt) lut[i + 1] = (int8_t)found;
       }
     }

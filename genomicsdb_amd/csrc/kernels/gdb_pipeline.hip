@@ -268,6 +268,28 @@ __global__ void k_median_keys(FragmentView fr, CombinePlan pl, CellMeta cm, Reco
   idx[t] = (uint32_t)t;
 }
 
+// ---- scalar reducer inputs, one value per (record, variant call) incidence (ScalarPre): the site thread then sums / counts
+// over a contiguous array instead of chasing cell -> validity mask -> field offset -> value once per call and field
+__global__ void k_scalar_values(FragmentView fr, CombinePlan pl, CellMeta cm, RecordTable rec, const uint64_t* inc_keys_sorted, const int64_t* inc_cell, int64_t T,
+                                int64_t nrows, int f, int keep_spanning, uint32_t* out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const bool is_float = pl.field[f].elem == GDB_ET_FLOAT;
+  const int64_t c = inc_cell[t];
+  uint32_t bits = is_float ? GDB_BCF_FLOAT_MISSING_BITS : (uint32_t)GDB_BCF_INT32_MISSING;
+  bool valid = field_valid(cm, c, f);
+  if (valid && !keep_spanning && (cm.cflags[c] & GDB_CF_DELETION)) {
+    const int64_t k = (int64_t)(inc_keys_sorted[t] / (uint64_t)nrows);
+    if (rec.start[k] > fr.begin[c]) valid = false;                                  // inc_is_spanning
+  }
+  if (valid) {
+    int n;
+    if (is_float) { const float v = cell_field<float>(fr, pl, f, c, n)[0]; if (gdb_float_valid(v)) bits = gdb_f2u(v); }
+    else { const int32_t v = cell_field<int32_t>(fr, pl, f, c, n)[0]; if (gdb_int_valid(v)) bits = (uint32_t)v; }
+  }
+  out[t] = bits;
+}
+
 // ---- medians of records with very many variant calls: one workgroup per (big record, median field) ------------------------
 constexpr int kBigRecord = 48;          // variant calls from which a record counts as big
 constexpr int kBigCapacity = 4096;      // values a workgroup holds in LDS; larger records keep the per-thread scan
@@ -1043,7 +1065,7 @@ struct DevicePipeline::Impl {
   DevBuf<SiteCtx> d_sx;
   DevBuf<uint64_t> med_keys, med_keys_sorted; DevBuf<uint32_t> med_idx, med_idx_sorted;
   DevBuf<int32_t> big_index, big_list; DevBuf<uint32_t> big_value; DevBuf<uint8_t> big_ok;
-  DevBuf<float> tie_buf; DevBuf<unsigned long long> tie_used;
+  DevBuf<float> tie_buf; DevBuf<unsigned long long> tie_used; DevBuf<uint32_t> scalar_pre;
   // entry text table
   DevBuf<unsigned long long> type_hkeys; DevBuf<int32_t> type_hrep, type_rep; DevBuf<uint8_t> type_hid, rtype;
   DevBuf<WalkCell> walk; DevBuf<int64_t> walk_inv;
@@ -1787,7 +1809,29 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
       tie.buf = S.tie_buf.p; tie.used = S.tie_used.p;
     }
   }
-  SiteCtx sx{fr, pl, cm, rec, hl, pc, nt, qw, so, med, big, tie};
+  // values of the scalar reducer fields per incidence (gdb_core.hpp: ScalarPre)
+  ScalarPre pre;
+  memset(&pre, 0, sizeof(pre));
+  for (int f = 0; f < GDB_MAX_FIELDS; ++f) pre.slot[f] = -1;
+  if (T > 0) {
+    std::vector<std::pair<int, int>> fields;   // (plan field, keep_spanning)
+    for (int i = 0; i < pl.n_info; ++i) {
+      const GdbFieldDesc& fd = pl.field[pl.info_field[i]];
+      if ((fd.combine_op == GDB_OP_MEDIAN || fd.combine_op == GDB_OP_SUM || fd.combine_op == GDB_OP_MEAN) && (fd.elem == GDB_ET_FLOAT || fd.elem == GDB_ET_INT))
+        fields.push_back(std::make_pair(pl.info_field[i], 0));
+    }
+    if (pl.qual_combine_op != GDB_OP_UNKNOWN && pl.f_QUAL >= 0) fields.push_back(std::make_pair(pl.f_QUAL, 1));
+    if (!fields.empty()) {
+      S.scalar_pre.ensure(fields.size() * (size_t)T);
+      for (size_t s = 0; s < fields.size(); ++s) {
+        hipLaunchKernelGGL(k_scalar_values, dim3(blocks_for(T)), dim3(kBlock), 0, st, fr, pl, cm, rec, (const uint64_t*)S.inc_keys_sorted.p, (const int64_t*)S.inc_vals_sorted.p, T,
+                           (int64_t)N, fields[s].first, fields[s].second, S.scalar_pre.p + s * (size_t)T);
+        pre.slot[fields[s].first] = (int8_t)s;
+      }
+      pre.val = S.scalar_pre.p; pre.stride = T; pre.enabled = 1;
+    }
+  }
+  SiteCtx sx{fr, pl, cm, rec, hl, pc, nt, qw, so, med, big, tie, pre};
   S.d_sx.ensure(1);
   HIP_CHECK(hipMemcpyAsync(S.d_sx.p, &sx, sizeof(SiteCtx), hipMemcpyHostToDevice, st));   // (sx outlives the copy: the function synchronises before it returns)
   STAGE("k_site_size");
