@@ -1,6 +1,7 @@
 """ctypes binding of libgenomicsdb_amd.so.  No fallback: a missing library is an ImportError-grade failure."""
 import ctypes
 import os
+import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libgenomicsdb_amd.so")
@@ -28,7 +29,7 @@ SYMBOLS = ["gdb_mi355_last_error", "gdb_mi355_device_count", "gdb_mi355_init", "
            "gdb_mi355_get_num_bytes_available", "gdb_mi355_read_next_byte", "gdb_mi355_read", "gdb_mi355_skip",
            "gdbamd_engine_create", "gdbamd_engine_destroy", "gdbamd_engine_num_fields", "gdbamd_engine_field_name",
            "gdbamd_engine_field_info", "gdbamd_engine_header", "gdbamd_engine_stage_cells", "gdbamd_engine_stage_cells_begin", "gdbamd_engine_stage_cells_append", "gdbamd_engine_stage_cells_end",
-           "gdbamd_engine_adopt_device_fragment", "gdbamd_engine_staged_info", "gdbamd_engine_set_reference", "gdbamd_engine_run_interval", "gdbamd_engine_split_point", "gdbamd_engine_save_fragment", "gdbamd_engine_load_fragment", "gdbamd_column_partition", "gdbamd_import_cells", "gdbamd_free"]
+           "gdbamd_engine_adopt_device_fragment", "gdbamd_engine_staged_info", "gdbamd_engine_set_reference", "gdbamd_engine_run_interval", "gdbamd_engine_prepare_interval", "gdbamd_engine_next_page", "gdbamd_engine_split_point", "gdbamd_engine_save_fragment", "gdbamd_engine_load_fragment", "gdbamd_column_partition", "gdbamd_import_cells", "gdbamd_free"]
 
 
 def lib():
@@ -38,6 +39,15 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libgenomicsdb_amd.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                            "the variant-combine path has no Python/CPU fallback")
+    # One HIP runtime per process: the torch wheel carries its own libamdhip64 / libhsa-runtime64 under a different soname, so
+    # a process that loads this library first (ROCm's runtime) and torch afterwards ends up with two runtimes, and the one that
+    # initialises second sees no GPU.  With torch loaded first this library binds to the runtime torch brought, and device
+    # pointers, streams and torch.distributed (RCCL) buffers are interchangeable (api.page_tensors, dist.gather_interval).
+    if "torch" not in sys.modules and not os.environ.get("GDBAMD_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = ctypes.CDLL(LIB_PATH)
     c = ctypes
     L.gdb_mi355_last_error.restype = c.c_char_p
@@ -79,6 +89,8 @@ def lib():
     L.gdbamd_column_partition.argtypes = [c.c_char_p, c.c_int, c.POINTER(c.c_int64), c.POINTER(c.c_int64)]
     L.gdbamd_import_cells.argtypes = [c.c_char_p, c.c_char_p, c.c_char_p, c.c_int, c.c_int64, c.c_int64, c.POINTER(c.c_void_p), c.POINTER(c.c_uint64), c.POINTER(c.c_int64)]
     L.gdbamd_free.argtypes = [c.c_void_p]
+    L.gdbamd_engine_prepare_interval.argtypes = [c.c_void_p, c.c_int64, c.c_int64]
+    L.gdbamd_engine_next_page.argtypes = [c.c_void_p, c.c_uint64, c.POINTER(c.c_void_p), c.POINTER(c.c_uint64)]
     _lib = L
     return L
 

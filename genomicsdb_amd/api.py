@@ -16,6 +16,13 @@ def _check(ok, what):
         raise GenomicsDBException("%s: %s" % (what, _lib.last_error()))
 
 
+class _DevicePage:
+    """an HBM page as an object torch can alias (CUDA array interface, version 2; ROCm builds of torch honour it)"""
+
+    def __init__(self, addr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(addr), False), "version": 2}
+
+
 class GenomicsDBQueryStream:
     """Byte stream of the combined gVCF (header first), the Python face of the six JNI entry points."""
 
@@ -154,6 +161,26 @@ class CombineEngine:
         rc = L.gdbamd_engine_run_interval(self._e, begin, end, arena_bytes, None, 0, ctypes.byref(n), ctypes.byref(st))
         _check(rc == 0, "run_interval")
         return None, st
+
+    def pages(self, begin=0, end=INT64_MAX - 1, arena_bytes=1 << 30):
+        """the VCF body of one column interval page by page, left in HBM: yields (device address, nbytes); an address is valid
+        until the next page is asked for"""
+        L = _lib.lib()
+        _check(L.gdbamd_engine_prepare_interval(self._e, begin, end) == 0, "prepare_interval")
+        p, n = ctypes.c_void_p(), ctypes.c_uint64()
+        while True:
+            rc = L.gdbamd_engine_next_page(self._e, arena_bytes, ctypes.byref(p), ctypes.byref(n))
+            _check(rc >= 0, "next_page")
+            if rc == 0:
+                return
+            yield p.value, n.value
+
+    def page_tensors(self, begin=0, end=INT64_MAX - 1, arena_bytes=1 << 30, device=None):
+        """pages() as torch uint8 tensors that alias the HBM page (no copy); a tensor is valid until the next page is asked for"""
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        for addr, n in self.pages(begin, end, arena_bytes):
+            yield torch.as_tensor(_DevicePage(addr, n), device=dev)
 
     def close(self):
         if self._e:

@@ -144,6 +144,25 @@ int gdbamd_engine_run_interval(void* e, int64_t qb, int64_t qe, uint64_t arena_b
   }, 1);
 }
 
+int gdbamd_engine_prepare_interval(void* e, int64_t qb, int64_t qe) {
+  return guarded([&]() -> int {
+    CombineEngine& eng = *((EngineHandle*)e)->eng;
+    eng.stage_reference_for(qb, qe);
+    eng.pipeline().prepare_interval(qb, qe);
+    return 0;
+  }, -1);
+}
+int gdbamd_engine_next_page(void* e, uint64_t arena_bytes, const void** dev_ptr, uint64_t* nbytes) {
+  return guarded([&]() -> int {
+    const char* p = nullptr;
+    uint64_t n = 0;
+    const bool more = ((EngineHandle*)e)->eng->pipeline().next_page(arena_bytes, &p, &n);
+    if (dev_ptr) *dev_ptr = more ? p : nullptr;
+    if (nbytes) *nbytes = more ? n : 0;
+    return more ? 1 : 0;
+  }, -1);
+}
+
 int gdbamd_engine_split_point(void* engine, int64_t qb, int64_t qe, int64_t max_columns, int64_t* piece_end) {
   try { *piece_end = ((EngineHandle*)engine)->eng->pipeline().split_point(qb, qe, max_columns); return 0; } catch (const std::exception& e) { g_last_error = e.what(); return -1; }
 }

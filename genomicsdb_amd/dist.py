@@ -48,3 +48,42 @@ def ordered_concat(body, dst=0):
     parts = [None] * dist.get_world_size() if dist.get_rank() == dst else None
     dist.gather_object(body, parts, dst=dst)
     return b"".join(parts) if parts is not None else None
+
+
+def ordered_concat_tensors(local, dst=0):
+    """Device-side flavour of ordered_concat: `local` is this rank's body as a 1-D uint8 tensor (in HBM under the "nccl"
+    backend = RCCL over xGMI, on the host under "gloo").  On rank `dst` returns ONE tensor holding the bodies of all ranks in
+    rank (= column partition) order, None on the other ranks.  Sizes travel by all_gather, the bytes point to point straight
+    into their place in the result - no staging through host memory, no pickling."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    mine = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
+    sizes = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(sizes, mine)
+    sizes = [int(x.item()) for x in sizes]
+    if rank != dst:
+        if sizes[rank]:
+            dist.send(local.contiguous(), dst=dst)
+        return None
+    out = torch.empty(sum(sizes), dtype=torch.uint8, device=local.device)
+    off = 0
+    for r in range(world):             # receive in rank order: a sender blocks until its turn, the result needs no reordering
+        view = out[off:off + sizes[r]]
+        if r == dst:
+            view.copy_(local)
+        elif sizes[r]:
+            dist.recv(view, src=r)
+        off += sizes[r]
+    return out
+
+
+def gather_interval(engine, begin, end, arena_bytes=1 << 30, dst=0):
+    """produce-combined-VCF over all ranks: every rank scans + combines its own column interval on its GPU (pages stay in HBM),
+    rank `dst` ends up with the VCF bodies of all partitions in column order as one uint8 tensor in its HBM."""
+    import torch
+    pages = [t.clone() for t in engine.page_tensors(begin, end, arena_bytes)]       # page memory is reused by the next page
+    local = torch.cat(pages) if pages else torch.empty(0, dtype=torch.uint8, device=torch.device("cuda", torch.cuda.current_device()))
+    return ordered_concat_tensors(local, dst=dst)

@@ -88,6 +88,13 @@ int gdbamd_engine_set_reference(void* engine, int64_t begin, const char* bases, 
 int gdbamd_engine_run_interval(void* engine, int64_t column_begin, int64_t column_end, uint64_t arena_bytes, char* host_out,
                                uint64_t host_cap, uint64_t* host_len, gdbamd_interval_stats* stats);
 
+/* the same in two steps, for consumers that take the pages where they are (HBM): prepare = sweep, site and sizing passes of
+ * the interval; next_page = the next <= arena_bytes of whole records.  *dev_ptr is device memory, valid until the next call
+ * on this engine.  next_page returns 1 (a page), 0 (interval exhausted) or -1 (error).
+ * (reference: the RWBuffer hand-over of GenomicsDBBCFGenerator::produce_next_batch, src/main/cpp/src/vcf/genomicsdb_bcf_generator.cc:96-125) */
+int gdbamd_engine_prepare_interval(void* engine, int64_t column_begin, int64_t column_end);
+int gdbamd_engine_next_page(void* engine, uint64_t arena_bytes, const void** dev_ptr, uint64_t* nbytes);
+
 /* ---- (3) host-only helpers (no device needed) ----------------------------------------------------------- */
 /* column partition of `rank` as the loader JSON defines it: begin from "column_partitions"[rank], end = next sorted begin - 1
  * (reference: GenomicsDBImportConfig::get_column_partition, src/main/cpp/src/config/json_config.cc:340-417) */

@@ -523,3 +523,27 @@ def test_vcf2tiledb_cli_imports_and_combines_in_line(gdb, tmp_path, name):
         r = subprocess.run([os.path.join(helpers.ROOT, "genomicsdb_amd", "gt_mpi_gather"), "-j", str(qf), "--produce-Broad-GVCF"], capture_output=True, timeout=120)
         assert r.returncode == 0, r.stderr.decode()
         assert r.stdout == helpers.golden_text("t0_1_2_vcf_at_0")
+
+
+def test_pages_stay_in_hbm_and_concat_over_rccl(gdb, tmp_path):
+    """the pull interface of the C ABI hands out the pages where they are (HBM); torch aliases them without a copy and
+    genomicsdb_amd.dist.gather_interval moves them with torch.distributed's "nccl" backend (= RCCL).  One GPU here, so the
+    group has one rank: the collective and the device buffers are exercised, the 2-rank ordering is covered by the gloo test."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from genomicsdb_amd import dist as gdist, synth
+    N, B, L = 200, 10_000_000, 3000
+    eng, q, cells = _c2_engine(gdb, tmp_path, N, B, L)
+    want, st = eng.run_interval(B, B + L - 1, arena_bytes=1 << 30)
+    got = b"".join(bytes(t.cpu().numpy().tobytes()) for t in eng.page_tensors(B, B + L - 1, arena_bytes=1 << 20))
+    assert st.num_records > 1000 and got == want
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        whole = gdist.gather_interval(eng, B, B + L - 1, arena_bytes=1 << 20, dst=0)
+        assert whole.is_cuda and whole.dtype == torch.uint8
+        assert bytes(whole.cpu().numpy().tobytes()) == want
+    finally:
+        dist.destroy_process_group()
+    eng.close()

@@ -45,6 +45,14 @@ def _worker(rank, world, port, q):
         body, nrec, _ = helpers.oracle_run(qj, cells, partition_begin=begin, with_header=False)
         dt, (recs,) = gdist.aggregate(1.0 + rank, [nrec])
         whole = gdist.ordered_concat(body)
+        # the tensor flavour (the one that runs over RCCL with the pages in HBM): same bytes, point to point into place
+        import torch
+        t = gdist.ordered_concat_tensors(torch.frombuffer(bytearray(body), dtype=torch.uint8))
+        assert (t is None) == (rank != 0)
+        if t is not None:
+            assert bytes(t.numpy().tobytes()) == whole
+        e = gdist.ordered_concat_tensors(torch.empty(0, dtype=torch.uint8) if rank == 1 else torch.frombuffer(bytearray(b"x"), dtype=torch.uint8))
+        assert e is None if rank else bytes(e.numpy().tobytes()) == b"x"
         q.put((rank, begin, end, sb, se, nrec, dt, recs, whole))
     finally:
         dist.destroy_process_group()
