@@ -1026,10 +1026,18 @@ __global__ void k_copy_offsets(const uint32_t* src, int64_t n, uint32_t base, ui
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[i] + base;
 }
-__global__ void k_gather_record_offsets(const uint64_t* chunk_off, int nchunks, int64_t P, uint64_t* rec_off) {
+// record offsets (the page splitter's table) and the largest record (one atomic per wavefront): the host only needs the two
+// totals unless the interval has to be paged
+__global__ void k_gather_record_offsets(const uint64_t* chunk_off, int nchunks, int64_t P, uint64_t* rec_off, unsigned long long* max_record) {
   int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k > P) return;
-  rec_off[k] = chunk_off[k * nchunks];
+  unsigned long long mine = 0;
+  if (k <= P) {
+    const uint64_t at = chunk_off[k * nchunks];
+    rec_off[k] = at;
+    if (k < P) mine = chunk_off[(k + 1) * nchunks] - at;
+  }
+  for (int d = 32; d > 0; d >>= 1) { const unsigned long long o = __shfl_xor(mine, d); mine = o > mine ? o : mine; }
+  if ((threadIdx.x & 63) == 0 && mine) atomicMax(max_record, mine);
 }
 
 }  // namespace
@@ -1059,7 +1067,7 @@ struct DevicePipeline::Impl {
   DevBuf<uint64_t> inc_keys, inc_keys_sorted; DevBuf<int64_t> inc_vals, inc_vals_sorted, hbase;
   DevBuf<uint32_t> lut_len, i2m_off; DevBuf<int8_t> i2m, gt_override; DevBuf<uint8_t> iflags;
   DevBuf<uint8_t> num_alleles, rflags; DevBuf<uint32_t> fmt_mask, prefix_len; DevBuf<char> site_staging, spill_buf; DevBuf<int32_t> spill_chunk; DevBuf<unsigned int> spill_next;
-  DevBuf<uint64_t> chunk_size, chunk_off, rec_off;
+  DevBuf<uint64_t> chunk_size, chunk_off, rec_off; DevBuf<unsigned long long> max_record;
   DevBuf<char> arena, temp;
   DevBuf<uint32_t> err; DevBuf<int32_t> counters;
   DevBuf<SiteCtx> d_sx;
@@ -1926,22 +1934,25 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   HIP_CHECK(hipMemsetAsync(S.chunk_size.p + nchunk_total, 0, sizeof(uint64_t), st));
   S.excl_scan(S.chunk_size.p, S.chunk_off.p, nchunk_total + 1);
   STAGE("k_gather_record_offsets");
-  hipLaunchKernelGGL(k_gather_record_offsets, dim3(blocks_for(P + 1)), dim3(kBlock), 0, st, S.chunk_off.p, nchunks, P, S.rec_off.p);
-  std::vector<uint64_t>& rec_off = S.iv.rec_off;
-  rec_off.resize((size_t)P + 1);
-  HIP_CHECK(hipMemcpyAsync(rec_off.data(), S.rec_off.p, (size_t)(P + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  S.max_record.ensure(1);
+  HIP_CHECK(hipMemsetAsync(S.max_record.p, 0, sizeof(unsigned long long), st));
+  hipLaunchKernelGGL(k_gather_record_offsets, dim3(blocks_for(P + 1)), dim3(kBlock), 0, st, S.chunk_off.p, nchunks, P, S.rec_off.p, S.max_record.p);
+  S.iv.rec_off.clear();             // fetched by next_page only when the interval does not fit one page
+  uint64_t totals[2] = {0, 0};      // bytes of the interval, bytes of its largest record
+  HIP_CHECK(hipMemcpyAsync(&totals[0], S.rec_off.p + P, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipMemcpyAsync(&totals[1], S.max_record.p, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   STAGE("before-sync-offsets");
   HIP_CHECK(hipEventRecord(ev[3], st));
   uint32_t eb = 0;
   HIP_CHECK(hipMemcpyAsync(&eb, S.err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
-  stats.bytes_out = rec_off[(size_t)P];
+  stats.bytes_out = totals[0];
   HIP_CHECK(hipEventElapsedTime(&stats.ms_sweep, ev[0], ev[1]));
   HIP_CHECK(hipEventElapsedTime(&stats.ms_site, ev[1], ev[2]));
   HIP_CHECK(hipEventElapsedTime(&stats.ms_size, ev[2], ev[3]));
   for (auto& e : ev) (void)hipEventDestroy(e);
   if (eb) throw GenomicsDBDeviceException("device error bits " + std::to_string(eb) + " (see GdbErr in gdb_types.h)");
-  for (int64_t k = 0; k < P; ++k) S.iv.max_record_bytes = std::max<uint64_t>(S.iv.max_record_bytes, rec_off[(size_t)k + 1] - rec_off[(size_t)k]);
+  S.iv.max_record_bytes = totals[1];
   S.iv.P = P; S.iv.nchunks = nchunks; S.iv.kp = 0;
   S.iv.sx = sx; S.iv.ex = ex; S.iv.ri = ri; S.iv.so = so; S.iv.rec = rec; S.iv.ac = ac; S.iv.resolved_whole = resolved_whole;
   S.iv.active = true;
@@ -1954,14 +1965,24 @@ bool DevicePipeline::next_page(uint64_t arena_bytes, const char** dev_ptr, uint6
   HIP_CHECK(hipSetDevice(S.device));
   hipStream_t st = S.stream;
   const int32_t N = S.hp.plan.num_query_rows;
-  const std::vector<uint64_t>& rec_off = iv.rec_off;
   const uint64_t arena_cap = std::max<uint64_t>(arena_bytes, iv.max_record_bytes);
   S.arena.ensure(std::min<uint64_t>(arena_cap, iv.stats.bytes_out) + 64);
   const int64_t kp = iv.kp, P = iv.P;
-  int64_t lo = kp + 1, hi = P;  // largest k_end with rec_off[k_end] - rec_off[kp] <= arena_cap
-  while (lo < hi) { int64_t mid = (lo + hi + 1) >> 1; if (rec_off[(size_t)mid] - rec_off[(size_t)kp] <= arena_cap) lo = mid; else hi = mid - 1; }
-  const int64_t ke = lo;
-  const uint64_t page_base = rec_off[(size_t)kp], page_bytes = rec_off[(size_t)ke] - page_base;
+  int64_t ke = P;
+  uint64_t page_base = 0, page_bytes = iv.stats.bytes_out;
+  if (kp > 0 || iv.stats.bytes_out > arena_cap) {   // paging: the record offsets are needed on the host
+    std::vector<uint64_t>& rec_off = iv.rec_off;
+    if (rec_off.empty()) {
+      rec_off.resize((size_t)P + 1);
+      HIP_CHECK(hipMemcpyAsync(rec_off.data(), S.rec_off.p, (size_t)(P + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+    }
+    int64_t lo = kp + 1, hi = P;  // largest k_end with rec_off[k_end] - rec_off[kp] <= arena_cap
+    while (lo < hi) { int64_t mid = (lo + hi + 1) >> 1; if (rec_off[(size_t)mid] - rec_off[(size_t)kp] <= arena_cap) lo = mid; else hi = mid - 1; }
+    ke = lo;
+    page_base = rec_off[(size_t)kp];
+    page_bytes = rec_off[(size_t)ke] - page_base;
+  }
   const int64_t np = ke - kp;
   hipEvent_t w0, w1, w2;
   HIP_CHECK(hipEventCreate(&w0)); HIP_CHECK(hipEventCreate(&w1)); HIP_CHECK(hipEventCreate(&w2));
