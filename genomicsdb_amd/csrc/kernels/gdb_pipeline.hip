@@ -1031,7 +1031,7 @@ __global__ void k_copy_offsets(const uint32_t* src, int64_t n, uint32_t base, ui
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[i] + base;
 }
-// record offsets (the page splitter's table) and the largest record (one atomic per wavefront): the host only needs the two
+// record offsets (the page splitter's table) and the largest record (one atomic per workgroup): the host only needs the two
 // totals unless the interval has to be paged
 __global__ void k_gather_record_offsets(const uint64_t* chunk_off, int nchunks, int64_t P, uint64_t* rec_off, unsigned long long* max_record) {
   int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1042,7 +1042,13 @@ __global__ void k_gather_record_offsets(const uint64_t* chunk_off, int nchunks, 
     if (k < P) mine = chunk_off[(k + 1) * nchunks] - at;
   }
   for (int d = 32; d > 0; d >>= 1) { const unsigned long long o = __shfl_xor(mine, d); mine = o > mine ? o : mine; }
-  if ((threadIdx.x & 63) == 0 && mine) atomicMax(max_record, mine);
+  __shared__ unsigned long long wave_max[kBlock / 64];
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kBlock / 64; ++w) mine = wave_max[w] > mine ? wave_max[w] : mine;
+    if (mine) atomicMax(max_record, mine);
+  }
 }
 
 }  // namespace
