@@ -547,3 +547,36 @@ def test_pages_stay_in_hbm_and_concat_over_rccl(gdb, tmp_path):
     finally:
         dist.destroy_process_group()
     eng.close()
+
+
+def test_empty_inputs(gdb, tmp_path):
+    """edges the reference handles by doing nothing: a query interval without any cell, an array without cells, a row range
+    whose samples have no data in the interval - the stream is the header alone (or an empty body), never an error"""
+    case = [c for c in CASES if c[0] == "t0_1_2_vcf_at_0"][0]
+    _, callsets, vid, ov, golden, mode = case
+    cells = helpers.cells_for(callsets, vid)
+    header = b"".join(l for l in helpers.golden_text(golden).splitlines(True) if l.startswith(b"#"))
+    # (1) interval beyond the last cell
+    q, pb = helpers.query_json(callsets, vid, {"query_column_ranges": [{"range_list": [{"low": 500_000_000, "high": 500_001_000}]}]}, mode)
+    want, nrec, _ = helpers.oracle_run(q, cells, partition_begin=pb)
+    s = gdb.GenomicsDBQueryStream(query_json=q, cells=cells, buffer_capacity=1 << 16)
+    got = s.read(); s.close()
+    assert nrec == 0 and got == want == header
+    # (2) interval between two cells of the array (a gap no interval covers)
+    q, pb = helpers.query_json(callsets, vid, {"query_column_ranges": [{"range_list": [{"low": 13000, "high": 13010}]}]}, mode)
+    want, nrec, _ = helpers.oracle_run(q, cells, partition_begin=pb)
+    s = gdb.GenomicsDBQueryStream(query_json=q, cells=cells, buffer_capacity=1 << 16)
+    got = s.read(); s.close()
+    assert got == want
+    # (3) no cells at all
+    q, pb = helpers.query_json(callsets, vid, ov, mode)
+    s = gdb.GenomicsDBQueryStream(query_json=q, cells=b"", buffer_capacity=1 << 16)
+    got = s.read(); s.close()
+    assert got == header
+    # (4) engine level: empty interval -> zero records, zero bytes, zero pages
+    eng = gdb.CombineEngine(q)
+    eng.stage_cells(cells)
+    body, st = eng.run_interval(600_000_000, 600_000_100, arena_bytes=1 << 20)
+    assert body == b"" and st.num_records == 0 and st.pages == 0
+    assert list(eng.pages(600_000_000, 600_000_100)) == []
+    eng.close()
