@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -414,6 +415,7 @@ __global__ void k_site_write(const SiteCtx* __restrict__ sxp, const char* __rest
 // Per-interval context in constant memory: plan, column pointers, per-cell metadata pointers.  Uniform accesses to it are
 // scalar loads through the scalar cache (a by-reference argument would turn each of them into a vector memory instruction).
 __constant__ EntryCtx c_ex;
+static std::mutex g_entry_ctx_mutex;   // see prepare_interval
 
 // the instantiations are kept out of line: one copy each instead of one per call site
 __device__ __noinline__ void entry_store(RecordInfo ri, int64_t c, char* dst, uint32_t* e) {
@@ -1865,6 +1867,10 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   S.chunk_size.ensure(nchunk_total + 1); S.chunk_off.ensure(nchunk_total + 2); S.rec_off.ensure(P + 2);
   RowIndex ri{S.row_ptr.p, S.perm.p, S.rm_begin.p};
   EntryCtx ex{fr, pl, cm, hl};
+  // c_ex is one symbol per device and process: pipelines of other host threads (one handle per thread, several handles per
+  // process is the reference's rule) must not upload theirs while this interval's slot kernels read it.  Held until the
+  // function returns, i.e. past the stream synchronisation behind the sizing pass.
+  std::unique_lock<std::mutex> entry_ctx_lock(g_entry_ctx_mutex);
   HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_ex), &ex, sizeof(EntryCtx), 0, hipMemcpyHostToDevice, st));
   // ---- S8a entry text table: record types, slots of (plain cell, type) / (record, heavy call) / no-call, text pool ------------
   if (T >= (1ll << 32)) throw GenomicsDBDeviceException("more than 2^32 (record, variant call) incidences in one interval: split the query interval");

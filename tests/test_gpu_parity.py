@@ -580,3 +580,49 @@ def test_empty_inputs(gdb, tmp_path):
     assert body == b"" and st.num_records == 0 and st.pages == 0
     assert list(eng.pages(600_000_000, 600_000_100)) == []
     eng.close()
+
+
+def test_two_handles_in_two_threads(gdb, tmp_path):
+    """the reference's threading rule at the boundary: one handle per thread, several handles per process.  Two engines with
+    different queries work at the same time from two host threads (ctypes releases the GIL); each must produce what it
+    produces alone (the per-interval context in constant memory is one symbol per process and is handed over under a lock;
+    this test exercises the threaded use, it does not prove the lock: the race window is a few hundred microseconds)."""
+    import hashlib
+    import threading
+    from genomicsdb_amd import synth
+    B = 10_000_000
+    specs = [(300, 4000, {}), (130, 6000, {"produce_GT_field": True})]
+    engines, wants = [], []
+    for i, (N, L, opts) in enumerate(specs):
+        g = synth.Generator(N, B, L + 2500, seed=synth.SEED + i)
+        cells, _ = g.chunk_bytes(B + L + 2500)
+        d = tmp_path / ("q%d" % i)
+        d.mkdir()
+        q = helpers.synth_query(d, N, B, B + L - 1)
+        q.update(opts)
+        e = gdb.CombineEngine(q)
+        e.stage_cells(cells)
+        e.set_reference(B, synth.reference(B, L + 4096, seed=synth.SEED + i))
+        body, st = e.run_interval(B, B + L - 1, arena_bytes=1 << 20)
+        engines.append((e, L))
+        wants.append(hashlib.sha256(body).hexdigest())
+    errors = []
+
+    def work(i):
+        e, L = engines[i]
+        try:
+            for rep in range(12):
+                body, _ = e.run_interval(B, B + L - 1, arena_bytes=1 << 20)
+                if hashlib.sha256(body).hexdigest() != wants[i]:
+                    errors.append((i, rep))
+        except Exception as ex:      # noqa: BLE001
+            errors.append((i, repr(ex)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert errors == []
+    for e, _ in engines:
+        e.close()
