@@ -71,7 +71,28 @@ def build_native(verbose=False):
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
+    build_jni(verbose)
     return LIB
+
+
+def build_jni(verbose=False):
+    """libtiledbgenomicsdb.so (the name the reference's Java loader asks for) = the six GenomicsDBQueryStream natives over the
+    C ABI.  Needs a JDK's jni.h: skipped (with a note) where there is none, as in the build image of this repo."""
+    jh = os.environ.get("JAVA_HOME", "")
+    inc = os.path.join(jh, "include") if jh else ""
+    if not inc or not os.path.exists(os.path.join(inc, "jni.h")):
+        if verbose:
+            print("JNI glue not built: no $JAVA_HOME/include/jni.h (csrc/jni/jni_query_stream.cc stays source only)", flush=True)
+        return None
+    out = os.path.join(PKG, "libtiledbgenomicsdb.so")
+    src = os.path.join(CSRC, "jni", "jni_query_stream.cc")
+    if _newer(out, [src, LIB]):
+        cmd = [HIPCC, "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + inc, "-I" + os.path.join(inc, "linux"), src, "-o", out, "-L" + PKG, "-lgenomicsdb_amd",
+               "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return out
 
 
 def build_oracle():
