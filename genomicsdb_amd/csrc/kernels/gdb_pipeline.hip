@@ -380,6 +380,34 @@ __global__ void __launch_bounds__(64) k_site_size(const SiteCtx* __restrict__ sx
   for (uint32_t q = 0; (q << 4) < nstaged; ++q) dst[q] = make_uint4(mine[4 * q], mine[4 * q + 1], mine[4 * q + 2], mine[4 * q + 3]);
   if (e) atomicOr(err, e);
 }
+// The parked fixed columns of a record (<= 256 bytes, 256-byte aligned staging slot) -> their place in the page, one wavefront
+// per record: lane j assembles the j-th ALIGNED destination word from its own source word and its left neighbour's
+// (v_alignbyte), so the record leaves as one coalesced store; only the two edge words go out bytewise.  Also writes the
+// newline of every record.
+__global__ void __launch_bounds__(256) k_site_copy(const uint32_t* __restrict__ prefix_len, const char* __restrict__ staging, int64_t k_begin, int64_t k_end,
+                                                   const uint64_t* __restrict__ chunk_off, int nchunks, uint64_t page_base, char* __restrict__ arena) {
+  const int64_t k = k_begin + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63u;
+  if (k >= k_end) return;
+  const uint32_t n = prefix_len[k];
+  char* rec = arena + (chunk_off[k * nchunks] - page_base);
+  if (lane == 0) arena[chunk_off[(k + 1) * nchunks] - page_base - 1] = '\n';
+  if (n > (uint32_t)kSiteStride) return;        // k_site_write formats or un-spills these
+  const uint32_t a = (uint32_t)((uintptr_t)rec & 3u);
+  const uint32_t cur = reinterpret_cast<const uint32_t*>(staging + (size_t)k * kSiteStride)[lane];
+  uint32_t prev = (uint32_t)__shfl_up((int)cur, 1);
+  if (lane == 0) prev = 0;
+  const uint32_t w = a ? __builtin_amdgcn_alignbyte(cur, prev, 4u - a) : cur;      // destination word `lane` = record bytes [4 lane - a, 4 lane - a + 4)
+  const int32_t r0 = (int32_t)(4u * lane) - (int32_t)a;
+  if (r0 >= 0 && r0 + 3 < (int32_t)n) {
+    *reinterpret_cast<uint32_t*>(rec + r0) = w;
+  } else {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) if (r0 + b >= 0 && r0 + b < (int32_t)n) rec[r0 + b] = (char)((w >> (8 * b)) & 0xFFu);
+  }
+  if (lane == 63 && a && 256 - (int32_t)a < (int32_t)n)                              // the 65th destination word of a full, misaligned record
+    for (int32_t r = 256 - (int32_t)a; r < (int32_t)n; ++r) rec[r] = (char)((cur >> (8 * (r & 3))) & 0xFFu);
+}
 __global__ void k_site_write(const SiteCtx* __restrict__ sxp, const char* __restrict__ staging, const char* __restrict__ spill_buf, const int32_t* __restrict__ spill_chunk, int64_t k_begin, int64_t k_end, const uint64_t* chunk_off, int nchunks,
                              uint64_t page_base, char* arena, uint32_t* err) {
   const SiteCtx& sx = *sxp;
@@ -389,15 +417,7 @@ __global__ void k_site_write(const SiteCtx* __restrict__ sxp, const char* __rest
   char* dst = arena + (chunk_off[k * nchunks] - page_base);
   const uint32_t n = sx.so.prefix_len[k];
   if (n <= (uint32_t)kSiteStride) {
-    const char* src = staging + (size_t)k * kSiteStride;
-    uint32_t i = 0;
-    for (; i < n && ((uintptr_t)(dst + i) & 3u); ++i) dst[i] = src[i];        // to the first destination word
-    for (; i + 4 <= n; i += 4) {                                              // whole destination words (source bytewise-assembled)
-      const uint32_t w = (uint32_t)(unsigned char)src[i] | ((uint32_t)(unsigned char)src[i + 1] << 8) | ((uint32_t)(unsigned char)src[i + 2] << 16) |
-                         ((uint32_t)(unsigned char)src[i + 3] << 24);
-      *reinterpret_cast<uint32_t*>(dst + i) = w;
-    }
-    for (; i < n; ++i) dst[i] = src[i];
+    return;                                     // parked whole in its staging slot: k_site_copy has written it (and the '\n')
   } else if (spill_chunk[k] >= 0) {
     const char* src = staging + (size_t)k * kSiteStride;
     for (uint32_t i = 0; i < (uint32_t)kSiteStride; ++i) dst[i] = src[i];
@@ -2011,6 +2031,7 @@ bool DevicePipeline::next_page(uint64_t arena_bytes, const char** dev_ptr, uint6
   HIP_CHECK(hipEventCreate(&w0)); HIP_CHECK(hipEventCreate(&w1)); HIP_CHECK(hipEventCreate(&w2));
   HIP_CHECK(hipEventRecord(w0, st));
   STAGE("k_site_write");
+  hipLaunchKernelGGL(k_site_copy, dim3(blocks_for(np, 4)), dim3(256), 0, st, (const uint32_t*)S.prefix_len.p, (const char*)S.site_staging.p, kp, ke, (const uint64_t*)S.chunk_off.p, iv.nchunks, page_base, S.arena.p);
   hipLaunchKernelGGL(k_site_write, dim3(blocks_for(np, 64)), dim3(64), 0, st, S.d_sx.p, (const char*)S.site_staging.p, (const char*)S.spill_buf.p, (const int32_t*)S.spill_chunk.p, kp, ke, S.chunk_off.p, iv.nchunks, page_base, S.arena.p, S.err.p);
   STAGE("k_assemble_write");
   const int wrun = write_run_length();
