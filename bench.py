@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--window-bp", type=int, default=1_000_000, help="columns per step (one batch); 1 Mb = 44.6 GB of VCF text at 1 000 samples")
     ap.add_argument("--arena-mb", type=int, default=49152, help="HBM page for the output text (one page per window at the defaults)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stream", action="store_true", help="skip the end-to-end leg through the query stream (gdb_mi355_read)")
     ap.add_argument("--cpu-sample-bp", type=int, default=12000, help="columns of the bounded CPU-baseline sample (~15 s of oracle time)")
     args = ap.parse_args()
 
@@ -145,12 +146,78 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(N, W, arena),
                          "alg_bytes_per_launch": alg_bytes_per_launch, "avg_launch_ms": avg_ms, "launches": int(launches)},
         }
+        if not args.no_stream and world == 1:         # the boundary GATK drives: header + body through gdb_mi355_read
+            out["stream_end_to_end"] = stream_end_to_end(N, B, min(W, Lbp), tmp, expect_body_bytes=None)
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(N, args.cpu_sample_bp, tmp)
     if out is not None:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def stream_end_to_end(N, B, W, tmp, expect_body_bytes=None):
+    """SURVEY 8(d) timing protocol, the part behind the device: t_stage (cells in host memory -> columnar fragment in HBM),
+    t_drain and the end-to-end rate of the C-ABI query stream (gdb_mi355_init_from_memory / gdb_mi355_read, the six JNI entry
+    points' twin) over one W-bp window of the same workload.  The caller's buffer is pinned host memory; the stream assembles
+    GDBAMD_DEVICE_PAGE_MB pages in two HBM arenas and drains them through its pinned ring while the next page is assembled."""
+    import torch
+    import genomicsdb_amd
+    from genomicsdb_amd import synth
+    import helpers
+    d = os.path.join(tmp, "stream")
+    os.makedirs(d, exist_ok=True)
+    # reference bases of the window as a FASTA the query names (positions before B are never asked for)
+    fasta = os.path.join(d, "synth_ref.fa")
+    with open(fasta, "wb") as f:
+        f.write(b">1\n")
+        f.write(b"N" * B)
+        f.write(synth.reference(B, W + 4096))
+        f.write(b"\n")
+    q = helpers.synth_query(d, N, B, B + W - 1)
+    q["reference_genome"] = fasta
+    gen = synth.Generator(N, B, W)
+    ptr, nbytes, ncells = gen.next_chunk(B + W)
+    t0 = time.time()
+    s = genomicsdb_amd.GenomicsDBQueryStream(query_json=q, cells=(ptr, nbytes), buffer_capacity=1 << 20)
+    t_stage = time.time() - t0
+    cap = 256 << 20
+    dst = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+    addr = dst.data_ptr()
+    total = 0
+    newlines = 0
+    t1 = time.time()
+    t_first = None
+    while True:
+        got = s.read_into(addr, cap)
+        if got <= 0:
+            break
+        if t_first is None:
+            t_first = time.time() - t1
+        total += got
+    t_read = time.time() - t1
+    st = s.stream_stats()
+    s.close()
+    gen.close()
+    body = int(st.bytes)
+    # records of the window: counted on the device copy of the same text would cost another pass; the stream's own page
+    # accounting gives the body bytes, the record count comes from one engine pass over the same cells
+    eng = genomicsdb_amd.CombineEngine(q, device=torch.cuda.current_device())
+    gen2 = synth.Generator(N, B, W)
+    p2, n2, _ = gen2.next_chunk(B + W)
+    eng.stage_cells_begin(); eng.stage_cells_append(p2, n2); eng.stage_cells_end()
+    _, est = eng.run_interval(B, B + W - 1, arena_bytes=48 << 30, fetch=False)
+    ok = int(est.bytes_out) == body
+    recs = int(est.num_records)
+    pcie_bound = 63.0   # GB/s, PCIe Gen5 x16 spec (MI355X_MICROARCH.md)
+    return {
+        "what": "header + body of one %d bp window of the same workload through gdb_mi355_read into a pinned 256 MiB buffer" % W,
+        "positions_per_sec": recs / t_read, "GBps": total / t_read / 1e9, "frac_of_pcie_spec": total / t_read / 1e9 / pcie_bound,
+        "t_stage_s": t_stage, "stage_GBps": nbytes / t_stage / 1e9, "cells": int(ncells), "cell_bytes": int(nbytes),
+        "t_drain_s": t_read, "t_first_byte_s": t_first, "bytes": int(total), "records": recs,
+        "t_waiting_for_copies_s": st.seconds_waiting_for_copies, "t_producing_s": st.seconds_producing,
+        "device_pages": int(st.pages), "ring_chunks": int(st.chunks), "body_bytes_match_engine": bool(ok),
+    }
 
 
 def pmc_traffic(N, W, arena):

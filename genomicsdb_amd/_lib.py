@@ -18,6 +18,11 @@ class IntervalStats(ctypes.Structure):
                 ("num_text_slots", ctypes.c_int64), ("text_pool_bytes", ctypes.c_int64)]
 
 
+class StreamStats(ctypes.Structure):
+    _fields_ = [("pages", ctypes.c_uint64), ("chunks", ctypes.c_uint64), ("bytes", ctypes.c_uint64),
+                ("seconds_waiting_for_copies", ctypes.c_double), ("seconds_producing", ctypes.c_double)]
+
+
 class DeviceColumn(ctypes.Structure):
     _fields_ = [("data", ctypes.c_void_p), ("off", ctypes.c_void_p)]
 
@@ -26,7 +31,7 @@ _lib = None
 
 # every symbol include/genomicsdb_amd.h declares
 SYMBOLS = ["gdb_mi355_last_error", "gdb_mi355_device_count", "gdb_mi355_init", "gdb_mi355_init_from_memory", "gdb_mi355_close",
-           "gdb_mi355_get_num_bytes_available", "gdb_mi355_read_next_byte", "gdb_mi355_read", "gdb_mi355_skip",
+           "gdb_mi355_get_num_bytes_available", "gdb_mi355_read_next_byte", "gdb_mi355_read", "gdb_mi355_skip", "gdb_mi355_get_stream_stats",
            "gdbamd_engine_create", "gdbamd_engine_destroy", "gdbamd_engine_num_fields", "gdbamd_engine_field_name",
            "gdbamd_engine_field_info", "gdbamd_engine_header", "gdbamd_engine_stage_cells", "gdbamd_engine_stage_cells_begin", "gdbamd_engine_stage_cells_append", "gdbamd_engine_stage_cells_end",
            "gdbamd_engine_adopt_device_fragment", "gdbamd_engine_staged_info", "gdbamd_engine_set_reference", "gdbamd_engine_run_interval", "gdbamd_engine_prepare_interval", "gdbamd_engine_next_page", "gdbamd_engine_split_point", "gdbamd_engine_save_fragment", "gdbamd_engine_load_fragment", "gdbamd_column_partition", "gdbamd_import_cells", "gdbamd_free"]
@@ -63,7 +68,8 @@ def lib():
     L.gdb_mi355_read_next_byte.restype = c.c_int
     L.gdb_mi355_read_next_byte.argtypes = [c.c_void_p]
     L.gdb_mi355_read.restype = c.c_int64
-    L.gdb_mi355_read.argtypes = [c.c_void_p, c.c_char_p, c.c_uint64, c.c_uint64]
+    L.gdb_mi355_read.argtypes = [c.c_void_p, c.c_void_p, c.c_uint64, c.c_uint64]
+    L.gdb_mi355_get_stream_stats.argtypes = [c.c_void_p, c.POINTER(StreamStats)]
     L.gdb_mi355_skip.restype = c.c_int64
     L.gdb_mi355_skip.argtypes = [c.c_void_p, c.c_uint64]
     L.gdbamd_engine_create.restype = c.c_void_p

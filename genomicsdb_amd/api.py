@@ -31,8 +31,12 @@ class GenomicsDBQueryStream:
         L = _lib.lib()
         if query_json is not None:
             txt = query_json if isinstance(query_json, str) else json.dumps(query_json)
-            self._cells = bytes(cells or b"")
-            self._h = L.gdb_mi355_init_from_memory(txt.encode(), self._cells, len(self._cells), buffer_capacity, int(produce_header_only))
+            if isinstance(cells, tuple):      # (host address, nbytes): cells that already lie in native memory (synthetic generator)
+                self._cells = None
+                self._h = L.gdb_mi355_init_from_memory(txt.encode(), ctypes.cast(cells[0], ctypes.c_char_p), cells[1], buffer_capacity, int(produce_header_only))
+            else:
+                self._cells = bytes(cells or b"")
+                self._h = L.gdb_mi355_init_from_memory(txt.encode(), self._cells, len(self._cells), buffer_capacity, int(produce_header_only))
         else:
             self._h = L.gdb_mi355_init((loader_json_file or "").encode(), (query_json_file or "").encode(), chr.encode(), start, end, rank,
                                        buffer_capacity, segment_size, int(is_bcf), int(produce_header_only), 0, 1)
@@ -54,6 +58,18 @@ class GenomicsDBQueryStream:
             if want is not None:
                 want -= got
         return b"".join(chunks)
+
+    def read_into(self, addr, n):
+        """up to n bytes of the stream into host memory at `addr` (e.g. a pinned torch tensor's data_ptr()); returns the count"""
+        got = _lib.lib().gdb_mi355_read(self._h, addr, 0, n)
+        if got < 0:
+            raise GenomicsDBException("read: " + _lib.last_error())
+        return got
+
+    def stream_stats(self):
+        st = _lib.StreamStats()
+        _check(_lib.lib().gdb_mi355_get_stream_stats(self._h, ctypes.byref(st)) == 0, "stream_stats")
+        return st
 
     def skip(self, n):
         return _lib.lib().gdb_mi355_skip(self._h, n)

@@ -51,6 +51,14 @@ int64_t gdb_mi355_skip(void* h, uint64_t n) {
   return guarded([&]() -> int64_t { return (int64_t)((GenomicsDBBCFGenerator*)h)->read_and_advance(nullptr, 0, n); }, (int64_t)-1);
 }
 
+int gdb_mi355_get_stream_stats(void* h, gdb_mi355_stream_stats* out) {
+  if (!h || !out) return -1;
+  const GenomicsDBBCFGenerator::DrainStats& d = ((GenomicsDBBCFGenerator*)h)->drain_stats();
+  out->pages = d.pages; out->chunks = d.chunks; out->bytes = d.bytes;
+  out->seconds_waiting_for_copies = d.seconds_waiting_for_copies; out->seconds_producing = d.seconds_producing;
+  return 0;
+}
+
 void* gdbamd_engine_create(const char* query_json_text, int device) {
   return guarded([&]() -> void* { auto* e = new EngineHandle; e->eng.reset(new CombineEngine(mini_json::parse(query_json_text), device)); return e; }, (void*)nullptr);
 }

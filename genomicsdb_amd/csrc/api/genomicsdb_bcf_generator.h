@@ -54,18 +54,42 @@ class GenomicsDBBCFGenerator {
   GenomicsDBBCFGenerator(const std::string& query_json_text, const uint8_t* cells, uint64_t nbytes, size_t buffer_capacity, bool produce_header_only);
   GenomicsDBBCFGenerator(const GenomicsDBBCFGenerator&) = delete;
   GenomicsDBBCFGenerator& operator=(const GenomicsDBBCFGenerator&) = delete;
+  ~GenomicsDBBCFGenerator();
   // n == SIZE_MAX: only produce the next batch
   size_t read_and_advance(uint8_t* dst, size_t offset, size_t n);
   uint8_t read_next_byte();
-  bool end() const { return m_done && m_next_read_idx >= m_buffer.size(); }
+  bool end() const { return m_done && m_ring_count == 0 && m_next_read_idx >= m_header.size(); }
   size_t get_buffer_capacity() const { return m_buffer_capacity; }
+  // the bytes of the current batch that have not been read yet (reference: get_read_batch() hands out the RWBuffer being read;
+  // include/vcf/genomicsdb_bcf_generator.h:33-93).  Valid until the next read / skip call.
+  struct RWBuffer { const uint8_t* m_buffer; size_t m_num_valid_bytes; size_t m_next_read_idx; };   // (member names of the reference's RWBuffer)
+  RWBuffer get_read_batch();
+  // drain statistics of the stream (bench: t_drain, end-to-end rate)
+  struct DrainStats { uint64_t pages = 0, chunks = 0, bytes = 0; double seconds_waiting_for_copies = 0, seconds_producing = 0; };
+  const DrainStats& drain_stats() const { return m_drain; }
  private:
   void common_init(bool produce_header_only);
-  void produce_next_batch();
+  // Stream machinery: the device assembles pages of up to device_page_bytes() (independent of the caller's buffer_capacity)
+  // alternately into two HBM arenas; a page leaves in chunks over a copy stream into a ring of pinned host buffers while the
+  // next page is being assembled; read() is served from the ring.
+  struct RingSlot { uint8_t* host = nullptr; size_t cap = 0, len = 0; void* done = nullptr; bool waited = false; };
+  bool advance_page();          // next page (of this or the next piece / interval) ready for draining; false: stream exhausted
+  void fill_ring();             // issue as many chunk copies as there are free slots
+  void pop_slot();
+  uint64_t device_page_bytes() const;
   std::unique_ptr<CombineEngine> m_engine;
   size_t m_buffer_capacity;
-  std::vector<uint8_t> m_buffer;  // current batch (host copy of the page drained from HBM)
-  size_t m_next_read_idx = 0;
+  std::vector<uint8_t> m_header;  // first bytes of the stream
+  size_t m_next_read_idx = 0;     // into the header while it lasts, then into the ring's head slot
+  std::vector<RingSlot> m_ring;
+  size_t m_ring_head = 0, m_ring_count = 0, m_slot_bytes = 0;
+  void* m_copy_stream = nullptr;                  // hipStream_t
+  void* m_arena_read[2] = {nullptr, nullptr};     // hipEvent_t: last copy out of arena i
+  DevicePipeline::PageTicket m_page, m_next_page;
+  bool m_page_valid = false, m_next_valid = false;
+  uint64_t m_page_off = 0;
+  int m_arena_toggle = 0;
+  DrainStats m_drain;
   bool m_done = false, m_interval_active = false, m_produce_header_only = false;
   unsigned m_query_column_interval_idx = 0;
   int64_t m_piece_begin = INT64_MIN, m_piece_end = 0, m_interval_end = 0;   // current piece of the current query interval

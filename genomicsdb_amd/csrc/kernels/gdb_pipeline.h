@@ -74,6 +74,12 @@ class DevicePipeline {
   // last column of the first piece of [qb, qe] that can be processed on its own with byte-identical output (cut before a cell begin)
   int64_t split_point(int64_t qb, int64_t qe, int64_t max_columns);
   bool next_page(uint64_t arena_bytes, const char** dev_ptr, uint64_t* nbytes);
+  // the same in two steps (asynchronous page production, two arenas): see gdb_pipeline.hip
+  struct PageTicket { int arena = 0; const char* dev = nullptr; uint64_t nbytes = 0; void* done_event = nullptr; };   // done_event: hipEvent_t recorded behind the page's kernels
+  bool begin_page(uint64_t arena_bytes, int arena_idx, PageTicket* ticket);
+  void finish_page(const PageTicket& ticket);
+  // hip_event (hipEvent_t) marks the consumer's last read of the arena; the next begin_page() into it waits for the event on the compute stream
+  void set_arena_release_event(int arena_idx, void* hip_event);
   const IntervalStats& interval_stats() const;
   // push interface built on the two calls above
   IntervalStats run_interval(int64_t qb, int64_t qe, uint64_t arena_bytes, PageCallback cb, void* user);

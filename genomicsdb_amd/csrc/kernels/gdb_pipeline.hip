@@ -434,16 +434,19 @@ __global__ void k_site_write(const SiteCtx* __restrict__ sxp, const char* __rest
 // ---- sample columns -------------------------------------------------------------------------------------------------
 // Per-interval context in constant memory: plan, column pointers, per-cell metadata pointers.  Uniform accesses to it are
 // scalar loads through the scalar cache (a by-reference argument would turn each of them into a vector memory instruction).
-__constant__ EntryCtx c_ex;
-static std::mutex g_entry_ctx_mutex;   // see prepare_interval
+// One slot per pipeline (leased for the pipeline's lifetime): the handles of one process no longer take turns on a single symbol.
+constexpr int kCtxSlots = 16;
+__constant__ EntryCtx c_ex[kCtxSlots];
+static std::mutex g_ctx_slot_mutex;
+static bool g_ctx_slot_used[kCtxSlots];
 
 // the instantiations are kept out of line: one copy each instead of one per call site
-__device__ __noinline__ void entry_store(RecordInfo ri, int64_t c, char* dst, uint32_t* e) {
-  (void)entry_emit(c_ex, ri, c, ByteSink(dst), e);
+__device__ __noinline__ void entry_store(int cs, RecordInfo ri, int64_t c, char* dst, uint32_t* e) {
+  (void)entry_emit(c_ex[cs], ri, c, ByteSink(dst), e);
 }
 // length of the text; its first `cap` bytes are left at dst (LDS)
-__device__ __noinline__ uint32_t entry_store_lds_capped(RecordInfo ri, int64_t c, gdb_lds_char* dst, uint32_t cap, uint32_t* e) {
-  return entry_emit(c_ex, ri, c, LdsCapSink(dst, cap), e).n;
+__device__ __noinline__ uint32_t entry_store_lds_capped(int cs, RecordInfo ri, int64_t c, gdb_lds_char* dst, uint32_t cap, uint32_t* e) {
+  return entry_emit(c_ex[cs], ri, c, LdsCapSink(dst, cap), e).n;
 }
 
 // ---- entry text table ---------------------------------------------------------------------------------------------
@@ -583,6 +586,7 @@ struct SlotTable {
   uint32_t light_base;    // = kMaxTypes: slots [0,kMaxTypes) are the no-call texts per type
   uint32_t heavy_base;
   uint32_t row_base;      // slots of (untabled record, sample): row_base + u * N + row
+  int32_t ctx;            // this pipeline's slot of c_ex
 };
 // PASS 0: ONE run of the field emitters gives the length of the text and, when it fits kSlotStride bytes (nearly always),
 // the text itself: formatted into a lane-private LDS strip, it leaves as 16-byte stores into the lane's inline slot.
@@ -596,7 +600,7 @@ template <int PASS> __device__ __forceinline__ void slot_fill(const SlotTable& s
       uint32_t* mine = strip + threadIdx.x * kStripWords;
       gdb_lds_char* txt = (gdb_lds_char*)mine;
       *txt = '\t';
-      len = 1u + entry_store_lds_capped(rinfo, c, txt + 1, (uint32_t)kSlotStride - 1u, e);
+      len = 1u + entry_store_lds_capped(st.ctx, rinfo, c, txt + 1, (uint32_t)kSlotStride - 1u, e);
       if (len <= (uint32_t)kSlotStride) {
         uint4* dst = reinterpret_cast<uint4*>(st.pool + (size_t)s * kSlotStride);
         for (uint32_t q = 0; (q << 4) < len; ++q) dst[q] = make_uint4(mine[4 * q], mine[4 * q + 1], mine[4 * q + 2], mine[4 * q + 3]);
@@ -606,14 +610,14 @@ template <int PASS> __device__ __forceinline__ void slot_fill(const SlotTable& s
   } else if (st.len[s] > (uint32_t)kSlotStride) {
     char* dst = st.pool_ovf + (size_t)st.ovf16[s] * 16;
     *dst = '\t';
-    entry_store(rinfo, c, dst + 1, e);
+    entry_store(st.ctx, rinfo, c, dst + 1, e);
   }
 }
 template <int PASS> __global__ void k_slots_nocall(SlotTable st, SiteOut so, const int32_t* type_rep, int ntypes, uint32_t* err) {
   const int t = threadIdx.x;
   if (blockIdx.x || t >= kMaxTypes) return;
   uint32_t e = 0;
-  if (t < ntypes) slot_fill<PASS>(st, (uint32_t)t, load_record_info(so, c_ex.hl, type_rep[t]), -1, &e);
+  if (t < ntypes) slot_fill<PASS>(st, (uint32_t)t, load_record_info(so, c_ex[st.ctx].hl, type_rep[t]), -1, &e);
   else if (PASS == 0) st.len[t] = 0;
   if (e) atomicOr(err, e);
 }
@@ -639,7 +643,7 @@ template <int PASS> __global__ void k_slots_light(SlotTable st, SiteOut so, cons
   for (uint32_t q = (uint32_t)sidx - tbase[i]; q; --q) m &= m - 1;     // the slot's rank among the cell's types -> its type
   const int t = __builtin_ctzll(m);
   uint32_t e = 0;
-  slot_fill<PASS>(st, s, load_record_info(so, c_ex.hl, type_rep[t]), c_base + (int64_t)i, &e);
+  slot_fill<PASS>(st, s, load_record_info(so, c_ex[st.ctx].hl, type_rep[t]), c_base + (int64_t)i, &e);
   if (e) atomicOr(err, e);
 }
 template <int PASS> __global__ void k_slots_heavy(SlotTable st, SiteOut so, const uint64_t* inc_keys_sorted, const int64_t* inc_cell, int64_t T, int64_t nrows,
@@ -648,7 +652,7 @@ template <int PASS> __global__ void k_slots_heavy(SlotTable st, SiteOut so, cons
   if (i >= T) return;
   uint32_t e = 0;
   const int64_t k = (int64_t)(inc_keys_sorted[i] / (uint64_t)nrows);
-  slot_fill<PASS>(st, st.heavy_base + (uint32_t)i, load_record_info(so, c_ex.hl, k), inc_cell[i], &e);
+  slot_fill<PASS>(st, st.heavy_base + (uint32_t)i, load_record_info(so, c_ex[st.ctx].hl, k), inc_cell[i], &e);
   if (e) atomicOr(err, e);
 }
 template <int PASS> __global__ void k_slots_untabled(SlotTable st, SiteOut so, RowIndex ri, RecordTable rec, const int32_t* urec, int64_t U, int32_t N, uint32_t* err) {
@@ -660,10 +664,10 @@ template <int PASS> __global__ void k_slots_untabled(SlotTable st, SiteOut so, R
   uint32_t e = 0;
   RowWalker w;
   w.init(ri, row, rec.start[k]);
-  const int64_t c = w.live(ri, c_ex.cm, rec.start[k]);
+  const int64_t c = w.live(ri, c_ex[st.ctx].cm, rec.start[k]);
   const uint32_t s = st.row_base + (uint32_t)i;
-  if (c >= 0 && (c_ex.cm.cflags[c] & GDB_CF_HEAVY)) { if (PASS == 0) st.len[s] = 0; }   // heavy calls have their incidence slot
-  else slot_fill<PASS>(st, s, load_record_info(so, c_ex.hl, k), c, &e);
+  if (c >= 0 && (c_ex[st.ctx].cm.cflags[c] & GDB_CF_HEAVY)) { if (PASS == 0) st.len[s] = 0; }   // heavy calls have their incidence slot
+  else slot_fill<PASS>(st, s, load_record_info(so, c_ex[st.ctx].hl, k), c, &e);
   if (e) atomicOr(err, e);
 }
 __global__ void k_slot_units(const uint32_t* len, int64_t S, uint32_t* units) {   // overflow-pool units of every slot
@@ -1101,8 +1105,14 @@ struct DevicePipeline::Impl {
   DevBuf<uint32_t> lut_len, i2m_off; DevBuf<int8_t> i2m, gt_override; DevBuf<uint8_t> iflags;
   DevBuf<uint8_t> num_alleles, rflags; DevBuf<uint32_t> fmt_mask, prefix_len; DevBuf<char> site_staging, spill_buf; DevBuf<int32_t> spill_chunk; DevBuf<unsigned int> spill_next;
   DevBuf<uint64_t> chunk_size, chunk_off, rec_off; DevBuf<unsigned long long> max_record;
-  DevBuf<char> arena, temp;
+  DevBuf<char> arena[2], temp;       // two output arenas: a consumer drains one while the next page is assembled into the other
   DevBuf<uint32_t> err; DevBuf<int32_t> counters;
+  int ctx_slot = -1;                 // this pipeline's element of c_ex
+  // persistent events (no create / destroy per interval) and one pinned block for every scalar that comes back to the host
+  hipEvent_t ev_prep[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_page[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};   // per arena: start, before / after the page assembly, page done
+  hipEvent_t arena_release[2] = {nullptr, nullptr};   // consumer's "this arena has been read" events (not owned)
+  struct HostBlock { uint64_t q[80]; uint32_t page_err[2]; } *hb = nullptr;   // hipHostMalloc
   DevBuf<SiteCtx> d_sx;
   DevBuf<uint64_t> med_keys, med_keys_sorted; DevBuf<uint32_t> med_idx, med_idx_sorted;
   DevBuf<int32_t> big_index, big_list; DevBuf<uint32_t> big_value; DevBuf<uint8_t> big_ok;
@@ -1159,23 +1169,33 @@ struct DevicePipeline::Impl {
     HIP_CHECK(rocprim::exclusive_scan(t, bytes, in, out, T(0), n, rocprim::plus<T>(), stream));
   }
   // a + b with one stream synchronisation (the usual "last exclusive-scan element + last count" total)
+  // (all read-backs land in the pinned block first: a copy to pageable memory would go through the runtime's staging path)
   template <class A, class B> int64_t read_back_sum(const A* pa, const B* pb) {
-    A a; B b;
-    HIP_CHECK(hipMemcpyAsync(&a, pa, sizeof(A), hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipMemcpyAsync(&b, pb, sizeof(B), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(&hb->q[0], pa, sizeof(A), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(&hb->q[1], pb, sizeof(B), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
+    A a; B b;
+    memcpy(&a, &hb->q[0], sizeof(A)); memcpy(&b, &hb->q[1], sizeof(B));
     return (int64_t)a + (int64_t)b;
   }
   // several scalars, one stream synchronisation
   struct Pending { void* dst; const void* src; size_t bytes; };
   void read_back_many(std::initializer_list<Pending> items) {
-    for (const Pending& it : items) HIP_CHECK(hipMemcpyAsync(it.dst, it.src, it.bytes, hipMemcpyDeviceToHost, stream));
+    size_t at = 0;
+    for (const Pending& it : items) {
+      if (at + it.bytes > sizeof(hb->q)) throw GenomicsDBDeviceException("read_back_many: pinned block too small");
+      HIP_CHECK(hipMemcpyAsync((char*)hb->q + at, it.src, it.bytes, hipMemcpyDeviceToHost, stream));
+      at += (it.bytes + 7) & ~(size_t)7;
+    }
     HIP_CHECK(hipStreamSynchronize(stream));
+    at = 0;
+    for (const Pending& it : items) { memcpy(it.dst, (const char*)hb->q + at, it.bytes); at += (it.bytes + 7) & ~(size_t)7; }
   }
   template <class T> T read_back(const T* p) {
     T v;
-    HIP_CHECK(hipMemcpyAsync(&v, p, sizeof(T), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(&hb->q[0], p, sizeof(T), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
+    memcpy(&v, &hb->q[0], sizeof(T));
     return v;
   }
   // records [k0, k0+n) in (type, position) order -> order[]
@@ -1219,13 +1239,29 @@ DevicePipeline::DevicePipeline(const HostPlan& hp, int device) : m_(new Impl) {
   up(m_->contigs, hp.contigs.data(), hp.contigs.size());
   m_->err.ensure(4);
   m_->counters.ensure(16 + kCountSpread);
+  for (auto& e : m_->ev_prep) HIP_CHECK(hipEventCreate(&e));
+  for (auto& a : m_->ev_page) for (auto& e : a) HIP_CHECK(hipEventCreate(&e));
+  HIP_CHECK(hipHostMalloc((void**)&m_->hb, sizeof(*m_->hb), hipHostMallocDefault));
+  memset(m_->hb, 0, sizeof(*m_->hb));
+  {
+    std::lock_guard<std::mutex> g(g_ctx_slot_mutex);
+    for (int i = 0; i < kCtxSlots && m_->ctx_slot < 0; ++i) if (!g_ctx_slot_used[i]) { g_ctx_slot_used[i] = true; m_->ctx_slot = i; }
+  }
+  if (m_->ctx_slot < 0) { this->~DevicePipeline(); throw GenomicsDBDeviceException("more than 16 engines alive in one process"); }
 }
 
 DevicePipeline::~DevicePipeline() {
   if (!m_) return;
+  if (m_->stream) (void)hipStreamSynchronize(m_->stream);
   m_->free_owned();
+  for (auto& p : m_->parts) for (void* b : p.bufs) (void)hipFree(b);
+  for (auto& e : m_->ev_prep) if (e) (void)hipEventDestroy(e);
+  for (auto& a : m_->ev_page) for (auto& e : a) if (e) (void)hipEventDestroy(e);
+  if (m_->hb) (void)hipHostFree(m_->hb);
+  if (m_->ctx_slot >= 0) { std::lock_guard<std::mutex> g(g_ctx_slot_mutex); g_ctx_slot_used[m_->ctx_slot] = false; }
   if (m_->stream) (void)hipStreamDestroy(m_->stream);
   delete m_;
+  m_ = nullptr;
 }
 
 void DevicePipeline::stage_fragment(const HostFragment& hf) {
@@ -1632,8 +1668,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   IntervalStats& stats = S.iv.stats;
   stats.num_cells = C;
   if (C == 0 || N == 0) return;
-  hipEvent_t ev[4];
-  for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
+  hipEvent_t* ev = S.ev_prep;
   HIP_CHECK(hipMemsetAsync(S.err.p, 0, sizeof(uint32_t), st));
   HIP_CHECK(hipMemsetAsync(S.counters.p, 0, (16 + kCountSpread) * sizeof(int32_t), st));
   HIP_CHECK(hipEventRecord(ev[0], st));
@@ -1672,8 +1707,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   hipLaunchKernelGGL(k_cell_window, dim3(1), dim3(64), 0, st, fr.begin, C, qb > INT64_MIN + S.max_span ? qb - S.max_span : INT64_MIN, qe, S.cwin.p);
   if (fr.nmarkers > 0) hipLaunchKernelGGL(k_cell_window, dim3(1), dim3(64), 0, st, fr.marker_begin, fr.nmarkers, qb, qe, S.cwin.p + 2);   // boundary markers in [qb, qe]
   int64_t cw[4] = {0, 0, 0, 0};
-  HIP_CHECK(hipMemcpyAsync(cw, S.cwin.p, (fr.nmarkers > 0 ? 4 : 2) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-  HIP_CHECK(hipStreamSynchronize(st));
+  S.read_back_many({{cw, S.cwin.p, (fr.nmarkers > 0 ? 4 : 2) * sizeof(int64_t)}});
   const int64_t c_base = cw[0], c_end = cw[1];
   const int64_t CW = c_end - c_base;
   if (CW <= 0) return;
@@ -1713,7 +1747,6 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   stats.num_records = P;
   if (P == 0) {
     stats.err_bits = S.read_back(S.err.p);
-    for (auto& e : ev) (void)hipEventDestroy(e);
     if (stats.err_bits) throw GenomicsDBDeviceException("device error bits " + std::to_string(stats.err_bits));
     return;
   }
@@ -1887,11 +1920,8 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   S.chunk_size.ensure(nchunk_total + 1); S.chunk_off.ensure(nchunk_total + 2); S.rec_off.ensure(P + 2);
   RowIndex ri{S.row_ptr.p, S.perm.p, S.rm_begin.p};
   EntryCtx ex{fr, pl, cm, hl};
-  // c_ex is one symbol per device and process: pipelines of other host threads (one handle per thread, several handles per
-  // process is the reference's rule) must not upload theirs while this interval's slot kernels read it.  Held until the
-  // function returns, i.e. past the stream synchronisation behind the sizing pass.
-  std::unique_lock<std::mutex> entry_ctx_lock(g_entry_ctx_mutex);
-  HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_ex), &ex, sizeof(EntryCtx), 0, hipMemcpyHostToDevice, st));
+  // every pipeline owns one element of c_ex (several handles per process is the reference's rule: they no longer serialise)
+  HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_ex), &ex, sizeof(EntryCtx), (size_t)S.ctx_slot * sizeof(EntryCtx), hipMemcpyHostToDevice, st));
   // ---- S8a entry text table: record types, slots of (plain cell, type) / (record, heavy call) / no-call, text pool ------------
   if (T >= (1ll << 32)) throw GenomicsDBDeviceException("more than 2^32 (record, variant call) incidences in one interval: split the query interval");
   S.type_hkeys.ensure(kTypeHash); S.type_hrep.ensure(kTypeHash); S.type_hid.ensure(kTypeHash); S.type_rep.ensure(kMaxTypes); S.rtype.ensure(P);
@@ -1931,7 +1961,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   S.slot_len.ensure(NS + 1); S.slot_units.ensure(NS + 1); S.slot_off.ensure(NS + 1); S.slot_desc.ensure(NS + 1);
   if (NS * (uint64_t)(kSlotStride / 16) >= (uint64_t)kOverflowBit) throw GenomicsDBDeviceException("entry text table exceeds 32 GiB: split the query interval");
   S.pool.ensure((size_t)NS * kSlotStride + 64);
-  SlotTable stt{S.slot_len.p, S.slot_off.p, S.pool.p, nullptr, (uint32_t)kMaxTypes, (uint32_t)(kMaxTypes + SL), (uint32_t)(kMaxTypes + SL + (uint64_t)T)};
+  SlotTable stt{S.slot_len.p, S.slot_off.p, S.pool.p, nullptr, (uint32_t)kMaxTypes, (uint32_t)(kMaxTypes + SL), (uint32_t)(kMaxTypes + SL + (uint64_t)T), (int32_t)S.ctx_slot};
   STAGE("k_slots<0>");
   hipLaunchKernelGGL(k_slots_nocall<0>, dim3(1), dim3(kMaxTypes), 0, st, stt, so, S.type_rep.p, ntypes, S.err.p);
   if (SL > 0) {
@@ -1982,18 +2012,14 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   hipLaunchKernelGGL(k_gather_record_offsets, dim3(blocks_for(P + 1)), dim3(kBlock), 0, st, S.chunk_off.p, nchunks, P, S.rec_off.p, S.max_record.p);
   S.iv.rec_off.clear();             // fetched by next_page only when the interval does not fit one page
   uint64_t totals[2] = {0, 0};      // bytes of the interval, bytes of its largest record
-  HIP_CHECK(hipMemcpyAsync(&totals[0], S.rec_off.p + P, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-  HIP_CHECK(hipMemcpyAsync(&totals[1], S.max_record.p, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   STAGE("before-sync-offsets");
   HIP_CHECK(hipEventRecord(ev[3], st));
   uint32_t eb = 0;
-  HIP_CHECK(hipMemcpyAsync(&eb, S.err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  HIP_CHECK(hipStreamSynchronize(st));
+  S.read_back_many({{&totals[0], S.rec_off.p + P, sizeof(uint64_t)}, {&totals[1], S.max_record.p, sizeof(uint64_t)}, {&eb, S.err.p, sizeof(uint32_t)}});
   stats.bytes_out = totals[0];
   HIP_CHECK(hipEventElapsedTime(&stats.ms_sweep, ev[0], ev[1]));
   HIP_CHECK(hipEventElapsedTime(&stats.ms_site, ev[1], ev[2]));
   HIP_CHECK(hipEventElapsedTime(&stats.ms_size, ev[2], ev[3]));
-  for (auto& e : ev) (void)hipEventDestroy(e);
   if (eb) throw GenomicsDBDeviceException("device error bits " + std::to_string(eb) + " (see GdbErr in gdb_types.h)");
   S.iv.max_record_bytes = totals[1];
   S.iv.P = P; S.iv.nchunks = nchunks; S.iv.kp = 0;
@@ -2001,15 +2027,19 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   S.iv.active = true;
 }
 
-bool DevicePipeline::next_page(uint64_t arena_bytes, const char** dev_ptr, uint64_t* nbytes) {
+// Page production in two steps so that a consumer can drain page p (copy engine, its own stream) while page p + 1 is being
+// assembled: begin_page() only enqueues the kernels of the next <= arena_bytes of whole records into arena `arena_idx`;
+// finish_page() waits for them and raises their error bits.  Before it overwrites an arena the compute stream waits for the
+// event the consumer registered with set_arena_release_event() (its last read of that arena).
+bool DevicePipeline::begin_page(uint64_t arena_bytes, int arena_idx, PageTicket* ticket) {
   Impl& S = *m_;
   Impl::IntervalState& iv = S.iv;
   if (!iv.active || iv.kp >= iv.P) { iv.active = false; return false; }
   HIP_CHECK(hipSetDevice(S.device));
   hipStream_t st = S.stream;
+  const int ai = arena_idx & 1;
   const int32_t N = S.hp.plan.num_query_rows;
   const uint64_t arena_cap = std::max<uint64_t>(arena_bytes, iv.max_record_bytes);
-  S.arena.ensure(std::min<uint64_t>(arena_cap, iv.stats.bytes_out) + 64);
   const int64_t kp = iv.kp, P = iv.P;
   int64_t ke = P;
   uint64_t page_base = 0, page_bytes = iv.stats.bytes_out;
@@ -2026,13 +2056,18 @@ bool DevicePipeline::next_page(uint64_t arena_bytes, const char** dev_ptr, uint6
     page_base = rec_off[(size_t)kp];
     page_bytes = rec_off[(size_t)ke] - page_base;
   }
+  if (S.arena_release[ai]) { HIP_CHECK(hipStreamWaitEvent(st, S.arena_release[ai], 0)); S.arena_release[ai] = nullptr; }
+  if (S.arena[ai].cap < page_bytes + 64) {   // (re)allocation frees memory a copy may still read: the stream has to be idle
+    HIP_CHECK(hipStreamSynchronize(st));
+    S.arena[ai].ensure(std::min<uint64_t>(arena_cap, iv.stats.bytes_out) + 64);
+  }
+  char* const arena = S.arena[ai].p;
   const int64_t np = ke - kp;
-  hipEvent_t w0, w1, w2;
-  HIP_CHECK(hipEventCreate(&w0)); HIP_CHECK(hipEventCreate(&w1)); HIP_CHECK(hipEventCreate(&w2));
-  HIP_CHECK(hipEventRecord(w0, st));
+  hipEvent_t* w = S.ev_page[ai];
+  HIP_CHECK(hipEventRecord(w[0], st));
   STAGE("k_site_write");
-  hipLaunchKernelGGL(k_site_copy, dim3(blocks_for(np, 4)), dim3(256), 0, st, (const uint32_t*)S.prefix_len.p, (const char*)S.site_staging.p, kp, ke, (const uint64_t*)S.chunk_off.p, iv.nchunks, page_base, S.arena.p);
-  hipLaunchKernelGGL(k_site_write, dim3(blocks_for(np, 64)), dim3(64), 0, st, S.d_sx.p, (const char*)S.site_staging.p, (const char*)S.spill_buf.p, (const int32_t*)S.spill_chunk.p, kp, ke, S.chunk_off.p, iv.nchunks, page_base, S.arena.p, S.err.p);
+  hipLaunchKernelGGL(k_site_copy, dim3(blocks_for(np, 4)), dim3(256), 0, st, (const uint32_t*)S.prefix_len.p, (const char*)S.site_staging.p, kp, ke, (const uint64_t*)S.chunk_off.p, iv.nchunks, page_base, arena);
+  hipLaunchKernelGGL(k_site_write, dim3(blocks_for(np, 64)), dim3(64), 0, st, S.d_sx.p, (const char*)S.site_staging.p, (const char*)S.spill_buf.p, (const int32_t*)S.spill_chunk.p, kp, ke, S.chunk_off.p, iv.nchunks, page_base, arena, S.err.p);
   STAGE("k_assemble_write");
   const int wrun = write_run_length();
   S.order_by_type(kp, np);
@@ -2042,16 +2077,26 @@ bool DevicePipeline::next_page(uint64_t arena_bytes, const char** dev_ptr, uint6
     S.resolved.ensure((size_t)np * iv.nchunks * kAsmRows);
     hipLaunchKernelGGL(k_assemble_size, wgrid, dim3(kAsmRows), 0, st, iv.ac, S.order.p, np, N, iv.nchunks, wrun, (uint64_t*)nullptr, S.resolved.p, kp);
   }
-  HIP_CHECK(hipEventRecord(w1, st));   // [w1, w2] brackets the page-assembly kernel alone (its duration feeds the roofline figure)
+  HIP_CHECK(hipEventRecord(w[1], st));   // [w1, w2] brackets the page-assembly kernel alone (its duration feeds the roofline figure)
   hipLaunchKernelGGL(k_assemble_write, wgrid, dim3(kAsmRows), 0, st, (const char*)S.pool.p, (const char*)S.pool_ovf.p, (const uint32_t*)S.prefix_len.p, (const uint2*)S.resolved.p,
-                     iv.resolved_whole ? (int64_t)0 : kp, (const int32_t*)S.order.p, np, iv.nchunks, wrun, (const uint64_t*)S.chunk_off.p, page_base, S.arena.p);
-  HIP_CHECK(hipEventRecord(w2, st));
-  HIP_CHECK(hipMemcpyAsync(&iv.stats.err_bits, S.err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  HIP_CHECK(hipStreamSynchronize(st));
+                     iv.resolved_whole ? (int64_t)0 : kp, (const int32_t*)S.order.p, np, iv.nchunks, wrun, (const uint64_t*)S.chunk_off.p, page_base, arena);
+  HIP_CHECK(hipEventRecord(w[2], st));
+  HIP_CHECK(hipMemcpyAsync(&S.hb->page_err[ai], S.err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipEventRecord(w[3], st));
+  iv.kp = ke;
+  ticket->arena = ai; ticket->dev = arena; ticket->nbytes = page_bytes; ticket->done_event = (void*)w[3];
+  return true;
+}
+
+void DevicePipeline::finish_page(const PageTicket& ticket) {
+  Impl& S = *m_;
+  Impl::IntervalState& iv = S.iv;
+  hipEvent_t* w = S.ev_page[ticket.arena & 1];
+  HIP_CHECK(hipEventSynchronize(w[3]));
   float ms_site = 0, ms_entry = 0;
-  HIP_CHECK(hipEventElapsedTime(&ms_site, w0, w1));
-  HIP_CHECK(hipEventElapsedTime(&ms_entry, w1, w2));
-  (void)hipEventDestroy(w0); (void)hipEventDestroy(w1); (void)hipEventDestroy(w2);
+  HIP_CHECK(hipEventElapsedTime(&ms_site, w[0], w[1]));
+  HIP_CHECK(hipEventElapsedTime(&ms_entry, w[1], w[2]));
+  iv.stats.err_bits = S.hb->page_err[ticket.arena & 1];
   iv.stats.ms_write += ms_site + ms_entry;
   iv.write_kernel_ms += ms_entry;
   iv.stats.write_launches++;
@@ -2059,9 +2104,16 @@ bool DevicePipeline::next_page(uint64_t arena_bytes, const char** dev_ptr, uint6
   iv.stats.pages++;
   iv.stats.ms_total = iv.stats.ms_sweep + iv.stats.ms_site + iv.stats.ms_size + iv.stats.ms_write;
   if (iv.stats.err_bits) throw GenomicsDBDeviceException("device error bits " + std::to_string(iv.stats.err_bits) + " (see GdbErr in gdb_types.h)");
-  iv.kp = ke;
-  *dev_ptr = S.arena.p;
-  *nbytes = page_bytes;
+}
+
+void DevicePipeline::set_arena_release_event(int arena_idx, void* hip_event) { m_->arena_release[arena_idx & 1] = (hipEvent_t)hip_event; }
+
+bool DevicePipeline::next_page(uint64_t arena_bytes, const char** dev_ptr, uint64_t* nbytes) {
+  PageTicket t;
+  if (!begin_page(arena_bytes, 0, &t)) return false;
+  finish_page(t);
+  *dev_ptr = t.dev;
+  *nbytes = t.nbytes;
   return true;
 }
 

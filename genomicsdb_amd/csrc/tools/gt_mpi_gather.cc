@@ -74,6 +74,8 @@ int main(int argc, char** argv) {
     FILE* out = out_name.empty() ? stdout : fopen(out_name.c_str(), "wb");
     if (!out) { std::cerr << "cannot open " << out_name << "\n"; return -1; }
     const size_t capacity = page_size ? page_size : (size_t)64u << 20;
+    // -p is the reference's combined_vcf_records_buffer_size_limit: here it also sizes the pages the device assembles
+    if (page_size) setenv("GDBAMD_DEVICE_PAGE_BYTES", std::to_string(page_size).c_str(), 1);
     const auto t0 = std::chrono::steady_clock::now();
     GenomicsDBBCFGenerator gen(loader_json, json_config, "", 0, 0, rank, capacity, segment_size, output_format.c_str(), false, false, true);
     std::vector<uint8_t> buf(std::max<size_t>(capacity, 1u << 20));

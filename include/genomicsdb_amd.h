@@ -28,7 +28,8 @@ int gdb_mi355_device_count(void);
 /* ---- (1) query stream ------------------------------------------------------------------------------------ */
 /* jniGenomicsDBInit: returns a handle or NULL.  chr == "" keeps the intervals of the query JSON; otherwise the
  * interval is contig offset + start-1 .. end-1 (1-based, inclusive).  is_bcf != 0 asks for BCF2 ("bu"), which this
- * build does not produce yet (returns NULL with an error); text VCF otherwise. */
+ * build does not produce yet (returns NULL with an error); text VCF otherwise.  buffer_capacity is what
+ * get_num_bytes_available reports (the reference's RWBuffer size); it does not size the device pages. */
 void* gdb_mi355_init(const char* loader_json_file, const char* query_json_file, const char* chr, int start, int end, int rank,
                      uint64_t buffer_capacity, uint64_t segment_size, int is_bcf, int produce_header_only,
                      int use_missing_values_only_not_vector_end, int keep_idx_fields_in_bcf_header);
@@ -40,6 +41,16 @@ uint64_t gdb_mi355_get_num_bytes_available(void* handle);       /* jniGenomicsDB
 int gdb_mi355_read_next_byte(void* handle);                     /* jniGenomicsDBReadNextByte: byte or -1 */
 int64_t gdb_mi355_read(void* handle, uint8_t* dst, uint64_t offset, uint64_t n); /* jniGenomicsDBRead: bytes copied, -1 on error */
 int64_t gdb_mi355_skip(void* handle, uint64_t n);               /* jniGenomicsDBSkip */
+/* How the stream was drained so far (not part of the reference's surface; bench / diagnostics).  The device assembles pages
+ * of GDBAMD_DEVICE_PAGE_MB (default 2048) MiB alternately into two HBM arenas - independently of buffer_capacity - and drains them
+ * through a ring of pinned host buffers (GDBAMD_RING_SLOTS x GDBAMD_RING_SLOT_MB, default 4 x 64 MiB) on a copy stream while the
+ * next page is assembled; gdb_mi355_read is served from the ring. */
+typedef struct gdb_mi355_stream_stats {
+  uint64_t pages, chunks, bytes;                 /* device pages produced, ring chunks copied, body bytes copied to the host */
+  double seconds_waiting_for_copies;             /* time read() spent blocked on a copy that had not landed yet */
+  double seconds_producing;                      /* host time inside the sweep / sizing / page launches (reader blocked) */
+} gdb_mi355_stream_stats;
+int gdb_mi355_get_stream_stats(void* handle, gdb_mi355_stream_stats* out);
 
 /* ---- (2) engine ------------------------------------------------------------------------------------------ */
 typedef struct gdbamd_interval_stats {

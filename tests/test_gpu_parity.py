@@ -33,8 +33,10 @@ def test_stream_matches_golden_and_oracle(gdb, case):
 
 
 @pytest.mark.parametrize("case", [c for c in SUPPORTED if c[5] == "query"][:8], ids=[c[0] for c in SUPPORTED if c[5] == "query"][:8])
-def test_stream_small_pages(gdb, case):
-    """buffer_capacity 128: one record per page, like the reference's '-p 128' batched_vcf runs"""
+def test_stream_small_pages(gdb, case, monkeypatch):
+    """128-byte device pages: one record per page, like the reference's '-p 128' batched_vcf runs (the device page size is
+    independent of buffer_capacity: GDBAMD_DEVICE_PAGE_BYTES sets it)"""
+    monkeypatch.setenv("GDBAMD_DEVICE_PAGE_BYTES", "128")
     name, callsets, vid, ov, golden, mode = case
     cells = helpers.cells_for(callsets, vid)
     q, pb = helpers.query_json(callsets, vid, ov, mode)
