@@ -27,14 +27,16 @@ class DeviceColumn(ctypes.Structure):
     _fields_ = [("data", ctypes.c_void_p), ("off", ctypes.c_void_p)]
 
 
+CELL_CHUNK_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64))
+
 _lib = None
 
 # every symbol include/genomicsdb_amd.h declares
 SYMBOLS = ["gdb_mi355_last_error", "gdb_mi355_device_count", "gdb_mi355_init", "gdb_mi355_init_from_memory", "gdb_mi355_close",
-           "gdb_mi355_get_num_bytes_available", "gdb_mi355_read_next_byte", "gdb_mi355_read", "gdb_mi355_skip", "gdb_mi355_get_stream_stats",
+           "gdb_mi355_get_num_bytes_available", "gdb_mi355_read_next_byte", "gdb_mi355_read", "gdb_mi355_skip", "gdb_mi355_peek", "gdb_mi355_get_stream_stats",
            "gdbamd_engine_create", "gdbamd_engine_destroy", "gdbamd_engine_num_fields", "gdbamd_engine_field_name",
            "gdbamd_engine_field_info", "gdbamd_engine_header", "gdbamd_engine_stage_cells", "gdbamd_engine_stage_cells_begin", "gdbamd_engine_stage_cells_append", "gdbamd_engine_stage_cells_end",
-           "gdbamd_engine_adopt_device_fragment", "gdbamd_engine_staged_info", "gdbamd_engine_set_reference", "gdbamd_engine_run_interval", "gdbamd_engine_prepare_interval", "gdbamd_engine_next_page", "gdbamd_engine_split_point", "gdbamd_engine_save_fragment", "gdbamd_engine_load_fragment", "gdbamd_column_partition", "gdbamd_import_cells", "gdbamd_free"]
+           "gdbamd_engine_adopt_device_fragment", "gdbamd_engine_open_array", "gdbamd_engine_open_memory_cells", "gdbamd_engine_open_cell_callback", "gdbamd_engine_cover", "gdbamd_engine_staged_info", "gdbamd_engine_set_reference", "gdbamd_engine_run_interval", "gdbamd_engine_prepare_interval", "gdbamd_engine_next_page", "gdbamd_engine_split_point", "gdbamd_engine_save_fragment", "gdbamd_engine_load_fragment", "gdbamd_column_partition", "gdbamd_import_cells", "gdbamd_free"]
 
 
 def lib():
@@ -69,6 +71,7 @@ def lib():
     L.gdb_mi355_read_next_byte.argtypes = [c.c_void_p]
     L.gdb_mi355_read.restype = c.c_int64
     L.gdb_mi355_read.argtypes = [c.c_void_p, c.c_void_p, c.c_uint64, c.c_uint64]
+    L.gdb_mi355_peek.argtypes = [c.c_void_p, c.POINTER(c.c_void_p), c.POINTER(c.c_uint64)]
     L.gdb_mi355_get_stream_stats.argtypes = [c.c_void_p, c.POINTER(StreamStats)]
     L.gdb_mi355_skip.restype = c.c_int64
     L.gdb_mi355_skip.argtypes = [c.c_void_p, c.c_uint64]
@@ -86,6 +89,10 @@ def lib():
     L.gdbamd_engine_stage_cells_append.argtypes = [c.c_void_p, c.c_void_p, c.c_uint64]
     L.gdbamd_engine_stage_cells_end.argtypes = [c.c_void_p]
     L.gdbamd_engine_adopt_device_fragment.argtypes = [c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p, c.c_void_p, c.POINTER(DeviceColumn), c.c_int, c.c_uint64]
+    L.gdbamd_engine_open_array.argtypes = [c.c_void_p, c.c_char_p]
+    L.gdbamd_engine_open_memory_cells.argtypes = [c.c_void_p, c.c_void_p, c.c_uint64]
+    L.gdbamd_engine_open_cell_callback.argtypes = [c.c_void_p, CELL_CHUNK_FN, c.c_void_p]
+    L.gdbamd_engine_cover.argtypes = [c.c_void_p, c.c_int64, c.POINTER(c.c_int64), c.POINTER(c.c_int64)]
     L.gdbamd_engine_staged_info.argtypes = [c.c_void_p, c.POINTER(c.c_int64), c.POINTER(c.c_uint64)]
     L.gdbamd_engine_set_reference.argtypes = [c.c_void_p, c.c_int64, c.c_char_p, c.c_uint64]
     L.gdbamd_engine_run_interval.argtypes = [c.c_void_p, c.c_int64, c.c_int64, c.c_uint64, c.c_void_p, c.c_uint64, c.POINTER(c.c_uint64), c.POINTER(IntervalStats)]

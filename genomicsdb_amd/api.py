@@ -130,6 +130,37 @@ class CombineEngine:
     def stage_cells_end(self):
         _check(_lib.lib().gdbamd_engine_stage_cells_end(self._e) == 0, "stage_cells_end")
 
+    # ---- arrays larger than the staging budget: column windows streamed through HBM (see include/genomicsdb_amd.h) ----
+    def open_array(self, directory):
+        _check(_lib.lib().gdbamd_engine_open_array(self._e, str(directory).encode()) == 0, "open_array")
+
+    def open_memory_cells(self, cells):
+        """cells: bytes, or (host address, nbytes); kept alive by this object"""
+        if isinstance(cells, tuple):
+            addr, n = cells
+        else:
+            self._keep.append(bytes(cells))
+            addr, n = ctypes.cast(ctypes.c_char_p(self._keep[-1]), ctypes.c_void_p).value, len(self._keep[-1])
+        _check(_lib.lib().gdbamd_engine_open_memory_cells(self._e, addr, n) == 0, "open_memory_cells")
+
+    def open_cell_callback(self, next_chunk):
+        """next_chunk() -> (host address, nbytes) of the next whole-column chunk (valid until the next call) or None at the end"""
+        def _fn(_user, pp, pn):
+            r = next_chunk()
+            if r is None:
+                return 0
+            pp[0], pn[0] = r[0], r[1]
+            return 1
+        cb = _lib.CELL_CHUNK_FN(_fn)
+        self._keep.append(cb)
+        _check(_lib.lib().gdbamd_engine_open_cell_callback(self._e, cb, None) == 0, "open_cell_callback")
+
+    def cover(self, column):
+        """stage windows until `column` is covered; returns (lo, hi): the query positions the staged fragment serves"""
+        lo, hi = ctypes.c_int64(), ctypes.c_int64()
+        _check(_lib.lib().gdbamd_engine_cover(self._e, column, ctypes.byref(lo), ctypes.byref(hi)) == 0, "cover")
+        return lo.value, hi.value
+
     def adopt_device_fragment(self, ncells, row_ptr, begin_ptr, end_ptr, cols, reference_cell_bytes, keepalive=None):
         """cols: list of (data_ptr, off_ptr_or_0) device addresses, one per plan field."""
         arr = (_lib.DeviceColumn * len(cols))()

@@ -76,19 +76,19 @@ def build_native(verbose=False):
 
 
 def build_jni(verbose=False):
-    """libtiledbgenomicsdb.so (the name the reference's Java loader asks for) = the six GenomicsDBQueryStream natives over the
-    C ABI.  Needs a JDK's jni.h: skipped (with a note) where there is none, as in the build image of this repo."""
+    """libtiledbgenomicsdb.so (the name the reference's Java loader asks for) = the GenomicsDBQueryStream natives and the
+    one-time initialiser over the C ABI.  Compiled against a JDK's jni.h when $JAVA_HOME has one, else against the minimal
+    stand-in csrc/jni/stub/jni.h (specification function-table indices only), so the glue is built and symbol-checked always."""
     jh = os.environ.get("JAVA_HOME", "")
     inc = os.path.join(jh, "include") if jh else ""
-    if not inc or not os.path.exists(os.path.join(inc, "jni.h")):
-        if verbose:
-            print("JNI glue not built: no $JAVA_HOME/include/jni.h (csrc/jni/jni_query_stream.cc stays source only)", flush=True)
-        return None
+    if inc and os.path.exists(os.path.join(inc, "jni.h")):
+        incs = ["-I" + inc, "-I" + os.path.join(inc, "linux")]
+    else:
+        incs = ["-I" + os.path.join(CSRC, "jni", "stub")]
     out = os.path.join(PKG, "libtiledbgenomicsdb.so")
     src = os.path.join(CSRC, "jni", "jni_query_stream.cc")
-    if _newer(out, [src, LIB]):
-        cmd = [HIPCC, "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + inc, "-I" + os.path.join(inc, "linux"), src, "-o", out, "-L" + PKG, "-lgenomicsdb_amd",
-               "-Wl,-rpath,$ORIGIN"]
+    if _newer(out, [src, LIB, os.path.join(CSRC, "jni", "stub", "jni.h"), os.path.join(ROOT, "include", "genomicsdb_amd.h")]):
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall"] + incs + [src, "-o", out, "-L" + PKG, "-lgenomicsdb_amd", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -102,6 +102,7 @@ def build_oracle():
 
 def build_hostsim():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "hostsim")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "jni_harness")])   # JVM-less driver of the JNI glue (tests only)
 
 
 if __name__ == "__main__":

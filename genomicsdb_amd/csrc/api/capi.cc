@@ -51,6 +51,18 @@ int64_t gdb_mi355_skip(void* h, uint64_t n) {
   return guarded([&]() -> int64_t { return (int64_t)((GenomicsDBBCFGenerator*)h)->read_and_advance(nullptr, 0, n); }, (int64_t)-1);
 }
 
+int gdb_mi355_peek(void* h, const uint8_t** ptr, uint64_t* n) {
+  if (!h || !ptr || !n) return -1;
+  return guarded([&]() -> int {
+    auto* g = (GenomicsDBBCFGenerator*)h;
+    for (;;) {
+      const GenomicsDBBCFGenerator::RWBuffer b = g->get_read_batch();
+      if (b.m_num_valid_bytes > b.m_next_read_idx) { *ptr = b.m_buffer + b.m_next_read_idx; *n = b.m_num_valid_bytes - b.m_next_read_idx; return 1; }
+      if (g->end() || b.m_buffer == nullptr) { *ptr = nullptr; *n = 0; return 0; }
+      g->read_and_advance(nullptr, 0, SIZE_MAX);     // an exhausted batch: produce the next one
+    }
+  }, -1);
+}
 int gdb_mi355_get_stream_stats(void* h, gdb_mi355_stream_stats* out) {
   if (!h || !out) return -1;
   const GenomicsDBBCFGenerator::DrainStats& d = ((GenomicsDBBCFGenerator*)h)->drain_stats();
@@ -105,6 +117,21 @@ int gdbamd_engine_adopt_device_fragment(void* e, int64_t ncells, const int32_t* 
     eng.reference_cell_bytes = reference_cell_bytes;
     eng.has_cells = ncells > 0;
     eng.num_cells = ncells;
+    return 0;
+  }, 1);
+}
+int gdbamd_engine_open_array(void* e, const char* dir) { return guarded([&]() -> int { ((EngineHandle*)e)->eng->open_array(dir ? dir : ""); return 0; }, 1); }
+int gdbamd_engine_open_memory_cells(void* e, const uint8_t* cells, uint64_t nbytes) {
+  return guarded([&]() -> int { ((EngineHandle*)e)->eng->open_memory_cells(cells, nbytes); return 0; }, 1);
+}
+int gdbamd_engine_open_cell_callback(void* e, gdbamd_cell_chunk_fn fn, void* user) {
+  return guarded([&]() -> int { ((EngineHandle*)e)->eng->open_cell_callback(fn, user); return 0; }, 1);
+}
+int gdbamd_engine_cover(void* e, int64_t column, int64_t* lo, int64_t* hi) {
+  return guarded([&]() -> int {
+    const CombineEngine::Coverage c = ((EngineHandle*)e)->eng->cover(column);
+    if (lo) *lo = c.lo;
+    if (hi) *hi = c.hi;
     return 0;
   }, 1);
 }

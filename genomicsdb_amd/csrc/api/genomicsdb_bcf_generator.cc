@@ -2,6 +2,10 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <chrono>
 #include <climits>
 #include <thread>
@@ -29,12 +33,14 @@ void CombineEngine::stage_cells(const uint8_t* cells, uint64_t nbytes) {
 
 void CombineEngine::stage_cells_begin() {
   reference_cell_bytes = 0; num_cells = 0; has_cells = false; min_begin = INT64_MAX; max_end = 0;
+  if (m_src.fd >= 0) { ::close(m_src.fd); m_src.fd = -1; }
+  m_src.kind = SRC_NONE;
   m_pipe->begin_staging();
 }
 void CombineEngine::stage_cells_append(const uint8_t* cells, uint64_t nbytes) {
-  if (!m_layout) m_layout.reset(new CellStreamLayout(m_qc, m_hp));
   // the stream goes to HBM as it is and is taken apart there (DevicePipeline::append_cells)
-  const DevicePipeline::CellStreamInfo info = m_pipe->append_cells(cells, nbytes, m_layout->schema, m_layout->attr_to_field, m_layout->row_map);
+  const CellStreamLayout& L = layout();
+  const DevicePipeline::CellStreamInfo info = m_pipe->append_cells(cells, nbytes, L.schema, L.attr_to_field, L.row_map);
   reference_cell_bytes += info.reference_cell_bytes;
   num_cells += info.ncells;
   if (info.ncells > 0) { min_begin = std::min(min_begin, info.min_begin); max_end = std::max(max_end, info.max_end); }
@@ -44,9 +50,39 @@ void CombineEngine::stage_cells_end() {
   m_pipe->finish_staging();
 }
 
+const CellStreamLayout& CombineEngine::layout() {
+  if (!m_layout) m_layout.reset(new CellStreamLayout(m_qc, m_hp));
+  return *m_layout;
+}
+std::vector<ColumnLayout> CombineEngine::expected_columns() {
+  const CellStreamLayout& L = layout();
+  std::vector<ColumnLayout> out((size_t)m_hp.plan.nfields);
+  for (size_t ai = 0; ai < L.schema.attrs.size(); ++ai) {
+    const int f = L.attr_to_field[ai];
+    if (f < 0) continue;
+    out[(size_t)f].var = L.schema.attrs[ai].var; out[(size_t)f].elem_size = L.schema.attrs[ai].elem_size; out[(size_t)f].fixed_num = L.schema.attrs[ai].num;
+  }
+  return out;
+}
+// what a fragment file depends on besides the cells: the array schema and the row <-> callset assignment
+uint64_t CombineEngine::schema_hash() {
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } };
+  const CellStreamLayout& L = layout();
+  for (const auto& a : L.schema.attrs) { mix(a.name.data(), a.name.size() + 1); const int32_t d[4] = {(int32_t)a.elem, a.var ? 1 : 0, a.num, a.elem_size}; mix(d, sizeof(d)); }
+  const VidMapper& vid = m_qc.get_vid_mapper();
+  for (int64_t r = 0; r < vid.get_num_callsets(); ++r) { std::string name; vid.get_callset_name(r, name); mix(name.data(), name.size() + 1); }
+  for (const CallSetInfo& c : vid.get_callsets()) {   // which sample of which file feeds which row
+    mix(c.m_name.data(), c.m_name.size() + 1); mix(c.m_filename.data(), c.m_filename.size() + 1);
+    const int64_t d[2] = {c.m_row_idx, c.m_idx_in_file}; mix(d, sizeof(d));
+  }
+  return h ? h : 1;
+}
+
 void CombineEngine::save_fragment(const std::string& path) {
   FragmentFileMeta meta;
   meta.reference_cell_bytes = reference_cell_bytes; meta.min_begin = min_begin; meta.max_end = max_end; meta.ncells = num_cells;
+  meta.schema_hash = schema_hash();
   m_pipe->save_fragment(path, meta);
 }
 void CombineEngine::load_fragment(const std::string& path) {
@@ -54,8 +90,168 @@ void CombineEngine::load_fragment(const std::string& path) {
   const VariantQueryConfig& qc = m_qc;
   for (uint64_t q = 0; q < qc.get_num_rows_to_query(); ++q)
     if (qc.get_array_row_idx_for_query_row_idx(q) != (int64_t)q) throw GenomicsDBConfigException("a columnar fragment file serves queries over all rows only");
-  const FragmentFileMeta meta = m_pipe->load_fragment(path);
+  const FragmentFileMeta meta = m_pipe->load_fragment(path, expected_columns(), schema_hash());
   reference_cell_bytes = meta.reference_cell_bytes; min_begin = meta.min_begin; max_end = meta.max_end; num_cells = meta.ncells; has_cells = num_cells > 0;
+  m_src = Source();
+}
+
+// ---- windowed array access ------------------------------------------------------------------------------------------------
+CombineEngine::~CombineEngine() {
+  if (m_src.fd >= 0) ::close(m_src.fd);
+  if (m_src.chunk) (void)hipHostFree(m_src.chunk);
+}
+
+uint64_t CombineEngine::staging_budget_bytes() const {
+  if (const char* e = getenv("GDBAMD_STAGE_BUDGET_BYTES")) return (uint64_t)std::max<long long>(1, atoll(e));
+  if (const char* e = getenv("GDBAMD_STAGE_BUDGET_MB")) return (uint64_t)std::max<long long>(1, atoll(e)) << 20;
+  return 8192ull << 20;   // cell bytes per window; the columnar fragment, its row index and the per-piece buffers come on top
+}
+
+void CombineEngine::open_memory_cells(const uint8_t* cells, uint64_t nbytes) {
+  if (m_src.fd >= 0) ::close(m_src.fd);
+  const Source keep = m_src;
+  m_src = Source();
+  m_src.chunk = keep.chunk; m_src.chunk_cap = keep.chunk_cap;
+  m_src.kind = SRC_CELLS_MEMORY; m_src.mem = cells; m_src.size = nbytes;
+  rewind_source();
+}
+
+void CombineEngine::open_cell_callback(CellChunkFn fn, void* user) {
+  if (m_src.fd >= 0) ::close(m_src.fd);
+  const Source keep = m_src;
+  m_src = Source();
+  m_src.chunk = keep.chunk; m_src.chunk_cap = keep.chunk_cap;
+  m_src.kind = SRC_CALLBACK; m_src.fn = fn; m_src.fn_user = user;
+  rewind_source();
+}
+
+void CombineEngine::open_array(const std::string& dir) {
+  if (m_src.fd >= 0) ::close(m_src.fd);
+  const Source keep = m_src;
+  m_src = Source();
+  m_src.chunk = keep.chunk; m_src.chunk_cap = keep.chunk_cap;
+  const std::string frag = dir + "/fragment.gdbamd", cells = dir + "/cells.bin";
+  struct stat cs;
+  const bool have_cells = ::stat(cells.c_str(), &cs) == 0;
+  // columnar fragment first: file -> HBM copies, no parsing.  It has to serve this query (all rows, callset order), to have been
+  // written under the same vid / callset mapping and, when it names a cells.bin, from the one that is there now.
+  bool identity = true;
+  for (uint64_t q = 0; q < m_qc.get_num_rows_to_query(); ++q) if (m_qc.get_array_row_idx_for_query_row_idx(q) != (int64_t)q) identity = false;
+  struct stat fs;
+  if (identity && ::stat(frag.c_str(), &fs) == 0) {
+    try {
+      const FragmentFileMeta meta = m_pipe->open_fragment_file(frag, expected_columns(), schema_hash());
+      const bool stale = have_cells && meta.source_bytes != 0 && (meta.source_bytes != (uint64_t)cs.st_size || meta.source_mtime != (int64_t)cs.st_mtime);
+      if (stale) m_pipe->close_fragment_file();
+      else {
+        m_src.kind = SRC_FRAGMENT_FILE; m_src.ncells_file = meta.ncells; m_src.size = (uint64_t)fs.st_size;
+        min_begin = meta.min_begin; max_end = meta.max_end;
+      }
+    } catch (const std::exception&) {
+      if (!have_cells) throw;    // nothing to fall back to
+    }
+  }
+  if (m_src.kind == SRC_NONE) {
+    m_src.fd = ::open(cells.c_str(), O_RDONLY);
+    if (m_src.fd < 0) throw std::runtime_error("cannot open " + cells);
+    m_src.kind = SRC_CELLS_FILE; m_src.size = (uint64_t)cs.st_size;
+  }
+  rewind_source();
+}
+
+void CombineEngine::rewind_source() {
+  m_src.cursor = 0; m_src.cell_cursor = 0; m_src.window_valid = false; m_src.eof = false; m_src.cov = Coverage{INT64_MIN, INT64_MIN};
+  reference_cell_bytes = 0; num_cells = 0; has_cells = false;
+  if (m_src.kind != SRC_FRAGMENT_FILE) { min_begin = INT64_MAX; max_end = 0; }
+}
+
+void CombineEngine::advance_window() {
+  Source& S = m_src;
+  const int64_t carry_from = S.window_valid ? S.cov.hi + 1 : INT64_MIN;
+  m_pipe->begin_staging(carry_from);
+  const uint64_t budget = staging_budget_bytes();
+  int64_t next_begin = INT64_MAX, new_cells = 0;
+  if (S.kind == SRC_FRAGMENT_FILE) {
+    const DevicePipeline::FragmentWindow w = m_pipe->append_fragment_cells(S.cell_cursor, budget);
+    S.cell_cursor = w.c1; next_begin = w.next_begin; new_cells = w.ncells;
+    reference_cell_bytes += w.reference_cell_bytes;
+    S.eof = S.cell_cursor >= S.ncells_file;
+  } else if (S.kind == SRC_CALLBACK) {
+    const CellStreamLayout& L = layout();
+    uint64_t taken = 0;
+    for (;;) {
+      if (!S.pending_valid) {
+        S.pending = nullptr; S.pending_bytes = 0;
+        if (!S.fn(S.fn_user, &S.pending, &S.pending_bytes)) { S.eof = true; break; }
+        S.pending_valid = true;
+        if (S.pending_bytes == 0) { S.pending_valid = false; continue; }
+      }
+      if (taken > 0 && taken + S.pending_bytes > budget) break;     // the chunk in hand opens the next window
+      const DevicePipeline::CellStreamInfo info = m_pipe->append_cells(S.pending, S.pending_bytes, L.schema, L.attr_to_field, L.row_map);
+      reference_cell_bytes += info.reference_cell_bytes;
+      new_cells += info.ncells;
+      if (info.ncells > 0) { min_begin = std::min(min_begin, info.min_begin); max_end = std::max(max_end, info.max_end); }
+      taken += S.pending_bytes;
+      S.pending_valid = false;
+    }
+    if (S.pending_valid) { int64_t col; memcpy(&col, S.pending + 8, 8); next_begin = col; }
+  } else {
+    // the binary cell stream in sub-chunks (whole begin columns each): read -> walk the sizes -> HBM, until the window is full
+    const CellStreamLayout& L = layout();
+    const uint64_t sub = std::min<uint64_t>(budget, (uint64_t)256 << 20);
+    uint64_t taken = 0;
+    std::vector<uint64_t> offs;
+    uint64_t want = sub;
+    while (taken < budget && S.cursor < S.size) {
+      const uint64_t n = std::min<uint64_t>(want, S.size - S.cursor);
+      const bool to_end = S.cursor + n >= S.size;
+      const uint8_t* buf;
+      if (S.kind == SRC_CELLS_MEMORY) buf = S.mem + S.cursor;
+      else {
+        if (S.chunk_cap < n) {
+          if (S.chunk) (void)hipHostFree(S.chunk);
+          S.chunk = nullptr; S.chunk_cap = 0;
+          if (hipHostMalloc((void**)&S.chunk, (size_t)n, hipHostMallocDefault) != hipSuccess) throw GenomicsDBDeviceException("cannot pin the cell read buffer");
+          S.chunk_cap = (size_t)n;
+        }
+        for (uint64_t got = 0; got < n;) {
+          const ssize_t k = ::pread(S.fd, S.chunk + got, (size_t)(n - got), (off_t)(S.cursor + got));
+          if (k <= 0) throw std::runtime_error("short read from cells.bin");
+          got += (uint64_t)k;
+        }
+        buf = S.chunk;
+      }
+      const DevicePipeline::CellWalk wk = DevicePipeline::walk_cells(buf, n, L.row_map, !to_end, offs);
+      if (wk.single_column) { want *= 2; continue; }     // one begin column wider than the sub-chunk: offer more bytes
+      const DevicePipeline::CellStreamInfo info = m_pipe->append_cells(buf, wk.bytes_taken, L.schema, L.attr_to_field, L.row_map, &offs, &wk);
+      reference_cell_bytes += info.reference_cell_bytes;
+      new_cells += info.ncells;
+      if (info.ncells > 0) { min_begin = std::min(min_begin, info.min_begin); max_end = std::max(max_end, info.max_end); }
+      S.cursor += wk.bytes_taken; taken += wk.bytes_taken;
+      next_begin = to_end ? INT64_MAX : wk.next_begin;
+      want = sub;
+    }
+    S.eof = S.cursor >= S.size;
+    if (S.eof) next_begin = INT64_MAX;
+  }
+  m_pipe->finish_staging();
+  num_cells += new_cells;
+  has_cells = new_cells + m_pipe->carried_cells() > 0;
+  if (carry_from != INT64_MIN && min_begin != INT64_MAX) min_begin = std::min(min_begin, carry_from);
+  S.cov.lo = S.window_valid ? S.cov.hi + 1 : INT64_MIN;
+  S.cov.hi = next_begin == INT64_MAX ? INT64_MAX - 1 : next_begin - 1;
+  S.window_valid = true;
+  ++windows_staged;
+}
+
+CombineEngine::Coverage CombineEngine::cover(int64_t column) {
+  if (m_src.kind == SRC_NONE) return Coverage{INT64_MIN, INT64_MAX - 1};   // staged by hand (stage_cells*, load_fragment, adopt): all of it
+  if (m_src.window_valid && column < m_src.cov.lo) {                       // an earlier interval than the current window: start over
+    if (m_src.kind == SRC_CALLBACK) throw GenomicsDBConfigException("a cell callback source is read once, front to back");
+    rewind_source();
+  }
+  while (!m_src.window_valid || (column > m_src.cov.hi && !m_src.eof)) advance_window();
+  return m_src.cov;
 }
 
 void CombineEngine::stage_reference_for(int64_t qb, int64_t qe) {
@@ -84,28 +280,23 @@ GenomicsDBBCFGenerator::GenomicsDBBCFGenerator(const std::string& loader_config_
     if (!qc.get_vid_mapper().get_contig_info(chr, ci)) throw GenomicsDBJNIException(std::string("Could not find TileDB column interval for contig: ") + chr);
     qc.set_column_interval_to_query(ci.m_tiledb_column_offset + (int64_t)start - 1, ci.m_tiledb_column_offset + (int64_t)end - 1);
   }
-  // array storage of this build: <workspace>/<array>/cells.bin = begin-cells in the reference binary-cell layout
-  // (the Intel TileDB fork's on-disk format is not available: SURVEY 8(f) rank 1)
-  const std::string dir = qc.get_workspace(my_rank) + "/" + qc.get_array_name(my_rank);
-  bool loaded = false;
-  {  // columnar fragment first: file -> HBM copies, no parsing
-    const std::string frag = dir + "/fragment.gdbamd";
-    if (FILE* fp = fopen(frag.c_str(), "rb")) {
-      fclose(fp);
-      try { m_engine->load_fragment(frag); loaded = true; } catch (const GenomicsDBConfigException&) { loaded = false; }   // row subset: take the cells
-    }
-  }
-  if (!loaded) {
-    std::vector<uint8_t> cells = read_binary_file(dir + "/cells.bin");
-    m_engine->stage_cells(cells.data(), cells.size());
-  }
+  // array storage of this build: <workspace>/<array>/fragment.gdbamd (columnar, validated) or cells.bin = begin-cells in the
+  // reference binary-cell layout (the Intel TileDB fork's on-disk format is not available: SURVEY 8(f) rank 1); either is read
+  // in column windows of the staging budget
+  m_engine->open_array(qc.get_workspace(my_rank) + "/" + qc.get_array_name(my_rank));
+  m_engine->cover(INT64_MIN);   // first window staged at construction, like the reference opens its array here
   common_init(produce_header_only);
 }
 
 GenomicsDBBCFGenerator::GenomicsDBBCFGenerator(const std::string& query_json_text, const uint8_t* cells, uint64_t nbytes, size_t buffer_capacity, bool produce_header_only)
     : m_buffer_capacity(buffer_capacity) {
   m_engine.reset(new CombineEngine(mini_json::parse(query_json_text), 0));
-  m_engine->stage_cells(cells, nbytes);
+  if (nbytes > m_engine->staging_budget_bytes()) {   // several windows: the stream comes back for the bytes, so it keeps them
+    m_owned_cells.assign(cells, cells + nbytes);
+    cells = m_owned_cells.data();
+  }
+  m_engine->open_memory_cells(cells, nbytes);
+  m_engine->cover(INT64_MIN);                         // the first window (for most arrays: all of it) is staged here; malformed cells fail here
   common_init(produce_header_only);
 }
 
@@ -166,7 +357,9 @@ bool GenomicsDBBCFGenerator::advance_page() {
       // a wide interval (a whole chromosome) is worked off in pieces whose buffers fit HBM; the cuts sit right before cell
       // begins, where the sweep closes its interval anyway, so the stream is byte-identical to the unsplit one
       if (m_piece_begin < qb || m_piece_begin > qe) m_piece_begin = qb;
-      const int64_t pe = pipe.split_point(m_piece_begin, qe, max_window_columns());
+      // (an array larger than the staging budget passes through HBM in column windows: a piece ends where the staged window does)
+      const CombineEngine::Coverage cov = m_engine->cover(m_piece_begin);
+      const int64_t pe = pipe.split_point(m_piece_begin, std::min(qe, cov.hi), max_window_columns());
       m_engine->stage_reference_for(m_piece_begin, pe);
       pipe.prepare_interval(m_piece_begin, pe);
       m_piece_end = pe;

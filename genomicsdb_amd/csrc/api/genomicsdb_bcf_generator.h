@@ -31,17 +31,51 @@ class CombineEngine {
   // the staged fragment as a columnar file (<workspace>/<array>/fragment.gdbamd is what the query stream opens first)
   void save_fragment(const std::string& path);
   void load_fragment(const std::string& path);
+  // ---- arrays larger than the staging budget: column windows streamed through HBM -----------------------------------------
+  // An array source is read window by window (whole begin columns, about staging_budget_bytes() each); the intervals still live
+  // at a window's end are carried into the next one on the device (DevicePipeline::begin_staging(carry_from)), the analogue of
+  // the reference's segment-at-a-time iterator + scan state (variant_storage_manager.cc:61-153, query_variants.h:126-191).
+  // An array that fits the budget is simply one window.
+  void open_array(const std::string& dir);                      // <workspace>/<array>: fragment.gdbamd when valid for this query, else cells.bin
+  void open_memory_cells(const uint8_t* cells, uint64_t nbytes);  // the caller keeps the bytes alive
+  // cells produced on demand: every call hands out the next chunk (whole begin columns, column-major across chunks; valid until
+  // the next call), 0 = no more.  One pass only: a query interval in front of the current window cannot be served.
+  typedef int (*CellChunkFn)(void* user, const uint8_t** cells, uint64_t* nbytes);
+  void open_cell_callback(CellChunkFn fn, void* user);
+  struct Coverage { int64_t lo, hi; };                          // every query position in [lo, hi] sees all its live cells in the staged fragment
+  Coverage cover(int64_t column);                               // stages windows until `column` is covered
+  uint64_t staging_budget_bytes() const;
+  int64_t windows_staged = 0;
   int64_t num_cells = 0;
   void stage_reference_for(int64_t qb, int64_t qe);
   uint64_t reference_cell_bytes = 0;
   int64_t min_begin = 0, max_end = 0;
   bool has_cells = false;
+  ~CombineEngine();
  private:
   VariantQueryConfig m_qc;
   HostPlan m_hp;
   std::unique_ptr<DevicePipeline> m_pipe;
   std::unique_ptr<CellStreamLayout> m_layout;   // attribute order, plan-field map, row map of the binary cell stream
   ReferenceGenomeInfo m_ref;
+  const CellStreamLayout& layout();
+  std::vector<ColumnLayout> expected_columns();
+  uint64_t schema_hash();
+  // array source
+  enum SourceKind { SRC_NONE, SRC_CELLS_FILE, SRC_CELLS_MEMORY, SRC_FRAGMENT_FILE, SRC_CALLBACK };
+  struct Source {
+    SourceKind kind = SRC_NONE;
+    int fd = -1; uint64_t size = 0, cursor = 0;      // cells file: byte cursor
+    const uint8_t* mem = nullptr;                    // cells in memory
+    int64_t cell_cursor = 0, ncells_file = 0;        // fragment file: cell cursor
+    uint8_t* chunk = nullptr; size_t chunk_cap = 0;  // pinned read buffer (cells file)
+    CellChunkFn fn = nullptr; void* fn_user = nullptr;   // callback: one chunk of lookahead
+    const uint8_t* pending = nullptr; uint64_t pending_bytes = 0; bool pending_valid = false;
+    bool window_valid = false, eof = false;
+    Coverage cov{INT64_MIN, INT64_MIN};
+  } m_src;
+  void rewind_source();
+  void advance_window();
 };
 
 class GenomicsDBBCFGenerator {
@@ -77,6 +111,7 @@ class GenomicsDBBCFGenerator {
   void fill_ring();             // issue as many chunk copies as there are free slots
   void pop_slot();
   uint64_t device_page_bytes() const;
+  std::vector<uint8_t> m_owned_cells;   // in-memory flavour: the cells (declared before the engine: it outlives it)
   std::unique_ptr<CombineEngine> m_engine;
   size_t m_buffer_capacity;
   std::vector<uint8_t> m_header;  // first bytes of the stream

@@ -1,11 +1,16 @@
-// jni_query_stream.cc - the six native methods of com.intel.genomicsdb.reader.GenomicsDBQueryStream on top of the C ABI
-// (include/genomicsdb_amd.h).  Reference: src/main/jni/src/genomicsdb_GenomicsDBQueryStream.cc:29-111 (the method names and
-// argument lists are fixed by the Java class, src/main/java/com/intel/genomicsdb/reader/GenomicsDBQueryStream.java:197-211).
+// jni_query_stream.cc - the native methods GATK4's GenomicsDBFeatureReader reaches, on top of the C ABI
+// (include/genomicsdb_amd.h): the six of com.intel.genomicsdb.reader.GenomicsDBQueryStream (reference
+// src/main/jni/src/genomicsdb_GenomicsDBQueryStream.cc:29-111; names and argument lists are fixed by the Java class,
+// src/main/java/com/intel/genomicsdb/reader/GenomicsDBQueryStream.java:197-211) and the one-time initialiser that
+// GenomicsDBLibLoader.loadLibrary() calls right after System.loadLibrary (src/main/jni/src/genomicsdb_jni_init.cc:28-34,
+// src/main/java/com/intel/genomicsdb/GenomicsDBLibLoader.java:36-53).
 //
-// Built only where a JDK is present (genomicsdb_amd/build.py looks for $JAVA_HOME/include/jni.h) into libtiledbgenomicsdb.so,
-// the library name the reference's Java loader asks for; this image has no JDK, so here the file is source only.
+// Built into libtiledbgenomicsdb.so, the library name the reference's Java loader asks for (src/main/CMakeLists.txt:66):
+// against $JAVA_HOME/include/jni.h where a JDK is present, else against csrc/jni/stub/jni.h (the JNI function-table indices
+// of the specification, nothing else), so the glue is compiled, linked and symbol-checked in every build.
 #include <jni.h>
 
+#include <algorithm>
 #include <cstdint>
 
 #include "../../../include/genomicsdb_amd.h"
@@ -24,6 +29,9 @@ struct UtfChars {          // GetStringUTFChars / ReleaseStringUTFChars as a sco
 }  // namespace
 
 extern "C" {
+
+// The reference initialises MPI here (JNIMpiInit); this build's ranks are launcher processes, there is nothing to set up.
+JNIEXPORT jint JNICALL Java_com_intel_genomicsdb_GenomicsDBLibLoader_jniGenomicsDBOneTimeInitialize(JNIEnv*, jclass) { return 0; }
 
 JNIEXPORT jlong JNICALL Java_com_intel_genomicsdb_reader_GenomicsDBQueryStream_jniGenomicsDBInit(
     JNIEnv* env, jobject, jstring loader_json, jstring query_json, jstring chr, jint start, jint end, jint rank, jlong buffer_capacity,
@@ -49,16 +57,26 @@ JNIEXPORT jbyte JNICALL Java_com_intel_genomicsdb_reader_GenomicsDBQueryStream_j
   return (jbyte)gdb_mi355_read_next_byte(handle_of(handle));
 }
 
+// Like the reference (:83-107): the bytes go from the stream's current batch - here a pinned ring buffer the copy engine fills -
+// into the Java array with SetByteArrayRegion, batch by batch.  No critical section: the GPU pipeline may run inside peek().
 JNIEXPORT jint JNICALL Java_com_intel_genomicsdb_reader_GenomicsDBQueryStream_jniGenomicsDBRead(JNIEnv* env, jobject, jlong handle, jbyteArray java_byte_array,
                                                                                                  jint offset, jint n) {
-  if (n <= 0) return 0;
-  // no JNI calls between Get- and ReleasePrimitiveArrayCritical (same discipline as the reference, :83-98)
-  jbyte* dst = static_cast<jbyte*>(env->GetPrimitiveArrayCritical(java_byte_array, NULL));
-  if (!dst) return 0;
-  const int64_t got = gdb_mi355_read(handle_of(handle), reinterpret_cast<uint8_t*>(dst), (uint64_t)offset, (uint64_t)n);
-  env->ReleasePrimitiveArrayCritical(java_byte_array, dst, 0);
-  if (got < 0) { throw_io(env, gdb_mi355_last_error()); return 0; }
-  return (jint)got;
+  void* h = handle_of(handle);
+  if (!h || n <= 0) return 0;
+  jint total = 0;
+  while (total < n) {
+    const uint8_t* p = NULL;
+    uint64_t avail = 0;
+    const int rc = gdb_mi355_peek(h, &p, &avail);
+    if (rc < 0) { throw_io(env, gdb_mi355_last_error()); return total; }
+    if (rc == 0 || avail == 0) break;                 // end of the stream
+    const jint k = (jint)std::min<uint64_t>(avail, (uint64_t)(n - total));
+    env->SetByteArrayRegion(java_byte_array, offset + total, k, reinterpret_cast<const jbyte*>(p));
+    if (env->ExceptionCheck()) return total;          // ArrayIndexOutOfBoundsException is pending
+    if (gdb_mi355_skip(h, (uint64_t)k) != (int64_t)k) { throw_io(env, gdb_mi355_last_error()); return total; }
+    total += k;
+  }
+  return total;
 }
 
 JNIEXPORT jlong JNICALL Java_com_intel_genomicsdb_reader_GenomicsDBQueryStream_jniGenomicsDBSkip(JNIEnv* env, jobject, jlong handle, jlong n) {

@@ -8,6 +8,7 @@
 #pragma once
 #include <cstdint>
 #include <string>
+#include <vector>
 
 #include "../core/gdb_types.h"
 #include "../host/combine_plan.h"
@@ -39,7 +40,13 @@ struct IntervalStats {
 };
 
 // what the engine needs to know about a staged fragment besides the columns
-struct FragmentFileMeta { uint64_t reference_cell_bytes = 0; int64_t min_begin = INT64_MAX, max_end = 0, ncells = 0; };
+struct FragmentFileMeta {
+  uint64_t reference_cell_bytes = 0; int64_t min_begin = INT64_MAX, max_end = 0, ncells = 0;
+  uint64_t schema_hash = 0;                    // vid + callset mapping the file was written under (0: unknown)
+  uint64_t source_bytes = 0; int64_t source_mtime = 0;   // size / mtime of the cells.bin it was made from (0: none)
+};
+// layout of one attribute column as the array schema defines it (what a fragment file is checked against)
+struct ColumnLayout { bool var = false; int elem_size = 4; int fixed_num = 1; };
 
 // page consumer: `dev_ptr` points to `nbytes` of VCF text in HBM, valid until the callback returns
 typedef void (*PageCallback)(void* user, const char* dev_ptr, uint64_t nbytes);
@@ -53,17 +60,38 @@ class DevicePipeline {
   // copy a host fragment to HBM (replaces the previously staged one)
   void stage_fragment(const HostFragment& hf);
   // staging in parts (column-major order across parts): begin, append host fragments, finish = one contiguous fragment in HBM
-  void begin_staging();
+  // carry_from != INT64_MIN: the cells of the fragment staged so far whose intervals reach column carry_from (at most one per
+  // sample) open the new fragment - windowed streaming of an array larger than the staging budget
+  void begin_staging(int64_t carry_from = INT64_MIN);
+  int64_t carried_cells() const;
   void append_fragment(const HostFragment& hf);
   // the same from the reference's binary cell stream: the bytes are copied to HBM as they are and taken apart there
   // (one thread per cell); the host only walks the cell sizes.  row_map: array row -> query row (-1: not queried)
   struct CellStreamInfo { int64_t ncells = 0; uint64_t reference_cell_bytes = 0; int64_t min_begin = INT64_MAX, max_end = 0; };
+  // result of walking the cell sizes of a buffer on the host (the format's one sequential dependency)
+  struct CellWalk {
+    int64_t nkept = 0, nmark = 0;                // cells of queried rows / of other array rows (boundary markers)
+    uint64_t reference_cell_bytes = 0, bytes_taken = 0;
+    int64_t first_begin = INT64_MAX, last_begin = INT64_MIN;
+    int64_t next_begin = INT64_MAX;              // whole_columns_only: begin column of the first cell left in the buffer
+    bool single_column = false;                  // whole_columns_only: the buffer holds (part of) one column only, nothing was taken
+  };
+  static CellWalk walk_cells(const uint8_t* cells, uint64_t nbytes, const std::vector<int32_t>& row_map, bool whole_columns_only, std::vector<uint64_t>& offs);
+  // walked / walk_info: the walk has been done by the caller (windowed streaming), offs = cell offsets + end offset
   CellStreamInfo append_cells(const uint8_t* cells, uint64_t nbytes, const VariantArraySchemaLite& schema, const std::vector<int>& attr_to_field,
-                              const std::vector<int32_t>& row_map);
+                              const std::vector<int32_t>& row_map, const std::vector<uint64_t>* walked = nullptr, const CellWalk* walk_info = nullptr);
   void finish_staging();
   // the staged fragment as a columnar file / a columnar file straight into HBM (format: gdb_pipeline.hip, 'columnar fragment file')
   void save_fragment(const std::string& path, const FragmentFileMeta& meta);
-  FragmentFileMeta load_fragment(const std::string& path);
+  FragmentFileMeta load_fragment(const std::string& path, const std::vector<ColumnLayout>& expected, uint64_t expected_schema_hash);
+  // the same window by window: open (validates the whole header against the file size and the expected layouts), then between
+  // begin_staging() and finish_staging() append the cells [c0, c1) that make up whole begin columns and about budget_bytes
+  struct FragmentFile;
+  struct FragmentWindow { int64_t c0 = 0, c1 = 0, ncells = 0, first_begin = INT64_MAX, last_begin = INT64_MIN, next_begin = INT64_MAX; uint64_t reference_cell_bytes = 0; };
+  FragmentFileMeta open_fragment_file(const std::string& path, const std::vector<ColumnLayout>& expected, uint64_t expected_schema_hash);
+  FragmentWindow append_fragment_cells(int64_t c0, uint64_t budget_bytes);
+  int64_t fragment_file_lower_bound(int64_t column);
+  void close_fragment_file();
   // adopt a fragment that already lives in HBM (e.g. torch tensors); the caller keeps ownership
   void adopt_fragment(const FragmentView& device_view);
   // reference bases for TileDB columns [begin, begin + bases.size())

@@ -5,10 +5,15 @@
 // HBM traffic: no MFMA, no GEMM reshaping (see DESIGN.md for the per-kernel byte accounting).
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -992,56 +997,120 @@ struct CellAttrDesc { int16_t var, elem_size; int32_t num; int32_t field; };   /
 struct CellSchemaDev { int32_t nattrs; CellAttrDesc a[kMaxSchemaAttrs]; };
 struct CellColumnsDev { char* data[GDB_MAX_FIELDS]; uint32_t* len[GDB_MAX_FIELDS]; const uint32_t* off[GDB_MAX_FIELDS]; uint32_t* frag_off[GDB_MAX_FIELDS]; };
 
-__device__ __forceinline__ int64_t load_i64_unaligned(const uint8_t* p) { int64_t v = 0; for (int i = 7; i >= 0; --i) v = (v << 8) | p[i]; return v; }
-__device__ __forceinline__ int32_t load_i32_unaligned(const uint8_t* p) { return (int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)); }
+// Unaligned sources.  A wavefront takes 64 consecutive cells (~10 KB of the stream): their bytes are fetched ONCE, coalesced
+// (16 bytes per lane), into an LDS tile, and the lanes - one cell each - walk their attributes out of LDS; spans that do not fit
+// the tile (cells with very long vectors) are read from global memory with unaligned dword loads instead.  (One thread per cell
+// reading global memory bytewise touched 64 different cache lines per load instruction: 54 GB of traffic for 1.45 GB of cells.)
+constexpr int kStageTile = 12 * 1024;       // LDS bytes per wavefront
+constexpr int kStageBlock = 256;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed)) PackedU32 { uint32_t v; };
+struct __attribute__((packed)) PackedU64 { uint64_t v; };
+struct GlobalBytes {
+  const uint8_t* p;
+  __device__ __forceinline__ uint8_t u8(uint32_t o) const { return p[o]; }
+  __device__ __forceinline__ uint32_t u32(uint32_t o) const { return reinterpret_cast<const PackedU32*>(p + o)->v; }
+  __device__ __forceinline__ uint64_t u64(uint32_t o) const { return reinterpret_cast<const PackedU64*>(p + o)->v; }
+};
+typedef __attribute__((address_space(3))) uint8_t gdb_lds_u8;
+struct LdsBytes {
+  const gdb_lds_u8* p;
+  __device__ __forceinline__ uint8_t u8(uint32_t o) const { return p[o]; }
+  __device__ __forceinline__ uint32_t u32(uint32_t o) const { return reinterpret_cast<const __attribute__((address_space(3))) PackedU32*>(p + o)->v; }
+  __device__ __forceinline__ uint64_t u64(uint32_t o) const { return reinterpret_cast<const __attribute__((address_space(3))) PackedU64*>(p + o)->v; }
+};
+// fetch the bytes of cells [w0, w1) of a wavefront into its tile; returns false (nothing fetched) when they do not fit
+__device__ __forceinline__ bool stage_tile_fetch(const uint8_t* __restrict__ cells, uint64_t span_begin, uint64_t span_end, gdb_lds_u8* tile, int lane, uint32_t& skew) {
+  const uint64_t a0 = span_begin & ~(uint64_t)15;
+  const uint64_t bytes = span_end - a0;
+  skew = (uint32_t)(span_begin - a0);
+  if (bytes > (uint64_t)kStageTile) return false;
+  for (uint32_t o = (uint32_t)lane * 16u; o < (uint32_t)bytes; o += 64u * 16u)   // (the buffer is padded by 16 bytes: the last load may run past the span)
+    *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(tile + o) = *reinterpret_cast<const u32x4*>(cells + a0 + o);
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // one wavefront, in-order LDS: a compiler-level fence is all it takes
+  return true;
+}
 
-__global__ void k_cells_measure(const uint8_t* __restrict__ cells, const uint64_t* __restrict__ cell_off, int64_t n, CellSchemaDev sch, const int32_t* __restrict__ row_map,
-                                int64_t nrows_array, int nfields, uint32_t* keep, uint32_t* is_marker, int32_t* qrow, int64_t* begin, int64_t* end, CellColumnsDev cols,
-                                uint32_t* err) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint8_t* c = cells + cell_off[i];
-  const int64_t row = load_i64_unaligned(c);
-  const int64_t size = (int64_t)(cell_off[i + 1] - cell_off[i]);
+template <class Bytes> __device__ __forceinline__ void cell_measure(const Bytes& c, int64_t i, int64_t size, const CellSchemaDev& sch, const int32_t* __restrict__ row_map,
+                                                                    int64_t nrows_array, uint32_t* keep, uint32_t* is_marker, int32_t* qrow, int64_t* begin, int64_t* end,
+                                                                    const CellColumnsDev& cols, uint32_t* err) {
+  const int64_t row = (int64_t)c.u64(0);
   const int32_t q = (row >= 0 && row < nrows_array) ? row_map[row] : -1;
   keep[i] = q >= 0 ? 1u : 0u;
   is_marker[i] = (q < 0 && row >= 0 && row < nrows_array) ? 1u : 0u;   // an array row outside the query: boundary marker
   qrow[i] = q;
-  begin[i] = load_i64_unaligned(c + 8);
-  const uint8_t* p = c + 24;
+  begin[i] = (int64_t)c.u64(8);
+  int64_t p = 24;
   for (int ai = 0; ai < sch.nattrs; ++ai) {
     const CellAttrDesc a = sch.a[ai];
     uint32_t cnt = (uint32_t)a.num;
-    if (a.var) { cnt = (uint32_t)load_i32_unaligned(p); p += 4; }
-    if (ai == 0) end[i] = load_i64_unaligned(p);
+    if (a.var) { if (p + 4 > size) { p = size + 1; break; } cnt = c.u32((uint32_t)p); p += 4; }
+    if (ai == 0) { if (p + 8 > size) { p = size + 1; break; } end[i] = (int64_t)c.u64((uint32_t)p); }
     if (a.field >= 0 && a.var) cols.len[a.field][i] = q >= 0 ? cnt : 0u;
-    p += (size_t)cnt * (size_t)a.elem_size;
-    if (p - c > size) break;
+    p += (int64_t)cnt * (int64_t)a.elem_size;
+    if (p > size) break;
   }
-  if (p - c != size) atomicOr(err, (uint32_t)GDB_ERR_CELL_STREAM);
-  (void)nfields;
+  if (p != size) atomicOr(err, (uint32_t)GDB_ERR_CELL_STREAM);
 }
-__global__ void k_cells_scatter(const uint8_t* __restrict__ cells, const uint64_t* __restrict__ cell_off, int64_t n, CellSchemaDev sch, const uint32_t* __restrict__ keep,
-                                const uint32_t* __restrict__ dest, const int32_t* __restrict__ qrow, const int64_t* __restrict__ begin, const int64_t* __restrict__ end,
-                                int32_t* row_out, int64_t* begin_out, int64_t* end_out, CellColumnsDev cols) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || !keep[i]) return;
-  const uint32_t d = dest[i];
-  row_out[d] = qrow[i]; begin_out[d] = begin[i]; end_out[d] = end[i];
-  const uint8_t* p = cells + cell_off[i] + 24;
+__global__ void __launch_bounds__(kStageBlock) k_cells_measure(const uint8_t* __restrict__ cells, const uint64_t* __restrict__ cell_off, int64_t n, CellSchemaDev sch,
+                                                             const int32_t* __restrict__ row_map, int64_t nrows_array, uint32_t* keep, uint32_t* is_marker, int32_t* qrow,
+                                                             int64_t* begin, int64_t* end, CellColumnsDev cols, uint32_t* err) {
+  __shared__ __attribute__((aligned(16))) uint8_t tiles[(kStageBlock / 64) * kStageTile];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t w0 = ((int64_t)blockIdx.x * (kStageBlock / 64) + wave) * 64;
+  if (w0 >= n) return;
+  const int64_t w1 = min(n, w0 + 64);
+  const int64_t i = w0 + lane;
+  gdb_lds_u8* tile = (gdb_lds_u8*)tiles + wave * kStageTile;
+  uint32_t skew;
+  const uint64_t span_begin = cell_off[w0];
+  const bool tiled = stage_tile_fetch(cells, span_begin, cell_off[w1], tile, lane, skew);   // uniform per wavefront
+  if (i >= w1) return;
+  const uint64_t o = cell_off[i];
+  const int64_t size = (int64_t)(cell_off[i + 1] - o);
+  if (tiled) cell_measure(LdsBytes{tile + skew + (uint32_t)(o - span_begin)}, i, size, sch, row_map, nrows_array, keep, is_marker, qrow, begin, end, cols, err);
+  else cell_measure(GlobalBytes{cells + o}, i, size, sch, row_map, nrows_array, keep, is_marker, qrow, begin, end, cols, err);
+}
+
+template <class Bytes> __device__ __forceinline__ void cell_scatter(const Bytes& c, int64_t i, uint32_t d, const CellSchemaDev& sch, const CellColumnsDev& cols) {
+  uint32_t p = 24;
   for (int ai = 0; ai < sch.nattrs; ++ai) {
     const CellAttrDesc a = sch.a[ai];
     uint32_t cnt = (uint32_t)a.num;
-    if (a.var) { cnt = (uint32_t)load_i32_unaligned(p); p += 4; }
-    const size_t bytes = (size_t)cnt * (size_t)a.elem_size;
+    if (a.var) { cnt = c.u32(p); p += 4; }
+    const uint32_t bytes = cnt * (uint32_t)a.elem_size;
     if (a.field >= 0) {
       char* dst;
       if (a.var) { const uint32_t o = cols.off[a.field][i]; cols.frag_off[a.field][d] = o; dst = cols.data[a.field] + (size_t)o * a.elem_size; }
       else dst = cols.data[a.field] + (size_t)d * bytes;
-      for (size_t b = 0; b < bytes; ++b) dst[b] = (char)p[b];
+      // destinations are element-aligned (columns are arrays of elements): whole-word stores for 4- and 8-byte elements
+      if (a.elem_size == 4) { for (uint32_t j = 0; j < cnt; ++j) reinterpret_cast<uint32_t*>(dst)[j] = c.u32(p + 4u * j); }
+      else if (a.elem_size == 8) { for (uint32_t j = 0; j < cnt; ++j) reinterpret_cast<uint64_t*>(dst)[j] = c.u64(p + 8u * j); }
+      else for (uint32_t b = 0; b < bytes; ++b) dst[b] = (char)c.u8(p + b);
     }
     p += bytes;
   }
+}
+__global__ void __launch_bounds__(kStageBlock) k_cells_scatter(const uint8_t* __restrict__ cells, const uint64_t* __restrict__ cell_off, int64_t n, CellSchemaDev sch,
+                                                             const uint32_t* __restrict__ keep, const uint32_t* __restrict__ dest, const int32_t* __restrict__ qrow,
+                                                             const int64_t* __restrict__ begin, const int64_t* __restrict__ end, int32_t* row_out, int64_t* begin_out,
+                                                             int64_t* end_out, CellColumnsDev cols) {
+  __shared__ __attribute__((aligned(16))) uint8_t tiles[(kStageBlock / 64) * kStageTile];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t w0 = ((int64_t)blockIdx.x * (kStageBlock / 64) + wave) * 64;
+  if (w0 >= n) return;
+  const int64_t w1 = min(n, w0 + 64);
+  const int64_t i = w0 + lane;
+  gdb_lds_u8* tile = (gdb_lds_u8*)tiles + wave * kStageTile;
+  uint32_t skew;
+  const uint64_t span_begin = cell_off[w0];
+  const bool tiled = stage_tile_fetch(cells, span_begin, cell_off[w1], tile, lane, skew);   // uniform per wavefront
+  if (i >= w1 || !keep[i]) return;
+  const uint32_t d = dest[i];
+  row_out[d] = qrow[i]; begin_out[d] = begin[i]; end_out[d] = end[i];
+  const uint64_t o = cell_off[i];
+  if (tiled) cell_scatter(LdsBytes{tile + skew + (uint32_t)(o - span_begin)}, i, d, sch, cols);
+  else cell_scatter(GlobalBytes{cells + o}, i, d, sch, cols);
 }
 __global__ void k_cells_markers(const uint32_t* is_marker, const uint32_t* mdest, const int64_t* begin, int64_t n, int64_t* marker_out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1051,6 +1120,53 @@ __global__ void k_cells_order_check(const int32_t* row, const int64_t* begin, in
   const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (d < 1 || d >= n) return;
   if (begin[d] < begin[d - 1] || (begin[d] == begin[d - 1] && row[d] <= row[d - 1])) atomicOr(err, (uint32_t)GDB_ERR_CELL_STREAM);
+}
+
+// ---- carry-over between column windows of an array that is streamed through HBM ---------------------------------------
+// The device analogue of VariantQueryProcessorScanState (query_variants.h:126-191): what survives a window is, per sample, its
+// last cell if that cell's interval reaches the first column of the next window (an earlier cell of the same sample is either
+// over or has been overridden by its successor, query_variants.cc:512-543).  At most one cell per sample.
+__global__ void k_last_in_row(const int32_t* __restrict__ row, int64_t C, long long* last) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) atomicMax(&last[row[c]], (long long)c);
+}
+__global__ void k_carry_select(const long long* last, const int64_t* __restrict__ end, int32_t N, int64_t carry_from, uint64_t* keys) {
+  const int32_t r = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (r >= N) return;
+  const long long c = last[r];
+  keys[r] = (c >= 0 && end[c] >= carry_from) ? (uint64_t)c : ~0ull;
+}
+__global__ void k_count_valid_keys(const uint64_t* sorted, int32_t N, int64_t* out) {   // keys are sorted: first index holding ~0
+  if (blockIdx.x || threadIdx.x) return;
+  int32_t lo = 0, hi = N;
+  while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (sorted[mid] != ~0ull) lo = mid + 1; else hi = mid; }
+  *out = lo;
+}
+__global__ void k_gather_coords(const uint64_t* list, int64_t K, const int32_t* row, const int64_t* begin, const int64_t* end, int32_t* row_out, int64_t* begin_out, int64_t* end_out) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  const int64_t c = (int64_t)list[k];
+  row_out[k] = row[c]; begin_out[k] = begin[c]; end_out[k] = end[c];
+}
+__global__ void k_gather_fixed(const uint64_t* list, int64_t K, const char* src, uint32_t bytes_per_cell, char* dst) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  const char* s = src + (size_t)list[k] * bytes_per_cell;
+  char* d = dst + (size_t)k * bytes_per_cell;
+  for (uint32_t b = 0; b < bytes_per_cell; ++b) d[b] = s[b];
+}
+__global__ void k_gather_var_len(const uint64_t* list, int64_t K, const uint32_t* off, uint32_t* len) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > K) return;
+  len[k] = k < K ? off[list[k] + 1] - off[list[k]] : 0u;
+}
+__global__ void k_gather_var(const uint64_t* list, int64_t K, const uint32_t* off, const char* src, uint32_t elem_size, const uint32_t* new_off, char* dst) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  const uint32_t a = off[list[k]], n = (off[list[k] + 1] - a) * elem_size;
+  const char* s = src + (size_t)a * elem_size;
+  char* d = dst + (size_t)new_off[k] * elem_size;
+  for (uint32_t b = 0; b < n; ++b) d[b] = s[b];
 }
 
 __global__ void k_copy_offsets(const uint32_t* src, int64_t n, uint32_t base, uint32_t* dst) {
@@ -1123,6 +1239,7 @@ struct DevicePipeline::Impl {
   // cell-stream staging (append_cells)
   DevBuf<uint8_t> raw_cells; DevBuf<uint64_t> raw_off; DevBuf<int32_t> raw_row_map, raw_qrow; DevBuf<uint32_t> raw_keep, raw_dest, raw_len, raw_voff, raw_mark, raw_mdest;
   DevBuf<int64_t> raw_begin, raw_end;
+  DevBuf<long long> carry_last; DevBuf<uint64_t> carry_keys, carry_sorted; int64_t carried_cells = 0;
   DevBuf<uint2> resolved;          // (pool offset, length) of every (record, sample): whole interval, or one page when that exceeds the budget
   DevBuf<uint32_t> type_occ;
   DevBuf<uint32_t> untabled, ubase; DevBuf<int32_t> urec, iota, order; DevBuf<uint32_t> order_keys, order_keys_sorted;
@@ -1131,6 +1248,7 @@ struct DevicePipeline::Impl {
   struct Part { FragmentView v; std::vector<size_t> data_bytes; std::vector<void*> bufs; };
   std::vector<Part> parts;
   std::vector<int> col_elem_size; std::vector<bool> col_var; std::vector<int> col_fixed_num;
+  std::unique_ptr<DevicePipeline::FragmentFile> ff;   // open columnar fragment file (windowed reads)
   struct IntervalState {
     bool active = false;
     int64_t P = 0, kp = 0;
@@ -1291,9 +1409,66 @@ void DevicePipeline::stage_fragment(const HostFragment& hf) {
   m_->classified = false;
 }
 
-void DevicePipeline::begin_staging() {
-  for (auto& p : m_->parts) for (void* b : p.bufs) (void)hipFree(b);
-  m_->parts.clear();
+void DevicePipeline::begin_staging(int64_t carry_from) {
+  Impl& S = *m_;
+  for (auto& p : S.parts) for (void* b : p.bufs) (void)hipFree(b);
+  S.parts.clear();
+  S.carried_cells = 0;
+  if (carry_from == INT64_MIN || S.fr.ncells == 0) return;
+  // ---- the staged fragment's live intervals at carry_from become the first part of the next fragment ---------------------
+  HIP_CHECK(hipSetDevice(S.device));
+  hipStream_t st = S.stream;
+  const int nf = S.hp.plan.nfields;
+  const int32_t N = S.hp.plan.num_query_rows;
+  if ((int)S.col_elem_size.size() < nf || !S.owns_fragment) throw GenomicsDBDeviceException("carry-over needs a fragment staged by this pipeline");
+  const FragmentView fr = S.fr;
+  const int64_t C = fr.ncells;
+  S.carry_last.ensure((size_t)N + 1); S.carry_keys.ensure((size_t)N + 1); S.carry_sorted.ensure((size_t)N + 1); S.cwin.ensure(4);
+  HIP_CHECK(hipMemsetAsync(S.carry_last.p, 0xFF, (size_t)N * sizeof(long long), st));
+  hipLaunchKernelGGL(k_last_in_row, dim3(blocks_for(C)), dim3(kBlock), 0, st, fr.row, C, S.carry_last.p);
+  hipLaunchKernelGGL(k_carry_select, dim3(blocks_for(N)), dim3(kBlock), 0, st, (const long long*)S.carry_last.p, fr.end, N, carry_from, S.carry_keys.p);
+  S.sort_keys(S.carry_keys.p, S.carry_sorted.p, (size_t)N, 64);
+  hipLaunchKernelGGL(k_count_valid_keys, dim3(1), dim3(64), 0, st, (const uint64_t*)S.carry_sorted.p, N, S.cwin.p);
+  const int64_t K = S.read_back(S.cwin.p);
+  if (K == 0) return;
+  Impl::Part part;
+  memset(&part.v, 0, sizeof(part.v));
+  part.v.ncells = K;
+  auto alloc = [&](size_t bytes) -> void* { void* d = nullptr; HIP_CHECK(hipMalloc(&d, std::max<size_t>(bytes, 16))); part.bufs.push_back(d); return d; };
+  const uint64_t* list = S.carry_sorted.p;
+  int32_t* row = (int32_t*)alloc((size_t)K * 4); int64_t* begin = (int64_t*)alloc((size_t)K * 8); int64_t* end = (int64_t*)alloc((size_t)K * 8);
+  hipLaunchKernelGGL(k_gather_coords, dim3(blocks_for(K)), dim3(kBlock), 0, st, list, K, fr.row, fr.begin, fr.end, row, begin, end);
+  part.v.row = row; part.v.begin = begin; part.v.end = end;
+  // variable-length columns: lengths -> offsets -> totals (one read-back for all fields)
+  std::vector<uint32_t*> new_off((size_t)nf, nullptr);
+  std::vector<uint32_t> totals((size_t)nf, 0);
+  S.raw_len.ensure((size_t)K + 2);
+  for (int f = 0; f < nf; ++f) if (S.col_var[(size_t)f]) {
+    new_off[(size_t)f] = (uint32_t*)alloc(((size_t)K + 1) * 4);
+    hipLaunchKernelGGL(k_gather_var_len, dim3(blocks_for(K + 1)), dim3(kBlock), 0, st, list, K, fr.col[f].off, S.raw_len.p);
+    S.excl_scan((const uint32_t*)S.raw_len.p, new_off[(size_t)f], (size_t)K + 1);
+  }
+  for (int f = 0; f < nf; ++f) if (S.col_var[(size_t)f]) totals[(size_t)f] = S.read_back(new_off[(size_t)f] + K);
+  part.data_bytes.assign((size_t)nf, 0);
+  for (int f = 0; f < nf; ++f) {
+    const uint32_t es = (uint32_t)S.col_elem_size[(size_t)f];
+    if (S.col_var[(size_t)f]) {
+      const size_t bytes = (size_t)totals[(size_t)f] * es;
+      char* data = (char*)alloc(bytes);
+      hipLaunchKernelGGL(k_gather_var, dim3(blocks_for(K)), dim3(kBlock), 0, st, list, K, fr.col[f].off, (const char*)fr.col[f].data, es, (const uint32_t*)new_off[(size_t)f], data);
+      part.v.col[f].data = data; part.v.col[f].off = new_off[(size_t)f];
+      part.data_bytes[(size_t)f] = bytes;
+    } else {
+      const uint32_t bpc = (uint32_t)S.col_fixed_num[(size_t)f] * es;
+      char* data = (char*)alloc((size_t)K * bpc);
+      hipLaunchKernelGGL(k_gather_fixed, dim3(blocks_for(K)), dim3(kBlock), 0, st, list, K, (const char*)fr.col[f].data, bpc, data);
+      part.v.col[f].data = data;
+      part.data_bytes[(size_t)f] = (size_t)K * bpc;
+    }
+  }
+  HIP_CHECK(hipStreamSynchronize(st));
+  S.parts.push_back(part);
+  S.carried_cells = K;
 }
 
 void DevicePipeline::append_fragment(const HostFragment& hf) {
@@ -1324,30 +1499,64 @@ void DevicePipeline::append_fragment(const HostFragment& hf) {
   m_->parts.push_back(part);
 }
 
+int64_t DevicePipeline::carried_cells() const { return m_->carried_cells; }
+
+// Walk of the cell sizes: the one sequential dependency of the format (every cell names its own size).  Stops at `nbytes` or,
+// with whole_columns_only, in front of the last begin column seen (it may continue behind the buffer).  offs gets the offset of
+// every cell taken plus the end offset.
+DevicePipeline::CellWalk DevicePipeline::walk_cells(const uint8_t* cells, uint64_t nbytes, const std::vector<int32_t>& row_map, bool whole_columns_only, std::vector<uint64_t>& offs) {
+  CellWalk w;
+  offs.clear();
+  offs.reserve((size_t)(nbytes / 128) + 16);
+  uint64_t off = 0, last_col_off = 0;
+  size_t last_col_idx = 0;
+  int64_t last_col = INT64_MIN, kept_at_col = 0, marks_at_col = 0; uint64_t bytes_at_col = 0;
+  while (off < nbytes) {
+    if (off + 32 > nbytes) { if (whole_columns_only) break; throw std::runtime_error("truncated cell stream"); }
+    int64_t row, col; uint64_t sz;
+    memcpy(&row, cells + off, 8); memcpy(&col, cells + off + 8, 8); memcpy(&sz, cells + off + 16, 8);
+    if (sz < 32) throw std::runtime_error("malformed cell stream (cell size below the fixed part)");
+    if (off + sz > nbytes) { if (whole_columns_only) break; throw std::runtime_error("truncated cell stream"); }
+    if (col != last_col) {
+      if (col < last_col) throw std::runtime_error("cells are not in column-major (col,row) order");
+      last_col = col; last_col_off = off; last_col_idx = offs.size(); kept_at_col = w.nkept; marks_at_col = w.nmark; bytes_at_col = w.reference_cell_bytes;
+    }
+    offs.push_back(off);
+    if (row >= 0 && (size_t)row < row_map.size()) { if (row_map[(size_t)row] >= 0) { ++w.nkept; w.reference_cell_bytes += sz; } else ++w.nmark; }
+    off += sz;
+  }
+  if (whole_columns_only && offs.empty() && nbytes > 0) { w.single_column = true; }   // not even one whole cell: offer more bytes
+  if (whole_columns_only && !offs.empty()) {
+    // more bytes follow this buffer: the last begin column seen may continue there, so it is left for the next call
+    if (last_col_idx > 0) { offs.resize(last_col_idx); off = last_col_off; w.nkept = kept_at_col; w.nmark = marks_at_col; w.reference_cell_bytes = bytes_at_col; }
+    else { offs.clear(); off = 0; w.nkept = w.nmark = 0; w.reference_cell_bytes = 0; w.single_column = true; }   // one column fills the buffer: offer more bytes
+    w.next_begin = last_col;
+  }
+  w.bytes_taken = off;
+  if (!offs.empty()) { int64_t c0; memcpy(&c0, cells + offs[0] + 8, 8); w.first_begin = c0; int64_t c1; memcpy(&c1, cells + offs.back() + 8, 8); w.last_begin = c1; }
+  offs.push_back(off);
+  return w;
+}
+
 DevicePipeline::CellStreamInfo DevicePipeline::append_cells(const uint8_t* cells, uint64_t nbytes, const VariantArraySchemaLite& schema,
-                                                          const std::vector<int>& attr_to_field, const std::vector<int32_t>& row_map) {
+                                                          const std::vector<int>& attr_to_field, const std::vector<int32_t>& row_map, const std::vector<uint64_t>* walked,
+                                                          const CellWalk* walk_info) {
   Impl& S = *m_;
   CellStreamInfo info;
   HIP_CHECK(hipSetDevice(S.device));
   hipStream_t st = S.stream;
   if (nbytes == 0) return info;
   if (schema.attrs.size() > (size_t)kMaxSchemaAttrs) throw UnsupportedOnDeviceException("more than 96 attributes in the array schema");
-  // ---- host: walk the cell sizes (the only sequential dependency of the format) --------------------------------------
-  std::vector<uint64_t> offs;
-  offs.reserve((size_t)(nbytes / 128) + 16);
-  int64_t nkept = 0, nmark = 0;
-  for (uint64_t off = 0; off < nbytes;) {
-    if (off + 32 > nbytes) throw std::runtime_error("truncated cell stream");
-    int64_t row; uint64_t sz;
-    memcpy(&row, cells + off, 8);
-    memcpy(&sz, cells + off + 16, 8);
-    if (sz < 32 || off + sz > nbytes) throw std::runtime_error("truncated cell stream");
-    offs.push_back(off);
-    if (row >= 0 && (size_t)row < row_map.size()) { if (row_map[(size_t)row] >= 0) { ++nkept; info.reference_cell_bytes += sz; } else ++nmark; }
-    off += sz;
-  }
-  const int64_t n = (int64_t)offs.size();
-  offs.push_back(nbytes);
+  std::vector<uint64_t> own;
+  CellWalk wk;
+  if (walked) { wk = *walk_info; }
+  else { wk = walk_cells(cells, nbytes, row_map, false, own); walked = &own; }
+  const std::vector<uint64_t>& offs = *walked;
+  const int64_t nkept = wk.nkept, nmark = wk.nmark;
+  info.reference_cell_bytes = wk.reference_cell_bytes;
+  const int64_t n = (int64_t)offs.size() - 1;
+  nbytes = offs.back();
+
   info.ncells = nkept;
   if (nkept == 0 && nmark == 0) return info;
   if (nkept >= (1ll << 32)) throw GenomicsDBDeviceException("more than 2^32 cells in one part: stage in smaller parts");
@@ -1378,8 +1587,8 @@ DevicePipeline::CellStreamInfo DevicePipeline::append_cells(const uint8_t* cells
     int v = 0;
     for (int f = 0; f < nf; ++f) if (S.col_var[(size_t)f]) { cols.len[f] = S.raw_len.p + (size_t)v * ((size_t)n + 1); cols.off[f] = S.raw_voff.p + (size_t)v * ((size_t)n + 1); ++v; }
   }
-  hipLaunchKernelGGL(k_cells_measure, dim3(blocks_for(n)), dim3(kBlock), 0, st, (const uint8_t*)S.raw_cells.p, (const uint64_t*)S.raw_off.p, n, sch,
-                     (const int32_t*)S.raw_row_map.p, (int64_t)row_map.size(), nf, S.raw_keep.p, S.raw_mark.p, S.raw_qrow.p, S.raw_begin.p, S.raw_end.p, cols, S.err.p);
+  hipLaunchKernelGGL(k_cells_measure, dim3(blocks_for(n, kStageBlock)), dim3(kStageBlock), 0, st, (const uint8_t*)S.raw_cells.p, (const uint64_t*)S.raw_off.p, n, sch,
+                     (const int32_t*)S.raw_row_map.p, (int64_t)row_map.size(), S.raw_keep.p, S.raw_mark.p, S.raw_qrow.p, S.raw_begin.p, S.raw_end.p, cols, S.err.p);
   HIP_CHECK(hipMemsetAsync(S.raw_keep.p + n, 0, sizeof(uint32_t), st));
   S.excl_scan(S.raw_keep.p, S.raw_dest.p, (size_t)n + 1);
   if (nmark > 0) { HIP_CHECK(hipMemsetAsync(S.raw_mark.p + n, 0, sizeof(uint32_t), st)); S.excl_scan(S.raw_mark.p, S.raw_mdest.p, (size_t)n + 1); }
@@ -1430,7 +1639,7 @@ DevicePipeline::CellStreamInfo DevicePipeline::append_cells(const uint8_t* cells
     part.v.col[f].data = cols.data[f];
     part.data_bytes.push_back(bytes);
   }
-  hipLaunchKernelGGL(k_cells_scatter, dim3(blocks_for(n)), dim3(kBlock), 0, st, (const uint8_t*)S.raw_cells.p, (const uint64_t*)S.raw_off.p, n, sch, (const uint32_t*)S.raw_keep.p,
+  hipLaunchKernelGGL(k_cells_scatter, dim3(blocks_for(n, kStageBlock)), dim3(kStageBlock), 0, st, (const uint8_t*)S.raw_cells.p, (const uint64_t*)S.raw_off.p, n, sch, (const uint32_t*)S.raw_keep.p,
                      (const uint32_t*)S.raw_dest.p, (const int32_t*)S.raw_qrow.p, (const int64_t*)S.raw_begin.p, (const int64_t*)S.raw_end.p, row, begin, end, cols);
   hipLaunchKernelGGL(k_cells_order_check, dim3(blocks_for(nkept)), dim3(kBlock), 0, st, (const int32_t*)row, (const int64_t*)begin, nkept, S.err.p);
   // first begin (the stream is sorted) and the largest END: what the FASTA window of the engine needs
@@ -1505,15 +1714,63 @@ void DevicePipeline::finish_staging() {
 
 // ---- columnar fragment file: the staged fragment as it lies in HBM, so that opening an array is file -> HBM copies ------
 // (the build's own fragment format; the Intel TileDB fork's on-disk format is not available.)
-// Layout, little endian: "GDBAMDF1", u32 version, u32 nfields, i64 ncells, i64 nmarkers, i32 num_rows, i32 pad,
-// u64 reference_cell_bytes, i64 min_begin, i64 max_end; per field: u8 var, u8 elem_size, u16 name_len, i32 fixed_num,
-// u64 data_bytes, name; then, each 64-byte aligned: row[], begin[], end[], marker_begin[], per field off[] (var only), data[].
+// Layout v2, little endian: "GDBAMDF2", u32 version, u32 nfields, i64 ncells, i64 nmarkers, i32 num_rows, i32 pad,
+// u64 reference_cell_bytes, i64 min_begin, i64 max_end, u64 schema_hash, u64 source_bytes, i64 source_mtime; per field: u8 var,
+// u8 elem_size, u16 name_len, i32 fixed_num, u64 data_bytes, name; then, each 64-byte aligned: row[], begin[], end[],
+// marker_begin[], per field off[] (var only), data[].  Cells are in (column, row) order, so a column window of the array is a
+// contiguous range of every section: the file is read window by window (open_fragment_file / append_fragment_cells) when the
+// array does not fit the staging budget.
 namespace {
-const char kFragMagic[8] = {'G', 'D', 'B', 'A', 'M', 'D', 'F', '1'};
+const char kFragMagic[8] = {'G', 'D', 'B', 'A', 'M', 'D', 'F', '2'};
 struct FragFieldHdr { uint8_t var, elem_size; uint16_t name_len; int32_t fixed_num; uint64_t data_bytes; };
 void put_bytes(std::vector<uint8_t>& o, const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; o.insert(o.end(), b, b + n); }
 void pad64(FILE* f, uint64_t& at) { static const char z[64] = {0}; const size_t r = (size_t)((64 - (at & 63)) & 63); if (r) { fwrite(z, 1, r, f); at += r; } }
+uint64_t align64(uint64_t at) { return (at + 63) & ~(uint64_t)63; }
 }  // namespace
+
+struct DevicePipeline::FragmentFile {
+  int fd = -1;
+  std::string path;
+  uint64_t file_size = 0;
+  FragmentFileMeta meta;
+  int64_t C = 0, M = 0;
+  uint64_t row_at = 0, begin_at = 0, end_at = 0, marker_at = 0;
+  struct Field { bool var = false; int elem_size = 4, fixed_num = 1; uint64_t data_bytes = 0, off_at = 0, data_at = 0; int plan_field = -1; };
+  std::vector<Field> fields;
+  std::vector<int64_t> markers;     // whole array on the host (boundary markers are rare: cells of rows outside the query)
+  size_t marker_cursor = 0;
+  // two pinned bounce buffers for file -> HBM copies
+  char* bounce[2] = {nullptr, nullptr};
+  hipEvent_t bounce_free[2] = {nullptr, nullptr};
+  static constexpr size_t kBounce = (size_t)64 << 20;
+  ~FragmentFile() {
+    if (fd >= 0) ::close(fd);
+    for (auto& b : bounce) if (b) (void)hipHostFree(b);
+    for (auto& e : bounce_free) if (e) (void)hipEventDestroy(e);
+  }
+  void read_at(void* dst, uint64_t at, size_t n) const {
+    char* d = (char*)dst;
+    while (n) {
+      const ssize_t k = ::pread(fd, d, n, (off_t)at);
+      if (k <= 0) throw std::runtime_error(path + ": truncated fragment file");
+      d += k; at += (uint64_t)k; n -= (size_t)k;
+    }
+  }
+  int64_t begin_of(int64_t c) const { int64_t v; read_at(&v, begin_at + (uint64_t)c * 8, 8); return v; }
+  // file bytes [at, at + n) -> device memory, through the pinned buffers (the read of chunk i + 1 overlaps the copy of chunk i)
+  void to_device(void* dev, uint64_t at, uint64_t n, hipStream_t st) {
+    int which = 0;
+    for (uint64_t done = 0; done < n;) {
+      const size_t k = (size_t)std::min<uint64_t>(kBounce, n - done);
+      if (!bounce[which]) { HIP_CHECK(hipHostMalloc((void**)&bounce[which], kBounce, hipHostMallocDefault)); HIP_CHECK(hipEventCreateWithFlags(&bounce_free[which], hipEventDisableTiming)); }
+      else HIP_CHECK(hipEventSynchronize(bounce_free[which]));
+      read_at(bounce[which], at + done, k);
+      HIP_CHECK(hipMemcpyAsync((char*)dev + done, bounce[which], k, hipMemcpyHostToDevice, st));
+      HIP_CHECK(hipEventRecord(bounce_free[which], st));
+      done += k; which ^= 1;
+    }
+  }
+};
 
 void DevicePipeline::save_fragment(const std::string& path, const FragmentFileMeta& meta) {
   Impl& S = *m_;
@@ -1532,24 +1789,31 @@ void DevicePipeline::save_fragment(const std::string& path, const FragmentFileMe
   }
   std::vector<uint8_t> hdr;
   put_bytes(hdr, kFragMagic, 8);
-  const uint32_t version = 1, nfields = (uint32_t)nf;
+  const uint32_t version = 2, nfields = (uint32_t)nf;
   const int32_t num_rows = S.hp.plan.num_query_rows, pad = 0;
   put_bytes(hdr, &version, 4); put_bytes(hdr, &nfields, 4); put_bytes(hdr, &C, 8); put_bytes(hdr, &fr.nmarkers, 8); put_bytes(hdr, &num_rows, 4); put_bytes(hdr, &pad, 4);
   put_bytes(hdr, &meta.reference_cell_bytes, 8); put_bytes(hdr, &meta.min_begin, 8); put_bytes(hdr, &meta.max_end, 8);
+  put_bytes(hdr, &meta.schema_hash, 8); put_bytes(hdr, &meta.source_bytes, 8); put_bytes(hdr, &meta.source_mtime, 8);
   for (int f = 0; f < nf; ++f) {
     const std::string& name = S.hp.field_names[(size_t)f];
     FragFieldHdr h{(uint8_t)(S.col_var[(size_t)f] ? 1 : 0), (uint8_t)S.col_elem_size[(size_t)f], (uint16_t)name.size(), (int32_t)S.col_fixed_num[(size_t)f], data_bytes[(size_t)f]};
     put_bytes(hdr, &h, sizeof(h)); put_bytes(hdr, name.data(), name.size());
   }
-  FILE* fp = fopen(path.c_str(), "wb");
-  if (!fp) throw std::runtime_error("cannot create " + path);
+  const std::string tmp_path = path + ".tmp";
+  FILE* fp = fopen(tmp_path.c_str(), "wb");
+  if (!fp) throw std::runtime_error("cannot create " + tmp_path);
   uint64_t at = 0;
   fwrite(hdr.data(), 1, hdr.size(), fp); at += hdr.size();
   std::vector<uint8_t> host;
   auto dump = [&](const void* dev, uint64_t bytes) {
     pad64(fp, at);
-    host.resize((size_t)bytes);
-    if (bytes) { HIP_CHECK(hipMemcpy(host.data(), dev, (size_t)bytes, hipMemcpyDeviceToHost)); if (fwrite(host.data(), 1, (size_t)bytes, fp) != bytes) { fclose(fp); throw std::runtime_error("short write to " + path); } }
+    for (uint64_t done = 0; done < bytes;) {     // in pieces: a column of a large array does not have to fit host memory twice
+      const size_t k = (size_t)std::min<uint64_t>((uint64_t)256 << 20, bytes - done);
+      host.resize(k);
+      HIP_CHECK(hipMemcpy(host.data(), (const char*)dev + done, k, hipMemcpyDeviceToHost));
+      if (fwrite(host.data(), 1, k, fp) != k) { fclose(fp); throw std::runtime_error("short write to " + tmp_path); }
+      done += k;
+    }
     at += bytes;
   };
   dump(fr.row, (uint64_t)C * 4); dump(fr.begin, (uint64_t)C * 8); dump(fr.end, (uint64_t)C * 8); dump(fr.marker_begin, (uint64_t)fr.nmarkers * 8);
@@ -1557,68 +1821,180 @@ void DevicePipeline::save_fragment(const std::string& path, const FragmentFileMe
     if (S.col_var[(size_t)f]) dump(fr.col[f].off, (uint64_t)(C + 1) * 4);
     dump(fr.col[f].data, data_bytes[(size_t)f]);
   }
-  fclose(fp);
+  if (fclose(fp) != 0 || rename(tmp_path.c_str(), path.c_str()) != 0) throw std::runtime_error("cannot write " + path);
 }
 
-FragmentFileMeta DevicePipeline::load_fragment(const std::string& path) {
+// Opens and VALIDATES a fragment file: every size the header names is checked against the file and every column against the
+// layout the query's schema expects (expected[f] for plan field f), so that a foreign or stale file is refused here instead of
+// faulting in a kernel.  Nothing of the pipeline changes when this throws.
+FragmentFileMeta DevicePipeline::open_fragment_file(const std::string& path, const std::vector<ColumnLayout>& expected, uint64_t expected_schema_hash) {
   Impl& S = *m_;
-  HIP_CHECK(hipSetDevice(S.device));
-  FILE* fp = fopen(path.c_str(), "rb");
-  if (!fp) throw std::runtime_error("cannot open " + path);
-  auto fail = [&](const std::string& why) { fclose(fp); throw std::runtime_error(path + ": " + why); };
+  std::unique_ptr<FragmentFile> ff(new FragmentFile);
+  ff->path = path;
+  ff->fd = ::open(path.c_str(), O_RDONLY);
+  if (ff->fd < 0) throw std::runtime_error("cannot open " + path);
+  struct stat sb;
+  if (fstat(ff->fd, &sb) != 0) throw std::runtime_error("cannot stat " + path);
+  ff->file_size = (uint64_t)sb.st_size;
+  auto fail = [&](const std::string& why) { throw std::runtime_error(path + ": " + why); };
   uint64_t at = 0;
-  auto rd = [&](void* p, size_t n) { if (fread(p, 1, n, fp) != n) fail("truncated fragment file"); at += n; };
+  auto rd = [&](void* p, size_t n) { if (at + n > ff->file_size) fail("truncated fragment file"); ff->read_at(p, at, n); at += n; };
   char magic[8];
   rd(magic, 8);
-  if (memcmp(magic, kFragMagic, 8) != 0) fail("not a genomicsdb_amd fragment file");
+  if (memcmp(magic, kFragMagic, 8) != 0) fail("not a genomicsdb_amd fragment file (version 2)");
   uint32_t version, nfields; int64_t C, M; int32_t num_rows, pad;
   FragmentFileMeta meta;
   rd(&version, 4); rd(&nfields, 4); rd(&C, 8); rd(&M, 8); rd(&num_rows, 4); rd(&pad, 4);
-  rd(&meta.reference_cell_bytes, 8); rd(&meta.min_begin, 8); rd(&meta.max_end, 8);
-  if (version != 1) fail("unsupported fragment file version");
+  rd(&meta.reference_cell_bytes, 8); rd(&meta.min_begin, 8); rd(&meta.max_end, 8); rd(&meta.schema_hash, 8); rd(&meta.source_bytes, 8); rd(&meta.source_mtime, 8);
+  if (version != 2) fail("unsupported fragment file version");
+  if (nfields == 0 || nfields > 4096) fail("implausible number of fields");
+  if (C < 0 || M < 0 || (uint64_t)C > ff->file_size / 20 + 1 || (uint64_t)M > ff->file_size / 8 + 1) fail("implausible cell / marker count");
   if (num_rows != S.hp.plan.num_query_rows) fail("fragment file was written for another set of query rows");
+  if (expected_schema_hash && meta.schema_hash != expected_schema_hash) fail("fragment file was written under another vid / callset mapping (stale)");
   struct FileField { FragFieldHdr h; std::string name; };
-  std::vector<FileField> ff(nfields);
-  for (auto& x : ff) { rd(&x.h, sizeof(x.h)); x.name.resize(x.h.name_len); if (x.h.name_len) rd(&x.name[0], x.h.name_len); }
+  std::vector<FileField> file_fields(nfields);
+  for (auto& x : file_fields) { rd(&x.h, sizeof(x.h)); x.name.resize(x.h.name_len); if (x.h.name_len) rd(&x.name[0], x.h.name_len); }
   const int nf = S.hp.plan.nfields;
+  if ((int)expected.size() != nf) fail("internal: expected column layouts do not match the plan");
   std::vector<int> file_to_plan(nfields, -1);
   for (int f = 0; f < nf; ++f) {
     int found = -1;
-    for (uint32_t i = 0; i < nfields; ++i) if (ff[i].name == S.hp.field_names[(size_t)f]) found = (int)i;
+    for (uint32_t i = 0; i < nfields; ++i) if (file_fields[i].name == S.hp.field_names[(size_t)f]) found = (int)i;
     if (found < 0) fail("attribute " + S.hp.field_names[(size_t)f] + " of the query is not in the fragment file");
+    const FragFieldHdr& h = file_fields[(size_t)found].h;
+    const ColumnLayout& want = expected[(size_t)f];
+    if ((h.var != 0) != want.var || (int)h.elem_size != want.elem_size || (!want.var && h.fixed_num != want.fixed_num))
+      fail("attribute " + S.hp.field_names[(size_t)f] + " has another layout in the fragment file than in the array schema");
     file_to_plan[(size_t)found] = f;
   }
-  S.free_owned();
-  FragmentView v;
-  memset(&v, 0, sizeof(v));
-  v.ncells = C; v.nmarkers = M;
-  meta.ncells = C;
-  std::vector<uint8_t> host;
-  auto skip_pad = [&]() { const size_t r = (size_t)((64 - (at & 63)) & 63); if (r) { if (fseek(fp, (long)r, SEEK_CUR) != 0) fail("truncated fragment file"); at += r; } };
-  auto load = [&](uint64_t bytes, bool keep) -> void* {
-    skip_pad();
-    void* d = nullptr;
-    if (keep) { HIP_CHECK(hipMalloc(&d, std::max<size_t>((size_t)bytes, 16))); S.owned.push_back(d); }
-    if (bytes) {
-      if (keep) { host.resize((size_t)bytes); rd(host.data(), (size_t)bytes); HIP_CHECK(hipMemcpy(d, host.data(), (size_t)bytes, hipMemcpyHostToDevice)); }
-      else { if (fseek(fp, (long)bytes, SEEK_CUR) != 0) fail("truncated fragment file"); at += bytes; }
-    }
-    return d;
-  };
-  v.row = (const int32_t*)load((uint64_t)C * 4, true); v.begin = (const int64_t*)load((uint64_t)C * 8, true); v.end = (const int64_t*)load((uint64_t)C * 8, true);
-  v.marker_begin = (const int64_t*)load((uint64_t)M * 8, true);
-  S.col_elem_size.assign((size_t)nf, 4); S.col_var.assign((size_t)nf, false); S.col_fixed_num.assign((size_t)nf, 1);
+  // section offsets, each checked against the file size
+  auto section = [&](uint64_t bytes) -> uint64_t { at = align64(at); const uint64_t here = at; if (bytes > ff->file_size || here > ff->file_size - bytes) fail("truncated fragment file"); at += bytes; return here; };
+  ff->C = C; ff->M = M;
+  ff->row_at = section((uint64_t)C * 4); ff->begin_at = section((uint64_t)C * 8); ff->end_at = section((uint64_t)C * 8); ff->marker_at = section((uint64_t)M * 8);
+  ff->fields.resize(nfields);
   for (uint32_t i = 0; i < nfields; ++i) {
-    const int f = file_to_plan[i];
-    const bool keep = f >= 0;
-    const uint32_t* off = ff[i].h.var ? (const uint32_t*)load((uint64_t)(C + 1) * 4, keep) : nullptr;
-    const void* data = load(ff[i].h.data_bytes, keep);
-    if (keep) { v.col[f].off = off; v.col[f].data = data; S.col_elem_size[(size_t)f] = ff[i].h.elem_size; S.col_var[(size_t)f] = ff[i].h.var != 0; S.col_fixed_num[(size_t)f] = ff[i].h.fixed_num; }
+    FragmentFile::Field& fd = ff->fields[i];
+    const FragFieldHdr& h = file_fields[i].h;
+    fd.var = h.var != 0; fd.elem_size = h.elem_size; fd.fixed_num = h.fixed_num; fd.data_bytes = h.data_bytes; fd.plan_field = file_to_plan[i];
+    if (fd.elem_size != 1 && fd.elem_size != 4 && fd.elem_size != 8) fail("unsupported element size");
+    if (fd.var) fd.off_at = section((uint64_t)(C + 1) * 4);
+    else if (fd.data_bytes != (uint64_t)C * (uint64_t)fd.fixed_num * (uint64_t)fd.elem_size) fail("fixed-length column size does not match the cell count");
+    fd.data_at = section(fd.data_bytes);
+    if (fd.var && C > 0) {   // the last offset has to name exactly the bytes of the data section
+      uint32_t first = 0, last = 0;
+      ff->read_at(&first, fd.off_at, 4); ff->read_at(&last, fd.off_at + (uint64_t)C * 4, 4);
+      if (first != 0 || (uint64_t)last * (uint64_t)fd.elem_size != fd.data_bytes) fail("offsets of a variable-length column do not match its data section");
+    }
   }
-  fclose(fp);
-  S.fr = v;
-  S.owns_fragment = true;
-  S.classified = false;
+  if (M > 0) { ff->markers.resize((size_t)M); ff->read_at(ff->markers.data(), ff->marker_at, (size_t)M * 8); }
+  meta.ncells = C;
+  ff->meta = meta;
+  S.ff = std::move(ff);
+  return meta;
+}
+
+void DevicePipeline::close_fragment_file() { m_->ff.reset(); }
+
+// first cell of the open file whose begin column is >= column
+int64_t DevicePipeline::fragment_file_lower_bound(int64_t column) {
+  FragmentFile& F = *m_->ff;
+  int64_t lo = 0, hi = F.C;
+  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (F.begin_of(mid) < column) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+
+// Appends the cells [c0, c1) of the open file to the staging area as one part, c1 chosen so that the part holds whole begin
+// columns and about budget_bytes of file data (at least one column).  Requires begin_staging() before and finish_staging() after.
+DevicePipeline::FragmentWindow DevicePipeline::append_fragment_cells(int64_t c0, uint64_t budget_bytes) {
+  Impl& S = *m_;
+  if (!S.ff) throw GenomicsDBDeviceException("append_fragment_cells: no fragment file is open");
+  FragmentFile& F = *S.ff;
+  HIP_CHECK(hipSetDevice(S.device));
+  hipStream_t st = S.stream;
+  FragmentWindow w;
+  w.c0 = c0; w.c1 = c0;
+  if (c0 >= F.C) return w;
+  // ---- the cut: whole columns, about budget_bytes ----------------------------------------------------------------------
+  const double bytes_per_cell = std::max(1.0, (double)F.file_size / (double)std::max<int64_t>(1, F.C));
+  int64_t want = std::max<int64_t>(1, (int64_t)((double)budget_bytes / bytes_per_cell));
+  int64_t c1;
+  for (;;) {
+    c1 = std::min(F.C, c0 + want);
+    if (c1 >= F.C) { c1 = F.C; break; }
+    // move the cut back to the first cell of the column that holds cell c1 (that column goes to the next window)
+    const int64_t col = F.begin_of(c1);
+    int64_t lo = c0, hi = c1;      // first cell in [c0, c1] with begin == col
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (F.begin_of(mid) < col) lo = mid + 1; else hi = mid; }
+    if (lo > c0) { c1 = lo; break; }
+    want *= 2;                     // one column is wider than the budget: take more
+  }
+  const int64_t n = c1 - c0;
+  w.c1 = c1; w.ncells = n;
+  w.first_begin = F.begin_of(c0); w.last_begin = F.begin_of(c1 - 1);
+  w.next_begin = c1 < F.C ? F.begin_of(c1) : INT64_MAX;
+  w.reference_cell_bytes = F.C > 0 ? (uint64_t)((double)F.meta.reference_cell_bytes * ((double)n / (double)F.C)) : 0;
+  // ---- the part ----------------------------------------------------------------------------------------------------------
+  Impl::Part part;
+  memset(&part.v, 0, sizeof(part.v));
+  part.v.ncells = n;
+  auto alloc = [&](size_t bytes) -> void* { void* d = nullptr; HIP_CHECK(hipMalloc(&d, std::max<size_t>(bytes, 16))); part.bufs.push_back(d); return d; };
+  void* row = alloc((size_t)n * 4); void* begin = alloc((size_t)n * 8); void* end = alloc((size_t)n * 8);
+  F.to_device(row, F.row_at + (uint64_t)c0 * 4, (uint64_t)n * 4, st);
+  F.to_device(begin, F.begin_at + (uint64_t)c0 * 8, (uint64_t)n * 8, st);
+  F.to_device(end, F.end_at + (uint64_t)c0 * 8, (uint64_t)n * 8, st);
+  part.v.row = (const int32_t*)row; part.v.begin = (const int64_t*)begin; part.v.end = (const int64_t*)end;
+  const int nf = S.hp.plan.nfields;
+  S.col_elem_size.assign((size_t)nf, 4); S.col_var.assign((size_t)nf, false); S.col_fixed_num.assign((size_t)nf, 1);
+  part.data_bytes.assign((size_t)nf, 0);
+  for (const FragmentFile::Field& fd : F.fields) {
+    const int f = fd.plan_field;
+    if (f < 0) continue;
+    S.col_elem_size[(size_t)f] = fd.elem_size; S.col_var[(size_t)f] = fd.var; S.col_fixed_num[(size_t)f] = fd.fixed_num;
+    if (fd.var) {
+      uint32_t o0 = 0, o1 = 0;
+      F.read_at(&o0, fd.off_at + (uint64_t)c0 * 4, 4); F.read_at(&o1, fd.off_at + (uint64_t)c1 * 4, 4);
+      if (o1 < o0 || (uint64_t)o1 * (uint64_t)fd.elem_size > fd.data_bytes) throw std::runtime_error(F.path + ": corrupt offsets in a variable-length column");
+      uint32_t* off = (uint32_t*)alloc(((size_t)n + 1) * 4);
+      F.to_device(off, fd.off_at + (uint64_t)c0 * 4, ((uint64_t)n + 1) * 4, st);
+      hipLaunchKernelGGL(k_copy_offsets, dim3(blocks_for(n + 1)), dim3(kBlock), 0, st, (const uint32_t*)off, n + 1, (uint32_t)(0u - o0), off);   // rebase to the part
+      const uint64_t bytes = (uint64_t)(o1 - o0) * (uint64_t)fd.elem_size;
+      void* data = alloc((size_t)bytes);
+      F.to_device(data, fd.data_at + (uint64_t)o0 * (uint64_t)fd.elem_size, bytes, st);
+      part.v.col[f].off = off; part.v.col[f].data = data;
+      part.data_bytes[(size_t)f] = (size_t)bytes;
+    } else {
+      const uint64_t bpc = (uint64_t)fd.fixed_num * (uint64_t)fd.elem_size;
+      void* data = alloc((size_t)((uint64_t)n * bpc));
+      F.to_device(data, fd.data_at + (uint64_t)c0 * bpc, (uint64_t)n * bpc, st);
+      part.v.col[f].data = data;
+      part.data_bytes[(size_t)f] = (size_t)((uint64_t)n * bpc);
+    }
+  }
+  // boundary markers whose column falls into this window
+  {
+    size_t m0 = F.marker_cursor;
+    if (m0 > 0 && (m0 > F.markers.size() || F.markers[m0 - 1] >= w.first_begin)) m0 = 0;           // a seek backwards: search again
+    while (m0 < F.markers.size() && F.markers[m0] < w.first_begin) ++m0;
+    size_t m1 = m0;
+    while (m1 < F.markers.size() && F.markers[m1] < w.next_begin) ++m1;
+    F.marker_cursor = m1;
+    if (m1 > m0) {
+      int64_t* mk = (int64_t*)alloc((m1 - m0) * 8);
+      HIP_CHECK(hipMemcpyAsync(mk, F.markers.data() + m0, (m1 - m0) * 8, hipMemcpyHostToDevice, st));
+      part.v.nmarkers = (int64_t)(m1 - m0); part.v.marker_begin = mk;
+    }
+  }
+  HIP_CHECK(hipStreamSynchronize(st));
+  S.parts.push_back(part);
+  return w;
+}
+
+FragmentFileMeta DevicePipeline::load_fragment(const std::string& path, const std::vector<ColumnLayout>& expected, uint64_t expected_schema_hash) {
+  const FragmentFileMeta meta = open_fragment_file(path, expected, expected_schema_hash);
+  begin_staging();
+  append_fragment_cells(0, UINT64_MAX / 4);
+  finish_staging();
+  close_fragment_file();
   return meta;
 }
 

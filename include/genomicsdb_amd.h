@@ -41,6 +41,10 @@ uint64_t gdb_mi355_get_num_bytes_available(void* handle);       /* jniGenomicsDB
 int gdb_mi355_read_next_byte(void* handle);                     /* jniGenomicsDBReadNextByte: byte or -1 */
 int64_t gdb_mi355_read(void* handle, uint8_t* dst, uint64_t offset, uint64_t n); /* jniGenomicsDBRead: bytes copied, -1 on error */
 int64_t gdb_mi355_skip(void* handle, uint64_t n);               /* jniGenomicsDBSkip */
+/* The unread bytes of the current batch where they lie (a pinned ring buffer), without copying: *ptr / *n are valid until the
+ * next call on this handle; consume them with gdb_mi355_skip.  1 = bytes available, 0 = end of the stream, -1 = error.
+ * (reference: GenomicsDBBCFGenerator::get_read_batch, include/vcf/genomicsdb_bcf_generator.h:60-63, which the JNI read loop uses) */
+int gdb_mi355_peek(void* handle, const uint8_t** ptr, uint64_t* n);
 /* How the stream was drained so far (not part of the reference's surface; bench / diagnostics).  The device assembles pages
  * of GDBAMD_DEVICE_PAGE_MB (default 2048) MiB alternately into two HBM arenas - independently of buffer_capacity - and drains them
  * through a ring of pinned host buffers (GDBAMD_RING_SLOTS x GDBAMD_RING_SLOT_MB, default 4 x 64 MiB) on a copy stream while the
@@ -90,6 +94,22 @@ int gdbamd_engine_split_point(void* engine, int64_t column_begin, int64_t column
  * Intel TileDB fork's on-disk format of the reference, variant_storage_manager.cc:61-153, is not available). */
 int gdbamd_engine_save_fragment(void* engine, const char* path);
 int gdbamd_engine_load_fragment(void* engine, const char* path);
+/* Arrays larger than the staging budget (GDBAMD_STAGE_BUDGET_MB, default 8192 MiB of cells per window): instead of staging by
+ * hand, name a source and let the engine pass it through HBM in column windows, carrying the intervals that are still live at a
+ * window's end into the next one on the device (the analogue of the reference's segment-at-a-time array iterator and
+ * VariantQueryProcessorScanState: variant_storage_manager.cc:61-153, query_variants.h:126-191).
+ *   open_array:         <dir>/fragment.gdbamd when it is valid for this query (checked against the array schema, the vid /
+ *                       callset mapping and the cells.bin it was made from), else <dir>/cells.bin
+ *   open_memory_cells:  begin-cells in host memory (the caller keeps them alive until the engine is destroyed)
+ *   open_cell_callback: cells produced on demand; fn hands out the next chunk of whole begin columns (valid until the next call)
+ *                       and returns 1, or returns 0 when there are no more; one pass, front to back
+ * cover(column) stages windows until `column` is covered and returns the range [*lo, *hi] of query positions the staged
+ * fragment serves: run intervals inside it, then ask again with *hi + 1. */
+typedef int (*gdbamd_cell_chunk_fn)(void* user, const uint8_t** cells, uint64_t* nbytes);
+int gdbamd_engine_open_array(void* engine, const char* dir);
+int gdbamd_engine_open_memory_cells(void* engine, const uint8_t* cells, uint64_t nbytes);
+int gdbamd_engine_open_cell_callback(void* engine, gdbamd_cell_chunk_fn fn, void* user);
+int gdbamd_engine_cover(void* engine, int64_t column, int64_t* lo, int64_t* hi);
 /* what is staged: #begin-cells and the sum of their reference binary-cell sizes ("bytes_in" of the byte accounting) */
 int gdbamd_engine_staged_info(void* engine, int64_t* ncells, uint64_t* reference_cell_bytes);
 /* reference bases for TileDB columns [begin, begin+len) (host pointer) */

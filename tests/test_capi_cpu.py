@@ -59,3 +59,23 @@ def test_unsupported_configurations_are_rejected_by_name():
     q, _ = helpers.query_json("t0_1_2_all_asa.json", "vid_all_asa.json", {}, "load")
     with pytest.raises(genomicsdb_amd.GenomicsDBException, match="UnsupportedOnDevice|not on the device path|multi-dimensional"):
         genomicsdb_amd.CombineEngine(q)
+
+
+def test_jni_glue_exports_every_native_method_of_the_java_classes():
+    """libtiledbgenomicsdb.so (built against a JDK's jni.h or the stand-in csrc/jni/stub/jni.h) must export the seven natives
+    GATK4's reader reaches: the six of GenomicsDBQueryStream (reference src/main/jni/include/genomicsdb_GenomicsDBQueryStream.h:17-58)
+    and GenomicsDBLibLoader.jniGenomicsDBOneTimeInitialize (src/main/jni/include/genomicsdb_GenomicsDBLibLoader.h)"""
+    import os
+    import subprocess
+    from genomicsdb_amd import build as b
+    so = b.build_jni()
+    assert so and os.path.exists(so)
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", so]).decode()
+    want = ["Java_com_intel_genomicsdb_GenomicsDBLibLoader_jniGenomicsDBOneTimeInitialize"] + [
+        "Java_com_intel_genomicsdb_reader_GenomicsDBQueryStream_jniGenomicsDB" + m
+        for m in ("Init", "Close", "GetNumBytesAvailable", "ReadNextByte", "Read", "Skip")]
+    for w in want:
+        assert (" T " + w) in syms, w
+    # and it resolves against the product library, nothing else of ours
+    needed = subprocess.check_output(["readelf", "-d", so]).decode()
+    assert "libgenomicsdb_amd.so" in needed and "oracle" not in needed
