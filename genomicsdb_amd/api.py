@@ -27,19 +27,23 @@ class GenomicsDBQueryStream:
     """Byte stream of the combined gVCF (header first), the Python face of the six JNI entry points."""
 
     def __init__(self, loader_json_file=None, query_json_file=None, chr="", start=0, end=0, rank=0, buffer_capacity=1048576,
-                 segment_size=1048576, is_bcf=False, produce_header_only=False, query_json=None, cells=None):
+                 segment_size=1048576, is_bcf=False, produce_header_only=False, query_json=None, cells=None,
+                 use_missing_values_only_not_vector_end=False, keep_idx_fields_in_bcf_header=True):
         L = _lib.lib()
         if query_json is not None:
             txt = query_json if isinstance(query_json, str) else json.dumps(query_json)
             if isinstance(cells, tuple):      # (host address, nbytes): cells that already lie in native memory (synthetic generator)
                 self._cells = None
-                self._h = L.gdb_mi355_init_from_memory(txt.encode(), ctypes.cast(cells[0], ctypes.c_char_p), cells[1], buffer_capacity, int(produce_header_only))
+                self._h = L.gdb_mi355_init_from_memory_format(txt.encode(), ctypes.cast(cells[0], ctypes.c_char_p), cells[1], buffer_capacity, int(produce_header_only),
+                                                              int(is_bcf), int(use_missing_values_only_not_vector_end), int(keep_idx_fields_in_bcf_header))
             else:
                 self._cells = bytes(cells or b"")
-                self._h = L.gdb_mi355_init_from_memory(txt.encode(), self._cells, len(self._cells), buffer_capacity, int(produce_header_only))
+                self._h = L.gdb_mi355_init_from_memory_format(txt.encode(), self._cells, len(self._cells), buffer_capacity, int(produce_header_only),
+                                                              int(is_bcf), int(use_missing_values_only_not_vector_end), int(keep_idx_fields_in_bcf_header))
         else:
             self._h = L.gdb_mi355_init((loader_json_file or "").encode(), (query_json_file or "").encode(), chr.encode(), start, end, rank,
-                                       buffer_capacity, segment_size, int(is_bcf), int(produce_header_only), 0, 1)
+                                       buffer_capacity, segment_size, int(is_bcf), int(produce_header_only), int(use_missing_values_only_not_vector_end),
+                                       int(keep_idx_fields_in_bcf_header))
         _check(self._h, "GenomicsDBQueryStream init")
 
     def read(self, n=-1):
@@ -92,10 +96,10 @@ class GenomicsDBQueryStream:
 class CombineEngine:
     """One column partition on one GPU: stage cells (or adopt device columns), run query intervals."""
 
-    def __init__(self, query_json, device=0):
+    def __init__(self, query_json, device=0, is_bcf=False, use_missing_values_only_not_vector_end=False):
         L = _lib.lib()
         txt = query_json if isinstance(query_json, str) else json.dumps(query_json)
-        self._e = L.gdbamd_engine_create(txt.encode(), device)
+        self._e = L.gdbamd_engine_create_format(txt.encode(), device, int(is_bcf), int(use_missing_values_only_not_vector_end))
         _check(self._e, "CombineEngine create")
         self._keep = []
 

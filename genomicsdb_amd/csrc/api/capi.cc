@@ -36,6 +36,12 @@ void* gdb_mi355_init(const char* loader_json_file, const char* query_json_file, 
 void* gdb_mi355_init_from_memory(const char* query_json_text, const uint8_t* cells, uint64_t nbytes, uint64_t buffer_capacity, int produce_header_only) {
   return guarded([&]() -> void* { return new GenomicsDBBCFGenerator(std::string(query_json_text), cells, nbytes, buffer_capacity, produce_header_only != 0); }, (void*)nullptr);
 }
+void* gdb_mi355_init_from_memory_format(const char* query_json_text, const uint8_t* cells, uint64_t nbytes, uint64_t buffer_capacity, int produce_header_only, int is_bcf,
+                                        int use_missing, int keep_idx) {
+  return guarded([&]() -> void* {
+    return new GenomicsDBBCFGenerator(std::string(query_json_text), cells, nbytes, buffer_capacity, produce_header_only != 0, is_bcf ? "bu" : "", is_bcf && use_missing, keep_idx != 0);
+  }, (void*)nullptr);
+}
 uint64_t gdb_mi355_close(void* h) { delete (GenomicsDBBCFGenerator*)h; return 0; }
 uint64_t gdb_mi355_get_num_bytes_available(void* h) { return h ? ((GenomicsDBBCFGenerator*)h)->get_buffer_capacity() : 0; }
 int gdb_mi355_read_next_byte(void* h) {
@@ -73,6 +79,13 @@ int gdb_mi355_get_stream_stats(void* h, gdb_mi355_stream_stats* out) {
 
 void* gdbamd_engine_create(const char* query_json_text, int device) {
   return guarded([&]() -> void* { auto* e = new EngineHandle; e->eng.reset(new CombineEngine(mini_json::parse(query_json_text), device)); return e; }, (void*)nullptr);
+}
+void* gdbamd_engine_create_format(const char* query_json_text, int device, int is_bcf, int use_missing) {
+  return guarded([&]() -> void* {
+    auto* e = new EngineHandle;
+    e->eng.reset(new CombineEngine(mini_json::parse(query_json_text), device, nullptr, 0, is_bcf ? "bu" : "", is_bcf && use_missing));
+    return e;
+  }, (void*)nullptr);
 }
 void gdbamd_engine_destroy(void* e) { delete (EngineHandle*)e; }
 int gdbamd_engine_num_fields(void* e) { return e ? ((EngineHandle*)e)->eng->plan().plan.nfields : -1; }

@@ -14,13 +14,14 @@
 
 namespace genomicsdb_amd {
 
-CombineEngine::CombineEngine(const mini_json::Value& query_json, int device, const GenomicsDBImportConfig* loader, int rank) {
+CombineEngine::CombineEngine(const mini_json::Value& query_json, int device, const GenomicsDBImportConfig* loader, int rank, const std::string& output_format,
+                             bool use_missing_values_only_not_vector_end) {
   if (loader) m_qc.update_from_loader(*loader, rank);
   m_qc.read_from_json(query_json, rank, "");
   m_qc.do_query_bookkeeping(m_qc.get_vid_mapper().get_num_callsets(), 0);
   std::string tmpl;
   if (!m_qc.get_vcf_header_filename().empty()) tmpl = mini_json::read_text_file(m_qc.get_vcf_header_filename());
-  m_hp = build_combine_plan(m_qc, tmpl);
+  m_hp = build_combine_plan(m_qc, tmpl, output_format, use_missing_values_only_not_vector_end);
   m_pipe.reset(new DevicePipeline(m_hp, device));
   if (!m_qc.get_reference_genome().empty()) m_ref.initialize(m_qc.get_reference_genome());
 }
@@ -263,17 +264,16 @@ void CombineEngine::stage_reference_for(int64_t qb, int64_t qe) {
 
 GenomicsDBBCFGenerator::GenomicsDBBCFGenerator(const std::string& loader_config_file, const std::string& query_config_file, const char* chr,
                                                const int start, const int end, int my_rank, size_t buffer_capacity, size_t, const char* output_format,
-                                               const bool produce_header_only, const bool, const bool)
+                                               const bool produce_header_only, const bool use_missing_values_only_not_vector_end, const bool keep_idx_fields_in_bcf_header)
     : m_buffer_capacity(buffer_capacity) {
-  if (output_format && strlen(output_format) > 0)
-    throw UnsupportedOnDeviceException(std::string("VCF output format \"") + output_format + "\": only text VCF (\"\") is produced by this build (SURVEY 8f-2)");
   GenomicsDBImportConfig loader;
   if (!loader_config_file.empty()) loader.read_from_file(loader_config_file, my_rank);
   // one process per GPU: the device is the launcher's LOCAL_RANK (torchrun / mpirun wrappers export it), else GDBAMD_DEVICE, else 0
   int device = 0;
   if (const char* e = getenv("GDBAMD_DEVICE")) device = atoi(e);
   else if (const char* e2 = getenv("LOCAL_RANK")) device = atoi(e2);
-  m_engine.reset(new CombineEngine(mini_json::parse_file(query_config_file), device, loader_config_file.empty() ? nullptr : &loader, my_rank));
+  m_engine.reset(new CombineEngine(mini_json::parse_file(query_config_file), device, loader_config_file.empty() ? nullptr : &loader, my_rank,
+                                   output_format ? output_format : "", use_missing_values_only_not_vector_end));
   VariantQueryConfig& qc = m_engine->query_config();
   if (chr && strlen(chr) > 0u) {
     ContigInfo ci;
@@ -285,26 +285,28 @@ GenomicsDBBCFGenerator::GenomicsDBBCFGenerator(const std::string& loader_config_
   // in column windows of the staging budget
   m_engine->open_array(qc.get_workspace(my_rank) + "/" + qc.get_array_name(my_rank));
   m_engine->cover(INT64_MIN);   // first window staged at construction, like the reference opens its array here
-  common_init(produce_header_only);
+  common_init(produce_header_only, keep_idx_fields_in_bcf_header);
 }
 
-GenomicsDBBCFGenerator::GenomicsDBBCFGenerator(const std::string& query_json_text, const uint8_t* cells, uint64_t nbytes, size_t buffer_capacity, bool produce_header_only)
+GenomicsDBBCFGenerator::GenomicsDBBCFGenerator(const std::string& query_json_text, const uint8_t* cells, uint64_t nbytes, size_t buffer_capacity, bool produce_header_only,
+                                               const char* output_format, bool use_missing_values_only_not_vector_end, bool keep_idx_fields_in_bcf_header)
     : m_buffer_capacity(buffer_capacity) {
-  m_engine.reset(new CombineEngine(mini_json::parse(query_json_text), 0));
+  m_engine.reset(new CombineEngine(mini_json::parse(query_json_text), 0, nullptr, 0, output_format ? output_format : "", use_missing_values_only_not_vector_end));
   if (nbytes > m_engine->staging_budget_bytes()) {   // several windows: the stream comes back for the bytes, so it keeps them
     m_owned_cells.assign(cells, cells + nbytes);
     cells = m_owned_cells.data();
   }
   m_engine->open_memory_cells(cells, nbytes);
   m_engine->cover(INT64_MIN);                         // the first window (for most arrays: all of it) is staged here; malformed cells fail here
-  common_init(produce_header_only);
+  common_init(produce_header_only, keep_idx_fields_in_bcf_header);
 }
 
 #define GEN_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) throw GenomicsDBDeviceException(std::string(#expr) + " failed: " + hipGetErrorString(_e)); } while (0)
 
-void GenomicsDBBCFGenerator::common_init(bool produce_header_only) {
+void GenomicsDBBCFGenerator::common_init(bool produce_header_only, bool keep_idx_fields_in_bcf_header) {
   m_produce_header_only = produce_header_only;
-  const std::string& h = m_engine->plan().header_text;  // first bytes = header (vcf_adapter.cc:475-488)
+  // first bytes = header (vcf_adapter.cc:475-488): the VCF text, or "BCF\2\2" + length + text (IDX keys kept or dropped) + NUL
+  const std::string h = m_engine->plan().plan.bcf_mode ? m_engine->plan().bcf_header_bytes(keep_idx_fields_in_bcf_header) : m_engine->plan().header_text;
   m_header.assign(h.begin(), h.end());
   m_next_read_idx = 0;
   if (produce_header_only) m_done = true;

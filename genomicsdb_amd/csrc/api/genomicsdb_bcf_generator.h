@@ -19,7 +19,9 @@ class GenomicsDBJNIException : public std::runtime_error {
 // what the engine needs to know about one query: configuration, plan, pipeline
 class CombineEngine {
  public:
-  explicit CombineEngine(const mini_json::Value& query_json, int device, const GenomicsDBImportConfig* loader = nullptr, int rank = 0);
+  // output_format "": VCF text, "bu": uncompressed BCF2 records (what GATK4's BCF2Codec reads); the two flags are the JNI's
+  explicit CombineEngine(const mini_json::Value& query_json, int device, const GenomicsDBImportConfig* loader = nullptr, int rank = 0,
+                         const std::string& output_format = "", bool use_missing_values_only_not_vector_end = false);
   VariantQueryConfig& query_config() { return m_qc; }
   const HostPlan& plan() const { return m_hp; }
   DevicePipeline& pipeline() { return *m_pipe; }
@@ -85,7 +87,8 @@ class GenomicsDBBCFGenerator {
                          const char* output_format = "bu", const bool produce_header_only = false,
                          const bool use_missing_values_only_not_vector_end = false, const bool keep_idx_fields_in_bcf_header = true);
   // in-memory flavour: query JSON text + begin-cells (reference binary-cell layout)
-  GenomicsDBBCFGenerator(const std::string& query_json_text, const uint8_t* cells, uint64_t nbytes, size_t buffer_capacity, bool produce_header_only);
+  GenomicsDBBCFGenerator(const std::string& query_json_text, const uint8_t* cells, uint64_t nbytes, size_t buffer_capacity, bool produce_header_only,
+                         const char* output_format = "", bool use_missing_values_only_not_vector_end = false, bool keep_idx_fields_in_bcf_header = true);
   GenomicsDBBCFGenerator(const GenomicsDBBCFGenerator&) = delete;
   GenomicsDBBCFGenerator& operator=(const GenomicsDBBCFGenerator&) = delete;
   ~GenomicsDBBCFGenerator();
@@ -102,7 +105,7 @@ class GenomicsDBBCFGenerator {
   struct DrainStats { uint64_t pages = 0, chunks = 0, bytes = 0; double seconds_waiting_for_copies = 0, seconds_producing = 0; };
   const DrainStats& drain_stats() const { return m_drain; }
  private:
-  void common_init(bool produce_header_only);
+  void common_init(bool produce_header_only, bool keep_idx_fields_in_bcf_header = true);
   // Stream machinery: the device assembles pages of up to device_page_bytes() (independent of the caller's buffer_capacity)
   // alternately into two HBM arenas; a page leaves in chunks over a copy stream into a ring of pinned host buffers while the
   // next page is being assembled; read() is served from the ring.

@@ -55,6 +55,8 @@ struct CellMeta {       // SoA, one entry per cell of the staged fragment
   int32_t* k_hi;
 };
 
+struct AlleleRef { const char* p; int len; int suffix_from; uint32_t hash; };  // allele text = p[0..len) + mergedREF[suffix_from..)
+
 struct RecordTable {    // one entry per output record (VCF line)
   int64_t npos;         // P
   const int64_t* start; // column interval of the record
@@ -91,20 +93,27 @@ struct NameTables {      // small text tables in device memory
   const int32_t* filter_name_off;  // per vid field idx (FILTER ids); len 0 = not in header
   const int32_t* filter_name_len;
   int32_t n_filter_names;
+  const int32_t* filter_bcf_id;    // per vid field idx: index in the BCF header dictionary (-1: not in the header)
 };
 
 // ---- sinks -----------------------------------------------------------------------------------------
+// (pos() / patch_u32(): the BCF emitters write a count first and fill it in once the values behind it are known)
 struct CountSink {
   uint64_t n;
   GDB_HD CountSink() : n(0) {}
   GDB_HD void put(char) { ++n; }
   GDB_HD void write(const char*, int len) { n += (uint64_t)len; }
+  GDB_HD uint32_t pos() const { return (uint32_t)n; }
+  GDB_HD void patch_u32(uint32_t, uint32_t) {}
 };
 struct ByteSink {
   char* p;
-  GDB_HD explicit ByteSink(char* q) : p(q) {}
+  char* base;
+  GDB_HD explicit ByteSink(char* q) : p(q), base(q) {}
   GDB_HD void put(char c) { *p++ = c; }
   GDB_HD void write(const char* s, int len) { for (int i = 0; i < len; ++i) *p++ = s[i]; }
+  GDB_HD uint32_t pos() const { return (uint32_t)(p - base); }
+  GDB_HD void patch_u32(uint32_t at, uint32_t v) { for (int i = 0; i < 4; ++i) base[at + i] = (char)((v >> (8 * i)) & 0xFFu); }
 };
 
 #if defined(__HIPCC__)
@@ -121,6 +130,8 @@ struct LdsCapSink {  // counts every byte, stores the first `cap` of them in LDS
     if (n + 8u <= cap) { const uint32_t a = (uint32_t)(uintptr_t)p + n; asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(w) : "memory"); n += (uint32_t)len; }
     else for (int i = 0; i < len; ++i) { put((char)(w & 0xFFu)); w >>= 8; }
   }
+  __device__ __forceinline__ uint32_t pos() const { return n; }
+  __device__ __forceinline__ void patch_u32(uint32_t at, uint32_t v) { for (int i = 0; i < 4; ++i) if (at + i < cap) p[at + i] = (char)((v >> (8 * i)) & 0xFFu); }
 };
 // The same with a second tier for the few long texts (records with very many ALT alleles): what does not fit the LDS strip goes
 // to one fixed-size chunk of a global pool, taken with an atomic when the first byte overflows.  n counts every byte; the text
@@ -146,6 +157,8 @@ struct LdsSpillSink {
     else for (int i = 0; i < len; ++i) { put((char)(w & 0xFFu)); w >>= 8; }
   }
   __device__ __forceinline__ bool complete() const { return n <= cap || (chunk >= 0 && n - cap <= kSpillChunk); }
+  __device__ __forceinline__ uint32_t pos() const { return n; }
+  __device__ __forceinline__ void patch_u32(uint32_t at, uint32_t v) { for (int i = 0; i < 4; ++i) if (at + i < cap) p[at + i] = (char)((v >> (8 * i)) & 0xFFu); }   // (only ever the record header)
 };
 #endif
 
@@ -384,7 +397,6 @@ GDB_HD void classify_cell(const FragmentView& fr, const CombinePlan& pl, const C
 }
 
 // ---- site (per record) ---------------------------------------------------------------------------------
-struct AlleleRef { const char* p; int len; int suffix_from; uint32_t hash; };  // text = p[0..len) + mergedREF[suffix_from..)
 // hash of the text an AlleleRef stands for (FNV-1a): the merge compares hashes first, strings only on a hash match - a site
 // with thousands of variant calls would otherwise re-read every merged allele string for every call
 GDB_HD uint32_t allele_hash(const char* p, int len, int suffix_from, const char* mref, int mref_len) {
@@ -523,6 +535,23 @@ struct ScalarPre {
   int32_t enabled;
 };
 
+// Records with very many variant calls (the hot sites of a dense region, the first record of a partition): everything in the
+// record logic that walks the calls - allele merge + LUTs, scalar reducers, FILTER - is done beforehand by one WORKGROUP per
+// record (k_site_huge: lane = call) and left here; site_emit then only formats.
+struct HugeScalar { int64_t nvalid, nbelow, nneg0, npos0; uint32_t sum_bits, median_bits; int32_t median_ok, pad; };   // median_ok: 0 none, 1 value, 2 zeros of both signs tie
+struct HugeSiteOut {
+  AlleleRef merged[GDB_MAX_MERGED_ALLELES];
+  const char* mref;            // longest REF among the calls starting at the record (null: take the reference base)
+  int32_t mref_len, nmerged;
+  int32_t filter_first_id, filter_multi, any_id, fallback;   // fallback != 0: a hash collision between two alleles - use the serial walk
+  HugeScalar scalar[GDB_MAX_INFO_FIELDS + 2];                // by ScalarPre slot
+};
+struct HugeSites {
+  const int32_t* index;        // [P] row of `out` or -1
+  const HugeSiteOut* out;
+  int32_t enabled;
+};
+
 struct SiteCtx {
   FragmentView fr;
   CombinePlan pl;
@@ -538,6 +567,7 @@ struct SiteCtx {
   BigMedians big;
   TieScratch tie;
   ScalarPre pre;
+  HugeSites huge;
 };
 
 // value of a scalar INFO-like field over the heavy list: median / sum / mean (variant_field_handler.cc:529-607).
@@ -581,6 +611,14 @@ template <class T> GDB_HD bool reduce_scalar(const SiteCtx& cx, int64_t k, int f
   const uint32_t* pre = (cx.pre.enabled && cx.pre.slot[f] >= 0) ? cx.pre.val + (int64_t)cx.pre.slot[f] * cx.pre.stride : nullptr;
   int64_t nvalid = 0, nbelow = 0, nneg0 = 0, npos0 = 0;
   T sum = 0;
+  const HugeSiteOut* hs = (cx.huge.enabled && pre && cx.huge.index[k] >= 0 && !cx.huge.out[cx.huge.index[k]].fallback) ? &cx.huge.out[cx.huge.index[k]] : nullptr;
+  if (hs) {   // a record with very many calls: counts, sum and median were taken by its workgroup (k_site_huge)
+    const HugeScalar& hv = hs->scalar[cx.pre.slot[f]];
+    nvalid = hv.nvalid; nbelow = hv.nbelow; nneg0 = hv.nneg0; npos0 = hv.npos0;
+    union { uint32_t u; T v; } x;
+    x.u = hv.sum_bits; sum = x.v;
+    if (nvalid && op == GDB_OP_MEDIAN && hv.median_ok == 1) { x.u = hv.median_bits; result = x.v; return true; }
+  } else
   for (int64_t t = b; t < e; ++t) {
     T v;
     if (!scalar_at<T>(cx, pre, t, s_k, f, keep_spanning, is_float, v)) continue;
@@ -728,6 +766,50 @@ template <class T, class Sink> GDB_HD bool info_vector_combine(const SiteCtx& cx
   return true;
 }
 
+// ---- BCF2 typed values (BCFv2.2 specification 6.3; htslib vcf.c: bcf_enc_size, bcf_enc_int1, bcf_enc_vint, bcf_enc_vchar) ---------
+#define GDB_BT_NULL 0
+#define GDB_BT_INT8 1
+#define GDB_BT_INT16 2
+#define GDB_BT_INT32 3
+#define GDB_BT_FLOAT 5
+#define GDB_BT_CHAR 7
+template <class Sink> GDB_HD void bcf_put_u16(Sink& s, uint32_t v) { s.put((char)(v & 0xFFu)); s.put((char)((v >> 8) & 0xFFu)); }
+template <class Sink> GDB_HD void bcf_put_u32(Sink& s, uint32_t v) { for (int i = 0; i < 4; ++i) s.put((char)((v >> (8 * i)) & 0xFFu)); }
+// smallest integer type that holds every value of [mn, mx]; the 8 lowest codes of every type are reserved (missing, vector end, ...)
+GDB_HD int bcf_int_type(int32_t mn, int32_t mx) {
+  if (mx <= 127 && mn >= -120) return GDB_BT_INT8;
+  if (mx <= 32767 && mn >= -32760) return GDB_BT_INT16;
+  return GDB_BT_INT32;
+}
+GDB_HD int bcf_type_width(int t) { return t == GDB_BT_INT8 || t == GDB_BT_CHAR ? 1 : t == GDB_BT_INT16 ? 2 : t == GDB_BT_NULL ? 0 : 4; }
+// one int32 (with the int32 missing / vector-end patterns) as an element of type t
+template <class Sink> GDB_HD void bcf_put_int(Sink& s, int32_t v, int t) {
+  if (t == GDB_BT_INT8) s.put(v == GDB_BCF_INT32_MISSING ? (char)0x80 : v == GDB_BCF_INT32_VECTOR_END ? (char)0x81 : (char)v);
+  else if (t == GDB_BT_INT16) bcf_put_u16(s, v == GDB_BCF_INT32_MISSING ? 0x8000u : v == GDB_BCF_INT32_VECTOR_END ? 0x8001u : (uint32_t)v);
+  else bcf_put_u32(s, (uint32_t)v);
+}
+template <class Sink> GDB_HD void bcf_enc_int1(Sink& s, int32_t x) {
+  const int t = (x == GDB_BCF_INT32_MISSING || x == GDB_BCF_INT32_VECTOR_END) ? GDB_BT_INT8 : bcf_int_type(x, x);
+  s.put((char)((1 << 4) | t));
+  bcf_put_int(s, x, t);
+}
+template <class Sink> GDB_HD void bcf_enc_size(Sink& s, int size, int type) {
+  if (size >= 15) { s.put((char)((15 << 4) | type)); bcf_enc_int1(s, size); }
+  else s.put((char)((size << 4) | type));
+}
+GDB_HD int bcf_enc_size_bytes(int size) { return size < 15 ? 1 : size <= 127 ? 3 : size <= 32767 ? 4 : 6; }
+GDB_HD int bcf_enc_int1_bytes(int32_t x) { return 1 + bcf_type_width((x == GDB_BCF_INT32_MISSING || x == GDB_BCF_INT32_VECTOR_END) ? GDB_BT_INT8 : bcf_int_type(x, x)); }
+// bcf_enc_vint: n values, one common type chosen over the values that are neither missing nor vector end
+template <class Sink> GDB_HD void bcf_enc_vint(Sink& s, const int32_t* a, int n) {
+  if (n <= 0) { s.put((char)0); return; }
+  if (n == 1) { bcf_enc_int1(s, a[0]); return; }
+  int32_t mx = INT32_MIN + 1, mn = INT32_MAX;
+  for (int i = 0; i < n; ++i) { if (a[i] == GDB_BCF_INT32_MISSING || a[i] == GDB_BCF_INT32_VECTOR_END) continue; if (mx < a[i]) mx = a[i]; if (mn > a[i]) mn = a[i]; }
+  const int t = bcf_int_type(mn, mx);
+  bcf_enc_size(s, n, t);
+  for (int i = 0; i < n; ++i) bcf_put_int(s, a[i], t);
+}
+
 GDB_HD int find_contig(const QueryWindow& qw, int64_t pos) {  // VidMapper::get_contig_location
   int lo = 0, hi = qw.ncontigs;  // last contig with offset <= pos
   while (lo < hi) { int mid = (lo + hi) >> 1; if (qw.contigs[mid].offset <= pos) lo = mid + 1; else hi = mid; }
@@ -735,6 +817,84 @@ GDB_HD int find_contig(const QueryWindow& qw, int64_t pos) {  // VidMapper::get_
   if (idx < 0) return -1;
   if (pos >= qw.contigs[idx].offset && pos < qw.contigs[idx].offset + qw.contigs[idx].length) return idx;
   return -1;
+}
+
+// the same combiners as typed BCF INFO values: key, then the vector (element_wise_sum: the summed elements; concatenate: every
+// element of every valid call in call order - vector-end elements included, a text writer stops at the first one)
+template <class T, class Sink> GDB_HD bool info_vector_combine_bcf(const SiteCtx& cx, int64_t k, int f, int op, int num_merged, bool non_ref_exists, bool remapping_needed,
+                                                                 Sink& sink, uint32_t* err) {
+  const CombinePlan& pl = cx.pl;
+  const GdbFieldDesc& fd = pl.field[f];
+  const int64_t b = cx.hl.base[k], e = cx.hl.base[k + 1];
+  const int64_t s_k = cx.rec.start[k];
+  const bool allele_dep = remapping_needed && (fd.length == GDB_VL_A || fd.length == GDB_VL_R);
+  const bool alt_only = fd.length == GDB_VL_A;
+  const bool is_float = fd.elem == GDB_ET_FLOAT;
+  T r[GDB_MAX_INFO_VECTOR];
+  int num_valid = 0;
+  // pass 0 (concatenate only): element count and integer range; pass 1: values
+  int n_total = 0;
+  int32_t mn = INT32_MAX, mx = INT32_MIN + 1;
+  int type = is_float ? GDB_BT_FLOAT : GDB_BT_INT8;
+  for (int pass = (op == GDB_OP_CONCATENATE ? 0 : 1); pass < 2; ++pass) {
+    if (pass == 1 && op == GDB_OP_CONCATENATE) {
+      if (n_total == 0) return false;
+      bcf_enc_int1(sink, pl.bcf_id[f]);
+      if (!is_float) type = bcf_int_type(mn, mx);
+      if (!is_float && n_total == 1) {}   // (bcf_enc_vint encodes a single value as a typed scalar: same bytes as a vector of one)
+      bcf_enc_size(sink, n_total, type);
+    }
+    for (int64_t t = b; t < e; ++t) {
+      if (inc_is_spanning(cx, t, s_k)) continue;
+      const int64_t c = cx.hl.cell[t];
+      if (!field_valid(cx.cm, c, f)) continue;
+      int n_in;
+      const T* p = cell_field<T>(cx.fr, pl, f, c, n_in);
+      int n = n_in;
+      const int8_t* lut = cx.hl.i2m + cx.hl.i2m_off[t];
+      const int nal = (int)GDB_CF_NALT(cx.cm.cflags[c]) + 1;
+      int nr_in = -1;
+      if (allele_dep) {
+        n = alt_only ? num_merged - 1 : num_merged;
+        if (non_ref_exists) for (int a = 0; a < nal; ++a) if (lut[a] == num_merged - 1) nr_in = a;
+      }
+      for (int i = 0; i < n; ++i) {
+        T v;
+        if (allele_dep) {
+          const int aj = alt_only ? i + 1 : i;
+          int in = -1;
+          for (int a = 0; a < nal; ++a) if (lut[a] == aj) { in = a; break; }
+          if (in < 0) in = nr_in;
+          const int idx = alt_only ? in - 1 : in;
+          if (in >= 0 && idx >= 0 && idx < n_in) v = p[idx]; else elem_set_missing(v);
+        } else v = p[i];
+        if (op == GDB_OP_CONCATENATE) {
+          if (pass == 0) {
+            ++n_total;
+            if (!is_float && !elem_is_missing(v) && !elem_is_vector_end(v)) { const int32_t iv = (int32_t)v; if (iv < mn) mn = iv; if (iv > mx) mx = iv; }
+          } else if (is_float) { union { T t; uint32_t u; } x; x.u = 0; x.t = v; bcf_put_u32(sink, x.u); }
+          else bcf_put_int(sink, (int32_t)v, type);
+          continue;
+        }
+        if (elem_is_missing(v) || elem_is_vector_end(v)) continue;
+        if (i >= GDB_MAX_INFO_VECTOR) { *err |= GDB_ERR_INFO_VECTOR_TOO_LONG; break; }
+        if (i < num_valid && !elem_is_missing(r[i])) r[i] += v;
+        else { r[i] = v; if (i >= num_valid) { for (int j = num_valid; j < i; ++j) elem_set_missing(r[j]); num_valid = i + 1; } }
+      }
+    }
+  }
+  if (op == GDB_OP_CONCATENATE) return true;
+  if (num_valid == 0) return false;
+  bcf_enc_int1(sink, pl.bcf_id[f]);
+  if (is_float) {
+    bcf_enc_size(sink, num_valid, GDB_BT_FLOAT);
+    for (int i = 0; i < num_valid; ++i) { union { T t; uint32_t u; } x; x.u = 0; x.t = r[i]; bcf_put_u32(sink, x.u); }
+  } else {
+    int32_t tmp[GDB_MAX_INFO_VECTOR];
+    for (int i = 0; i < num_valid; ++i) tmp[i] = (int32_t)r[i];
+    bcf_enc_vint(sink, tmp, num_valid);
+  }
+  return true;
 }
 
 // Per-record site logic.  PASS 0 (Sink = CountSink, write_luts = false) sizes the prefix; PASS 1 writes the prefix
@@ -763,47 +923,20 @@ GDB_HD int merged_find_or_add(AlleleRef* merged, int& nmerged, MergeIndex& ix, c
   return nmerged++;
 }
 
-template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& sink, bool write_luts, uint32_t* err) {
+// REF of the lowest-row cell starting at s_k (cells are (col,row) sorted; a plain reference block counts), or null
+GDB_HD const char* site_first_ref(const SiteCtx& cx, int64_t s_k, int& len) {
+  int64_t lo = 0, hi = cx.fr.ncells;
+  while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (cx.fr.begin[mid] < s_k) lo = mid + 1; else hi = mid; }
+  len = 0;
+  if (lo < cx.fr.ncells && cx.fr.begin[lo] == s_k && field_valid(cx.cm, lo, cx.pl.f_REF)) return cell_field<char>(cx.fr, cx.pl, cx.pl.f_REF, lo, len);
+  return nullptr;
+}
+// What one variant call of a record feeds into the allele merge, in the order the reference's merge_alt_alleles sees it
+// (spanning deletions folded in as handle_deletions does): find_or_add(candidate) returns the candidate's merged index; with
+// write_luts the call's input -> merged LUT, its flags and the min-PL genotype of a spanning deletion are stored.
+GDB_HD const char* gdb_star_allele() { return "*"; }
+template <class F> GDB_HD void site_merge_call(const SiteCtx& cx, int64_t t, int64_t s_k, const char* mref, int mref_len, bool write_luts, F& find_or_add, uint32_t* err) {
   const CombinePlan& pl = cx.pl;
-  const int64_t s_k = cx.rec.start[k], e_k = cx.rec.end[k];
-  const int64_t hb = cx.hl.base[k], he = cx.hl.base[k + 1];
-  // -- merged REF: longest REF among calls that START here (merge_reference_allele) -------------------
-  const char* mref = nullptr;
-  int mref_len = 0;
-  char ref_base = 'N';
-  {
-    // lowest-row cell starting at s_k (cells are (col,row) sorted)
-    int64_t lo = 0, hi = cx.fr.ncells;
-    while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (cx.fr.begin[mid] < s_k) lo = mid + 1; else hi = mid; }
-    if (lo < cx.fr.ncells && cx.fr.begin[lo] == s_k && field_valid(cx.cm, lo, pl.f_REF)) {
-      int n;
-      mref = cell_field<char>(cx.fr, pl, pl.f_REF, lo, n);
-      mref_len = n;
-    }
-    for (int64_t t = hb; t < he; ++t) {
-      int64_t c = cx.hl.cell[t];
-      if (cx.fr.begin[c] != s_k || !field_valid(cx.cm, c, pl.f_REF)) continue;
-      int n;
-      const char* r = cell_field<char>(cx.fr, pl, pl.f_REF, c, n);
-      if (n > mref_len) { mref = r; mref_len = n; }
-    }
-    if (mref_len == 0 || (mref_len == 1 && mref[0] == 'N')) {
-      // nobody starts here: base from the reference genome (broad_combined_gvcf.cc:825-830)
-      int64_t off = s_k - cx.qw.ref_begin;
-      char b = (cx.qw.ref_bases && off >= 0 && off < cx.qw.ref_len) ? cx.qw.ref_bases[off] : 'N';
-      ref_base = (b == 'A' || b == 'C' || b == 'G' || b == 'T') ? b : 'N';
-      mref = &ref_base;
-      mref_len = 1;
-    }
-  }
-  // -- merged ALT list + LUTs (merge_alt_alleles), spanning deletions folded in (handle_deletions) ------
-  AlleleRef merged[GDB_MAX_MERGED_ALLELES];
-  MergeIndex mix;
-  mix.built = false;
-  int nmerged = 1;  // index 0 = REF
-  const char star = '*';
-  bool non_ref_exists = cx.pc.nr_cnt[k] > 0;
-  for (int64_t t = hb; t < he; ++t) {
     int64_t c = cx.hl.cell[t];
     uint32_t cf = cx.cm.cflags[c];
     int ref_len = 0, alt_len = 0;
@@ -842,9 +975,9 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
         }
       }
       if (lowest < 0) { *err |= GDB_ERR_INTERNAL; lowest = 1; }
-      AlleleRef cand{&star, 1, -1, 0u};
+      AlleleRef cand{gdb_star_allele(), 1, -1, 0u};
       cand.hash = allele_hash(cand.p, cand.len, cand.suffix_from, mref, mref_len);
-      const int found = merged_find_or_add(merged, nmerged, mix, cand, mref, mref_len, err);
+      const int found = find_or_add(cand);
       if (lut) lut[lowest] = (int8_t)found;
       if (lut && pl.min_PL_GT_for_spanning_deletions && pl.produce_GT_field && pl_exists && pl.f_GT >= 0 && field_valid(cx.cm, c, pl.f_GT)) {
         // update_GT_to_correspond_to_min_PL_value on the REDUCED PL (alleles REF,*,[<NON_REF>])
@@ -893,14 +1026,59 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
         if (tl > 0 && tok[0] == '&') continue;  // <NON_REF> goes last
         AlleleRef cand{tok, tl, (suffix_needed && !allele_is_symbolic(tok, tl)) ? ref_len : -1, 0u};
         cand.hash = allele_hash(cand.p, cand.len, cand.suffix_from, mref, mref_len);
-        const int found = merged_find_or_add(merged, nmerged, mix, cand, mref, mref_len, err);
+        const int found = find_or_add(cand);
         if (lut && i + 1 <= nalt) lut[i + 1] = (int8_t)found;
       }
     }
     if (write_luts) cx.hl.iflags[t] = iflag;
+}
+
+template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& sink, bool write_luts, uint32_t* err) {
+  const CombinePlan& pl = cx.pl;
+  const int64_t s_k = cx.rec.start[k], e_k = cx.rec.end[k];
+  const int64_t hb = cx.hl.base[k], he = cx.hl.base[k + 1];
+  // -- merged REF: longest REF among calls that START here (merge_reference_allele) -------------------
+  const char* mref = nullptr;
+  int mref_len = 0;
+  char ref_base = 'N';
+  const HugeSiteOut* hsite = (cx.huge.enabled && cx.huge.index[k] >= 0 && !cx.huge.out[cx.huge.index[k]].fallback) ? &cx.huge.out[cx.huge.index[k]] : nullptr;
+  {
+    if (hsite) { mref = hsite->mref; mref_len = hsite->mref_len; }
+    else mref = site_first_ref(cx, s_k, mref_len);
+    if (!hsite) for (int64_t t = hb; t < he; ++t) {
+      int64_t c = cx.hl.cell[t];
+      if (cx.fr.begin[c] != s_k || !field_valid(cx.cm, c, pl.f_REF)) continue;
+      int n;
+      const char* r = cell_field<char>(cx.fr, pl, pl.f_REF, c, n);
+      if (n > mref_len) { mref = r; mref_len = n; }
+    }
+    if (mref_len == 0 || (mref_len == 1 && mref[0] == 'N')) {
+      // nobody starts here: base from the reference genome (broad_combined_gvcf.cc:825-830)
+      int64_t off = s_k - cx.qw.ref_begin;
+      char b = (cx.qw.ref_bases && off >= 0 && off < cx.qw.ref_len) ? cx.qw.ref_bases[off] : 'N';
+      ref_base = (b == 'A' || b == 'C' || b == 'G' || b == 'T') ? b : 'N';
+      mref = &ref_base;
+      mref_len = 1;
+    }
+  }
+  // -- merged ALT list + LUTs (merge_alt_alleles), spanning deletions folded in (handle_deletions) ------
+  AlleleRef merged[GDB_MAX_MERGED_ALLELES];
+  MergeIndex mix;
+  mix.built = false;
+  int nmerged = 1;  // index 0 = REF
+  bool non_ref_exists = cx.pc.nr_cnt[k] > 0;
+  if (hsite) {
+    nmerged = hsite->nmerged;
+    for (int j = 1; j < nmerged; ++j) merged[j] = hsite->merged[j];
+  } else {
+    struct SerialMerge {
+      AlleleRef* merged; int* nmerged; MergeIndex* mix; const char* mref; int mref_len; uint32_t* err;
+      GDB_HD int operator()(const AlleleRef& cand) { return merged_find_or_add(merged, *nmerged, *mix, cand, mref, mref_len, err); }
+    } fa{merged, &nmerged, &mix, mref, mref_len, err};
+    for (int64_t t = hb; t < he; ++t) site_merge_call(cx, t, s_k, mref, mref_len, write_luts, fa, err);
   }
   const int num_merged = nmerged + (non_ref_exists ? 1 : 0);
-  if (write_luts && non_ref_exists) {
+  if (write_luts && non_ref_exists && !hsite) {
     for (int64_t t = hb; t < he; ++t) {
       int64_t c = cx.hl.cell[t];
       uint32_t cf = cx.cm.cflags[c];
@@ -932,6 +1110,117 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
   int ci = find_contig(cx.qw, s_k);
   if (ci < 0) { *err |= GDB_ERR_INTERNAL; ci = 0; }
   const GdbContig& ctg = cx.qw.contigs[ci];
+  if (pl.bcf_mode) {
+    // BCF2 shared block (BCFv2.2 6.3.1; the order of the reference's bcf_update_* calls, broad_combined_gvcf.cc:795-880):
+    // CHROM POS rlen QUAL n_allele|n_info n_fmt|n_sample ID alleles FILTER INFO...; l_shared / l_indiv and the FORMAT block
+    // are written by the page assembly.  rlen = END - POS for interval records, else the length of REF.
+    int n_fmt = 0;
+    for (uint32_t m = fmt_mask; m; m &= m - 1) ++n_fmt;
+    bcf_put_u32(sink, (uint32_t)ctg.rid);
+    bcf_put_u32(sink, (uint32_t)(s_k - ctg.offset));
+    bcf_put_u32(sink, (uint32_t)(e_k > s_k ? e_k - s_k + 1 : (int64_t)mref_len));
+    float qv;
+    uint32_t qbits = GDB_BCF_FLOAT_MISSING_BITS;
+    if (pl.qual_combine_op != GDB_OP_UNKNOWN && pl.f_QUAL >= 0 && reduce_scalar<float>(cx, k, pl.f_QUAL, pl.qual_combine_op, true, qv, err)) qbits = gdb_f2u(qv);
+    bcf_put_u32(sink, qbits);
+    const uint32_t at_counts = sink.pos();
+    bcf_put_u32(sink, (uint32_t)num_merged << 16);          // n_info patched below
+    bcf_put_u32(sink, ((uint32_t)n_fmt << 24) | ((uint32_t)pl.bcf_n_sample & 0xFFFFFFu));
+    // ID (same sorted token union as the text flavour)
+    {
+      const char* tp[GDB_MAX_ID_TOKENS]; int tn[GDB_MAX_ID_TOKENS]; int nt = 0;
+      if (pl.f_ID >= 0 && !(hsite && !hsite->any_id))
+        for (int64_t t = hb; t < he; ++t) {
+          const int64_t c = cx.hl.cell[t];
+          if (!field_valid(cx.cm, c, pl.f_ID)) continue;
+          int n;
+          const char* p = cell_field<char>(cx.fr, pl, pl.f_ID, c, n);
+          int last = 0;
+          for (int i = 0; i <= n; ++i) {
+            if (i < n && p[i] != ';') continue;
+            const int len = i - last;
+            if (i == n && len == 0) break;
+            int pos = 0, cmp = 1;
+            for (; pos < nt; ++pos) {
+              const int m = len < tn[pos] ? len : tn[pos];
+              cmp = 0;
+              for (int j = 0; j < m && cmp == 0; ++j) cmp = (int)(unsigned char)p[last + j] - (int)(unsigned char)tp[pos][j];
+              if (cmp == 0) cmp = len - tn[pos];
+              if (cmp <= 0) break;
+            }
+            if (pos == nt || cmp != 0) {
+              if (nt >= GDB_MAX_ID_TOKENS) { *err |= GDB_ERR_TOO_MANY_ID_TOKENS; }
+              else { for (int j = nt; j > pos; --j) { tp[j] = tp[j - 1]; tn[j] = tn[j - 1]; } tp[pos] = p + last; tn[pos] = len; ++nt; }
+            }
+            last = i + 1;
+          }
+        }
+      int total = nt ? nt - 1 : 0;
+      for (int i = 0; i < nt; ++i) total += tn[i];
+      bcf_enc_size(sink, total, GDB_BT_CHAR);
+      for (int i = 0; i < nt; ++i) { if (i) sink.put(';'); sink.write(tp[i], tn[i]); }
+    }
+    // alleles
+    bcf_enc_size(sink, mref_len, GDB_BT_CHAR);
+    sink.write(mref, mref_len);
+    for (int j = 1; j < nmerged; ++j) {
+      const int sl = merged[j].suffix_from >= 0 ? mref_len - merged[j].suffix_from : 0;
+      bcf_enc_size(sink, merged[j].len + sl, GDB_BT_CHAR);
+      sink.write(merged[j].p, merged[j].len);
+      if (sl) sink.write(mref + merged[j].suffix_from, sl);
+    }
+    if (non_ref_exists) { const char nr[] = "<NON_REF>"; bcf_enc_size(sink, 9, GDB_BT_CHAR); sink.write(nr, 9); }
+    // FILTER
+    {
+      int first_id = -1;
+      bool multi = false;
+      if (hsite) { first_id = hsite->filter_first_id; multi = hsite->filter_multi != 0; }
+      else if (pl.produce_FILTER_field && pl.f_FILTER >= 0)
+        for (int64_t t = hb; t < he; ++t) {
+          int64_t c = cx.hl.cell[t];
+          if (!field_valid(cx.cm, c, pl.f_FILTER)) continue;
+          int n;
+          const int32_t* p = cell_field<int32_t>(cx.fr, pl, pl.f_FILTER, c, n);
+          for (int i = 0; i < n; ++i) { if (first_id < 0) first_id = p[i]; else if (p[i] != first_id) multi = true; }
+        }
+      if (multi) *err |= GDB_ERR_INTERNAL;
+      const int32_t hid = (first_id >= 0 && first_id < cx.names.n_filter_names) ? cx.names.filter_bcf_id[first_id] : -1;
+      if (hid >= 0) bcf_enc_int1(sink, hid); else sink.put((char)0);
+    }
+    // INFO: END, reducers in query order, DP
+    uint32_t n_info = 0;
+    if (e_k > s_k) { bcf_enc_int1(sink, pl.bcf_end_id); bcf_enc_int1(sink, (int32_t)(e_k - ctg.offset + 1)); ++n_info; }
+    for (int i = 0; i < pl.n_info; ++i) {
+      const int f = pl.info_field[i];
+      const GdbFieldDesc& fd = pl.field[f];
+      if (fd.combine_op == GDB_OP_ELEMENT_WISE_SUM || fd.combine_op == GDB_OP_CONCATENATE) {
+        bool found;
+        if (fd.elem == GDB_ET_FLOAT) found = info_vector_combine_bcf<float>(cx, k, f, fd.combine_op, num_merged, non_ref_exists, !ref_block_only, sink, err);
+        else found = info_vector_combine_bcf<int32_t>(cx, k, f, fd.combine_op, num_merged, non_ref_exists, !ref_block_only, sink, err);
+        if (found) ++n_info;
+        continue;
+      }
+      if (fd.elem == GDB_ET_FLOAT) {
+        float v;
+        if (!reduce_scalar<float>(cx, k, f, fd.combine_op, false, v, err)) continue;
+        bcf_enc_int1(sink, pl.bcf_id[f]);
+        sink.put((char)((1 << 4) | GDB_BT_FLOAT));
+        bcf_put_u32(sink, gdb_f2u(v));
+      } else {
+        int32_t v;
+        if (!reduce_scalar<int32_t>(cx, k, f, fd.combine_op, false, v, err)) continue;
+        bcf_enc_int1(sink, pl.bcf_id[f]);
+        bcf_enc_int1(sink, v);
+      }
+      ++n_info;
+    }
+    {
+      const int32_t dp = cx.pc.dp_sum[k];
+      if ((pl.f_DP >= 0 || pl.f_DP_FORMAT >= 0) && dp > 0 && !ref_block_only) { bcf_enc_int1(sink, pl.bcf_dp_id); bcf_enc_int1(sink, dp); ++n_info; }
+    }
+    sink.patch_u32(at_counts, ((uint32_t)num_merged << 16) | (n_info & 0xFFFFu));
+    return;
+  }
   sink.write(cx.qw.contig_names + ctg.name_off, ctg.name_len);
   sink.put('\t');
   put_i64(sink, s_k - ctg.offset + 1);
@@ -940,7 +1229,7 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
   // the reference's DEBUG build - the one the goldens come from - keeps them in a std::set)
   {
     const char* tp[GDB_MAX_ID_TOKENS]; int tn[GDB_MAX_ID_TOKENS]; int nt = 0;
-    if (pl.f_ID >= 0)
+    if (pl.f_ID >= 0 && !(hsite && !hsite->any_id))
       for (int64_t t = hb; t < he; ++t) {
         const int64_t c = cx.hl.cell[t];
         if (!field_valid(cx.cm, c, pl.f_ID)) continue;
@@ -992,7 +1281,8 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
   {
     int first_id = -1;
     bool multi = false;
-    if (pl.produce_FILTER_field && pl.f_FILTER >= 0)
+    if (hsite) { first_id = hsite->filter_first_id; multi = hsite->filter_multi != 0; }
+    else if (pl.produce_FILTER_field && pl.f_FILTER >= 0)
       for (int64_t t = hb; t < he; ++t) {
         int64_t c = cx.hl.cell[t];
         if (!field_valid(cx.cm, c, pl.f_FILTER)) continue;
@@ -1104,6 +1394,28 @@ struct EntryMaps {
 
 // Each field kind has its own out-of-line emitter taking and returning the sink BY VALUE: keeps every function small
 // and the cursor in registers (a char store through a by-reference sink may alias the sink itself).
+// merged allele index of GT element out_i (input allele a) of a live call, -1 = no call ('.'):
+// remap_GT_field (variant_operations.cc:233-263) with the min-PL override of spanning deletions
+GDB_FIELD_FN int32_t gt_merged_allele(const EntryCtx& cx, const RecordInfo& ri, const EntryMaps& em, int32_t a, int out_i) {
+  int32_t m = -1;
+  if (em.iflag & GDB_IF_GT_OVERRIDE) {  // min-PL genotype over the reduced alleles: 0 REF, 1 '*', 2 <NON_REF>
+    const int ra = cx.hl.gt_override[GDB_MAX_PLOIDY * em.inc + (out_i < GDB_MAX_PLOIDY ? out_i : GDB_MAX_PLOIDY - 1)];
+    if (ra == 0) m = 0;
+    else if (ra == 2) m = ri.num_merged - 1;
+    else { for (int q = 1; q < em.n_in; ++q) if (em.i2m && em.i2m[q] >= 0 && em.i2m[q] != ri.num_merged - 1) { m = em.i2m[q]; break; } }
+  } else if (a == GDB_TILEDB_NULL_INT32 || a == -1 || a == GDB_BCF_INT32_MISSING) {
+    m = -1;
+  } else if (!em.remap) {
+    m = a;
+  } else {
+    int8_t mm = -1;
+    if (a >= 0 && a < em.n_in) mm = em.i2m ? em.i2m[a] : (a == 0 ? (int8_t)0 : ((em.nr_exists && a == 1) ? (int8_t)(ri.num_merged - 1) : (int8_t)-1));
+    if (mm >= 0) m = mm;
+    else if ((em.iflag & GDB_IF_SPANNING) && (em.iflag & GDB_IF_NO_NR)) m = -1;
+    else m = em.nr_exists ? ri.num_merged - 1 : -1;
+  }
+  return m;
+}
 template <class Sink> GDB_FIELD_FN Sink emit_GT(Sink s, const EntryCtx& cx, const RecordInfo& ri, const EntryMaps& em, int64_t c) {
   const CombinePlan& pl = cx.pl;
   const int f = pl.f_GT;
@@ -1114,26 +1426,7 @@ template <class Sink> GDB_FIELD_FN Sink emit_GT(Sink s, const EntryCtx& cx, cons
   int out_i = 0;
   for (int j = 0; j < n; j += step, ++out_i) {
     if (out_i) s.put((pp && g[j - 1] > 0) ? '|' : '/');
-    int32_t m = -1;
-    if (pl.produce_GT_field) {
-      int32_t a = g[j];
-      if (em.iflag & GDB_IF_GT_OVERRIDE) {  // min-PL genotype over the reduced alleles: 0 REF, 1 '*', 2 <NON_REF>
-        const int ra = cx.hl.gt_override[GDB_MAX_PLOIDY * em.inc + (out_i < GDB_MAX_PLOIDY ? out_i : GDB_MAX_PLOIDY - 1)];
-        if (ra == 0) m = 0;
-        else if (ra == 2) m = ri.num_merged - 1;
-        else { for (int q = 1; q < em.n_in; ++q) if (em.i2m && em.i2m[q] >= 0 && em.i2m[q] != ri.num_merged - 1) { m = em.i2m[q]; break; } }
-      } else if (a == GDB_TILEDB_NULL_INT32 || a == -1 || a == GDB_BCF_INT32_MISSING) {
-        m = -1;
-      } else if (!em.remap) {
-        m = a;
-      } else {
-        int8_t mm = -1;
-        if (a >= 0 && a < em.n_in) mm = em.i2m ? em.i2m[a] : (a == 0 ? (int8_t)0 : ((em.nr_exists && a == 1) ? (int8_t)(ri.num_merged - 1) : (int8_t)-1));
-        if (mm >= 0) m = mm;
-        else if ((em.iflag & GDB_IF_SPANNING) && (em.iflag & GDB_IF_NO_NR)) m = -1;
-        else m = em.nr_exists ? ri.num_merged - 1 : -1;
-      }
-    }
+    const int32_t m = pl.produce_GT_field ? gt_merged_allele(cx, ri, em, g[j], out_i) : -1;
     if (m < 0) s.put('.'); else put_i32(s, m);
   }
   if (out_i == 0) s.put('.');

@@ -103,10 +103,16 @@ struct CombinePlan {
   int32_t max_diploid_alt_alleles;
   int32_t qual_combine_op;  // GDB_OP_UNKNOWN unless the vid configures one
   int32_t num_query_rows;   // N: sample columns of the output
+  // BCF2 ("bu") output: typed binary records instead of text (vcf_adapter.cc:475-509); ids of the header dictionary
+  int32_t bcf_mode;                           // 0: VCF text
+  int32_t use_missing_values_not_vector_end;  // the JNI flag for htsjdk (variant_field_handler.cc:846-866)
+  int32_t bcf_n_sample;                       // n_sample of every record (0 for sites-only queries)
+  int32_t bcf_end_id, bcf_dp_id;              // dictionary index of END / DP
+  int32_t bcf_id[GDB_MAX_FIELDS];             // dictionary index of the VCF name of plan field f (-1: none)
 };
 
 // Query-row mapping + contig table live in device memory next to the fragment.
-struct GdbContig { int64_t offset, length; int32_t name_off, name_len; };
+struct GdbContig { int64_t offset, length; int32_t name_off, name_len; int32_t rid, pad; };   // rid: index in the header's contig dictionary
 
 struct QueryWindow {
   int64_t qb, qe;               // inclusive column interval being scanned

@@ -6,7 +6,24 @@
 
 namespace genomicsdb_amd {
 
-HostPlan build_combine_plan(const VariantQueryConfig& qc, const std::string& tmpl) {
+std::string HostPlan::bcf_header_bytes(bool keep_idx_fields) const {
+  std::string text;
+  for (size_t i = 0; i < header_lines.size(); ++i) {
+    const std::string& l = header_lines[i];
+    if (keep_idx_fields && header_line_idx[i] >= 0 && !l.empty() && l.back() == '>') text += l.substr(0, l.size() - 1) + ",IDX=" + std::to_string(header_line_idx[i]) + ">";
+    else text += l;
+    text += '\n';
+  }
+  text += header_text.substr(header_text.rfind("#CHROM"));
+  std::string out("BCF\2\2", 5);
+  const uint32_t l_text = (uint32_t)text.size() + 1;
+  out.append((const char*)&l_text, 4);
+  out += text;
+  out.push_back('\0');
+  return out;
+}
+
+HostPlan build_combine_plan(const VariantQueryConfig& qc, const std::string& tmpl, const std::string& output_format, bool use_missing_values_not_vector_end) {
   if (!qc.is_bookkeeping_done()) throw BroadCombinedGVCFException("do_query_bookkeeping() must run first");
   const VidMapper& vid = qc.get_vid_mapper();
   HostPlan hp;
@@ -179,6 +196,47 @@ HostPlan build_combine_plan(const VariantQueryConfig& qc, const std::string& tmp
     hp.contig_names += c.m_name;
     hp.contigs.push_back(g);
   }
+  // ---- header dictionaries (htslib bcf_hdr_parse): FILTER / INFO / FORMAT ids share one dictionary, PASS is entry 0, the others
+  // follow in order of first appearance; contigs have their own, in line order
+  {
+    std::vector<std::pair<std::string, int>> dict;   // id -> index
+    auto find_id = [&](const std::string& id) -> int { for (auto& d : dict) if (d.first == id) return d.second; return -1; };
+    dict.push_back(std::make_pair(std::string("PASS"), 0));
+    std::vector<std::pair<std::string, int>> ctg_dict;
+    for (auto& l : lines) {
+      int idx = -1;
+      const bool is_dict = l.rfind("##FILTER=", 0) == 0 || l.rfind("##INFO=", 0) == 0 || l.rfind("##FORMAT=", 0) == 0;
+      const bool is_ctg = l.rfind("##contig=", 0) == 0;
+      size_t idp = l.find("<ID=");
+      if ((is_dict || is_ctg) && idp != std::string::npos) {
+        size_t ide = l.find_first_of(",>", idp + 4);
+        const std::string id = l.substr(idp + 4, ide - idp - 4);
+        if (is_dict) { idx = find_id(id); if (idx < 0) { idx = (int)dict.size(); dict.push_back(std::make_pair(id, idx)); } }
+        else { idx = (int)ctg_dict.size(); ctg_dict.push_back(std::make_pair(id, idx)); }
+      }
+      hp.header_lines.push_back(l);
+      hp.header_line_idx.push_back(idx);
+    }
+    for (int f = 0; f < GDB_MAX_FIELDS; ++f) pl.bcf_id[f] = -1;
+    for (int f = 0; f < pl.nfields; ++f) { const FieldInfo* fi = vid.get_field_info(hp.field_names[(size_t)f]); if (fi) pl.bcf_id[f] = find_id(fi->m_vcf_name); }
+    pl.bcf_end_id = find_id("END");
+    pl.bcf_dp_id = find_id("DP");
+    for (unsigned i = 0; i < vid.get_num_fields(); ++i) {
+      const FieldInfo& fi = vid.get_field_info(i);
+      hp.filter_bcf_id.push_back(have[0].count(fi.m_vcf_name) ? find_id(fi.m_vcf_name) : -1);
+    }
+    for (auto& g : hp.contigs) {
+      const std::string name = hp.contig_names.substr((size_t)g.name_off, (size_t)g.name_len);
+      g.rid = -1; g.pad = 0;
+      for (auto& c : ctg_dict) if (c.first == name) g.rid = c.second;
+    }
+  }
+  pl.bcf_mode = output_format == "bu" ? 1 : 0;
+  if (!output_format.empty() && output_format != "bu")
+    throw UnsupportedOnDeviceException("VCF output format \"" + output_format + "\": this build streams text VCF (\"\") or uncompressed BCF2 (\"bu\")");
+  pl.use_missing_values_not_vector_end = use_missing_values_not_vector_end ? 1 : 0;
+  pl.bcf_n_sample = sites_only ? 0 : (int32_t)qc.get_num_rows_to_query();
+  if (pl.bcf_mode && pl.bcf_end_id < 0) throw BroadCombinedGVCFException("BCF output needs an INFO END line in the header");
   std::sort(hp.contigs.begin(), hp.contigs.end(), [](const GdbContig& a, const GdbContig& b) { return a.offset < b.offset; });
   for (auto& l : lines) { hp.header_text += l; hp.header_text += '\n'; }
   hp.header_text += "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO";

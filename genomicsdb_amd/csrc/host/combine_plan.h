@@ -23,6 +23,12 @@ struct HostPlan {
   CombinePlan plan;
   std::vector<std::string> field_names;  // plan field idx -> array attribute name
   std::string header_text;               // template "##" lines + added lines + #CHROM line
+  // BCF2 ("bu") flavour of the stream: "BCF\2\2", l_text, the same text with an IDX key on every FILTER / INFO / FORMAT / contig
+  // line (or without, keep_idx_fields_in_bcf_header = false), NUL  (htslib bcf_hdr_write; fork: bcf_hdr_serialize, vcf_adapter.cc:475-488)
+  std::string bcf_header_bytes(bool keep_idx_fields) const;
+  std::vector<std::string> header_lines;  // "##" lines of header_text in order
+  std::vector<int32_t> header_line_idx;   // dictionary index of each such line (-1: the line is no dictionary entry)
+  std::vector<int32_t> filter_bcf_id;     // per vid field idx: dictionary index of the FILTER of that name (-1: not in the header)
   // name tables (NameTables on the device)
   std::string names_text;
   std::vector<int32_t> field_name_off, field_name_len, filter_name_off, filter_name_len;
@@ -31,6 +37,8 @@ struct HostPlan {
   std::string contig_names;
 };
 
-HostPlan build_combine_plan(const VariantQueryConfig& qc, const std::string& template_header_text);
+// output_format "" / "z": VCF text; "bu": BCF2 records.  use_missing_values_not_vector_end: the JNI flag for htsjdk.
+HostPlan build_combine_plan(const VariantQueryConfig& qc, const std::string& template_header_text, const std::string& output_format = "",
+                            bool use_missing_values_not_vector_end = false);
 
 }  // namespace genomicsdb_amd

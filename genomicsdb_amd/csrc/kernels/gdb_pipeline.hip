@@ -23,6 +23,7 @@
 #include <rocprim/iterator/reverse_iterator.hpp>
 
 #include "../core/gdb_stages.hpp"
+#include "../core/gdb_bcf.hpp"
 #include "gdb_pipeline.h"
 
 namespace genomicsdb_amd {
@@ -98,6 +99,11 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_dpp(uint32_t v) {
   return v;
 }
 __device__ __forceinline__ uint32_t wave_total(uint32_t inclusive) { return (uint32_t)__builtin_amdgcn_readlane((int)inclusive, 63); }
+
+// unaligned 4 / 8 byte accesses (gfx950 serves them in hardware)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed)) PackedU32 { uint32_t v; };
+struct __attribute__((packed)) PackedU64 { uint64_t v; };
 
 // ---- elementwise stage kernels -----------------------------------------------------------------------------
 __global__ void k_classify(FragmentView fr, CombinePlan pl, CellMeta cm, uint32_t* err) {
@@ -454,6 +460,14 @@ __device__ __noinline__ uint32_t entry_store_lds_capped(int cs, RecordInfo ri, i
   return entry_emit(c_ex[cs], ri, c, LdsCapSink(dst, cap), e).n;
 }
 
+// binary (BCF) flavour of the same two wrappers
+__device__ __noinline__ void entry_bin_store(int cs, RecordInfo ri, int64_t c, char* dst, uint32_t* e) {
+  (void)entry_emit_bin(c_ex[cs], ri, c, ByteSink(dst), e);
+}
+__device__ __noinline__ uint32_t entry_bin_lds_capped(int cs, RecordInfo ri, int64_t c, gdb_lds_char* dst, uint32_t cap, uint32_t* e) {
+  return entry_emit_bin(c_ex[cs], ri, c, LdsCapSink(dst, cap), e).n;
+}
+
 // ---- entry text table ---------------------------------------------------------------------------------------------
 // The sample columns are >99 % of the output bytes, and almost all of them repeat: a reference-block call is live in ~100
 // consecutive records and its text depends only on (cell, record type) with type = (FORMAT mask, remap flags, #merged
@@ -592,6 +606,7 @@ struct SlotTable {
   uint32_t heavy_base;
   uint32_t row_base;      // slots of (untabled record, sample): row_base + u * N + row
   int32_t ctx;            // this pipeline's slot of c_ex
+  int32_t bcf;            // entries are binary (gdb_bcf.hpp) instead of text
 };
 // PASS 0: ONE run of the field emitters gives the length of the text and, when it fits kSlotStride bytes (nearly always),
 // the text itself: formatted into a lane-private LDS strip, it leaves as 16-byte stores into the lane's inline slot.
@@ -604,8 +619,11 @@ template <int PASS> __device__ __forceinline__ void slot_fill(const SlotTable& s
       __shared__ uint32_t strip[kSlotBlock * kStripWords];
       uint32_t* mine = strip + threadIdx.x * kStripWords;
       gdb_lds_char* txt = (gdb_lds_char*)mine;
+      if (st.bcf) len = entry_bin_lds_capped(st.ctx, rinfo, c, txt, (uint32_t)kSlotStride, e);
+      else {
       *txt = '\t';
       len = 1u + entry_store_lds_capped(st.ctx, rinfo, c, txt + 1, (uint32_t)kSlotStride - 1u, e);
+      }
       if (len <= (uint32_t)kSlotStride) {
         uint4* dst = reinterpret_cast<uint4*>(st.pool + (size_t)s * kSlotStride);
         for (uint32_t q = 0; (q << 4) < len; ++q) dst[q] = make_uint4(mine[4 * q], mine[4 * q + 1], mine[4 * q + 2], mine[4 * q + 3]);
@@ -614,6 +632,7 @@ template <int PASS> __device__ __forceinline__ void slot_fill(const SlotTable& s
     st.len[s] = len;
   } else if (st.len[s] > (uint32_t)kSlotStride) {
     char* dst = st.pool_ovf + (size_t)st.ovf16[s] * 16;
+    if (st.bcf) { entry_bin_store(st.ctx, rinfo, c, dst, e); return; }
     *dst = '\t';
     entry_store(st.ctx, rinfo, c, dst + 1, e);
   }
@@ -979,6 +998,156 @@ k_assemble_write(const char* __restrict__ pool, const char* __restrict__ pool_ov
   }
 }
 
+// ---- BCF2 page assembly ("bu") ------------------------------------------------------------------------------------------------
+// The FORMAT block of a BCF record is field-major with a fixed stride per sample, so once the vector length and the integer
+// type of every (record, field) are known a sample's values have a fixed place: no scan over variable-length texts.
+// k_bcf_field_meta reduces the entries' summaries per (record, 64-sample chunk), k_bcf_layout per record (and sizes the record),
+// k_bcf_shared writes l_shared / l_indiv, the shared block and the key + type bytes of every field, k_bcf_write the values.
+__global__ void __launch_bounds__(kAsmRows) k_bcf_field_meta(const uint2* __restrict__ resolved, const char* __restrict__ pool, const char* __restrict__ pool_ovf,
+                                                           const uint32_t* __restrict__ fmt_mask, int nchunks, int F, uint32_t* __restrict__ part) {
+  const int64_t rc = blockIdx.x;                       // record * nchunks + chunk
+  const int64_t k = rc / nchunks;
+  const int lane = threadIdx.x;
+  const uint2 d = resolved[rc * kAsmRows + lane];
+  const char* src = ((d.x & kOverflowBit) ? pool_ovf : pool) + (size_t)(d.x & ~kOverflowBit) * 16;
+  const int nf = __popc(fmt_mask[k]);
+  for (int q = 0; q < nf; ++q) {                        // uniform
+    uint32_t w = d.y ? reinterpret_cast<const uint32_t*>(src)[q] : 0u;   // (entries are 16-byte aligned)
+    uint32_t n = w & 0xFFFFu;
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)n, off, 64); n = o > n ? o : n; }
+    const uint32_t cls = __any((int)((w >> 16) >= 2u)) ? 2u : (__any((int)((w >> 16) >= 1u)) ? 1u : 0u);
+    if (lane == 0) part[rc * F + q] = n | (cls << 16);
+  }
+}
+struct BcfLayout {            // per record
+  uint32_t* fmeta;            // [P * F]  bits 0..15 vector length, 16..19 BCF type code, 24..31 bytes of key + type descriptor
+  uint32_t* foff;             // [P * F]  offset of the field's key inside the record
+  uint32_t* l_indiv;          // [P]
+  uint64_t* rec_size;         // [P]
+};
+__global__ void k_bcf_layout(CombinePlan pl, const uint32_t* __restrict__ part, const uint32_t* __restrict__ fmt_mask, const uint32_t* __restrict__ prefix_len, int64_t P, int nchunks,
+                             int F, BcfLayout lay) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= P) return;
+  const uint32_t mask = fmt_mask[k];
+  uint32_t at = 8u + prefix_len[k];              // l_shared, l_indiv, shared block
+  const uint32_t indiv_begin = at;
+  int q = 0;
+  for (int i = 0; i < pl.n_format; ++i) {
+    if (!((mask >> i) & 1u)) continue;
+    uint32_t sum = 0;
+    for (int ch = 0; ch < nchunks; ++ch) sum = bcf_summary_max(sum, part[(k * nchunks + ch) * F + q]);
+    const int t = bcf_field_type(pl, i, sum);
+    const uint32_t cnt = (sum & 0xFFFFu) ? (sum & 0xFFFFu) : 1u;   // (a field in the mask has a value somewhere; 1 keeps the layout sane otherwise)
+    const int f = pl.format_field[i];
+    const int32_t key = (f == pl.f_DP && pl.f_DP_FORMAT >= 0) ? pl.bcf_dp_id : pl.bcf_id[f];
+    const uint32_t hdr = (uint32_t)bcf_enc_int1_bytes(key) + (uint32_t)bcf_enc_size_bytes((int)cnt);
+    lay.fmeta[k * F + q] = cnt | ((uint32_t)t << 16) | (hdr << 24);
+    lay.foff[k * F + q] = at;
+    at += hdr + (uint32_t)pl.bcf_n_sample * cnt * (uint32_t)bcf_type_width(t);
+    ++q;
+  }
+  lay.l_indiv[k] = at - indiv_begin;
+  lay.rec_size[k] = at;
+}
+__global__ void k_bcf_max_record(const uint64_t* rec_size, int64_t P, unsigned long long* max_record) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long mine = k < P ? rec_size[k] : 0ull;
+  for (int d = 32; d > 0; d >>= 1) { const unsigned long long o = __shfl_xor(mine, d); mine = o > mine ? o : mine; }
+  if ((threadIdx.x & 63) == 0 && mine) atomicMax(max_record, mine);
+}
+// l_shared, l_indiv, the shared block (parked by the site pass) and the key / type bytes of every FORMAT field: one thread per record
+__global__ void k_bcf_shared(const SiteCtx* __restrict__ sxp, const char* __restrict__ staging, const char* __restrict__ spill_buf, const int32_t* __restrict__ spill_chunk,
+                             int64_t k_begin, int64_t k_end, const uint64_t* __restrict__ rec_off, uint64_t page_base, BcfLayout lay, int F, char* __restrict__ arena, uint32_t* err) {
+  const SiteCtx& sx = *sxp;
+  const int64_t k = k_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= k_end) return;
+  const CombinePlan& pl = sx.pl;
+  char* rec = arena + (rec_off[k] - page_base);
+  const uint32_t n = sx.so.prefix_len[k];
+  ByteSink head(rec);
+  bcf_put_u32(head, n);
+  bcf_put_u32(head, lay.l_indiv[k]);
+  char* dst = rec + 8;
+  uint32_t e = 0;
+  if (n <= (uint32_t)kSiteStride) {
+    const char* src = staging + (size_t)k * kSiteStride;
+    for (uint32_t i = 0; i < n; ++i) dst[i] = src[i];
+  } else if (spill_chunk[k] >= 0) {
+    const char* src = staging + (size_t)k * kSiteStride;
+    for (uint32_t i = 0; i < (uint32_t)kSiteStride; ++i) dst[i] = src[i];
+    const char* tail = spill_buf + (size_t)spill_chunk[k] * kSpillChunk;
+    for (uint32_t i = kSiteStride; i < n; ++i) dst[i] = tail[i - kSiteStride];
+  } else {
+    ByteSink bs(dst);
+    site_emit(sx, k, bs, false, &e);
+  }
+  const uint32_t mask = sx.so.fmt_mask[k];
+  int q = 0;
+  for (int i = 0; i < pl.n_format; ++i) {
+    if (!((mask >> i) & 1u)) continue;
+    const uint32_t m = lay.fmeta[k * F + q];
+    ByteSink fs(rec + lay.foff[k * F + q]);
+    const int f = pl.format_field[i];
+    bcf_enc_int1(fs, (f == pl.f_DP && pl.f_DP_FORMAT >= 0) ? pl.bcf_dp_id : pl.bcf_id[f]);
+    bcf_enc_size(fs, (int)(m & 0xFFFFu), (int)((m >> 16) & 0xFu));
+    ++q;
+  }
+  if (e) atomicOr(err, e);
+}
+// values: one wavefront = one record x 64 samples; every lane converts its entry's elements of field q to the record's type
+// and pads up to the record's vector length (collect_and_extend_fields, variant_field_handler.cc:846-866)
+__global__ void __launch_bounds__(kAsmRows) k_bcf_write(CombinePlan pl, const uint2* __restrict__ resolved, const char* __restrict__ pool, const char* __restrict__ pool_ovf,
+                                                      const uint32_t* __restrict__ fmt_mask, int64_t k_begin, int nchunks, int F, int32_t N, BcfLayout lay,
+                                                      const uint64_t* __restrict__ rec_off, uint64_t page_base, char* __restrict__ arena) {
+  const int64_t k = k_begin + (int64_t)(blockIdx.x / (unsigned)nchunks);
+  const int ch = (int)(blockIdx.x % (unsigned)nchunks);
+  const int lane = threadIdx.x;
+  const int32_t r = ch * kAsmRows + lane;
+  const uint2 d = resolved[(k * nchunks + ch) * kAsmRows + lane];
+  const char* src = ((d.x & kOverflowBit) ? pool_ovf : pool) + (size_t)(d.x & ~kOverflowBit) * 16;
+  const uint32_t mask = fmt_mask[k];
+  const int nf = __popc(mask);
+  char* rec = arena + (rec_off[k] - page_base);
+  uint32_t body = 4u * (uint32_t)nf;            // this lane's read position inside its entry
+  const bool flag = pl.use_missing_values_not_vector_end != 0;
+  int q = 0;
+  for (int i = 0; i < pl.n_format; ++i) {       // uniform
+    if (!((mask >> i) & 1u)) continue;
+    const uint32_t m = lay.fmeta[k * F + q];
+    const uint32_t cnt = m & 0xFFFFu, t = (m >> 16) & 0xFu, hdr = m >> 24;
+    const uint32_t w = (uint32_t)bcf_type_width((int)t);
+    const int es = bcf_field_elem_size(pl, i);
+    const uint32_t n = d.y ? (reinterpret_cast<const uint32_t*>(src)[q] & 0xFFFFu) : 0u;
+    const bool is_gt = pl.format_field[i] == pl.f_GT;
+    if (r < N) {
+      char* dst = rec + lay.foff[k * F + q] + hdr + (size_t)r * cnt * w;
+      for (uint32_t j = 0; j < cnt; ++j) {
+        if (t == GDB_BT_CHAR) {
+          char v;
+          if (j < n) v = src[body + j];
+          else if (j == 0 && n == 0) v = flag ? (char)0 : (char)7;      // no value: '.' (vector end under the htsjdk flag)
+          else v = (char)0;                                              // pad with vector end
+          dst[j] = v;
+        } else {
+          uint32_t v;
+          if (j < n) v = reinterpret_cast<const PackedU32*>(src + body + 4u * j)->v;
+          else if (t == GDB_BT_FLOAT) v = (j == 0 && n == 0) ? GDB_BCF_FLOAT_MISSING_BITS : (flag ? GDB_BCF_FLOAT_MISSING_BITS : GDB_BCF_FLOAT_VECTOR_END_BITS);
+          else if (j == 0 && n == 0) v = is_gt ? (flag ? 0u : (uint32_t)GDB_BCF_INT32_VECTOR_END) : (uint32_t)GDB_BCF_INT32_MISSING;   // GT: no-call allele under the flag
+          else v = flag ? (uint32_t)GDB_BCF_INT32_MISSING : (uint32_t)GDB_BCF_INT32_VECTOR_END;
+          if (t == GDB_BT_INT8) dst[j] = (int32_t)v == GDB_BCF_INT32_MISSING ? (char)0x80 : (int32_t)v == GDB_BCF_INT32_VECTOR_END ? (char)0x81 : (char)v;
+          else if (t == GDB_BT_INT16) {
+            const uint16_t h = (int32_t)v == GDB_BCF_INT32_MISSING ? (uint16_t)0x8000u : (int32_t)v == GDB_BCF_INT32_VECTOR_END ? (uint16_t)0x8001u : (uint16_t)v;
+            dst[2 * j] = (char)(h & 0xFFu); dst[2 * j + 1] = (char)(h >> 8);
+          } else { for (int b = 0; b < 4; ++b) dst[4 * j + b] = (char)((v >> (8 * b)) & 0xFFu); }
+        }
+      }
+    }
+    body += n * (uint32_t)es;
+    ++q;
+  }
+}
+
 // sort key of the assembly order: (block of 2^block_log2 consecutive records, record type); the value is the record index
 __global__ void k_order_keys(const uint8_t* rtype, int32_t base, int64_t n, int block_log2, uint32_t* keys, int32_t* vals) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1003,9 +1172,6 @@ struct CellColumnsDev { char* data[GDB_MAX_FIELDS]; uint32_t* len[GDB_MAX_FIELDS
 // reading global memory bytewise touched 64 different cache lines per load instruction: 54 GB of traffic for 1.45 GB of cells.)
 constexpr int kStageTile = 12 * 1024;       // LDS bytes per wavefront
 constexpr int kStageBlock = 256;
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-struct __attribute__((packed)) PackedU32 { uint32_t v; };
-struct __attribute__((packed)) PackedU64 { uint64_t v; };
 struct GlobalBytes {
   const uint8_t* p;
   __device__ __forceinline__ uint8_t u8(uint32_t o) const { return p[o]; }
@@ -1206,7 +1372,8 @@ struct DevicePipeline::Impl {
   std::vector<void*> owned;
   // small tables
   DevBuf<char> names_text, contig_names, ref_bases;
-  DevBuf<int32_t> field_name_off, field_name_len, filter_name_off, filter_name_len;
+  DevBuf<int32_t> field_name_off, field_name_len, filter_name_off, filter_name_len, filter_bcf_id;
+  DevBuf<uint32_t> bcf_part, bcf_fmeta, bcf_foff, bcf_lindiv; DevBuf<uint64_t> bcf_rec_size;   // BCF page assembly
   DevBuf<GdbContig> contigs;
   int64_t ref_begin = 0, ref_len = 0;
   // per-cell
@@ -1259,6 +1426,7 @@ struct DevicePipeline::Impl {
     IntervalStats stats;
     SiteCtx sx; EntryCtx ex; RowIndex ri; SiteOut so; RecordTable rec; AsmCtx ac;
     bool resolved_whole = false;
+    bool bcf = false; int bcf_F = 0; BcfLayout lay{nullptr, nullptr, nullptr, nullptr};
   } iv;
 
   void* temp_storage(size_t bytes) { temp.ensure(bytes + 256); return temp.p; }
@@ -1354,6 +1522,7 @@ DevicePipeline::DevicePipeline(const HostPlan& hp, int device) : m_(new Impl) {
   up(m_->field_name_len, hp.field_name_len.data(), hp.field_name_len.size());
   up(m_->filter_name_off, hp.filter_name_off.data(), hp.filter_name_off.size());
   up(m_->filter_name_len, hp.filter_name_len.data(), hp.filter_name_len.size());
+  up(m_->filter_bcf_id, hp.filter_bcf_id.data(), hp.filter_bcf_id.size());
   up(m_->contigs, hp.contigs.data(), hp.contigs.size());
   m_->err.ensure(4);
   m_->counters.ensure(16 + kCountSpread);
@@ -2206,7 +2375,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   qw.qb = qb; qw.qe = qe;
   qw.contigs = S.contigs.p; qw.ncontigs = (int32_t)S.hp.contigs.size(); qw.contig_names = S.contig_names.p;
   qw.ref_bases = S.ref_len ? S.ref_bases.p : nullptr; qw.ref_begin = S.ref_begin; qw.ref_len = S.ref_len;
-  NameTables nt{S.names_text.p, S.field_name_off.p, S.field_name_len.p, S.filter_name_off.p, S.filter_name_len.p, (int32_t)S.hp.filter_name_off.size()};
+  NameTables nt{S.names_text.p, S.field_name_off.p, S.field_name_len.p, S.filter_name_off.p, S.filter_name_len.p, (int32_t)S.hp.filter_name_off.size(), S.filter_bcf_id.p};
   PresenceCounts pc{d_fmt, d_dp, d_nr, stride};
   MedianOrder med;
   memset(&med, 0, sizeof(med));
@@ -2337,7 +2506,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   S.slot_len.ensure(NS + 1); S.slot_units.ensure(NS + 1); S.slot_off.ensure(NS + 1); S.slot_desc.ensure(NS + 1);
   if (NS * (uint64_t)(kSlotStride / 16) >= (uint64_t)kOverflowBit) throw GenomicsDBDeviceException("entry text table exceeds 32 GiB: split the query interval");
   S.pool.ensure((size_t)NS * kSlotStride + 64);
-  SlotTable stt{S.slot_len.p, S.slot_off.p, S.pool.p, nullptr, (uint32_t)kMaxTypes, (uint32_t)(kMaxTypes + SL), (uint32_t)(kMaxTypes + SL + (uint64_t)T), (int32_t)S.ctx_slot};
+  SlotTable stt{S.slot_len.p, S.slot_off.p, S.pool.p, nullptr, (uint32_t)kMaxTypes, (uint32_t)(kMaxTypes + SL), (uint32_t)(kMaxTypes + SL + (uint64_t)T), (int32_t)S.ctx_slot, pl.bcf_mode};
   STAGE("k_slots<0>");
   hipLaunchKernelGGL(k_slots_nocall<0>, dim3(1), dim3(kMaxTypes), 0, st, stt, so, S.type_rep.p, ntypes, S.err.p);
   if (SL > 0) {
@@ -2376,16 +2545,34 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   STAGE("k_assemble_size");
   S.order_by_type(0, P);
   const uint64_t resolved_bytes = (uint64_t)P * nchunks * kAsmRows * sizeof(uint2);
-  const bool resolved_whole = resolved_bytes <= resolved_budget_bytes();
+  const bool resolved_whole = resolved_bytes <= resolved_budget_bytes() || pl.bcf_mode;
   if (resolved_whole) S.resolved.ensure((size_t)P * nchunks * kAsmRows);
+  S.max_record.ensure(1);
+  HIP_CHECK(hipMemsetAsync(S.max_record.p, 0, sizeof(unsigned long long), st));
+  BcfLayout lay{nullptr, nullptr, nullptr, nullptr};
+  const int bcf_F = std::max(1, pl.n_format);
+  if (pl.bcf_mode) {
+    // BCF2: resolve the (record, sample) matrix, reduce the entries' summaries to vector length + type per (record, field), size the records
+    hipLaunchKernelGGL(k_assemble_size, dim3(run_blocks * (unsigned)nchunks), dim3(kAsmRows), 0, st, ac, S.order.p, P, N, nchunks, run, (uint64_t*)nullptr, S.resolved.p, (int64_t)0);
+    S.bcf_part.ensure(nchunk_total * (size_t)bcf_F + 1); S.bcf_fmeta.ensure((size_t)P * bcf_F + 1); S.bcf_foff.ensure((size_t)P * bcf_F + 1); S.bcf_lindiv.ensure((size_t)P + 1);
+    S.bcf_rec_size.ensure((size_t)P + 2);
+    lay = BcfLayout{S.bcf_fmeta.p, S.bcf_foff.p, S.bcf_lindiv.p, S.bcf_rec_size.p};
+    STAGE("k_bcf_field_meta");
+    hipLaunchKernelGGL(k_bcf_field_meta, dim3((unsigned)nchunk_total), dim3(kAsmRows), 0, st, (const uint2*)S.resolved.p, (const char*)S.pool.p, (const char*)S.pool_ovf.p,
+                       (const uint32_t*)S.fmt_mask.p, nchunks, bcf_F, S.bcf_part.p);
+    hipLaunchKernelGGL(k_bcf_layout, dim3(blocks_for(P)), dim3(kBlock), 0, st, pl, (const uint32_t*)S.bcf_part.p, (const uint32_t*)S.fmt_mask.p, (const uint32_t*)S.prefix_len.p, P,
+                       nchunks, bcf_F, lay);
+    HIP_CHECK(hipMemsetAsync(S.bcf_rec_size.p + P, 0, sizeof(uint64_t), st));
+    S.excl_scan(S.bcf_rec_size.p, S.rec_off.p, (size_t)P + 1);
+    hipLaunchKernelGGL(k_bcf_max_record, dim3(blocks_for(P)), dim3(kBlock), 0, st, (const uint64_t*)S.bcf_rec_size.p, P, S.max_record.p);
+  } else {
   hipLaunchKernelGGL(k_assemble_size, dim3(run_blocks * (unsigned)nchunks), dim3(kAsmRows), 0, st, ac, S.order.p, P, N, nchunks, run, S.chunk_size.p,
                      resolved_whole ? S.resolved.p : nullptr, (int64_t)0);
   HIP_CHECK(hipMemsetAsync(S.chunk_size.p + nchunk_total, 0, sizeof(uint64_t), st));
   S.excl_scan(S.chunk_size.p, S.chunk_off.p, nchunk_total + 1);
   STAGE("k_gather_record_offsets");
-  S.max_record.ensure(1);
-  HIP_CHECK(hipMemsetAsync(S.max_record.p, 0, sizeof(unsigned long long), st));
   hipLaunchKernelGGL(k_gather_record_offsets, dim3(blocks_for(P + 1)), dim3(kBlock), 0, st, S.chunk_off.p, nchunks, P, S.rec_off.p, S.max_record.p);
+  }
   S.iv.rec_off.clear();             // fetched by next_page only when the interval does not fit one page
   uint64_t totals[2] = {0, 0};      // bytes of the interval, bytes of its largest record
   STAGE("before-sync-offsets");
@@ -2400,6 +2587,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   S.iv.max_record_bytes = totals[1];
   S.iv.P = P; S.iv.nchunks = nchunks; S.iv.kp = 0;
   S.iv.sx = sx; S.iv.ex = ex; S.iv.ri = ri; S.iv.so = so; S.iv.rec = rec; S.iv.ac = ac; S.iv.resolved_whole = resolved_whole;
+  S.iv.bcf = pl.bcf_mode != 0; S.iv.bcf_F = bcf_F; S.iv.lay = lay;
   S.iv.active = true;
 }
 
@@ -2441,6 +2629,22 @@ bool DevicePipeline::begin_page(uint64_t arena_bytes, int arena_idx, PageTicket*
   const int64_t np = ke - kp;
   hipEvent_t* w = S.ev_page[ai];
   HIP_CHECK(hipEventRecord(w[0], st));
+  if (iv.bcf) {
+    STAGE("k_bcf_shared");
+    hipLaunchKernelGGL(k_bcf_shared, dim3(blocks_for(np, 64)), dim3(64), 0, st, S.d_sx.p, (const char*)S.site_staging.p, (const char*)S.spill_buf.p, (const int32_t*)S.spill_chunk.p, kp, ke,
+                       (const uint64_t*)S.rec_off.p, page_base, iv.lay, iv.bcf_F, arena, S.err.p);
+    HIP_CHECK(hipEventRecord(w[1], st));
+    STAGE("k_bcf_write");
+    if (S.hp.plan.n_format > 0 && !S.hp.plan.sites_only_query)
+      hipLaunchKernelGGL(k_bcf_write, dim3((unsigned)(np * iv.nchunks)), dim3(kAsmRows), 0, st, S.hp.plan, (const uint2*)S.resolved.p, (const char*)S.pool.p, (const char*)S.pool_ovf.p,
+                         (const uint32_t*)S.fmt_mask.p, kp, iv.nchunks, iv.bcf_F, N, iv.lay, (const uint64_t*)S.rec_off.p, page_base, arena);
+    HIP_CHECK(hipEventRecord(w[2], st));
+    HIP_CHECK(hipMemcpyAsync(&S.hb->page_err[ai], S.err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipEventRecord(w[3], st));
+    iv.kp = ke;
+    ticket->arena = ai; ticket->dev = arena; ticket->nbytes = page_bytes; ticket->done_event = (void*)w[3];
+    return true;
+  }
   STAGE("k_site_write");
   hipLaunchKernelGGL(k_site_copy, dim3(blocks_for(np, 4)), dim3(256), 0, st, (const uint32_t*)S.prefix_len.p, (const char*)S.site_staging.p, kp, ke, (const uint64_t*)S.chunk_off.p, iv.nchunks, page_base, arena);
   hipLaunchKernelGGL(k_site_write, dim3(blocks_for(np, 64)), dim3(64), 0, st, S.d_sx.p, (const char*)S.site_staging.p, (const char*)S.spill_buf.p, (const int32_t*)S.spill_chunk.p, kp, ke, S.chunk_off.p, iv.nchunks, page_base, arena, S.err.p);

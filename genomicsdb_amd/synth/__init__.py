@@ -50,7 +50,7 @@ class Generator:
         """returns (host address, nbytes, ncells) valid until the next call"""
         p = ctypes.c_void_p()
         n = ctypes.c_uint64()
-        nc = lib().gdbsynth_next_chunk(self._h, col_end, nthreads or min(16, os.cpu_count() or 1), ctypes.byref(p), ctypes.byref(n))
+        nc = lib().gdbsynth_next_chunk(self._h, col_end, nthreads or min(48, os.cpu_count() or 1), ctypes.byref(p), ctypes.byref(n))
         return p.value, n.value, nc
 
     def chunk_bytes(self, col_end, nthreads=None):

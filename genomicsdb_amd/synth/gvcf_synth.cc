@@ -142,65 +142,103 @@ struct Synth {
     pos[row] = r.end + 1;
   }
 
-  static void put(std::vector<uint8_t>& o, const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; o.insert(o.end(), b, b + n); }
-  template <class T> static void putv(std::vector<uint8_t>& o, T v) { put(o, &v, sizeof(T)); }
-
   // one cell in the reference binary layout, attribute order of tests/inputs/vid.json:
   // END REF ALT QUAL FILTER | BaseQRankSum ClippingRankSum MQRankSum ReadPosRankSum MQ RAW_MQ MQ0 DP | DP_FORMAT GQ SB AD PL PGT PID MIN_DP GT
-  static void write_cell(std::vector<uint8_t>& o, const Rec& r) {
-    size_t start = o.size();
-    putv<int64_t>(o, r.row); putv<int64_t>(o, r.begin); putv<uint64_t>(o, 0);
-    putv<int64_t>(o, r.end);
-    putv<int32_t>(o, r.reflen); put(o, r.ref, r.reflen);
-    if (r.kind == 0) { putv<int32_t>(o, 1); o.push_back('&'); }
-    else { putv<int32_t>(o, r.altlen + 2); put(o, r.alt, r.altlen); o.push_back('|'); o.push_back('&'); }
-    if (r.kind == 0) putv<uint32_t>(o, NULL_F32); else putv<float>(o, r.qual);
-    putv<int32_t>(o, 0);  // FILTER: none
-    if (r.kind == 0) { for (int i = 0; i < 6; ++i) putv<uint32_t>(o, NULL_F32); putv<int32_t>(o, NULL_I32); putv<int32_t>(o, NULL_I32); }
+  struct Out {
+    uint8_t* p;
+    void put(const void* src, size_t n) { memcpy(p, src, n); p += n; }
+    template <class T> void v(T x) { memcpy(p, &x, sizeof(T)); p += sizeof(T); }
+    void c(char ch) { *p++ = (uint8_t)ch; }
+  };
+  static uint32_t cell_size(const Rec& r) {
+    // coords 24 + END 8 + REF 4+len + ALT 4+len + QUAL 4 + FILTER 4 + 8 INFO words 32 + DP_FORMAT 4 + GQ 4 + SB 16 + AD + PL + PGT 4 + PID 4 + MIN_DP 4 + GT 12
+    const uint32_t alt = r.kind == 0 ? 1u : (uint32_t)r.altlen + 2u;
+    const uint32_t ad_pl = r.kind == 0 ? (4u + 4u + 12u) : (4u + 12u + 4u + 24u);
+    return 24u + 8u + 4u + r.reflen + 4u + alt + 4u + 4u + 32u + 4u + 4u + 16u + ad_pl + 4u + 4u + 4u + 12u;
+  }
+  static void write_cell(uint8_t* dst, const Rec& r) {
+    Out o{dst};
+    o.v<int64_t>(r.row); o.v<int64_t>(r.begin); o.v<uint64_t>(0);
+    o.v<int64_t>(r.end);
+    o.v<int32_t>(r.reflen); o.put(r.ref, r.reflen);
+    if (r.kind == 0) { o.v<int32_t>(1); o.c('&'); }
+    else { o.v<int32_t>(r.altlen + 2); o.put(r.alt, r.altlen); o.c('|'); o.c('&'); }
+    if (r.kind == 0) o.v<uint32_t>(NULL_F32); else o.v<float>(r.qual);
+    o.v<int32_t>(0);  // FILTER: none
+    if (r.kind == 0) { for (int i = 0; i < 6; ++i) o.v<uint32_t>(NULL_F32); o.v<int32_t>(NULL_I32); o.v<int32_t>(NULL_I32); }
     else {
-      for (int i = 0; i < 4; ++i) putv<float>(o, r.rs[i]);
-      putv<float>(o, r.mq); putv<float>(o, r.raw_mq); putv<int32_t>(o, 0); putv<int32_t>(o, r.dp);
+      for (int i = 0; i < 4; ++i) o.v<float>(r.rs[i]);
+      o.v<float>(r.mq); o.v<float>(r.raw_mq); o.v<int32_t>(0); o.v<int32_t>(r.dp);
     }
-    putv<int32_t>(o, r.dp);  // DP_FORMAT
-    putv<int32_t>(o, r.gq);
-    if (r.kind == 0) { for (int i = 0; i < 4; ++i) putv<int32_t>(o, NULL_I32); putv<int32_t>(o, 0); putv<int32_t>(o, 3); for (int i = 0; i < 3; ++i) putv<int32_t>(o, r.pl[i]); }
+    o.v<int32_t>(r.dp);  // DP_FORMAT
+    o.v<int32_t>(r.gq);
+    if (r.kind == 0) { for (int i = 0; i < 4; ++i) o.v<int32_t>(NULL_I32); o.v<int32_t>(0); o.v<int32_t>(3); for (int i = 0; i < 3; ++i) o.v<int32_t>(r.pl[i]); }
     else {
-      for (int i = 0; i < 4; ++i) putv<int32_t>(o, r.sb[i]);
-      putv<int32_t>(o, 3); for (int i = 0; i < 3; ++i) putv<int32_t>(o, r.ad[i]);
-      putv<int32_t>(o, 6); for (int i = 0; i < 6; ++i) putv<int32_t>(o, r.pl[i]);
+      for (int i = 0; i < 4; ++i) o.v<int32_t>(r.sb[i]);
+      o.v<int32_t>(3); for (int i = 0; i < 3; ++i) o.v<int32_t>(r.ad[i]);
+      o.v<int32_t>(6); for (int i = 0; i < 6; ++i) o.v<int32_t>(r.pl[i]);
     }
-    putv<int32_t>(o, 0); putv<int32_t>(o, 0);  // PGT, PID
-    putv<int32_t>(o, r.min_dp);
-    putv<int32_t>(o, 2);
-    if (r.kind == 0) { putv<int32_t>(o, 0); putv<int32_t>(o, 0); }
-    else { putv<int32_t>(o, r.hom ? 1 : 0); putv<int32_t>(o, 1); }
-    uint64_t sz = o.size() - start;
-    memcpy(&o[start + 16], &sz, 8);
+    o.v<int32_t>(0); o.v<int32_t>(0);  // PGT, PID
+    o.v<int32_t>(r.min_dp);
+    o.v<int32_t>(2);
+    if (r.kind == 0) { o.v<int32_t>(0); o.v<int32_t>(0); }
+    else { o.v<int32_t>(r.hom ? 1 : 0); o.v<int32_t>(1); }
+    const uint64_t sz = (uint64_t)(o.p - dst);
+    memcpy(dst + 16, &sz, 8);
   }
 
-  // all cells with chunk_begin <= begin < col_end, column-major order
+  // all cells with chunk_begin <= begin < col_end, column-major order.  Every thread generates a block of consecutive samples;
+  // a counting pass over (column, thread) gives each thread the place of its cells inside every column (within a thread the
+  // cells of one column come out in ascending sample order), so generation, ordering and serialisation all run in parallel.
   void next_chunk(int64_t col_end, int nthreads) {
     if (col_end > B + L) col_end = B + L;
-    std::vector<std::vector<Rec>> per_thread((size_t)nthreads);
-    auto work = [&](int t) {
-      std::vector<Rec>& out = per_thread[(size_t)t];
+    const int64_t ncols = std::max<int64_t>(0, col_end - chunk_begin);
+    const int T = std::max(1, std::min(nthreads, (int)n_samples));
+    std::vector<std::vector<Rec>> recs((size_t)T);
+    std::vector<std::vector<uint32_t>> cnt((size_t)T), bytes((size_t)T);
+    auto gen = [&](int t) {
+      const int32_t r0 = (int32_t)((int64_t)n_samples * t / T), r1 = (int32_t)((int64_t)n_samples * (t + 1) / T);
+      std::vector<Rec>& out = recs[(size_t)t];
+      cnt[(size_t)t].assign((size_t)ncols, 0); bytes[(size_t)t].assign((size_t)ncols, 0);
       Rec r;
-      for (int32_t row = t; row < n_samples; row += nthreads)
-        while (pos[row] < col_end) { next_record(row, r); out.push_back(r); }
+      for (int32_t row = r0; row < r1; ++row)
+        while (pos[row] < col_end) {
+          next_record(row, r);
+          out.push_back(r);
+          const size_t c = (size_t)(r.begin - chunk_begin);
+          cnt[(size_t)t][c]++; bytes[(size_t)t][c] += cell_size(r);
+        }
     };
-    std::vector<std::thread> th;
-    for (int t = 0; t < nthreads; ++t) th.emplace_back(work, t);
-    for (auto& x : th) x.join();
-    std::vector<const Rec*> all;
-    size_t total = 0;
-    for (auto& v : per_thread) total += v.size();
-    all.reserve(total);
-    for (auto& v : per_thread) for (auto& r : v) all.push_back(&r);
-    std::sort(all.begin(), all.end(), [](const Rec* a, const Rec* b) { return a->begin < b->begin || (a->begin == b->begin && a->row < b->row); });
-    cells.clear();
-    cells.reserve(total * 160);
-    for (auto* r : all) write_cell(cells, *r);
-    last_ncells = (int64_t)total;
+    {
+      std::vector<std::thread> th;
+      for (int t = 0; t < T; ++t) th.emplace_back(gen, t);
+      for (auto& x : th) x.join();
+    }
+    // place of (column, thread) in the chunk: bytes[t][c] becomes the byte offset of thread t's first cell of column c
+    std::vector<uint64_t> col_base((size_t)ncols + 1, 0);
+    uint64_t at = 0; int64_t total = 0;
+    for (int64_t c = 0; c < ncols; ++c) {
+      col_base[(size_t)c] = at;
+      uint32_t within = 0;
+      for (int t = 0; t < T; ++t) { const uint32_t b = bytes[(size_t)t][(size_t)c]; bytes[(size_t)t][(size_t)c] = within; within += b; total += cnt[(size_t)t][(size_t)c]; }
+      at += within;
+    }
+    cells.resize((size_t)at);
+    uint8_t* base = cells.data();
+    auto ser = [&](int t) {
+      std::vector<uint32_t>& off = bytes[(size_t)t];
+      for (const Rec& r : recs[(size_t)t]) {
+        const size_t c = (size_t)(r.begin - chunk_begin);
+        write_cell(base + col_base[c] + off[c], r);
+        off[c] += cell_size(r);
+      }
+    };
+    {
+      std::vector<std::thread> th;
+      for (int t = 0; t < T; ++t) th.emplace_back(ser, t);
+      for (auto& x : th) x.join();
+    }
+    last_ncells = total;
     chunk_begin = col_end;
   }
 };

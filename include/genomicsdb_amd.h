@@ -27,8 +27,9 @@ int gdb_mi355_device_count(void);
 
 /* ---- (1) query stream ------------------------------------------------------------------------------------ */
 /* jniGenomicsDBInit: returns a handle or NULL.  chr == "" keeps the intervals of the query JSON; otherwise the
- * interval is contig offset + start-1 .. end-1 (1-based, inclusive).  is_bcf != 0 asks for BCF2 ("bu"), which this
- * build does not produce yet (returns NULL with an error); text VCF otherwise.  buffer_capacity is what
+ * interval is contig offset + start-1 .. end-1 (1-based, inclusive).  is_bcf != 0: uncompressed BCF2 ("bu": "BCF\2\2" header,
+ * typed records - what GATK4's BCF2Codec reads; vcf_adapter.cc:475-509), with the two htsjdk switches of the JNI
+ * (use_missing_values_only_not_vector_end, keep_idx_fields_in_bcf_header); text VCF otherwise.  buffer_capacity is what
  * get_num_bytes_available reports (the reference's RWBuffer size); it does not size the device pages. */
 void* gdb_mi355_init(const char* loader_json_file, const char* query_json_file, const char* chr, int start, int end, int rank,
                      uint64_t buffer_capacity, uint64_t segment_size, int is_bcf, int produce_header_only,
@@ -36,6 +37,8 @@ void* gdb_mi355_init(const char* loader_json_file, const char* query_json_file, 
 /* same stream, configuration and cells handed over in memory (tests, embedding) */
 void* gdb_mi355_init_from_memory(const char* query_json_text, const uint8_t* cells, uint64_t cells_nbytes, uint64_t buffer_capacity,
                                  int produce_header_only);
+void* gdb_mi355_init_from_memory_format(const char* query_json_text, const uint8_t* cells, uint64_t cells_nbytes, uint64_t buffer_capacity,
+                                        int produce_header_only, int is_bcf, int use_missing_values_only_not_vector_end, int keep_idx_fields_in_bcf_header);
 uint64_t gdb_mi355_close(void* handle);                         /* jniGenomicsDBClose */
 uint64_t gdb_mi355_get_num_bytes_available(void* handle);       /* jniGenomicsDBGetNumBytesAvailable: buffer capacity */
 int gdb_mi355_read_next_byte(void* handle);                     /* jniGenomicsDBReadNextByte: byte or -1 */
@@ -71,6 +74,7 @@ typedef struct gdbamd_interval_stats {
 typedef struct gdbamd_device_column { const void* data; const uint32_t* off; } gdbamd_device_column;
 
 void* gdbamd_engine_create(const char* query_json_text, int device);          /* NULL on error */
+void* gdbamd_engine_create_format(const char* query_json_text, int device, int is_bcf, int use_missing_values_only_not_vector_end);  /* pages hold BCF2 records */
 void gdbamd_engine_destroy(void* engine);
 int gdbamd_engine_num_fields(void* engine);                                     /* plan fields = staged attribute columns */
 const char* gdbamd_engine_field_name(void* engine, int f);                      /* array attribute name of plan field f */

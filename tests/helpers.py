@@ -156,3 +156,15 @@ def synth_query(tmpdir, n_samples, begin, end):
         "attributes": VCF_ATTRIBUTES_ORDER,
         "query_column_ranges": [[[begin, end]]],
     }
+
+
+def format_float(v):
+    """float -> text as the goldens pin it (the oracle's format_float; used by the BCF2 decoder of the tests)"""
+    buf = ctypes.create_string_buffer(64)
+    oracle_lib().oracle_format_float(ctypes.c_float(v), buf, 64)
+    return buf.value.decode()
+
+
+def bcf_stream_to_text(data):
+    import bcf2text
+    return bcf2text.stream_to_vcf_text(data, format_float)

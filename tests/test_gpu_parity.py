@@ -52,18 +52,22 @@ def test_stream_small_pages(gdb, case, monkeypatch):
 
 
 def test_unsupported_configurations_fail_loudly(gdb, tmp_path):
-    """BCF output and allele-specific annotation fields are not produced by this build: errors, never silent fallbacks"""
+    """allele-specific annotation fields and compressed BCF are not produced by this build: errors, never silent fallbacks"""
     q, _ = helpers.query_json("t0_1_2_all_asa.json", "vid_all_asa.json", {}, "load")
     with pytest.raises(gdb.GenomicsDBException):
         gdb.CombineEngine(q)
-    from genomicsdb_amd import _lib
-    import json as _json
     case = CASES[0]
     qj, _ = helpers.query_json(case[1], case[2], case[3], case[5])
+    qj["vcf_output_format"] = "b"     # BGZF-compressed BCF: only "" (text) and "bu" are streamed
+    import subprocess, os, json as _json
     qf = tmp_path / "q.json"
+    (tmp_path / "ws" / "a").mkdir(parents=True)
+    (tmp_path / "ws" / "a" / "cells.bin").write_bytes(helpers.cells_for(case[1], case[2]))
+    qj["workspace"], qj["array"] = str(tmp_path / "ws"), "a"
     qf.write_text(_json.dumps(qj))
-    h = _lib.lib().gdb_mi355_init(b"", str(qf).encode(), b"", 0, 0, 0, 1 << 20, 1 << 20, 1, 0, 0, 1)   # is_bcf = 1
-    assert not h and b"bu" in _lib.lib().gdb_mi355_last_error()
+    tool = os.path.join(helpers.ROOT, "genomicsdb_amd", "gt_mpi_gather")
+    r = subprocess.run([tool, "-j", str(qf), "--produce-Broad-GVCF"], capture_output=True, timeout=120)
+    assert r.returncode != 0 and b"output format" in r.stderr
 
 
 def test_engine_stats_and_header(gdb):
@@ -833,3 +837,100 @@ def test_jni_natives_driven_like_the_jvm_would(gdb, tmp_path):
     assert got is not None and got[:hdr_len] == want[:hdr_len] and got[hdr_len:] and got[hdr_len:] in want
     got, e = run(b"no_such_contig", 1, 10, 4096, 0)
     assert got is None and "contig" in e
+    # is_bcf = true, what GATK4's GenomicsDBFeatureReader asks for with BCF2Codec
+    out, n = ctypes.c_void_p(), ctypes.c_uint64()
+    err = ctypes.create_string_buffer(2048)
+    assert H.jni_harness_read_stream(b"", str(qf).encode(), b"", 0, 0, 1, 3000, 0, ctypes.byref(out), ctypes.byref(n), err, 2048) == 0, err.value
+    bcf = ctypes.string_at(out.value, n.value)
+    H.jni_harness_free(out)
+    assert bcf[:5] == b"BCF\x02\x02" and helpers.bcf_stream_to_text(bcf) == want
+
+
+# ---- BCF2 ("bu"), what GATK4's GenomicsDBFeatureReader decodes with BCF2Codec -----------------------------------------------
+@pytest.mark.parametrize("case", SUPPORTED, ids=[c[0] for c in SUPPORTED])
+def test_bcf_stream_decodes_to_the_golden_text(gdb, case, monkeypatch):
+    """output format "bu": the stream is 'BCF\\2\\2' + header + typed records; decoded by the tests' own BCF2 reader and printed
+    the way htslib prints a record (tests/tools/bcf2text.py) it must be the reference's TEXT golden, header included - with and
+    without IDX keys in the header, in one page and in pages of a few records"""
+    name, callsets, vid, ov, golden, mode = case
+    cells = helpers.cells_for(callsets, vid)
+    q, pb = helpers.query_json(callsets, vid, ov, mode)
+    want = helpers.golden_text(golden)
+    s = gdb.GenomicsDBQueryStream(query_json=q, cells=cells, buffer_capacity=1 << 20, is_bcf=True)
+    one_page = s.read()
+    s.close()
+    assert one_page[:5] == b"BCF\x02\x02"
+    assert helpers.bcf_stream_to_text(one_page) == want
+    assert b",IDX=" in one_page
+    s = gdb.GenomicsDBQueryStream(query_json=q, cells=cells, buffer_capacity=1 << 20, is_bcf=True, keep_idx_fields_in_bcf_header=False)
+    no_idx = s.read()
+    s.close()
+    assert b",IDX=" not in no_idx and helpers.bcf_stream_to_text(no_idx) == want
+    monkeypatch.setenv("GDBAMD_DEVICE_PAGE_BYTES", "700")
+    s = gdb.GenomicsDBQueryStream(query_json=q, cells=cells, buffer_capacity=1 << 20, is_bcf=True)
+    paged = s.read()
+    s.close()
+    assert paged == one_page
+
+
+def test_bcf_htsjdk_flag_uses_missing_values_only(gdb):
+    """use_missing_values_only_not_vector_end (the JNI flag for htsjdk, which has no vector-end values): no vector-end code
+    anywhere in the FORMAT blocks, absent GT = no-call alleles; the records still decode"""
+    import bcf2text
+    case = [c for c in CASES if c[0] == "t0_haploid_triploid_1_2_3_triploid_deletion_vcf"][0]
+    name, callsets, vid, ov, golden, mode = case
+    cells = helpers.cells_for(callsets, vid)
+    q, pb = helpers.query_json(callsets, vid, ov, mode)
+    s = gdb.GenomicsDBQueryStream(query_json=q, cells=cells, buffer_capacity=1 << 20, is_bcf=True, use_missing_values_only_not_vector_end=True)
+    data = s.read()
+    s.close()
+    hdr, recs = bcf2text.parse_stream(data)
+    assert recs
+    text = helpers.bcf_stream_to_text(data).decode()
+    body = [l for l in text.split("\n") if l and not l.startswith("#")]
+    want = [l for l in helpers.golden_text(golden).decode().split("\n") if l and not l.startswith("#")]
+    assert len(body) == len(want)
+    for got_line, want_line in zip(body, want):
+        g, w = got_line.split("\t"), want_line.split("\t")
+        assert g[:9] == w[:9]
+        for gs, ws in zip(g[9:], w[9:]):       # same values; shorter vectors are padded with '.' instead of being cut
+            for gf, wf in zip(gs.split(":"), ws.split(":")):
+                gf = gf.replace("-65", ".")      # a GT padded with the int8 MISSING code, as htslib's bcf_format_gt prints it ((-128 >> 1) - 1)
+                gv, wv = gf.replace("/", ",").replace("|", ",").split(","), wf.replace("/", ",").replace("|", ",").split(",")
+                assert gv[:len(wv)] == wv or wv == ["."], (gf, wf)
+                assert all(x == "." for x in gv[len(wv):]), (gf, wf, got_line[:120])
+
+
+def test_bcf_synthetic_widths_and_text_agree(gdb, tmp_path):
+    """300 synthetic samples x 5 kb: int8 / int16 / int32 FORMAT vectors chosen per record like htslib's bcf_enc_vint, PL
+    vectors of every merged-allele count; the decoded BCF stream equals the text stream of the same engine (which equals the
+    oracle, test_synthetic_matches_oracle)"""
+    import bcf2text
+    import struct
+    from genomicsdb_amd import synth
+    N, B, L = 300, 10_000_000, 5000
+    cells, _ = _synth_cells(N, B, L)
+    q = helpers.synth_query(tmp_path, N, B + 300, B + L - 400)
+    ref = synth.reference(B, L + 16)
+    et = gdb.CombineEngine(q)
+    et.stage_cells(cells)
+    et.set_reference(B, ref)
+    text_body, st = et.run_interval(B + 300, B + L - 400, arena_bytes=1 << 30)
+    hdr_text = et.header
+    et.close()
+    eb = gdb.CombineEngine(q, is_bcf=True)
+    eb.stage_cells(cells)
+    eb.set_reference(B, ref)
+    bcf_body, sb = eb.run_interval(B + 300, B + L - 400, arena_bytes=1 << 30)
+    bcf_paged, sp = eb.run_interval(B + 300, B + L - 400, arena_bytes=1 << 20)
+    eb.close()
+    assert sb.num_records == st.num_records and sp.pages > 3 and bcf_paged == bcf_body
+    h = bcf2text.Header(hdr_text.decode())
+    at, lines, types_seen = 0, [], set()
+    while at < len(bcf_body):
+        l_shared, l_indiv = struct.unpack_from("<II", bcf_body, at)
+        rec = bcf_body[at:at + 8 + l_shared + l_indiv]
+        lines.append(bcf2text.record_to_text(h, rec, helpers.format_float))
+        at += len(rec)
+    assert ("\n".join(lines) + "\n").encode() == text_body
+    assert len(bcf_body) < len(text_body)
