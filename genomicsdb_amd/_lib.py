@@ -15,7 +15,8 @@ class IntervalStats(ctypes.Structure):
                 ("ms_size", ctypes.c_float), ("ms_write", ctypes.c_float), ("ms_total", ctypes.c_float),
                 ("ms_write_kernel_avg", ctypes.c_float),
                 ("num_record_types", ctypes.c_int32), ("reserved0", ctypes.c_int32),
-                ("num_text_slots", ctypes.c_int64), ("text_pool_bytes", ctypes.c_int64)]
+                ("num_text_slots", ctypes.c_int64), ("text_pool_bytes", ctypes.c_int64),
+                ("num_remap_elements", ctypes.c_uint64)]
 
 
 class StreamStats(ctypes.Structure):

@@ -187,6 +187,7 @@ int gdbamd_engine_run_interval(void* e, int64_t qb, int64_t qe, uint64_t arena_b
       out->ms_write_kernel_avg = s.ms_write_kernel_avg;
       out->num_record_types = s.num_record_types; out->reserved0 = 0;
       out->num_text_slots = s.num_text_slots; out->text_pool_bytes = s.text_pool_bytes;
+      out->num_remap_elements = s.num_remap_elements;
     }
     return 0;
   }, 1);

@@ -37,6 +37,7 @@ struct IntervalStats {
   int num_record_types = 0;       // distinct (FORMAT mask, #merged alleles, remap flags)
   int64_t num_text_slots = 0;     // (cell, type) + (record, variant call) + no-call texts
   int64_t text_pool_bytes = 0;
+  uint64_t num_remap_elements = 0; // sum over re-indexed records of (calls with PL) x (merged genotypes)
 };
 
 // what the engine needs to know about a staged fragment besides the columns

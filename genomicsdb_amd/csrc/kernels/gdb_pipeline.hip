@@ -367,6 +367,278 @@ __global__ void __launch_bounds__(kBlock) k_big_medians(FragmentView fr, Combine
   }
 }
 
+// ---- records with very many variant calls: one WORKGROUP per record does everything that walks the calls ----------------------
+// One thread walking the ~10 000 calls of a hot site is a chain of dependent loads, ~14 us per call (BASELINE configs[4]: 142 of
+// 146 ms of an interval).  Here lane = call: the ALT alleles of all calls go through an LDS hash table keyed by the allele hash,
+// every entry keeps the smallest (call, token) position it was seen at, and the merged list is the entries in that order - the
+// first-appearance order of the reference's merge_alt_alleles (variant_operations.cc:134-228); a second pass looks every
+// candidate up, writes the input -> merged LUTs (strings compared against the entry's representative: a true hash collision
+// sends the record back to the serial walk) and the flags / min-PL genotypes.  Scalar INFO reducers: counts and integer sums by
+// reduction, float sums in call order by one thread out of LDS-staged chunks (float addition is not associative), medians by a
+// 4-pass radix select over the order-preserving keys; FILTER union by reduction.  site_emit then only formats (HugeSites).
+constexpr int kHugeRecord = 256;          // variant calls from which a record counts as huge
+constexpr int kMaxHugeRecords = 8192;
+constexpr int kHugeTable = 512;           // LDS hash table slots (at most 127 distinct alleles per record)
+constexpr uint32_t kHugeEmpty = 0xFFFFFFFFu;
+__global__ void k_huge_records(const int64_t* hbase, int64_t P, int32_t* huge_index, int32_t* huge_list, int32_t* counter) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= P) return;
+  const int64_t n = hbase[k + 1] - hbase[k];
+  int32_t idx = -1;
+  if (n > kHugeRecord) { idx = atomicAdd(counter, 1); if (idx < kMaxHugeRecords) huge_list[idx] = (int32_t)k; else idx = -1; }
+  huge_index[k] = idx;
+}
+struct HugeTable { uint32_t* hash; uint32_t* order; int16_t* midx; int32_t* overflow; };
+__device__ __forceinline__ uint32_t huge_fix_hash(uint32_t h) { return h == kHugeEmpty ? 0xFFFFFFFEu : h; }
+struct HugeInsert {          // pass A: note every candidate allele with the position it appears at
+  HugeTable tb; uint32_t order_base; uint32_t i;
+  __device__ int operator()(const AlleleRef& cand) {
+    const uint32_t h = huge_fix_hash(cand.hash);
+    uint32_t s = h & (kHugeTable - 1);
+    for (int probe = 0; probe < kHugeTable; ++probe, s = (s + 1) & (kHugeTable - 1)) {
+      uint32_t cur = tb.hash[s];
+      if (cur == kHugeEmpty) cur = atomicCAS(&tb.hash[s], kHugeEmpty, h);
+      if (cur == kHugeEmpty || cur == h) { atomicMin(&tb.order[s], order_base + i); ++i; return 0; }
+    }
+    *tb.overflow = 1;
+    ++i;
+    return 0;
+  }
+};
+struct HugePick {            // the i-th candidate of a call (the representative of a table entry)
+  uint32_t want, i; AlleleRef out; bool found;
+  __device__ int operator()(const AlleleRef& cand) { if (i == want) { out = cand; found = true; } ++i; return 0; }
+};
+struct HugeLookup {          // pass C: merged index of every candidate
+  HugeTable tb; const AlleleRef* merged; const char* mref; int mref_len; int32_t* fallback;
+  __device__ int operator()(const AlleleRef& cand) {
+    const uint32_t h = huge_fix_hash(cand.hash);
+    uint32_t s = h & (kHugeTable - 1);
+    for (int probe = 0; probe < kHugeTable; ++probe, s = (s + 1) & (kHugeTable - 1)) {
+      if (tb.hash[s] == h) {
+        const int m = tb.midx[s];
+        if (m < 1 || !allele_equal(merged[m], cand, mref, mref_len)) { *fallback = 1; return 1; }   // two alleles, one hash: serial walk
+        return m;
+      }
+      if (tb.hash[s] == kHugeEmpty) break;
+    }
+    *fallback = 1;
+    return 1;
+  }
+};
+__global__ void __launch_bounds__(kBlock) k_site_huge(const SiteCtx* __restrict__ sxp, const int32_t* __restrict__ huge_list, const int32_t* __restrict__ counter,
+                                                      HugeSiteOut* __restrict__ out, uint32_t* err) {
+  const SiteCtx& cx = *sxp;
+  const CombinePlan& pl = cx.pl;
+  __shared__ uint32_t tab_hash[kHugeTable], tab_order[kHugeTable];
+  __shared__ int16_t tab_midx[kHugeTable];
+  __shared__ unsigned long long s_key, s_cnt[4], s_filter;
+  __shared__ int32_t s_flags[4];              // [0] table overflow, [1] fallback, [2] filter multi, [3] any id
+  __shared__ int32_t s_nocc, s_isum;
+  __shared__ const char* s_mref;
+  __shared__ int32_t s_mref_len;
+  __shared__ uint32_t s_hist[256], s_prefix, s_mask, s_first_t;
+  __shared__ long long s_rank;
+  __shared__ uint32_t s_stage[2048];
+  const int tid = threadIdx.x;
+  const int count = min(*counter, kMaxHugeRecords);
+  uint32_t e = 0;
+  for (int bi = blockIdx.x; bi < count; bi += gridDim.x) {      // uniform
+    const int64_t k = huge_list[bi];
+    const int64_t hb = cx.hl.base[k], he = cx.hl.base[k + 1];
+    const int64_t s_k = cx.rec.start[k];
+    HugeSiteOut& o = out[bi];
+    // ---- merged REF: longest REF among the calls starting here, the first one at equal length ---------------------------------
+    if (tid == 0) {
+      int len0 = 0;
+      s_mref = site_first_ref(cx, s_k, len0);
+      s_mref_len = len0;
+      s_key = ((unsigned long long)(uint32_t)len0 << 32) | 0xFFFFFFFFull;
+      s_flags[0] = s_flags[1] = s_flags[2] = s_flags[3] = 0;
+      s_nocc = 0;
+      s_filter = ~0ull;
+    }
+    for (int s = tid; s < kHugeTable; s += kBlock) { tab_hash[s] = kHugeEmpty; tab_order[s] = 0xFFFFFFFFu; tab_midx[s] = 0; }
+    __syncthreads();
+    for (int64_t t = hb + tid; t < he; t += kBlock) {
+      const int64_t c = cx.hl.cell[t];
+      if (cx.fr.begin[c] != s_k || !field_valid(cx.cm, c, pl.f_REF)) continue;
+      int n;
+      cell_field<char>(cx.fr, pl, pl.f_REF, c, n);
+      atomicMax(&s_key, ((unsigned long long)(uint32_t)n << 32) | (unsigned long long)(0xFFFFFFFEu - (uint32_t)(t - hb)));
+    }
+    __syncthreads();
+    if (tid == 0 && (uint32_t)s_key != 0xFFFFFFFFu) {
+      const int64_t t = hb + (int64_t)(0xFFFFFFFEu - (uint32_t)s_key);
+      int n;
+      s_mref = cell_field<char>(cx.fr, pl, pl.f_REF, cx.hl.cell[t], n);
+      s_mref_len = n;
+    }
+    __syncthreads();
+    const char* mref = s_mref;
+    const int mref_len = s_mref_len;
+    HugeTable tb{tab_hash, tab_order, tab_midx, &s_flags[0]};
+    // ---- pass A: candidates -> table ---------------------------------------------------------------------------------------------
+    for (int64_t t = hb + tid; t < he; t += kBlock) {
+      HugeInsert fa{tb, (uint32_t)(t - hb) << 6, 0u};
+      site_merge_call(cx, t, s_k, mref, mref_len, false, fa, &e);
+      if (fa.i > 63u) s_flags[1] = 1;                          // more tokens than the position key holds: serial walk
+    }
+    __syncthreads();
+    // ---- merged order = ascending first position; representatives -----------------------------------------------------------------
+    for (int s = tid; s < kHugeTable; s += kBlock) {
+      if (tab_hash[s] == kHugeEmpty) continue;
+      const uint32_t mine = tab_order[s];
+      int rank = 0;
+      for (int s2 = 0; s2 < kHugeTable; ++s2) rank += (tab_hash[s2] != kHugeEmpty && tab_order[s2] < mine) ? 1 : 0;
+      atomicAdd(&s_nocc, 1);
+      if (rank + 1 >= GDB_MAX_MERGED_ALLELES - 1) { e |= GDB_ERR_TOO_MANY_MERGED_ALLELES; tab_midx[s] = 1; continue; }
+      tab_midx[s] = (int16_t)(rank + 1);
+      HugePick pk{mine & 63u, 0u, AlleleRef{nullptr, 0, -1, 0u}, false};
+      uint32_t e2 = 0;
+      site_merge_call(cx, hb + (int64_t)(mine >> 6), s_k, mref, mref_len, false, pk, &e2);
+      if (pk.found) o.merged[rank + 1] = pk.out; else s_flags[1] = 1;
+    }
+    __syncthreads();
+    const int nmerged = min(1 + s_nocc, GDB_MAX_MERGED_ALLELES - 1);
+    const int num_merged = nmerged + (cx.pc.nr_cnt[k] > 0 ? 1 : 0);
+    // ---- pass C: LUTs, flags, min-PL genotypes; <NON_REF> last -----------------------------------------------------------------------
+    for (int64_t t = hb + tid; t < he; t += kBlock) {
+      HugeLookup fc{tb, o.merged, mref, mref_len, &s_flags[1]};
+      site_merge_call(cx, t, s_k, mref, mref_len, true, fc, &e);
+      const int64_t c = cx.hl.cell[t];
+      const uint32_t cf = cx.cm.cflags[c];
+      if (cx.pc.nr_cnt[k] > 0 && (cf & GDB_CF_HAS_NR)) {
+        int alt_len;
+        const char* alt = cell_field<char>(cx.fr, pl, pl.f_ALT, c, alt_len);
+        const char* tok; int tl;
+        for (int i = 0; alt_token(alt, alt_len, i, tok, tl); ++i)
+          if (tl > 0 && tok[0] == '&' && i + 1 <= (int)GDB_CF_NALT(cf)) cx.hl.i2m[cx.hl.i2m_off[t] + i + 1] = (int8_t)(num_merged - 1);
+      }
+    }
+    // ---- FILTER union, ID presence ----------------------------------------------------------------------------------------------------
+    const bool do_filter = pl.produce_FILTER_field && pl.f_FILTER >= 0;
+    if (do_filter || pl.f_ID >= 0)
+      for (int64_t t = hb + tid; t < he; t += kBlock) {
+        const int64_t c = cx.hl.cell[t];
+        if (pl.f_ID >= 0 && field_valid(cx.cm, c, pl.f_ID)) s_flags[3] = 1;
+        if (do_filter && field_valid(cx.cm, c, pl.f_FILTER)) {
+          int n;
+          const int32_t* p = cell_field<int32_t>(cx.fr, pl, pl.f_FILTER, c, n);
+          if (n > 0) atomicMin(&s_filter, ((unsigned long long)(uint32_t)(t - hb) << 32) | (unsigned long long)(uint32_t)p[0]);
+        }
+      }
+    __syncthreads();
+    if (do_filter && s_filter != ~0ull) {
+      const int32_t first_id = (int32_t)(uint32_t)s_filter;
+      for (int64_t t = hb + tid; t < he; t += kBlock) {
+        const int64_t c = cx.hl.cell[t];
+        if (!field_valid(cx.cm, c, pl.f_FILTER)) continue;
+        int n;
+        const int32_t* p = cell_field<int32_t>(cx.fr, pl, pl.f_FILTER, c, n);
+        for (int i = 0; i < n; ++i) if (p[i] != first_id) s_flags[2] = 1;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      o.mref = mref; o.mref_len = mref_len; o.nmerged = nmerged;
+      o.filter_first_id = (do_filter && s_filter != ~0ull) ? (int32_t)(uint32_t)s_filter : -1;
+      o.filter_multi = s_flags[2]; o.any_id = s_flags[3];
+      o.fallback = (s_flags[0] || s_flags[1]) ? 1 : 0;
+    }
+    // ---- scalar reducers over the gathered per-call values (ScalarPre) ---------------------------------------------------------------
+    if (cx.pre.enabled)
+      for (int f = 0; f < pl.nfields; ++f) {                    // uniform
+        const int slot = cx.pre.slot[f];
+        if (slot < 0) continue;
+        const bool is_float = pl.field[f].elem == GDB_ET_FLOAT;
+        const int op = (f == pl.f_QUAL) ? pl.qual_combine_op : pl.field[f].combine_op;
+        const uint32_t missing = is_float ? GDB_BCF_FLOAT_MISSING_BITS : (uint32_t)GDB_BCF_INT32_MISSING;
+        const uint32_t* val = cx.pre.val + (int64_t)slot * cx.pre.stride;
+        if (tid < 4) s_cnt[tid] = 0;
+        if (tid == 0) { s_isum = 0; s_first_t = 0xFFFFFFFFu; }
+        __syncthreads();
+        unsigned long long nvalid = 0, nbelow = 0, nneg0 = 0, npos0 = 0;
+        int32_t isum = 0;
+        for (int64_t t = hb + tid; t < he; t += kBlock) {
+          const uint32_t u = val[t];
+          if (u == missing) continue;
+          ++nvalid;
+          if (is_float) { nneg0 += u == 0x80000000u; npos0 += u == 0u; nbelow += __uint_as_float(u) < 0.0f; }
+          else isum += (int32_t)u;
+        }
+        if (nvalid) atomicAdd(&s_cnt[0], nvalid);
+        if (nbelow) atomicAdd(&s_cnt[1], nbelow);
+        if (nneg0) atomicAdd(&s_cnt[2], nneg0);
+        if (npos0) atomicAdd(&s_cnt[3], npos0);
+        if (isum) atomicAdd(&s_isum, isum);
+        __syncthreads();
+        const long long total_valid = (long long)s_cnt[0];
+        uint32_t sum_bits = (uint32_t)s_isum;
+        if (is_float && (op == GDB_OP_SUM || op == GDB_OP_MEAN)) {
+          // float sum in call order: chunks staged in LDS by everybody, added up by one thread
+          float fsum = 0.0f;
+          for (int64_t t0 = hb; t0 < he; t0 += 2048) {             // uniform
+            const int64_t m = min((int64_t)2048, he - t0);
+            for (int64_t j = tid; j < m; j += kBlock) s_stage[j] = val[t0 + j];
+            __syncthreads();
+            if (tid == 0) for (int64_t j = 0; j < m; ++j) { const uint32_t u = s_stage[j]; if (u != missing) fsum += __uint_as_float(u); }
+            __syncthreads();
+          }
+          sum_bits = __float_as_uint(fsum);
+        }
+        uint32_t median_bits = 0;
+        int32_t median_ok = 0;
+        if (op == GDB_OP_MEDIAN && total_valid > 0) {
+          // radix select of the element of rank total_valid / 2 (std::nth_element at the mid point), 8 bits per pass
+          if (tid == 0) { s_prefix = 0; s_mask = 0; s_rank = total_valid / 2; }
+          __syncthreads();
+          for (int pass = 0; pass < 4; ++pass) {                  // uniform
+            const int shift = 24 - 8 * pass;
+            s_hist[tid] = 0;                                       // (kBlock == 256)
+            __syncthreads();
+            const uint32_t prefix = s_prefix, mask = s_mask;
+            for (int64_t t = hb + tid; t < he; t += kBlock) {
+              const uint32_t u = val[t];
+              if (u == missing) continue;
+              const uint32_t key = is_float ? gdb_orderable_bits(__uint_as_float(u)) : gdb_orderable_bits((int32_t)u);
+              if ((key & mask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+              long long r = s_rank;
+              uint32_t b = 0;
+              for (; b < 255u && r >= (long long)s_hist[b]; ++b) r -= s_hist[b];
+              s_rank = r; s_prefix = prefix | (b << shift); s_mask = mask | (255u << shift);
+            }
+            __syncthreads();
+          }
+          const uint32_t want = s_prefix;
+          for (int64_t t = hb + tid; t < he; t += kBlock) {       // among equal values the first call supplies the bits
+            const uint32_t u = val[t];
+            if (u == missing) continue;
+            const uint32_t key = is_float ? gdb_orderable_bits(__uint_as_float(u)) : gdb_orderable_bits((int32_t)u);
+            if (key == want) atomicMin(&s_first_t, (uint32_t)(t - hb));
+          }
+          __syncthreads();
+          if (s_first_t != 0xFFFFFFFFu) {
+            median_bits = val[hb + s_first_t];
+            const bool zero = is_float && (median_bits << 1) == 0u;
+            median_ok = (zero && s_cnt[2] && s_cnt[3]) ? 2 : 1;   // zeros of both signs: the reference's nth_element decides (reduce_scalar)
+          }
+        }
+        if (tid == 0) {
+          HugeScalar& hv = o.scalar[slot];
+          hv.nvalid = total_valid; hv.nbelow = (long long)s_cnt[1]; hv.nneg0 = (long long)s_cnt[2]; hv.npos0 = (long long)s_cnt[3];
+          hv.sum_bits = sum_bits; hv.median_bits = median_bits; hv.median_ok = median_ok; hv.pad = 0;
+        }
+        __syncthreads();
+      }
+    __syncthreads();
+  }
+  if (e) atomicOr(err, e);
+}
+
 // ---- site kernels: one thread per record -----------------------------------------------------------------------
 // Pass 0 runs the record logic ONCE: allele merge, LUTs, per-record flags - and the text of the fixed columns, formatted
 // through a capped LDS sink into a lane-private strip and parked in a fixed-stride staging slot.  The page pass then only
@@ -998,6 +1270,208 @@ k_assemble_write(const char* __restrict__ pool, const char* __restrict__ pool_ov
   }
 }
 
+// ---- page assembly from a sparse change list instead of the dense (record, sample) matrix ----------------------------------------
+// Along a run of same-type records a sample keeps its slot until its live cell changes: ~2 of the 64 lanes of a chunk per record.
+// The sizing pass therefore leaves, per (run, chunk), the first record's row (64 x (off16, len)) and then only the CHANGES
+// (step, lane, off16, len), 8 bytes each - a twelfth of the matrix traffic on c2.  More important is what the page pass does
+// with them: the change list is wave-uniform data, so it and the texts of the changed lanes are fetched with SCALAR loads
+// (s_load, counted by lgkmcnt) and moved into the lanes' registers with v_writelane.  The steady-state loop then has no vector
+// load left: gfx9 has one in-order vmcnt for loads and stores, and every vector load in the loop made the wavefront wait for
+// the acknowledgement of the previous record's page stores (~75 % of its cycles); now the stores stream.
+struct EventBuf {
+  uint2* init;       // [blocks * 64]        row of the first record of every (run, chunk)
+  uint2* ev;         // [blocks * run * 64]  changes: x = off16 (overflow bit included), y = len (20 bits) | lane << 20 | step << 26
+  uint32_t* count;   // [blocks]
+  int32_t run;
+};
+constexpr uint32_t kEvLenBits = 20, kEvLenMask = (1u << kEvLenBits) - 1u;
+
+__global__ void __launch_bounds__(kAsmRows)
+k_assemble_size_ev(AsmCtx a, const int32_t* __restrict__ order, int64_t n, int32_t N, int nchunks, int run, uint64_t* __restrict__ chunk_size, EventBuf eb, uint32_t* err) {
+  const int64_t ib = (int64_t)(blockIdx.x / (unsigned)nchunks) * run;      // (run <= 64: one batch of per-lane record scalars)
+  const int64_t ie = min(n, ib + (int64_t)run);
+  const int ch = (int)(blockIdx.x % (unsigned)nchunks);
+  const int lane = threadIdx.x;
+  const int32_t r = ch * kAsmRows + lane;
+  const int64_t b = blockIdx.x;
+  uint2* __restrict__ my_ev = eb.ev + b * (int64_t)run * kAsmRows;
+  uint32_t nev = 0;
+  SlotWalker w;
+  int64_t prev_k = INT64_MAX;
+  uint32_t cur_slot = kNoSlot;
+  uint2 cur = make_uint2(0, 0);
+  const int cnt = (int)(ie - ib);
+  int32_t my_k = 0; int64_t my_s = 0; uint32_t my_t = 0; uint64_t my_total = 0;
+  if (lane < cnt) {
+    my_k = order[ib + lane];
+    my_s = a.rec_start[my_k];
+    my_t = a.rtype[my_k];
+    if (ch == 0) my_total = a.prefix_len[my_k];
+    if (ch == nchunks - 1) my_total += 1;                 // '\n'
+  }
+  for (int jj = 0; jj < cnt; ++jj) {                      // uniform
+    const int64_t k = __builtin_amdgcn_readlane(my_k, jj);
+    const int64_t s = readlane64(my_s, jj);
+    const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)my_t, jj);
+    uint2 d = make_uint2(0, 0);
+    bool changed = false;
+    if (r < N) {
+      if (k < prev_k) w.init(a, r, s); else w.advance(a, s);  // uniform branch: a new type restarts at its first record
+      const uint32_t sl = w.slot(a, k, s, t, r);
+      if (sl != cur_slot) { cur_slot = sl; const uint2 nd = a.desc[sl]; changed = nd.x != cur.x || nd.y != cur.y; cur = nd; }
+      d = cur;
+    }
+    prev_k = k;
+    if (jj == 0) eb.init[b * kAsmRows + lane] = d;
+    else {
+      const uint64_t m = __ballot(changed);
+      if (m) {
+        if (changed) {
+          const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+          my_ev[nev + rank] = make_uint2(d.x, (d.y & kEvLenMask) | ((uint32_t)lane << kEvLenBits) | ((uint32_t)jj << 26));
+          if (d.y > kEvLenMask) atomicOr(err, (uint32_t)GDB_ERR_INTERNAL);
+        }
+        nev += (uint32_t)__popcll(m);
+      }
+    }
+    const uint32_t total = wave_total(wave_inclusive_scan_dpp(d.y));
+    if (lane == jj) my_total += total;
+  }
+  if (lane < cnt) chunk_size[(int64_t)my_k * nchunks + ch] = my_total;
+  if (lane == 0) eb.count[b] = nev;
+}
+
+// scalar memory reads the compiler does not know about: the values are tied to the wait that makes them valid
+__device__ __forceinline__ u32x4 sload_x4(const void* p) { u32x4 v; asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(v) : "s"(p) : "memory"); return v; }
+__device__ __forceinline__ uint64_t sload_x2(const void* p) { uint64_t v; asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(v) : "s"(p) : "memory"); return v; }
+__device__ __forceinline__ void swait(uint64_t& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a) : : "memory"); }
+__device__ __forceinline__ void swait(u32x4& a, u32x4& b, u32x4& c, u32x4& d, u32x4& e) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c), "+s"(d), "+s"(e) : : "memory"); }
+// v_writelane with an SGPR value takes its lane select from M0 (one scalar operand per VALU instruction on gfx9)
+__device__ __forceinline__ uint32_t wlane(uint32_t sval, uint32_t l, uint32_t old) {
+  asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(sval), "s"(l) : "m0");
+  return old;
+}
+__device__ __forceinline__ void wlane4(uint4& dst, const u32x4& sv, uint32_t l) {
+  asm volatile("s_mov_b32 m0, %8\n\tv_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0\n\tv_writelane_b32 %2, %6, m0\n\tv_writelane_b32 %3, %7, m0"
+               : "+v"(dst.x), "+v"(dst.y), "+v"(dst.z), "+v"(dst.w) : "s"(sv.x), "s"(sv.y), "s"(sv.z), "s"(sv.w), "s"(l) : "m0");
+}
+
+__global__ void __launch_bounds__(kAsmRows)
+k_assemble_write_ev(const char* __restrict__ pool, const char* __restrict__ pool_ovf, const uint32_t* __restrict__ prefix_len, EventBuf eb, int64_t b0,
+                    const int32_t* __restrict__ order, int64_t n, int nchunks, int run, const uint64_t* __restrict__ chunk_off, uint64_t page_base, char* __restrict__ arena) {
+  const int64_t ib = (int64_t)(blockIdx.x / (unsigned)nchunks) * run;
+  const int64_t ie = min(n, ib + (int64_t)run);
+  const int ch = (int)(blockIdx.x % (unsigned)nchunks);
+  const int lane = threadIdx.x;
+  const int64_t b = b0 + blockIdx.x;
+  __shared__ __attribute__((aligned(16))) char lds_buf[kWaveLds + 16];
+  const int cnt = (int)(ie - ib);
+  int32_t my_k = 0; int64_t my_dst = 0;
+  if (lane < cnt) {
+    my_k = order[ib + lane];
+    my_dst = (int64_t)(chunk_off[(int64_t)my_k * nchunks + ch] - page_base) + (ch == 0 ? prefix_len[my_k] : 0u);
+  }
+  // state of the first record: one coalesced row + the texts (vector loads: nothing of this wavefront is in flight yet)
+  const uint2 d0 = eb.init[b * kAsmRows + lane];
+  uint32_t len = d0.y, cur_off = d0.x;
+  SlotText txt;
+  {
+    const char* src = ((cur_off & kOverflowBit) ? pool_ovf : pool) + (size_t)(cur_off & ~kOverflowBit) * 16;
+#pragma unroll
+    for (int q = 0; q < kTextChunks; ++q) txt.x[q] = load_chunk(src, q, len);
+  }
+  const uint32_t nev = (uint32_t)__builtin_amdgcn_readfirstlane((int)eb.count[b]);
+  const uint2* __restrict__ evp = eb.ev + b * (int64_t)run * kAsmRows;
+  uint32_t pe = 0;
+  uint64_t next_ev = 0;
+  if (nev) { next_ev = sload_x2(evp); swait(next_ev); }
+  for (int jj = 0; jj < cnt; ++jj) {                        // uniform
+    // ---- the changes of this record: scalar loads + v_writelane -----------------------------------------------------------------------
+    while (pe < nev && (uint32_t)(next_ev >> 58) == (uint32_t)jj) {     // uniform
+      const uint32_t ex = (uint32_t)next_ev, ey = (uint32_t)(next_ev >> 32);
+      const uint32_t L = (ey >> kEvLenBits) & 63u, elen = ey & kEvLenMask;
+      const char* src = ((ex & kOverflowBit) ? pool_ovf : pool) + (size_t)(ex & ~kOverflowBit) * 16;
+      u32x4 t0 = sload_x4(src), t1 = sload_x4(src + 16), t2 = sload_x4(src + 32), t3 = sload_x4(src + 48), t4 = sload_x4(src + 64);   // (the pools are padded: reading past a short text is harmless)
+      ++pe;
+      uint64_t nx = next_ev;
+      if (pe < nev) nx = sload_x2(evp + pe);
+      swait(t0, t1, t2, t3, t4);
+      swait(nx);
+      wlane4(txt.x[0], t0, L); wlane4(txt.x[1], t1, L); wlane4(txt.x[2], t2, L); wlane4(txt.x[3], t3, L); wlane4(txt.x[4], t4, L);
+      len = wlane(elen, L, len);
+      cur_off = wlane(ex, L, cur_off);
+      next_ev = nx;
+    }
+    const uint32_t inc = wave_inclusive_scan_dpp(len);
+    const uint32_t excl = inc - len;
+    const uint32_t total = wave_total(inc);
+    if (total == 0) continue;                             // uniform: no FORMAT columns in this record
+    char* const grec = arena + readlane64(my_dst, jj);
+    const char* cur_src = ((cur_off & kOverflowBit) ? pool_ovf : pool) + (size_t)(cur_off & ~kOverflowBit) * 16;
+    uint32_t l0 = 0, base_off = 0;
+    while (base_off < total) {                            // uniform
+      char* gdst = grec + base_off;
+      const uint32_t al = (uint32_t)((uintptr_t)gdst & 15u);
+      const bool fits = (uint32_t)lane >= l0 && al + (inc - base_off) <= (uint32_t)kWaveLds;
+      const uint64_t fit_mask = __ballot(fits) >> l0;
+      const uint32_t len_l0 = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)(l0 < 64u ? l0 : 63u));
+      if (!(fit_mask & 1ull) || len_l0 > (uint32_t)kCooperativeEntry) {   // a long text (or one that exceeds the image): the whole wavefront copies it
+        const char* big_src = (const char*)(uintptr_t)readlane64((int64_t)(uintptr_t)cur_src, (int)l0);
+        const uint32_t big_len = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)l0);
+        uint32_t head = (16u - al) & 15u;
+        if (head > big_len) head = big_len;
+        if ((uint32_t)lane < head) gdst[lane] = big_src[lane];
+        const uint32_t nwords = (big_len - head) >> 4;
+        uint4* gw = reinterpret_cast<uint4*>(gdst + head);
+        for (uint32_t wq = lane; wq < nwords; wq += kAsmRows) {
+          const char* sp = big_src + head + ((size_t)wq << 4);
+          const uint4 lo = *reinterpret_cast<const uint4*>((uintptr_t)sp & ~(uintptr_t)15);
+          const uint4 hi = *reinterpret_cast<const uint4*>(((uintptr_t)sp & ~(uintptr_t)15) + 16);
+          const uint32_t sh = (uint32_t)((uintptr_t)sp & 15u);
+          const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          uint32_t o[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t a = w[(sh >> 2) + q], bb = w[(sh >> 2) + q + 1 < 8 ? (sh >> 2) + q + 1 : 7];
+            o[q] = __builtin_amdgcn_alignbyte(bb, a, sh & 3u);
+          }
+          gw[wq] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        const uint32_t tail_at = head + (nwords << 4);
+        if ((uint32_t)lane < big_len - tail_at) gdst[tail_at + lane] = big_src[tail_at + lane];
+        base_off = (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)l0);
+        ++l0;
+        continue;
+      }
+      const uint32_t nfit = fit_mask == ~0ull ? 64u - l0 : (uint32_t)__builtin_ctzll(~fit_mask);
+      const uint32_t l1 = l0 + nfit;
+      const uint32_t pass_total = (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)(l1 - 1)) - base_off;
+      const bool mine = (uint32_t)lane >= l0 && (uint32_t)lane < l1;
+      SlotCopy cp;
+      cp.begin((gdb_lds_char*)lds_buf + al + (excl - base_off), mine ? len : 0u);
+      cp.chunk(0, txt.x[0]);
+#pragma unroll
+      for (int q = 1; q < kTextChunks; ++q) if (__any((int)cp.needs(q))) cp.chunk(q, txt.x[q]);
+      for (uint32_t q = kTextChunks; __any((int)cp.needs(q)); ++q) cp.chunk(q, load_chunk(cur_src, q, mine ? len : 0u));
+      cp.finish();
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      const char* img = lds_buf + al;
+      uint32_t head = (16u - al) & 15u;
+      if (head > pass_total) head = pass_total;
+      const uint32_t nwords = (pass_total - head) >> 4;
+      const uint32_t tail_at = head + (nwords << 4);
+      if ((uint32_t)lane < head) gdst[lane] = img[lane];
+      const uint4* lsrc = reinterpret_cast<const uint4*>(img + head);
+      uint4* gw = reinterpret_cast<uint4*>(gdst + head);
+      for (uint32_t wq = lane; wq < nwords; wq += kAsmRows) gw[wq] = lsrc[wq];
+      if ((uint32_t)lane < pass_total - tail_at) gdst[tail_at + lane] = img[tail_at + lane];
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      l0 = l1;
+      base_off += pass_total;
+    }
+  }
+}
+
 // ---- BCF2 page assembly ("bu") ------------------------------------------------------------------------------------------------
 // The FORMAT block of a BCF record is field-major with a fixed stride per sample, so once the vector length and the integer
 // type of every (record, field) are known a sample's values have a fixed place: no scan over variable-length texts.
@@ -1146,6 +1620,19 @@ __global__ void __launch_bounds__(kAsmRows) k_bcf_write(CombinePlan pl, const ui
     body += n * (uint32_t)es;
     ++q;
   }
+}
+
+// SURVEY 8(d) "remap elements": per record that needs re-indexing, (calls with a valid genotype-length field) x (merged genotypes) -
+// the element count of the reference's O(G) remap loop (variant_field_handler.cc:134-191), diploid genotype count
+__global__ void k_remap_elements(SiteOut so, const int32_t* __restrict__ pl_cnt, int64_t P, int pl_bit, unsigned long long* total) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long mine = 0;
+  if (k < P && (so.rflags[k] & GDB_RF_REMAPPING_NEEDED) && ((so.fmt_mask[k] >> pl_bit) & 1u)) {
+    const unsigned long long a = so.num_alleles[k];
+    mine = (unsigned long long)pl_cnt[k] * (a * (a + 1) / 2);
+  }
+  for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(total, mine);
 }
 
 // sort key of the assembly order: (block of 2^block_log2 consecutive records, record type); the value is the record index
@@ -1399,6 +1886,8 @@ struct DevicePipeline::Impl {
   DevBuf<SiteCtx> d_sx;
   DevBuf<uint64_t> med_keys, med_keys_sorted; DevBuf<uint32_t> med_idx, med_idx_sorted;
   DevBuf<int32_t> big_index, big_list; DevBuf<uint32_t> big_value; DevBuf<uint8_t> big_ok;
+  DevBuf<unsigned long long> remap_total;
+  DevBuf<int32_t> huge_index, huge_list; DevBuf<HugeSiteOut> huge_out; DevBuf<SiteCtx> d_sx0;
   DevBuf<uint32_t> slot_cell; DevBuf<float> tie_buf; DevBuf<unsigned long long> tie_used; DevBuf<uint32_t> scalar_pre;
   // entry text table
   DevBuf<unsigned long long> type_hkeys; DevBuf<int32_t> type_hrep, type_rep; DevBuf<uint8_t> type_hid, rtype;
@@ -2450,7 +2939,19 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
       pre.val = S.scalar_pre.p; pre.stride = T; pre.enabled = 1;
     }
   }
-  SiteCtx sx{fr, pl, cm, rec, hl, pc, nt, qw, so, med, big, tie, pre};
+  // records with very many variant calls: their call walk is done by one workgroup each, before the per-thread site pass
+  HugeSites huge;
+  memset(&huge, 0, sizeof(huge));
+  SiteCtx sx0{fr, pl, cm, rec, hl, pc, nt, qw, so, med, big, tie, pre, huge};
+  if (T > (int64_t)kHugeRecord && !getenv("GDBAMD_NO_HUGE_SITES")) {
+    S.huge_index.ensure((size_t)P); S.huge_list.ensure(kMaxHugeRecords); S.huge_out.ensure(kMaxHugeRecords); S.d_sx0.ensure(1);
+    HIP_CHECK(hipMemcpyAsync(S.d_sx0.p, &sx0, sizeof(SiteCtx), hipMemcpyHostToDevice, st));
+    STAGE("k_site_huge");
+    hipLaunchKernelGGL(k_huge_records, dim3(blocks_for(P)), dim3(kBlock), 0, st, (const int64_t*)S.hbase.p, P, S.huge_index.p, S.huge_list.p, S.counters.p + 3);
+    hipLaunchKernelGGL(k_site_huge, dim3(1024), dim3(kBlock), 0, st, (const SiteCtx*)S.d_sx0.p, (const int32_t*)S.huge_list.p, (const int32_t*)(S.counters.p + 3), S.huge_out.p, S.err.p);
+    huge.index = S.huge_index.p; huge.out = S.huge_out.p; huge.enabled = 1;
+  }
+  SiteCtx sx{fr, pl, cm, rec, hl, pc, nt, qw, so, med, big, tie, pre, huge};
   S.d_sx.ensure(1);
   HIP_CHECK(hipMemcpyAsync(S.d_sx.p, &sx, sizeof(SiteCtx), hipMemcpyHostToDevice, st));   // (sx outlives the copy: the function synchronises before it returns)
   STAGE("k_site_size");
@@ -2458,6 +2959,11 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   S.spill_buf.ensure((size_t)kSpillChunks * kSpillChunk); S.spill_chunk.ensure((size_t)P); S.spill_next.ensure(1);
   HIP_CHECK(hipMemsetAsync(S.spill_next.p, 0, sizeof(unsigned int), st));
   hipLaunchKernelGGL(k_site_size, dim3(blocks_for(P, 64)), dim3(64), 0, st, S.d_sx.p, S.site_staging.p, SpillPool{S.spill_buf.p, S.spill_next.p, (uint32_t)kSpillChunks}, S.spill_chunk.p, S.err.p);
+  S.remap_total.ensure(1);
+  HIP_CHECK(hipMemsetAsync(S.remap_total.p, 0, sizeof(unsigned long long), st));
+  for (int i = 0; i < pl.n_format; ++i)
+    if (pl.format_field[i] == pl.f_PL && pl.f_PL >= 0)
+      hipLaunchKernelGGL(k_remap_elements, dim3(blocks_for(P)), dim3(kBlock), 0, st, so, (const int32_t*)(d_fmt + (size_t)i * stride), P, i, S.remap_total.p);
   HIP_CHECK(hipEventRecord(ev[2], st));
   // ---- S8 sample-column sizes + offsets ---------------------------------------------------------------------------
   const int nchunks = (N + kAsmRows - 1) / kAsmRows;
@@ -2578,8 +3084,11 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   STAGE("before-sync-offsets");
   HIP_CHECK(hipEventRecord(ev[3], st));
   uint32_t eb = 0;
-  S.read_back_many({{&totals[0], S.rec_off.p + P, sizeof(uint64_t)}, {&totals[1], S.max_record.p, sizeof(uint64_t)}, {&eb, S.err.p, sizeof(uint32_t)}});
+  uint64_t remap_elems = 0;
+  S.read_back_many({{&totals[0], S.rec_off.p + P, sizeof(uint64_t)}, {&totals[1], S.max_record.p, sizeof(uint64_t)}, {&eb, S.err.p, sizeof(uint32_t)},
+                    {&remap_elems, S.remap_total.p, sizeof(uint64_t)}});
   stats.bytes_out = totals[0];
+  stats.num_remap_elements = remap_elems;
   HIP_CHECK(hipEventElapsedTime(&stats.ms_sweep, ev[0], ev[1]));
   HIP_CHECK(hipEventElapsedTime(&stats.ms_site, ev[1], ev[2]));
   HIP_CHECK(hipEventElapsedTime(&stats.ms_size, ev[2], ev[3]));

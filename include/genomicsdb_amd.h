@@ -68,6 +68,7 @@ typedef struct gdbamd_interval_stats {
   float ms_sweep, ms_site, ms_size, ms_write, ms_total, ms_write_kernel_avg;
   int32_t num_record_types, reserved0;   /* entry text table: distinct record types, slots, pool bytes */
   int64_t num_text_slots, text_pool_bytes;
+  uint64_t num_remap_elements;           /* sum over re-indexed records of (calls with PL) x (merged genotypes): the PL remap work */
 } gdbamd_interval_stats;
 
 /* one attribute column in device memory; off == NULL for fixed-length attributes */

@@ -444,7 +444,7 @@ def test_c3_width_10000_samples_matches_oracle(gdb, tmp_path, monkeypatch):
     eng.close()
 
 
-def test_c5_width_12000_samples_dense_site_matches_oracle(gdb, tmp_path):
+def test_c5_width_12000_samples_dense_site_matches_oracle(gdb, tmp_path, monkeypatch):
     """BASELINE.json configs[4]-style site at 12 000 rows: every sample starts an insertion from a pool of 64 alleles at one
     column - the allele merge of that record sees 12 000 variant calls, each PL vector is re-indexed over ~2 000 genotypes"""
     from genomicsdb_amd import synth
@@ -462,6 +462,31 @@ def test_c5_width_12000_samples_dense_site_matches_oracle(gdb, tmp_path):
     assert got == want
     widest = max(len(l.split(b"\t")[4].split(b",")) for l in want.split(b"\n") if l)
     assert widest >= 60
+    monkeypatch.setenv("GDBAMD_NO_HUGE_SITES", "1")     # the one-thread walk of the calls gives the same bytes
+    got2, _ = eng.run_interval(B + 30, B + L - 1, arena_bytes=64 << 20)
+    assert got2 == want
+    eng.close()
+
+
+def test_c5_50000_samples_hot_site_matches_oracle(gdb, tmp_path, monkeypatch):
+    """BASELINE.json configs[4] at its stated sample count: 50 000 samples all start an insertion from a pool of 64 alleles at
+    one column.  The record's call walk (allele merge, LUTs, reducers, medians by radix select) is done by one workgroup
+    (k_site_huge); the bytes must be the oracle's, and the same with the serial walk forced (GDBAMD_NO_HUGE_SITES)"""
+    from genomicsdb_amd import synth
+    N, B = 50_000, 10_000_000
+    g = synth.Generator(N, B, 2600, dense=(B + 40, 20, 50, 64))      # the hot column is B + 50
+    cells, nc = g.chunk_bytes(B + 2600)
+    g.close()
+    q = helpers.synth_query(tmp_path, N, B + 50, B + 50)
+    q["max_diploid_alt_alleles_that_can_be_genotyped"] = 70      # 64 pool alleles + '*' + <NON_REF>: PL stays (2 278 genotypes per call)
+    want, nrec, _ = helpers.oracle_run_synth(q, cells, synth.SEED, with_header=False)
+    eng = gdb.CombineEngine(q)
+    eng.stage_cells(cells)
+    eng.set_reference(B, synth.reference(B, 4096))
+    got, st = eng.run_interval(B + 50, B + 50, arena_bytes=2 << 30)
+    assert st.num_records == nrec == 1
+    assert got == want
+    assert len(want.split(b"\t")[4].split(b",")) >= 52 and st.num_remap_elements >= 50_000 * 52 * 53 // 2
     eng.close()
 
 

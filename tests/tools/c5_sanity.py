@@ -20,5 +20,6 @@ for rep in range(2):
     t0 = time.time()
     _, st = eng.run_interval(B, B + L - 1, arena_bytes=32 << 30, fetch=False)
     dt = time.time() - t0
-    print("rep %d: %.1f ms; sweep %.2f site %.2f size %.2f write %.2f; records %d, %.2f GB out (%.0f KB/record), %.2f GB/s, %.0f positions/s" % (
-        rep, dt * 1e3, st.ms_sweep, st.ms_site, st.ms_size, st.ms_write, st.num_records, st.bytes_out / 1e9, st.bytes_out / max(1, st.num_records) / 1e3, st.bytes_out / dt / 1e9, st.num_records / dt))
+    print("rep %d: %.1f ms; sweep %.2f site %.2f size %.2f write %.2f; records %d, %.2f GB out (%.0f KB/record), %.2f GB/s, %.0f positions/s, %.3g remap elements/s" % (
+        rep, dt * 1e3, st.ms_sweep, st.ms_site, st.ms_size, st.ms_write, st.num_records, st.bytes_out / 1e9, st.bytes_out / max(1, st.num_records) / 1e3, st.bytes_out / dt / 1e9, st.num_records / dt,
+        st.num_remap_elements / dt))
