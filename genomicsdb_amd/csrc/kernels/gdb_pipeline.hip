@@ -73,6 +73,13 @@ inline uint64_t resolved_budget_bytes() {
   const char* e = getenv("GDBAMD_RESOLVED_MB");
   return e && *e ? (uint64_t)atoll(e) << 20 : (uint64_t)32 << 30;
 }
+// records per (run, chunk) of the change-list page assembly (<= 64); GDBAMD_EVENTS=1 selects it instead of the dense matrix
+inline int event_run_length() { const char* e = getenv("GDBAMD_EV_RUN"); return e && *e ? std::max(1, std::min(64, atoi(e))) : 32; }
+// (off by default: measured slower than the dense matrix - the scalar loads of a record's changes are a serial chain)
+inline bool events_enabled() { const char* e = getenv("GDBAMD_EVENTS"); return e && *e && *e != '0'; }
+// wavefronts (= neighbouring 64-sample chunks) per workgroup of the page assembly: 4 measured best on the store-only model
+inline int write_waves_per_group() { const char* e = getenv("GDBAMD_WRITE_WAVES"); return e && *e ? atoi(e) : 1; }
+inline int write_image_kb() { const char* e = getenv("GDBAMD_WRITE_IMAGE_KB"); return e && *e ? atoi(e) : 8; }
 inline int order_block_log2() {
   const char* e = getenv("GDBAMD_ORDER_BLOCK_LOG2");
   return e && *e ? std::max(0, std::min(30, atoi(e))) : 12;
@@ -1056,35 +1063,43 @@ struct SlotWalker {
 // The last, partial word is stored whole: it spills at most 3 bytes past the entry, and every spilled byte is a HEAD byte
 // (the bytes before the first word boundary) of one of the following entries.  The head bytes are therefore written by
 // finish(), after the words of all lanes (LDS executes a wavefront's instructions in order), which repairs the spill.
+// The stores are PREDICATED BY ADDRESS, not by branches: a word (or head byte) that is out of range goes to a per-lane scrap word
+// behind the image.  As `if (m < nw) dw[m] = ...` every one of the ~20 stores of a record step compiled into v_cmp +
+// s_and_saveexec + a taken branch + s_or: the wavefront spent more issue slots on exec-mask bookkeeping than on the copy.
 struct SlotCopy {
   gdb_lds_char* dst;
   __attribute__((address_space(3))) uint32_t* dw;
+  __attribute__((address_space(3))) uint32_t* scrap;
   uint32_t n, h, nw, carry, head_word;
-  __device__ __forceinline__ void begin(gdb_lds_char* d, uint32_t len) {
+  __device__ __forceinline__ void begin(gdb_lds_char* d, uint32_t len, gdb_lds_char* scrap_word) {
     dst = d; n = len;
     h = (4u - ((uint32_t)(uintptr_t)d & 3u)) & 3u;
     if (h > n) h = n;
     nw = (n - h + 3u) >> 2;          // destination words, the last one possibly partial
     dw = (__attribute__((address_space(3))) uint32_t*)(d + h);
+    scrap = (__attribute__((address_space(3))) uint32_t*)scrap_word;
     carry = 0; head_word = 0;
   }
+  __device__ __forceinline__ void put(uint32_t m, uint32_t v) const { *((m < nw) ? dw + m : scrap) = v; }   // (m - 1 with m == 0 wraps: out of range)
   // source chunk q (bytes [16q, 16q+16)) -> destination words 4q-1 .. 4q+2
   __device__ __forceinline__ void chunk(uint32_t q, const uint4& x) {
     if (q == 0) head_word = x.x;
     const uint32_t m1 = q << 2;      // word m takes source bytes [h+4m, h+4m+4): low part in source word m, high part in m+1
-    if (m1 >= 1 && m1 - 1 < nw) dw[m1 - 1] = __builtin_amdgcn_alignbyte(x.x, carry, h);
-    if (m1 < nw) dw[m1] = __builtin_amdgcn_alignbyte(x.y, x.x, h);
-    if (m1 + 1 < nw) dw[m1 + 1] = __builtin_amdgcn_alignbyte(x.z, x.y, h);
-    if (m1 + 2 < nw) dw[m1 + 2] = __builtin_amdgcn_alignbyte(x.w, x.z, h);
+    put(m1 - 1u, __builtin_amdgcn_alignbyte(x.x, carry, h));
+    put(m1, __builtin_amdgcn_alignbyte(x.y, x.x, h));
+    put(m1 + 1u, __builtin_amdgcn_alignbyte(x.z, x.y, h));
+    put(m1 + 2u, __builtin_amdgcn_alignbyte(x.w, x.z, h));
     carry = x.w;
   }
   __device__ __forceinline__ bool needs(uint32_t q) const { return (q << 2) <= nw && nw > 0; }   // q >= 1
   __device__ __forceinline__ void finish() const {
-    if (h > 0) dst[0] = (char)(head_word & 0xFFu);
-    if (h > 1) dst[1] = (char)((head_word >> 8) & 0xFFu);
-    if (h > 2) dst[2] = (char)((head_word >> 16) & 0xFFu);
+    gdb_lds_char* sc = (gdb_lds_char*)scrap;
+    *((h > 0) ? dst : sc) = (char)(head_word & 0xFFu);
+    *((h > 1) ? dst + 1 : sc) = (char)((head_word >> 8) & 0xFFu);
+    *((h > 2) ? dst + 2 : sc) = (char)((head_word >> 16) & 0xFFu);
   }
 };
+constexpr int kScrapBytes = 64 * 4;   // one scrap word per lane behind the LDS image
 __device__ __forceinline__ uint4 load_chunk(const char* __restrict__ src, uint32_t q, uint32_t n) {
   uint4 x = make_uint4(0, 0, 0, 0);
   if ((q << 4) < n) x = *reinterpret_cast<const uint4*>(src + (q << 4));
@@ -1163,16 +1178,29 @@ struct SlotText { uint4 x[kTextChunks]; };
 // builder + flusher wavefront pairs 5.6; skewed software pipeline with two LDS images 4.2; unaligned ds_write_b128 of whole
 // chunks instead of the funnel-shifted words (gfx950 accepts any byte alignment, but it costs 3.8 vs 2.9).  All of them trade resident
 // wavefronts for fewer exposed waits, and lose: the kernel is bound by (resident wavefronts) / (per-record latency).
-__global__ void __launch_bounds__(kAsmRows)
+// Which (run, chunk) a wavefront takes.  Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own L2: with
+// "chunk fast" numbering the 16 chunks of a record - 2.8 KB runs that share their first and last cache line with the neighbour
+// chunk - were written from 8 different L2s.  A store-only kernel of exactly this shape (tests/tools/microbench/store_bw.hip)
+// goes from 3.4 to 4.6 TB/s when the numbering keeps the chunks of a record run on one XCD, and to 5.1 TB/s with 4 neighbouring
+// chunks per workgroup (4 wavefronts, one LDS image each, still no barrier); the page assembly sat exactly on the 3.4.
+template <int WAVES> __device__ __forceinline__ int64_t xcd_aware_unit(int64_t total_units) {
+  const unsigned nb = gridDim.x, per = nb / 8u;
+  const unsigned lb = blockIdx.x < per * 8u ? (blockIdx.x % 8u) * per + blockIdx.x / 8u : blockIdx.x;
+  const int64_t u = (int64_t)lb * WAVES + (int64_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform: scalar registers)
+  return u < total_units ? u : -1;
+}
+template <int WAVES, int kWaveLds> __global__ void __launch_bounds__(kAsmRows * WAVES)
 k_assemble_write(const char* __restrict__ pool, const char* __restrict__ pool_ovf, const uint32_t* __restrict__ prefix_len, const uint2* __restrict__ resolved, int64_t resolved_base,
                  const int32_t* __restrict__ order, int64_t n, int nchunks, int run, const uint64_t* __restrict__ chunk_off, uint64_t page_base,
                  char* __restrict__ arena) {
-  // chunk is the fast grid dimension: the 16 chunk wavefronts of a record run are in flight together
-  const int64_t ib = (int64_t)(blockIdx.x / (unsigned)nchunks) * run;
+  const int64_t unit = xcd_aware_unit<WAVES>(((n + run - 1) / run) * (int64_t)nchunks);
+  if (unit < 0) return;
+  const int64_t ib = (unit / nchunks) * run;
   const int64_t ie = min(n, ib + (int64_t)run);
-  const int ch = (int)(blockIdx.x % (unsigned)nchunks);
-  const int lane = threadIdx.x;
-  __shared__ __attribute__((aligned(16))) char lds_buf[kWaveLds + 16];
+  const int ch = (int)(unit % nchunks);
+  const int lane = threadIdx.x & 63;
+  __shared__ __attribute__((aligned(16))) char lds_all[WAVES][kWaveLds + 16 + kScrapBytes];
+  char* const lds_buf = &lds_all[threadIdx.x >> 6][0];
   uint2 cur = make_uint2(0xFFFFFFFFu, 0);
   const char* cur_src = pool;
   SlotText txt;
@@ -1243,7 +1271,7 @@ k_assemble_write(const char* __restrict__ pool, const char* __restrict__ pool_ov
         const uint32_t pass_total = (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)(l1 - 1)) - base_off;
         const bool mine = (uint32_t)lane >= l0 && (uint32_t)lane < l1;
         SlotCopy cp;
-        cp.begin((gdb_lds_char*)lds_buf + al + (excl - base_off), mine ? len : 0u);
+        cp.begin((gdb_lds_char*)lds_buf + al + (excl - base_off), mine ? len : 0u, (gdb_lds_char*)lds_buf + kWaveLds + 16 + 4 * lane);
         cp.chunk(0, txt.x[0]);
 #pragma unroll
         for (int q = 1; q < kTextChunks; ++q) if (__any((int)cp.needs(q))) cp.chunk(q, txt.x[q]);
@@ -1347,24 +1375,30 @@ __device__ __forceinline__ uint64_t sload_x2(const void* p) { uint64_t v; asm vo
 __device__ __forceinline__ void swait(uint64_t& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a) : : "memory"); }
 __device__ __forceinline__ void swait(u32x4& a, u32x4& b, u32x4& c, u32x4& d, u32x4& e) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c), "+s"(d), "+s"(e) : : "memory"); }
 // v_writelane with an SGPR value takes its lane select from M0 (one scalar operand per VALU instruction on gfx9)
+// (M0 is saved and restored: the compiler keeps it out of its own allocation but may rely on its value)
 __device__ __forceinline__ uint32_t wlane(uint32_t sval, uint32_t l, uint32_t old) {
-  asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(sval), "s"(l) : "m0");
+  uint32_t keep;
+  asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1" : "+v"(old), "=&s"(keep) : "s"(sval), "s"(l));
   return old;
 }
 __device__ __forceinline__ void wlane4(uint4& dst, const u32x4& sv, uint32_t l) {
-  asm volatile("s_mov_b32 m0, %8\n\tv_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0\n\tv_writelane_b32 %2, %6, m0\n\tv_writelane_b32 %3, %7, m0"
-               : "+v"(dst.x), "+v"(dst.y), "+v"(dst.z), "+v"(dst.w) : "s"(sv.x), "s"(sv.y), "s"(sv.z), "s"(sv.w), "s"(l) : "m0");
+  uint32_t keep;
+  asm volatile("s_mov_b32 %4, m0\n\ts_mov_b32 m0, %9\n\tv_writelane_b32 %0, %5, m0\n\tv_writelane_b32 %1, %6, m0\n\tv_writelane_b32 %2, %7, m0\n\tv_writelane_b32 %3, %8, m0\n\ts_mov_b32 m0, %4"
+               : "+v"(dst.x), "+v"(dst.y), "+v"(dst.z), "+v"(dst.w), "=&s"(keep) : "s"(sv.x), "s"(sv.y), "s"(sv.z), "s"(sv.w), "s"(l));
 }
 
-__global__ void __launch_bounds__(kAsmRows)
+template <int WAVES> __global__ void __launch_bounds__(kAsmRows * WAVES)
 k_assemble_write_ev(const char* __restrict__ pool, const char* __restrict__ pool_ovf, const uint32_t* __restrict__ prefix_len, EventBuf eb, int64_t b0,
                     const int32_t* __restrict__ order, int64_t n, int nchunks, int run, const uint64_t* __restrict__ chunk_off, uint64_t page_base, char* __restrict__ arena) {
-  const int64_t ib = (int64_t)(blockIdx.x / (unsigned)nchunks) * run;
+  const int64_t unit = xcd_aware_unit<WAVES>(((n + run - 1) / run) * (int64_t)nchunks);
+  if (unit < 0) return;
+  const int64_t ib = (unit / nchunks) * run;
   const int64_t ie = min(n, ib + (int64_t)run);
-  const int ch = (int)(blockIdx.x % (unsigned)nchunks);
-  const int lane = threadIdx.x;
-  const int64_t b = b0 + blockIdx.x;
-  __shared__ __attribute__((aligned(16))) char lds_buf[kWaveLds + 16];
+  const int ch = (int)(unit % nchunks);
+  const int lane = threadIdx.x & 63;
+  const int64_t b = b0 + unit;
+  __shared__ __attribute__((aligned(16))) char lds_all[WAVES][kWaveLds + 16 + kScrapBytes];
+  char* const lds_buf = &lds_all[threadIdx.x >> 6][0];
   const int cnt = (int)(ie - ib);
   int32_t my_k = 0; int64_t my_dst = 0;
   if (lane < cnt) {
@@ -1448,7 +1482,7 @@ k_assemble_write_ev(const char* __restrict__ pool, const char* __restrict__ pool
       const uint32_t pass_total = (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)(l1 - 1)) - base_off;
       const bool mine = (uint32_t)lane >= l0 && (uint32_t)lane < l1;
       SlotCopy cp;
-      cp.begin((gdb_lds_char*)lds_buf + al + (excl - base_off), mine ? len : 0u);
+      cp.begin((gdb_lds_char*)lds_buf + al + (excl - base_off), mine ? len : 0u, (gdb_lds_char*)lds_buf + kWaveLds + 16 + 4 * lane);
       cp.chunk(0, txt.x[0]);
 #pragma unroll
       for (int q = 1; q < kTextChunks; ++q) if (__any((int)cp.needs(q))) cp.chunk(q, txt.x[q]);
@@ -1916,6 +1950,7 @@ struct DevicePipeline::Impl {
     SiteCtx sx; EntryCtx ex; RowIndex ri; SiteOut so; RecordTable rec; AsmCtx ac;
     bool resolved_whole = false;
     bool bcf = false; int bcf_F = 0; BcfLayout lay{nullptr, nullptr, nullptr, nullptr};
+    bool events = false; int evrun = 0; EventBuf eb{nullptr, nullptr, nullptr, 0};
   } iv;
 
   void* temp_storage(size_t bytes) { temp.ensure(bytes + 256); return temp.p; }
@@ -1985,6 +2020,9 @@ struct DevicePipeline::Impl {
     hipLaunchKernelGGL(k_order_keys, dim3(blocks_for(n)), dim3(kBlock), 0, stream, (const uint8_t*)rtype.p, (int32_t)k0, n, block_log2, order_keys.p, iota.p);
     sort_pairs(order_keys.p, order_keys_sorted.p, iota.p, order.p, (size_t)n, std::min(32, 8 + bits_for((uint64_t)(n >> block_log2))));
   }
+  // the change-list flavour keeps the interval's order for all its pages (pages that do not fall on order blocks re-sort `order`)
+  DevBuf<int32_t> order_iv; bool order_iv_valid = false;
+  DevBuf<uint2> ev_init, ev_buf; DevBuf<uint32_t> ev_count;
   void free_owned() { for (void* p : owned) (void)hipFree(p); owned.clear(); }
 };
 
@@ -2693,6 +2731,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   Impl& S = *m_;
   S.iv = Impl::IntervalState();
   S.order_k0 = S.order_n = -1;
+  S.order_iv_valid = false;
   HIP_CHECK(hipSetDevice(S.device));
   hipStream_t st = S.stream;
   const CombinePlan& pl = S.hp.plan;
@@ -3051,7 +3090,9 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   STAGE("k_assemble_size");
   S.order_by_type(0, P);
   const uint64_t resolved_bytes = (uint64_t)P * nchunks * kAsmRows * sizeof(uint2);
-  const bool resolved_whole = resolved_bytes <= resolved_budget_bytes() || pl.bcf_mode;
+  bool use_events = false;
+  EventBuf ebuf{nullptr, nullptr, nullptr, 0};
+  const bool resolved_whole = pl.bcf_mode || (resolved_bytes <= resolved_budget_bytes() && !(events_enabled() && ((1 << order_block_log2()) % event_run_length()) == 0));
   if (resolved_whole) S.resolved.ensure((size_t)P * nchunks * kAsmRows);
   S.max_record.ensure(1);
   HIP_CHECK(hipMemsetAsync(S.max_record.p, 0, sizeof(unsigned long long), st));
@@ -3072,6 +3113,18 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
     S.excl_scan(S.bcf_rec_size.p, S.rec_off.p, (size_t)P + 1);
     hipLaunchKernelGGL(k_bcf_max_record, dim3(blocks_for(P)), dim3(kBlock), 0, st, (const uint64_t*)S.bcf_rec_size.p, P, S.max_record.p);
   } else {
+  const int evrun = event_run_length();
+  const uint64_t ev_blocks = (uint64_t)((P + evrun - 1) / evrun) * (uint64_t)nchunks;
+  use_events = events_enabled() && ev_blocks * (uint64_t)evrun * kAsmRows * sizeof(uint2) <= resolved_budget_bytes() && ((1 << order_block_log2()) % evrun) == 0;
+  if (use_events) {
+    // sizing pass that leaves the change list of every (run, chunk) instead of the dense matrix
+    S.ev_init.ensure((size_t)ev_blocks * kAsmRows); S.ev_buf.ensure((size_t)ev_blocks * evrun * kAsmRows); S.ev_count.ensure((size_t)ev_blocks);
+    ebuf = EventBuf{S.ev_init.p, S.ev_buf.p, S.ev_count.p, evrun};
+    hipLaunchKernelGGL(k_assemble_size_ev, dim3((unsigned)ev_blocks), dim3(kAsmRows), 0, st, ac, S.order.p, P, N, nchunks, evrun, S.chunk_size.p, ebuf, S.err.p);
+    S.order_iv.ensure((size_t)P);
+    HIP_CHECK(hipMemcpyAsync(S.order_iv.p, S.order.p, (size_t)P * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    S.order_iv_valid = true;
+  } else
   hipLaunchKernelGGL(k_assemble_size, dim3(run_blocks * (unsigned)nchunks), dim3(kAsmRows), 0, st, ac, S.order.p, P, N, nchunks, run, S.chunk_size.p,
                      resolved_whole ? S.resolved.p : nullptr, (int64_t)0);
   HIP_CHECK(hipMemsetAsync(S.chunk_size.p + nchunk_total, 0, sizeof(uint64_t), st));
@@ -3097,6 +3150,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   S.iv.P = P; S.iv.nchunks = nchunks; S.iv.kp = 0;
   S.iv.sx = sx; S.iv.ex = ex; S.iv.ri = ri; S.iv.so = so; S.iv.rec = rec; S.iv.ac = ac; S.iv.resolved_whole = resolved_whole;
   S.iv.bcf = pl.bcf_mode != 0; S.iv.bcf_F = bcf_F; S.iv.lay = lay;
+  S.iv.events = use_events; S.iv.evrun = ebuf.run; S.iv.eb = ebuf;
   S.iv.active = true;
 }
 
@@ -3126,6 +3180,11 @@ bool DevicePipeline::begin_page(uint64_t arena_bytes, int arena_idx, PageTicket*
     int64_t lo = kp + 1, hi = P;  // largest k_end with rec_off[k_end] - rec_off[kp] <= arena_cap
     while (lo < hi) { int64_t mid = (lo + hi + 1) >> 1; if (rec_off[(size_t)mid] - rec_off[(size_t)kp] <= arena_cap) lo = mid; else hi = mid - 1; }
     ke = lo;
+    // the change list is laid out over the interval's order blocks: a page that ends on a block boundary can use it as it is
+    if (iv.events && !iv.bcf) {
+      const int64_t blk = (int64_t)1 << order_block_log2();
+      if (ke < P && (kp % blk) == 0 && (ke / blk) * blk > kp) ke = (ke / blk) * blk;
+    }
     page_base = rec_off[(size_t)kp];
     page_bytes = rec_off[(size_t)ke] - page_base;
   }
@@ -3158,6 +3217,27 @@ bool DevicePipeline::begin_page(uint64_t arena_bytes, int arena_idx, PageTicket*
   hipLaunchKernelGGL(k_site_copy, dim3(blocks_for(np, 4)), dim3(256), 0, st, (const uint32_t*)S.prefix_len.p, (const char*)S.site_staging.p, kp, ke, (const uint64_t*)S.chunk_off.p, iv.nchunks, page_base, arena);
   hipLaunchKernelGGL(k_site_write, dim3(blocks_for(np, 64)), dim3(64), 0, st, S.d_sx.p, (const char*)S.site_staging.p, (const char*)S.spill_buf.p, (const int32_t*)S.spill_chunk.p, kp, ke, S.chunk_off.p, iv.nchunks, page_base, arena, S.err.p);
   STAGE("k_assemble_write");
+  {
+    const int64_t blk = (int64_t)1 << order_block_log2();
+    if (iv.events && S.order_iv_valid && (kp % blk) == 0 && (ke == P || (ke % blk) == 0)) {
+      const int evrun = iv.evrun;
+      const unsigned eruns = (unsigned)((np + evrun - 1) / evrun);
+      HIP_CHECK(hipEventRecord(w[1], st));
+      const unsigned units = eruns * (unsigned)iv.nchunks;
+      if (write_waves_per_group() >= 4)
+        hipLaunchKernelGGL(k_assemble_write_ev<4>, dim3((units + 3u) / 4u), dim3(kAsmRows * 4), 0, st, (const char*)S.pool.p, (const char*)S.pool_ovf.p, (const uint32_t*)S.prefix_len.p,
+                           iv.eb, (int64_t)(kp / evrun) * iv.nchunks, (const int32_t*)(S.order_iv.p + kp), np, iv.nchunks, evrun, (const uint64_t*)S.chunk_off.p, page_base, arena);
+      else
+        hipLaunchKernelGGL(k_assemble_write_ev<1>, dim3(units), dim3(kAsmRows), 0, st, (const char*)S.pool.p, (const char*)S.pool_ovf.p, (const uint32_t*)S.prefix_len.p,
+                           iv.eb, (int64_t)(kp / evrun) * iv.nchunks, (const int32_t*)(S.order_iv.p + kp), np, iv.nchunks, evrun, (const uint64_t*)S.chunk_off.p, page_base, arena);
+      HIP_CHECK(hipEventRecord(w[2], st));
+      HIP_CHECK(hipMemcpyAsync(&S.hb->page_err[ai], S.err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipEventRecord(w[3], st));
+      iv.kp = ke;
+      ticket->arena = ai; ticket->dev = arena; ticket->nbytes = page_bytes; ticket->done_event = (void*)w[3];
+      return true;
+    }
+  }
   const int wrun = write_run_length();
   S.order_by_type(kp, np);
   const unsigned wruns = (unsigned)((np + wrun - 1) / wrun);
@@ -3167,8 +3247,19 @@ bool DevicePipeline::begin_page(uint64_t arena_bytes, int arena_idx, PageTicket*
     hipLaunchKernelGGL(k_assemble_size, wgrid, dim3(kAsmRows), 0, st, iv.ac, S.order.p, np, N, iv.nchunks, wrun, (uint64_t*)nullptr, S.resolved.p, kp);
   }
   HIP_CHECK(hipEventRecord(w[1], st));   // [w1, w2] brackets the page-assembly kernel alone (its duration feeds the roofline figure)
-  hipLaunchKernelGGL(k_assemble_write, wgrid, dim3(kAsmRows), 0, st, (const char*)S.pool.p, (const char*)S.pool_ovf.p, (const uint32_t*)S.prefix_len.p, (const uint2*)S.resolved.p,
-                     iv.resolved_whole ? (int64_t)0 : kp, (const int32_t*)S.order.p, np, iv.nchunks, wrun, (const uint64_t*)S.chunk_off.p, page_base, arena);
+#define GDB_LAUNCH_WRITE(W, L) hipLaunchKernelGGL((k_assemble_write<W, L>), dim3((wgrid.x + (W) - 1u) / (W)), dim3(kAsmRows * (W)), 0, st, (const char*)S.pool.p, (const char*)S.pool_ovf.p, \
+    (const uint32_t*)S.prefix_len.p, (const uint2*)S.resolved.p, iv.resolved_whole ? (int64_t)0 : kp, (const int32_t*)S.order.p, np, iv.nchunks, wrun, (const uint64_t*)S.chunk_off.p, page_base, arena)
+  {
+    const int ww = write_waves_per_group(), wl = write_image_kb();
+    if (ww >= 4 && wl <= 4) GDB_LAUNCH_WRITE(4, 4096);
+    else if (ww >= 4 && wl <= 6) GDB_LAUNCH_WRITE(4, 6144);
+    else if (ww >= 4) GDB_LAUNCH_WRITE(4, 8192);
+    else if (ww == 2 && wl <= 4) GDB_LAUNCH_WRITE(2, 4096);
+    else if (ww == 2) GDB_LAUNCH_WRITE(2, 8192);
+    else if (wl <= 4) GDB_LAUNCH_WRITE(1, 4096);
+    else GDB_LAUNCH_WRITE(1, 8192);
+  }
+#undef GDB_LAUNCH_WRITE
   HIP_CHECK(hipEventRecord(w[2], st));
   HIP_CHECK(hipMemcpyAsync(&S.hb->page_err[ai], S.err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipEventRecord(w[3], st));

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -48,6 +49,9 @@ struct Rec {
   char alt[8];
   float qual, rs[4], mq, raw_mq;
   int32_t dp, gq, min_dp, sb[4], ad[3], pl[6];
+  uint8_t nfilter, idlen;       // optional modes (gdbsynth_set_modes): FILTER ids, ID text
+  int32_t filter[2];
+  char id[24];
 };
 
 const int32_t NULL_I32 = 0x7FFFFFFF;
@@ -68,6 +72,15 @@ struct Synth {
   int64_t dense_begin = 0, dense_len = 0, hot_stride = 50;
   int dense_K = 0;
   double rs_scale = 1000.0;   // rank sums are rounded to 1 / rs_scale (coarse scales make tied medians, zeros of both signs included)
+  // optional modes, all off by default (the plain stream stays byte-identical): decisions come from a hash of (seed, row, begin),
+  // not from the per-sample stream.  overlap: the next record of a sample begins INSIDE a reference block / deletion (the scan's
+  // overlap override, query_variants.cc:512-543); filter: variant cells carry FILTER = [filter_id]; filter2: some carry
+  // [filter_id2] instead (records that unite two different ids); id: variant cells carry one or two ';'-separated ID tokens
+  // (the array schema then has an ID attribute between ALT and QUAL)
+  int overlap_permille = 0, filter_permille = 0, filter2_permille = 0, id_permille = 0;
+  int32_t filter_id = 1, filter_id2 = 0;
+  bool with_id = false;
+  uint64_t mode_hash(int32_t row, int64_t begin, uint64_t salt) const { return hash2(seed ^ salt, (uint64_t)begin * 0x9E3779B97F4A7C15ull + (uint64_t)row); }
   bool in_dense(int64_t p) const { return dense_len > 0 && p >= dense_begin && p < dense_begin + dense_len; }
   bool is_hot(int64_t p) const { return in_dense(p) && (p % hot_stride) == 0; }
 
@@ -140,6 +153,27 @@ struct Synth {
       r.ad[2] = 0;
     }
     pos[row] = r.end + 1;
+    if (overlap_permille > 0 && (r.kind == 0 || r.kind == 2) && r.end - r.begin >= 2 && !in_dense(r.begin)) {
+      const uint64_t h = mode_hash(row, r.begin, 0x0f0f1234abcdull);
+      if ((int)(h % 1000) < overlap_permille) pos[row] = r.begin + 1 + (int64_t)((h >> 20) % (uint64_t)(r.end - r.begin));   // in (begin, end]
+    }
+    if (r.kind != 0) {
+      if (filter_permille > 0 || filter2_permille > 0) {
+        const int v = (int)(mode_hash(row, r.begin, 0x77aa55ull) % 1000);
+        if (v < filter2_permille) { r.nfilter = 1; r.filter[0] = filter_id2; }
+        else if (v < filter2_permille + filter_permille) { r.nfilter = 1; r.filter[0] = filter_id; }
+      }
+      if (with_id && id_permille > 0) {
+        const uint64_t h = mode_hash(row, r.begin, 0x1d1d1dull);
+        if ((int)(h % 1000) < id_permille) {
+          // tokens shared per site (so that unions meet equal and different tokens): rs<site hash % 4>, sometimes a second one
+          const uint64_t sh = hash2(seed ^ 0x1d5eedull, (uint64_t)r.begin);
+          int n = snprintf(r.id, sizeof(r.id), "rs%u", (unsigned)(100 + (sh + (h >> 12)) % 4));
+          if ((h >> 30) & 1) n += snprintf(r.id + n, sizeof(r.id) - (size_t)n, ";x%u", (unsigned)((h >> 33) % 3));
+          r.idlen = (uint8_t)n;
+        }
+      }
+    }
   }
 
   // one cell in the reference binary layout, attribute order of tests/inputs/vid.json:
@@ -154,8 +188,9 @@ struct Synth {
     // coords 24 + END 8 + REF 4+len + ALT 4+len + QUAL 4 + FILTER 4 + 8 INFO words 32 + DP_FORMAT 4 + GQ 4 + SB 16 + AD + PL + PGT 4 + PID 4 + MIN_DP 4 + GT 12
     const uint32_t alt = r.kind == 0 ? 1u : (uint32_t)r.altlen + 2u;
     const uint32_t ad_pl = r.kind == 0 ? (4u + 4u + 12u) : (4u + 12u + 4u + 24u);
-    return 24u + 8u + 4u + r.reflen + 4u + alt + 4u + 4u + 32u + 4u + 4u + 16u + ad_pl + 4u + 4u + 4u + 12u;
+    return 24u + 8u + 4u + r.reflen + 4u + alt + 4u + 4u + 32u + 4u + 4u + 16u + ad_pl + 4u + 4u + 4u + 12u + 4u * r.nfilter + (r.idlen & 0x80 ? 4u + (r.idlen & 0x7Fu) : 0u);
   }
+  // (idlen bit 7 = the schema has an ID attribute; set for every record of such a stream by next_record's caller)
   static void write_cell(uint8_t* dst, const Rec& r) {
     Out o{dst};
     o.v<int64_t>(r.row); o.v<int64_t>(r.begin); o.v<uint64_t>(0);
@@ -163,8 +198,9 @@ struct Synth {
     o.v<int32_t>(r.reflen); o.put(r.ref, r.reflen);
     if (r.kind == 0) { o.v<int32_t>(1); o.c('&'); }
     else { o.v<int32_t>(r.altlen + 2); o.put(r.alt, r.altlen); o.c('|'); o.c('&'); }
+    if (r.idlen & 0x80) { o.v<int32_t>(r.idlen & 0x7F); o.put(r.id, r.idlen & 0x7Fu); }   // ID (only when the schema has it)
     if (r.kind == 0) o.v<uint32_t>(NULL_F32); else o.v<float>(r.qual);
-    o.v<int32_t>(0);  // FILTER: none
+    o.v<int32_t>(r.nfilter); for (int i = 0; i < r.nfilter; ++i) o.v<int32_t>(r.filter[i]);  // FILTER
     if (r.kind == 0) { for (int i = 0; i < 6; ++i) o.v<uint32_t>(NULL_F32); o.v<int32_t>(NULL_I32); o.v<int32_t>(NULL_I32); }
     else {
       for (int i = 0; i < 4; ++i) o.v<float>(r.rs[i]);
@@ -204,6 +240,7 @@ struct Synth {
       for (int32_t row = r0; row < r1; ++row)
         while (pos[row] < col_end) {
           next_record(row, r);
+          if (with_id) r.idlen |= 0x80;
           out.push_back(r);
           const size_t c = (size_t)(r.begin - chunk_begin);
           cnt[(size_t)t][c]++; bytes[(size_t)t][c] += cell_size(r);
@@ -262,6 +299,11 @@ void* gdbsynth_create(uint64_t seed, int32_t n_samples, int64_t B, int64_t L) {
 }
 void gdbsynth_destroy(void* h) { delete (Synth*)h; }
 void gdbsynth_set_rank_sum_scale(void* h, double scale) { ((Synth*)h)->rs_scale = scale > 0 ? scale : 1000.0; }
+void gdbsynth_set_modes(void* h, int overlap_permille, int filter_permille, int filter2_permille, int id_permille, int filter_id, int filter_id2, int with_id) {
+  Synth* s = (Synth*)h;
+  s->overlap_permille = overlap_permille; s->filter_permille = filter_permille; s->filter2_permille = filter2_permille; s->id_permille = id_permille;
+  s->filter_id = filter_id; s->filter_id2 = filter_id2; s->with_id = with_id != 0;
+}
 // generates the next chunk (cells beginning before col_end); returns #cells, *cells / *nbytes valid until the next call
 int64_t gdbsynth_next_chunk(void* h, int64_t col_end, int nthreads, const uint8_t** cells, uint64_t* nbytes) {
   Synth* s = (Synth*)h;

@@ -146,14 +146,14 @@ def oracle_run_synth(query, cells, seed, buffer_limit=0, with_header=True):
     return txt, nrec.value, secs.value
 
 
-def synth_query(tmpdir, n_samples, begin, end):
+def synth_query(tmpdir, n_samples, begin, end, with_id=False):
     """query JSON for the synthetic workload (vcf_attributes_order, vid.json schema, one contig)"""
     from genomicsdb_amd import synth
-    vp, cp = synth.write_metadata(str(tmpdir), n_samples, os.path.join(GOLDEN, "inputs", "vid.json"))
+    vp, cp = synth.write_metadata(str(tmpdir), n_samples, os.path.join(GOLDEN, "inputs", "vid.json"), with_id=with_id)
     return {
         "vid_mapping_file": vp, "callset_mapping_file": cp,
         "vcf_header_filename": os.path.join(GOLDEN, "inputs", "template_vcf_header.vcf"),
-        "attributes": VCF_ATTRIBUTES_ORDER,
+        "attributes": VCF_ATTRIBUTES_ORDER + (["ID"] if with_id else []),
         "query_column_ranges": [[[begin, end]]],
     }
 
