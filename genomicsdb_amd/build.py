@@ -24,6 +24,7 @@ SOURCES = [
     "host/reference_genome.cc",
     "host/vcf_importer.cc",
     "api/genomicsdb_bcf_generator.cc",
+    "api/genomicsdb_operators.cc",
     "api/capi.cc",
 ]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -103,6 +104,7 @@ def build_oracle():
 def build_hostsim():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "hostsim")])
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "jni_harness")])   # JVM-less driver of the JNI glue (tests only)
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "compat")])        # reference-shaped C++ caller (tests only)
 
 
 if __name__ == "__main__":

@@ -26,6 +26,17 @@ CombineEngine::CombineEngine(const mini_json::Value& query_json, int device, con
   if (!m_qc.get_reference_genome().empty()) m_ref.initialize(m_qc.get_reference_genome());
 }
 
+CombineEngine::CombineEngine(const VariantQueryConfig& query_config, int device, const std::string& output_format, bool use_missing_values_only_not_vector_end,
+                             unsigned max_diploid_alt_alleles) : m_qc(query_config) {
+  if (max_diploid_alt_alleles) m_qc.set_max_diploid_alt_alleles_that_can_be_genotyped(max_diploid_alt_alleles);
+  if (!m_qc.is_bookkeeping_done()) m_qc.do_query_bookkeeping(m_qc.get_vid_mapper().get_num_callsets(), 0);
+  std::string tmpl;
+  if (!m_qc.get_vcf_header_filename().empty()) tmpl = mini_json::read_text_file(m_qc.get_vcf_header_filename());
+  m_hp = build_combine_plan(m_qc, tmpl, output_format, use_missing_values_only_not_vector_end);
+  m_pipe.reset(new DevicePipeline(m_hp, device));
+  if (!m_qc.get_reference_genome().empty()) m_ref.initialize(m_qc.get_reference_genome());
+}
+
 void CombineEngine::stage_cells(const uint8_t* cells, uint64_t nbytes) {
   stage_cells_begin();
   stage_cells_append(cells, nbytes);

@@ -22,6 +22,10 @@ class CombineEngine {
   // output_format "": VCF text, "bu": uncompressed BCF2 records (what GATK4's BCF2Codec reads); the two flags are the JNI's
   explicit CombineEngine(const mini_json::Value& query_json, int device, const GenomicsDBImportConfig* loader = nullptr, int rank = 0,
                          const std::string& output_format = "", bool use_missing_values_only_not_vector_end = false);
+  // from a query configuration the caller has already read (the reference's C++ entry: VariantQueryProcessor + operator);
+  // max_diploid_alt_alleles != 0 overrides the configuration's value (the operator constructor's argument)
+  CombineEngine(const VariantQueryConfig& query_config, int device, const std::string& output_format, bool use_missing_values_only_not_vector_end,
+                unsigned max_diploid_alt_alleles = 0);
   VariantQueryConfig& query_config() { return m_qc; }
   const HostPlan& plan() const { return m_hp; }
   DevicePipeline& pipeline() { return *m_pipe; }

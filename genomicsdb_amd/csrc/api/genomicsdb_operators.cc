@@ -1,0 +1,134 @@
+#include "genomicsdb_operators.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <climits>
+#include <cstdlib>
+#include <cstring>
+
+namespace genomicsdb_amd {
+
+// ---- adapters -----------------------------------------------------------------------------------------------------------------
+VCFAdapter::~VCFAdapter() { if (m_out && m_owns_out) fclose(m_out); else if (m_out) fflush(m_out); }
+
+void VCFAdapter::initialize(const VariantQueryConfig& qc) {
+  m_output_format = qc.get_vcf_output_format();
+  m_buffer_limit = qc.get_combined_vcf_records_buffer_size_limit();
+  if (!m_open_output) return;
+  const std::string& fn = qc.get_vcf_output_filename();
+  if (fn.empty() || fn == "-") { m_out = stdout; m_owns_out = false; }
+  else { m_out = fopen(fn.c_str(), "wb"); m_owns_out = true; if (!m_out) throw VCFAdapterException("cannot open " + fn); }
+}
+void VCFAdapter::handoff(const uint8_t* bytes, size_t n) {
+  if (!m_out) throw VCFAdapterException("VCFAdapter::initialize() has not opened an output");
+  if (n && fwrite(bytes, 1, n, m_out) != n) throw VCFAdapterException("short write");
+}
+void VCFSerializedBufferAdapter::handoff(const uint8_t* bytes, size_t n) {
+  if (!m_rw_buffer) throw VCFAdapterException("VCFSerializedBufferAdapter: set_buffer() first");
+  RWBuffer& b = *m_rw_buffer;
+  if (b.m_buffer.size() < b.m_num_valid_bytes + n) b.m_buffer.resize(std::max(2 * b.m_buffer.size() + 1, b.m_num_valid_bytes + n));   // (the reference grows it the same way)
+  if (n) memcpy(&b.m_buffer[b.m_num_valid_bytes], bytes, n);
+  b.m_num_valid_bytes += n;
+}
+void VCFSerializedBufferAdapter::do_output() {
+  if (!m_rw_buffer || !m_out) return;
+  const RWBuffer& b = *m_rw_buffer;
+  if (b.m_num_valid_bytes && fwrite(&b.m_buffer[0], 1, b.m_num_valid_bytes, m_out) != b.m_num_valid_bytes) throw VCFAdapterException("short write");
+}
+
+// ---- operators ----------------------------------------------------------------------------------------------------------------
+void SingleVariantOperatorBase::operate(Variant&, const VariantQueryConfig&) {
+  throw VariantOperationException("per-record operate() is not called on the device path: the scan hands whole pages to the recognised BroadCombinedGVCFOperator, "
+                                  "or to BatchedVariantOperatorBase::operate_on_page()");
+}
+const Variant& GA4GHOperator::get_remapped_variant() const {
+  throw VariantOperationException("remapped Variant objects are not materialised on the host (the records are combined in HBM)");
+}
+BroadCombinedGVCFOperator::BroadCombinedGVCFOperator(VCFAdapter& vcf_adapter, const VidMapper& id_mapper, const VariantQueryConfig& query_config,
+                                                     const unsigned max_alt, const bool use_missing_values_only_not_vector_end)
+    : GA4GHOperator(query_config, id_mapper, max_alt), m_vcf_adapter(&vcf_adapter), m_use_missing_values_not_vector_end(use_missing_values_only_not_vector_end) {}
+
+// ---- the scan -------------------------------------------------------------------------------------------------------------------
+struct VariantQueryProcessor::Engine {
+  std::unique_ptr<CombineEngine> eng;
+  std::string format;
+  bool use_missing = false, header_done = false;
+  unsigned max_alt = 0;
+  std::vector<uint8_t> host;      // page -> host bounce
+};
+
+VariantQueryProcessor::VariantQueryProcessor(VariantStorageManager* sm, const std::string& array_name, const VidMapper&) : m_storage_manager(sm), m_array_name(array_name) {
+  if (!sm) throw VariantOperationException("VariantQueryProcessor needs a VariantStorageManager");
+}
+VariantQueryProcessor::~VariantQueryProcessor() {}
+
+void VariantQueryProcessor::do_query_bookkeeping(const VariantArraySchema&, VariantQueryConfig& query_config, const VidMapper& vid_mapper, const bool) const {
+  if (!query_config.is_bookkeeping_done()) query_config.do_query_bookkeeping(vid_mapper.get_num_callsets(), 0);
+}
+
+void VariantQueryProcessor::scan_and_operate(const int, const VariantQueryConfig& query_config, SingleVariantOperatorBase& variant_operator, unsigned column_interval_idx,
+                                             bool, VariantQueryProcessorScanState* scan_state) const {
+  auto* gvcf = dynamic_cast<BroadCombinedGVCFOperator*>(&variant_operator);
+  auto* batched = dynamic_cast<BatchedVariantOperatorBase*>(&variant_operator);
+  if (!gvcf && !batched)
+    throw VariantOperationException("this operator's per-record operate() cannot run on the device path; the built-in BroadCombinedGVCFOperator is recognised, "
+                                    "other operators take pages through BatchedVariantOperatorBase::operate_on_page()");
+  const std::string format = gvcf ? gvcf->get_vcf_adapter().get_output_format() : std::string();
+  const bool use_missing = gvcf && gvcf->use_missing_values_only_not_vector_end();
+  if (!m_engine || m_engine->format != format || m_engine->use_missing != use_missing) {
+    m_engine.reset(new Engine);
+    m_engine->format = format; m_engine->use_missing = use_missing;
+    int device = 0;
+    if (const char* e = getenv("GDBAMD_DEVICE")) device = atoi(e); else if (const char* e2 = getenv("LOCAL_RANK")) device = atoi(e2);
+    // the engine is configured from the caller's query configuration (its JSON form): attributes, rows, intervals, switches
+    m_engine->eng.reset(new CombineEngine(query_config, device, format, use_missing, gvcf ? gvcf->get_max_diploid_alt_alleles_that_can_be_genotyped() : 0u));
+    m_engine->eng->open_array(m_storage_manager->get_workspace() + "/" + m_array_name);
+  }
+  CombineEngine& eng = *m_engine->eng;
+  VariantQueryProcessorScanState local_state;
+  VariantQueryProcessorScanState& st = scan_state ? *scan_state : local_state;
+  if (gvcf && !m_engine->header_done) {       // the reference's operator constructor writes the header through its adapter
+    const HostPlan& hp = eng.plan();
+    const auto* ser = dynamic_cast<VCFSerializedBufferAdapter*>(&gvcf->get_vcf_adapter());
+    const std::string h = hp.plan.bcf_mode ? hp.bcf_header_bytes(ser ? ser->keep_idx_fields_in_bcf_header() : true) : hp.header_text;
+    gvcf->get_vcf_adapter().handoff((const uint8_t*)h.data(), h.size());
+    m_engine->header_done = true;
+  }
+  const VariantQueryConfig& qc = eng.query_config();
+  const unsigned nint = std::max(1u, qc.get_num_column_intervals());
+  if (column_interval_idx >= nint) { st.m_done = true; return; }
+  if (!st.m_started) {
+    st.m_started = true;
+    st.m_piece_begin = qc.get_num_column_intervals() ? qc.get_column_begin(column_interval_idx) : 0;
+    st.m_interval_end = qc.get_num_column_intervals() ? qc.get_column_end(column_interval_idx) : INT64_MAX - 1;
+    st.m_piece_active = false;
+  }
+  const uint64_t page_bytes = gvcf && dynamic_cast<VCFSerializedBufferAdapter*>(&gvcf->get_vcf_adapter()) ? std::max<uint64_t>(1, query_config.get_combined_vcf_records_buffer_size_limit())
+                                                                                                          : (uint64_t)256 << 20;
+  DevicePipeline& pipe = eng.pipeline();
+  for (;;) {
+    if (!st.m_piece_active) {
+      if (st.m_piece_begin > st.m_interval_end) { st.m_done = true; return; }
+      const CombineEngine::Coverage cov = eng.cover(st.m_piece_begin);
+      const int64_t n = std::max<int64_t>(1, (int64_t)eng.plan().plan.num_query_rows);
+      const int64_t pe = pipe.split_point(st.m_piece_begin, std::min(st.m_interval_end, cov.hi), std::max<int64_t>(1000, (int64_t)(48ll << 30) / (n * 64)));
+      eng.stage_reference_for(st.m_piece_begin, pe);
+      pipe.prepare_interval(st.m_piece_begin, pe);
+      st.m_piece_begin = pe + 1;             // (the piece in flight is remembered by the pipeline)
+      st.m_piece_active = true;
+    }
+    const char* dev = nullptr;
+    uint64_t nb = 0;
+    if (!pipe.next_page(page_bytes, &dev, &nb)) { st.m_piece_active = false; continue; }
+    if (batched) batched->operate_on_page(dev, nb, qc.get_num_column_intervals() ? qc.get_column_begin(column_interval_idx) : 0, st.m_interval_end);
+    else {
+      m_engine->host.resize((size_t)nb);
+      if (nb && hipMemcpy(m_engine->host.data(), dev, (size_t)nb, hipMemcpyDeviceToHost) != hipSuccess) throw GenomicsDBDeviceException("page copy to host failed");
+      gvcf->get_vcf_adapter().handoff(m_engine->host.data(), (size_t)nb);
+      if (gvcf->overflow()) return;          // the caller drains the buffer and comes back (scan state: not at the end)
+    }
+  }
+}
+
+}  // namespace genomicsdb_amd

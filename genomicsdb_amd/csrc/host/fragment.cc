@@ -71,8 +71,9 @@ HostFragment fragment_from_cells(const uint8_t* cells, size_t nbytes, const Vari
     memcpy(&row, cells + off, 8);
     memcpy(&col, cells + off + 8, 8);
     memcpy(&cell_size, cells + off + 16, 8);
-    if (off + cell_size > nbytes) throw std::runtime_error("truncated cell stream");
+    if (cell_size < 32 || off + cell_size > nbytes) throw std::runtime_error("truncated cell stream");
     const uint8_t* p = cells + off + 24;
+    const uint8_t* const cell_end = cells + off + cell_size;      // every read below is checked against the cell it belongs to
     int32_t qrow = (row >= 0 && (size_t)row < row_map.size()) ? row_map[(size_t)row] : -1;
     if (qrow >= 0) {
       if (col < prev_col || (col == prev_col && qrow <= prev_row)) throw std::runtime_error("cells are not in column-major (col,row) order");
@@ -82,8 +83,14 @@ HostFragment fragment_from_cells(const uint8_t* cells, size_t nbytes, const Vari
     for (size_t ai = 0; ai < schema.attrs.size(); ++ai) {
       const auto& a = schema.attrs[ai];
       uint32_t n = (uint32_t)a.num;
-      if (a.var) { int32_t len; memcpy(&len, p, 4); p += 4; n = (uint32_t)len; }
+      if (a.var) {
+        if (p + 4 > cell_end) throw std::runtime_error("cell size mismatch while parsing the cell stream");
+        int32_t len; memcpy(&len, p, 4); p += 4;
+        if (len < 0) throw std::runtime_error("cell size mismatch while parsing the cell stream");
+        n = (uint32_t)len;
+      }
       size_t bytes = (size_t)n * (size_t)a.elem_size;
+      if (bytes > (size_t)(cell_end - p) || (ai == 0 && bytes < 8)) throw std::runtime_error("cell size mismatch while parsing the cell stream");
       if (qrow >= 0) {
         if (ai == 0) { int64_t e; memcpy(&e, p, 8); fr.end.push_back(e); }
         int f = attr_to_field[ai];

@@ -71,6 +71,7 @@ class VariantQueryConfig {
   bool sites_only_query() const { return m_sites_only_query; }
   bool produce_GT_with_min_PL_value_for_spanning_deletions() const { return m_produce_GT_with_min_PL_value_for_spanning_deletions; }
   unsigned get_max_diploid_alt_alleles_that_can_be_genotyped() const { return m_max_diploid_alt_alleles_that_can_be_genotyped; }
+  void set_max_diploid_alt_alleles_that_can_be_genotyped(unsigned v) { m_max_diploid_alt_alleles_that_can_be_genotyped = v; }
   size_t get_combined_vcf_records_buffer_size_limit() const { return m_combined_vcf_records_buffer_size_limit; }
   void set_combined_vcf_records_buffer_size_limit(size_t v) { m_combined_vcf_records_buffer_size_limit = v ? v : 1; }
   const std::string& get_vcf_header_filename() const { return m_vcf_header_filename; }

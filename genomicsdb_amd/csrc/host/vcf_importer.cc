@@ -185,6 +185,12 @@ std::vector<uint8_t> import_callsets_to_cells(const VidMapper& vid, const Import
   std::vector<uint8_t> bytes;
   std::vector<Cell> cells;
   ImportStats st;
+  // Intervals that begin in front of the column partition and reach into it are part of the partition: per row the LATEST cell
+  // beginning at or before the partition begin counts - if it still covers the partition begin it is handed over first, at its own
+  // coordinates; a later cell of the row that ends before the partition drops it
+  // (LoaderOperatorBase::handle_intervals_spanning_partition_begin, load_operators.cc:33-79).
+  struct Spanning { int64_t col = INT64_MIN, end = INT64_MIN; std::vector<uint8_t> cell; };
+  std::unordered_map<int64_t, Spanning> spanning;
   std::vector<Tok> cols, alts, info_kv, fmt_keys, svals, scratch;
   std::vector<uint8_t> body;
   for (const std::string& fn : files) {
@@ -241,7 +247,19 @@ std::vector<uint8_t> import_callsets_to_cells(const VidMapper& vid, const Import
       if (info_find("END", endv)) end = ci.m_tiledb_column_offset + parse_int(endv, "END") - 1;
       else if (opt.treat_deletions_as_intervals)
         for (const Tok& a : alts) if (deletion_indel(ref, a)) { end = col + (int64_t)ref.n - 1; break; }
-      if (col < opt.column_begin || col > opt.column_end) continue;
+      if (col > opt.column_end) continue;
+      const bool before_partition = col < opt.column_begin;
+      if (before_partition) {   // only the latest cell per row at or before the partition begin matters: note it, build the bytes only if it reaches in
+        bool any_candidate = false;
+        for (int s = 0; s < n_samples; ++s) {
+          if (sample_row[(size_t)s] < 0) continue;
+          Spanning& sp = spanning[sample_row[(size_t)s]];
+          if (col >= sp.col) { sp.col = col; sp.end = end; sp.cell.clear(); if (end >= opt.column_begin) any_candidate = true; }
+        }
+        if (!any_candidate) continue;
+      } else if (col == opt.column_begin) {
+        for (int s = 0; s < n_samples; ++s) if (sample_row[(size_t)s] >= 0) { Spanning& sp = spanning[sample_row[(size_t)s]]; sp.col = col; sp.end = end; sp.cell.clear(); }   // a cell AT the begin replaces what spanned it
+      }
       std::string alt_ser;
       for (size_t i = 0; i < alts.size(); ++i) { if (i) alt_ser += '|'; if (tok_is(alts[i], "<NON_REF>")) alt_ser += '&'; else alt_ser.append(alts[i].p, alts[i].n); }
       fmt_keys.clear();
@@ -280,12 +298,29 @@ std::vector<uint8_t> import_callsets_to_cells(const VidMapper& vid, const Import
           else encode_values(body, a, present, v, 1, 0, scratch);
         }
         const uint64_t cell_size = 16 + 8 + body.size();
+        if (before_partition) {
+          Spanning& sp = spanning[sample_row[(size_t)s]];
+          if (sp.col == col && sp.end >= opt.column_begin) {     // still this row's latest: keep the bytes aside
+            sp.cell.clear();
+            put<int64_t>(sp.cell, sample_row[(size_t)s]); put<int64_t>(sp.cell, col); put<uint64_t>(sp.cell, cell_size);
+            sp.cell.insert(sp.cell.end(), body.begin(), body.end());
+          }
+          continue;
+        }
         Cell c{sample_row[(size_t)s], col, bytes.size(), (size_t)cell_size};
         put<int64_t>(bytes, c.row); put<int64_t>(bytes, c.col); put<uint64_t>(bytes, cell_size);
         bytes.insert(bytes.end(), body.begin(), body.end());
         cells.push_back(c);
       }
     }
+  }
+  for (auto& kv : spanning) {
+    const Spanning& sp = kv.second;
+    if (sp.col >= opt.column_begin || sp.end < opt.column_begin || sp.cell.empty()) continue;
+    Cell c{kv.first, sp.col, bytes.size(), sp.cell.size()};
+    bytes.insert(bytes.end(), sp.cell.begin(), sp.cell.end());
+    cells.push_back(c);
+    ++st.num_spanning_cells;
   }
   std::stable_sort(cells.begin(), cells.end(), [](const Cell& a, const Cell& b) { return a.col != b.col ? a.col < b.col : a.row < b.row; });
   std::vector<uint8_t> out;

@@ -33,7 +33,7 @@ struct ImportOptions {
   int64_t column_begin = 0, column_end = INT64_MAX - 1;   // column partition: cells that begin inside are kept
   std::string file_root;                           // prefix of relative "filename" entries of the callset mapping
 };
-struct ImportStats { int64_t num_files = 0, num_records = 0, num_cells = 0; uint64_t num_bytes = 0; };
+struct ImportStats { int64_t num_files = 0, num_records = 0, num_cells = 0, num_spanning_cells = 0; uint64_t num_bytes = 0; };   // num_spanning_cells: intervals replayed at the partition begin
 
 // every callset of vid's callset mapping (file, idx_in_file, row_idx); cells in column-major (column, row) order
 std::vector<uint8_t> import_callsets_to_cells(const VidMapper& vid, const ImportOptions& opt, ImportStats* stats = nullptr);

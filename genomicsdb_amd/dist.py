@@ -70,20 +70,30 @@ def ordered_concat_tensors(local, dst=0):
         return None
     out = torch.empty(sum(sizes), dtype=torch.uint8, device=local.device)
     off = 0
-    for r in range(world):             # receive in rank order: a sender blocks until its turn, the result needs no reordering
-        view = out[off:off + sizes[r]]
+    pending = []
+    for r in range(world):             # every body has its place (prefix sum of the sizes): all receives are posted at once and
+        view = out[off:off + sizes[r]]  # run side by side - over xGMI each sender has its own link to the root
         if r == dst:
             view.copy_(local)
         elif sizes[r]:
-            dist.recv(view, src=r)
+            pending.append(dist.irecv(view, src=r))
         off += sizes[r]
+    for w in pending:
+        w.wait()
     return out
 
 
-def gather_interval(engine, begin, end, arena_bytes=1 << 30, dst=0):
-    """produce-combined-VCF over all ranks: every rank scans + combines its own column interval on its GPU (pages stay in HBM),
-    rank `dst` ends up with the VCF bodies of all partitions in column order as one uint8 tensor in its HBM."""
+def gather_interval(engine, begin, end, arena_bytes=None, dst=0):
+    """produce-combined-VCF over all ranks: every rank scans + combines its own column interval on its GPU, rank `dst` ends up
+    with the VCF bodies of all partitions in column order as one uint8 tensor in its HBM.  A rank's body is assembled as ONE page
+    (the arena grows to the size of the body), so what is sent is the page itself where it lies: no clone, no concatenation;
+    the root copies only its own page into the result."""
     import torch
-    pages = [t.clone() for t in engine.page_tensors(begin, end, arena_bytes)]       # page memory is reused by the next page
-    local = torch.cat(pages) if pages else torch.empty(0, dtype=torch.uint8, device=torch.device("cuda", torch.cuda.current_device()))
+    empty = lambda: torch.empty(0, dtype=torch.uint8, device=torch.device("cuda", torch.cuda.current_device()))
+    if arena_bytes is None:             # one page = the whole body, sent where it lies
+        pages = list(engine.page_tensors(begin, end, 1 << 62))
+        local = pages[0] if pages else empty()
+    else:                               # a caller-limited arena is reused page after page: the pages have to be copied out and joined
+        pages = [t.clone() for t in engine.page_tensors(begin, end, arena_bytes)]
+        local = torch.cat(pages) if pages else empty()
     return ordered_concat_tensors(local, dst=dst)

@@ -31,10 +31,13 @@ static const int64_t lut_missing_value = -1;
 class CombineAllelesLUT {  // include/utils/lut.h:65-343 (input-ordered layout)
  public:
   void resize_luts_if_needed(size_t ncalls, size_t nalleles) {
-    if (i2m_.size() < ncalls) { i2m_.resize(ncalls); m2i_.resize(ncalls); }
+    const bool more_rows = i2m_.size() < ncalls, more_cols = nalleles > ncols_;
+    if (!more_rows && !more_cols && sized_) return;      // (the rows are only walked when something grows: the call is made per allele pair)
+    if (more_rows) { i2m_.resize(ncalls); m2i_.resize(ncalls); }
     ncols_ = std::max(ncols_, nalleles);
     for (auto& v : i2m_) if (v.size() < ncols_) v.resize(ncols_, lut_missing_value);
     for (auto& v : m2i_) if (v.size() < ncols_) v.resize(ncols_, lut_missing_value);
+    sized_ = true;
   }
   void resize_luts_if_needed(size_t nalleles) { resize_luts_if_needed(i2m_.size(), nalleles); }
   void reset_luts() {
@@ -58,6 +61,7 @@ class CombineAllelesLUT {  // include/utils/lut.h:65-343 (input-ordered layout)
  private:
   std::vector<std::vector<int64_t>> i2m_, m2i_;
   size_t ncols_ = 10;
+  bool sized_ = false;
 };
 
 inline int bcf_alleles2gt(int a, int b) { return a > b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; }

@@ -1,0 +1,80 @@
+// gt_mpi_gather_shaped.cc - TEST: a caller written the way the reference's own tool is (tools/src/gt_mpi_gather.cc:322-366
+// scan_and_produce_Broad_GVCF and :531-612 main), with the reference's global class names, compiled against this build's
+// headers and linked to libgenomicsdb_amd.so.  It must compile unchanged in shape and, on a GPU, print the reference's golden.
+//   gt_mpi_gather_shaped <query.json> [page_size]
+#define GENOMICSDB_AMD_GLOBAL_NAMES
+#include "../../genomicsdb_amd/csrc/api/genomicsdb_operators.h"
+
+#include <algorithm>
+#include <iostream>
+
+void scan_and_produce_Broad_GVCF(const VariantQueryProcessor& qp, const VariantQueryConfig& query_config, VCFAdapter& vcf_adapter, const VidMapper& id_mapper,
+                                 int my_world_mpi_rank) {
+  // Read output in batches if required.  Must initialize buffer before constructing gvcf_op
+  RWBuffer rw_buffer;
+  auto serialized_vcf_adapter_ptr = dynamic_cast<VCFSerializedBufferAdapter*>(&vcf_adapter);
+  if (serialized_vcf_adapter_ptr) serialized_vcf_adapter_ptr->set_buffer(rw_buffer);
+  SingleVariantOperatorBase* op_ptr = new BroadCombinedGVCFOperator(vcf_adapter, id_mapper, query_config, query_config.get_max_diploid_alt_alleles_that_can_be_genotyped());
+  // At least 1 iteration
+  VariantQueryProcessorScanState scan_state;
+  for (auto i = 0u; i < std::max(1u, query_config.get_num_column_intervals()); ++i) {
+    while (!scan_state.end()) {
+      qp.scan_and_operate(qp.get_array_descriptor(), query_config, *op_ptr, i, true, &scan_state);
+      if (serialized_vcf_adapter_ptr) {
+        serialized_vcf_adapter_ptr->do_output();
+        rw_buffer.m_num_valid_bytes = 0u;
+      }
+    }
+    scan_state.reset();
+  }
+  (void)my_world_mpi_rank;
+  delete op_ptr;
+}
+
+// an operator of the caller's own: per-record operate() is refused by the device scan, loudly
+class MyPerRecordOperator : public SingleVariantOperatorBase {
+ public:
+  explicit MyPerRecordOperator(const VidMapper* m) : SingleVariantOperatorBase(m) {}
+};
+// ... while the batched hook receives the pages
+class CountingOperator : public BatchedVariantOperatorBase {
+ public:
+  explicit CountingOperator(const VidMapper* m) : BatchedVariantOperatorBase(m) {}
+  void operate_on_page(const char*, uint64_t nbytes, int64_t, int64_t) override { bytes += nbytes; ++pages; }
+  uint64_t bytes = 0; int pages = 0;
+};
+
+int main(int argc, char** argv) {
+  if (argc < 2) { std::cerr << "usage: gt_mpi_gather_shaped <query.json> [page_size]\n"; return -1; }
+  const std::string json_config_file = argv[1];
+  const size_t page_size = argc > 2 ? strtoull(argv[2], 0, 10) : 0u;
+  const int my_world_mpi_rank = 0;
+  try {
+    VariantQueryConfig query_config;
+    VCFAdapter vcf_adapter_base;
+    VCFSerializedBufferAdapter serialized_vcf_adapter(true, true);
+    auto& vcf_adapter = (page_size > 0u) ? dynamic_cast<VCFAdapter&>(serialized_vcf_adapter) : vcf_adapter_base;
+    query_config.read_from_file(json_config_file, my_world_mpi_rank);
+    if (page_size > 0u) query_config.set_combined_vcf_records_buffer_size_limit(page_size);
+    vcf_adapter.initialize(query_config);
+    const std::string workspace = query_config.get_workspace(my_world_mpi_rank);
+    const std::string array_name = query_config.get_array_name(my_world_mpi_rank);
+    VariantStorageManager sm(workspace, 10u * 1024u * 1024u);
+    VariantQueryProcessor qp(&sm, array_name, query_config.get_vid_mapper());
+    qp.do_query_bookkeeping(qp.get_array_schema(), query_config, query_config.get_vid_mapper(), true);
+    scan_and_produce_Broad_GVCF(qp, query_config, vcf_adapter, query_config.get_vid_mapper(), my_world_mpi_rank);
+    if (argc > 3) {   // the other two kinds of operator
+      MyPerRecordOperator mine(&query_config.get_vid_mapper());
+      bool refused = false;
+      try { qp.scan_and_operate(qp.get_array_descriptor(), query_config, mine, 0, true, 0); } catch (const VariantOperationException&) { refused = true; }
+      CountingOperator counter(&query_config.get_vid_mapper());
+      qp.scan_and_operate(qp.get_array_descriptor(), query_config, counter, 0, true, 0);
+      std::cerr << "per-record operator refused: " << (refused ? "yes" : "no") << ", batched hook: " << counter.pages << " pages, " << counter.bytes << " bytes\n";
+    }
+    sm.close_array(qp.get_array_descriptor());
+  } catch (const std::exception& e) {
+    std::cerr << "gt_mpi_gather_shaped: " << e.what() << "\n";
+    return -1;
+  }
+  return 0;
+}

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../genomicsdb_amd/csrc/core/gdb_stages.hpp"
+#include "../../genomicsdb_amd/csrc/core/gdb_bcf.hpp"
 #include "../../genomicsdb_amd/csrc/host/combine_plan.h"
 #include "../../genomicsdb_amd/csrc/host/fragment.h"
 #include "../../genomicsdb_amd/csrc/host/reference_genome.h"
@@ -216,6 +217,28 @@ int hostsim_nth_element_same(const float* values, int64_t n, int64_t nth, int de
     std::__introselect(b.begin(), b.begin() + nth, b.end(), (long)depth_limit, __gnu_cxx::__ops::__iter_less_iter());
   }
   return memcmp(a.data(), b.data(), (size_t)n * sizeof(float)) == 0 ? 1 : 0;
+}
+
+// genotype-order known answers (tests/golden/genotype_tables.json): the device's own enumeration (gdb_next_genotype /
+// gdb_genotype_index / the closed forms of ploidy 1 and 2, as bin_remap_genotypes and emit_remap_genotypes use them) run over an
+// input vector whose element g holds g: out[merged genotype] = input genotype index or -1.  m2i[k] = input allele of merged allele k
+int hostsim_genotype_map(const int32_t* m2i, int num_merged, int nr_in, int ploidy, int64_t* out, int cap) {
+  EntryMaps em;
+  memset(&em, 0, sizeof(em));
+  for (int k = 0; k < GDB_MAX_MERGED_ALLELES; ++k) em.m2i[k] = (int8_t)(k < num_merged ? m2i[k] : -1);
+  em.nr_in = nr_in; em.light = false; em.remap = true;
+  std::vector<int32_t> data(100000);
+  for (size_t i = 0; i < data.size(); ++i) data[i] = (int32_t)i;
+  std::vector<char> buf(4 * 100000);
+  ByteSink bs(buf.data());
+  BinTrack tr;
+  tr.reset();
+  uint32_t err = 0;
+  bin_remap_genotypes(bs, tr, data.data(), (int)data.size(), em, num_merged, ploidy, &err);
+  if (err) return -1;
+  const int n = (int)tr.n;
+  for (int i = 0; i < n && i < cap; ++i) { int32_t v; memcpy(&v, buf.data() + 4 * i, 4); out[i] = v == GDB_BCF_INT32_MISSING ? -1 : v; }
+  return n;
 }
 
 }  // extern "C"

@@ -79,3 +79,13 @@ def test_jni_glue_exports_every_native_method_of_the_java_classes():
     # and it resolves against the product library, nothing else of ours
     needed = subprocess.check_output(["readelf", "-d", so]).decode()
     assert "libgenomicsdb_amd.so" in needed and "oracle" not in needed
+
+
+def test_reference_shaped_cpp_caller_compiles_against_the_operator_headers():
+    """a caller in the shape of tools/src/gt_mpi_gather.cc:322-366 + :531-612 (VariantStorageManager, VariantQueryProcessor,
+    VCFAdapter / VCFSerializedBufferAdapter + RWBuffer, BroadCombinedGVCFOperator, scan_and_operate with a scan state, the
+    reference's global class names) compiles and links against this build (tests/compat); the GPU suite runs it"""
+    import subprocess
+    d = os.path.join(ROOT, "tests", "compat")
+    subprocess.check_call(["make", "-s", "-B", "-C", d])
+    assert os.path.exists(os.path.join(d, "gt_mpi_gather_shaped"))

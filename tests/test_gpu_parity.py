@@ -399,8 +399,8 @@ def test_columnar_fragment_file_round_trip(gdb, tmp_path):
 
 
 def test_differential_fuzz_against_the_oracle(gdb):
-    """40 random synthetic configurations (sample counts, window offsets, dense high-ALT regions, query switches, page sizes,
-    staging in parts) through tests/tools/fuzz.py; 680 further cases were run the same way during round 1 (0 mismatches)"""
+    """40 random synthetic configurations (sample counts, window offsets, dense high-ALT regions, overlapping intervals of one
+    sample, FILTER ids, ID tokens, query switches, page sizes, staging in parts) through tests/tools/fuzz.py"""
     import os
     import subprocess
     import sys
@@ -573,6 +573,8 @@ def test_pages_stay_in_hbm_and_concat_over_rccl(gdb, tmp_path):
     dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
     try:
         whole = gdist.gather_interval(eng, B, B + L - 1, arena_bytes=1 << 20, dst=0)
+        whole_one_page = gdist.gather_interval(eng, B, B + L - 1, dst=0)        # the body as ONE page, sent where it lies
+        assert torch.equal(whole, whole_one_page)
         assert whole.is_cuda and whole.dtype == torch.uint8
         assert bytes(whole.cpu().numpy().tobytes()) == want
     finally:
@@ -959,3 +961,160 @@ def test_bcf_synthetic_widths_and_text_agree(gdb, tmp_path):
         at += len(rec)
     assert ("\n".join(lines) + "\n").encode() == text_body
     assert len(bcf_body) < len(text_body)
+
+
+def test_overlaps_filters_and_ids_on_synthetic_input(gdb, tmp_path):
+    """the generator's overlap / FILTER / ID modes at a size where every record unites several samples: a sample's next record
+    beginning inside its reference block or deletion (overlap override, query_variants.cc:512-543), FILTER unions of one id,
+    sorted ID-token unions; two DIFFERENT filter ids in one record have no pinned order and are refused loudly"""
+    from genomicsdb_amd import synth
+    N, B, L = 400, 10_000_000, 3000
+    g = synth.Generator(N, B, L + 2500, overlap_permille=300, filter_permille=400, id_permille=500, with_id=True)
+    cells, nc = g.chunk_bytes(B + L + 2500)
+    q = helpers.synth_query(tmp_path, N, B + 200, B + L - 300, with_id=True)
+    q["produce_FILTER_field"] = True
+    want, nrec, _ = helpers.oracle_run_synth(q, cells, synth.SEED, with_header=False)
+    lines = [l.split(b"\t") for l in want.split(b"\n") if l]
+    assert sum(1 for l in lines if b";" in l[2]) > 20 and sum(1 for l in lines if l[6] == b"LowQual") > 100
+    eng = gdb.CombineEngine(q)
+    eng.stage_cells(cells)
+    eng.set_reference(B, synth.reference(B, L + 4096))
+    got, st = eng.run_interval(B + 200, B + L - 300, arena_bytes=1 << 22)
+    assert st.num_records == nrec and got == want
+    eng.close()
+    g2 = synth.Generator(N, B, L + 2500, filter_permille=400, filter2_permille=400)
+    cells2, _ = g2.chunk_bytes(B + L + 2500)
+    q2 = helpers.synth_query(tmp_path, N, B + 200, B + L - 300)
+    q2["produce_FILTER_field"] = True
+    eng = gdb.CombineEngine(q2)
+    eng.stage_cells(cells2)
+    with pytest.raises(gdb.GenomicsDBException, match="error bits"):
+        eng.run_interval(B + 200, B + L - 300, arena_bytes=1 << 22)
+    eng.close()
+
+
+def _stream_checksum(eng, begin, end, arena_bytes, split_every=None):
+    """position-weighted checksums of the VCF body of [begin, end], computed on the device where the pages lie (no host copy):
+    independent of how the stream was paged or cut into pieces"""
+    import torch
+    MOD = 1_000_003
+    s1 = s2 = s3 = 0          # exact (Python integers): a chunk's partial sums stay below 2^63, the totals need not
+    offset = 0
+    pieces = [(begin, end)]
+    if split_every:      # cuts that keep the stream byte-identical sit right before a cell begin: the engine names them
+        pieces, cur = [], begin
+        while cur <= end:
+            pe = eng.split_point(cur, end, split_every)
+            pieces.append((cur, pe))
+            cur = pe + 1
+    npages = 0
+    for pb, pe in pieces:
+        for page in eng.page_tensors(pb, pe, arena_bytes=arena_bytes):
+            npages += 1
+            n = page.numel()
+            for c0 in range(0, n, 1 << 28):
+                x = page[c0:c0 + (1 << 28)].to(torch.int64)
+                w = (torch.arange(offset + c0, offset + c0 + x.numel(), device="cuda", dtype=torch.int64) % MOD) + 1
+                s1 += int(x.sum())
+                s2 += int((x * w).sum())
+                s3 += int(((x == 10).to(torch.int64) * w).sum())      # newline positions: the record boundaries
+            offset += n
+    return offset, s1, s2, s3, npages
+
+
+def test_c2_full_size_two_pagings_agree(gdb, tmp_path):
+    """BASELINE.json configs[1] at its full size - 1 000 samples x 10 Mb, the workload bench.py times: ten 1 Mb windows with one
+    44 GB page each against 500 kb pieces in 3 GB pages; byte count, byte sum and two position-weighted checksums of the stream,
+    taken on the device, must agree (the oracle needs hours for this size; at 1 500 bp it is compared byte for byte)"""
+    import torch
+    from genomicsdb_amd import synth
+    N, B, L = 1000, 10_000_000, 10_000_000
+    q = helpers.synth_query(tmp_path, N, B, B + L - 1)
+    eng = gdb.CombineEngine(q)
+    g = synth.Generator(N, B, L)
+    eng.stage_cells_begin()
+    col = B
+    while col < B + L:
+        col = min(B + L, col + 1_000_000)
+        ptr, nbytes, nc = g.next_chunk(col)
+        eng.stage_cells_append(ptr, nbytes)
+    eng.stage_cells_end()
+    g.close()
+    eng.set_reference(B, synth.reference(B, L + 4096))
+    totals_a, totals_b = [], []
+    for w in range(10):
+        wb, we = B + w * 1_000_000, B + (w + 1) * 1_000_000 - 1
+        totals_a.append(_stream_checksum(eng, wb, we, 48 << 30))
+        totals_b.append(_stream_checksum(eng, wb, we, 3 << 30, split_every=500_000))
+        assert totals_a[-1][4] == 1 and totals_b[-1][4] > 10
+        assert totals_a[-1][:4] == totals_b[-1][:4], "window %d" % w
+        assert totals_a[-1][0] > 40e9
+    eng.close()
+
+
+def test_c4_sample_count_100000_rows_matches_oracle(gdb, tmp_path):
+    """BASELINE.json configs[3]'s sample count on a narrow window: 100 000 samples (1 563 chunks of 64 sample columns, a first
+    record with 100 000 calls starting at the partition begin - allele merge, medians and sums by its workgroup), 24 columns"""
+    from genomicsdb_amd import synth
+    N, B, L = 100_000, 10_000_000, 24
+    g = synth.Generator(N, B, 400)
+    cells, nc = g.chunk_bytes(B + 400)
+    g.close()
+    q = helpers.synth_query(tmp_path, N, B, B + L - 1)
+    want, nrec, _ = helpers.oracle_run_synth(q, cells, synth.SEED, with_header=False)
+    eng = gdb.CombineEngine(q)
+    eng.stage_cells(cells)
+    eng.set_reference(B, synth.reference(B, 4096))
+    got, st = eng.run_interval(B, B + L - 1, arena_bytes=64 << 20)
+    assert st.num_records == nrec and st.pages > 1
+    assert got == want
+    eng.close()
+
+
+def test_partitions_imported_separately_concatenate_to_the_whole_scan(gdb):
+    """two column partitions imported on their own (the second one begins at 12202, inside reference blocks of all three samples:
+    the importer replays those intervals at the partition begin, load_operators.cc:33-79) and scanned on the device; their
+    bodies back to back = one scan of the whole array over the query intervals [0, 12201], [12202, ...]"""
+    import os
+    v = os.path.join(helpers.GOLDEN, "inputs", "vid.json")
+    c = os.path.join(helpers.GOLDEN, "inputs", "callsets", "t0_1_2.json")
+    bodies = []
+    for begin, end in ((0, 12201), (12202, 2**62)):
+        cells, ncells = gdb.import_cells(v, c, file_root=helpers.GOLDEN, column_begin=begin, column_end=end)
+        qj, _ = helpers.query_json("t0_1_2.json", "vid.json", {"query_column_ranges": [[[begin, min(end, 1_000_000_000)]]]}, "query")
+        e = gdb.CombineEngine(qj)
+        e.stage_cells(cells)
+        body, st = e.run_interval(begin, min(end, 1_000_000_000), arena_bytes=1 << 20)
+        bodies.append(body)
+        e.close()
+    full = helpers.cells_for("t0_1_2.json", "vid.json")
+    qj, _ = helpers.query_json("t0_1_2.json", "vid.json", {"query_column_ranges": [[[0, 12201], [12202, 1_000_000_000]]]}, "query")
+    want, nrec, _ = helpers.oracle_run(qj, full, with_header=False)
+    assert b"".join(bodies) == want
+
+
+def test_reference_shaped_cpp_caller_produces_the_golden(gdb, tmp_path):
+    """tests/compat/gt_mpi_gather_shaped (a C++ caller in the shape of the reference's tool, on the source-compatible operator
+    classes): stdout is the golden, in one go and in 128-byte batches through VCFSerializedBufferAdapter + RWBuffer; a per-record
+    operator of the caller's own is refused, the batched hook gets the pages"""
+    import json
+    import os
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(helpers.ROOT, "tests", "compat")])
+    tool = os.path.join(helpers.ROOT, "tests", "compat", "gt_mpi_gather_shaped")
+    case = [c for c in CASES if c[0] == "t0_1_2_vcf_at_0"][0]
+    _, callsets, vid, ov, golden, mode = case
+    q, _ = helpers.query_json(callsets, vid, ov, mode)
+    ws = tmp_path / "ws"
+    (ws / "t0_1_2").mkdir(parents=True)
+    (ws / "t0_1_2" / "cells.bin").write_bytes(helpers.cells_for(callsets, vid))
+    q["workspace"] = str(ws)
+    q["array"] = "t0_1_2"
+    qf = tmp_path / "query.json"
+    qf.write_text(json.dumps(q))
+    for page in ("0", "128"):
+        r = subprocess.run([tool, str(qf), page], capture_output=True, timeout=120)
+        assert r.returncode == 0, r.stderr.decode()
+        assert r.stdout == helpers.golden_text(golden)
+    r = subprocess.run([tool, str(qf), "0", "more"], capture_output=True, timeout=120)
+    assert r.returncode == 0 and b"per-record operator refused: yes" in r.stderr and b"batched hook: 1 pages" in r.stderr

@@ -81,3 +81,54 @@ def test_two_ranks_partition_reduce_concat():
     body_golden = b"".join(l for l in golden.splitlines(True) if not l.startswith(b"#"))
     assert whole0.endswith(body_golden) and n1 == body_golden.count(b"\n")
     assert whole0.count(b"\n") == n0 + n1
+
+
+def _import_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import genomicsdb_amd
+    from genomicsdb_amd import dist as gdist
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        # every rank IMPORTS its own column partition from the gVCFs (like one rank of `mpirun -n 2 vcf2tiledb`): the cells that
+        # begin in it plus, replayed first, the intervals that begin before it and reach into it
+        begin, end = gdist.column_partition(json.dumps(LOADER), rank)
+        v = os.path.join(helpers.GOLDEN, "inputs", "vid.json")
+        c = os.path.join(helpers.GOLDEN, "inputs", "callsets", "t0_1_2.json")
+        cells, ncells = genomicsdb_amd.import_cells(v, c, file_root=helpers.GOLDEN, column_begin=begin, column_end=min(end, 2**62))
+        qj, _ = helpers.query_json("t0_1_2.json", "vid.json", {"query_column_ranges": [[[begin, min(end, 1_000_000_000)]]]}, "query")
+        body, nrec, _ = helpers.oracle_run(qj, cells, partition_begin=begin, with_header=False)     # (the oracle is the checker of this CPU test)
+        whole = gdist.ordered_concat(body)
+        q.put((rank, begin, ncells, nrec, whole))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_import_their_partitions_and_concat():
+    """partition-boundary replay end to end: rank 1's partition begins at 12202, inside reference blocks of all three samples;
+    the concatenation of the two partition scans must be what ONE scan of the whole array gives for the two query intervals
+    [0, 12201] and [12202, ...] - the interval that crosses the boundary is split there in both"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_import_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, b0, nc0, n0, whole0), (_, b1, nc1, n1, whole1) = res
+    cells = helpers.cells_for("t0_1_2.json", "vid.json")
+    qj, _ = helpers.query_json("t0_1_2.json", "vid.json", {"query_column_ranges": [[[0, 12201], [12202, 1_000_000_000]]]}, "query")
+    want, nrec, _ = helpers.oracle_run(qj, cells, with_header=False)
+    assert whole1 is None and whole0 == want and n0 + n1 == nrec
+    import struct
+    off, ncells_full = 0, 0
+    while off < len(cells):
+        off += struct.unpack_from("<Q", cells, off + 16)[0]
+        ncells_full += 1
+    assert nc0 + nc1 > ncells_full          # the replayed intervals exist in both partitions

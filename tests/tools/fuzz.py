@@ -30,9 +30,16 @@ for case in range(ncases):
     arena = rnd.choice([1 << 12, 1 << 16, 1 << 20, 1 << 26])
     tmp = tempfile.mkdtemp()
     rs_scale = rnd.choice([None, None, 1.0, 2.0, 10.0])      # coarse rank sums: tied medians, zeros of both signs
-    g = synth.Generator(N, B, off + L + 2500, seed=gseed, dense=dense, rank_sum_scale=rs_scale)
+    # generator modes: overlapping intervals of one sample (the scan's overlap override), FILTER ids on the variant cells (one id:
+    # unions of equal ids across samples), ID tokens (sorted union, one or two tokens per call; the schema gains an ID attribute)
+    modes = {}
+    if rnd.random() < 0.4: modes["overlap_permille"] = rnd.choice([30, 150, 400])
+    if rnd.random() < 0.3: modes["filter_permille"] = rnd.choice([100, 500]); opts["produce_FILTER_field"] = True
+    with_id = rnd.random() < 0.3
+    if with_id: modes["id_permille"] = rnd.choice([100, 600]); modes["with_id"] = True
+    g = synth.Generator(N, B, off + L + 2500, seed=gseed, dense=dense, rank_sum_scale=rs_scale, **modes)
     cells, nc = g.chunk_bytes(B + off + L + 2500)
-    q = helpers.synth_query(tmp, N, qb, qe)
+    q = helpers.synth_query(tmp, N, qb, qe, with_id=with_id)
     q.update(opts)
     want, nrec, _ = helpers.oracle_run_synth(q, cells, gseed, with_header=False)
     eng = genomicsdb_amd.CombineEngine(q)
@@ -67,6 +74,6 @@ for case in range(ncases):
     eng.close()
     if not ok:
         bad += 1
-        print("MISMATCH case %d: N=%d L=%d B=%d off=%d seed=%d dense=%s rs_scale=%s opts=%s arena=%d parts=%d records %d/%d" % (case, N, L, B, off, gseed, dense, rs_scale, opts, arena, nparts, st.num_records, nrec), flush=True)
+        print("MISMATCH case %d: N=%d L=%d B=%d off=%d seed=%d dense=%s rs_scale=%s opts=%s modes=%s arena=%d parts=%d records %d/%d" % (case, N, L, B, off, gseed, dense, rs_scale, opts, modes, arena, nparts, st.num_records, nrec), flush=True)
 print("fuzz: %d cases, %d mismatches, %.0f s" % (ncases, bad, time.time() - t00))
 sys.exit(1 if bad else 0)
