@@ -79,6 +79,7 @@ inline int event_run_length() { const char* e = getenv("GDBAMD_EV_RUN"); return 
 inline bool events_enabled() { const char* e = getenv("GDBAMD_EVENTS"); return e && *e && *e != '0'; }
 // wavefronts (= neighbouring 64-sample chunks) per workgroup of the page assembly: 4 measured best on the store-only model
 inline int write_waves_per_group() { const char* e = getenv("GDBAMD_WRITE_WAVES"); return e && *e ? atoi(e) : 1; }
+inline bool xcd_aware_numbering() { const char* e = getenv("GDBAMD_XCD_AWARE"); return !(e && *e == '0'); }
 inline int write_image_kb() { const char* e = getenv("GDBAMD_WRITE_IMAGE_KB"); return e && *e ? atoi(e) : 8; }
 inline int order_block_log2() {
   const char* e = getenv("GDBAMD_ORDER_BLOCK_LOG2");
@@ -1183,17 +1184,17 @@ struct SlotText { uint4 x[kTextChunks]; };
 // chunk - were written from 8 different L2s.  A store-only kernel of exactly this shape (tests/tools/microbench/store_bw.hip)
 // goes from 3.4 to 4.6 TB/s when the numbering keeps the chunks of a record run on one XCD, and to 5.1 TB/s with 4 neighbouring
 // chunks per workgroup (4 wavefronts, one LDS image each, still no barrier); the page assembly sat exactly on the 3.4.
-template <int WAVES> __device__ __forceinline__ int64_t xcd_aware_unit(int64_t total_units) {
+template <int WAVES> __device__ __forceinline__ int64_t xcd_aware_unit(int64_t total_units, int xcd_aware = 1) {
   const unsigned nb = gridDim.x, per = nb / 8u;
-  const unsigned lb = blockIdx.x < per * 8u ? (blockIdx.x % 8u) * per + blockIdx.x / 8u : blockIdx.x;
+  const unsigned lb = (xcd_aware && blockIdx.x < per * 8u) ? (blockIdx.x % 8u) * per + blockIdx.x / 8u : blockIdx.x;
   const int64_t u = (int64_t)lb * WAVES + (int64_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform: scalar registers)
   return u < total_units ? u : -1;
 }
 template <int WAVES, int kWaveLds> __global__ void __launch_bounds__(kAsmRows * WAVES)
 k_assemble_write(const char* __restrict__ pool, const char* __restrict__ pool_ovf, const uint32_t* __restrict__ prefix_len, const uint2* __restrict__ resolved, int64_t resolved_base,
                  const int32_t* __restrict__ order, int64_t n, int nchunks, int run, const uint64_t* __restrict__ chunk_off, uint64_t page_base,
-                 char* __restrict__ arena) {
-  const int64_t unit = xcd_aware_unit<WAVES>(((n + run - 1) / run) * (int64_t)nchunks);
+                 char* __restrict__ arena, int xcd_aware) {
+  const int64_t unit = xcd_aware_unit<WAVES>(((n + run - 1) / run) * (int64_t)nchunks, xcd_aware);
   if (unit < 0) return;
   const int64_t ib = (unit / nchunks) * run;
   const int64_t ie = min(n, ib + (int64_t)run);
@@ -3248,7 +3249,7 @@ bool DevicePipeline::begin_page(uint64_t arena_bytes, int arena_idx, PageTicket*
   }
   HIP_CHECK(hipEventRecord(w[1], st));   // [w1, w2] brackets the page-assembly kernel alone (its duration feeds the roofline figure)
 #define GDB_LAUNCH_WRITE(W, L) hipLaunchKernelGGL((k_assemble_write<W, L>), dim3((wgrid.x + (W) - 1u) / (W)), dim3(kAsmRows * (W)), 0, st, (const char*)S.pool.p, (const char*)S.pool_ovf.p, \
-    (const uint32_t*)S.prefix_len.p, (const uint2*)S.resolved.p, iv.resolved_whole ? (int64_t)0 : kp, (const int32_t*)S.order.p, np, iv.nchunks, wrun, (const uint64_t*)S.chunk_off.p, page_base, arena)
+    (const uint32_t*)S.prefix_len.p, (const uint2*)S.resolved.p, iv.resolved_whole ? (int64_t)0 : kp, (const int32_t*)S.order.p, np, iv.nchunks, wrun, (const uint64_t*)S.chunk_off.p, page_base, arena, xcd_aware_numbering() ? 1 : 0)
   {
     const int ww = write_waves_per_group(), wl = write_image_kb();
     if (ww >= 4 && wl <= 4) GDB_LAUNCH_WRITE(4, 4096);
