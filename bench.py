@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--interval-bp", type=int, default=10_000_000)
     ap.add_argument("--window-bp", type=int, default=1_000_000, help="columns per step (one batch); 1 Mb = 44.6 GB of VCF text at 1 000 samples")
     ap.add_argument("--arena-mb", type=int, default=49152, help="HBM page for the output text (one page per window at the defaults)")
+    ap.add_argument("--bcf", action="store_true", help="pages of BCF2 records (output format \"bu\") instead of VCF text; not the headline configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stream-input", action="store_true",
                     help="c3 shape: the array is NOT resident - its cells pass through HBM in column windows of the staging budget "
@@ -76,7 +77,7 @@ def main():
     need_bp = min(Lbp, W * min(nwin, total_steps))  # stage only the windows the run will touch
     tmp = tempfile.mkdtemp(prefix="gdbamd_bench_")
     q = helpers.synth_query(tmp, N, B, B + Lbp - 1)
-    eng = genomicsdb_amd.CombineEngine(q, device=device_index)
+    eng = genomicsdb_amd.CombineEngine(q, device=device_index, is_bcf=args.bcf)
 
     # ---- generate + stage (not timed): cells -> columnar fragment in HBM, in 1 Mb parts ---------------------------------
     t0 = time.time()
@@ -140,7 +141,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/int32", "data": "synthetic",
             "config": {"workload": "c2: %d synthetic-gVCF samples x %d bp (BASELINE.json configs[1]); step = one %d bp column window"
-                       % (N, Lbp, W), "samples": N, "interval_bp": Lbp, "window_bp": W, "output": "VCF text, bit-exact",
+                       % (N, Lbp, W), "samples": N, "interval_bp": Lbp, "window_bp": W, "output": "BCF2 records (bu)" if args.bcf else "VCF text, bit-exact",
                        "partition_per_gpu": True},
             "cells_per_sec": cells_all / dt,
             "bytes_out_per_position": bo_all / max(1.0, recs_all),
@@ -148,11 +149,12 @@ def main():
             "whole_path_GBps": (bo_all + bi_all) / dt / 1e9,
             "phase_ms": {k: v / args.steps for k, v in ms.items()},
             "stage_seconds_untimed": t_stage,
-            "roofline": {"bound": "hbm", "kernel": "k_assemble_write", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(N, W, arena),
+            "roofline": {"bound": "hbm", "kernel": "k_bcf_write" if args.bcf else "k_assemble_write", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None if args.bcf else pmc_traffic(N, W, arena),
                          "alg_bytes_per_launch": alg_bytes_per_launch, "avg_launch_ms": avg_ms, "launches": int(launches)},
         }
-        if not args.no_stream and world == 1:         # the boundary GATK drives: header + body through gdb_mi355_read
+        if not args.no_stream and world == 1 and not args.bcf:         # the boundary GATK drives: header + body through gdb_mi355_read
+            eng.close()                                                 # (the timed engine's HBM - fragment, 48 GB arena, tables - is given back first)
             out["stream_end_to_end"] = stream_end_to_end(N, B, min(W, Lbp), tmp, expect_body_bytes=None)
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(N, args.cpu_sample_bp, tmp)
@@ -317,15 +319,27 @@ def stream_end_to_end(N, B, W, tmp, expect_body_bytes=None):
     }
 
 
+def kernel_source_hash():
+    """what the traffic file is tied to: the sources the kernels are compiled from"""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ("genomicsdb_amd/csrc/kernels/gdb_pipeline.hip", "genomicsdb_amd/csrc/core/gdb_core.hpp", "genomicsdb_amd/csrc/core/gdb_stages.hpp",
+                "genomicsdb_amd/csrc/core/gdb_bcf.hpp", "genomicsdb_amd/csrc/core/gdb_types.h"):
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(N, W, arena):
     """HBM bytes per k_assemble_write launch from the rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate passes,
-    MI355X_MICROARCH.md 'HBM'): measured with tests/tools/prof_traffic.sh on this very configuration and committed under
-    profiles/; null for any other configuration."""
-    path = os.path.join(ROOT, "profiles", "r1_traffic.json")
+    MI355X_MICROARCH.md 'HBM'), measured with tests/tools/prof_traffic.sh on this very configuration and committed as
+    profiles/traffic.json together with the hash of the kernel sources it was measured on.  null when the file was made for
+    another configuration or the kernel sources have changed since (a stale figure is worse than none)."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
-        if t.get("samples") == N and t.get("window_bp") == W and t.get("arena_bytes") == arena:
+        if t.get("samples") == N and t.get("window_bp") == W and t.get("arena_bytes") == arena and t.get("kernel_source_hash") == kernel_source_hash():
             return t["k_assemble_write"]["hbm_bytes_per_launch"]
     except Exception:
         pass

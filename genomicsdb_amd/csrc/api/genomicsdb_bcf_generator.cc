@@ -371,10 +371,19 @@ bool GenomicsDBBCFGenerator::advance_page() {
       // begins, where the sweep closes its interval anyway, so the stream is byte-identical to the unsplit one
       if (m_piece_begin < qb || m_piece_begin > qe) m_piece_begin = qb;
       // (an array larger than the staging budget passes through HBM in column windows: a piece ends where the staged window does)
+      const bool trace = getenv("GDBAMD_STREAM_TRACE") != nullptr;
+      auto now = []() { return std::chrono::steady_clock::now(); };
+      auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+      const auto t0 = now();
       const CombineEngine::Coverage cov = m_engine->cover(m_piece_begin);
+      const auto t1 = now();
       const int64_t pe = pipe.split_point(m_piece_begin, std::min(qe, cov.hi), max_window_columns());
+      const auto t2 = now();
       m_engine->stage_reference_for(m_piece_begin, pe);
+      const auto t3 = now();
       pipe.prepare_interval(m_piece_begin, pe);
+      if (trace) fprintf(stderr, "[gdbamd stream] piece [%lld, %lld]: cover %.3f s, split_point %.3f s, reference %.3f s, prepare_interval %.3f s\n", (long long)m_piece_begin, (long long)pe,
+                         secs(t0, t1), secs(t1, t2), secs(t2, t3), secs(t3, now()));
       m_piece_end = pe;
       m_interval_end = qe;
       m_interval_active = true;

@@ -2,8 +2,9 @@
 //
 // Same roles as the text emitters of gdb_core.hpp (entry_emit / emit_field): what a live call contributes to a record of a given
 // type, computed once per (cell, record type) / (record, variant call) / no-call slot - here as a small binary entry:
-//     u32 summary[nf]            one word per FORMAT field of the record type, in emission order:
-//                                bits 0..15 element count n (0: the call has no value for this field), bits 16..17 integer
+//     u16 summary[nf]            one per FORMAT field of the record type, in emission order (padded to a multiple of 4 bytes;
+//                                up to 8 fields arrive with the entry's first 16-byte load):
+//                                bits 0..13 element count n (0: the call has no value for this field), bits 14..15 integer
 //                                class (0 int8, 1 int16, 2 int32: the narrowest BCF type that holds the call's values)
 //     body                       the n elements of every field back to back: int32 / float as 4 bytes, char as 1 byte
 // The page assembly reduces the summaries of the N samples of a record to the per-(record, field) vector length and type
@@ -19,7 +20,7 @@ struct BinTrack {            // running summary of the field being emitted
   int32_t mn, mx;
   GDB_HD void reset() { n = 0; mn = INT32_MAX; mx = INT32_MIN + 1; }
   GDB_HD void see(int32_t v) { if (v != GDB_BCF_INT32_MISSING && v != GDB_BCF_INT32_VECTOR_END) { if (v < mn) mn = v; if (v > mx) mx = v; } }
-  GDB_HD uint32_t word() const { const int t = bcf_int_type(mn, mx); return (n & 0xFFFFu) | ((uint32_t)(t - GDB_BT_INT8) << 16); }
+  GDB_HD uint32_t word() const { const int t = bcf_int_type(mn, mx); return (n & 0x3FFFu) | ((uint32_t)(t - GDB_BT_INT8) << 14); }
 };
 template <class Sink> GDB_HD void bin_put_i32(Sink& s, BinTrack& tr, int32_t v) { bcf_put_u32(s, (uint32_t)v); tr.see(v); ++tr.n; }
 template <class Sink> GDB_HD void bin_put_f32(Sink& s, BinTrack& tr, float v) { bcf_put_u32(s, gdb_f2u(v)); ++tr.n; }
@@ -124,28 +125,35 @@ template <class Sink> GDB_HD Sink entry_emit_bin(const EntryCtx& cx, const Recor
   int nf = 0;
   for (uint32_t m = ri.fmt_mask; m; m &= m - 1) ++nf;
   const uint32_t hdr_at = s.pos();
-  for (int q = 0; q < nf; ++q) bcf_put_u32(s, 0u);
+  for (int q = 0; q < nf; q += 2) bcf_put_u32(s, 0u);
   int q = 0;
+  uint32_t pair = 0;          // the summaries of fields q & ~1 and q | 1
   for (int i = 0; i < pl.n_format; ++i) {
     if (!((ri.fmt_mask >> i) & 1)) continue;
     if (c >= 0) {
       BinTrack tr;
       tr.reset();
       bin_field(s, tr, cx, ri, em, i, c, err);
-      if (tr.n > 0xFFFFu) *err |= GDB_ERR_INTERNAL;
-      if (tr.n) s.patch_u32(hdr_at + 4u * (uint32_t)q, tr.word());
+      if (tr.n > 0x3FFFu) *err |= GDB_ERR_INTERNAL;
+      if (tr.n) pair |= tr.word() << (16 * (q & 1));
+    }
+    if ((q & 1) || q == nf - 1) {
+      if (pair) s.patch_u32(hdr_at + 4u * (uint32_t)(q >> 1), pair);
+      pair = 0;
     }
     ++q;
   }
   return s;
 }
+GDB_HD uint32_t bcf_summary_bytes(int nf) { return ((uint32_t)nf * 2u + 3u) & ~3u; }
+GDB_HD uint32_t bcf_summary_n(uint32_t s) { return s & 0x3FFFu; }
+GDB_HD uint32_t bcf_summary_class(uint32_t s) { return (s & 0x8000u) ? 2u : ((s >> 14) & 1u); }   // (a maximum kept as an OR of the two bits)
 
 // ---- per-(record, field) layout of the FORMAT block ------------------------------------------------------------------------
-// what the N summaries of a record's samples reduce to, per FORMAT field: bits 0..15 = longest vector, 16..17 = widest class
+// what the N summaries of a record's samples reduce to, per FORMAT field: bits 0..13 = longest vector, 14..15 = OR of the classes
 GDB_HD uint32_t bcf_summary_max(uint32_t a, uint32_t b) {
-  const uint32_t n = (a & 0xFFFFu) > (b & 0xFFFFu) ? (a & 0xFFFFu) : (b & 0xFFFFu);
-  const uint32_t c = (a >> 16) > (b >> 16) ? (a >> 16) : (b >> 16);
-  return n | (c << 16);
+  const uint32_t n = (a & 0x3FFFu) > (b & 0x3FFFu) ? (a & 0x3FFFu) : (b & 0x3FFFu);
+  return n | ((a | b) & 0xC000u);
 }
 GDB_HD int bcf_field_elem_size(const CombinePlan& pl, int fmt_i) {
   const int f = pl.format_field[fmt_i];
@@ -157,5 +165,5 @@ GDB_HD int bcf_field_type(const CombinePlan& pl, int fmt_i, uint32_t summary) { 
   const int e = (f == pl.f_DP && pl.f_DP_FORMAT >= 0) ? GDB_ET_INT : pl.field[f].elem;
   if (e == GDB_ET_CHAR || e == GDB_ET_FLAG) return GDB_BT_CHAR;
   if (e == GDB_ET_FLOAT) return GDB_BT_FLOAT;
-  return GDB_BT_INT8 + (int)((summary >> 16) & 3u);
+  return GDB_BT_INT8 + (int)bcf_summary_class(summary);
 }

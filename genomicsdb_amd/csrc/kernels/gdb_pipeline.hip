@@ -1512,20 +1512,47 @@ k_assemble_write_ev(const char* __restrict__ pool, const char* __restrict__ pool
 // type of every (record, field) are known a sample's values have a fixed place: no scan over variable-length texts.
 // k_bcf_field_meta reduces the entries' summaries per (record, 64-sample chunk), k_bcf_layout per record (and sizes the record),
 // k_bcf_shared writes l_shared / l_indiv, the shared block and the key + type bytes of every field, k_bcf_write the values.
+constexpr int kBcfRun = 32;        // records one wavefront of the BCF kernels takes in a row (same chunk)
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+// maximum over the wavefront of a pair of 16-bit summaries (vector length: maximum; class bits: OR)
+__device__ __forceinline__ uint32_t bcf_pair_reduce(uint32_t v) {
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
+    const u16x2 n = __builtin_elementwise_max(__builtin_bit_cast(u16x2, v & 0x3FFF3FFFu), __builtin_bit_cast(u16x2, o & 0x3FFF3FFFu));
+    v = __builtin_bit_cast(uint32_t, n) | ((v | o) & 0xC000C000u);
+  }
+  return v;
+}
+// part[(record, chunk)][pair word]: a lane's entry rarely changes from one record to the next (a call spans many records), so the
+// summary words stay in registers and only the lanes whose entry changed go to memory.
 __global__ void __launch_bounds__(kAsmRows) k_bcf_field_meta(const uint2* __restrict__ resolved, const char* __restrict__ pool, const char* __restrict__ pool_ovf,
-                                                           const uint32_t* __restrict__ fmt_mask, int nchunks, int F, uint32_t* __restrict__ part) {
-  const int64_t rc = blockIdx.x;                       // record * nchunks + chunk
-  const int64_t k = rc / nchunks;
+                                                           const uint32_t* __restrict__ fmt_mask, int64_t P, int nchunks, int F, uint32_t* __restrict__ part) {
+  const int64_t unit = xcd_aware_unit<1>(((P + kBcfRun - 1) / kBcfRun) * (int64_t)nchunks);
+  if (unit < 0) return;
+  const int64_t k0 = (unit / nchunks) * kBcfRun, k1 = min(P, k0 + (int64_t)kBcfRun);
+  const int ch = (int)(unit % nchunks);
   const int lane = threadIdx.x;
-  const uint2 d = resolved[rc * kAsmRows + lane];
-  const char* src = ((d.x & kOverflowBit) ? pool_ovf : pool) + (size_t)(d.x & ~kOverflowBit) * 16;
-  const int nf = __popc(fmt_mask[k]);
-  for (int q = 0; q < nf; ++q) {                        // uniform
-    uint32_t w = d.y ? reinterpret_cast<const uint32_t*>(src)[q] : 0u;   // (entries are 16-byte aligned)
-    uint32_t n = w & 0xFFFFu;
-    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)n, off, 64); n = o > n ? o : n; }
-    const uint32_t cls = __any((int)((w >> 16) >= 2u)) ? 2u : (__any((int)((w >> 16) >= 1u)) ? 1u : 0u);
-    if (lane == 0) part[rc * F + q] = n | (cls << 16);
+  const int W = (F + 1) >> 1;
+  uint32_t held = 0xFFFFFFFFu;        // the entry whose first 16 bytes are in h
+  u32x4 h = {0u, 0u, 0u, 0u};
+  for (int64_t k = k0; k < k1; ++k) {                    // uniform
+    const int64_t rc = k * nchunks + ch;
+    const uint2 d = resolved[rc * kAsmRows + lane];
+    const char* src = ((d.x & kOverflowBit) ? pool_ovf : pool) + (size_t)(d.x & ~kOverflowBit) * 16;
+    const int words = (__popc(fmt_mask[k]) + 1) >> 1;
+    if (d.y && d.x != held) { h = *reinterpret_cast<const u32x4*>(src); held = d.x; }   // (entries are 16-byte aligned and padded)
+    uint32_t mine = 0;
+    for (int w0 = 0; w0 < words; w0 += 4) {               // uniform
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (d.y) v = w0 == 0 ? h : *reinterpret_cast<const u32x4*>(src + 4 * w0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (w0 + c >= words) break;
+        const uint32_t r = bcf_pair_reduce(v[c]);
+        if (lane == w0 + c) mine = r;
+      }
+    }
+    if (lane < words) part[rc * W + lane] = mine;
   }
 }
 struct BcfLayout {            // per record
@@ -1539,15 +1566,16 @@ __global__ void k_bcf_layout(CombinePlan pl, const uint32_t* __restrict__ part, 
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= P) return;
   const uint32_t mask = fmt_mask[k];
+  const int W = (F + 1) >> 1;
   uint32_t at = 8u + prefix_len[k];              // l_shared, l_indiv, shared block
   const uint32_t indiv_begin = at;
   int q = 0;
   for (int i = 0; i < pl.n_format; ++i) {
     if (!((mask >> i) & 1u)) continue;
     uint32_t sum = 0;
-    for (int ch = 0; ch < nchunks; ++ch) sum = bcf_summary_max(sum, part[(k * nchunks + ch) * F + q]);
+    for (int ch = 0; ch < nchunks; ++ch) sum = bcf_summary_max(sum, (part[(k * nchunks + ch) * W + (q >> 1)] >> (16 * (q & 1))) & 0xFFFFu);
     const int t = bcf_field_type(pl, i, sum);
-    const uint32_t cnt = (sum & 0xFFFFu) ? (sum & 0xFFFFu) : 1u;   // (a field in the mask has a value somewhere; 1 keeps the layout sane otherwise)
+    const uint32_t cnt = bcf_summary_n(sum) ? bcf_summary_n(sum) : 1u;   // (a field in the mask has a value somewhere; 1 keeps the layout sane otherwise)
     const int f = pl.format_field[i];
     const int32_t key = (f == pl.f_DP && pl.f_DP_FORMAT >= 0) ? pl.bcf_dp_id : pl.bcf_id[f];
     const uint32_t hdr = (uint32_t)bcf_enc_int1_bytes(key) + (uint32_t)bcf_enc_size_bytes((int)cnt);
@@ -1604,56 +1632,102 @@ __global__ void k_bcf_shared(const SiteCtx* __restrict__ sxp, const char* __rest
   }
   if (e) atomicOr(err, e);
 }
-// values: one wavefront = one record x 64 samples; every lane converts its entry's elements of field q to the record's type
-// and pads up to the record's vector length (collect_and_extend_fields, variant_field_handler.cc:846-866)
-__global__ void __launch_bounds__(kAsmRows) k_bcf_write(CombinePlan pl, const uint2* __restrict__ resolved, const char* __restrict__ pool, const char* __restrict__ pool_ovf,
-                                                      const uint32_t* __restrict__ fmt_mask, int64_t k_begin, int nchunks, int F, int32_t N, BcfLayout lay,
-                                                      const uint64_t* __restrict__ rec_off, uint64_t page_base, char* __restrict__ arena) {
-  const int64_t k = k_begin + (int64_t)(blockIdx.x / (unsigned)nchunks);
-  const int ch = (int)(blockIdx.x % (unsigned)nchunks);
-  const int lane = threadIdx.x;
-  const int32_t r = ch * kAsmRows + lane;
-  const uint2 d = resolved[(k * nchunks + ch) * kAsmRows + lane];
-  const char* src = ((d.x & kOverflowBit) ? pool_ovf : pool) + (size_t)(d.x & ~kOverflowBit) * 16;
-  const uint32_t mask = fmt_mask[k];
-  const int nf = __popc(mask);
-  char* rec = arena + (rec_off[k] - page_base);
-  uint32_t body = 4u * (uint32_t)nf;            // this lane's read position inside its entry
-  const bool flag = pl.use_missing_values_not_vector_end != 0;
-  int q = 0;
-  for (int i = 0; i < pl.n_format; ++i) {       // uniform
-    if (!((mask >> i) & 1u)) continue;
-    const uint32_t m = lay.fmeta[k * F + q];
-    const uint32_t cnt = m & 0xFFFFu, t = (m >> 16) & 0xFu, hdr = m >> 24;
-    const uint32_t w = (uint32_t)bcf_type_width((int)t);
-    const int es = bcf_field_elem_size(pl, i);
-    const uint32_t n = d.y ? (reinterpret_cast<const uint32_t*>(src)[q] & 0xFFFFu) : 0u;
-    const bool is_gt = pl.format_field[i] == pl.f_GT;
-    if (r < N) {
-      char* dst = rec + lay.foff[k * F + q] + hdr + (size_t)r * cnt * w;
-      for (uint32_t j = 0; j < cnt; ++j) {
-        if (t == GDB_BT_CHAR) {
-          char v;
-          if (j < n) v = src[body + j];
-          else if (j == 0 && n == 0) v = flag ? (char)0 : (char)7;      // no value: '.' (vector end under the htsjdk flag)
-          else v = (char)0;                                              // pad with vector end
-          dst[j] = v;
-        } else {
-          uint32_t v;
-          if (j < n) v = reinterpret_cast<const PackedU32*>(src + body + 4u * j)->v;
-          else if (t == GDB_BT_FLOAT) v = (j == 0 && n == 0) ? GDB_BCF_FLOAT_MISSING_BITS : (flag ? GDB_BCF_FLOAT_MISSING_BITS : GDB_BCF_FLOAT_VECTOR_END_BITS);
-          else if (j == 0 && n == 0) v = is_gt ? (flag ? 0u : (uint32_t)GDB_BCF_INT32_VECTOR_END) : (uint32_t)GDB_BCF_INT32_MISSING;   // GT: no-call allele under the flag
-          else v = flag ? (uint32_t)GDB_BCF_INT32_MISSING : (uint32_t)GDB_BCF_INT32_VECTOR_END;
-          if (t == GDB_BT_INT8) dst[j] = (int32_t)v == GDB_BCF_INT32_MISSING ? (char)0x80 : (int32_t)v == GDB_BCF_INT32_VECTOR_END ? (char)0x81 : (char)v;
-          else if (t == GDB_BT_INT16) {
-            const uint16_t h = (int32_t)v == GDB_BCF_INT32_MISSING ? (uint16_t)0x8000u : (int32_t)v == GDB_BCF_INT32_VECTOR_END ? (uint16_t)0x8001u : (uint16_t)v;
-            dst[2 * j] = (char)(h & 0xFFu); dst[2 * j + 1] = (char)(h >> 8);
-          } else { for (int b = 0; b < 4; ++b) dst[4 * j + b] = (char)((v >> (8 * b)) & 0xFFu); }
-        }
-      }
+// values: one wavefront = a run of records x 64 samples.  A lane keeps its entry in an LDS slot (and reloads it only when the
+// resolved pointer changes), converts the elements of field q to the record's type, pads up to the record's vector length
+// (collect_and_extend_fields, variant_field_handler.cc:846-866) into an LDS image of the 64 samples' values, and the wavefront
+// moves the image to the record with aligned 16-byte stores.
+struct __attribute__((packed)) PackedU16 { uint16_t v; };
+constexpr int kBcfEntryCap = 96;     // bytes of an entry kept in the lane's LDS slot (the rest is read from the pool)
+constexpr int kBcfImageSample = 32;  // bytes per sample and field that go through the LDS image (longer vectors: direct stores)
+// one sample's cnt values of a field of BCF type t, from its entry (n elements at `in`) to `out`.  first / rest: what stands where
+// the call has no element (the first position of an empty vector, every other one).  The two pointers are LDS or global by
+// instantiation, so the accesses are ds_ / global_ instructions and not flat ones.
+template <class Out, class In> __device__ __forceinline__ void bcf_sample_values(Out* out, const In* in, uint32_t n, uint32_t cnt, uint32_t t, uint32_t first, uint32_t rest) {
+  if (t == GDB_BT_CHAR) {
+    for (uint32_t j = 0; j < cnt; ++j) out[j] = j < n ? in[j] : (char)(j == 0 ? first : rest);
+  } else if (t == GDB_BT_INT8) {
+    for (uint32_t j = 0; j < cnt; ++j) {
+      const int32_t v = (int32_t)(j < n ? reinterpret_cast<const PackedU32*>(in + 4u * j)->v : (j == 0 ? first : rest));
+      out[j] = v == GDB_BCF_INT32_MISSING ? (char)0x80 : v == GDB_BCF_INT32_VECTOR_END ? (char)0x81 : (char)v;
     }
-    body += n * (uint32_t)es;
-    ++q;
+  } else if (t == GDB_BT_INT16) {
+    for (uint32_t j = 0; j < cnt; ++j) {
+      const int32_t v = (int32_t)(j < n ? reinterpret_cast<const PackedU32*>(in + 4u * j)->v : (j == 0 ? first : rest));
+      reinterpret_cast<PackedU16*>(out + 2u * j)->v = v == GDB_BCF_INT32_MISSING ? (uint16_t)0x8000u : v == GDB_BCF_INT32_VECTOR_END ? (uint16_t)0x8001u : (uint16_t)v;
+    }
+  } else {                      // int32 and float: the stored bits
+    for (uint32_t j = 0; j < cnt; ++j) reinterpret_cast<PackedU32*>(out + 4u * j)->v = j < n ? reinterpret_cast<const PackedU32*>(in + 4u * j)->v : (j == 0 ? first : rest);
+  }
+}
+__global__ void __launch_bounds__(kAsmRows) k_bcf_write(CombinePlan pl, const uint2* __restrict__ resolved, const char* __restrict__ pool, const char* __restrict__ pool_ovf,
+                                                      const uint32_t* __restrict__ fmt_mask, int64_t k_begin, int64_t np, int nchunks, int F, int32_t N, BcfLayout lay,
+                                                      const uint64_t* __restrict__ rec_off, uint64_t page_base, char* __restrict__ arena) {
+  __shared__ __attribute__((aligned(16))) char s_entry[kAsmRows * kBcfEntryCap];
+  __shared__ __attribute__((aligned(16))) char s_image[kAsmRows * kBcfImageSample + 16];
+  const int64_t unit = xcd_aware_unit<1>(((np + kBcfRun - 1) / kBcfRun) * (int64_t)nchunks);
+  if (unit < 0) return;
+  const int64_t k0 = k_begin + (unit / nchunks) * kBcfRun, k1 = min(k_begin + np, k0 + (int64_t)kBcfRun);
+  const int ch = (int)(unit % nchunks);
+  const int lane = threadIdx.x;
+  const uint32_t nsamp = (uint32_t)min((int32_t)kAsmRows, N - ch * kAsmRows);
+  const bool flag = pl.use_missing_values_not_vector_end != 0;
+  const bool live = (uint32_t)lane < nsamp;
+  uint32_t held = 0xFFFFFFFFu;
+  for (int64_t k = k0; k < k1; ++k) {                    // uniform
+    const uint2 d = resolved[(k * nchunks + ch) * kAsmRows + lane];
+    const char* src = ((d.x & kOverflowBit) ? pool_ovf : pool) + (size_t)(d.x & ~kOverflowBit) * 16;
+    if (d.y && d.x != held) {
+      const uint32_t take = d.y < (uint32_t)kBcfEntryCap ? d.y : (uint32_t)kBcfEntryCap;
+      for (uint32_t o = 0; o < take; o += 16) *reinterpret_cast<u32x4*>(s_entry + lane * kBcfEntryCap + o) = *reinterpret_cast<const u32x4*>(src + o);
+      held = d.x;
+    }
+    const bool whole = !__any((int)(live && d.y > (uint32_t)kBcfEntryCap));   // every live lane's entry is in its slot
+    const uint32_t mask = fmt_mask[k];
+    const int nf = __popc(mask);
+    char* rec = arena + (rec_off[k] - page_base);
+    uint32_t body = bcf_summary_bytes(nf);        // this lane's read position inside its entry
+    int q = 0;
+    for (int i = 0; i < pl.n_format; ++i) {       // uniform
+      if (!((mask >> i) & 1u)) continue;
+      const uint32_t m = lay.fmeta[k * F + q];
+      const uint32_t cnt = m & 0xFFFFu, t = (m >> 16) & 0xFu, hdr = m >> 24;
+      const uint32_t w = (uint32_t)bcf_type_width((int)t);
+      const int es = bcf_field_elem_size(pl, i);
+      const uint32_t n = d.y ? bcf_summary_n(reinterpret_cast<const uint16_t*>(s_entry + lane * kBcfEntryCap)[q]) : 0u;
+      const bool is_gt = pl.format_field[i] == pl.f_GT;
+      // no element: CHAR '.' then vector ends (all vector ends under the htsjdk flag); FLOAT / INT missing then vector ends
+      // (missing everywhere under the flag); GT is all vector ends (no-call alleles under the flag)
+      uint32_t first, rest;
+      if (t == GDB_BT_CHAR) { first = flag ? 0u : 7u; rest = 0u; }
+      else if (t == GDB_BT_FLOAT) { first = GDB_BCF_FLOAT_MISSING_BITS; rest = flag ? GDB_BCF_FLOAT_MISSING_BITS : GDB_BCF_FLOAT_VECTOR_END_BITS; }
+      else { first = is_gt ? (flag ? 0u : (uint32_t)GDB_BCF_INT32_VECTOR_END) : (uint32_t)GDB_BCF_INT32_MISSING; rest = flag ? (uint32_t)GDB_BCF_INT32_MISSING : (uint32_t)GDB_BCF_INT32_VECTOR_END; }
+      const uint32_t per = cnt * w;                // bytes per sample
+      char* const fdst = rec + lay.foff[k * F + q] + hdr + (size_t)ch * kAsmRows * per;     // the 64 samples' values of this field
+      if (per <= (uint32_t)kBcfImageSample) {      // uniform
+        const uint32_t al = (uint32_t)((uintptr_t)fdst & 15u);
+        if (live) {
+          if (whole) bcf_sample_values(s_image + al + (uint32_t)lane * per, s_entry + lane * kBcfEntryCap + body, n, cnt, t, first, rest);
+          else bcf_sample_values(s_image + al + (uint32_t)lane * per, src + body, n, cnt, t, first, rest);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        const char* img = s_image + al;
+        const uint32_t total = nsamp * per;
+        uint32_t head = (16u - al) & 15u;
+        if (head > total) head = total;
+        const uint32_t nwords = (total - head) >> 4;
+        const uint32_t tail_at = head + (nwords << 4);
+        if ((uint32_t)lane < head) fdst[lane] = img[lane];
+        const u32x4* lsrc = reinterpret_cast<const u32x4*>(img + head);
+        u32x4* gw = reinterpret_cast<u32x4*>(fdst + head);
+        for (uint32_t wq = lane; wq < nwords; wq += kAsmRows) gw[wq] = lsrc[wq];
+        if ((uint32_t)lane < total - tail_at) fdst[tail_at + lane] = img[tail_at + lane];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      } else if (live) {
+        bcf_sample_values(fdst + (size_t)lane * per, src + body, n, cnt, t, first, rest);
+      }
+      body += n * (uint32_t)es;
+      ++q;
+    }
   }
 }
 
@@ -3106,8 +3180,8 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
     S.bcf_rec_size.ensure((size_t)P + 2);
     lay = BcfLayout{S.bcf_fmeta.p, S.bcf_foff.p, S.bcf_lindiv.p, S.bcf_rec_size.p};
     STAGE("k_bcf_field_meta");
-    hipLaunchKernelGGL(k_bcf_field_meta, dim3((unsigned)nchunk_total), dim3(kAsmRows), 0, st, (const uint2*)S.resolved.p, (const char*)S.pool.p, (const char*)S.pool_ovf.p,
-                       (const uint32_t*)S.fmt_mask.p, nchunks, bcf_F, S.bcf_part.p);
+    hipLaunchKernelGGL(k_bcf_field_meta, dim3((unsigned)(((P + kBcfRun - 1) / kBcfRun) * nchunks)), dim3(kAsmRows), 0, st, (const uint2*)S.resolved.p, (const char*)S.pool.p,
+                       (const char*)S.pool_ovf.p, (const uint32_t*)S.fmt_mask.p, P, nchunks, bcf_F, S.bcf_part.p);
     hipLaunchKernelGGL(k_bcf_layout, dim3(blocks_for(P)), dim3(kBlock), 0, st, pl, (const uint32_t*)S.bcf_part.p, (const uint32_t*)S.fmt_mask.p, (const uint32_t*)S.prefix_len.p, P,
                        nchunks, bcf_F, lay);
     HIP_CHECK(hipMemsetAsync(S.bcf_rec_size.p + P, 0, sizeof(uint64_t), st));
@@ -3205,8 +3279,8 @@ bool DevicePipeline::begin_page(uint64_t arena_bytes, int arena_idx, PageTicket*
     HIP_CHECK(hipEventRecord(w[1], st));
     STAGE("k_bcf_write");
     if (S.hp.plan.n_format > 0 && !S.hp.plan.sites_only_query)
-      hipLaunchKernelGGL(k_bcf_write, dim3((unsigned)(np * iv.nchunks)), dim3(kAsmRows), 0, st, S.hp.plan, (const uint2*)S.resolved.p, (const char*)S.pool.p, (const char*)S.pool_ovf.p,
-                         (const uint32_t*)S.fmt_mask.p, kp, iv.nchunks, iv.bcf_F, N, iv.lay, (const uint64_t*)S.rec_off.p, page_base, arena);
+      hipLaunchKernelGGL(k_bcf_write, dim3((unsigned)(((np + kBcfRun - 1) / kBcfRun) * iv.nchunks)), dim3(kAsmRows), 0, st, S.hp.plan, (const uint2*)S.resolved.p, (const char*)S.pool.p,
+                         (const char*)S.pool_ovf.p, (const uint32_t*)S.fmt_mask.p, kp, np, iv.nchunks, iv.bcf_F, N, iv.lay, (const uint64_t*)S.rec_off.p, page_base, arena);
     HIP_CHECK(hipEventRecord(w[2], st));
     HIP_CHECK(hipMemcpyAsync(&S.hb->page_err[ai], S.err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipEventRecord(w[3], st));

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
+#include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 __global__ void k_fill(uint4* __restrict__ p, size_t n16) {
@@ -87,6 +88,45 @@ __global__ void k_chunks2(char* __restrict__ base, size_t run_bytes, size_t stri
   }
 }
 
+// Which XCD does workgroup b run on?  (XCC_ID hardware register, gfx940+.)  The XCD-aware numbering assumes blockIdx % 8.
+__global__ void k_xcc(uint32_t* out) { if (threadIdx.x == 0) out[blockIdx.x] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)); }
+// mode 3: every workgroup asks the hardware which XCD it is on and takes the next unit of THAT XCD's eighth of the units
+// (stealing from the others when its own is exhausted): robust against any dispatch order
+__global__ void __launch_bounds__(64) k_chunks_dyn(char* __restrict__ base, size_t run_bytes, size_t stride_bytes, int runs, int chunks_per_record, unsigned nlogical, unsigned* ctr) {
+  const int lane = threadIdx.x;
+  __shared__ unsigned s_unit;
+  if (lane == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 7u;
+    const unsigned per = (nlogical + 7u) / 8u;
+    unsigned unit = 0xFFFFFFFFu;
+    for (unsigned t = 0; t < 8u && unit == 0xFFFFFFFFu; ++t) {
+      const unsigned x = (xcc + t) & 7u;
+      const unsigned lo = x * per, hi = min(nlogical, lo + per);
+      if (lo >= hi) continue;
+      const unsigned u = atomicAdd(&ctr[x], 1u);
+      if (lo + u < hi) unit = lo + u;
+    }
+    s_unit = unit;
+  }
+  __syncthreads();
+  const unsigned lid = s_unit;
+  if (lid == 0xFFFFFFFFu) return;
+  const size_t rec0 = (size_t)(lid / chunks_per_record) * runs;
+  const int ch = lid % chunks_per_record;
+  for (int r = 0; r < runs; ++r) {
+    char* g = base + (rec0 + r) * stride_bytes + (size_t)ch * run_bytes;
+    const uint32_t al = (uint32_t)((uintptr_t)g & 15u);
+    uint32_t head = (16u - al) & 15u;
+    const uint32_t nwords = (uint32_t)((run_bytes - head) >> 4);
+    const uint32_t tail_at = head + (nwords << 4);
+    if ((uint32_t)lane < head) g[lane] = (char)lane;
+    uint4* gw = reinterpret_cast<uint4*>(g + head);
+    const uint4 v = make_uint4(lane, r, 3, 4);
+    for (uint32_t wq = lane; wq < nwords; wq += 64) gw[wq] = v;
+    if ((uint32_t)lane < run_bytes - tail_at) g[tail_at + lane] = (char)lane;
+  }
+}
+
 int main(int argc, char** argv) {
   const size_t gb = argc > 1 ? (size_t)atoll(argv[1]) : 32;
   const size_t bytes = gb << 30, n16 = bytes / 16;
@@ -126,6 +166,25 @@ int main(int argc, char** argv) {
       char nm[128];
       snprintf(nm, 128, "shaped: %3d rec/wave, %2d waves/WG, %s", runs, wpb, mode ? "XCD-aware" : "chunk-fast");
       time(nm, (double)records * cpr * run_bytes, [&]() { hipLaunchKernelGGL(k_chunks2, dim3((nlogical + wpb - 1) / wpb), dim3(64 * wpb), 0, 0, a, run_bytes, stride, runs, cpr, mode, nlogical); });
+    }
+    {
+      const int runs = 32;
+      const size_t records = bytes / stride / runs * runs;
+      const unsigned nlogical = (unsigned)(records / runs * cpr);
+      unsigned* ctr; CK(hipMalloc(&ctr, 64));
+      time("shaped:  32 rec/wave, units taken per XCC_ID", (double)records * cpr * run_bytes, [&]() { CK(hipMemsetAsync(ctr, 0, 64, 0)); hipLaunchKernelGGL(k_chunks_dyn, dim3(nlogical), dim3(64), 0, 0, a, run_bytes, stride, runs, cpr, nlogical, ctr); });
+      // does blockIdx % 8 name the XCD?
+      const unsigned nb = 1u << 16;
+      uint32_t* dx; CK(hipMalloc(&dx, nb * 4));
+      hipLaunchKernelGGL(k_xcc, dim3(nb), dim3(64), 0, 0, dx);
+      std::vector<uint32_t> hx(nb);
+      CK(hipMemcpy(hx.data(), dx, nb * 4, hipMemcpyDeviceToHost));
+      unsigned best = 0; int best_c = 0; unsigned hist[16] = {0};
+      for (unsigned b2 = 0; b2 < nb; ++b2) hist[hx[b2] & 15u]++;
+      for (int c = 0; c < 8; ++c) { unsigned ok = 0; for (unsigned b2 = 0; b2 < nb; ++b2) ok += ((hx[b2] & 7u) == ((b2 + c) & 7u)); if (ok > best) { best = ok; best_c = c; } }
+      printf("XCC_ID of 65536 workgroups: blockIdx %% 8 names the XCD (rotation %d) for %.1f %% of them; per-XCD counts", best_c, 100.0 * best / nb);
+      for (int x = 0; x < 8; ++x) printf(" %u", hist[x]);
+      printf("\n");
     }
     for (int runs : {2, 8}) {
       const size_t records = bytes / stride / runs * runs;
