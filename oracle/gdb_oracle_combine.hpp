@@ -18,7 +18,10 @@
 #pragma once
 #include <cmath>
 #include <functional>
+#include <iomanip>
+#include <map>
 #include <set>
+#include <sstream>
 #include <unordered_set>
 
 #include "gdb_oracle_scan.hpp"
@@ -81,6 +84,26 @@ inline uint64_t get_genotype_index(std::vector<int>& v, bool is_sorted) {
   }
 }
 
+// ---- 2-D fields: <u64 size of data><inner vectors back to back><u64 #entries><u64 offsets x (#entries + 1)> -----------------------
+// (genomicsdb_multid_vector_field.h:69-86; the walk of GenomicsDBMultiDVectorIdx over dimension 0, multid_vector_field.cc:118-205)
+struct MultiD2View {
+  const uint8_t* p;
+  uint64_t data_size = 0, n = 0;
+  explicit MultiD2View(const std::string& blob) : p((const uint8_t*)blob.data()) {
+    ORACLE_VERIFY(blob.size() >= 24u);
+    memcpy(&data_size, p, 8);
+    memcpy(&n, p + 8 + data_size, 8);
+  }
+  uint64_t off(uint64_t i) const { uint64_t v; memcpy(&v, p + 8 + data_size + 8 + 8 * i, 8); return v; }
+  uint64_t num_entries() const { return n; }
+  const uint8_t* ptr(uint64_t i) const { return p + 8 + off(i); }
+  uint64_t bytes(uint64_t i) const { return off(i + 1) - off(i); }
+};
+// remap_allele_specific_annotations (variant_operations.cc:482-549): dimension 0 of the input re-indexed to the merged alleles,
+// an allele the input does not have takes the input's <NON_REF> entry (none: 0 bytes)
+inline std::string remap_allele_specific_annotations(const std::string& orig, uint64_t call, const class CombineAllelesLUT& lut, unsigned num_merged,
+                                                     bool NON_REF_exists, bool alt_only);
+
 // ---- typed access helpers over Field -----------------------------------------------------------
 template <class T> struct FieldVec;
 template <> struct FieldVec<int32_t> {
@@ -95,6 +118,34 @@ template <> struct FieldVec<float> {
   static float missing() { return u2f(bcf_float_missing_bits); }
   static float vector_end() { return u2f(bcf_float_vector_end_bits); }
 };
+
+inline std::string remap_allele_specific_annotations(const std::string& orig, uint64_t call, const CombineAllelesLUT& lut, unsigned num_merged,
+                                                     bool NON_REF_exists, bool alt_only) {
+  MultiD2View in(orig);
+  const int64_t merged_nr = NON_REF_exists ? (int64_t)(int)(num_merged - 1) : lut_missing_value;
+  const int64_t input_nr = NON_REF_exists ? lut.get_input_idx_for_merged(call, merged_nr) : lut_missing_value;
+  const unsigned length = alt_only ? num_merged - 1u : num_merged;
+  std::vector<uint64_t> offsets(length + 1u, 0u);
+  std::string data;
+  for (unsigned j = 0; j < length; ++j) {
+    const unsigned allele_j = alt_only ? j + 1u : j;
+    int64_t in_j = lut.get_input_idx_for_merged(call, allele_j);
+    if (CombineAllelesLUT::is_missing_value(in_j)) {
+      if (CombineAllelesLUT::is_missing_value(input_nr)) { offsets[j + 1u] = offsets[j]; continue; }
+      in_j = input_nr;
+    }
+    const int64_t input_j = alt_only ? in_j - 1 : in_j;
+    if (input_j >= 0 && (uint64_t)input_j < in.num_entries()) data.append((const char*)in.ptr((uint64_t)input_j), in.bytes((uint64_t)input_j));
+    offsets[j + 1u] = data.size();
+  }
+  std::string out;
+  const uint64_t size = data.size(), n = length;
+  out.append((const char*)&size, 8);
+  out += data;
+  out.append((const char*)&n, 8);
+  out.append((const char*)offsets.data(), offsets.size() * 8u);
+  return out;
+}
 
 typedef std::function<void(uint64_t out_idx, bool has_value, uint64_t in_idx)> RemapSink;
 
@@ -453,6 +504,7 @@ class BroadCombinedGVCFOperator : public SingleVariantOperatorBase {
   std::vector<unsigned> ploidy_;
   // BroadCombinedGVCFOperator state
   std::vector<FieldTuple> INFO_fields_vec_, FORMAT_fields_vec_;
+  std::map<unsigned, std::pair<unsigned, unsigned>> INFO_histogram_field_map_;   // composite vid field idx -> (query idx of the bins, of the counts)
   FieldTuple qual_tuple_{UNDEFINED_IDX, UNDEFINED_IDX, nullptr};
   std::set<std::string> hdr_ids_;
   std::string curr_contig_name_, next_contig_name_;
@@ -500,10 +552,27 @@ class BroadCombinedGVCFOperator : public SingleVariantOperatorBase {
       if (l.compare(0, 9, "##contig=") == 0) contigs_in_hdr.insert(id);
     }
     auto add_field_to_hdr_if_missing = [&](const std::string& field_name, int cls) {
-      if (have[cls].count(field_name)) return;
       const FieldInfo* fi = vid_->get_field_info(field_name);
+      // a multi-D or tuple field must be a String with Number=1 in the header: a line that says otherwise is removed and added
+      // again with its description (vcf_adapter.cc:62-95)
+      const bool multid = fi && (fi->num_elements_in_tuple() > 1u || fi->ndim > 1u);
+      std::string kept_description;
+      if (multid && have[cls].count(field_name)) {
+        const std::string prefix = std::string("##") + (cls == 1 ? "INFO" : "FORMAT") + "=<ID=" + field_name + ",";
+        for (size_t li = 0; li < lines.size(); ++li)
+          if (lines[li].compare(0, prefix.size(), prefix) == 0) {
+            size_t dp = lines[li].find("Description=");
+            if (dp != std::string::npos) { size_t de = lines[li].rfind('>'); kept_description = lines[li].substr(dp + 12, de - dp - 12); }
+            lines.erase(lines.begin() + (long)li);
+            break;
+          }
+        have[cls].erase(field_name);
+      }
+      if (have[cls].count(field_name)) return;
       std::string h = std::string("##") + (cls == 0 ? "FILTER" : cls == 1 ? "INFO" : "FORMAT") + "=<ID=" + field_name;
-      if (cls != 0) {
+      if (cls != 0 && multid) {
+        h += ",Number=1,Type=String";
+      } else if (cls != 0) {
         if (cls == 2 && field_name == "GT") h += ",Number=1,Type=String,Description=\"Genotype\"";
         else {
           ORACLE_VERIFY(fi != nullptr);
@@ -521,7 +590,8 @@ class BroadCombinedGVCFOperator : public SingleVariantOperatorBase {
           h += fi->et == ET_FLAG ? "Flag" : fi->et == ET_INT ? "Integer" : fi->et == ET_FLOAT ? "Float" : "String";
         }
       }
-      if (!(cls == 2 && field_name == "GT")) h += ",Description=\"" + field_name + "\"";
+      if (!kept_description.empty()) h += ",Description=" + kept_description;
+      else if (!(cls == 2 && field_name == "GT")) h += ",Description=\"" + field_name + "\"";
       h += ">";
       lines.push_back(h);
       have[cls].insert(field_name);
@@ -541,7 +611,17 @@ class BroadCombinedGVCFOperator : public SingleVariantOperatorBase {
                         (fi->is_INFO && ((ke == GVCF_DP_IDX && op == OP_DP) || (op == OP_MOVE_TO_FORMAT && !sites_only)));
       if (add_INFO) {
         if (op == OP_UNKNOWN) { /* WARNING: field will NOT be part of INFO */ }
-        else if (op == OP_HISTOGRAM_SUM) throw OracleException("histogram_sum is not supported by the oracle (SURVEY 8f-4)");
+        else if (op == OP_HISTOGRAM_SUM) {   // broad_combined_gvcf.cc:194-221: the pair (bin field, count field) of the composite parent
+          INFO_fields_vec_.push_back({ke, i, fi});
+          add_field_to_hdr_if_missing(fi->vcf_name, 1);
+          ORACLE_VERIFY(fi->is_flattened);
+          const FieldInfo& parent = vid_->fields[(size_t)fi->parent_composite_field_idx];
+          if (parent.num_elements_in_tuple() != 2u)
+            throw OracleException("Operation histogram_sum is only supported for fields whose elements are tuple with 2 constituent elements; field " + parent.name);
+          if (fi->et != ET_INT && fi->et != ET_FLOAT) throw OracleException("histogram_sum needs int or float tuple elements; field " + parent.name);
+          auto& pr = INFO_histogram_field_map_[(unsigned)fi->parent_composite_field_idx];
+          if (fi->element_index_in_tuple == 0u) pr.first = i; else pr.second = i;
+        }
         else { INFO_fields_vec_.push_back({ke, i, fi}); add_field_to_hdr_if_missing(fi->vcf_name, 1); }
       }
       if (add_FORMAT) {
@@ -662,6 +742,8 @@ class BroadCombinedGVCFOperator : public SingleVariantOperatorBase {
       run(orig.iv.size(), [&](uint64_t o, bool has, uint64_t i) { if (o < dst.iv.size()) dst.iv[o] = has ? orig.iv[i] : bcf_int32_missing; });
     } else if (orig.kind == FK_FLOAT) {
       run(orig.fv.size(), [&](uint64_t o, bool has, uint64_t i) { if (o < dst.fv.size()) dst.fv[o] = has ? orig.fv[i] : u2f(bcf_float_missing_bits); });
+    } else if (orig.kind == FK_STRING && fi.ndim == 2u) {   // remap_allele_specific_annotations (variant_operations.cc:551-570)
+      dst.sv = remap_allele_specific_annotations(orig.sv, call, lut, num_merged, NON_REF_exists, fi.is_only_ALT_dependent());
     } else throw OracleException("remap of non-numeric allele-dependent field is not supported");
   }
 
@@ -882,6 +964,12 @@ class BroadCombinedGVCFOperator : public SingleVariantOperatorBase {
         throw OracleException("median on a string field");
       }
       case OP_ELEMENT_WISE_SUM: {  // compute_valid_element_wise_sum (:618-664)
+        if (fi.ndim == 2u) {       // compute_valid_element_wise_sum_2D_vector + stringify_2D_vector (:666-740)
+          res.type = 2;
+          if (is_float) return element_wise_sum_2D<float>(src, q, fi, res.sv);
+          if (is_int) return element_wise_sum_2D<int32_t>(src, q, fi, res.sv);
+          throw OracleException("2-D element_wise_sum on a string field");
+        }
         unsigned num_valid = 0;
         if (is_float) {
           std::vector<float>& r = res.fv;
@@ -923,6 +1011,83 @@ class BroadCombinedGVCFOperator : public SingleVariantOperatorBase {
       default: throw OracleException("Unknown VCF field combine operation");
     }
   }
+  // compute_valid_element_wise_sum_2D_vector (variant_field_handler.cc:666-714) + stringify_2D_vector (:716-740)
+  template <class T> bool element_wise_sum_2D(const Variant& src, unsigned q, const FieldInfo& fi, std::string& text) {
+    uint64_t num_valid_elements = 0;
+    std::vector<std::vector<T>> result;
+    for (const auto& c : src.calls) {
+      if (!c.is_valid) continue;
+      const Field& f = c.fields[q];
+      if (!(f.non_null && f.valid)) continue;
+      MultiD2View idx(f.sv);
+      if (idx.num_entries() > result.size()) result.resize(idx.num_entries());
+      for (uint64_t d0 = 0; d0 < idx.num_entries(); ++d0) {
+        const uint64_t num_elements = idx.bytes(d0) / sizeof(T);
+        if (num_elements > result[d0].size()) result[d0].resize(num_elements, FieldVec<T>::missing());
+        for (uint64_t i = 0; i < num_elements; ++i) {
+          T val; memcpy(&val, idx.ptr(d0) + i * sizeof(T), sizeof(T));
+          if (is_bcf_valid_value(val)) {
+            if (is_bcf_valid_value(result[d0][i])) result[d0][i] += val; else result[d0][i] = val;
+            ++num_valid_elements;
+          }
+        }
+      }
+    }
+    if (num_valid_elements == 0u) return false;
+    std::stringstream s;
+    for (size_t i = 0; i < result.size(); ++i) {
+      if (i) s << fi.vcf_delimiter[0];
+      for (size_t j = 0; j < result[i].size(); ++j) {
+        if (j) s << fi.vcf_delimiter[1];
+        if (is_bcf_valid_value(result[i][j])) s << std::fixed << std::setprecision(3) << result[i][j];
+      }
+    }
+    text = s.str();
+    return true;
+  }
+  // compute_valid_histogram_sum_2D_vector_and_stringify (broad_combined_gvcf.cc:431-521)
+  template <class T1, class T2> bool histogram_sum_2D(const Variant& src, unsigned q_bin, unsigned q_count, const FieldInfo& fi_bin, std::string& text) {
+    uint64_t num_calls_with_field = 0;
+    std::vector<std::map<T1, T2>> histogram_map_vec;
+    for (const auto& c : src.calls) {
+      if (!c.is_valid) continue;
+      const Field& fb = c.fields[q_bin];
+      const Field& fc = c.fields[q_count];
+      if (!(fb.non_null && fb.valid)) continue;
+      ORACLE_VERIFY(fc.non_null && fc.valid);
+      MultiD2View ib(fb.sv), ic(fc.sv);
+      ORACLE_VERIFY(ib.num_entries() == ic.num_entries());
+      if (ib.num_entries() > histogram_map_vec.size()) histogram_map_vec.resize(ib.num_entries());
+      for (uint64_t d0 = 0; d0 < ib.num_entries(); ++d0) {
+        const uint64_t num_elements = ib.bytes(d0) / sizeof(T1);
+        ORACLE_VERIFY(num_elements == ic.bytes(d0) / sizeof(T2));
+        auto& m = histogram_map_vec[d0];
+        for (uint64_t i = 0; i < num_elements; ++i) {
+          T1 vb; T2 vc;
+          memcpy(&vb, ib.ptr(d0) + i * sizeof(T1), sizeof(T1));
+          memcpy(&vc, ic.ptr(d0) + i * sizeof(T2), sizeof(T2));
+          if (is_bcf_valid_value(vb) && is_bcf_valid_value(vc)) {
+            auto ins = m.insert(std::pair<T1, T2>(vb, vc));
+            if (!ins.second) ins.first->second += vc;
+          }
+        }
+      }
+      ++num_calls_with_field;
+    }
+    if (num_calls_with_field == 0u) return false;
+    std::stringstream s;
+    for (size_t i = 0; i < histogram_map_vec.size(); ++i) {
+      if (i) s << fi_bin.vcf_delimiter[0];
+      bool first = true;
+      for (auto& pr : histogram_map_vec[i]) {
+        if (!first) s << fi_bin.vcf_delimiter[1];
+        s << std::fixed << std::setprecision(3) << pr.first << fi_bin.vcf_delimiter[1] << pr.second;
+        first = false;
+      }
+    }
+    text = s.str();
+    return true;
+  }
   // handle_INFO_fields (:523-601)
   void handle_INFO_fields(const Variant& variant) {
     if (remapped_variant_.col_end > remapped_variant_.col_begin) {
@@ -935,6 +1100,19 @@ class BroadCombinedGVCFOperator : public SingleVariantOperatorBase {
         RecInfo& e = rec_.info_slot(t.info->vcf_name);
         e.type = res.type; e.iv = res.iv; e.fv = res.fv; e.sv = res.sv;
       }
+    }
+    for (auto& kv : INFO_histogram_field_map_) {   // (:562-600) after the other INFO fields, by composite vid field idx
+      const unsigned q_bin = kv.second.first, q_count = kv.second.second;
+      const FieldInfo& fb = *qc_->attrs[q_bin].info;
+      const FieldInfo& fc = *qc_->attrs[q_count].info;
+      const Variant& src = (remapping_needed_ && fc.is_allele_dependent()) ? remapped_variant_ : variant;
+      std::string text;
+      bool found = false;
+      if (fb.et == ET_FLOAT && fc.et == ET_FLOAT) found = histogram_sum_2D<float, float>(src, q_bin, q_count, fb, text);
+      else if (fb.et == ET_FLOAT) found = histogram_sum_2D<float, int32_t>(src, q_bin, q_count, fb, text);
+      else if (fc.et == ET_FLOAT) found = histogram_sum_2D<int32_t, float>(src, q_bin, q_count, fb, text);
+      else found = histogram_sum_2D<int32_t, int32_t>(src, q_bin, q_count, fb, text);
+      if (found) { RecInfo& e = rec_.info_slot(fb.vcf_name); e.type = 2; e.sv = text; }
     }
   }
 

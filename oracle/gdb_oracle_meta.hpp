@@ -116,6 +116,16 @@ struct FieldInfo {
   unsigned num_elements = 1;  // fixed-length fields
   ElementType et = ET_INT;
   CombineOp combine_op = OP_UNKNOWN;
+  // multi-dimensional fields and fields whose elements are tuples (vid_mapper.h:151-280 FieldLengthDescriptor /
+  // FieldElementTypeDescriptor): `ld` is the descriptor of dimension 0, the data of a 2-D field is one byte blob per tuple
+  // element (genomicsdb_multid_vector_field.h:69-86), every tuple element is a flattened field of its own
+  unsigned ndim = 1;
+  char vcf_delimiter[2] = {'|', ','};
+  std::vector<ElementType> tuple_et;     // element types of the tuple (size 1 for plain fields)
+  bool is_flattened = false;
+  unsigned element_index_in_tuple = 0;
+  int parent_composite_field_idx = -1;
+  unsigned num_elements_in_tuple() const { return tuple_et.empty() ? 1u : (unsigned)tuple_et.size(); }
   bool is_fixed() const { return ld == VL_FIXED; }
   bool is_allele_dependent() const { return ld == VL_A || ld == VL_R || ld == VL_G; }
   bool is_genotype_dependent() const { return ld == VL_G; }
@@ -237,8 +247,15 @@ class VidMapper {
       if (d.HasMember("length")) parse_length(name, d["length"], f);
       else if (ke != UNDEFINED_IDX) known_field_default_length(ke, f.ld, f.num_elements);
       ORACLE_VERIFY(d.HasMember("type"));
-      if (!d["type"].IsString()) throw OracleException("tuple-typed field " + name + " is not supported by the oracle (SURVEY 8f-4)");
-      f.et = parse_type(d["type"].GetString());
+      if (d["type"].IsString()) f.tuple_et.assign(1, parse_type(d["type"].GetString()));
+      else for (size_t j = 0; j < d["type"].Size(); ++j) f.tuple_et.push_back(parse_type(d["type"][j].GetString()));   // vid_mapper.cc:1456-1482
+      ORACLE_VERIFY(!f.tuple_et.empty());
+      f.et = f.tuple_et[0];
+      if (d.HasMember("vcf_delimiter")) {  // vid_mapper.cc:1412-1428
+        const auto& vd = d["vcf_delimiter"];
+        if (vd.IsString()) f.vcf_delimiter[0] = vd.GetString()[0];
+        else for (size_t j = 0; j < vd.Size() && j < 2; ++j) f.vcf_delimiter[j] = vd[j].GetString()[0];
+      }
       if (d.HasMember("VCF_field_combine_operation")) {
         f.combine_op = parse_combine_op(d["VCF_field_combine_operation"].GetString(), name);
         if (f.combine_op == OP_CONCATENATE && f.ld != VL_VAR)
@@ -259,8 +276,28 @@ class VidMapper {
         field_name_to_idx[g.name] = g.idx;
         fields.push_back(g);
       }
+      // every element of a type tuple becomes a field <name>_tuple_element_<i> (vid_mapper.cc:751-787)
+      if (f.num_elements_in_tuple() > 1u) {
+        const int original = f.idx, format_idx = (f.is_INFO && f.is_FORMAT) ? f.idx + 1 : f.idx;
+        for (unsigned j = 0; j < ((f.is_INFO && f.is_FORMAT) ? 2u : 1u); ++j)
+          for (unsigned t = 0; t < f.num_elements_in_tuple(); ++t) {
+            FieldInfo g = fields[j == 0u ? original : format_idx];
+            g.name += "_tuple_element_" + std::to_string(t);
+            g.idx = (int)fields.size();
+            g.tuple_et.assign(1, f.tuple_et[t]);
+            g.et = f.tuple_et[t];
+            g.element_index_in_tuple = t;
+            g.is_flattened = true;
+            g.parent_composite_field_idx = j == 0u ? original : format_idx;
+            field_name_to_idx[g.name] = g.idx;
+            fields.push_back(g);
+          }
+      }
     }
     add_mandatory_fields();
+  }
+  const FieldInfo* get_flattened_field_info(const FieldInfo* fi, unsigned tuple_element_index) const {  // vid_mapper.cc:790-800
+    return get_field_info(fi->name + "_tuple_element_" + std::to_string(tuple_element_index));
   }
 
   void load_callsets(const mini_json::Value& doc) {
@@ -320,7 +357,12 @@ class VidMapper {
       f.ld = VL_FIXED; f.num_elements = (unsigned)v["fixed_length"].GetInt64(); return;
     }
     if (v.IsArray() && v.Size() == 1) { parse_length(name, v[0], f); return; }
-    throw OracleException("multi-dimensional field " + name + " is not supported by the oracle (SURVEY 8f-4)");
+    if (v.IsArray() && v.Size() == 2) {  // [ dimension 0, dimension 1 ]: the descriptor of dimension 0 decides the allele dependence
+      parse_length(name, v[0], f);
+      f.ndim = 2;
+      return;
+    }
+    throw OracleException("field " + name + " has more than 2 dimensions: not supported by the oracle");
   }
   void add_one(const char* n, ElementType et, LengthDescriptor ld, bool info) {
     if (field_name_to_idx.count(n)) return;
@@ -356,13 +398,20 @@ inline ArraySchema build_array_schema(const VidMapper& vid) {
   if (vid.field_name_to_idx.count("ID")) s.attrs.push_back({"ID", ET_CHAR, true, 0});
   s.attrs.push_back({"QUAL", ET_FLOAT, false, 1});
   s.attrs.push_back({"FILTER", ET_INT, true, 0});
+  // (a composite field - tuple of several elements - is not an attribute, its flattened elements are; the TileDB type of a
+  // multi-D field is a variable number of bytes)
   for (const auto& f : vid.fields) {
-    if (f.name == "END") continue;
-    if (f.is_INFO) s.attrs.push_back({f.name, f.et, !f.is_fixed(), f.is_fixed() ? f.num_elements : 0u});
+    if (f.name == "END" || f.num_elements_in_tuple() > 1u) continue;
+    if (!f.is_INFO) continue;
+    if (f.ndim > 1u) s.attrs.push_back({f.name, ET_CHAR, true, 0u});
+    else s.attrs.push_back({f.name, f.et, !f.is_fixed(), f.is_fixed() ? f.num_elements : 0u});
   }
   for (const auto& f : vid.fields) {
-    if (f.name == "END") continue;
-    if (f.is_FORMAT) s.attrs.push_back({f.is_INFO ? f.name + "_FORMAT" : f.name, f.et, !f.is_fixed(), f.is_fixed() ? f.num_elements : 0u});
+    if (f.name == "END" || f.num_elements_in_tuple() > 1u) continue;
+    if (!f.is_FORMAT) continue;
+    const std::string n = f.is_INFO ? f.name + "_FORMAT" : f.name;
+    if (f.ndim > 1u) s.attrs.push_back({n, ET_CHAR, true, 0u});
+    else s.attrs.push_back({n, f.et, !f.is_fixed(), f.is_fixed() ? f.num_elements : 0u});
   }
   return s;
 }
@@ -527,7 +576,25 @@ class QueryConfig {
 
   // VariantQueryProcessor::do_query_bookkeeping (query_variants.cc:578-685) with
   // finalize_queried_attributes (:243-279) and obtain_TileDB_attribute_idxs (:281-294)
+  // VariantQueryConfig::flatten_composite_fields (variant_query_config.cc:187-229): the elements of a queried composite field
+  // join the end of the list, the composite itself leaves it
+  void flatten_composite_fields(const VidMapper& vid) {
+    std::vector<std::string> names;
+    for (auto& a : attrs) names.push_back(a.name);
+    std::vector<std::string> keep, extra;
+    for (auto& n : names) {
+      const FieldInfo* fi = vid.get_field_info(n);
+      if (!fi) throw OracleException("Field " + n + " not found in vid mapping");
+      if (fi->num_elements_in_tuple() > 1u) { for (unsigned j = 0; j < fi->num_elements_in_tuple(); ++j) extra.push_back(vid.get_flattened_field_info(fi, j)->name); }
+      else keep.push_back(n);
+    }
+    if (extra.empty()) return;
+    clear_attributes();
+    for (auto& n : keep) add_attribute_to_query(n, UNDEFINED_IDX);
+    for (auto& n : extra) add_attribute_to_query(n, UNDEFINED_IDX);
+  }
   void do_query_bookkeeping(const ArraySchema& schema, const VidMapper& vid, int64_t num_rows, int64_t lb_row) {
+    flatten_composite_fields(vid);
     if (attrs.empty() || sites_only_query) {
       std::vector<std::string> names;
       if (attrs.empty()) for (auto& a : schema.attrs) names.push_back(a.name);

@@ -52,6 +52,7 @@ CASES = [
     ("t0_1_2_DS_ID_vcf_at_0", "t0_1_2.json", "vid_DS_ID.json", {}, "t0_1_2_DS_ID_vcf_at_0", "load"),
     ("t0_with_missing_PL_SB_fields_t1", "t0_with_missing_PL_SB_fields_t1.json", "vid.json", {},
      "t0_with_missing_PL_SB_fields_t1.vcf", "load"),
+    ("t0_1_2_all_asa_loading", "t0_1_2_all_asa.json", "vid_all_asa.json", {}, "t0_1_2_all_asa_loading", "load"),
     ("t0_1_2_combined", "t0_1_2_combined.json", "vid.json", {"query_column_ranges": FULL}, "t0_1_2_combined", "query"),
     ("t0_1_2_combined_loading", "t0_1_2_combined.json", "vid.json", {}, "t0_1_2_combined", "load"),
     (HT + "_loading", HT + ".json", "vid_DS_ID_phased_GT.json", {}, HT + "_loading", "load"),
@@ -74,5 +75,4 @@ CASES = [
 
 # Goldens of the hot path that are NOT covered yet, with the reason (kept visible on purpose).
 UNCOVERED = {
-    "t0_1_2_all_asa_loading": "2-D allele-specific annotation fields + histogram_sum (SURVEY.md 8(f) rank 4)",
 }

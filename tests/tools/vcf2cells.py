@@ -22,8 +22,12 @@ TileDB null sentinels (Intel TileDB fork constants; see DESIGN.md "sentinels"):
 bcf missing/vector_end (htslib): int32 INT32_MIN / INT32_MIN+1,
   float bits 0x7F800001 / 0x7F800002.
 
-Only what the fixtures need is implemented (no multi-D / tuple fields: those
-fixtures - vid_all_asa.json - are listed as "next" in SURVEY.md 8(f)).
+Two-dimensional fields ("length": [ "R", "var" ], allele-specific annotations written as
+delimited strings in the VCF) are stored as the reference stores them
+(GenomicsDBMultiDVectorField::parse_and_store_numeric, genomicsdb_multid_vector_field.cc:238-464;
+vcf2binary.cc:857-913): one variable-length byte attribute per element of the type tuple,
+   [i32 nbytes][u64 size of data][inner vectors back to back][u64 #entries][u64 offsets x (#entries + 1)]
+An empty inner vector holds one bcf-missing element ("" and "NaN" parse to missing).
 """
 import gzip
 import json
@@ -64,15 +68,26 @@ class Field:
         self.idx = idx
         self.cls = set(d.get("vcf_field_class", []))
         t = d["type"]
-        if isinstance(t, list):
-            raise NotImplementedError("tuple fields are not handled by the fixture importer")
-        self.kind = ("int" if t in INT_TYPES else "float" if t in FLOAT_TYPES
-                     else "flag" if t in FLAG_TYPES else "str")
+        kind_of = lambda x: ("int" if x in INT_TYPES else "float" if x in FLOAT_TYPES
+                             else "flag" if x in FLAG_TYPES else "str")
+        self.tuple_kinds = [kind_of(x) for x in t] if isinstance(t, list) else [kind_of(t)]
+        self.kind = self.tuple_kinds[0]
+        self.tuple_idx = None     # index in the parent's type tuple (flattened children only)
+        self.ndim = 1
         length = d.get("length", None)
         if length is None:
             length = KNOWN_LENGTH.get(name, 1) if name in KNOWN_FIELDS else 1
+        if isinstance(length, list) and len(length) == 1:
+            length = length[0]
+        if isinstance(length, dict):
+            length = length.get("variable_length_descriptor", length.get("fixed_length"))
         if isinstance(length, list):
-            raise NotImplementedError("multi-D fields are not handled by the fixture importer")
+            if len(length) != 2:
+                raise NotImplementedError("fields of more than 2 dimensions are not handled by the fixture importer")
+            self.ndim = 2
+            delim = d.get("vcf_delimiter", ["|", ","])
+            self.delims = [delim] if isinstance(delim, str) else list(delim)
+            length = "VAR"        # stored as a variable-length byte attribute
         if isinstance(length, str):
             up = length.upper()
             if up in LENGTH_ALIASES:
@@ -114,6 +129,17 @@ def load_vid(path):
             g.cls = {"FORMAT"}
             f.cls = {"INFO"}
             fields.append(g)
+        if len(f.tuple_kinds) > 1:
+            # every element of the type tuple becomes a field <name>_tuple_element_<i> (vcf name unchanged); the
+            # composite parent keeps its index but is not an attribute of the array (vid_mapper.cc:751-787, :399-404)
+            f.is_composite = True
+            for i, k in enumerate(f.tuple_kinds):
+                g = Field(name, len(fields), info)
+                g.name = "%s_tuple_element_%d" % (name, i)
+                g.cls = set(f.cls)
+                g.kind = k
+                g.tuple_idx = i
+                fields.append(g)
     contigs = OrderedDict()
     cd = d["contigs"]
     citems = cd.items() if isinstance(cd, dict) else [
@@ -130,8 +156,8 @@ def schema_attributes(fields):
     if "ID" in names:
         attrs.append("ID")
     attrs += ["QUAL", "FILTER"]
-    info = [f for f in fields if "INFO" in f.cls and f.name != "END"]
-    fmt = [f for f in fields if "FORMAT" in f.cls and f.name != "END"]
+    info = [f for f in fields if "INFO" in f.cls and f.name != "END" and not getattr(f, "is_composite", False)]
+    fmt = [f for f in fields if "FORMAT" in f.cls and f.name != "END" and not getattr(f, "is_composite", False)]
     return attrs, info, fmt
 
 
@@ -170,8 +196,59 @@ def f32_bits(x):
     return struct.unpack("<I", struct.pack("<f", x))[0]
 
 
+def parse_2d_element(kind, tok):
+    """str_to_element<int|float> (genomicsdb_multid_vector_field.cc:31-87): "" and NaN are bcf missing."""
+    if tok == "" or tok.lower() == "nan":
+        return None
+    return int(tok, 0) if kind == "int" else float(tok)
+
+
+def encode_2d(field, text, n_samples=1, sample_idx=0):
+    """A delimited 2-D string -> the bytes of this tuple element's attribute.  Tuple elements alternate inside an
+    inner vector ("bin,count,bin,count"); shorter tuple elements are padded with missing; with several samples in
+    the VCF a sum-like INFO field is divided up among them (vcf2binary.cc:862-884: histogram_sum divides the
+    second tuple element only)."""
+    if text is None or text == ".":
+        return struct.pack("<i", 0)
+    kinds = field.tuple_kinds
+    me = field.tuple_idx or 0
+    divide = field.is_sum_like and "INFO" in field.cls and n_samples > 1
+    if divide and field.combine == "histogram_sum":
+        divide = me == 1
+    data = b""
+    offsets = [0]
+    for inner in text.split(field.delims[0]):
+        toks = inner.split(field.delims[1])
+        per = [[] for _ in kinds]
+        for i, tok in enumerate(toks):
+            per[i % len(kinds)].append(tok)
+        n = max(len(x) for x in per)
+        mine = per[me] + [""] * (n - len(per[me]))
+        for tok in mine:
+            v = parse_2d_element(kinds[me], tok)
+            if kinds[me] == "int":
+                if v is None:
+                    v = BCF_INT32_MISSING
+                elif divide:
+                    q, r = divmod(v, n_samples)
+                    v = q + (1 if sample_idx < r else 0)
+                data += struct.pack("<i", v)
+            else:
+                if v is None:
+                    data += struct.pack("<I", BCF_FLOAT_MISSING_BITS)
+                else:
+                    if divide:
+                        v = struct.unpack("<f", struct.pack("<f", v))[0] / n_samples
+                    data += struct.pack("<f", v)
+        offsets.append(len(data))
+    blob = struct.pack("<Q", len(data)) + data + struct.pack("<Q", len(offsets) - 1) + b"".join(struct.pack("<Q", o) for o in offsets)
+    return struct.pack("<i", len(blob)) + blob
+
+
 def encode_values(field, text, n_alt, n_samples=1, sample_idx=0):
     """One INFO/FORMAT value string -> attribute bytes (vcf2binary.cc:771-969)."""
+    if field.ndim == 2:
+        return encode_2d(field, text, n_samples, sample_idx)
     missing = text is None or text == "."
     if field.kind == "flag":
         return bytes([1 if text is not None else TILEDB_NULL_CHAR])
