@@ -377,6 +377,7 @@ GDB_HD void classify_cell(const FragmentView& fr, const CombinePlan& pl, const C
   // QUAL / FILTER rule would read
   bool heavy = !(flags & GDB_CF_REFBLOCK);
   for (int i = 0; i < pl.n_info; ++i) if ((vmask >> pl.info_field[i]) & 1) heavy = true;
+  for (int i = 0; i < pl.n_histogram; ++i) if ((vmask >> pl.histogram_bin_field[i]) & 1) heavy = true;
   if (pl.qual_combine_op != GDB_OP_UNKNOWN && pl.f_QUAL >= 0 && ((vmask >> pl.f_QUAL) & 1)) heavy = true;
   if (pl.produce_FILTER_field && pl.f_FILTER >= 0 && ((vmask >> pl.f_FILTER) & 1)) heavy = true;
   if (pl.f_ID >= 0 && ((vmask >> pl.f_ID) & 1)) heavy = true;   // ID union (broad_combined_gvcf.cc:730-763)
@@ -897,6 +898,8 @@ template <class T, class Sink> GDB_HD bool info_vector_combine_bcf(const SiteCtx
   return true;
 }
 
+#include "gdb_asa.hpp"
+
 // Per-record site logic.  PASS 0 (Sink = CountSink, write_luts = false) sizes the prefix; PASS 1 writes the prefix
 // text and the per-incidence allele LUTs / flags.  One call handles one record.
 // Position of `cand` in the merged allele list, appended when it is new (CombineAllelesLUT / merge_alt_alleles order: first
@@ -1193,6 +1196,7 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
     for (int i = 0; i < pl.n_info; ++i) {
       const int f = pl.info_field[i];
       const GdbFieldDesc& fd = pl.field[f];
+      if (fd.ndim == 2) { bool any2 = false; if (info_asa_sum(cx, k, f, num_merged, non_ref_exists, !ref_block_only, true, sink, any2, err)) ++n_info; continue; }
       if (fd.combine_op == GDB_OP_ELEMENT_WISE_SUM || fd.combine_op == GDB_OP_CONCATENATE) {
         bool found;
         if (fd.elem == GDB_ET_FLOAT) found = info_vector_combine_bcf<float>(cx, k, f, fd.combine_op, num_merged, non_ref_exists, !ref_block_only, sink, err);
@@ -1213,6 +1217,10 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
         bcf_enc_int1(sink, v);
       }
       ++n_info;
+    }
+    for (int i = 0; i < pl.n_histogram; ++i) {
+      bool any2 = false;
+      if (info_asa_histogram(cx, k, pl.histogram_bin_field[i], pl.histogram_count_field[i], num_merged, non_ref_exists, !ref_block_only, true, sink, any2, err)) ++n_info;
     }
     {
       const int32_t dp = cx.pc.dp_sum[k];
@@ -1303,6 +1311,7 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
     for (int i = 0; i < pl.n_info; ++i) {
       int f = pl.info_field[i];
       const GdbFieldDesc& fd = pl.field[f];
+      if (fd.ndim == 2) { info_asa_sum(cx, k, f, num_merged, non_ref_exists, !ref_block_only, false, sink, any, err); continue; }
       if (fd.combine_op == GDB_OP_ELEMENT_WISE_SUM || fd.combine_op == GDB_OP_CONCATENATE) {
         if (fd.elem == GDB_ET_FLOAT) info_vector_combine<float>(cx, k, f, fd.combine_op, num_merged, non_ref_exists, !ref_block_only, sink, any, err);
         else info_vector_combine<int32_t>(cx, k, f, fd.combine_op, num_merged, non_ref_exists, !ref_block_only, sink, any, err);
@@ -1325,6 +1334,8 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
       }
       any = true;
     }
+    for (int i = 0; i < pl.n_histogram; ++i)
+      info_asa_histogram(cx, k, pl.histogram_bin_field[i], pl.histogram_count_field[i], num_merged, non_ref_exists, !ref_block_only, false, sink, any, err);
     int32_t dp = cx.pc.dp_sum[k];
     if ((pl.f_DP >= 0 || pl.f_DP_FORMAT >= 0) && dp > 0 && !ref_block_only) {
       if (any) sink.put(';');

@@ -29,6 +29,7 @@
 #define GDB_MAX_PLOIDY 8            // general-ploidy genotype enumeration (G-length fields, min-PL genotype)
 #define GDB_MAX_INFO_VECTOR 64       // elements of an element_wise_sum INFO vector
 #define GDB_MAX_ID_TOKENS 16        // distinct ';'-separated ID tokens per output record
+#define GDB_MAX_HISTOGRAM_FIELDS 8  // composite (bins, counts) INFO fields reduced with histogram_sum
 
 // htslib / TileDB sentinels (reference include/vcf/vcf.h:59-218)
 #define GDB_BCF_INT32_MISSING ((int32_t)0x80000000)
@@ -67,6 +68,11 @@ struct GdbFieldDesc {
   int32_t combine_op;  // GdbCombineOp (INFO fields)
   int32_t is_info, is_format;
   int32_t known_enum;  // reference KnownVariantFieldsEnum or -1
+  // 2-D fields (allele-specific annotations): elem is GDB_ET_CHAR (the attribute is a byte blob, gdb_asa.hpp), `length` the
+  // descriptor of dimension 0, elem2d the type of the values inside, delim0 / delim1 the VCF delimiters of the two dimensions
+  int32_t ndim;
+  int32_t elem2d;
+  int32_t delim0, delim1;
 };
 
 // One attribute column of a staged fragment.  var-length: off[c]..off[c+1] elements of `data`.
@@ -96,6 +102,8 @@ struct CombinePlan {
   // emission order
   int32_t n_info;
   int32_t info_field[GDB_MAX_INFO_FIELDS];    // INFO fields with a combine op, query order (DP excluded)
+  int32_t n_histogram;                        // histogram_sum pairs, emitted after the other INFO fields (broad_combined_gvcf.cc:562-600)
+  int32_t histogram_bin_field[GDB_MAX_HISTOGRAM_FIELDS], histogram_count_field[GDB_MAX_HISTOGRAM_FIELDS];
   int32_t n_format;
   int32_t format_field[GDB_MAX_FORMAT_FIELDS];  // FORMAT fields, query order, INFO-DP pseudo entry last (if queried)
   // flags

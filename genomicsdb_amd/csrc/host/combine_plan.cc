@@ -1,6 +1,8 @@
 #include "combine_plan.h"
 
 #include <algorithm>
+#include <array>
+#include <map>
 #include <cstring>
 #include <set>
 
@@ -37,13 +39,19 @@ HostPlan build_combine_plan(const VariantQueryConfig& qc, const std::string& tmp
     const std::string& name = qc.get_query_attribute_name(q);
     if (name == "END") continue;
     const FieldInfo* fi = qc.get_field_info_for_query_attribute_idx(q);
-    if (fi->m_unsupported_on_device) throw UnsupportedOnDeviceException("multi-dimensional / tuple field " + name + " (SURVEY 8f-4)");
+    if (fi->m_unsupported_on_device) throw UnsupportedOnDeviceException("field " + name + " has more than 2 dimensions");
+    if (fi->m_num_dimensions == 2 && !(fi->m_is_vcf_INFO_field && !fi->m_is_vcf_FORMAT_field))
+      throw UnsupportedOnDeviceException("2-dimensional FORMAT field " + name + ": only INFO annotations are combined on the device");
     if (pl.nfields >= GDB_MAX_FIELDS) throw UnsupportedOnDeviceException("more than GDB_MAX_FIELDS queried attributes");
     int f = pl.nfields++;
     q2f[q] = f;
     hp.field_names.push_back(name);
     GdbFieldDesc& d = pl.field[f];
-    d.elem = fi->m_element_type;
+    d.elem = fi->m_num_dimensions == 2 ? GDB_ET_CHAR : fi->m_element_type;   // a 2-D field is a byte blob (gdb_asa.hpp)
+    d.ndim = (int32_t)fi->m_num_dimensions;
+    d.elem2d = fi->m_element_type;
+    d.delim0 = (unsigned char)fi->m_vcf_delimiter[0];
+    d.delim1 = (unsigned char)fi->m_vcf_delimiter[1];
     d.length = fi->m_length_descriptor;
     d.fixed_num = (int)fi->m_num_elements;
     d.combine_op = fi->m_VCF_field_combine_operation;
@@ -91,10 +99,27 @@ HostPlan build_combine_plan(const VariantQueryConfig& qc, const std::string& tmp
     if (l.rfind("##contig=", 0) == 0) hdr_contigs.insert(id);
   }
   auto add_field_to_hdr_if_missing = [&](const std::string& name, int cls) {
-    if (have[cls].count(name)) return;
     const FieldInfo* fi = vid.get_field_info(name);
+    // a multi-D or tuple field is a String with Number=1 in the header: a template line that says otherwise is removed and
+    // added again, keeping its description (vcf_adapter.cc:62-95)
+    const bool multid = fi && cls != 0 && (fi->get_num_elements_in_tuple() > 1u || fi->m_num_dimensions > 1u);
+    std::string kept_description;
+    if (multid && have[cls].count(name)) {
+      const std::string prefix = std::string("##") + (cls == 1 ? "INFO" : "FORMAT") + "=<ID=" + name + ",";
+      for (size_t li = 0; li < lines.size(); ++li)
+        if (lines[li].rfind(prefix, 0) == 0) {
+          const size_t dp = lines[li].find("Description="), de = lines[li].rfind('>');
+          if (dp != std::string::npos && de != std::string::npos && de > dp + 12) kept_description = lines[li].substr(dp + 12, de - dp - 12);
+          lines.erase(lines.begin() + (long)li);
+          break;
+        }
+      have[cls].erase(name);
+    }
+    if (have[cls].count(name)) return;
     std::string h = std::string("##") + (cls == 0 ? "FILTER" : cls == 1 ? "INFO" : "FORMAT") + "=<ID=" + name;
-    if (cls == 2 && name == "GT") h += ",Number=1,Type=String,Description=\"Genotype\"";
+    if (multid) {
+      h += ",Number=1,Type=String,Description=" + (kept_description.empty() ? "\"" + name + "\"" : kept_description);
+    } else if (cls == 2 && name == "GT") h += ",Number=1,Type=String,Description=\"Genotype\"";
     else {
       if (cls != 0) {
         if (!fi) throw BroadCombinedGVCFException("no vid info for header field " + name);
@@ -122,6 +147,7 @@ HostPlan build_combine_plan(const VariantQueryConfig& qc, const std::string& tmp
   const bool sites_only = qc.sites_only_query();
   int dp_info_plan_field = -1;
   std::vector<int> fmt_list;
+  std::map<int, std::array<int, 2>> histogram_pairs;   // composite vid field idx -> plan fields of (bins, counts)
   for (unsigned q = 0; q < qc.get_num_queried_attributes(); ++q) {
     int f = q2f[q];
     if (f < 0) continue;
@@ -131,9 +157,26 @@ HostPlan build_combine_plan(const VariantQueryConfig& qc, const std::string& tmp
     bool add_INFO = fi->m_is_vcf_INFO_field && ke != GVCF_END_IDX && (ke != GVCF_DP_IDX || op != GDB_OP_DP) && op != GDB_OP_MOVE_TO_FORMAT;
     bool add_FORMAT = (fi->m_is_vcf_FORMAT_field && (!sites_only || ke == GVCF_DP_FORMAT_IDX || ke == GVCF_MIN_DP_IDX)) ||
                       (fi->m_is_vcf_INFO_field && ((ke == GVCF_DP_IDX && op == GDB_OP_DP) || (op == GDB_OP_MOVE_TO_FORMAT && !sites_only)));
+    if (add_INFO && op == GDB_OP_HISTOGRAM_SUM) {   // the (bins, counts) pair of a composite field (broad_combined_gvcf.cc:194-221)
+      add_field_to_hdr_if_missing(fi->m_vcf_name, 1);
+      if (!fi->is_flattened_field()) throw BroadCombinedGVCFException("Operation histogram_sum needs a field whose elements are tuples; field " + fi->m_name);
+      const FieldInfo& parent = vid.get_field_info((unsigned)fi->m_parent_composite_field_idx);
+      if (parent.get_num_elements_in_tuple() != 2u)
+        throw BroadCombinedGVCFException("Operation histogram_sum is only supported for fields whose elements are tuple with 2 constituent elements; field " + parent.m_name +
+                                         " does not satisfy this requirement");
+      if (fi->m_element_type != GDB_ET_INT && fi->m_element_type != GDB_ET_FLOAT)
+        throw BroadCombinedGVCFException("Operation histogram_sum is only supported for tuple elements that are int or float; field " + parent.m_name);
+      if (fi->m_num_dimensions != 2) throw UnsupportedOnDeviceException("histogram_sum over a field that is not 2-dimensional: " + parent.m_name);
+      auto it = histogram_pairs.find(fi->m_parent_composite_field_idx);
+      if (it == histogram_pairs.end()) it = histogram_pairs.insert(std::make_pair(fi->m_parent_composite_field_idx, std::array<int, 2>{{-1, -1}})).first;
+      it->second[fi->m_element_index_in_tuple == 0u ? 0 : 1] = f;
+      continue;
+    }
     if (add_INFO && op != GDB_OP_UNKNOWN) {  // UNKNOWN: "field will NOT be part of INFO fields" warning in the reference
       if (op != GDB_OP_SUM && op != GDB_OP_MEAN && op != GDB_OP_MEDIAN && op != GDB_OP_ELEMENT_WISE_SUM && op != GDB_OP_CONCATENATE)
-        throw UnsupportedOnDeviceException("INFO combine operation of field " + fi->m_name + " (histogram_sum) is not on the device path yet");
+        throw UnsupportedOnDeviceException("INFO combine operation of field " + fi->m_name + " is not on the device path");
+      if (fi->m_num_dimensions == 2 && op != GDB_OP_ELEMENT_WISE_SUM)
+        throw UnsupportedOnDeviceException("2-dimensional INFO field " + fi->m_name + ": only element_wise_sum and histogram_sum are defined for it");
       if ((op == GDB_OP_ELEMENT_WISE_SUM || op == GDB_OP_CONCATENATE) && fi->m_length_descriptor == GDB_VL_G)
         throw UnsupportedOnDeviceException("genotype-length INFO vector " + fi->m_name + " is not on the device path yet");
       if (fi->m_element_type != GDB_ET_INT && fi->m_element_type != GDB_ET_FLOAT)
@@ -153,6 +196,14 @@ HostPlan build_combine_plan(const VariantQueryConfig& qc, const std::string& tmp
         add_field_to_hdr_if_missing("DP", 1);
       }
     }
+  }
+  for (auto& kv : histogram_pairs) {
+    if (pl.n_histogram >= GDB_MAX_HISTOGRAM_FIELDS) throw UnsupportedOnDeviceException("too many histogram_sum fields");
+    if (kv.second[0] < 0 || kv.second[1] < 0)
+      throw BroadCombinedGVCFException("histogram_sum needs both tuple elements of field " + vid.get_field_info((unsigned)kv.first).m_name + " among the queried attributes");
+    pl.histogram_bin_field[pl.n_histogram] = kv.second[0];
+    pl.histogram_count_field[pl.n_histogram] = kv.second[1];
+    ++pl.n_histogram;
   }
   if (pl.f_FILTER >= 0)
     for (unsigned i = 0; i < vid.get_num_fields(); ++i) if (vid.get_field_info(i).m_is_vcf_FILTER_field) add_field_to_hdr_if_missing(vid.get_field_info(i).m_vcf_name, 0);

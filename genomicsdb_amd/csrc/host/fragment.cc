@@ -12,8 +12,8 @@ VariantArraySchemaLite::VariantArraySchemaLite(const VidMapper& vid) {
     if (n == "END") { a.elem = GDB_ET_INT; a.var = false; a.num = 1; a.elem_size = 8; attrs.push_back(a); continue; }
     const FieldInfo* fi = vid.get_field_info(n);
     if (!fi) throw VidMapperException("schema attribute " + n + " has no field info");
-    a.elem = fi->m_element_type;
-    a.var = !fi->is_fixed_length_field();
+    a.elem = fi->m_num_dimensions > 1 ? GDB_ET_CHAR : fi->m_element_type;   // multi-D fields: a variable number of bytes
+    a.var = fi->m_num_dimensions > 1 || !fi->is_fixed_length_field();
     a.num = a.var ? 0 : (int)fi->m_num_elements;
     a.elem_size = (a.elem == GDB_ET_INT || a.elem == GDB_ET_FLOAT) ? 4 : 1;
     attrs.push_back(a);

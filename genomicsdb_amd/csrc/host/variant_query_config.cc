@@ -242,6 +242,18 @@ void VariantQueryConfig::do_query_bookkeeping(int64_t num_rows_in_array, int64_t
   m_query_attribute_name_to_query_idx.clear();
   std::vector<std::string> schema = m_vid_mapper.schema_attribute_names();
   std::vector<std::string> names = m_attributes.empty() ? schema : m_attributes;  // no attributes = all (query_variants.cc:245-251)
+  {  // flatten_composite_fields (variant_query_config.cc:187-229): the tuple elements of a queried composite join the end of the
+     // list, the composite itself leaves it
+    std::vector<std::string> keep, extra;
+    for (auto& n : names) {
+      const FieldInfo* fi = m_vid_mapper.get_field_info(n);
+      if (!fi) throw UnknownQueryAttributeException("Field " + n + " not found in vid mapping");
+      if (fi->get_num_elements_in_tuple() > 1u) for (unsigned j = 0; j < fi->get_num_elements_in_tuple(); ++j) extra.push_back(m_vid_mapper.get_flattened_field_info(fi, j)->m_name);
+      else keep.push_back(n);
+    }
+    keep.insert(keep.end(), extra.begin(), extra.end());
+    names = keep;
+  }
   for (auto& n : names) {
     const FieldInfo* fi = m_vid_mapper.get_field_info(n);
     if (!fi) throw UnknownQueryAttributeException("Field " + n + " not found in vid mapping");

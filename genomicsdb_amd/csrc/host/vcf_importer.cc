@@ -7,6 +7,7 @@
 #include <climits>
 #include <cstdlib>
 #include <cstring>
+#include <strings.h>
 #include <unordered_map>
 
 namespace genomicsdb_amd {
@@ -50,6 +51,7 @@ struct Attr {            // one INFO / FORMAT attribute of the schema, in cell o
   const FieldInfo* fi;
   bool info;
   bool sum_like;         // FieldInfo::is_VCF_field_combine_operation_sum (vid_mapper.cc:1187-1193)
+  const FieldInfo* parent = nullptr;   // the composite field of a flattened tuple element
 };
 
 // bcf_get_variant_type(line, j) == VCF_INDEL && strlen(REF) > strlen(ALT) (vcf2binary.cc:1046-1057; htslib bcf_set_variant_type),
@@ -85,9 +87,56 @@ double parse_double(const Tok& t, const std::string& what) {
   return v;
 }
 
+// A 2-dimensional value ("1.0,2.0|3.0|4.0", the elements of a type tuple alternating inside an inner vector) -> the byte blob of
+// THIS tuple element: <u64 size of data><inner vectors><u64 #entries><u64 offsets x (#entries + 1)>
+// (GenomicsDBMultiDVectorField::parse_and_store_numeric, genomicsdb_multid_vector_field.cc:238-464; vcf2binary.cc:857-913).
+// "" and "NaN" are bcf missing (str_to_element, :31-87), shorter tuple elements are padded with missing, and a sum-like INFO
+// field of a multi-sample VCF is divided up among the samples (histogram_sum: the counts only, vcf2binary.cc:862-884).
+void encode_2d(std::vector<uint8_t>& o, const Attr& a, const FieldInfo& parent, bool present, const Tok& text, int n_samples, int sample_idx) {
+  const FieldInfo& f = *a.fi;
+  if (!present || tok_is(text, ".")) { put<int32_t>(o, 0); return; }
+  const unsigned ntuple = parent.get_num_elements_in_tuple(), me = f.is_flattened_field() ? f.m_element_index_in_tuple : 0u;
+  const bool is_int = f.m_element_type == GDB_ET_INT;
+  bool divide = a.sum_like && a.info && n_samples > 1;
+  if (divide && f.m_VCF_field_combine_operation == GDB_OP_HISTOGRAM_SUM) divide = me == 1u;
+  std::vector<uint8_t> data;
+  std::vector<uint64_t> offsets(1, 0);
+  std::vector<Tok> inners, toks;
+  split(text.p, text.n, f.m_vcf_delimiter[0], inners);
+  if (inners.empty()) inners.push_back(Tok{text.p, 0});
+  for (const Tok& inner : inners) {
+    toks.clear();
+    split(inner.p, inner.n, f.m_vcf_delimiter[1], toks);
+    if (toks.empty()) toks.push_back(Tok{inner.p, 0});
+    const size_t n = (toks.size() + ntuple - 1) / ntuple;     // elements of the longest tuple element
+    for (size_t i = 0; i < n; ++i) {
+      const size_t at = i * ntuple + me;
+      const Tok t = at < toks.size() ? toks[at] : Tok{inner.p, 0};
+      const bool missing = t.n == 0 || (t.n == 3 && strncasecmp(t.p, "NaN", 3) == 0);
+      if (is_int) {
+        int64_t v = kBcfIntMissing;
+        if (!missing) {
+          v = strtoll(tok_str(t).c_str(), nullptr, 0);
+          if (divide) { int64_t q = v / n_samples, r = v % n_samples; v = q + (sample_idx < r ? 1 : 0); }
+        }
+        put<int32_t>(data, (int32_t)v);
+      } else if (missing) put<uint32_t>(data, kBcfFloatMissingBits);
+      else { float v = strtof(tok_str(t).c_str(), nullptr); if (divide) v = v / (float)n_samples; put<float>(data, v); }
+    }
+    offsets.push_back((uint64_t)data.size());
+  }
+  const size_t blob = 8 + data.size() + 8 + 8 * offsets.size();
+  put<int32_t>(o, (int32_t)blob);
+  put<uint64_t>(o, (uint64_t)data.size());
+  o.insert(o.end(), data.begin(), data.end());
+  put<uint64_t>(o, (uint64_t)(offsets.size() - 1));
+  for (uint64_t x : offsets) put<uint64_t>(o, x);
+}
+
 // one INFO / FORMAT value string -> attribute bytes (vcf2binary.cc:771-969).  present = the key exists in the record
 void encode_values(std::vector<uint8_t>& o, const Attr& a, bool present, const Tok& text, int n_samples, int sample_idx, std::vector<Tok>& scratch) {
   const FieldInfo& f = *a.fi;
+  if (f.m_num_dimensions == 2) { encode_2d(o, a, a.parent ? *a.parent : f, present, text, n_samples, sample_idx); return; }
   const bool missing = !present || tok_is(text, ".");
   if (f.m_element_type == GDB_ET_FLAG) { o.push_back((uint8_t)(present ? 1 : kTileDBNullChar)); return; }
   if (f.m_element_type == GDB_ET_CHAR) {
@@ -167,12 +216,19 @@ std::vector<uint8_t> import_callsets_to_cells(const VidMapper& vid, const Import
     const GdbCombineOp op = f.m_VCF_field_combine_operation;
     const bool sum_like = op == GDB_OP_SUM || op == GDB_OP_DP || op == GDB_OP_ELEMENT_WISE_SUM || op == GDB_OP_HISTOGRAM_SUM;
     if (f.m_unsupported_on_device && (f.m_is_vcf_INFO_field || f.m_is_vcf_FORMAT_field))
-      throw VCF2BinaryException("field " + f.m_name + ": multi-dimensional / tuple fields are not imported by this build");
-    if (f.m_is_vcf_INFO_field) info_attrs.push_back(Attr{&f, true, sum_like});
+      throw VCF2BinaryException("field " + f.m_name + ": fields of more than 2 dimensions are not imported by this build");
+    if (f.get_num_elements_in_tuple() > 1u) {   // a composite is not an attribute, its flattened tuple elements are
+      if (f.m_num_dimensions != 2) throw VCF2BinaryException("field " + f.m_name + ": tuple elements are only imported for 2-dimensional fields");
+      continue;
+    }
+    const FieldInfo* parent = f.is_flattened_field() ? &vid.get_field_info((unsigned)f.m_parent_composite_field_idx) : nullptr;
+    if (f.m_is_vcf_INFO_field) { Attr a{&f, true, sum_like}; a.parent = parent; info_attrs.push_back(a); }
   }
   for (unsigned i = 0; i < vid.get_num_fields(); ++i) {
     const FieldInfo& f = vid.get_field_info(i);
-    if (f.m_name != "END" && f.m_is_vcf_FORMAT_field) fmt_attrs.push_back(Attr{&f, false, false});
+    if (f.get_num_elements_in_tuple() > 1u) continue;
+    const FieldInfo* parent = f.is_flattened_field() ? &vid.get_field_info((unsigned)f.m_parent_composite_field_idx) : nullptr;
+    if (f.m_name != "END" && f.m_is_vcf_FORMAT_field) { Attr a{&f, false, false}; a.parent = parent; fmt_attrs.push_back(a); }
   }
   // callsets grouped by file, in mapping order
   std::vector<std::string> files;

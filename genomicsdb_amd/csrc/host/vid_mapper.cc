@@ -85,7 +85,7 @@ bool parse_length(const mini_json::Value& v, GdbLength& ld, unsigned& n) {
     return true;
   }
   if (v.IsArray() && v.Size() == 1) return parse_length(v[0], ld, n);
-  return false;  // multi-dimensional
+  return false;  // multi-dimensional: the caller handles 2 dimensions
 }
 
 }  // namespace
@@ -93,6 +93,10 @@ bool parse_length(const mini_json::Value& v, GdbLength& ld, unsigned& n) {
 const FieldInfo* VidMapper::get_field_info(const std::string& name) const {
   auto it = m_field_name_to_idx.find(name);
   return it == m_field_name_to_idx.end() ? nullptr : &m_field_idx_to_info[it->second];
+}
+
+const FieldInfo* VidMapper::get_flattened_field_info(const FieldInfo* field_info, unsigned tuple_element_index) const {
+  return get_field_info(field_info->m_name + "_tuple_element_" + std::to_string(tuple_element_index));
 }
 
 bool VidMapper::get_contig_info(const std::string& name, ContigInfo& out) const {
@@ -163,11 +167,23 @@ void VidMapper::parse_vid_json(const mini_json::Value& doc) {
         else if (c == "FORMAT") f.m_is_vcf_FORMAT_field = true;
         else if (c == "FILTER") f.m_is_vcf_FILTER_field = true;
       }
-    if (d.HasMember("length")) { if (!parse_length(d["length"], f.m_length_descriptor, f.m_num_elements)) f.m_unsupported_on_device = true; }
-    else if (ke >= 0) default_length(ke, f.m_length_descriptor, f.m_num_elements);
+    if (d.HasMember("length")) {
+      if (!parse_length(d["length"], f.m_length_descriptor, f.m_num_elements)) {
+        const auto& la = d["length"];
+        if (la.IsArray() && la.Size() == 2 && parse_length(la[0], f.m_length_descriptor, f.m_num_elements)) f.m_num_dimensions = 2;
+        else f.m_unsupported_on_device = true;
+      }
+    } else if (ke >= 0) default_length(ke, f.m_length_descriptor, f.m_num_elements);
     if (!d.HasMember("type")) throw VidMapperException("Field " + name + " has no \"type\"");
-    if (d["type"].IsString()) f.m_element_type = parse_type_name(d["type"].GetString());
-    else { f.m_unsupported_on_device = true; f.m_element_type = GDB_ET_CHAR; }
+    if (d["type"].IsString()) f.m_tuple_element_types.assign(1, parse_type_name(d["type"].GetString()));
+    else for (size_t j = 0; j < d["type"].Size(); ++j) f.m_tuple_element_types.push_back(parse_type_name(d["type"][j].GetString()));
+    if (f.m_tuple_element_types.empty()) throw VidMapperException("Field " + name + " has an empty \"type\" list");
+    f.m_element_type = f.m_tuple_element_types[0];
+    if (d.HasMember("vcf_delimiter")) {
+      const auto& vd = d["vcf_delimiter"];
+      if (vd.IsString()) { if (!vd.GetString().empty()) f.m_vcf_delimiter[0] = vd.GetString()[0]; }
+      else for (size_t j = 0; j < vd.Size() && j < 2; ++j) if (!vd[j].GetString().empty()) f.m_vcf_delimiter[j] = vd[j].GetString()[0];
+    }
     if (d.HasMember("VCF_field_combine_operation")) {
       f.m_VCF_field_combine_operation = parse_combine_op(d["VCF_field_combine_operation"].GetString(), name);
       if (f.m_VCF_field_combine_operation == GDB_OP_CONCATENATE && f.m_length_descriptor != GDB_VL_VAR)
@@ -184,6 +200,23 @@ void VidMapper::parse_vid_json(const mini_json::Value& doc) {
       m_field_idx_to_info[f.m_field_idx].m_is_vcf_FORMAT_field = false;
       m_field_name_to_idx[g.m_name] = g.m_field_idx;
       m_field_idx_to_info.push_back(g);
+    }
+    if (f.get_num_elements_in_tuple() > 1u) {  // the elements of the tuple as fields of their own (vid_mapper.cc:751-787)
+      const bool both = f.m_is_vcf_INFO_field && f.m_is_vcf_FORMAT_field;
+      const int original = f.m_field_idx, format_idx = both ? f.m_field_idx + 1 : f.m_field_idx;
+      for (unsigned j = 0; j < (both ? 2u : 1u); ++j)
+        for (unsigned t = 0; t < f.get_num_elements_in_tuple(); ++t) {
+          FieldInfo g = m_field_idx_to_info[(size_t)(j == 0u ? original : format_idx)];
+          g.m_name += "_tuple_element_" + std::to_string(t);
+          g.m_field_idx = (int)m_field_idx_to_info.size();
+          g.m_tuple_element_types.assign(1, f.m_tuple_element_types[t]);
+          g.m_element_type = f.m_tuple_element_types[t];
+          g.m_element_index_in_tuple = t;
+          g.m_is_flattened_field = true;
+          g.m_parent_composite_field_idx = j == 0u ? original : format_idx;
+          m_field_name_to_idx[g.m_name] = g.m_field_idx;
+          m_field_idx_to_info.push_back(g);
+        }
     }
   }
   add_mandatory_fields();
@@ -235,8 +268,10 @@ std::vector<std::string> VidMapper::schema_attribute_names() const {
   if (m_field_name_to_idx.count("ID")) a.push_back("ID");
   a.push_back("QUAL");
   a.push_back("FILTER");
-  for (auto& f : m_field_idx_to_info) if (f.m_name != "END" && f.m_is_vcf_INFO_field) a.push_back(f.m_name);
-  for (auto& f : m_field_idx_to_info) if (f.m_name != "END" && f.m_is_vcf_FORMAT_field) a.push_back(f.m_is_vcf_INFO_field ? f.m_name + "_FORMAT" : f.m_name);
+  // (a composite field is not an attribute, its flattened tuple elements are: vid_mapper.cc:399-404)
+  for (auto& f : m_field_idx_to_info) if (f.m_name != "END" && f.get_num_elements_in_tuple() == 1u && f.m_is_vcf_INFO_field) a.push_back(f.m_name);
+  for (auto& f : m_field_idx_to_info)
+    if (f.m_name != "END" && f.get_num_elements_in_tuple() == 1u && f.m_is_vcf_FORMAT_field) a.push_back(f.m_is_vcf_INFO_field ? f.m_name + "_FORMAT" : f.m_name);
   return a;
 }
 

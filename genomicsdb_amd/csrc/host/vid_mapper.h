@@ -35,7 +35,19 @@ struct FieldInfo {
   unsigned m_num_elements = 1;
   GdbElem m_element_type = GDB_ET_INT;
   GdbCombineOp m_VCF_field_combine_operation = GDB_OP_UNKNOWN;
-  bool m_unsupported_on_device = false;  // multi-D / tuple fields
+  bool m_unsupported_on_device = false;  // fields of more than 2 dimensions
+  // 2-D fields (allele-specific annotations, "length": [ "R", "var" ]) and fields whose elements are tuples ("type": [ "float",
+  // "int" ]): m_length_descriptor describes dimension 0, the data is one byte blob per tuple element
+  // (genomicsdb_multid_vector_field.h:69-86), every tuple element is a flattened field <name>_tuple_element_<i> of its own
+  // with the vcf name of the composite (reference vid_mapper.cc:727-800)
+  unsigned m_num_dimensions = 1;
+  char m_vcf_delimiter[2] = {'|', ','};
+  std::vector<GdbElem> m_tuple_element_types;
+  bool m_is_flattened_field = false;
+  unsigned m_element_index_in_tuple = 0;
+  int m_parent_composite_field_idx = -1;
+  unsigned get_num_elements_in_tuple() const { return m_tuple_element_types.empty() ? 1u : (unsigned)m_tuple_element_types.size(); }
+  bool is_flattened_field() const { return m_is_flattened_field; }
   bool is_fixed_length_field() const { return m_length_descriptor == GDB_VL_FIXED; }
   bool is_length_allele_dependent() const { return m_length_descriptor == GDB_VL_A || m_length_descriptor == GDB_VL_R || m_length_descriptor == GDB_VL_G; }
   bool is_length_genotype_dependent() const { return m_length_descriptor == GDB_VL_G; }
@@ -54,6 +66,7 @@ class VidMapper {
   unsigned get_num_fields() const { return (unsigned)m_field_idx_to_info.size(); }
   const FieldInfo& get_field_info(unsigned idx) const { return m_field_idx_to_info[idx]; }
   const FieldInfo* get_field_info(const std::string& name) const;
+  const FieldInfo* get_flattened_field_info(const FieldInfo* field_info, unsigned tuple_element_index) const;
   unsigned get_num_contigs() const { return (unsigned)m_contig_idx_to_info.size(); }
   const ContigInfo& get_contig_info(unsigned idx) const { return m_contig_idx_to_info[idx]; }
   bool get_contig_info(const std::string& name, ContigInfo& out) const;

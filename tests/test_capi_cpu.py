@@ -52,12 +52,18 @@ def test_product_does_not_reference_oracle():
     assert not bad, bad
 
 
-def test_unsupported_configurations_are_rejected_by_name():
+def test_unsupported_configurations_are_rejected_by_name(tmp_path):
     """what the device path does not implement is refused when the plan is built (before any device work), with the
-    reference-facing exception text: allele-specific (2-D) annotation fields + histogram_sum"""
+    reference-facing exception text: annotation fields of more than two dimensions"""
     import genomicsdb_amd
+    import json
+    vid = json.load(open(os.path.join(helpers.GOLDEN, "inputs", "vid_all_asa.json")))
+    vid["fields"]["AS_RAW_MQ"]["length"] = ["R", "var", "var"]
+    vid["fields"]["AS_RAW_MQ"]["vcf_delimiter"] = ["|", ",", ":"]
+    (tmp_path / "vid3d.json").write_text(json.dumps(vid))
     q, _ = helpers.query_json("t0_1_2_all_asa.json", "vid_all_asa.json", {}, "load")
-    with pytest.raises(genomicsdb_amd.GenomicsDBException, match="UnsupportedOnDevice|not on the device path|multi-dimensional"):
+    q["vid_mapping_file"] = str(tmp_path / "vid3d.json")
+    with pytest.raises(genomicsdb_amd.GenomicsDBException, match="UnsupportedOnDevice|more than 2 dimensions"):
         genomicsdb_amd.CombineEngine(q)
 
 

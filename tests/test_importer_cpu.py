@@ -78,6 +78,4 @@ def test_import_errors_are_loud(gdb, tmp_path):
     v, c = _paths("t0_1_2.json", "vid.json")
     with pytest.raises(gdb.GenomicsDBException, match="cannot open"):
         gdb.import_cells(v, c, file_root=str(tmp_path))
-    va, ca = _paths("t0_1_2_all_asa.json", "vid_all_asa.json")
-    with pytest.raises(gdb.GenomicsDBException, match="multi-dimensional"):
-        gdb.import_cells(va, ca, file_root=helpers.GOLDEN)
+
