@@ -1673,8 +1673,29 @@ __global__ void __launch_bounds__(kAsmRows) k_bcf_write(CombinePlan pl, const ui
   const bool flag = pl.use_missing_values_not_vector_end != 0;
   const bool live = (uint32_t)lane < nsamp;
   uint32_t held = 0xFFFFFFFFu;
+  // what the record loop needs from memory is fetched one record ahead, as vector loads: the sample's resolved entry, and the
+  // record's row of the layout (lane q holds field q's fmeta / foff; every lane its own copy of fmt_mask and the record offset).
+  // (Scalar loads per field sat on the critical path: ~14 dependent s_load + s_waitcnt per (record, chunk).)
+  // per FORMAT field of the plan (lane i): bytes per element in the entries, GT or not
+  uint32_t my_field = 0;
+  if (lane < pl.n_format) my_field = (uint32_t)bcf_field_elem_size(pl, lane) | (pl.format_field[lane] == pl.f_GT ? 0x100u : 0u);
+  const int n_format = pl.n_format;
+  uint2 d_next = resolved[(k0 * nchunks + ch) * kAsmRows + lane];
+  uint32_t meta_next = lane < F ? lay.fmeta[k0 * F + lane] : 0u, foff_next = lane < F ? lay.foff[k0 * F + lane] : 0u;
+  uint32_t mask_next = fmt_mask[k0];
+  uint64_t roff_next = rec_off[k0];
   for (int64_t k = k0; k < k1; ++k) {                    // uniform
-    const uint2 d = resolved[(k * nchunks + ch) * kAsmRows + lane];
+    const uint2 d = d_next;
+    const uint32_t my_meta = meta_next, my_foff = foff_next;
+    const uint32_t mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)mask_next);
+    char* rec = arena + (readlane64((int64_t)roff_next, 0) - (int64_t)page_base);
+    if (k + 1 < k1) {
+      d_next = resolved[((k + 1) * nchunks + ch) * kAsmRows + lane];
+      meta_next = lane < F ? lay.fmeta[(k + 1) * F + lane] : 0u;
+      foff_next = lane < F ? lay.foff[(k + 1) * F + lane] : 0u;
+      mask_next = fmt_mask[k + 1];
+      roff_next = rec_off[k + 1];
+    }
     const char* src = ((d.x & kOverflowBit) ? pool_ovf : pool) + (size_t)(d.x & ~kOverflowBit) * 16;
     if (d.y && d.x != held) {
       const uint32_t take = d.y < (uint32_t)kBcfEntryCap ? d.y : (uint32_t)kBcfEntryCap;
@@ -1682,19 +1703,18 @@ __global__ void __launch_bounds__(kAsmRows) k_bcf_write(CombinePlan pl, const ui
       held = d.x;
     }
     const bool whole = !__any((int)(live && d.y > (uint32_t)kBcfEntryCap));   // every live lane's entry is in its slot
-    const uint32_t mask = fmt_mask[k];
     const int nf = __popc(mask);
-    char* rec = arena + (rec_off[k] - page_base);
     uint32_t body = bcf_summary_bytes(nf);        // this lane's read position inside its entry
     int q = 0;
-    for (int i = 0; i < pl.n_format; ++i) {       // uniform
+    for (int i = 0; i < n_format; ++i) {          // uniform
       if (!((mask >> i) & 1u)) continue;
-      const uint32_t m = lay.fmeta[k * F + q];
+      const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)my_meta, q);
       const uint32_t cnt = m & 0xFFFFu, t = (m >> 16) & 0xFu, hdr = m >> 24;
       const uint32_t w = (uint32_t)bcf_type_width((int)t);
-      const int es = bcf_field_elem_size(pl, i);
+      const uint32_t fld = (uint32_t)__builtin_amdgcn_readlane((int)my_field, i);
+      const int es = (int)(fld & 0xFFu);
       const uint32_t n = d.y ? bcf_summary_n(reinterpret_cast<const uint16_t*>(s_entry + lane * kBcfEntryCap)[q]) : 0u;
-      const bool is_gt = pl.format_field[i] == pl.f_GT;
+      const bool is_gt = (fld & 0x100u) != 0u;
       // no element: CHAR '.' then vector ends (all vector ends under the htsjdk flag); FLOAT / INT missing then vector ends
       // (missing everywhere under the flag); GT is all vector ends (no-call alleles under the flag)
       uint32_t first, rest;
@@ -1702,7 +1722,7 @@ __global__ void __launch_bounds__(kAsmRows) k_bcf_write(CombinePlan pl, const ui
       else if (t == GDB_BT_FLOAT) { first = GDB_BCF_FLOAT_MISSING_BITS; rest = flag ? GDB_BCF_FLOAT_MISSING_BITS : GDB_BCF_FLOAT_VECTOR_END_BITS; }
       else { first = is_gt ? (flag ? 0u : (uint32_t)GDB_BCF_INT32_VECTOR_END) : (uint32_t)GDB_BCF_INT32_MISSING; rest = flag ? (uint32_t)GDB_BCF_INT32_MISSING : (uint32_t)GDB_BCF_INT32_VECTOR_END; }
       const uint32_t per = cnt * w;                // bytes per sample
-      char* const fdst = rec + lay.foff[k * F + q] + hdr + (size_t)ch * kAsmRows * per;     // the 64 samples' values of this field
+      char* const fdst = rec + (uint32_t)__builtin_amdgcn_readlane((int)my_foff, q) + hdr + (size_t)ch * kAsmRows * per;     // the 64 samples' values of this field
       if (per <= (uint32_t)kBcfImageSample) {      // uniform
         const uint32_t al = (uint32_t)((uintptr_t)fdst & 15u);
         if (live) {

@@ -1112,7 +1112,7 @@ class BroadCombinedGVCFOperator : public SingleVariantOperatorBase {
       else if (fb.et == ET_FLOAT) found = histogram_sum_2D<float, int32_t>(src, q_bin, q_count, fb, text);
       else if (fc.et == ET_FLOAT) found = histogram_sum_2D<int32_t, float>(src, q_bin, q_count, fb, text);
       else found = histogram_sum_2D<int32_t, int32_t>(src, q_bin, q_count, fb, text);
-      if (found) { RecInfo& e = rec_.info_slot(fb.vcf_name); e.type = 2; e.sv = text; }
+      if (found && !text.empty()) { RecInfo& e = rec_.info_slot(fb.vcf_name); e.type = 2; e.sv = text; }   // (bcf_update_info with 0 values adds nothing)
     }
   }
 

@@ -1115,3 +1115,27 @@ def test_reference_shaped_cpp_caller_produces_the_golden(gdb, tmp_path):
         assert r.stdout == helpers.golden_text(golden)
     r = subprocess.run([tool, str(qf), "0", "more"], capture_output=True, timeout=120)
     assert r.returncode == 0 and b"per-record operator refused: yes" in r.stderr and b"batched hook: 1 pages" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,is_bcf", [(5, False), (6, False), (7, True)])
+def test_allele_specific_annotations_fuzz_on_device(gdb, seed, is_bcf):
+    """random per-allele vectors / histograms (empty vectors, NaN, repeated bins, ALT subsets per sample) through the device path:
+    2-D element_wise_sum and histogram_sum (gdb_asa.hpp) against the oracle, as VCF text and decoded from the BCF2 stream"""
+    import numpy as np
+    from test_hostsim_golden import _asa_cells
+    rng = np.random.default_rng(seed)
+    cells = _asa_cells(rng, 3, 60)
+    q, pb = helpers.query_json("t0_1_2_all_asa.json", "vid_all_asa.json", {}, "load")
+    want, nrec, _ = helpers.oracle_run(q, cells, partition_begin=pb)
+    assert nrec >= 40 and want.count(b"AS_RAW_MQRankSum=") > 15
+    if not is_bcf:
+        s = gdb.GenomicsDBQueryStream(query_json=q, cells=cells, buffer_capacity=1 << 20)
+        got = s.read()
+        s.close()
+        assert got == want
+    else:
+        s = gdb.GenomicsDBQueryStream(query_json=q, cells=cells, buffer_capacity=1 << 20, is_bcf=True)
+        data = s.read()
+        s.close()
+        assert helpers.bcf_stream_to_text(data) == want

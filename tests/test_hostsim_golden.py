@@ -69,3 +69,93 @@ def test_median_selection_is_the_c_library_selection():
             check(np.round(rng.standard_normal(n), 1) + np.float32(0.0) * rng.choice([-1.0, 1.0], size=n))
             check(rng.standard_normal(n), nth=int(rng.integers(0, n)))
         check(np.arange(n)); check(np.arange(n)[::-1]); check(np.zeros(n)); check(np.concatenate([np.arange(n // 2), np.arange(n - n // 2)[::-1]]))
+
+
+ASA_ATTRIBUTES = ["END", "REF", "ALT", "BaseQRankSum", "ClippingRankSum", "MQRankSum", "ReadPosRankSum", "MQ", "RAW_MQ", "MQ0", "DP",
+                  "GT", "GQ", "SB", "AD", "PL", "PGT", "PID", "MIN_DP", "DP_FORMAT", "FILTER", "AS_RAW_MQ", "AS_RAW_MQRankSum"]
+
+
+def test_queried_composite_field_is_flattened():
+    """A query that names a composite field (AS_RAW_MQRankSum: tuple of bins and counts) gets its flattened tuple elements at the
+    end of the attribute list (VariantQueryConfig::flatten_composite_fields, variant_query_config.cc:187-229; the attribute list
+    is run.py's asa_vcf_attributes).  Oracle and kernel bodies agree, and the record of the golden is in the output."""
+    cells = helpers.cells_for("t0_1_2_all_asa.json", "vid_all_asa.json")
+    q, pb = helpers.query_json("t0_1_2_all_asa.json", "vid_all_asa.json", {"query_column_ranges": [{"range_list": [{"low": 0, "high": 1000000000}]}]}, "query")
+    q["attributes"] = ASA_ATTRIBUTES
+    want, nrec, _ = helpers.oracle_run(q, cells, partition_begin=pb)
+    got, errbits = helpers.hostsim_run(q, cells)
+    assert errbits == 0 and got == want
+    assert b"AS_RAW_MQ=8.000,10.000,9.000|28.000,16.000,18.000,14.000|31.000|32.000,12.000,13.000,14.000;AS_RAW_MQRankSum=|0.600,6,0.800,2,0.900,15|0.100,2,0.600,7|" in want
+
+
+def _asa_cells(rng, n_samples, n_sites):
+    """synthetic cells for vid_all_asa.json: every site has a shared pool of ALT alleles, each sample takes some of them and
+    carries random per-allele vectors / histograms (empty vectors, NaN and repeated bins included)"""
+    import struct
+    import vcf2cells
+    import os
+    fields, contigs = vcf2cells.load_vid(os.path.join(helpers.GOLDEN, "inputs", "vid_all_asa.json"))
+    attrs, info_fields, fmt_fields = vcf2cells.schema_attributes(fields)
+    cells = []
+    for s in range(n_sites):
+        col = 1000 + 10 * s
+        pool = ["A", "C", "T", "GA"][: 1 + int(rng.integers(0, 4))]
+        for row in range(n_samples):
+            if rng.random() < 0.15:
+                continue
+            k = 1 + int(rng.integers(0, len(pool)))
+            alts = list(rng.permutation(pool)[:k]) + ["<NON_REF>"]
+            nall = len(alts) + 1
+
+            def vec(lo, hi, as_int=False):
+                n = int(rng.integers(lo, hi + 1))
+                out = []
+                for _ in range(n):
+                    if rng.random() < 0.1:
+                        out.append("NaN" if not as_int else "")
+                    elif as_int:
+                        out.append(str(int(rng.integers(0, 50))))
+                    else:
+                        out.append("%.2f" % (rng.integers(-4000, 4000) / 100.0))
+                return out
+            mq = "|".join(",".join(vec(0, 4)) for _ in range(nall)) if rng.random() < 0.85 else None
+            def hist():
+                n = int(rng.integers(0, 4))
+                toks = []
+                for _ in range(n):
+                    toks += ["%.1f" % (int(rng.integers(-5, 6)) / 10.0) if rng.random() > 0.1 else "NaN", str(int(rng.integers(1, 20)))]
+                return ",".join(toks)
+            rs = "|".join(hist() for _ in range(nall)) if rng.random() < 0.85 else None
+            info_d = {"AS_RAW_MQ": mq, "AS_RAW_MQRankSum": rs}
+            alt_ser = "|".join("&" if a == "<NON_REF>" else a for a in alts)
+            body = struct.pack("<q", col)
+            body += struct.pack("<i", 1) + b"G"
+            body += struct.pack("<i", len(alt_ser)) + alt_ser.encode()
+            body += struct.pack("<I", vcf2cells.TILEDB_NULL_FLOAT_BITS)
+            body += struct.pack("<i", 0)
+            for f in info_fields:
+                body += vcf2cells.encode_values(f, info_d.get(f.vcf_name), len(alts))
+            for f in fmt_fields:
+                if f.vcf_name == "GT":
+                    body += vcf2cells.encode_gt(f, "0/1")
+                else:
+                    body += vcf2cells.encode_values(f, None, len(alts))
+            cells.append((row, col, struct.pack("<qqQ", row, col, 24 + len(body)) + body))
+    cells.sort(key=lambda t: (t[1], t[0]))
+    return b"".join(c[2] for c in cells)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_allele_specific_annotations_fuzz(seed):
+    """random per-allele vectors and histograms over sites with different ALT subsets per sample: the streaming reducers of
+    gdb_asa.hpp (allele-LUT lookup per element, next-larger-bin selection) against the oracle's remapped blobs, vectors and
+    std::map (remap_allele_specific_annotations, compute_valid_element_wise_sum_2D_vector, histogram_sum)"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    cells = _asa_cells(rng, 3, 40)
+    q, pb = helpers.query_json("t0_1_2_all_asa.json", "vid_all_asa.json", {}, "load")
+    want, nrec, _ = helpers.oracle_run(q, cells, partition_begin=pb)
+    got, errbits = helpers.hostsim_run(q, cells)
+    assert errbits == 0
+    assert nrec >= 30 and want.count(b"AS_RAW_MQ=") > 10 and want.count(b"AS_RAW_MQRankSum=") > 10
+    assert got == want

@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -x -q 2>&1 | tail -8
-python bench.py --no-cpu-baseline --no-stream 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('text',d['value'], d['roofline']['avg_launch_ms'], d['ms_per_step'], d['phase_ms'])"
+python -m pytest tests -m gpu -x -q -k "bcf or jni or allele_specific" 2>&1 | tail -3
+for d in 0 3; do GDBAMD_BCF_DBG=$d python bench.py --bcf --steps 3 --warmup 1 --no-cpu-baseline --no-stream 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('bcf dbg=$d',d['value'], d['ms_per_step'], d['phase_ms'])"; done
