@@ -233,9 +233,18 @@ void CombineEngine::advance_window() {
         }
         buf = S.chunk;
       }
-      const DevicePipeline::CellWalk wk = DevicePipeline::walk_cells(buf, n, L.row_map, !to_end, offs);
-      if (wk.single_column) { want *= 2; continue; }     // one begin column wider than the sub-chunk: offer more bytes
-      const DevicePipeline::CellStreamInfo info = m_pipe->append_cells(buf, wk.bytes_taken, L.schema, L.attr_to_field, L.row_map, &offs, &wk);
+      // the sizes are walked on the device (GDBAMD_HOST_WALK=1: by one host thread, for comparison)
+      static const bool host_walk = getenv("GDBAMD_HOST_WALK") != nullptr;
+      DevicePipeline::CellWalk wk;
+      DevicePipeline::CellStreamInfo info;
+      if (host_walk) {
+        wk = DevicePipeline::walk_cells(buf, n, L.row_map, !to_end, offs);
+        if (wk.single_column) { want *= 2; continue; }     // one begin column wider than the sub-chunk: offer more bytes
+        info = m_pipe->append_cells(buf, wk.bytes_taken, L.schema, L.attr_to_field, L.row_map, &offs, &wk);
+      } else {
+        info = m_pipe->append_cells(buf, n, L.schema, L.attr_to_field, L.row_map, nullptr, nullptr, !to_end, &wk);
+        if (wk.single_column) { want *= 2; continue; }
+      }
       reference_cell_bytes += info.reference_cell_bytes;
       new_cells += info.ncells;
       if (info.ncells > 0) { min_begin = std::min(min_begin, info.min_begin); max_end = std::max(max_end, info.max_end); }

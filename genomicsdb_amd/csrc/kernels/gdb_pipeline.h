@@ -78,9 +78,14 @@ class DevicePipeline {
     bool single_column = false;                  // whole_columns_only: the buffer holds (part of) one column only, nothing was taken
   };
   static CellWalk walk_cells(const uint8_t* cells, uint64_t nbytes, const std::vector<int32_t>& row_map, bool whole_columns_only, std::vector<uint64_t>& offs);
-  // walked / walk_info: the walk has been done by the caller (windowed streaming), offs = cell offsets + end offset
+  // The cells of a buffer into HBM columns.  The sizes are walked ON THE DEVICE (candidate headers + pointer doubling, see
+  // gdb_pipeline.hip "the walk of the cell sizes"); whole_columns_only: more bytes follow the buffer, so the last begin column
+  // seen (and a cell the buffer cuts through) is left for the next call - walk_out says how many bytes were taken and where the
+  // next window begins.  walked / walk_info: the walk has been done by the caller on the host (walk_cells; GDBAMD_HOST_WALK=1),
+  // offs = cell offsets + end offset.
   CellStreamInfo append_cells(const uint8_t* cells, uint64_t nbytes, const VariantArraySchemaLite& schema, const std::vector<int>& attr_to_field,
-                              const std::vector<int32_t>& row_map, const std::vector<uint64_t>* walked = nullptr, const CellWalk* walk_info = nullptr);
+                              const std::vector<int32_t>& row_map, const std::vector<uint64_t>* walked = nullptr, const CellWalk* walk_info = nullptr,
+                              bool whole_columns_only = false, CellWalk* walk_out = nullptr);
   void finish_staging();
   // the staged fragment as a columnar file / a columnar file straight into HBM (format: gdb_pipeline.hip, 'columnar fragment file')
   void save_fragment(const std::string& path, const FragmentFileMeta& meta);

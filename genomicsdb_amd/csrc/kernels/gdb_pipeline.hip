@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -1894,6 +1895,113 @@ __global__ void __launch_bounds__(kStageBlock) k_cells_scatter(const uint8_t* __
   if (tiled) cell_scatter(LdsBytes{tile + skew + (uint32_t)(o - span_begin)}, i, d, sch, cols);
   else cell_scatter(GlobalBytes{cells + o}, i, d, sch, cols);
 }
+// ---- the walk of the cell sizes, on the device ---------------------------------------------------------------------------------
+// Every cell names its own size, so finding the cell boundaries is a pointer chase: 13 ms of one host core per 270 MB, the longest
+// item of the input path.  Here every byte position with a plausible cell header is a candidate (k_walk_candidates: row inside the
+// array, column >= 0, a size that fits), a candidate's successor is the candidate at position + size, and the true cells are the
+// ones reachable from position 0: pointer doubling over the candidate list (log2 #candidates rounds, k_walk_jump).  False
+// candidates (payload bytes that look like a header) are harmless: nothing true points at them.  The chain's end says what
+// happened: it ended exactly at the buffer's end, the buffer ends inside a cell / a header (more bytes follow: the window is cut
+// in front of that cell), or a successor is no candidate (malformed stream: error).
+constexpr uint32_t kWalkEnd = 0, kWalkTruncNext = 1, kWalkTruncSelf = 2, kWalkBroken = 3;   // successor codes: M + code
+__device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ __forceinline__ bool walk_plausible(const uint8_t* __restrict__ cells, uint64_t p, uint64_t nbytes, uint64_t nrows, uint64_t& size) {
+  if (p + 32 > nbytes) return false;
+  const uint64_t row = load_u64_unaligned(cells + p), col = load_u64_unaligned(cells + p + 8);
+  size = load_u64_unaligned(cells + p + 16);
+  return row < nrows && (int64_t)col >= 0 && size >= 32 && size < (1ull << 31);
+}
+__global__ void k_walk_candidates(const uint8_t* __restrict__ cells, uint64_t nbytes, uint64_t nrows, uint64_t nwords, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ word_count) {
+  const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one byte position per lane, one bitmap word per wavefront
+  uint64_t size;
+  const bool c = p < nbytes && walk_plausible(cells, p, nbytes, nrows, size);
+  const uint64_t m = __ballot(c);
+  if ((threadIdx.x & 63) == 0 && (p >> 6) < nwords) { bitmap[p >> 6] = m; word_count[p >> 6] = (uint32_t)__popcll(m); }
+}
+__global__ void k_walk_successors(const uint8_t* __restrict__ cells, uint64_t nbytes, uint64_t nwords, const uint64_t* __restrict__ bitmap, const uint32_t* __restrict__ word_rank,
+                                  uint32_t M, uint64_t* __restrict__ pos, uint32_t* __restrict__ succ) {
+  const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nbytes) return;
+  const uint64_t w = bitmap[p >> 6];
+  if (!((w >> (p & 63)) & 1ull)) return;
+  const uint32_t i = word_rank[p >> 6] + (uint32_t)__popcll(w & ((1ull << (p & 63)) - 1ull));
+  const uint64_t s = p + load_u64_unaligned(cells + p + 16);
+  pos[i] = p;
+  uint32_t nx;
+  if (s > nbytes) nx = M + kWalkTruncSelf;
+  else if (s == nbytes) nx = M + kWalkEnd;
+  else if (s + 32 > nbytes) nx = M + kWalkTruncNext;
+  else {
+    const uint64_t ws = bitmap[s >> 6];
+    nx = ((ws >> (s & 63)) & 1ull) ? word_rank[s >> 6] + (uint32_t)__popcll(ws & ((1ull << (s & 63)) - 1ull)) : M + kWalkBroken;
+  }
+  succ[i] = nx;
+}
+__global__ void k_walk_init(uint32_t M, const uint64_t* __restrict__ pos, uint8_t* __restrict__ reach, uint32_t* __restrict__ jump, uint32_t* err) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < M) reach[i] = (i == 0 && pos[0] == 0) ? 1 : 0;
+  else if (i < M + 4) { reach[i] = 0; jump[i] = i; }                       // the four end codes point at themselves
+  if (i == 0 && pos[0] != 0) atomicOr(err, (uint32_t)GDB_ERR_CELL_STREAM);   // the stream does not begin with a cell
+}
+// one round of pointer doubling: whatever is reached marks what it points at, then every pointer jumps twice as far
+__global__ void k_walk_jump(uint32_t M, uint8_t* __restrict__ reach, const uint32_t* __restrict__ jump_in, uint32_t* __restrict__ jump_out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const uint32_t j = jump_in[i];
+  if (reach[i]) reach[j] = 1;
+  jump_out[i] = jump_in[j];
+}
+__global__ void k_walk_flags(uint32_t M, const uint8_t* __restrict__ reach, const uint32_t* __restrict__ succ, uint32_t* __restrict__ flag) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= M) flag[i] = (i < M && reach[i] && succ[i] != M + kWalkTruncSelf) ? 1u : 0u;     // a cell the buffer cuts through is not taken
+}
+// walk_out: [0] number of cells, [1] end offset of the last one, [2] how the chain ended
+__global__ void k_walk_compact(uint32_t M, const uint8_t* __restrict__ cells, const uint8_t* __restrict__ reach, const uint32_t* __restrict__ succ, const uint32_t* __restrict__ flag,
+                               const uint32_t* __restrict__ dest, const uint64_t* __restrict__ pos, uint64_t* __restrict__ cell_off, uint64_t* __restrict__ walk_out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  if (flag[i]) cell_off[dest[i]] = pos[i];
+  if (reach[i] && succ[i] >= M) {                                         // the one reached cell that ends the chain
+    const uint32_t code = succ[i] - M;
+    const uint64_t end = code == kWalkTruncSelf ? pos[i] : pos[i] + load_u64_unaligned(cells + pos[i] + 16);
+    cell_off[dest[M]] = end;
+    walk_out[0] = dest[M]; walk_out[1] = end; walk_out[2] = code;
+  }
+}
+// After k_cells_measure: begin columns must not decrease; with more bytes to come the last begin column seen is left for the
+// next call (it may continue there).  cut_out: [0] cells taken, [1] bytes taken, [2] next begin column, [3] "one column fills the
+// buffer", [4] kept cells, [5] markers, [6] first begin, [7] last begin, [8] bytes of the kept cells, [9 ...] elements of every
+// variable-length column.
+__global__ void k_walk_order(const int64_t* __restrict__ begin, int64_t n, uint32_t* err) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 1 && i < n && begin[i] < begin[i - 1]) atomicOr(err, (uint32_t)GDB_ERR_CELL_STREAM);
+}
+struct WalkCutCols { const uint32_t* off[GDB_MAX_FIELDS]; int32_t nf; };
+__global__ void k_walk_cut(const int64_t* __restrict__ begin, const uint64_t* __restrict__ cell_off, const uint32_t* __restrict__ keep_dest, const uint32_t* __restrict__ mark_dest,
+                           int64_t n, int whole_columns_only, WalkCutCols vc, int64_t* __restrict__ cut_out) {
+  if (blockIdx.x || threadIdx.x) return;
+  int64_t take = n, next_begin = INT64_MAX, single = 0;
+  if (whole_columns_only) {
+    if (n == 0) single = 1;
+    else {
+      const int64_t last = begin[n - 1];
+      int64_t lo = 0, hi = n;
+      while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (begin[mid] < last) lo = mid + 1; else hi = mid; }
+      if (lo > 0) { take = lo; next_begin = last; } else { take = 0; single = 1; next_begin = last; }
+    }
+  }
+  cut_out[0] = take; cut_out[1] = (int64_t)cell_off[take]; cut_out[2] = next_begin; cut_out[3] = single;
+  cut_out[4] = keep_dest[take]; cut_out[5] = mark_dest[take];
+  cut_out[6] = take > 0 ? begin[0] : 0; cut_out[7] = take > 0 ? begin[take - 1] : 0;
+  for (int f = 0; f < vc.nf; ++f) cut_out[9 + f] = vc.off[f] ? (int64_t)vc.off[f][take] : 0;
+}
+__global__ void k_walk_kept_bytes(const uint32_t* __restrict__ keep, const uint64_t* __restrict__ cell_off, const int64_t* __restrict__ cut_out, unsigned long long* total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long mine = (i < cut_out[0] && keep[i]) ? (unsigned long long)(cell_off[i + 1] - cell_off[i]) : 0ull;
+  for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(total, mine);
+}
+
 __global__ void k_cells_markers(const uint32_t* is_marker, const uint32_t* mdest, const int64_t* begin, int64_t n, int64_t* marker_out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && is_marker[i]) marker_out[mdest[i]] = begin[i];
@@ -2024,6 +2132,9 @@ struct DevicePipeline::Impl {
   // cell-stream staging (append_cells)
   DevBuf<uint8_t> raw_cells; DevBuf<uint64_t> raw_off; DevBuf<int32_t> raw_row_map, raw_qrow; DevBuf<uint32_t> raw_keep, raw_dest, raw_len, raw_voff, raw_mark, raw_mdest;
   DevBuf<int64_t> raw_begin, raw_end;
+  // the walk of the cell sizes on the device
+  DevBuf<uint64_t> walk_bitmap, walk_pos, walk_out; DevBuf<uint32_t> walk_wcount, walk_wrank, walk_succ, walk_jump_a, walk_jump_b, walk_flag, walk_dest; DevBuf<uint8_t> walk_reach;
+  DevBuf<int64_t> walk_cut; DevBuf<unsigned long long> walk_kept_bytes;
   DevBuf<long long> carry_last; DevBuf<uint64_t> carry_keys, carry_sorted; int64_t carried_cells = 0;
   DevBuf<uint2> resolved;          // (pool offset, length) of every (record, sample): whole interval, or one page when that exceeds the budget
   DevBuf<uint32_t> type_occ;
@@ -2331,26 +2442,17 @@ DevicePipeline::CellWalk DevicePipeline::walk_cells(const uint8_t* cells, uint64
 
 DevicePipeline::CellStreamInfo DevicePipeline::append_cells(const uint8_t* cells, uint64_t nbytes, const VariantArraySchemaLite& schema,
                                                           const std::vector<int>& attr_to_field, const std::vector<int32_t>& row_map, const std::vector<uint64_t>* walked,
-                                                          const CellWalk* walk_info) {
+                                                          const CellWalk* walk_info, bool whole_columns_only, CellWalk* walk_out) {
   Impl& S = *m_;
   CellStreamInfo info;
   HIP_CHECK(hipSetDevice(S.device));
   hipStream_t st = S.stream;
+  if (walk_out) *walk_out = CellWalk();
   if (nbytes == 0) return info;
   if (schema.attrs.size() > (size_t)kMaxSchemaAttrs) throw UnsupportedOnDeviceException("more than 96 attributes in the array schema");
-  std::vector<uint64_t> own;
-  CellWalk wk;
-  if (walked) { wk = *walk_info; }
-  else { wk = walk_cells(cells, nbytes, row_map, false, own); walked = &own; }
-  const std::vector<uint64_t>& offs = *walked;
-  const int64_t nkept = wk.nkept, nmark = wk.nmark;
-  info.reference_cell_bytes = wk.reference_cell_bytes;
-  const int64_t n = (int64_t)offs.size() - 1;
-  nbytes = offs.back();
-
-  info.ncells = nkept;
-  if (nkept == 0 && nmark == 0) return info;
-  if (nkept >= (1ll << 32)) throw GenomicsDBDeviceException("more than 2^32 cells in one part: stage in smaller parts");
+  static const bool trace = getenv("GDBAMD_STREAM_TRACE") != nullptr;
+  const auto tw0 = std::chrono::steady_clock::now();
+  const bool device_walk = walked == nullptr;
   const int nf = S.hp.plan.nfields;
   CellSchemaDev sch;
   memset(&sch, 0, sizeof(sch));
@@ -2362,13 +2464,63 @@ DevicePipeline::CellStreamInfo DevicePipeline::append_cells(const uint8_t* cells
     const int f = attr_to_field[ai];
     if (f >= 0) { S.col_elem_size[(size_t)f] = a.elem_size; S.col_var[(size_t)f] = a.var; S.col_fixed_num[(size_t)f] = a.num; }
   }
-  // ---- device: raw bytes, offsets, row map ------------------------------------------------------------------------------
-  S.raw_cells.ensure(nbytes + 16); S.raw_off.ensure((size_t)n + 1); S.raw_row_map.ensure(std::max<size_t>(row_map.size(), 1));
-  HIP_CHECK(hipMemcpyAsync(S.raw_cells.p, cells, nbytes, hipMemcpyHostToDevice, st));
-  HIP_CHECK(hipMemcpyAsync(S.raw_off.p, offs.data(), (size_t)(n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+  // ---- device: raw bytes, cell offsets, row map -------------------------------------------------------------------------
+  HIP_CHECK(hipMemsetAsync(S.err.p, 0, sizeof(uint32_t), st));
+  int64_t n = 0;
+  if (!device_walk) {
+    nbytes = walked->back();
+    n = (int64_t)walked->size() - 1;
+    if (walk_info->nkept == 0 && walk_info->nmark == 0) return info;
+    S.raw_cells.ensure(nbytes + 64); S.raw_off.ensure((size_t)n + 1);
+    HIP_CHECK(hipMemcpyAsync(S.raw_cells.p, cells, nbytes, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(S.raw_off.p, walked->data(), (size_t)(n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+  } else {
+    S.raw_cells.ensure(nbytes + 64);
+    HIP_CHECK(hipMemcpyAsync(S.raw_cells.p, cells, nbytes, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemsetAsync(S.raw_cells.p + nbytes, 0, 64, st));
+    const uint64_t nwords = (nbytes + 63) >> 6;
+    S.walk_bitmap.ensure(nwords + 1); S.walk_wcount.ensure(nwords + 1); S.walk_wrank.ensure(nwords + 1); S.walk_out.ensure(4);
+    HIP_CHECK(hipMemsetAsync(S.walk_out.p, 0, 4 * sizeof(uint64_t), st));
+    const unsigned pos_blocks = (unsigned)((nbytes + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_walk_candidates, dim3(pos_blocks), dim3(kBlock), 0, st, (const uint8_t*)S.raw_cells.p, nbytes, (uint64_t)1 << 40, nwords, S.walk_bitmap.p, S.walk_wcount.p);
+    HIP_CHECK(hipMemsetAsync(S.walk_wcount.p + nwords, 0, sizeof(uint32_t), st));
+    S.excl_scan((const uint32_t*)S.walk_wcount.p, S.walk_wrank.p, (size_t)nwords + 1);
+    const uint32_t M = S.read_back(S.walk_wrank.p + nwords);
+    if (M == 0) {
+      if (whole_columns_only && nbytes < 32) { if (walk_out) walk_out->single_column = true; return info; }   // not even a header: offer more bytes
+      throw std::runtime_error(nbytes < 32 ? "truncated cell stream" : "malformed cell stream (no cell header at its beginning)");
+    }
+    if (M >= 0xFFFFFFF0u) throw GenomicsDBDeviceException("more than 2^32 cell-header candidates in one part: stage in smaller parts");
+    S.walk_pos.ensure(M); S.walk_succ.ensure((size_t)M + 4); S.walk_jump_a.ensure((size_t)M + 4); S.walk_jump_b.ensure((size_t)M + 4); S.walk_reach.ensure((size_t)M + 4);
+    S.walk_flag.ensure((size_t)M + 1); S.walk_dest.ensure((size_t)M + 1); S.raw_off.ensure((size_t)M + 1);
+    hipLaunchKernelGGL(k_walk_successors, dim3(pos_blocks), dim3(kBlock), 0, st, (const uint8_t*)S.raw_cells.p, nbytes, nwords, (const uint64_t*)S.walk_bitmap.p, (const uint32_t*)S.walk_wrank.p, M,
+                       S.walk_pos.p, S.walk_jump_a.p);
+    HIP_CHECK(hipMemcpyAsync(S.walk_succ.p, S.walk_jump_a.p, (size_t)M * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_walk_init, dim3(blocks_for((int64_t)M + 4)), dim3(kBlock), 0, st, M, (const uint64_t*)S.walk_pos.p, S.walk_reach.p, S.walk_jump_a.p, S.err.p);
+    HIP_CHECK(hipMemcpyAsync(S.walk_jump_b.p + M, S.walk_jump_a.p + M, 4 * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    uint32_t* ja = S.walk_jump_a.p; uint32_t* jb = S.walk_jump_b.p;
+    int rounds = 1;
+    while ((1ull << rounds) < (uint64_t)M + 1) ++rounds;
+    for (int r = 0; r <= rounds; ++r) {
+      hipLaunchKernelGGL(k_walk_jump, dim3(blocks_for((int64_t)M)), dim3(kBlock), 0, st, M, S.walk_reach.p, (const uint32_t*)ja, jb);
+      std::swap(ja, jb);
+    }
+    hipLaunchKernelGGL(k_walk_flags, dim3(blocks_for((int64_t)M + 1)), dim3(kBlock), 0, st, M, (const uint8_t*)S.walk_reach.p, (const uint32_t*)S.walk_succ.p, S.walk_flag.p);
+    S.excl_scan((const uint32_t*)S.walk_flag.p, S.walk_dest.p, (size_t)M + 1);
+    hipLaunchKernelGGL(k_walk_compact, dim3(blocks_for((int64_t)M)), dim3(kBlock), 0, st, M, (const uint8_t*)S.raw_cells.p, (const uint8_t*)S.walk_reach.p, (const uint32_t*)S.walk_succ.p,
+                       (const uint32_t*)S.walk_flag.p, (const uint32_t*)S.walk_dest.p, (const uint64_t*)S.walk_pos.p, S.raw_off.p, S.walk_out.p);
+    uint64_t wo[3]; uint32_t eb0 = 0;
+    S.read_back_many({{wo, S.walk_out.p, sizeof(wo)}, {&eb0, S.err.p, sizeof(uint32_t)}});
+    if (eb0) throw std::runtime_error("malformed cell stream (it does not begin with a cell)");
+    if (wo[2] == kWalkBroken) throw std::runtime_error("malformed cell stream (a cell's size does not lead to the next cell)");
+    if (wo[2] != kWalkEnd && !whole_columns_only) throw std::runtime_error("truncated cell stream");
+    n = (int64_t)wo[0];
+    if (n == 0) { if (walk_out && whole_columns_only) walk_out->single_column = true; return info; }   // not even one whole cell: offer more bytes
+  }
+  const auto tw1 = std::chrono::steady_clock::now();
+  S.raw_row_map.ensure(std::max<size_t>(row_map.size(), 1));
   if (!row_map.empty()) HIP_CHECK(hipMemcpyAsync(S.raw_row_map.p, row_map.data(), row_map.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
   S.raw_keep.ensure((size_t)n + 1); S.raw_dest.ensure((size_t)n + 1); S.raw_mark.ensure((size_t)n + 1); S.raw_mdest.ensure((size_t)n + 1); S.raw_qrow.ensure((size_t)n); S.raw_begin.ensure((size_t)n); S.raw_end.ensure((size_t)n);
-  HIP_CHECK(hipMemsetAsync(S.err.p, 0, sizeof(uint32_t), st));
   CellColumnsDev cols;
   memset(&cols, 0, sizeof(cols));
   int nvar = 0;
@@ -2382,17 +2534,49 @@ DevicePipeline::CellStreamInfo DevicePipeline::append_cells(const uint8_t* cells
                      (const int32_t*)S.raw_row_map.p, (int64_t)row_map.size(), S.raw_keep.p, S.raw_mark.p, S.raw_qrow.p, S.raw_begin.p, S.raw_end.p, cols, S.err.p);
   HIP_CHECK(hipMemsetAsync(S.raw_keep.p + n, 0, sizeof(uint32_t), st));
   S.excl_scan(S.raw_keep.p, S.raw_dest.p, (size_t)n + 1);
-  if (nmark > 0) { HIP_CHECK(hipMemsetAsync(S.raw_mark.p + n, 0, sizeof(uint32_t), st)); S.excl_scan(S.raw_mark.p, S.raw_mdest.p, (size_t)n + 1); }
-  std::vector<uint32_t> totals((size_t)nf, 0);
+  HIP_CHECK(hipMemsetAsync(S.raw_mark.p + n, 0, sizeof(uint32_t), st));
+  S.excl_scan(S.raw_mark.p, S.raw_mdest.p, (size_t)n + 1);
   for (int f = 0; f < nf; ++f) if (S.col_var[(size_t)f]) {
     HIP_CHECK(hipMemsetAsync(cols.len[f] + n, 0, sizeof(uint32_t), st));
     S.excl_scan((const uint32_t*)cols.len[f], const_cast<uint32_t*>(cols.off[f]), (size_t)n + 1);
   }
-  for (int f = 0; f < nf; ++f) if (S.col_var[(size_t)f]) HIP_CHECK(hipMemcpyAsync(&totals[(size_t)f], cols.off[f] + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  // what is taken: everything, or (more bytes to come) everything in front of the last begin column seen
+  CellWalk wk;
+  std::vector<uint32_t> totals((size_t)nf, 0);
+  {
+    S.walk_cut.ensure(9 + GDB_MAX_FIELDS); S.walk_kept_bytes.ensure(1);
+    HIP_CHECK(hipMemsetAsync(S.walk_kept_bytes.p, 0, sizeof(unsigned long long), st));
+    WalkCutCols vc;
+    memset(&vc, 0, sizeof(vc));
+    vc.nf = nf;
+    for (int f = 0; f < nf; ++f) vc.off[f] = S.col_var[(size_t)f] ? cols.off[f] : nullptr;
+    if (device_walk) hipLaunchKernelGGL(k_walk_order, dim3(blocks_for(n)), dim3(kBlock), 0, st, (const int64_t*)S.raw_begin.p, n, S.err.p);
+    hipLaunchKernelGGL(k_walk_cut, dim3(1), dim3(64), 0, st, (const int64_t*)S.raw_begin.p, (const uint64_t*)S.raw_off.p, (const uint32_t*)S.raw_dest.p, (const uint32_t*)S.raw_mdest.p, n,
+                       (device_walk && whole_columns_only) ? 1 : 0, vc, S.walk_cut.p);
+    hipLaunchKernelGGL(k_walk_kept_bytes, dim3(blocks_for(n)), dim3(kBlock), 0, st, (const uint32_t*)S.raw_keep.p, (const uint64_t*)S.raw_off.p, (const int64_t*)S.walk_cut.p, S.walk_kept_bytes.p);
+    int64_t cut[9 + GDB_MAX_FIELDS];
+    unsigned long long kept_bytes = 0;
+    uint32_t eb = 0;
+    S.read_back_many({{cut, S.walk_cut.p, (size_t)(9 + nf) * sizeof(int64_t)}, {&kept_bytes, S.walk_kept_bytes.p, sizeof(kept_bytes)}, {&eb, S.err.p, sizeof(uint32_t)}});
+    if (eb) throw std::runtime_error(device_walk ? "malformed cell stream (cell sizes do not match the schema, or the cells are not in column-major (col,row) order)"
+                                                 : "cell size mismatch while parsing the cell stream");
+    n = cut[0];
+    wk.bytes_taken = (uint64_t)cut[1]; wk.next_begin = cut[2]; wk.single_column = cut[3] != 0;
+    wk.nkept = cut[4]; wk.nmark = cut[5];
+    if (n > 0) { wk.first_begin = cut[6]; wk.last_begin = cut[7]; }
+    wk.reference_cell_bytes = kept_bytes;
+    for (int f = 0; f < nf; ++f) totals[(size_t)f] = (uint32_t)cut[9 + f];
+    if (!device_walk) { wk.next_begin = walk_info->next_begin; wk.single_column = walk_info->single_column; }
+  }
+  if (walk_out) *walk_out = wk;
+  const auto tw2 = std::chrono::steady_clock::now();
+  const int64_t nkept = wk.nkept, nmark = wk.nmark;
+  info.reference_cell_bytes = wk.reference_cell_bytes;
+  info.ncells = nkept;
+  nbytes = wk.bytes_taken;
+  if (nkept == 0 && nmark == 0) return info;
+  if (nkept >= (1ll << 32)) throw GenomicsDBDeviceException("more than 2^32 cells in one part: stage in smaller parts");
   uint32_t eb = 0;
-  HIP_CHECK(hipMemcpyAsync(&eb, S.err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  HIP_CHECK(hipStreamSynchronize(st));
-  if (eb) throw std::runtime_error("cell size mismatch while parsing the cell stream");
   // ---- the part's columns ----------------------------------------------------------------------------------------------
   Impl::Part part;
   memset(&part.v, 0, sizeof(part.v));
@@ -2444,6 +2628,11 @@ DevicePipeline::CellStreamInfo DevicePipeline::append_cells(const uint8_t* cells
   S.read_back_many({{&info.min_begin, begin, sizeof(int64_t)}, {&info.max_end, S.span_max.p, sizeof(int64_t)}, {&eb, S.err.p, sizeof(uint32_t)}});
   if (eb) { for (void* b : part.bufs) (void)hipFree(b); throw std::runtime_error("cells are not in column-major (col,row) order"); }
   S.parts.push_back(part);
+  if (trace) {
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    fprintf(stderr, "[gdbamd stage] %.1f MB, %lld cells: size walk %.4f s, copy + measure + scans %.4f s, allocate + scatter %.4f s\n", nbytes / 1e6, (long long)n, secs(tw0, tw1),
+            secs(tw1, tw2), secs(tw2, std::chrono::steady_clock::now()));
+  }
   return info;
 }
 

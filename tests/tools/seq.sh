@@ -1,3 +1,7 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -x -q -k "bcf or jni or allele_specific" 2>&1 | tail -3
-for d in 0 3; do GDBAMD_BCF_DBG=$d python bench.py --bcf --steps 3 --warmup 1 --no-cpu-baseline --no-stream 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('bcf dbg=$d',d['value'], d['ms_per_step'], d['phase_ms'])"; done
+python -m pytest tests -m gpu -x -q 2>&1 | tail -12
+mkdir -p gpurun_out/c3
+GDBAMD_STREAM_TRACE=1 GDBAMD_STAGE_BUDGET_MB=2048 python bench.py --stream-input --samples 10000 --interval-bp 1000000 --window-bp 50000 --no-cpu-baseline > gpurun_out/c3/line.json 2> gpurun_out/c3/trace.txt
+grep "gdbamd stage" gpurun_out/c3/trace.txt | sed -n 3,8p
+python -c "
+import json;d=json.load(open('gpurun_out/c3/line.json'));print(d['value'], d['input_path'], d.get('positions_per_sec_excluding_generator'))"
