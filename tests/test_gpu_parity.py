@@ -1139,3 +1139,41 @@ def test_allele_specific_annotations_fuzz_on_device(gdb, seed, is_bcf):
         data = s.read()
         s.close()
         assert helpers.bcf_stream_to_text(data) == want
+
+
+@pytest.mark.gpu
+def test_cell_walk_ignores_header_lookalikes_in_payload(gdb, monkeypatch):
+    """the cell boundaries are found on the device from candidate headers (a plausible row / column / size at a byte position) by
+    pointer doubling from position 0: bytes inside a cell that look exactly like a header - here the counts of a histogram, laid
+    out as (row 1, column 5000, size 64) - are candidates nothing true points at.  Same output as the oracle, whole stream and in
+    windows of a few cells (the window cut runs on the device too)."""
+    import numpy as np
+    from test_hostsim_golden import _asa_cells
+    rng = np.random.default_rng(21)
+    cells = _asa_cells(rng, 3, 50, lookalike=True)
+    assert cells.count(np.array([1, 0, 5000, 0, 64, 0], dtype="<i4").tobytes()) > 100
+    q, pb = helpers.query_json("t0_1_2_all_asa.json", "vid_all_asa.json", {}, "load")
+    want, nrec, _ = helpers.oracle_run(q, cells, partition_begin=pb)
+    s = gdb.GenomicsDBQueryStream(query_json=q, cells=cells, buffer_capacity=1 << 20)
+    got = s.read()
+    s.close()
+    assert got == want
+    monkeypatch.setenv("GDBAMD_STAGE_BUDGET_BYTES", "3000")
+    s = gdb.GenomicsDBQueryStream(query_json=q, cells=cells, buffer_capacity=1 << 20)
+    got = s.read()
+    s.close()
+    assert got == want
+
+
+@pytest.mark.gpu
+def test_malformed_cell_streams_are_refused(gdb):
+    """a stream cut inside a cell, a cell size that does not lead to the next cell, and a stream that does not begin with a cell are
+    errors of the device walk, as they are errors of a sequential walk"""
+    import struct
+    case = CASES[0]
+    cells = helpers.cells_for(case[1], case[2])
+    q, _ = helpers.query_json(case[1], case[2], case[3], case[5])
+    for bad in (cells[:-10], cells[:16] + struct.pack("<Q", struct.unpack_from("<Q", cells, 16)[0] + 3) + cells[24:], b"\xff" * 8 + cells[8:]):
+        with pytest.raises(gdb.GenomicsDBException, match="truncated|malformed"):
+            s = gdb.GenomicsDBQueryStream(query_json=q, cells=bad, buffer_capacity=1 << 20)
+            s.read()

@@ -88,7 +88,7 @@ def test_queried_composite_field_is_flattened():
     assert b"AS_RAW_MQ=8.000,10.000,9.000|28.000,16.000,18.000,14.000|31.000|32.000,12.000,13.000,14.000;AS_RAW_MQRankSum=|0.600,6,0.800,2,0.900,15|0.100,2,0.600,7|" in want
 
 
-def _asa_cells(rng, n_samples, n_sites):
+def _asa_cells(rng, n_samples, n_sites, lookalike=False):
     """synthetic cells for vid_all_asa.json: every site has a shared pool of ALT alleles, each sample takes some of them and
     carries random per-allele vectors / histograms (empty vectors, NaN and repeated bins included)"""
     import struct
@@ -126,6 +126,11 @@ def _asa_cells(rng, n_samples, n_sites):
                     toks += ["%.1f" % (int(rng.integers(-5, 6)) / 10.0) if rng.random() > 0.1 else "NaN", str(int(rng.integers(1, 20)))]
                 return ",".join(toks)
             rs = "|".join(hist() for _ in range(nall)) if rng.random() < 0.85 else None
+            if lookalike:
+                # the counts of one allele, as consecutive int32: [1, 0, 5000, 0, 64, 0, 7, 7] = the bytes of a cell header
+                # (row 1, column 5000, cell size 64) in the middle of a cell's payload
+                fake = "0.1,1,0.2,0,0.3,5000,0.4,0,0.5,64,0.6,0,0.7,7,0.8,7"
+                rs = "|".join([fake] + [hist() for _ in range(nall - 1)])
             info_d = {"AS_RAW_MQ": mq, "AS_RAW_MQRankSum": rs}
             alt_ser = "|".join("&" if a == "<NON_REF>" else a for a in alts)
             body = struct.pack("<q", col)
