@@ -76,7 +76,7 @@ inline uint64_t resolved_budget_bytes() {
 }
 // records per (run, chunk) of the change-list page assembly (<= 64); GDBAMD_EVENTS=1 selects it instead of the dense matrix
 inline int event_run_length() { const char* e = getenv("GDBAMD_EV_RUN"); return e && *e ? std::max(1, std::min(64, atoi(e))) : 32; }
-// (off by default: measured slower than the dense matrix - the scalar loads of a record's changes are a serial chain)
+// (off by default: measured slower than the dense matrix, with scalar loads of the changes and with vector loads + v_readlane)
 inline bool events_enabled() { const char* e = getenv("GDBAMD_EVENTS"); return e && *e && *e != '0'; }
 // wavefronts (= neighbouring 64-sample chunks) per workgroup of the page assembly: 4 measured best on the store-only model
 inline int write_waves_per_group() { const char* e = getenv("GDBAMD_WRITE_WAVES"); return e && *e ? atoi(e) : 1; }
@@ -1418,25 +1418,35 @@ k_assemble_write_ev(const char* __restrict__ pool, const char* __restrict__ pool
   }
   const uint32_t nev = (uint32_t)__builtin_amdgcn_readfirstlane((int)eb.count[b]);
   const uint2* __restrict__ evp = eb.ev + b * (int64_t)run * kAsmRows;
-  uint32_t pe = 0;
-  uint64_t next_ev = 0;
-  if (nev) { next_ev = sload_x2(evp); swait(next_ev); }
+  // the change list, 64 entries at a time: one per lane (a coalesced load), consumed in order with v_readlane.  (The first version
+  // took every entry and its text with scalar loads - s_load_dwordx4 x 5 + s_waitcnt per change - and was latency-bound.)
+  uint32_t ebase = 0, consumed = 0;
+  uint2 evr = make_uint2(0u, 0xFFFFFFFFu);
+  if ((uint32_t)lane < nev) evr = evp[lane];
   for (int jj = 0; jj < cnt; ++jj) {                        // uniform
-    // ---- the changes of this record: scalar loads + v_writelane -----------------------------------------------------------------------
-    while (pe < nev && (uint32_t)(next_ev >> 58) == (uint32_t)jj) {     // uniform
-      const uint32_t ex = (uint32_t)next_ev, ey = (uint32_t)(next_ev >> 32);
-      const uint32_t L = (ey >> kEvLenBits) & 63u, elen = ey & kEvLenMask;
-      const char* src = ((ex & kOverflowBit) ? pool_ovf : pool) + (size_t)(ex & ~kOverflowBit) * 16;
-      u32x4 t0 = sload_x4(src), t1 = sload_x4(src + 16), t2 = sload_x4(src + 32), t3 = sload_x4(src + 48), t4 = sload_x4(src + 64);   // (the pools are padded: reading past a short text is harmless)
-      ++pe;
-      uint64_t nx = next_ev;
-      if (pe < nev) nx = sload_x2(evp + pe);
-      swait(t0, t1, t2, t3, t4);
-      swait(nx);
-      wlane4(txt.x[0], t0, L); wlane4(txt.x[1], t1, L); wlane4(txt.x[2], t2, L); wlane4(txt.x[3], t3, L); wlane4(txt.x[4], t4, L);
-      len = wlane(elen, L, len);
-      cur_off = wlane(ex, L, cur_off);
-      next_ev = nx;
+    // ---- the changes of this record --------------------------------------------------------------------------------------------------
+    bool changed = false;
+    for (;;) {                                              // uniform
+      if (ebase + consumed >= nev) break;
+      if (consumed == 64u) {
+        ebase += 64u; consumed = 0;
+        evr = make_uint2(0u, 0xFFFFFFFFu);
+        if (ebase + (uint32_t)lane < nev) evr = evp[ebase + lane];
+      }
+      const uint32_t ey = (uint32_t)__builtin_amdgcn_readlane((int)evr.y, (int)consumed);
+      if ((ey >> 26) != (uint32_t)jj) break;
+      const uint32_t ex = (uint32_t)__builtin_amdgcn_readlane((int)evr.x, (int)consumed);
+      if ((uint32_t)lane == ((ey >> kEvLenBits) & 63u)) {
+        len = ey & kEvLenMask;
+        cur_off = ex;
+        changed = true;
+      }
+      ++consumed;
+    }
+    if (changed) {      // the texts of all lanes that changed in this record: one group of loads (one exposed latency)
+      const char* src = ((cur_off & kOverflowBit) ? pool_ovf : pool) + (size_t)(cur_off & ~kOverflowBit) * 16;
+#pragma unroll
+      for (int q = 0; q < kTextChunks; ++q) txt.x[q] = load_chunk(src, q, len);
     }
     const uint32_t inc = wave_inclusive_scan_dpp(len);
     const uint32_t excl = inc - len;

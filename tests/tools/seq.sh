@@ -1,7 +1,4 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -x -q 2>&1 | tail -12
-mkdir -p gpurun_out/c3
-GDBAMD_STREAM_TRACE=1 GDBAMD_STAGE_BUDGET_MB=2048 python bench.py --stream-input --samples 10000 --interval-bp 1000000 --window-bp 50000 --no-cpu-baseline > gpurun_out/c3/line.json 2> gpurun_out/c3/trace.txt
-grep "gdbamd stage" gpurun_out/c3/trace.txt | sed -n 3,8p
-python -c "
-import json;d=json.load(open('gpurun_out/c3/line.json'));print(d['value'], d['input_path'], d.get('positions_per_sec_excluding_generator'))"
+GDBAMD_EVENTS=1 python -m pytest tests -m gpu -x -q -k "golden and stream" 2>&1 | tail -2
+for d in 0; do GDBAMD_EV_DBG=$d GDBAMD_EVENTS=1 python bench.py --no-cpu-baseline --no-stream --steps 4 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('events dbg=$d',d['value'], d['roofline']['avg_launch_ms'], d['ms_per_step'], d['phase_ms'])"; done
+python bench.py --no-cpu-baseline --no-stream --steps 4 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('matrix',d['value'], d['roofline']['avg_launch_ms'], d['ms_per_step'], d['phase_ms'])"
