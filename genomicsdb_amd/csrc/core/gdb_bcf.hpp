@@ -6,7 +6,8 @@
 //                                up to 8 fields arrive with the entry's first 16-byte load):
 //                                bits 0..13 element count n (0: the call has no value for this field), bits 14..15 integer
 //                                class (0 int8, 1 int16, 2 int32: the narrowest BCF type that holds the call's values)
-//     body                       the n elements of every field back to back: int32 / float as 4 bytes, char as 1 byte
+//     body                       the n elements of every field back to back: int32 / float as 4 bytes (on a 4-byte boundary of the
+//                                entry: zero padding behind a string field), char as 1 byte
 // The page assembly reduces the summaries of the N samples of a record to the per-(record, field) vector length and type
 // (what htslib's bcf_update_format does in bcf_enc_vint, vcf.c) and then converts and pads every entry into its fixed-stride
 // place: absent values become [missing, vector_end ...] (GT: vector_end; the htsjdk flags change both), as
@@ -117,6 +118,11 @@ template <class Sink> GDB_HD void bin_field(Sink& s, BinTrack& tr, const EntryCt
   }
 }
 
+GDB_HD int bcf_field_elem_size(const CombinePlan& pl, int fmt_i) {
+  const int f = pl.format_field[fmt_i];
+  const int e = (f == pl.f_DP && pl.f_DP_FORMAT >= 0) ? GDB_ET_INT : pl.field[f].elem;
+  return (e == GDB_ET_CHAR || e == GDB_ET_FLAG) ? 1 : 4;
+}
 // binary entry of one (record, sample) column.  c < 0: the sample has no live call (every summary stays 0).
 template <class Sink> GDB_HD Sink entry_emit_bin(const EntryCtx& cx, const RecordInfo& ri, int64_t c, Sink s, uint32_t* err) {
   const CombinePlan& pl = cx.pl;
@@ -133,6 +139,7 @@ template <class Sink> GDB_HD Sink entry_emit_bin(const EntryCtx& cx, const Recor
     if (c >= 0) {
       BinTrack tr;
       tr.reset();
+      if (bcf_field_elem_size(pl, i) == 4) while ((s.pos() - hdr_at) & 3u) s.put((char)0);   // 4-byte values start on a 4-byte boundary of the entry
       bin_field(s, tr, cx, ri, em, i, c, err);
       if (tr.n > 0x3FFFu) *err |= GDB_ERR_INTERNAL;
       if (tr.n) pair |= tr.word() << (16 * (q & 1));
@@ -154,11 +161,6 @@ GDB_HD uint32_t bcf_summary_class(uint32_t s) { return (s & 0x8000u) ? 2u : ((s 
 GDB_HD uint32_t bcf_summary_max(uint32_t a, uint32_t b) {
   const uint32_t n = (a & 0x3FFFu) > (b & 0x3FFFu) ? (a & 0x3FFFu) : (b & 0x3FFFu);
   return n | ((a | b) & 0xC000u);
-}
-GDB_HD int bcf_field_elem_size(const CombinePlan& pl, int fmt_i) {
-  const int f = pl.format_field[fmt_i];
-  const int e = (f == pl.f_DP && pl.f_DP_FORMAT >= 0) ? GDB_ET_INT : pl.field[f].elem;
-  return (e == GDB_ET_CHAR || e == GDB_ET_FLAG) ? 1 : 4;
 }
 GDB_HD int bcf_field_type(const CombinePlan& pl, int fmt_i, uint32_t summary) {   // BCF type code of the field in this record
   const int f = pl.format_field[fmt_i];

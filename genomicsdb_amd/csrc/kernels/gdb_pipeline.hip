@@ -1523,7 +1523,9 @@ k_assemble_write_ev(const char* __restrict__ pool, const char* __restrict__ pool
 // type of every (record, field) are known a sample's values have a fixed place: no scan over variable-length texts.
 // k_bcf_field_meta reduces the entries' summaries per (record, 64-sample chunk), k_bcf_layout per record (and sizes the record),
 // k_bcf_shared writes l_shared / l_indiv, the shared block and the key + type bytes of every field, k_bcf_write the values.
-constexpr int kBcfRun = 32;        // records one wavefront of the BCF kernels takes in a row (same chunk)
+constexpr int kBcfRun = 256;       // records one wavefront of the BCF kernels takes in a row (same chunk), 64 at a time
+  // (every run begins with a full format of its 64 samples and two dependent fetches of per-record data: with runs of 32 that start
+  // was most of the kernel)
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 // maximum over the wavefront of a pair of 16-bit summaries (vector length: maximum; class bits: OR)
 __device__ __forceinline__ uint32_t bcf_pair_reduce(uint32_t v) {
@@ -1537,7 +1539,7 @@ __device__ __forceinline__ uint32_t bcf_pair_reduce(uint32_t v) {
 // part[(record, chunk)][pair word]: a lane's entry rarely changes from one record to the next (a call spans many records), so the
 // summary words stay in registers and only the lanes whose entry changed go to memory.
 __global__ void __launch_bounds__(kAsmRows) k_bcf_field_meta(const uint2* __restrict__ resolved, const char* __restrict__ pool, const char* __restrict__ pool_ovf,
-                                                           const uint32_t* __restrict__ fmt_mask, int64_t P, int nchunks, int F, uint32_t* __restrict__ part) {
+                                                           const uint32_t* __restrict__ fmt_mask, const int32_t* __restrict__ order, int64_t P, int nchunks, int F, uint32_t* __restrict__ part) {
   const int64_t unit = xcd_aware_unit<1>(((P + kBcfRun - 1) / kBcfRun) * (int64_t)nchunks);
   if (unit < 0) return;
   const int64_t k0 = (unit / nchunks) * kBcfRun, k1 = min(P, k0 + (int64_t)kBcfRun);
@@ -1546,7 +1548,11 @@ __global__ void __launch_bounds__(kAsmRows) k_bcf_field_meta(const uint2* __rest
   const int W = (F + 1) >> 1;
   uint32_t held = 0xFFFFFFFFu;        // the entry whose first 16 bytes are in h
   u32x4 h = {0u, 0u, 0u, 0u};
-  for (int64_t k = k0; k < k1; ++k) {                    // uniform
+  // records in (block, type) order (`order`, like the text assembly): along a run the samples keep their entries
+  int32_t my_k = 0;
+  for (int64_t i = k0; i < k1; ++i) {                    // uniform
+    if (((i - k0) & 63) == 0) my_k = (i + lane < k1) ? order[i + lane] : 0;
+    const int64_t k = __builtin_amdgcn_readlane(my_k, (int)((i - k0) & 63));
     const int64_t rc = k * nchunks + ch;
     const uint2 d = resolved[rc * kAsmRows + lane];
     const char* src = ((d.x & kOverflowBit) ? pool_ovf : pool) + (size_t)(d.x & ~kOverflowBit) * 16;
@@ -1648,73 +1654,212 @@ __global__ void k_bcf_shared(const SiteCtx* __restrict__ sxp, const char* __rest
 // (collect_and_extend_fields, variant_field_handler.cc:846-866) into an LDS image of the 64 samples' values, and the wavefront
 // moves the image to the record with aligned 16-byte stores.
 struct __attribute__((packed)) PackedU16 { uint16_t v; };
-constexpr int kBcfEntryCap = 96;     // bytes of an entry kept in the lane's LDS slot (the rest is read from the pool)
+constexpr int kBcfEntryCap = 128;    // bytes of an entry kept in the lane's LDS slot (the rest is read from the pool)
 constexpr int kBcfImageSample = 32;  // bytes per sample and field that go through the LDS image (longer vectors: direct stores)
 // one sample's cnt values of a field of BCF type t, from its entry (n elements at `in`) to `out`.  first / rest: what stands where
 // the call has no element (the first position of an empty vector, every other one).  The two pointers are LDS or global by
-// instantiation, so the accesses are ds_ / global_ instructions and not flat ones.
+// instantiation, so the accesses are ds_ / global_ instructions and not flat ones.  4-byte elements are 4-byte aligned in the entries.
 template <class Out, class In> __device__ __forceinline__ void bcf_sample_values(Out* out, const In* in, uint32_t n, uint32_t cnt, uint32_t t, uint32_t first, uint32_t rest) {
   if (t == GDB_BT_CHAR) {
     for (uint32_t j = 0; j < cnt; ++j) out[j] = j < n ? in[j] : (char)(j == 0 ? first : rest);
   } else if (t == GDB_BT_INT8) {
     for (uint32_t j = 0; j < cnt; ++j) {
-      const int32_t v = (int32_t)(j < n ? reinterpret_cast<const PackedU32*>(in + 4u * j)->v : (j == 0 ? first : rest));
+      const int32_t v = (int32_t)(j < n ? reinterpret_cast<const uint32_t*>(in)[j] : (j == 0 ? first : rest));
       out[j] = v == GDB_BCF_INT32_MISSING ? (char)0x80 : v == GDB_BCF_INT32_VECTOR_END ? (char)0x81 : (char)v;
     }
   } else if (t == GDB_BT_INT16) {
     for (uint32_t j = 0; j < cnt; ++j) {
-      const int32_t v = (int32_t)(j < n ? reinterpret_cast<const PackedU32*>(in + 4u * j)->v : (j == 0 ? first : rest));
+      const int32_t v = (int32_t)(j < n ? reinterpret_cast<const uint32_t*>(in)[j] : (j == 0 ? first : rest));
       reinterpret_cast<PackedU16*>(out + 2u * j)->v = v == GDB_BCF_INT32_MISSING ? (uint16_t)0x8000u : v == GDB_BCF_INT32_VECTOR_END ? (uint16_t)0x8001u : (uint16_t)v;
     }
   } else {                      // int32 and float: the stored bits
-    for (uint32_t j = 0; j < cnt; ++j) reinterpret_cast<PackedU32*>(out + 4u * j)->v = j < n ? reinterpret_cast<const PackedU32*>(in + 4u * j)->v : (j == 0 ? first : rest);
+    for (uint32_t j = 0; j < cnt; ++j) reinterpret_cast<PackedU32*>(out + 4u * j)->v = j < n ? reinterpret_cast<const uint32_t*>(in)[j] : (j == 0 ? first : rest);
   }
 }
+// is the layout of the idx-th record (in assembly order) the layout of the one before it?  (exact comparison of mask and rows)
+__global__ void k_bcf_same_layout(const int32_t* __restrict__ order, const uint32_t* __restrict__ fmt_mask, const uint32_t* __restrict__ fmeta, int64_t np, int F, uint8_t* __restrict__ same) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= np) return;
+  bool eq = idx > 0;
+  if (eq) {
+    const int64_t k = order[idx], kp = order[idx - 1];
+    const uint32_t m = fmt_mask[k];
+    eq = m == fmt_mask[kp];
+    const int nf = __popc(m);
+    for (int q = 0; eq && q < nf; ++q) eq = fmeta[k * F + q] == fmeta[kp * F + q];
+  }
+  same[idx] = eq ? 1 : 0;
+}
+struct __attribute__((packed)) PackedU128 { u32x4 v; };
+constexpr int kBcfImageBytes = 4096;     // LDS image of the FORMAT values of one (record, 64-sample chunk), every field a 16-byte aligned region
+constexpr int kBcfImageSets = kBcfImageBytes / (16 * kAsmRows);
+constexpr int kBcfBatch = 4;             // records whose resolved rows are fetched together
+// One wavefront = a run of records x 64 samples.
+// FAST PATH (the record's values for 64 samples fit the LDS image): the image holds one region per FORMAT field (sample-major,
+// exactly the bytes that go to the record) and PERSISTS from record to record.  What a lane wrote for its sample stays valid while
+// its resolved entry and the record's layout (vector length and type of every field) do not change - a call spans many records,
+// so most (record, chunk) steps format nothing or a lane or two - and every record ends with the same flush: each lane moves
+// 16-byte words of the image to offsets it computed when the layout last changed (unaligned 16-byte stores; the record's base is
+// the only thing that differs).  Per-field constants live in lanes (lane q = q-th field of the record) and reach the field loop
+// through v_readlane; everything the loop needs from memory arrives one record ahead as vector loads.
+// SLOW PATH (long vectors): field by field through a 2 KB image with aligned stores, or straight to the page.
 __global__ void __launch_bounds__(kAsmRows) k_bcf_write(CombinePlan pl, const uint2* __restrict__ resolved, const char* __restrict__ pool, const char* __restrict__ pool_ovf,
-                                                      const uint32_t* __restrict__ fmt_mask, int64_t k_begin, int64_t np, int nchunks, int F, int32_t N, BcfLayout lay,
-                                                      const uint64_t* __restrict__ rec_off, uint64_t page_base, char* __restrict__ arena) {
+                                                      const uint32_t* __restrict__ fmt_mask, const int32_t* __restrict__ order, const uint8_t* __restrict__ same_layout, int64_t np, int nchunks,
+                                                      int F, int32_t N, BcfLayout lay, const uint64_t* __restrict__ rec_off, uint64_t page_base, char* __restrict__ arena) {
   __shared__ __attribute__((aligned(16))) char s_entry[kAsmRows * kBcfEntryCap];
-  __shared__ __attribute__((aligned(16))) char s_image[kAsmRows * kBcfImageSample + 16];
+  __shared__ __attribute__((aligned(16))) char s_image[kBcfImageBytes + 16];
+  __shared__ uint2 s_rows[kBcfBatch][kAsmRows];
   const int64_t unit = xcd_aware_unit<1>(((np + kBcfRun - 1) / kBcfRun) * (int64_t)nchunks);
   if (unit < 0) return;
-  const int64_t k0 = k_begin + (unit / nchunks) * kBcfRun, k1 = min(k_begin + np, k0 + (int64_t)kBcfRun);
+  // order[0 .. np): the page's records in (block, type) order - along a run of one type the layout and most entries stay the same
+  const int64_t i0 = (unit / nchunks) * kBcfRun, i1 = min(np, i0 + (int64_t)kBcfRun);
   const int ch = (int)(unit % nchunks);
   const int lane = threadIdx.x;
   const uint32_t nsamp = (uint32_t)min((int32_t)kAsmRows, N - ch * kAsmRows);
   const bool flag = pl.use_missing_values_not_vector_end != 0;
   const bool live = (uint32_t)lane < nsamp;
-  uint32_t held = 0xFFFFFFFFu;
-  // what the record loop needs from memory is fetched one record ahead, as vector loads: the sample's resolved entry, and the
-  // record's row of the layout (lane q holds field q's fmeta / foff; every lane its own copy of fmt_mask and the record offset).
-  // (Scalar loads per field sat on the critical path: ~14 dependent s_load + s_waitcnt per (record, chunk).)
+  uint32_t slot_key = 0xFFFFFFFFu;      // the entry in this lane's LDS slot
+  uint32_t img_key = 0xFFFFFFFFu;       // the entry (or "none") this lane's image bytes were formatted from
+  bool img_valid = false;               // uniform: the image holds the previous record's layout
   // per FORMAT field of the plan (lane i): bytes per element in the entries, GT or not
   uint32_t my_field = 0;
   if (lane < pl.n_format) my_field = (uint32_t)bcf_field_elem_size(pl, lane) | (pl.format_field[lane] == pl.f_GT ? 0x100u : 0u);
   const int n_format = pl.n_format;
-  uint2 d_next = resolved[(k0 * nchunks + ch) * kAsmRows + lane];
-  uint32_t meta_next = lane < F ? lay.fmeta[k0 * F + lane] : 0u, foff_next = lane < F ? lay.foff[k0 * F + lane] : 0u;
-  uint32_t mask_next = fmt_mask[k0];
-  uint64_t roff_next = rec_off[k0];
-  for (int64_t k = k0; k < k1; ++k) {                    // uniform
-    const uint2 d = d_next;
-    const uint32_t my_meta = meta_next, my_foff = foff_next;
-    const uint32_t mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)mask_next);
-    char* rec = arena + (readlane64((int64_t)roff_next, 0) - (int64_t)page_base);
-    if (k + 1 < k1) {
-      d_next = resolved[((k + 1) * nchunks + ch) * kAsmRows + lane];
-      meta_next = lane < F ? lay.fmeta[(k + 1) * F + lane] : 0u;
-      foff_next = lane < F ? lay.foff[(k + 1) * F + lane] : 0u;
-      mask_next = fmt_mask[k + 1];
-      roff_next = rec_off[k + 1];
+  // per field q of the current layout (lane q): bytes per sample, region offset in the image, offset of the region in the record
+  // relative to the first field's key, padding values, element size in the entries
+  uint32_t q_per = 0, q_reg = 0, q_grel = 0, q_first = 0, q_rest = 0, q_es = 0;
+  uint32_t nsets = 0;
+  uint32_t desc_g[kBcfImageSets], desc_nv[kBcfImageSets];
+#pragma unroll
+  for (int sidx = 0; sidx < kBcfImageSets; ++sidx) { desc_g[sidx] = 0; desc_nv[sidx] = 0; }
+  // per record of the run (lane j = j-th record): index, mask, offset in the page, offset of the first FORMAT key, "same layout as
+  // the record before" - one load each for the whole run, v_readlane in the loop.
+  int32_t my_k = 0; uint32_t my_mask = 0, my_foff0 = 0, my_same = 0; uint64_t my_roff = 0;
+  int cnt_run = 0;
+  uint32_t my_meta = 0, my_foff = 0;
+  for (int64_t i = i0; i < i1; ++i) {                    // uniform
+    const int j = (int)((i - i0) & 63);
+    if (j == 0) {                                         // the next 64 records of the run
+      const bool in_run = i + lane < i1;
+      my_k = in_run ? order[i + lane] : 0;
+      my_mask = in_run ? fmt_mask[my_k] : 0u;
+      my_roff = in_run ? rec_off[my_k] : 0ull;
+      my_foff0 = in_run ? lay.foff[(int64_t)my_k * F] : 0u;
+      my_same = in_run ? (uint32_t)same_layout[i + lane] : 0u;
+      cnt_run = (int)min((int64_t)64, i1 - i);
+      // (the loads are waited for HERE: left pending, the compiler's s_waitcnt vmcnt(0) lands at the top of every step, where it also
+      // waits for the previous step's stores)
+      asm volatile("" : "+v"(my_k), "+v"(my_mask), "+v"(my_foff0), "+v"(my_same), "+v"(my_roff));
     }
+    // the samples' resolved entries of the next kBcfBatch records: all loads in flight at once, parked in LDS.  (A load per record
+    // - even issued records ahead - ends in s_waitcnt vmcnt(0) at the loop's back edge: every step then waits a full memory
+    // latency, for its load and for the previous step's stores.)
+    if ((j % kBcfBatch) == 0) {
+      uint2 t[kBcfBatch];
+#pragma unroll
+      for (int b = 0; b < kBcfBatch; ++b) {
+        const int jb = j + b < cnt_run ? j + b : cnt_run - 1;
+        const int64_t kk = __builtin_amdgcn_readlane(my_k, jb);
+        t[b] = resolved[(kk * nchunks + ch) * kAsmRows + lane];
+      }
+#pragma unroll
+      for (int b = 0; b < kBcfBatch; ++b) s_rows[b][lane] = t[b];
+    }
+    const uint2 d = s_rows[j % kBcfBatch][lane];
+    const int64_t k = __builtin_amdgcn_readlane(my_k, j);
+    const uint32_t mask = (uint32_t)__builtin_amdgcn_readlane((int)my_mask, j);
+    char* rec = arena + (readlane64((int64_t)my_roff, j) - (int64_t)page_base);
     const char* src = ((d.x & kOverflowBit) ? pool_ovf : pool) + (size_t)(d.x & ~kOverflowBit) * 16;
-    if (d.y && d.x != held) {
+    if (d.y && d.x != slot_key) {                         // all 16-byte pieces in flight at once, then into the slot: one exposed latency
       const uint32_t take = d.y < (uint32_t)kBcfEntryCap ? d.y : (uint32_t)kBcfEntryCap;
-      for (uint32_t o = 0; o < take; o += 16) *reinterpret_cast<u32x4*>(s_entry + lane * kBcfEntryCap + o) = *reinterpret_cast<const u32x4*>(src + o);
-      held = d.x;
+      u32x4 piece[kBcfEntryCap / 16];
+#pragma unroll
+      for (int o = 0; o < kBcfEntryCap / 16; ++o) { piece[o] = u32x4{0u, 0u, 0u, 0u}; if ((uint32_t)o * 16u < take) piece[o] = *reinterpret_cast<const u32x4*>(src + o * 16); }
+#pragma unroll
+      for (int o = 0; o < kBcfEntryCap / 16; ++o) if ((uint32_t)o * 16u < take) *reinterpret_cast<u32x4*>(s_entry + lane * kBcfEntryCap + o * 16) = piece[o];
+      slot_key = d.x;
     }
+    const uint32_t key = d.y ? d.x : 0xFFFFFFFEu;
     const bool whole = !__any((int)(live && d.y > (uint32_t)kBcfEntryCap));   // every live lane's entry is in its slot
     const int nf = __popc(mask);
+    // ---- layout: unchanged from the previous record? ------------------------------------------------------------------------------
+    const bool same = img_valid && __builtin_amdgcn_readlane((int)my_same, j) != 0;
+    bool fits = true;
+    if (!same) {
+      my_meta = lane < F ? lay.fmeta[k * F + lane] : 0u;       // (a layout change is rare: these two loads are not worth prefetching)
+      my_foff = lane < F ? lay.foff[k * F + lane] : 0u;
+      // lane q: the plan field behind the q-th set bit of the mask
+      int my_i = 0;
+      { int qq = 0; for (int i = 0; i < n_format; ++i) if ((mask >> i) & 1u) { if (lane == qq) my_i = i; ++qq; } }
+      const uint32_t fld = (uint32_t)__shfl((int)my_field, my_i, 64);
+      const uint32_t cnt = my_meta & 0xFFFFu, t = (my_meta >> 16) & 0xFu, hdr = my_meta >> 24;
+      const uint32_t w = (uint32_t)bcf_type_width((int)t);
+      const bool is_gt = (fld & 0x100u) != 0u;
+      q_es = fld & 0xFFu;
+      q_per = lane < nf ? cnt * w : 0u;
+      if (t == GDB_BT_CHAR) { q_first = flag ? 0u : 7u; q_rest = 0u; }
+      else if (t == GDB_BT_FLOAT) { q_first = GDB_BCF_FLOAT_MISSING_BITS; q_rest = flag ? GDB_BCF_FLOAT_MISSING_BITS : GDB_BCF_FLOAT_VECTOR_END_BITS; }
+      else { q_first = is_gt ? (flag ? 0u : (uint32_t)GDB_BCF_INT32_VECTOR_END) : (uint32_t)GDB_BCF_INT32_MISSING; q_rest = flag ? (uint32_t)GDB_BCF_INT32_MISSING : (uint32_t)GDB_BCF_INT32_VECTOR_END; }
+      const uint32_t size = nsamp * q_per, size_a = (size + 15u) & ~15u;
+      const uint32_t incl = wave_inclusive_scan_dpp(size_a);
+      q_reg = incl - size_a;
+      const uint32_t total = wave_total(incl);
+      const uint32_t foff0 = (uint32_t)__builtin_amdgcn_readlane((int)my_foff, 0);
+      q_grel = (my_foff - foff0) + hdr + (uint32_t)ch * kAsmRows * q_per;
+      fits = total <= (uint32_t)kBcfImageBytes && !__any((int)(lane < nf && (q_per == 0u || q_per > 1024u)));
+      if (fits) {
+        nsets = (total + 1023u) >> 10;
+#pragma unroll
+        for (int sidx = 0; sidx < kBcfImageSets; ++sidx) {
+          const uint32_t b = 16u * ((uint32_t)lane + 64u * (uint32_t)sidx);
+          uint32_t g = 0, nv = 0;
+          if ((uint32_t)sidx < nsets)
+            for (int q = 0; q < nf; ++q) {               // uniform
+              const uint32_t ro = (uint32_t)__builtin_amdgcn_readlane((int)q_reg, q), sz = nsamp * (uint32_t)__builtin_amdgcn_readlane((int)q_per, q);
+              const uint32_t gr = (uint32_t)__builtin_amdgcn_readlane((int)q_grel, q);
+              if (b >= ro && b < ro + sz) { g = gr + (b - ro); nv = ro + sz - b < 16u ? ro + sz - b : 16u; }
+            }
+          desc_g[sidx] = g; desc_nv[sidx] = nv;
+        }
+      }
+    }
+    if (fits) {
+      // ---- format the lanes whose entry changed (all of them after a layout change) -------------------------------------------------
+      const bool need = live && (!same || key != img_key);
+      if (__any((int)need)) {
+        uint32_t body = bcf_summary_bytes(nf);
+        for (int q = 0; q < nf; ++q) {                   // uniform
+          const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)my_meta, q);
+          const uint32_t cnt = m & 0xFFFFu, t = (m >> 16) & 0xFu;
+          const uint32_t per = (uint32_t)__builtin_amdgcn_readlane((int)q_per, q), ro = (uint32_t)__builtin_amdgcn_readlane((int)q_reg, q);
+          const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)q_first, q), rest = (uint32_t)__builtin_amdgcn_readlane((int)q_rest, q);
+          const uint32_t es = (uint32_t)__builtin_amdgcn_readlane((int)q_es, q);
+          const uint32_t n = d.y ? bcf_summary_n(reinterpret_cast<const uint16_t*>(s_entry + lane * kBcfEntryCap)[q]) : 0u;
+          if (es == 4u) body = (body + 3u) & ~3u;
+          if (need) {
+            if (whole) bcf_sample_values(s_image + ro + (uint32_t)lane * per, s_entry + lane * kBcfEntryCap + body, n, cnt, t, first, rest);
+            else bcf_sample_values(s_image + ro + (uint32_t)lane * per, src + body, n, cnt, t, first, rest);
+          }
+          body += n * es;
+        }
+        if (need) img_key = key;
+      }
+      img_valid = true;
+      // ---- flush: every lane its words of the image ----------------------------------------------------------------------------------
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      char* const gbase = rec + (uint32_t)__builtin_amdgcn_readlane((int)my_foff0, j);
+#pragma unroll
+      for (int sidx = 0; sidx < kBcfImageSets; ++sidx) {
+        if ((uint32_t)sidx >= nsets) break;              // uniform
+        const char* lw = s_image + 16u * ((uint32_t)lane + 64u * (uint32_t)sidx);
+        if (desc_nv[sidx] == 16u) reinterpret_cast<PackedU128*>(gbase + desc_g[sidx])->v = *reinterpret_cast<const u32x4*>(lw);
+        else for (uint32_t j = 0; j < desc_nv[sidx]; ++j) gbase[desc_g[sidx] + j] = lw[j];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      continue;
+    }
+    // ---- slow path: field by field --------------------------------------------------------------------------------------------------
+    img_valid = false;
     uint32_t body = bcf_summary_bytes(nf);        // this lane's read position inside its entry
     int q = 0;
     for (int i = 0; i < n_format; ++i) {          // uniform
@@ -1726,6 +1871,7 @@ __global__ void __launch_bounds__(kAsmRows) k_bcf_write(CombinePlan pl, const ui
       const int es = (int)(fld & 0xFFu);
       const uint32_t n = d.y ? bcf_summary_n(reinterpret_cast<const uint16_t*>(s_entry + lane * kBcfEntryCap)[q]) : 0u;
       const bool is_gt = (fld & 0x100u) != 0u;
+      if (es == 4) body = (body + 3u) & ~3u;
       // no element: CHAR '.' then vector ends (all vector ends under the htsjdk flag); FLOAT / INT missing then vector ends
       // (missing everywhere under the flag); GT is all vector ends (no-call alleles under the flag)
       uint32_t first, rest;
@@ -2107,7 +2253,7 @@ struct DevicePipeline::Impl {
   // small tables
   DevBuf<char> names_text, contig_names, ref_bases;
   DevBuf<int32_t> field_name_off, field_name_len, filter_name_off, filter_name_len, filter_bcf_id;
-  DevBuf<uint32_t> bcf_part, bcf_fmeta, bcf_foff, bcf_lindiv; DevBuf<uint64_t> bcf_rec_size;   // BCF page assembly
+  DevBuf<uint32_t> bcf_part, bcf_fmeta, bcf_foff, bcf_lindiv; DevBuf<uint64_t> bcf_rec_size; DevBuf<uint8_t> bcf_same;   // BCF page assembly
   DevBuf<GdbContig> contigs;
   int64_t ref_begin = 0, ref_len = 0;
   // per-cell
@@ -3400,7 +3546,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
     lay = BcfLayout{S.bcf_fmeta.p, S.bcf_foff.p, S.bcf_lindiv.p, S.bcf_rec_size.p};
     STAGE("k_bcf_field_meta");
     hipLaunchKernelGGL(k_bcf_field_meta, dim3((unsigned)(((P + kBcfRun - 1) / kBcfRun) * nchunks)), dim3(kAsmRows), 0, st, (const uint2*)S.resolved.p, (const char*)S.pool.p,
-                       (const char*)S.pool_ovf.p, (const uint32_t*)S.fmt_mask.p, P, nchunks, bcf_F, S.bcf_part.p);
+                       (const char*)S.pool_ovf.p, (const uint32_t*)S.fmt_mask.p, (const int32_t*)S.order.p, P, nchunks, bcf_F, S.bcf_part.p);
     hipLaunchKernelGGL(k_bcf_layout, dim3(blocks_for(P)), dim3(kBlock), 0, st, pl, (const uint32_t*)S.bcf_part.p, (const uint32_t*)S.fmt_mask.p, (const uint32_t*)S.prefix_len.p, P,
                        nchunks, bcf_F, lay);
     HIP_CHECK(hipMemsetAsync(S.bcf_rec_size.p + P, 0, sizeof(uint64_t), st));
@@ -3497,9 +3643,12 @@ bool DevicePipeline::begin_page(uint64_t arena_bytes, int arena_idx, PageTicket*
                        (const uint64_t*)S.rec_off.p, page_base, iv.lay, iv.bcf_F, arena, S.err.p);
     HIP_CHECK(hipEventRecord(w[1], st));
     STAGE("k_bcf_write");
+    S.order_by_type(kp, np);
+    S.bcf_same.ensure((size_t)np + 1);
+    hipLaunchKernelGGL(k_bcf_same_layout, dim3(blocks_for(np)), dim3(kBlock), 0, st, (const int32_t*)S.order.p, (const uint32_t*)S.fmt_mask.p, (const uint32_t*)iv.lay.fmeta, np, iv.bcf_F, S.bcf_same.p);
     if (S.hp.plan.n_format > 0 && !S.hp.plan.sites_only_query)
       hipLaunchKernelGGL(k_bcf_write, dim3((unsigned)(((np + kBcfRun - 1) / kBcfRun) * iv.nchunks)), dim3(kAsmRows), 0, st, S.hp.plan, (const uint2*)S.resolved.p, (const char*)S.pool.p,
-                         (const char*)S.pool_ovf.p, (const uint32_t*)S.fmt_mask.p, kp, np, iv.nchunks, iv.bcf_F, N, iv.lay, (const uint64_t*)S.rec_off.p, page_base, arena);
+                         (const char*)S.pool_ovf.p, (const uint32_t*)S.fmt_mask.p, (const int32_t*)S.order.p, (const uint8_t*)S.bcf_same.p, np, iv.nchunks, iv.bcf_F, N, iv.lay, (const uint64_t*)S.rec_off.p, page_base, arena);
     HIP_CHECK(hipEventRecord(w[2], st));
     HIP_CHECK(hipMemcpyAsync(&S.hb->page_err[ai], S.err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipEventRecord(w[3], st));
