@@ -1729,6 +1729,10 @@ __global__ void __launch_bounds__(kAsmRows) k_bcf_write(CombinePlan pl, const ui
   // relative to the first field's key, padding values, element size in the entries
   uint32_t q_per = 0, q_reg = 0, q_grel = 0, q_first = 0, q_rest = 0, q_es = 0;
   uint32_t nsets = 0;
+  // per output element e of ONE sample under the current layout (lane e; all fields back to back): its field, index in the field,
+  // BCF type, place in the image (sample 0) - what the one-sample-at-a-time format below needs
+  uint32_t e_q = 0, e_j = 0, e_t = 0, e_dst = 0;
+  uint32_t n_elems = 0;                 // elements per sample (0: more than 64, the lanes-are-samples format is used)
   uint32_t desc_g[kBcfImageSets], desc_nv[kBcfImageSets];
 #pragma unroll
   for (int sidx = 0; sidx < kBcfImageSets; ++sidx) { desc_g[sidx] = 0; desc_nv[sidx] = 0; }
@@ -1821,12 +1825,61 @@ __global__ void __launch_bounds__(kAsmRows) k_bcf_write(CombinePlan pl, const ui
             }
           desc_g[sidx] = g; desc_nv[sidx] = nv;
         }
+        // lane e -> (field, index): the fields' element counts are a prefix-sum away
+        const uint32_t cnt_incl = wave_inclusive_scan_dpp(lane < nf ? cnt : 0u);
+        const uint32_t all_elems = wave_total(cnt_incl);
+        n_elems = all_elems <= (uint32_t)kAsmRows ? all_elems : 0u;
+        e_q = 0; e_j = 0; e_t = 0; e_dst = 0;
+        if (n_elems)
+          for (int q = 0; q < nf; ++q) {                 // uniform
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)cnt_incl, q), m = (uint32_t)__builtin_amdgcn_readlane((int)my_meta, q);
+            const uint32_t lo = hi - (m & 0xFFFFu);
+            if ((uint32_t)lane >= lo && (uint32_t)lane < hi) {
+              e_q = (uint32_t)q; e_j = (uint32_t)lane - lo; e_t = (m >> 16) & 0xFu;
+              e_dst = (uint32_t)__builtin_amdgcn_readlane((int)q_reg, q) + e_j * (uint32_t)bcf_type_width((int)e_t);
+            }
+          }
       }
     }
     if (fits) {
       // ---- format the lanes whose entry changed (all of them after a layout change) -------------------------------------------------
       const bool need = live && (!same || key != img_key);
-      if (__any((int)need)) {
+      const uint64_t need_mask = __ballot(need);
+      if (need_mask && same && n_elems && whole) {
+        // Few samples changed (a lane or two per step): one sample at a time, lane e = its e-th output element.  The sample's
+        // element counts come from its entry's summary (lane q), the offsets of its fields inside the entry from a short serial
+        // walk (4-byte fields are 4-byte aligned), then every lane fetches, converts and stores its own element.
+        for (uint64_t rem = need_mask; rem; rem &= rem - 1ull) {   // uniform
+          const int L = __builtin_ctzll(rem);
+          const uint32_t dyL = (uint32_t)__builtin_amdgcn_readlane((int)d.y, L);
+          const char* const slotL = s_entry + L * kBcfEntryCap;
+          uint32_t n_vec = 0;                                     // lane q: elements the sample has for field q
+          if (dyL && lane < nf) n_vec = bcf_summary_n(reinterpret_cast<const uint16_t*>(slotL)[lane]);
+          uint32_t body_vec = 0, b = bcf_summary_bytes(nf);
+          for (int q = 0; q < nf; ++q) {                           // uniform
+            const uint32_t es = (uint32_t)__builtin_amdgcn_readlane((int)q_es, q), nq = (uint32_t)__builtin_amdgcn_readlane((int)n_vec, q);
+            if (es == 4u) b = (b + 3u) & ~3u;
+            if (lane == q) body_vec = b;
+            b += nq * es;
+          }
+          if ((uint32_t)lane < n_elems) {
+            const uint32_t n = (uint32_t)__shfl((int)n_vec, (int)e_q, 64), body = (uint32_t)__shfl((int)body_vec, (int)e_q, 64);
+            const uint32_t first = (uint32_t)__shfl((int)q_first, (int)e_q, 64), rest = (uint32_t)__shfl((int)q_rest, (int)e_q, 64);
+            const uint32_t per = (uint32_t)__shfl((int)q_per, (int)e_q, 64);
+            char* const out = s_image + e_dst + (uint32_t)L * per;
+            if (e_t == GDB_BT_CHAR) {
+              out[0] = e_j < n ? slotL[body + e_j] : (char)(e_j == 0 ? first : rest);
+            } else {
+              const uint32_t v = e_j < n ? *reinterpret_cast<const uint32_t*>(slotL + body + 4u * e_j) : (e_j == 0 ? first : rest);
+              if (e_t == GDB_BT_INT8) out[0] = (int32_t)v == GDB_BCF_INT32_MISSING ? (char)0x80 : (int32_t)v == GDB_BCF_INT32_VECTOR_END ? (char)0x81 : (char)v;
+              else if (e_t == GDB_BT_INT16)
+                *reinterpret_cast<uint16_t*>(out) = (int32_t)v == GDB_BCF_INT32_MISSING ? (uint16_t)0x8000u : (int32_t)v == GDB_BCF_INT32_VECTOR_END ? (uint16_t)0x8001u : (uint16_t)v;
+              else *reinterpret_cast<uint32_t*>(out) = v;
+            }
+          }
+        }
+        if (need) img_key = key;
+      } else if (need_mask) {
         uint32_t body = bcf_summary_bytes(nf);
         for (int q = 0; q < nf; ++q) {                   // uniform
           const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)my_meta, q);
