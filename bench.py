@@ -324,7 +324,7 @@ def kernel_source_hash():
     import hashlib
     h = hashlib.sha256()
     for rel in ("genomicsdb_amd/csrc/kernels/gdb_pipeline.hip", "genomicsdb_amd/csrc/core/gdb_core.hpp", "genomicsdb_amd/csrc/core/gdb_stages.hpp",
-                "genomicsdb_amd/csrc/core/gdb_bcf.hpp", "genomicsdb_amd/csrc/core/gdb_types.h"):
+                "genomicsdb_amd/csrc/core/gdb_bcf.hpp", "genomicsdb_amd/csrc/core/gdb_asa.hpp", "genomicsdb_amd/csrc/core/gdb_types.h"):
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
