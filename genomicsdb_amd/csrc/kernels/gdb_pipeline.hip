@@ -2116,9 +2116,10 @@ constexpr uint32_t kWalkEnd = 0, kWalkTruncNext = 1, kWalkTruncSelf = 2, kWalkBr
 __device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 __device__ __forceinline__ bool walk_plausible(const uint8_t* __restrict__ cells, uint64_t p, uint64_t nbytes, uint64_t nrows, uint64_t& size) {
   if (p + 32 > nbytes) return false;
+  size = load_u64_unaligned(cells + p + 16);                  // the most selective test first: most positions stop here
+  if (size < 32 || size >= (1ull << 31)) return false;
   const uint64_t row = load_u64_unaligned(cells + p), col = load_u64_unaligned(cells + p + 8);
-  size = load_u64_unaligned(cells + p + 16);
-  return row < nrows && (int64_t)col >= 0 && size >= 32 && size < (1ull << 31);
+  return row < nrows && (int64_t)col >= 0;
 }
 __global__ void k_walk_candidates(const uint8_t* __restrict__ cells, uint64_t nbytes, uint64_t nrows, uint64_t nwords, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ word_count) {
   const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one byte position per lane, one bitmap word per wavefront
@@ -2129,22 +2130,23 @@ __global__ void k_walk_candidates(const uint8_t* __restrict__ cells, uint64_t nb
 }
 __global__ void k_walk_successors(const uint8_t* __restrict__ cells, uint64_t nbytes, uint64_t nwords, const uint64_t* __restrict__ bitmap, const uint32_t* __restrict__ word_rank,
                                   uint32_t M, uint64_t* __restrict__ pos, uint32_t* __restrict__ succ) {
-  const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= nbytes) return;
-  const uint64_t w = bitmap[p >> 6];
-  if (!((w >> (p & 63)) & 1ull)) return;
-  const uint32_t i = word_rank[p >> 6] + (uint32_t)__popcll(w & ((1ull << (p & 63)) - 1ull));
-  const uint64_t s = p + load_u64_unaligned(cells + p + 16);
-  pos[i] = p;
-  uint32_t nx;
-  if (s > nbytes) nx = M + kWalkTruncSelf;
-  else if (s == nbytes) nx = M + kWalkEnd;
-  else if (s + 32 > nbytes) nx = M + kWalkTruncNext;
-  else {
-    const uint64_t ws = bitmap[s >> 6];
-    nx = ((ws >> (s & 63)) & 1ull) ? word_rank[s >> 6] + (uint32_t)__popcll(ws & ((1ull << (s & 63)) - 1ull)) : M + kWalkBroken;
+  const uint64_t wi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;     // one bitmap word per thread: its candidates, in order
+  if (wi >= nwords) return;
+  uint32_t i = word_rank[wi];
+  for (uint64_t w = bitmap[wi]; w; w &= w - 1ull, ++i) {
+    const uint64_t p = (wi << 6) + (uint64_t)__builtin_ctzll(w);
+    const uint64_t s = p + load_u64_unaligned(cells + p + 16);
+    pos[i] = p;
+    uint32_t nx;
+    if (s > nbytes) nx = M + kWalkTruncSelf;
+    else if (s == nbytes) nx = M + kWalkEnd;
+    else if (s + 32 > nbytes) nx = M + kWalkTruncNext;
+    else {
+      const uint64_t ws = bitmap[s >> 6];
+      nx = ((ws >> (s & 63)) & 1ull) ? word_rank[s >> 6] + (uint32_t)__popcll(ws & ((1ull << (s & 63)) - 1ull)) : M + kWalkBroken;
+    }
+    succ[i] = nx;
   }
-  succ[i] = nx;
 }
 __global__ void k_walk_init(uint32_t M, const uint64_t* __restrict__ pos, uint8_t* __restrict__ reach, uint32_t* __restrict__ jump, uint32_t* err) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2205,10 +2207,13 @@ __global__ void k_walk_cut(const int64_t* __restrict__ begin, const uint64_t* __
   for (int f = 0; f < vc.nf; ++f) cut_out[9 + f] = vc.off[f] ? (int64_t)vc.off[f][take] : 0;
 }
 __global__ void k_walk_kept_bytes(const uint32_t* __restrict__ keep, const uint64_t* __restrict__ cell_off, const int64_t* __restrict__ cut_out, unsigned long long* total) {
+  __shared__ unsigned long long part[kBlock / 64];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long mine = (i < cut_out[0] && keep[i]) ? (unsigned long long)(cell_off[i + 1] - cell_off[i]) : 0ull;
   for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d);
-  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(total, mine);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) { unsigned long long sum = 0; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += part[w]; if (sum) atomicAdd(total, sum); }
 }
 
 __global__ void k_cells_markers(const uint32_t* is_marker, const uint32_t* mdest, const int64_t* begin, int64_t n, int64_t* marker_out) {
@@ -2688,7 +2693,7 @@ DevicePipeline::CellStreamInfo DevicePipeline::append_cells(const uint8_t* cells
     HIP_CHECK(hipMemcpyAsync(S.raw_cells.p, cells, nbytes, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemsetAsync(S.raw_cells.p + nbytes, 0, 64, st));
     const uint64_t nwords = (nbytes + 63) >> 6;
-    S.walk_bitmap.ensure(nwords + 1); S.walk_wcount.ensure(nwords + 1); S.walk_wrank.ensure(nwords + 1); S.walk_out.ensure(4);
+    S.walk_bitmap.ensure(nwords + 1); S.walk_wcount.ensure(nwords + 1); S.walk_wrank.ensure(nwords + 1); S.walk_out.ensure(8);
     HIP_CHECK(hipMemsetAsync(S.walk_out.p, 0, 4 * sizeof(uint64_t), st));
     const unsigned pos_blocks = (unsigned)((nbytes + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(k_walk_candidates, dim3(pos_blocks), dim3(kBlock), 0, st, (const uint8_t*)S.raw_cells.p, nbytes, (uint64_t)1 << 40, nwords, S.walk_bitmap.p, S.walk_wcount.p);
@@ -2702,7 +2707,7 @@ DevicePipeline::CellStreamInfo DevicePipeline::append_cells(const uint8_t* cells
     if (M >= 0xFFFFFFF0u) throw GenomicsDBDeviceException("more than 2^32 cell-header candidates in one part: stage in smaller parts");
     S.walk_pos.ensure(M); S.walk_succ.ensure((size_t)M + 4); S.walk_jump_a.ensure((size_t)M + 4); S.walk_jump_b.ensure((size_t)M + 4); S.walk_reach.ensure((size_t)M + 4);
     S.walk_flag.ensure((size_t)M + 1); S.walk_dest.ensure((size_t)M + 1); S.raw_off.ensure((size_t)M + 1);
-    hipLaunchKernelGGL(k_walk_successors, dim3(pos_blocks), dim3(kBlock), 0, st, (const uint8_t*)S.raw_cells.p, nbytes, nwords, (const uint64_t*)S.walk_bitmap.p, (const uint32_t*)S.walk_wrank.p, M,
+    hipLaunchKernelGGL(k_walk_successors, dim3(blocks_for((int64_t)nwords)), dim3(kBlock), 0, st, (const uint8_t*)S.raw_cells.p, nbytes, nwords, (const uint64_t*)S.walk_bitmap.p, (const uint32_t*)S.walk_wrank.p, M,
                        S.walk_pos.p, S.walk_jump_a.p);
     HIP_CHECK(hipMemcpyAsync(S.walk_succ.p, S.walk_jump_a.p, (size_t)M * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(k_walk_init, dim3(blocks_for((int64_t)M + 4)), dim3(kBlock), 0, st, M, (const uint64_t*)S.walk_pos.p, S.walk_reach.p, S.walk_jump_a.p, S.err.p);
@@ -2710,7 +2715,7 @@ DevicePipeline::CellStreamInfo DevicePipeline::append_cells(const uint8_t* cells
     uint32_t* ja = S.walk_jump_a.p; uint32_t* jb = S.walk_jump_b.p;
     int rounds = 1;
     while ((1ull << rounds) < (uint64_t)M + 1) ++rounds;
-    for (int r = 0; r <= rounds; ++r) {
+    for (int r = 0; r <= rounds; ++r) {      // (a "every candidate's successor is its neighbour" shortcut does not apply: c2's payloads hold header look-alikes)
       hipLaunchKernelGGL(k_walk_jump, dim3(blocks_for((int64_t)M)), dim3(kBlock), 0, st, M, S.walk_reach.p, (const uint32_t*)ja, jb);
       std::swap(ja, jb);
     }
