@@ -1177,3 +1177,37 @@ def test_malformed_cell_streams_are_refused(gdb):
         with pytest.raises(gdb.GenomicsDBException, match="truncated|malformed"):
             s = gdb.GenomicsDBQueryStream(query_json=q, cells=bad, buffer_capacity=1 << 20)
             s.read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_alt", [50, 64])
+def test_bcf_high_alt_dense_region_decodes_to_the_oracle_text(gdb, tmp_path, max_alt):
+    """the dense high-ALT region as BCF2: PL vectors of more than 64 elements per sample (the lanes-are-samples format), entries
+    longer than an LDS slot, records whose 64-sample values do not fit the persistent image (the field-by-field path), next to
+    plain records on the fast path - decoded with the tests' BCF2 reader, every record equals the oracle's text"""
+    import bcf2text
+    import struct
+    from genomicsdb_amd import synth
+    N, B, L = 150, 10_000_000, 330
+    g = synth.Generator(N, B, L + 500, dense=(B + 100, 200, 50, 64))
+    cells, nc = g.chunk_bytes(B + L + 500)
+    q = helpers.synth_query(tmp_path, N, B, B + L - 1)
+    q["max_diploid_alt_alleles_that_can_be_genotyped"] = max_alt
+    want, nrec, _ = helpers.oracle_run_synth(q, cells, synth.SEED, with_header=False)
+    eb = gdb.CombineEngine(q, is_bcf=True)
+    eb.stage_cells(cells)
+    eb.set_reference(B, synth.reference(B, L + 4096))
+    hdr_text = eb.header
+    body, st = eb.run_interval(B, B + L - 1, arena_bytes=1 << 30)
+    paged, sp = eb.run_interval(B, B + L - 1, arena_bytes=1 << 14)
+    eb.close()
+    assert st.num_records == nrec and paged == body and sp.pages > 1
+    text = hdr_text[hdr_text.index(b"##"):] if hdr_text[:3] == b"BCF" else hdr_text
+    h = bcf2text.Header(text.decode(errors="replace").rstrip("\x00"))
+    at, lines = 0, []
+    while at < len(body):
+        l_shared, l_indiv = struct.unpack_from("<II", body, at)
+        rec = body[at:at + 8 + l_shared + l_indiv]
+        lines.append(bcf2text.record_to_text(h, rec, helpers.format_float))
+        at += len(rec)
+    assert ("\n".join(lines) + "\n").encode() == want
