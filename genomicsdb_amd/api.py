@@ -189,9 +189,10 @@ class CombineEngine:
         _check(_lib.lib().gdbamd_engine_split_point(self._e, begin, end, max_columns, ctypes.byref(pe)) == 0, "split_point")
         return pe.value
 
-    def save_fragment(self, path):
-        """the staged fragment as a columnar file (file -> HBM copies on load, no parsing)"""
-        _check(_lib.lib().gdbamd_engine_save_fragment(self._e, str(path).encode()) == 0, "save_fragment")
+    def save_fragment(self, path, compress=False):
+        """the staged fragment as a columnar file; compress: DEFLATE tiles that are inflated on the device when the file is read"""
+        fn = _lib.lib().gdbamd_engine_save_fragment_compressed if compress else _lib.lib().gdbamd_engine_save_fragment
+        _check(fn(self._e, str(path).encode()) == 0, "save_fragment")
 
     def load_fragment(self, path):
         _check(_lib.lib().gdbamd_engine_load_fragment(self._e, str(path).encode()) == 0, "load_fragment")

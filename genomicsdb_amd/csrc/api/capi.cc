@@ -218,6 +218,9 @@ int gdbamd_engine_split_point(void* engine, int64_t qb, int64_t qe, int64_t max_
 int gdbamd_engine_save_fragment(void* engine, const char* path) {
   try { ((EngineHandle*)engine)->eng->save_fragment(path); return 0; } catch (const std::exception& e) { g_last_error = e.what(); return -1; }
 }
+int gdbamd_engine_save_fragment_compressed(void* engine, const char* path) {
+  try { ((EngineHandle*)engine)->eng->save_fragment(path, true); return 0; } catch (const std::exception& e) { g_last_error = e.what(); return -1; }
+}
 int gdbamd_engine_load_fragment(void* engine, const char* path) {
   try { ((EngineHandle*)engine)->eng->load_fragment(path); return 0; } catch (const std::exception& e) { g_last_error = e.what(); return -1; }
 }

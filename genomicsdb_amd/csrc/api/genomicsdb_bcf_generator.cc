@@ -91,11 +91,11 @@ uint64_t CombineEngine::schema_hash() {
   return h ? h : 1;
 }
 
-void CombineEngine::save_fragment(const std::string& path) {
+void CombineEngine::save_fragment(const std::string& path, bool compress) {
   FragmentFileMeta meta;
   meta.reference_cell_bytes = reference_cell_bytes; meta.min_begin = min_begin; meta.max_end = max_end; meta.ncells = num_cells;
   meta.schema_hash = schema_hash();
-  m_pipe->save_fragment(path, meta);
+  m_pipe->save_fragment(path, meta, compress);
 }
 void CombineEngine::load_fragment(const std::string& path) {
   // the file holds QUERY row indices: it only fits a query over all rows of the array in callset order

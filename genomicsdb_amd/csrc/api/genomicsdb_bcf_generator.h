@@ -35,7 +35,7 @@ class CombineEngine {
   void stage_cells_append(const uint8_t* cells, uint64_t nbytes);
   void stage_cells_end();
   // the staged fragment as a columnar file (<workspace>/<array>/fragment.gdbamd is what the query stream opens first)
-  void save_fragment(const std::string& path);
+  void save_fragment(const std::string& path, bool compress = false);
   void load_fragment(const std::string& path);
   // ---- arrays larger than the staging budget: column windows streamed through HBM -----------------------------------------
   // An array source is read window by window (whole begin columns, about staging_budget_bytes() each); the intervals still live

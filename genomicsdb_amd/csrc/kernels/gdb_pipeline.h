@@ -88,7 +88,8 @@ class DevicePipeline {
                               bool whole_columns_only = false, CellWalk* walk_out = nullptr);
   void finish_staging();
   // the staged fragment as a columnar file / a columnar file straight into HBM (format: gdb_pipeline.hip, 'columnar fragment file')
-  void save_fragment(const std::string& path, const FragmentFileMeta& meta);
+  // compress: version 3 - every data section as DEFLATE tiles (stored / fixed-Huffman blocks) that are inflated on the device when read
+  void save_fragment(const std::string& path, const FragmentFileMeta& meta, bool compress = false);
   FragmentFileMeta load_fragment(const std::string& path, const std::vector<ColumnLayout>& expected, uint64_t expected_schema_hash);
   // the same window by window: open (validates the whole header against the file size and the expected layouts), then between
   // begin_staging() and finish_staging() append the cells [c0, c1) that make up whole begin columns and about budget_bytes

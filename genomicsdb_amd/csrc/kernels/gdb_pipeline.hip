@@ -8,6 +8,7 @@
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -16,6 +17,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -2349,6 +2351,7 @@ struct DevicePipeline::Impl {
   // the walk of the cell sizes on the device
   DevBuf<uint64_t> walk_bitmap, walk_pos, walk_out; DevBuf<uint32_t> walk_wcount, walk_wrank, walk_succ, walk_jump_a, walk_jump_b, walk_flag, walk_dest; DevBuf<uint8_t> walk_reach;
   DevBuf<int64_t> walk_cut; DevBuf<unsigned long long> walk_kept_bytes;
+  DevBuf<uint8_t> inflate_in, inflate_out; DevBuf<uint64_t> inflate_off; DevBuf<uint32_t> inflate_want;   // DEFLATE tiles of a compressed fragment file
   DevBuf<long long> carry_last; DevBuf<uint64_t> carry_keys, carry_sorted; int64_t carried_cells = 0;
   DevBuf<uint2> resolved;          // (pool offset, length) of every (record, sample): whole interval, or one page when that exceeds the budget
   DevBuf<uint32_t> type_occ;
@@ -2915,6 +2918,96 @@ void DevicePipeline::finish_staging() {
 // contiguous range of every section: the file is read window by window (open_fragment_file / append_fragment_cells) when the
 // array does not fit the staging budget.
 namespace {
+// ---- DEFLATE tiles of the fragment file, inflated on the device -------------------------------------------------------------------
+// The data sections of a compressed fragment file (version 3) are cut into tiles of kFragTile uncompressed bytes, each a raw
+// DEFLATE stream (RFC 1951) of its own - the analogue of the gzip'd attribute tiles of the reference's TileDB arrays
+// (genomicsdb_iterators.cc:334-423 reads them tile by tile).  Compressed bytes cross PCIe, one thread inflates one tile:
+// a window has tens of thousands of tiles, so the serial bit-by-bit nature of a DEFLATE stream is spread over as many lanes.
+// The writer (save_fragment, zlib with strategy Z_FIXED) emits stored and FIXED-Huffman blocks only: the decoder then needs no
+// per-stream code tables - a literal / length code is 7 to 9 bits and is classified arithmetically (RFC 1951, 3.2.6).  A block
+// with dynamic codes is refused (error bit), as is any malformed or overlong stream.
+constexpr uint32_t kFragTile = 8192;
+__device__ const uint16_t kInfLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__device__ const uint8_t kInfLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__device__ const uint16_t kInfDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__device__ const uint8_t kInfDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+struct InflateBits {
+  const uint8_t* p; const uint8_t* end;
+  uint64_t buf; int n;
+  // After refill() at least 33 bits are buffered while input remains (no consumer takes more than 19 between two refills).  Eight
+  // bytes at a time while they last: the stream is read front to back by one lane, one unaligned 8-byte load per 3 to 7 bytes used.
+  __device__ __forceinline__ void refill() {
+    if (n > 32) return;
+    if (p + 8 <= end) {
+      uint64_t w;
+      __builtin_memcpy(&w, p, 8);
+      buf |= w << n;
+      const int take = (63 - n) >> 3;
+      p += take; n += take * 8;
+      buf &= (1ull << n) - 1ull;                 // (n <= 63: the bits of the byte that was not taken are read again next time)
+    } else while (n <= 56 && p < end) { buf |= (uint64_t)(*p++) << n; n += 8; }
+  }
+  __device__ __forceinline__ uint32_t peek(int k) const { return (uint32_t)(buf & ((1ull << k) - 1ull)); }
+  __device__ __forceinline__ void drop(int k) { buf >>= k; n -= k; }
+  __device__ __forceinline__ uint32_t get(int k) { const uint32_t v = peek(k); drop(k); return v; }   // (k <= 16; refill() first)
+};
+// job t: compressed bytes [in_off[t], in_off[t + 1]) of `comp` -> want[t] bytes at out + t * kFragTile
+__global__ void k_inflate_tiles(const uint8_t* __restrict__ comp, const uint64_t* __restrict__ in_off, const uint32_t* __restrict__ want_bytes, int64_t ntiles, uint8_t* __restrict__ out, uint32_t* err) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntiles) return;
+  uint8_t* const o = out + (uint64_t)t * kFragTile;
+  const uint32_t want = want_bytes[t];
+  InflateBits b{comp + in_off[t], comp + in_off[t + 1], 0ull, 0};
+  uint32_t at = 0;
+  bool bad = false, last = false;
+  while (!last && !bad) {
+    b.refill();
+    if (b.n < 3) { bad = true; break; }
+    last = b.get(1) != 0;
+    const uint32_t type = b.get(2);
+    if (type == 0) {                                   // stored: LEN, NLEN, bytes
+      b.drop(b.n & 7);
+      b.refill();
+      if (b.n < 32) { bad = true; break; }
+      const uint32_t len = b.get(16), nlen = b.get(16);
+      if ((len ^ nlen) != 0xFFFFu || at + len > want) { bad = true; break; }
+      for (uint32_t i = 0; i < len; ++i) { b.refill(); if (b.n < 8) { bad = true; break; } o[at++] = (uint8_t)b.get(8); }
+    } else if (type == 1) {                            // fixed Huffman codes
+      for (;;) {
+        b.refill();
+        if (b.n < 7) { bad = true; break; }
+        uint32_t sym;
+        const uint32_t c7 = __brev(b.peek(7)) >> 25;   // Huffman codes are packed most-significant bit first
+        if (c7 <= 0x17u) { sym = 256u + c7; b.drop(7); }
+        else {
+          const uint32_t c8 = __brev(b.peek(8)) >> 24;
+          if (c8 >= 0x30u && c8 <= 0xBFu) { sym = c8 - 0x30u; b.drop(8); }
+          else if (c8 >= 0xC0u && c8 <= 0xC7u) { sym = 280u + (c8 - 0xC0u); b.drop(8); }
+          else {
+            const uint32_t c9 = __brev(b.peek(9)) >> 23;
+            if (c9 < 0x190u) { bad = true; break; }
+            sym = 144u + (c9 - 0x190u); b.drop(9);
+          }
+        }
+        if (b.n < 0) { bad = true; break; }
+        if (sym < 256u) { if (at >= want) { bad = true; break; } o[at++] = (uint8_t)sym; continue; }
+        if (sym == 256u) break;
+        if (sym > 285u) { bad = true; break; }
+        b.refill();
+        const uint32_t li = sym - 257u;
+        const uint32_t len = kInfLenBase[li] + b.get(kInfLenExtra[li]);
+        const uint32_t dc = __brev(b.get(5)) >> 27;
+        if (dc >= 30u) { bad = true; break; }
+        b.refill();
+        const uint32_t dist = kInfDistBase[dc] + b.get(kInfDistExtra[dc]);
+        if (b.n < 0 || dist > at || at + len > want) { bad = true; break; }
+        for (uint32_t i = 0; i < len; ++i, ++at) o[at] = o[at - dist];
+      }
+    } else bad = true;                                 // dynamic codes (or the reserved type): not written by this build
+  }
+  if (bad || at != want) atomicOr(err, (uint32_t)GDB_ERR_CELL_STREAM);
+}
+
 const char kFragMagic[8] = {'G', 'D', 'B', 'A', 'M', 'D', 'F', '2'};
 struct FragFieldHdr { uint8_t var, elem_size; uint16_t name_len; int32_t fixed_num; uint64_t data_bytes; };
 void put_bytes(std::vector<uint8_t>& o, const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; o.insert(o.end(), b, b + n); }
@@ -2929,8 +3022,13 @@ struct DevicePipeline::FragmentFile {
   FragmentFileMeta meta;
   int64_t C = 0, M = 0;
   uint64_t row_at = 0, begin_at = 0, end_at = 0, marker_at = 0;
-  struct Field { bool var = false; int elem_size = 4, fixed_num = 1; uint64_t data_bytes = 0, off_at = 0, data_at = 0; int plan_field = -1; };
+  struct Field {
+    bool var = false; int elem_size = 4, fixed_num = 1; uint64_t data_bytes = 0, off_at = 0, data_at = 0; int plan_field = -1;
+    // version 3: the data section is DEFLATE tiles: [payload][u64 tile offset x (ntiles + 1)][u64 ntiles], stored_bytes in all
+    bool compressed = false; uint64_t stored_bytes = 0, ntiles = 0, index_at = 0;
+  };
   std::vector<Field> fields;
+  bool compressed = false;
   std::vector<int64_t> markers;     // whole array on the host (boundary markers are rare: cells of rows outside the query)
   size_t marker_cursor = 0;
   // two pinned bounce buffers for file -> HBM copies
@@ -2966,7 +3064,22 @@ struct DevicePipeline::FragmentFile {
   }
 };
 
-void DevicePipeline::save_fragment(const std::string& path, const FragmentFileMeta& meta) {
+// one tile as a raw DEFLATE stream of stored / fixed-Huffman blocks (zlib, strategy Z_FIXED): what k_inflate_tiles reads
+static void deflate_tile_fixed(const uint8_t* src, size_t n, std::vector<uint8_t>& out) {
+  z_stream zs;
+  memset(&zs, 0, sizeof(zs));
+  if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_FIXED) != Z_OK) throw std::runtime_error("deflateInit2 failed");
+  out.resize(deflateBound(&zs, (uLong)n) + 16);
+  zs.next_in = const_cast<Bytef*>(src); zs.avail_in = (uInt)n;
+  zs.next_out = out.data(); zs.avail_out = (uInt)out.size();
+  const int rc = deflate(&zs, Z_FINISH);
+  const size_t produced = out.size() - zs.avail_out;
+  deflateEnd(&zs);
+  if (rc != Z_STREAM_END) throw std::runtime_error("deflate failed");
+  out.resize(produced);
+}
+
+void DevicePipeline::save_fragment(const std::string& path, const FragmentFileMeta& meta, bool compress) {
   Impl& S = *m_;
   HIP_CHECK(hipSetDevice(S.device));
   const FragmentView& fr = S.fr;
@@ -2983,7 +3096,7 @@ void DevicePipeline::save_fragment(const std::string& path, const FragmentFileMe
   }
   std::vector<uint8_t> hdr;
   put_bytes(hdr, kFragMagic, 8);
-  const uint32_t version = 2, nfields = (uint32_t)nf;
+  const uint32_t version = compress ? 3u : 2u, nfields = (uint32_t)nf;
   const int32_t num_rows = S.hp.plan.num_query_rows, pad = 0;
   put_bytes(hdr, &version, 4); put_bytes(hdr, &nfields, 4); put_bytes(hdr, &C, 8); put_bytes(hdr, &fr.nmarkers, 8); put_bytes(hdr, &num_rows, 4); put_bytes(hdr, &pad, 4);
   put_bytes(hdr, &meta.reference_cell_bytes, 8); put_bytes(hdr, &meta.min_begin, 8); put_bytes(hdr, &meta.max_end, 8);
@@ -2993,6 +3106,9 @@ void DevicePipeline::save_fragment(const std::string& path, const FragmentFileMe
     FragFieldHdr h{(uint8_t)(S.col_var[(size_t)f] ? 1 : 0), (uint8_t)S.col_elem_size[(size_t)f], (uint16_t)name.size(), (int32_t)S.col_fixed_num[(size_t)f], data_bytes[(size_t)f]};
     put_bytes(hdr, &h, sizeof(h)); put_bytes(hdr, name.data(), name.size());
   }
+  const size_t stored_at = hdr.size();              // version 3: bytes every data section occupies in the file (patched in at the end)
+  std::vector<uint64_t> stored((size_t)nf, 0);
+  if (compress) put_bytes(hdr, stored.data(), stored.size() * 8);
   const std::string tmp_path = path + ".tmp";
   FILE* fp = fopen(tmp_path.c_str(), "wb");
   if (!fp) throw std::runtime_error("cannot create " + tmp_path);
@@ -3011,9 +3127,47 @@ void DevicePipeline::save_fragment(const std::string& path, const FragmentFileMe
     at += bytes;
   };
   dump(fr.row, (uint64_t)C * 4); dump(fr.begin, (uint64_t)C * 8); dump(fr.end, (uint64_t)C * 8); dump(fr.marker_begin, (uint64_t)fr.nmarkers * 8);
+  // a data section as DEFLATE tiles: payload, then the tile offsets and the tile count
+  auto dump_tiles = [&](const void* dev, uint64_t bytes) -> uint64_t {
+    pad64(fp, at);
+    const uint64_t ntiles = (bytes + kFragTile - 1) / kFragTile;
+    std::vector<uint64_t> tile_off(1, 0);
+    const uint64_t piece = (uint64_t)4096 * kFragTile;           // 128 MB of tiles at a time
+    const unsigned nthreads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    for (uint64_t done = 0; done < bytes; done += piece) {
+      const size_t k = (size_t)std::min<uint64_t>(piece, bytes - done);
+      host.resize(k);
+      HIP_CHECK(hipMemcpy(host.data(), (const char*)dev + done, k, hipMemcpyDeviceToHost));
+      const size_t nt = (k + kFragTile - 1) / kFragTile;
+      std::vector<std::vector<uint8_t>> z(nt);
+      std::vector<std::thread> pool;
+      std::string failure;
+      std::mutex fm;
+      for (unsigned w = 0; w < nthreads; ++w)
+        pool.emplace_back([&, w]() {
+          try { for (size_t t = w; t < nt; t += nthreads) deflate_tile_fixed(host.data() + t * kFragTile, std::min<size_t>(kFragTile, k - t * kFragTile), z[t]); }
+          catch (const std::exception& e) { std::lock_guard<std::mutex> g(fm); failure = e.what(); }
+        });
+      for (auto& th : pool) th.join();
+      if (!failure.empty()) { fclose(fp); throw std::runtime_error(failure); }
+      for (size_t t = 0; t < nt; ++t) {
+        if (fwrite(z[t].data(), 1, z[t].size(), fp) != z[t].size()) { fclose(fp); throw std::runtime_error("short write to " + tmp_path); }
+        tile_off.push_back(tile_off.back() + z[t].size());
+      }
+    }
+    fwrite(tile_off.data(), 8, tile_off.size(), fp);
+    fwrite(&ntiles, 8, 1, fp);
+    const uint64_t total = tile_off.back() + 8 * tile_off.size() + 8;
+    at += total;
+    return total;
+  };
   for (int f = 0; f < nf; ++f) {
     if (S.col_var[(size_t)f]) dump(fr.col[f].off, (uint64_t)(C + 1) * 4);
-    dump(fr.col[f].data, data_bytes[(size_t)f]);
+    if (compress) stored[(size_t)f] = dump_tiles(fr.col[f].data, data_bytes[(size_t)f]);
+    else dump(fr.col[f].data, data_bytes[(size_t)f]);
+  }
+  if (compress) {
+    if (fseek(fp, (long)stored_at, SEEK_SET) != 0 || fwrite(stored.data(), 8, stored.size(), fp) != stored.size()) { fclose(fp); throw std::runtime_error("cannot write " + tmp_path); }
   }
   if (fclose(fp) != 0 || rename(tmp_path.c_str(), path.c_str()) != 0) throw std::runtime_error("cannot write " + path);
 }
@@ -3040,7 +3194,8 @@ FragmentFileMeta DevicePipeline::open_fragment_file(const std::string& path, con
   FragmentFileMeta meta;
   rd(&version, 4); rd(&nfields, 4); rd(&C, 8); rd(&M, 8); rd(&num_rows, 4); rd(&pad, 4);
   rd(&meta.reference_cell_bytes, 8); rd(&meta.min_begin, 8); rd(&meta.max_end, 8); rd(&meta.schema_hash, 8); rd(&meta.source_bytes, 8); rd(&meta.source_mtime, 8);
-  if (version != 2) fail("unsupported fragment file version");
+  if (version != 2 && version != 3) fail("unsupported fragment file version");
+  ff->compressed = version == 3;
   if (nfields == 0 || nfields > 4096) fail("implausible number of fields");
   if (C < 0 || M < 0 || (uint64_t)C > ff->file_size / 20 + 1 || (uint64_t)M > ff->file_size / 8 + 1) fail("implausible cell / marker count");
   if (num_rows != S.hp.plan.num_query_rows) fail("fragment file was written for another set of query rows");
@@ -3048,6 +3203,8 @@ FragmentFileMeta DevicePipeline::open_fragment_file(const std::string& path, con
   struct FileField { FragFieldHdr h; std::string name; };
   std::vector<FileField> file_fields(nfields);
   for (auto& x : file_fields) { rd(&x.h, sizeof(x.h)); x.name.resize(x.h.name_len); if (x.h.name_len) rd(&x.name[0], x.h.name_len); }
+  std::vector<uint64_t> stored(nfields, 0);
+  if (ff->compressed) rd(stored.data(), (size_t)nfields * 8);
   const int nf = S.hp.plan.nfields;
   if ((int)expected.size() != nf) fail("internal: expected column layouts do not match the plan");
   std::vector<int> file_to_plan(nfields, -1);
@@ -3073,7 +3230,21 @@ FragmentFileMeta DevicePipeline::open_fragment_file(const std::string& path, con
     if (fd.elem_size != 1 && fd.elem_size != 4 && fd.elem_size != 8) fail("unsupported element size");
     if (fd.var) fd.off_at = section((uint64_t)(C + 1) * 4);
     else if (fd.data_bytes != (uint64_t)C * (uint64_t)fd.fixed_num * (uint64_t)fd.elem_size) fail("fixed-length column size does not match the cell count");
-    fd.data_at = section(fd.data_bytes);
+    if (!ff->compressed) fd.data_at = section(fd.data_bytes);
+    else {
+      // DEFLATE tiles: the index behind the payload has to agree with the section size, the tile count with the data size
+      fd.compressed = true; fd.stored_bytes = stored[i];
+      fd.ntiles = (fd.data_bytes + kFragTile - 1) / kFragTile;
+      if (fd.stored_bytes < 16 + 8 * fd.ntiles) fail("compressed section shorter than its tile index");
+      fd.data_at = section(fd.stored_bytes);
+      uint64_t nt_file = 0;
+      ff->read_at(&nt_file, fd.data_at + fd.stored_bytes - 8, 8);
+      if (nt_file != fd.ntiles) fail("tile count of a compressed section does not match its size");
+      fd.index_at = fd.data_at + fd.stored_bytes - 8 - 8 * (fd.ntiles + 1);
+      uint64_t first_off = 1, last_off = 0;
+      ff->read_at(&first_off, fd.index_at, 8); ff->read_at(&last_off, fd.index_at + 8 * fd.ntiles, 8);
+      if (first_off != 0 || fd.data_at + last_off != fd.index_at) fail("tile index of a compressed section does not match its payload");
+    }
     if (fd.var && C > 0) {   // the last offset has to name exactly the bytes of the data section
       uint32_t first = 0, last = 0;
       ff->read_at(&first, fd.off_at, 4); ff->read_at(&last, fd.off_at + (uint64_t)C * 4, 4);
@@ -3140,6 +3311,43 @@ DevicePipeline::FragmentWindow DevicePipeline::append_fragment_cells(int64_t c0,
   const int nf = S.hp.plan.nfields;
   S.col_elem_size.assign((size_t)nf, 4); S.col_var.assign((size_t)nf, false); S.col_fixed_num.assign((size_t)nf, 1);
   part.data_bytes.assign((size_t)nf, 0);
+  // bytes [a, a + nbytes) of a field's data -> device.  Compressed sections: the tiles that cover the range cross PCIe as they are in
+  // the file; ALL tiles of the window (every field) are inflated by ONE launch of k_inflate_tiles (one thread per tile: the more
+  // tiles in flight, the better the serial decoding of each is hidden), then the ranges are copied out of the inflated tiles.
+  struct InflateCopy { void* dev; uint64_t from, bytes; };
+  std::vector<uint64_t> job_in(1, 0);
+  std::vector<uint32_t> job_want;
+  std::vector<InflateCopy> copies;
+  std::vector<std::pair<uint64_t, uint64_t>> file_ranges;      // (file offset, bytes) of the compressed bytes, in job order
+  auto data_to_device = [&](const FragmentFile::Field& fd, void* dev, uint64_t a, uint64_t nbytes) {
+    if (!fd.compressed) { F.to_device(dev, fd.data_at + a, nbytes, st); return; }
+    if (nbytes == 0) return;
+    const uint64_t t0 = a / kFragTile, t1 = (a + nbytes - 1) / kFragTile, nt = t1 - t0 + 1;
+    std::vector<uint64_t> offs((size_t)nt + 1);
+    F.read_at(offs.data(), fd.index_at + 8 * t0, (size_t)(nt + 1) * 8);
+    for (uint64_t i = 0; i < nt; ++i) if (offs[i + 1] < offs[i] || fd.data_at + offs[i + 1] > fd.index_at) throw std::runtime_error(F.path + ": corrupt tile index");
+    const uint64_t first_job = job_want.size();
+    for (uint64_t i = 0; i < nt; ++i) {
+      job_in.push_back(job_in.back() + (offs[i + 1] - offs[i]));
+      job_want.push_back((uint32_t)std::min<uint64_t>(kFragTile, fd.data_bytes - (t0 + i) * kFragTile));
+    }
+    file_ranges.emplace_back(fd.data_at + offs[0], offs[nt] - offs[0]);
+    copies.push_back(InflateCopy{dev, first_job * kFragTile + (a - t0 * kFragTile), nbytes});
+  };
+  auto inflate_all = [&]() {
+    const uint64_t njobs = job_want.size();
+    if (njobs == 0) return;
+    S.inflate_in.ensure(job_in.back() + 16); S.inflate_off.ensure((size_t)njobs + 1); S.inflate_want.ensure((size_t)njobs); S.inflate_out.ensure(njobs * kFragTile);
+    uint64_t at_in = 0;
+    for (auto& fr : file_ranges) { F.to_device(S.inflate_in.p + at_in, fr.first, fr.second, st); at_in += fr.second; }
+    HIP_CHECK(hipMemcpyAsync(S.inflate_off.p, job_in.data(), (size_t)(njobs + 1) * 8, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(S.inflate_want.p, job_want.data(), (size_t)njobs * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_inflate_tiles, dim3(blocks_for((int64_t)njobs, 64)), dim3(64), 0, st, (const uint8_t*)S.inflate_in.p, (const uint64_t*)S.inflate_off.p, (const uint32_t*)S.inflate_want.p,
+                       (int64_t)njobs, S.inflate_out.p, S.err.p);
+    for (auto& c : copies) HIP_CHECK(hipMemcpyAsync(c.dev, S.inflate_out.p + c.from, c.bytes, hipMemcpyDeviceToDevice, st));
+    HIP_CHECK(hipStreamSynchronize(st));                          // (the host vectors above are read by the copies)
+  };
+  if (F.compressed) HIP_CHECK(hipMemsetAsync(S.err.p, 0, sizeof(uint32_t), st));
   for (const FragmentFile::Field& fd : F.fields) {
     const int f = fd.plan_field;
     if (f < 0) continue;
@@ -3153,17 +3361,18 @@ DevicePipeline::FragmentWindow DevicePipeline::append_fragment_cells(int64_t c0,
       hipLaunchKernelGGL(k_copy_offsets, dim3(blocks_for(n + 1)), dim3(kBlock), 0, st, (const uint32_t*)off, n + 1, (uint32_t)(0u - o0), off);   // rebase to the part
       const uint64_t bytes = (uint64_t)(o1 - o0) * (uint64_t)fd.elem_size;
       void* data = alloc((size_t)bytes);
-      F.to_device(data, fd.data_at + (uint64_t)o0 * (uint64_t)fd.elem_size, bytes, st);
+      data_to_device(fd, data, (uint64_t)o0 * (uint64_t)fd.elem_size, bytes);
       part.v.col[f].off = off; part.v.col[f].data = data;
       part.data_bytes[(size_t)f] = (size_t)bytes;
     } else {
       const uint64_t bpc = (uint64_t)fd.fixed_num * (uint64_t)fd.elem_size;
       void* data = alloc((size_t)((uint64_t)n * bpc));
-      F.to_device(data, fd.data_at + (uint64_t)c0 * bpc, (uint64_t)n * bpc, st);
+      data_to_device(fd, data, (uint64_t)c0 * bpc, (uint64_t)n * bpc);
       part.v.col[f].data = data;
       part.data_bytes[(size_t)f] = (size_t)((uint64_t)n * bpc);
     }
   }
+  inflate_all();
   // boundary markers whose column falls into this window
   {
     size_t m0 = F.marker_cursor;
@@ -3179,6 +3388,10 @@ DevicePipeline::FragmentWindow DevicePipeline::append_fragment_cells(int64_t c0,
     }
   }
   HIP_CHECK(hipStreamSynchronize(st));
+  if (F.compressed && S.read_back(S.err.p) != 0u) {
+    for (void* b : part.bufs) (void)hipFree(b);
+    throw std::runtime_error(F.path + ": a compressed tile does not inflate to its size (corrupt file, or DEFLATE blocks with dynamic codes)");
+  }
   S.parts.push_back(part);
   return w;
 }

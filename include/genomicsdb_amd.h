@@ -98,6 +98,10 @@ int gdbamd_engine_split_point(void* engine, int64_t column_begin, int64_t column
  * <workspace>/<array>/fragment.gdbamd when present (else cells.bin).  This is the build's own format (the
  * Intel TileDB fork's on-disk format of the reference, variant_storage_manager.cc:61-153, is not available). */
 int gdbamd_engine_save_fragment(void* engine, const char* path);
+/* the same file with every data section cut into 8 KiB tiles, each a raw DEFLATE stream (stored / fixed-Huffman blocks): compressed
+ * bytes cross PCIe and are inflated on the device, one thread per tile (the place of the gzip'd attribute tiles of the reference's
+ * TileDB arrays, genomicsdb_iterators.cc:334-423) */
+int gdbamd_engine_save_fragment_compressed(void* engine, const char* path);
 int gdbamd_engine_load_fragment(void* engine, const char* path);
 /* Arrays larger than the staging budget (GDBAMD_STAGE_BUDGET_MB, default 8192 MiB of cells per window): instead of staging by
  * hand, name a source and let the engine pass it through HBM in column windows, carrying the intervals that are still live at a

@@ -1211,3 +1211,98 @@ def test_bcf_high_alt_dense_region_decodes_to_the_oracle_text(gdb, tmp_path, max
         lines.append(bcf2text.record_to_text(h, rec, helpers.format_float))
         at += len(rec)
     assert ("\n".join(lines) + "\n").encode() == want
+
+
+@pytest.mark.gpu
+def test_compressed_fragment_file_is_inflated_on_the_device(gdb, tmp_path, monkeypatch):
+    """fragment file version 3: every data section as 8 KiB DEFLATE tiles (stored / fixed-Huffman blocks, any inflate reads them -
+    checked here with zlib), compressed bytes to the device, one thread inflates one tile.  Loaded whole and read window by window
+    the stream equals the stream from the raw cells; the file is smaller than the uncompressed one; a flipped byte inside a tile
+    and a tile recompressed with dynamic Huffman codes are errors, not wrong output."""
+    import json
+    import os
+    import struct
+    import zlib
+    from genomicsdb_amd import synth
+    N, B, L = 150, 10_000_000, 24_000
+    cells, nc = _synth_cells(N, B, L)
+    q = helpers.synth_query(tmp_path, N, B + 500, B + L - 700)
+    monkeypatch.delenv("GDBAMD_STAGE_BUDGET_BYTES", raising=False)
+    s = gdb.GenomicsDBQueryStream(query_json=q, cells=cells, buffer_capacity=1 << 20)
+    resident = s.read()
+    s.close()
+    ws = tmp_path / "ws"
+    (ws / "arr").mkdir(parents=True)
+    e = gdb.CombineEngine(q)
+    e.stage_cells(cells)
+    e.save_fragment(ws / "arr" / "raw.gdbamd")
+    e.save_fragment(ws / "arr" / "fragment.gdbamd", compress=True)
+    e.close()
+    raw_size, z_size = os.path.getsize(ws / "arr" / "raw.gdbamd"), os.path.getsize(ws / "arr" / "fragment.gdbamd")
+    assert z_size < 0.8 * raw_size
+    # (a) loaded whole
+    bodies = []
+    for name in ("raw.gdbamd", "fragment.gdbamd"):
+        e = gdb.CombineEngine(q)
+        e.load_fragment(ws / "arr" / name)
+        e.set_reference(B, synth.reference(B, L + 4096))
+        body, st = e.run_interval(B + 500, B + L - 700, arena_bytes=1 << 30)
+        e.close()
+        bodies.append(body)
+    whole = bodies[1]
+    assert bodies[0] == bodies[1] and len(whole) > 0
+    # (b) as the array of a workspace, in windows of a ninth of the cells
+    q2 = dict(q)
+    q2["workspace"] = str(ws)
+    q2["array"] = "arr"
+    qf = tmp_path / "query.json"
+    qf.write_text(json.dumps(q2))
+    os.remove(ws / "arr" / "raw.gdbamd")
+    monkeypatch.setenv("GDBAMD_STAGE_BUDGET_BYTES", str(len(cells) // 9))
+    s = gdb.GenomicsDBQueryStream(query_json_file=str(qf), buffer_capacity=1 << 20)
+    assert s.read() == resident
+    s.close()
+    monkeypatch.delenv("GDBAMD_STAGE_BUDGET_BYTES")
+    # (c) the tiles are plain DEFLATE: walk the header to the first data section that has tiles; its first tile inflates with zlib
+    blob = bytearray((ws / "arr" / "fragment.gdbamd").read_bytes())
+    assert blob[:8] == b"GDBAMDF2" and struct.unpack_from("<I", blob, 8)[0] == 3
+    nfields, C, M = struct.unpack_from("<Iqq", blob, 12)
+    at = 88
+    fields = []
+    for _ in range(nfields):
+        var, es, name_len, fixed_num, data_bytes = struct.unpack_from("<BBHiQ", blob, at)
+        at += 16 + name_len
+        fields.append((var, data_bytes))
+    stored = struct.unpack_from("<%dQ" % nfields, blob, at)
+    at += 8 * nfields
+    al = lambda x: (x + 63) & ~63
+    for n in (C * 4, C * 8, C * 8, M * 8):
+        at = al(at) + n
+    payload_at = offs = None
+    for (var, data_bytes), st_bytes in zip(fields, stored):
+        if var:
+            at = al(at) + (C + 1) * 4
+        at = al(at)
+        ntiles = struct.unpack_from("<Q", blob, at + st_bytes - 8)[0]
+        assert ntiles == (data_bytes + 8191) // 8192
+        if ntiles and payload_at is None:
+            index_at = at + st_bytes - 8 - 8 * (ntiles + 1)
+            offs = struct.unpack_from("<%dQ" % (ntiles + 1), blob, index_at)
+            payload_at = at
+            first_len = min(8192, data_bytes)
+        at += st_bytes
+    assert at == len(blob) and payload_at is not None
+    first = zlib.decompressobj(-15).decompress(bytes(blob[payload_at + offs[0]:payload_at + offs[1]]))
+    assert len(first) == first_len
+    # (d) a damaged tile / a tile with dynamic Huffman codes is refused
+    bad = bytearray(blob)
+    bad[payload_at + offs[0] + (offs[1] - offs[0]) // 2] ^= 0x5A
+    (ws / "arr" / "fragment.gdbamd").write_bytes(bytes(bad))
+    e = gdb.CombineEngine(q)
+    with pytest.raises(gdb.GenomicsDBException, match="inflate|corrupt|tile"):
+        e.load_fragment(ws / "arr" / "fragment.gdbamd")
+        e.set_reference(B, synth.reference(B, L + 4096))
+        got, _ = e.run_interval(B + 500, B + L - 700, arena_bytes=1 << 30)
+        assert got == whole          # (a flip that happens to decode to the same size must still give the same bytes)
+        raise gdb.GenomicsDBException("tile: damage left the bytes unchanged")
+    e.close()
