@@ -2351,7 +2351,7 @@ struct DevicePipeline::Impl {
   // the walk of the cell sizes on the device
   DevBuf<uint64_t> walk_bitmap, walk_pos, walk_out; DevBuf<uint32_t> walk_wcount, walk_wrank, walk_succ, walk_jump_a, walk_jump_b, walk_flag, walk_dest; DevBuf<uint8_t> walk_reach;
   DevBuf<int64_t> walk_cut; DevBuf<unsigned long long> walk_kept_bytes;
-  DevBuf<uint8_t> inflate_in, inflate_out; DevBuf<uint64_t> inflate_off; DevBuf<uint32_t> inflate_want;   // DEFLATE tiles of a compressed fragment file
+  DevBuf<uint8_t> inflate_in, inflate_out, inflate_scratch; DevBuf<uint64_t> inflate_off; DevBuf<uint32_t> inflate_want;   // DEFLATE tiles of a compressed fragment file
   DevBuf<long long> carry_last; DevBuf<uint64_t> carry_keys, carry_sorted; int64_t carried_cells = 0;
   DevBuf<uint2> resolved;          // (pool offset, length) of every (record, sample): whole interval, or one page when that exceeds the budget
   DevBuf<uint32_t> type_occ;
@@ -2924,8 +2924,9 @@ namespace {
 // (genomicsdb_iterators.cc:334-423 reads them tile by tile).  Compressed bytes cross PCIe, one thread inflates one tile:
 // a window has tens of thousands of tiles, so the serial bit-by-bit nature of a DEFLATE stream is spread over as many lanes.
 // The writer (save_fragment, zlib with strategy Z_FIXED) emits stored and FIXED-Huffman blocks only: the decoder then needs no
-// per-stream code tables - a literal / length code is 7 to 9 bits and is classified arithmetically (RFC 1951, 3.2.6).  A block
-// with dynamic codes is refused (error bit), as is any malformed or overlong stream.
+// per-stream code tables - a literal / length code is 7 to 9 bits and is classified arithmetically (RFC 1951, 3.2.6).  Blocks with
+// dynamic codes (a file compressed by something else) are decoded too, with tables in memory; a malformed or overlong stream raises
+// an error bit.
 constexpr uint32_t kFragTile = 8192;
 __device__ const uint16_t kInfLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
 __device__ const uint8_t kInfLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -2951,10 +2952,46 @@ struct InflateBits {
   __device__ __forceinline__ void drop(int k) { buf >>= k; n -= k; }
   __device__ __forceinline__ uint32_t get(int k) { const uint32_t v = peek(k); drop(k); return v; }   // (k <= 16; refill() first)
 };
+// Blocks with DYNAMIC codes (what a default zlib / gzip writer produces): canonical Huffman decoding bit by bit over a count-per-length
+// and a symbols-in-code-order table (RFC 1951, 3.2.2 and 3.2.7), the tables of a lane in its own slice of a global scratch buffer.
+// Slower than the fixed codes (up to 15 steps per symbol, tables in memory) - the files this build writes do not need it.
+struct InflateCode { uint16_t* count; uint16_t* symbol; };            // count[16], symbol[n]
+constexpr int kInflateScratch = 320 + 2 * (16 + 288) + 2 * (16 + 32);  // bytes per lane: code lengths, literal / length code, distance code
+__device__ __forceinline__ int inflate_decode(InflateBits& b, const InflateCode& h) {
+  int code = 0, first = 0, index = 0;
+  b.refill();
+  for (int len = 1; len <= 15; ++len) {
+    if (b.n < 1) return -1;
+    code |= (int)b.get(1);
+    const int count = h.count[len];
+    if (code - count < first) return h.symbol[index + (code - first)];
+    index += count; first += count;
+    first <<= 1; code <<= 1;
+    if (len == 8) b.refill();
+  }
+  return -1;
+}
+// code lengths -> tables; returns the number of unused codes (0: complete; < 0: over-subscribed)
+__device__ __forceinline__ int inflate_construct(const InflateCode& h, const uint8_t* length, int n) {
+  for (int len = 0; len <= 15; ++len) h.count[len] = 0;
+  for (int sym = 0; sym < n; ++sym) h.count[length[sym]]++;
+  if (h.count[0] == n) return 0;
+  int left = 1;
+  for (int len = 1; len <= 15; ++len) { left <<= 1; left -= h.count[len]; if (left < 0) return left; }
+  uint16_t offs[16];
+  offs[1] = 0;
+  for (int len = 1; len < 15; ++len) offs[len + 1] = (uint16_t)(offs[len] + h.count[len]);
+  for (int sym = 0; sym < n; ++sym) if (length[sym] != 0) h.symbol[offs[length[sym]]++] = (uint16_t)sym;
+  return left;
+}
 // job t: compressed bytes [in_off[t], in_off[t + 1]) of `comp` -> want[t] bytes at out + t * kFragTile
-__global__ void k_inflate_tiles(const uint8_t* __restrict__ comp, const uint64_t* __restrict__ in_off, const uint32_t* __restrict__ want_bytes, int64_t ntiles, uint8_t* __restrict__ out, uint32_t* err) {
+__global__ void k_inflate_tiles(const uint8_t* __restrict__ comp, const uint64_t* __restrict__ in_off, const uint32_t* __restrict__ want_bytes, int64_t ntiles, uint8_t* __restrict__ out,
+                                uint8_t* __restrict__ scratch, uint32_t* err) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= ntiles) return;
+  uint8_t* const lengths = scratch + (uint64_t)t * kInflateScratch;                                       // [320]
+  const InflateCode lencode{reinterpret_cast<uint16_t*>(lengths + 320), reinterpret_cast<uint16_t*>(lengths + 320) + 16};
+  const InflateCode distcode{lencode.symbol + 288, lencode.symbol + 288 + 16};
   uint8_t* const o = out + (uint64_t)t * kFragTile;
   const uint32_t want = want_bytes[t];
   InflateBits b{comp + in_off[t], comp + in_off[t + 1], 0ull, 0};
@@ -3003,7 +3040,57 @@ __global__ void k_inflate_tiles(const uint8_t* __restrict__ comp, const uint64_t
         if (b.n < 0 || dist > at || at + len > want) { bad = true; break; }
         for (uint32_t i = 0; i < len; ++i, ++at) o[at] = o[at - dist];
       }
-    } else bad = true;                                 // dynamic codes (or the reserved type): not written by this build
+    } else if (type == 2) {                            // dynamic codes: read the code lengths, build both tables, decode
+      b.refill();
+      if (b.n < 14) { bad = true; break; }
+      const int nlen = (int)b.get(5) + 257, ndist = (int)b.get(5) + 1, ncode = (int)b.get(4) + 4;
+      if (nlen > 286 || ndist > 30) { bad = true; break; }
+      const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+      for (int i = 0; i < 19; ++i) lengths[i] = 0;
+      for (int i = 0; i < ncode; ++i) { b.refill(); if (b.n < 3) { bad = true; break; } lengths[order[i]] = (uint8_t)b.get(3); }
+      if (bad) break;
+      if (inflate_construct(lencode, lengths, 19) != 0) { bad = true; break; }       // the code-length code must be complete
+      int index = 0;
+      while (index < nlen + ndist && !bad) {
+        int sym = inflate_decode(b, lencode);
+        if (sym < 0) { bad = true; break; }
+        if (sym < 16) lengths[index++] = (uint8_t)sym;
+        else {
+          int rep_len = 0;
+          b.refill();
+          if (sym == 16) { if (index == 0) { bad = true; break; } rep_len = lengths[index - 1]; sym = 3 + (int)b.get(2); }
+          else if (sym == 17) sym = 3 + (int)b.get(3);
+          else sym = 11 + (int)b.get(7);
+          if (b.n < 0 || index + sym > nlen + ndist) { bad = true; break; }
+          while (sym--) lengths[index++] = (uint8_t)rep_len;
+        }
+      }
+      if (bad) break;
+      if (lengths[256] == 0) { bad = true; break; }                                 // no end-of-block code
+      // (the distance lengths are moved aside first: building the literal / length tables must not clobber them)
+      uint8_t dlen[30];
+      for (int i = 0; i < ndist; ++i) dlen[i] = lengths[nlen + i];
+      int rc = inflate_construct(lencode, lengths, nlen);
+      if (rc < 0 || (rc > 0 && nlen - lencode.count[0] != 1)) { bad = true; break; }
+      rc = inflate_construct(distcode, dlen, ndist);
+      if (rc < 0 || (rc > 0 && ndist - distcode.count[0] != 1)) { bad = true; break; }
+      for (;;) {
+        const int sym = inflate_decode(b, lencode);
+        if (sym < 0) { bad = true; break; }
+        if (sym < 256) { if (at >= want) { bad = true; break; } o[at++] = (uint8_t)sym; continue; }
+        if (sym == 256) break;
+        if (sym > 285) { bad = true; break; }
+        b.refill();
+        const uint32_t li = (uint32_t)sym - 257u;
+        const uint32_t len = kInfLenBase[li] + b.get(kInfLenExtra[li]);
+        const int dc = inflate_decode(b, distcode);
+        if (dc < 0 || dc >= 30) { bad = true; break; }
+        b.refill();
+        const uint32_t dist = kInfDistBase[dc] + b.get(kInfDistExtra[dc]);
+        if (b.n < 0 || dist > at || at + len > want) { bad = true; break; }
+        for (uint32_t i = 0; i < len; ++i, ++at) o[at] = o[at - dist];
+      }
+    } else bad = true;                                 // the reserved block type
   }
   if (bad || at != want) atomicOr(err, (uint32_t)GDB_ERR_CELL_STREAM);
 }
@@ -3338,12 +3425,13 @@ DevicePipeline::FragmentWindow DevicePipeline::append_fragment_cells(int64_t c0,
     const uint64_t njobs = job_want.size();
     if (njobs == 0) return;
     S.inflate_in.ensure(job_in.back() + 16); S.inflate_off.ensure((size_t)njobs + 1); S.inflate_want.ensure((size_t)njobs); S.inflate_out.ensure(njobs * kFragTile);
+    S.inflate_scratch.ensure(njobs * (size_t)kInflateScratch);
     uint64_t at_in = 0;
     for (auto& fr : file_ranges) { F.to_device(S.inflate_in.p + at_in, fr.first, fr.second, st); at_in += fr.second; }
     HIP_CHECK(hipMemcpyAsync(S.inflate_off.p, job_in.data(), (size_t)(njobs + 1) * 8, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(S.inflate_want.p, job_want.data(), (size_t)njobs * 4, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_inflate_tiles, dim3(blocks_for((int64_t)njobs, 64)), dim3(64), 0, st, (const uint8_t*)S.inflate_in.p, (const uint64_t*)S.inflate_off.p, (const uint32_t*)S.inflate_want.p,
-                       (int64_t)njobs, S.inflate_out.p, S.err.p);
+                       (int64_t)njobs, S.inflate_out.p, S.inflate_scratch.p, S.err.p);
     for (auto& c : copies) HIP_CHECK(hipMemcpyAsync(c.dev, S.inflate_out.p + c.from, c.bytes, hipMemcpyDeviceToDevice, st));
     HIP_CHECK(hipStreamSynchronize(st));                          // (the host vectors above are read by the copies)
   };

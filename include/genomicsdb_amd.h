@@ -99,7 +99,7 @@ int gdbamd_engine_split_point(void* engine, int64_t column_begin, int64_t column
  * Intel TileDB fork's on-disk format of the reference, variant_storage_manager.cc:61-153, is not available). */
 int gdbamd_engine_save_fragment(void* engine, const char* path);
 /* the same file with every data section cut into 8 KiB tiles, each a raw DEFLATE stream (stored / fixed-Huffman blocks): compressed
- * bytes cross PCIe and are inflated on the device, one thread per tile (the place of the gzip'd attribute tiles of the reference's
+ * bytes cross PCIe and are inflated on the device (fixed and dynamic Huffman codes), one thread per tile (the place of the gzip'd attribute tiles of the reference's
  * TileDB arrays, genomicsdb_iterators.cc:334-423) */
 int gdbamd_engine_save_fragment_compressed(void* engine, const char* path);
 int gdbamd_engine_load_fragment(void* engine, const char* path);

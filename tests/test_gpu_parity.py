@@ -1217,8 +1217,8 @@ def test_bcf_high_alt_dense_region_decodes_to_the_oracle_text(gdb, tmp_path, max
 def test_compressed_fragment_file_is_inflated_on_the_device(gdb, tmp_path, monkeypatch):
     """fragment file version 3: every data section as 8 KiB DEFLATE tiles (stored / fixed-Huffman blocks, any inflate reads them -
     checked here with zlib), compressed bytes to the device, one thread inflates one tile.  Loaded whole and read window by window
-    the stream equals the stream from the raw cells; the file is smaller than the uncompressed one; a flipped byte inside a tile
-    and a tile recompressed with dynamic Huffman codes are errors, not wrong output."""
+    the stream equals the stream from the raw cells; the file is smaller than the uncompressed one; tiles recompressed by a default
+    zlib writer (dynamic Huffman codes) inflate to the same bytes; a flipped byte inside a tile is an error, not wrong output."""
     import json
     import os
     import struct
@@ -1294,7 +1294,55 @@ def test_compressed_fragment_file_is_inflated_on_the_device(gdb, tmp_path, monke
     assert at == len(blob) and payload_at is not None
     first = zlib.decompressobj(-15).decompress(bytes(blob[payload_at + offs[0]:payload_at + offs[1]]))
     assert len(first) == first_len
-    # (d) a damaged tile / a tile with dynamic Huffman codes is refused
+    # (d) the same file with every tile recompressed by a default zlib writer (dynamic Huffman codes, as gzip'd tiles have them): the
+    #     device inflate builds the code tables per tile; same bytes out
+    def rebuild(blob, recompress):
+        out = bytearray(blob[:88])
+        at = 88
+        for _ in range(nfields):
+            name_len = struct.unpack_from("<H", blob, at + 2)[0]
+            out += blob[at:at + 16 + name_len]
+            at += 16 + name_len
+        stored_pos = len(out)
+        out += b"\x00" * (8 * nfields)
+        at += 8 * nfields
+        pad = lambda buf: buf.extend(b"\x00" * ((64 - len(buf) % 64) % 64))
+        for n in (C * 4, C * 8, C * 8, M * 8):
+            at = al(at); pad(out)
+            out += blob[at:at + n]; at += n
+        new_stored = []
+        for (var, data_bytes), st_bytes in zip(fields, stored):
+            if var:
+                at = al(at); pad(out)
+                out += blob[at:at + (C + 1) * 4]; at += (C + 1) * 4
+            at = al(at); pad(out)
+            nt = (data_bytes + 8191) // 8192
+            index_at = at + st_bytes - 8 - 8 * (nt + 1)
+            toffs = struct.unpack_from("<%dQ" % (nt + 1), blob, index_at)
+            tiles = [recompress(zlib.decompressobj(-15).decompress(bytes(blob[at + toffs[i]:at + toffs[i + 1]]))) for i in range(nt)]
+            new_offs = [0]
+            for z in tiles:
+                out += z
+                new_offs.append(new_offs[-1] + len(z))
+            out += struct.pack("<%dQ" % (nt + 1), *new_offs) + struct.pack("<Q", nt)
+            new_stored.append(new_offs[-1] + 8 * (nt + 1) + 8)
+            at += st_bytes
+        struct.pack_into("<%dQ" % nfields, out, stored_pos, *new_stored)
+        return bytes(out)
+
+    def dynamic(raw):
+        co = zlib.compressobj(9, zlib.DEFLATED, -15)
+        return co.compress(raw) + co.flush()
+    dyn_blob = rebuild(blob, dynamic)
+    assert len(dyn_blob) < len(blob)
+    (ws / "arr" / "dynamic.gdbamd").write_bytes(dyn_blob)
+    e = gdb.CombineEngine(q)
+    e.load_fragment(ws / "arr" / "dynamic.gdbamd")
+    e.set_reference(B, synth.reference(B, L + 4096))
+    body, _ = e.run_interval(B + 500, B + L - 700, arena_bytes=1 << 30)
+    e.close()
+    assert body == whole
+    # (e) a damaged tile is an error, not wrong output
     bad = bytearray(blob)
     bad[payload_at + offs[0] + (offs[1] - offs[0]) // 2] ^= 0x5A
     (ws / "arr" / "fragment.gdbamd").write_bytes(bytes(bad))
