@@ -18,6 +18,7 @@ CombineEngine::CombineEngine(const mini_json::Value& query_json, int device, con
                              bool use_missing_values_only_not_vector_end) {
   if (loader) m_qc.update_from_loader(*loader, rank);
   m_qc.read_from_json(query_json, rank, "");
+  if (loader) m_qc.subset_query_column_ranges_based_on_partition(*loader, rank);
   m_qc.do_query_bookkeeping(m_qc.get_vid_mapper().get_num_callsets(), 0);
   std::string tmpl;
   if (!m_qc.get_vcf_header_filename().empty()) tmpl = mini_json::read_text_file(m_qc.get_vcf_header_filename());

@@ -128,6 +128,15 @@ void VariantQueryConfig::update_from_loader(const GenomicsDBImportConfig& l, int
   if (m_array_name.empty() && !l.m_array_names.empty()) m_array_name = l.get_array_name(rank);
 }
 
+void VariantQueryConfig::subset_query_column_ranges_based_on_partition(const GenomicsDBImportConfig& loader, int rank) {
+  if (!loader.is_partitioned_by_column()) return;
+  const ColumnRange mine = loader.get_column_partition(rank);
+  std::vector<ColumnRange> kept;
+  for (const ColumnRange& r : m_query_column_intervals)
+    if (r.second >= mine.first && r.first <= mine.second) kept.push_back(r);
+  m_query_column_intervals = kept;
+}
+
 void VariantQueryConfig::read_from_json(const mini_json::Value& j, int rank, const std::string& base_dir) {
   (void)dir_of;
   if (j.HasMember("vid_mapping_file")) m_vid_mapping_file = pick_rank(j["vid_mapping_file"], rank).GetString();

@@ -30,6 +30,7 @@ class GenomicsDBImportConfig {
   void read_from_file(const std::string& filename, int rank = 0);
   void read_from_json(const mini_json::Value& doc, int rank = 0);
   ColumnRange get_column_partition(int rank) const;
+  bool is_partitioned_by_column() const { return !m_column_partitions.empty(); }
   const std::string& get_workspace(int rank) const { return m_workspaces.size() == 1 ? m_workspaces[0] : m_workspaces.at((size_t)rank); }
   const std::string& get_array_name(int rank) const { return m_array_names.size() == 1 ? m_array_names[0] : m_array_names.at((size_t)rank); }
   std::string m_vid_mapping_file, m_callset_mapping_file, m_vcf_header_filename, m_reference_genome;
@@ -47,6 +48,10 @@ class VariantQueryConfig {
   void read_from_file(const std::string& filename, int rank = 0);
   void read_from_json(const mini_json::Value& doc, int rank = 0, const std::string& base_dir = "");
   void update_from_loader(const GenomicsDBImportConfig& loader, int rank = 0);
+  // keeps the queried column ranges that overlap the loader's column partition of this rank (reference
+  // GenomicsDBConfigBase::subset_query_column_ranges_based_on_partition, genomicsdb_config_base.cc:205-223; the query stream
+  // calls it right after reading the query JSON, genomicsdb_bcf_generator.cc:52-53)
+  void subset_query_column_ranges_based_on_partition(const GenomicsDBImportConfig& loader, int rank = 0);
   // do_query_bookkeeping for the produce-Broad-GVCF path (alleles always required)
   void do_query_bookkeeping(int64_t num_rows_in_array, int64_t lb_row_idx = 0);
   bool is_bookkeeping_done() const { return m_done_bookkeeping; }
