@@ -46,6 +46,20 @@ class CountingOperator : public BatchedVariantOperatorBase {
 
 int main(int argc, char** argv) {
   if (argc < 2) { std::cerr << "usage: gt_mpi_gather_shaped <query.json> [page_size]\n"; return -1; }
+  if (std::string(argv[1]) == "--config-selftest" && argc >= 5) {
+    // host only: loader + query JSON the way GenomicsDBBCFGenerator reads them (genomicsdb_bcf_generator.cc:44-53), then the ranges left
+    try {
+      const int rank = atoi(argv[4]);
+      GenomicsDBImportConfig loader_config;
+      loader_config.read_from_file(argv[3], rank);
+      VariantQueryConfig query_config;
+      query_config.update_from_loader(loader_config, rank);
+      query_config.read_from_file(argv[2], rank);
+      query_config.subset_query_column_ranges_based_on_partition(loader_config, rank);
+      for (unsigned i = 0; i < query_config.get_num_column_intervals(); ++i) std::cout << query_config.get_column_begin(i) << "-" << query_config.get_column_end(i) << "\n";
+      return 0;
+    } catch (const std::exception& e) { std::cerr << e.what() << "\n"; return -2; }
+  }
   const std::string json_config_file = argv[1];
   const size_t page_size = argc > 2 ? strtoull(argv[2], 0, 10) : 0u;
   const int my_world_mpi_rank = 0;

@@ -95,3 +95,26 @@ def test_reference_shaped_cpp_caller_compiles_against_the_operator_headers():
     d = os.path.join(ROOT, "tests", "compat")
     subprocess.check_call(["make", "-s", "-B", "-C", d])
     assert os.path.exists(os.path.join(d, "gt_mpi_gather_shaped"))
+
+
+def test_query_ranges_are_subset_by_the_loader_partition(tmp_path):
+    """GenomicsDBConfigBase::subset_query_column_ranges_based_on_partition (genomicsdb_config_base.cc:205-223): of the queried
+    ranges a rank keeps the ones that overlap its column partition of the loader JSON - driven through the reference-named config
+    classes by the reference-shaped C++ caller, host only"""
+    import json
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "compat", "gt_mpi_gather_shaped")
+    if not os.path.exists(exe):
+        from genomicsdb_amd import build as b
+        b.build_native()
+    q, _ = helpers.query_json("t0_1_2.json", "vid.json", {"query_column_ranges": [[[0, 100], [5000, 6000], [20000, 30000]]]}, "query")
+    loader = {"column_partitions": [{"begin": 0}, {"begin": 5500}, {"begin": 25000}], "vid_mapping_file": q["vid_mapping_file"],
+              "callset_mapping_file": q["callset_mapping_file"]}
+    (tmp_path / "q.json").write_text(json.dumps(q))
+    (tmp_path / "l.json").write_text(json.dumps(loader))
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "genomicsdb_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    want = {0: "0-100\n5000-6000\n", 1: "5000-6000\n20000-30000\n", 2: "20000-30000\n"}
+    for rank, text in want.items():
+        r = subprocess.run([exe, "--config-selftest", str(tmp_path / "q.json"), str(tmp_path / "l.json"), str(rank)], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout == text
