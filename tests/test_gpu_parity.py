@@ -1354,3 +1354,38 @@ def test_compressed_fragment_file_is_inflated_on_the_device(gdb, tmp_path, monke
         assert got == whole          # (a flip that happens to decode to the same size must still give the same bytes)
         raise gdb.GenomicsDBException("tile: damage left the bytes unchanged")
     e.close()
+
+
+@pytest.mark.gpu
+def test_host_walk_and_device_walk_stage_the_same_cells(gdb, tmp_path, monkeypatch):
+    """GDBAMD_HOST_WALK=1 (the walk of the cell sizes by one host thread, kept for comparison) and the device walk cut the windows at
+    the same cells: same stream from cells.bin in windows of a ninth of the file"""
+    import json
+    import os
+    import subprocess
+    import sys
+    N, B, L = 120, 10_000_000, 20_000
+    cells, nc = _synth_cells(N, B, L)
+    q = helpers.synth_query(tmp_path, N, B + 300, B + L - 500)
+    ws = tmp_path / "ws"
+    (ws / "arr").mkdir(parents=True)
+    (ws / "arr" / "cells.bin").write_bytes(cells)
+    q2 = dict(q)
+    q2["workspace"] = str(ws)
+    q2["array"] = "arr"
+    qf = tmp_path / "query.json"
+    qf.write_text(json.dumps(q2))
+    # the switch is read once per process: one child process per setting
+    code = ("import sys, hashlib; sys.path.insert(0, %r); import genomicsdb_amd as g; "
+            "s = g.GenomicsDBQueryStream(query_json_file=%r, buffer_capacity=1 << 20); d = s.read(); s.close(); print(len(d), hashlib.sha256(d).hexdigest())"
+            % (helpers.ROOT, str(qf)))
+    outs = []
+    for host_walk in (False, True):
+        env = dict(os.environ, GDBAMD_STAGE_BUDGET_BYTES=str(len(cells) // 9))
+        env.pop("GDBAMD_HOST_WALK", None)
+        if host_walk:
+            env["GDBAMD_HOST_WALK"] = "1"
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] and int(outs[0].split()[0]) > 100000
