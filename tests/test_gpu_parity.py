@@ -1389,3 +1389,20 @@ def test_host_walk_and_device_walk_stage_the_same_cells(gdb, tmp_path, monkeypat
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.strip().splitlines()[-1])
     assert outs[0] == outs[1] and int(outs[0].split()[0]) > 100000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [c for c in SUPPORTED if c[0] in ("t0_1_2_loading", "t6_7_8_loading", "t0_overlapping_loading", "t0_1_2_all_asa_loading",
+                                                                   "t0_haploid_triploid_1_2_3_triploid_deletion_loading", "info_ops1")],
+                         ids=lambda c: c[0])
+def test_bcf_stream_with_one_column_per_window(gdb, case, monkeypatch):
+    """BCF2 output from an array that is streamed one begin column per window (staging budget of one byte: every live interval
+    crosses a carry-over): the decoded stream is still the reference's text golden"""
+    monkeypatch.setenv("GDBAMD_STAGE_BUDGET_BYTES", "1")
+    name, callsets, vid, ov, golden, mode = case
+    cells = helpers.cells_for(callsets, vid)
+    q, pb = helpers.query_json(callsets, vid, ov, mode)
+    s = gdb.GenomicsDBQueryStream(query_json=q, cells=cells, buffer_capacity=1 << 20, is_bcf=True)
+    data = s.read()
+    s.close()
+    assert helpers.bcf_stream_to_text(data) == helpers.golden_text(golden)
