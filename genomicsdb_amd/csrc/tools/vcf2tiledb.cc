@@ -80,6 +80,27 @@ int main(int argc, char** argv) {
       if (!cells.empty() && fwrite(cells.data(), 1, cells.size(), f) != cells.size()) { fclose(f); throw GenomicsDBConfigException("short write to " + dir + "/cells.bin"); }
       fclose(f);
       remove((dir + "/fragment.gdbamd").c_str());   // a columnar copy of older cells must not shadow the new array
+      // "compress_tiledb_array" (the reference's loader gzips the attribute tiles of the array it writes): the columnar fragment file with
+      // its data sections as DEFLATE tiles goes next to cells.bin; queries read it window by window and inflate the tiles on the device
+      if (doc.HasMember("compress_tiledb_array") && doc["compress_tiledb_array"].GetBool() && !cells.empty()) {
+        const auto tc = std::chrono::steady_clock::now();
+        const size_t close_at = loader_text.rfind('}');
+        if (close_at == std::string::npos) throw GenomicsDBConfigException("loader JSON is not an object");
+        const std::string all_text = loader_text.substr(0, close_at) + ", \"query_column_ranges\": [[[" + std::to_string(part.first) + ", " + std::to_string(part.second) + "]]]" +
+                                     loader_text.substr(close_at);
+        try {
+          CombineEngine eng(mini_json::parse(all_text), 0, nullptr, rank, "", false);
+          eng.stage_cells(cells.data(), cells.size());
+          eng.save_fragment(dir + "/fragment.gdbamd", true);
+          struct stat fs;
+          const long long zbytes = ::stat((dir + "/fragment.gdbamd").c_str(), &fs) == 0 ? (long long)fs.st_size : -1;
+          std::cerr << "GENOMICSDB_TIMER,Rank," << rank << ",compress_tiledb_array,Wall-clock time(s)," << std::chrono::duration<double>(std::chrono::steady_clock::now() - tc).count()
+                    << ",cells_bytes," << cells.size() << ",fragment_bytes," << zbytes << "\n";
+        } catch (const GenomicsDBDeviceException& e) {
+          // (the columnar file is built from columns staged in HBM: without a device the array stays as cells.bin, which every reader accepts)
+          std::cerr << "vcf2tiledb: compress_tiledb_array skipped: " << e.what() << "\n";
+        }
+      }
     }
     if (loader.m_produce_combined_vcf) {
       // the loader JSON doubles as the query JSON of the in-line combine: every attribute, the whole column partition

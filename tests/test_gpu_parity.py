@@ -551,6 +551,19 @@ def test_vcf2tiledb_cli_imports_and_combines_in_line(gdb, tmp_path, name):
         r = subprocess.run([os.path.join(helpers.ROOT, "genomicsdb_amd", "gt_mpi_gather"), "-j", str(qf), "--produce-Broad-GVCF"], capture_output=True, timeout=120)
         assert r.returncode == 0, r.stderr.decode()
         assert r.stdout == helpers.golden_text("t0_1_2_vcf_at_0")
+        # the loader's "compress_tiledb_array": the array also gets the columnar file with DEFLATE tiles; with cells.bin moved away the
+        # query tool reads that file (tiles inflated on the device) and prints the same golden
+        loader["compress_tiledb_array"] = True
+        loader["produce_combined_vcf"] = False
+        lf.write_text(json.dumps(loader))
+        r = subprocess.run([tool, str(lf)], capture_output=True, timeout=120, cwd=helpers.GOLDEN)
+        assert r.returncode == 0 and b"compress_tiledb_array" in r.stderr, r.stderr.decode()
+        frag = tmp_path / "ws" / "arr" / "fragment.gdbamd"
+        assert frag.exists() and frag.read_bytes()[8:12] == b"\x03\x00\x00\x00"
+        os.rename(tmp_path / "ws" / "arr" / "cells.bin", tmp_path / "ws" / "arr" / "cells.bin.away")
+        r = subprocess.run([os.path.join(helpers.ROOT, "genomicsdb_amd", "gt_mpi_gather"), "-j", str(qf), "--produce-Broad-GVCF"], capture_output=True, timeout=120)
+        assert r.returncode == 0, r.stderr.decode()
+        assert r.stdout == helpers.golden_text("t0_1_2_vcf_at_0")
 
 
 def test_pages_stay_in_hbm_and_concat_over_rccl(gdb, tmp_path):
