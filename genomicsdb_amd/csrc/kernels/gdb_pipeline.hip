@@ -3108,14 +3108,17 @@ struct DevicePipeline::FragmentFile {
   uint64_t file_size = 0;
   FragmentFileMeta meta;
   int64_t C = 0, M = 0;
-  uint64_t row_at = 0, begin_at = 0, end_at = 0, marker_at = 0;
-  struct Field {
-    bool var = false; int elem_size = 4, fixed_num = 1; uint64_t data_bytes = 0, off_at = 0, data_at = 0; int plan_field = -1;
-    // version 3: the data section is DEFLATE tiles: [payload][u64 tile offset x (ntiles + 1)][u64 ntiles], stored_bytes in all
-    bool compressed = false; uint64_t stored_bytes = 0, ntiles = 0, index_at = 0;
-  };
+  uint64_t marker_at = 0;
+  // a section of the file: `bytes` of a column.  Version 3 stores every section but the markers as DEFLATE tiles of kFragTile bytes:
+  // [payload][u64 tile offset x (ntiles + 1)][u64 ntiles], `stored` bytes in all
+  struct Section { uint64_t at = 0, bytes = 0, stored = 0, ntiles = 0, index_at = 0; bool compressed = false; };
+  Section sec_row, sec_begin, sec_end;
+  struct Field { bool var = false; int elem_size = 4, fixed_num = 1; uint64_t data_bytes = 0; int plan_field = -1; Section off, data; };
   std::vector<Field> fields;
   bool compressed = false;
+  uint64_t raw_bytes = 0;       // of all column sections as they are in device memory (== their file bytes when not compressed)
+  // the last tile a host-side lookup inflated (the binary searches over `begin` and the offset look-ups stay on the host)
+  const Section* cached_sec = nullptr; uint64_t cached_tile = ~0ull; std::vector<uint8_t> cached_bytes;
   std::vector<int64_t> markers;     // whole array on the host (boundary markers are rare: cells of rows outside the query)
   size_t marker_cursor = 0;
   // two pinned bounce buffers for file -> HBM copies
@@ -3135,7 +3138,37 @@ struct DevicePipeline::FragmentFile {
       d += k; at += (uint64_t)k; n -= (size_t)k;
     }
   }
-  int64_t begin_of(int64_t c) const { int64_t v; read_at(&v, begin_at + (uint64_t)c * 8, 8); return v; }
+  // bytes [off, off + n) of a section into host memory; a compressed section: zlib inflates the tile(s) that hold them
+  void host_read(const Section& sec, uint64_t off, void* dst, size_t n) {
+    if (off + n > sec.bytes) throw std::runtime_error(path + ": read beyond a section of the fragment file");
+    if (!sec.compressed) { read_at(dst, sec.at + off, n); return; }
+    char* d = (char*)dst;
+    while (n) {
+      const uint64_t t = off / kFragTile, in_tile = off % kFragTile;
+      if (cached_sec != &sec || cached_tile != t) {
+        uint64_t o[2];
+        read_at(o, sec.index_at + 8 * t, 16);
+        if (o[1] < o[0] || sec.at + o[1] > sec.index_at) throw std::runtime_error(path + ": corrupt tile index");
+        std::vector<uint8_t> z((size_t)(o[1] - o[0]));
+        read_at(z.data(), sec.at + o[0], z.size());
+        const size_t want = (size_t)std::min<uint64_t>(kFragTile, sec.bytes - t * kFragTile);
+        cached_bytes.resize(want);
+        z_stream zs;
+        memset(&zs, 0, sizeof(zs));
+        if (inflateInit2(&zs, -15) != Z_OK) throw std::runtime_error("inflateInit2 failed");
+        zs.next_in = z.data(); zs.avail_in = (uInt)z.size(); zs.next_out = cached_bytes.data(); zs.avail_out = (uInt)want;
+        const int rc = inflate(&zs, Z_FINISH);
+        const size_t got = want - zs.avail_out;
+        inflateEnd(&zs);
+        if (rc != Z_STREAM_END || got != want) { cached_sec = nullptr; throw std::runtime_error(path + ": a compressed tile does not inflate to its size"); }
+        cached_sec = &sec; cached_tile = t;
+      }
+      const size_t k = (size_t)std::min<uint64_t>(n, cached_bytes.size() - in_tile);
+      memcpy(d, cached_bytes.data() + in_tile, k);
+      d += k; off += k; n -= k;
+    }
+  }
+  int64_t begin_of(int64_t c) { int64_t v; host_read(sec_begin, (uint64_t)c * 8, &v, 8); return v; }
   // file bytes [at, at + n) -> device memory, through the pinned buffers (the read of chunk i + 1 overlaps the copy of chunk i)
   void to_device(void* dev, uint64_t at, uint64_t n, hipStream_t st) {
     int which = 0;
@@ -3193,8 +3226,8 @@ void DevicePipeline::save_fragment(const std::string& path, const FragmentFileMe
     FragFieldHdr h{(uint8_t)(S.col_var[(size_t)f] ? 1 : 0), (uint8_t)S.col_elem_size[(size_t)f], (uint16_t)name.size(), (int32_t)S.col_fixed_num[(size_t)f], data_bytes[(size_t)f]};
     put_bytes(hdr, &h, sizeof(h)); put_bytes(hdr, name.data(), name.size());
   }
-  const size_t stored_at = hdr.size();              // version 3: bytes every data section occupies in the file (patched in at the end)
-  std::vector<uint64_t> stored((size_t)nf, 0);
+  const size_t stored_at = hdr.size();              // version 3: bytes every section occupies in the file (patched in at the end):
+  std::vector<uint64_t> stored(3 + 2 * (size_t)nf, 0);   // row, begin, end, then (offsets, data) per field
   if (compress) put_bytes(hdr, stored.data(), stored.size() * 8);
   const std::string tmp_path = path + ".tmp";
   FILE* fp = fopen(tmp_path.c_str(), "wb");
@@ -3213,8 +3246,7 @@ void DevicePipeline::save_fragment(const std::string& path, const FragmentFileMe
     }
     at += bytes;
   };
-  dump(fr.row, (uint64_t)C * 4); dump(fr.begin, (uint64_t)C * 8); dump(fr.end, (uint64_t)C * 8); dump(fr.marker_begin, (uint64_t)fr.nmarkers * 8);
-  // a data section as DEFLATE tiles: payload, then the tile offsets and the tile count
+  // a section as DEFLATE tiles: payload, then the tile offsets and the tile count
   auto dump_tiles = [&](const void* dev, uint64_t bytes) -> uint64_t {
     pad64(fp, at);
     const uint64_t ntiles = (bytes + kFragTile - 1) / kFragTile;
@@ -3248,10 +3280,12 @@ void DevicePipeline::save_fragment(const std::string& path, const FragmentFileMe
     at += total;
     return total;
   };
+  auto put_section = [&](const void* dev, uint64_t bytes, size_t stored_idx) { if (compress) stored[stored_idx] = dump_tiles(dev, bytes); else dump(dev, bytes); };
+  put_section(fr.row, (uint64_t)C * 4, 0); put_section(fr.begin, (uint64_t)C * 8, 1); put_section(fr.end, (uint64_t)C * 8, 2);
+  dump(fr.marker_begin, (uint64_t)fr.nmarkers * 8);
   for (int f = 0; f < nf; ++f) {
-    if (S.col_var[(size_t)f]) dump(fr.col[f].off, (uint64_t)(C + 1) * 4);
-    if (compress) stored[(size_t)f] = dump_tiles(fr.col[f].data, data_bytes[(size_t)f]);
-    else dump(fr.col[f].data, data_bytes[(size_t)f]);
+    if (S.col_var[(size_t)f]) put_section(fr.col[f].off, (uint64_t)(C + 1) * 4, 3 + 2 * (size_t)f);
+    put_section(fr.col[f].data, data_bytes[(size_t)f], 4 + 2 * (size_t)f);
   }
   if (compress) {
     if (fseek(fp, (long)stored_at, SEEK_SET) != 0 || fwrite(stored.data(), 8, stored.size(), fp) != stored.size()) { fclose(fp); throw std::runtime_error("cannot write " + tmp_path); }
@@ -3290,8 +3324,8 @@ FragmentFileMeta DevicePipeline::open_fragment_file(const std::string& path, con
   struct FileField { FragFieldHdr h; std::string name; };
   std::vector<FileField> file_fields(nfields);
   for (auto& x : file_fields) { rd(&x.h, sizeof(x.h)); x.name.resize(x.h.name_len); if (x.h.name_len) rd(&x.name[0], x.h.name_len); }
-  std::vector<uint64_t> stored(nfields, 0);
-  if (ff->compressed) rd(stored.data(), (size_t)nfields * 8);
+  std::vector<uint64_t> stored(3 + 2 * (size_t)nfields, 0);
+  if (ff->compressed) rd(stored.data(), stored.size() * 8);
   const int nf = S.hp.plan.nfields;
   if ((int)expected.size() != nf) fail("internal: expected column layouts do not match the plan");
   std::vector<int> file_to_plan(nfields, -1);
@@ -3308,33 +3342,39 @@ FragmentFileMeta DevicePipeline::open_fragment_file(const std::string& path, con
   // section offsets, each checked against the file size
   auto section = [&](uint64_t bytes) -> uint64_t { at = align64(at); const uint64_t here = at; if (bytes > ff->file_size || here > ff->file_size - bytes) fail("truncated fragment file"); at += bytes; return here; };
   ff->C = C; ff->M = M;
-  ff->row_at = section((uint64_t)C * 4); ff->begin_at = section((uint64_t)C * 8); ff->end_at = section((uint64_t)C * 8); ff->marker_at = section((uint64_t)M * 8);
+  // a column section: raw, or DEFLATE tiles whose index behind the payload has to agree with the section size and the tile count
+  auto make_section = [&](uint64_t bytes, uint64_t stored_bytes) -> FragmentFile::Section {
+    FragmentFile::Section sec;
+    sec.bytes = bytes;
+    ff->raw_bytes += bytes;
+    if (!ff->compressed) { sec.at = section(bytes); return sec; }
+    sec.compressed = true; sec.stored = stored_bytes;
+    sec.ntiles = (bytes + kFragTile - 1) / kFragTile;
+    if (sec.stored < 16 + 8 * sec.ntiles) fail("compressed section shorter than its tile index");
+    sec.at = section(sec.stored);
+    uint64_t nt_file = 0;
+    ff->read_at(&nt_file, sec.at + sec.stored - 8, 8);
+    if (nt_file != sec.ntiles) fail("tile count of a compressed section does not match its size");
+    sec.index_at = sec.at + sec.stored - 8 - 8 * (sec.ntiles + 1);
+    uint64_t first_off = 1, last_off = 0;
+    ff->read_at(&first_off, sec.index_at, 8); ff->read_at(&last_off, sec.index_at + 8 * sec.ntiles, 8);
+    if (first_off != 0 || sec.at + last_off != sec.index_at) fail("tile index of a compressed section does not match its payload");
+    return sec;
+  };
+  ff->sec_row = make_section((uint64_t)C * 4, stored[0]); ff->sec_begin = make_section((uint64_t)C * 8, stored[1]); ff->sec_end = make_section((uint64_t)C * 8, stored[2]);
+  ff->marker_at = section((uint64_t)M * 8);
   ff->fields.resize(nfields);
   for (uint32_t i = 0; i < nfields; ++i) {
     FragmentFile::Field& fd = ff->fields[i];
     const FragFieldHdr& h = file_fields[i].h;
     fd.var = h.var != 0; fd.elem_size = h.elem_size; fd.fixed_num = h.fixed_num; fd.data_bytes = h.data_bytes; fd.plan_field = file_to_plan[i];
     if (fd.elem_size != 1 && fd.elem_size != 4 && fd.elem_size != 8) fail("unsupported element size");
-    if (fd.var) fd.off_at = section((uint64_t)(C + 1) * 4);
+    if (fd.var) fd.off = make_section((uint64_t)(C + 1) * 4, stored[3 + 2 * (size_t)i]);
     else if (fd.data_bytes != (uint64_t)C * (uint64_t)fd.fixed_num * (uint64_t)fd.elem_size) fail("fixed-length column size does not match the cell count");
-    if (!ff->compressed) fd.data_at = section(fd.data_bytes);
-    else {
-      // DEFLATE tiles: the index behind the payload has to agree with the section size, the tile count with the data size
-      fd.compressed = true; fd.stored_bytes = stored[i];
-      fd.ntiles = (fd.data_bytes + kFragTile - 1) / kFragTile;
-      if (fd.stored_bytes < 16 + 8 * fd.ntiles) fail("compressed section shorter than its tile index");
-      fd.data_at = section(fd.stored_bytes);
-      uint64_t nt_file = 0;
-      ff->read_at(&nt_file, fd.data_at + fd.stored_bytes - 8, 8);
-      if (nt_file != fd.ntiles) fail("tile count of a compressed section does not match its size");
-      fd.index_at = fd.data_at + fd.stored_bytes - 8 - 8 * (fd.ntiles + 1);
-      uint64_t first_off = 1, last_off = 0;
-      ff->read_at(&first_off, fd.index_at, 8); ff->read_at(&last_off, fd.index_at + 8 * fd.ntiles, 8);
-      if (first_off != 0 || fd.data_at + last_off != fd.index_at) fail("tile index of a compressed section does not match its payload");
-    }
+    fd.data = make_section(fd.data_bytes, stored[4 + 2 * (size_t)i]);
     if (fd.var && C > 0) {   // the last offset has to name exactly the bytes of the data section
       uint32_t first = 0, last = 0;
-      ff->read_at(&first, fd.off_at, 4); ff->read_at(&last, fd.off_at + (uint64_t)C * 4, 4);
+      ff->host_read(fd.off, 0, &first, 4); ff->host_read(fd.off, (uint64_t)C * 4, &last, 4);
       if (first != 0 || (uint64_t)last * (uint64_t)fd.elem_size != fd.data_bytes) fail("offsets of a variable-length column do not match its data section");
     }
   }
@@ -3356,7 +3396,7 @@ int64_t DevicePipeline::fragment_file_lower_bound(int64_t column) {
 }
 
 // Appends the cells [c0, c1) of the open file to the staging area as one part, c1 chosen so that the part holds whole begin
-// columns and about budget_bytes of file data (at least one column).  Requires begin_staging() before and finish_staging() after.
+// columns and about budget_bytes of column data (at least one column).  Requires begin_staging() before and finish_staging() after.
 DevicePipeline::FragmentWindow DevicePipeline::append_fragment_cells(int64_t c0, uint64_t budget_bytes) {
   Impl& S = *m_;
   if (!S.ff) throw GenomicsDBDeviceException("append_fragment_cells: no fragment file is open");
@@ -3367,7 +3407,7 @@ DevicePipeline::FragmentWindow DevicePipeline::append_fragment_cells(int64_t c0,
   w.c0 = c0; w.c1 = c0;
   if (c0 >= F.C) return w;
   // ---- the cut: whole columns, about budget_bytes ----------------------------------------------------------------------
-  const double bytes_per_cell = std::max(1.0, (double)F.file_size / (double)std::max<int64_t>(1, F.C));
+  const double bytes_per_cell = std::max(1.0, (double)F.raw_bytes / (double)std::max<int64_t>(1, F.C));   // (as inflated: the budget is device memory)
   int64_t want = std::max<int64_t>(1, (int64_t)((double)budget_bytes / bytes_per_cell));
   int64_t c1;
   for (;;) {
@@ -3391,9 +3431,6 @@ DevicePipeline::FragmentWindow DevicePipeline::append_fragment_cells(int64_t c0,
   part.v.ncells = n;
   auto alloc = [&](size_t bytes) -> void* { void* d = nullptr; HIP_CHECK(hipMalloc(&d, std::max<size_t>(bytes, 16))); part.bufs.push_back(d); return d; };
   void* row = alloc((size_t)n * 4); void* begin = alloc((size_t)n * 8); void* end = alloc((size_t)n * 8);
-  F.to_device(row, F.row_at + (uint64_t)c0 * 4, (uint64_t)n * 4, st);
-  F.to_device(begin, F.begin_at + (uint64_t)c0 * 8, (uint64_t)n * 8, st);
-  F.to_device(end, F.end_at + (uint64_t)c0 * 8, (uint64_t)n * 8, st);
   part.v.row = (const int32_t*)row; part.v.begin = (const int64_t*)begin; part.v.end = (const int64_t*)end;
   const int nf = S.hp.plan.nfields;
   S.col_elem_size.assign((size_t)nf, 4); S.col_var.assign((size_t)nf, false); S.col_fixed_num.assign((size_t)nf, 1);
@@ -3402,25 +3439,31 @@ DevicePipeline::FragmentWindow DevicePipeline::append_fragment_cells(int64_t c0,
   // the file; ALL tiles of the window (every field) are inflated by ONE launch of k_inflate_tiles (one thread per tile: the more
   // tiles in flight, the better the serial decoding of each is hidden), then the ranges are copied out of the inflated tiles.
   struct InflateCopy { void* dev; uint64_t from, bytes; };
+  struct Rebase { uint32_t* off; uint32_t delta; };
+  std::vector<Rebase> rebase;
   std::vector<uint64_t> job_in(1, 0);
   std::vector<uint32_t> job_want;
   std::vector<InflateCopy> copies;
   std::vector<std::pair<uint64_t, uint64_t>> file_ranges;      // (file offset, bytes) of the compressed bytes, in job order
-  auto data_to_device = [&](const FragmentFile::Field& fd, void* dev, uint64_t a, uint64_t nbytes) {
-    if (!fd.compressed) { F.to_device(dev, fd.data_at + a, nbytes, st); return; }
+  auto section_to_device = [&](const FragmentFile::Section& sec, void* dev, uint64_t a, uint64_t nbytes) {
+    if (a + nbytes > sec.bytes) throw std::runtime_error(F.path + ": read beyond a section of the fragment file");
+    if (!sec.compressed) { F.to_device(dev, sec.at + a, nbytes, st); return; }
     if (nbytes == 0) return;
     const uint64_t t0 = a / kFragTile, t1 = (a + nbytes - 1) / kFragTile, nt = t1 - t0 + 1;
     std::vector<uint64_t> offs((size_t)nt + 1);
-    F.read_at(offs.data(), fd.index_at + 8 * t0, (size_t)(nt + 1) * 8);
-    for (uint64_t i = 0; i < nt; ++i) if (offs[i + 1] < offs[i] || fd.data_at + offs[i + 1] > fd.index_at) throw std::runtime_error(F.path + ": corrupt tile index");
+    F.read_at(offs.data(), sec.index_at + 8 * t0, (size_t)(nt + 1) * 8);
+    for (uint64_t i = 0; i < nt; ++i) if (offs[i + 1] < offs[i] || sec.at + offs[i + 1] > sec.index_at) throw std::runtime_error(F.path + ": corrupt tile index");
     const uint64_t first_job = job_want.size();
     for (uint64_t i = 0; i < nt; ++i) {
       job_in.push_back(job_in.back() + (offs[i + 1] - offs[i]));
-      job_want.push_back((uint32_t)std::min<uint64_t>(kFragTile, fd.data_bytes - (t0 + i) * kFragTile));
+      job_want.push_back((uint32_t)std::min<uint64_t>(kFragTile, sec.bytes - (t0 + i) * kFragTile));
     }
-    file_ranges.emplace_back(fd.data_at + offs[0], offs[nt] - offs[0]);
+    file_ranges.emplace_back(sec.at + offs[0], offs[nt] - offs[0]);
     copies.push_back(InflateCopy{dev, first_job * kFragTile + (a - t0 * kFragTile), nbytes});
   };
+  section_to_device(F.sec_row, row, (uint64_t)c0 * 4, (uint64_t)n * 4);
+  section_to_device(F.sec_begin, begin, (uint64_t)c0 * 8, (uint64_t)n * 8);
+  section_to_device(F.sec_end, end, (uint64_t)c0 * 8, (uint64_t)n * 8);
   auto inflate_all = [&]() {
     const uint64_t njobs = job_want.size();
     if (njobs == 0) return;
@@ -3435,6 +3478,7 @@ DevicePipeline::FragmentWindow DevicePipeline::append_fragment_cells(int64_t c0,
     for (auto& c : copies) HIP_CHECK(hipMemcpyAsync(c.dev, S.inflate_out.p + c.from, c.bytes, hipMemcpyDeviceToDevice, st));
     HIP_CHECK(hipStreamSynchronize(st));                          // (the host vectors above are read by the copies)
   };
+  auto rebase_offsets = [&]() { for (auto& r : rebase) hipLaunchKernelGGL(k_copy_offsets, dim3(blocks_for(n + 1)), dim3(kBlock), 0, st, (const uint32_t*)r.off, n + 1, r.delta, r.off); };
   if (F.compressed) HIP_CHECK(hipMemsetAsync(S.err.p, 0, sizeof(uint32_t), st));
   for (const FragmentFile::Field& fd : F.fields) {
     const int f = fd.plan_field;
@@ -3442,25 +3486,26 @@ DevicePipeline::FragmentWindow DevicePipeline::append_fragment_cells(int64_t c0,
     S.col_elem_size[(size_t)f] = fd.elem_size; S.col_var[(size_t)f] = fd.var; S.col_fixed_num[(size_t)f] = fd.fixed_num;
     if (fd.var) {
       uint32_t o0 = 0, o1 = 0;
-      F.read_at(&o0, fd.off_at + (uint64_t)c0 * 4, 4); F.read_at(&o1, fd.off_at + (uint64_t)c1 * 4, 4);
+      F.host_read(fd.off, (uint64_t)c0 * 4, &o0, 4); F.host_read(fd.off, (uint64_t)c1 * 4, &o1, 4);
       if (o1 < o0 || (uint64_t)o1 * (uint64_t)fd.elem_size > fd.data_bytes) throw std::runtime_error(F.path + ": corrupt offsets in a variable-length column");
       uint32_t* off = (uint32_t*)alloc(((size_t)n + 1) * 4);
-      F.to_device(off, fd.off_at + (uint64_t)c0 * 4, ((uint64_t)n + 1) * 4, st);
-      hipLaunchKernelGGL(k_copy_offsets, dim3(blocks_for(n + 1)), dim3(kBlock), 0, st, (const uint32_t*)off, n + 1, (uint32_t)(0u - o0), off);   // rebase to the part
+      section_to_device(fd.off, off, (uint64_t)c0 * 4, ((uint64_t)n + 1) * 4);
+      rebase.push_back(Rebase{off, (uint32_t)(0u - o0)});        // (rebased to the part once the tiles are inflated)
       const uint64_t bytes = (uint64_t)(o1 - o0) * (uint64_t)fd.elem_size;
       void* data = alloc((size_t)bytes);
-      data_to_device(fd, data, (uint64_t)o0 * (uint64_t)fd.elem_size, bytes);
+      section_to_device(fd.data, data, (uint64_t)o0 * (uint64_t)fd.elem_size, bytes);
       part.v.col[f].off = off; part.v.col[f].data = data;
       part.data_bytes[(size_t)f] = (size_t)bytes;
     } else {
       const uint64_t bpc = (uint64_t)fd.fixed_num * (uint64_t)fd.elem_size;
       void* data = alloc((size_t)((uint64_t)n * bpc));
-      data_to_device(fd, data, (uint64_t)c0 * bpc, (uint64_t)n * bpc);
+      section_to_device(fd.data, data, (uint64_t)c0 * bpc, (uint64_t)n * bpc);
       part.v.col[f].data = data;
       part.data_bytes[(size_t)f] = (size_t)((uint64_t)n * bpc);
     }
   }
   inflate_all();
+  rebase_offsets();
   // boundary markers whose column falls into this window
   {
     size_t m0 = F.marker_cursor;
@@ -3478,7 +3523,7 @@ DevicePipeline::FragmentWindow DevicePipeline::append_fragment_cells(int64_t c0,
   HIP_CHECK(hipStreamSynchronize(st));
   if (F.compressed && S.read_back(S.err.p) != 0u) {
     for (void* b : part.bufs) (void)hipFree(b);
-    throw std::runtime_error(F.path + ": a compressed tile does not inflate to its size (corrupt file, or DEFLATE blocks with dynamic codes)");
+    throw std::runtime_error(F.path + ": a compressed tile does not inflate to its size (corrupt file)");
   }
   S.parts.push_back(part);
   return w;

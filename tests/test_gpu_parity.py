@@ -1228,7 +1228,7 @@ def test_bcf_high_alt_dense_region_decodes_to_the_oracle_text(gdb, tmp_path, max
 
 @pytest.mark.gpu
 def test_compressed_fragment_file_is_inflated_on_the_device(gdb, tmp_path, monkeypatch):
-    """fragment file version 3: every data section as 8 KiB DEFLATE tiles (stored / fixed-Huffman blocks, any inflate reads them -
+    """fragment file version 3: every column section (coordinates, offsets, data) as 8 KiB DEFLATE tiles (stored / fixed-Huffman blocks, any inflate reads them -
     checked here with zlib), compressed bytes to the device, one thread inflates one tile.  Loaded whole and read window by window
     the stream equals the stream from the raw cells; the file is smaller than the uncompressed one; tiles recompressed by a default
     zlib writer (dynamic Huffman codes) inflate to the same bytes; a flipped byte inside a tile is an error, not wrong output."""
@@ -1252,7 +1252,7 @@ def test_compressed_fragment_file_is_inflated_on_the_device(gdb, tmp_path, monke
     e.save_fragment(ws / "arr" / "fragment.gdbamd", compress=True)
     e.close()
     raw_size, z_size = os.path.getsize(ws / "arr" / "raw.gdbamd"), os.path.getsize(ws / "arr" / "fragment.gdbamd")
-    assert z_size < 0.8 * raw_size
+    assert z_size < 0.5 * raw_size
     # (a) loaded whole
     bodies = []
     for name in ("raw.gdbamd", "fragment.gdbamd"):
@@ -1286,23 +1286,30 @@ def test_compressed_fragment_file_is_inflated_on_the_device(gdb, tmp_path, monke
         var, es, name_len, fixed_num, data_bytes = struct.unpack_from("<BBHiQ", blob, at)
         at += 16 + name_len
         fields.append((var, data_bytes))
-    stored = struct.unpack_from("<%dQ" % nfields, blob, at)
-    at += 8 * nfields
+    nsec = 3 + 2 * nfields                                  # row, begin, end, then (offsets, data) per field
+    stored = struct.unpack_from("<%dQ" % nsec, blob, at)
+    at += 8 * nsec
     al = lambda x: (x + 63) & ~63
-    for n in (C * 4, C * 8, C * 8, M * 8):
-        at = al(at) + n
-    payload_at = offs = None
-    for (var, data_bytes), st_bytes in zip(fields, stored):
+    # (section size, index into `stored`) in file order; None = the boundary markers, which stay raw
+    layout = [(C * 4, 0), (C * 8, 1), (C * 8, 2), (M * 8, None)]
+    for i, (var, data_bytes) in enumerate(fields):
         if var:
-            at = al(at) + (C + 1) * 4
+            layout.append(((C + 1) * 4, 3 + 2 * i))
+        layout.append((data_bytes, 4 + 2 * i))
+    payload_at = offs = None
+    for nbytes, si in layout:
         at = al(at)
+        if si is None:
+            at += nbytes
+            continue
+        st_bytes = stored[si]
         ntiles = struct.unpack_from("<Q", blob, at + st_bytes - 8)[0]
-        assert ntiles == (data_bytes + 8191) // 8192
-        if ntiles and payload_at is None:
+        assert ntiles == (nbytes + 8191) // 8192
+        if ntiles and si >= 3 and payload_at is None:       # the first field section: damaged in (e)
             index_at = at + st_bytes - 8 - 8 * (ntiles + 1)
             offs = struct.unpack_from("<%dQ" % (ntiles + 1), blob, index_at)
             payload_at = at
-            first_len = min(8192, data_bytes)
+            first_len = min(8192, nbytes)
         at += st_bytes
     assert at == len(blob) and payload_at is not None
     first = zlib.decompressobj(-15).decompress(bytes(blob[payload_at + offs[0]:payload_at + offs[1]]))
@@ -1317,19 +1324,17 @@ def test_compressed_fragment_file_is_inflated_on_the_device(gdb, tmp_path, monke
             out += blob[at:at + 16 + name_len]
             at += 16 + name_len
         stored_pos = len(out)
-        out += b"\x00" * (8 * nfields)
-        at += 8 * nfields
+        out += b"\x00" * (8 * nsec)
+        at += 8 * nsec
         pad = lambda buf: buf.extend(b"\x00" * ((64 - len(buf) % 64) % 64))
-        for n in (C * 4, C * 8, C * 8, M * 8):
+        new_stored = list(stored)
+        for nbytes, si in layout:
             at = al(at); pad(out)
-            out += blob[at:at + n]; at += n
-        new_stored = []
-        for (var, data_bytes), st_bytes in zip(fields, stored):
-            if var:
-                at = al(at); pad(out)
-                out += blob[at:at + (C + 1) * 4]; at += (C + 1) * 4
-            at = al(at); pad(out)
-            nt = (data_bytes + 8191) // 8192
+            if si is None:
+                out += blob[at:at + nbytes]; at += nbytes
+                continue
+            st_bytes = stored[si]
+            nt = (nbytes + 8191) // 8192
             index_at = at + st_bytes - 8 - 8 * (nt + 1)
             toffs = struct.unpack_from("<%dQ" % (nt + 1), blob, index_at)
             tiles = [recompress(zlib.decompressobj(-15).decompress(bytes(blob[at + toffs[i]:at + toffs[i + 1]]))) for i in range(nt)]
@@ -1338,9 +1343,9 @@ def test_compressed_fragment_file_is_inflated_on_the_device(gdb, tmp_path, monke
                 out += z
                 new_offs.append(new_offs[-1] + len(z))
             out += struct.pack("<%dQ" % (nt + 1), *new_offs) + struct.pack("<Q", nt)
-            new_stored.append(new_offs[-1] + 8 * (nt + 1) + 8)
+            new_stored[si] = new_offs[-1] + 8 * (nt + 1) + 8
             at += st_bytes
-        struct.pack_into("<%dQ" % nfields, out, stored_pos, *new_stored)
+        struct.pack_into("<%dQ" % nsec, out, stored_pos, *new_stored)
         return bytes(out)
 
     def dynamic(raw):
