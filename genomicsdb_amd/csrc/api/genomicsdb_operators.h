@@ -84,6 +84,7 @@ class VariantStorageManager {        // names a workspace; arrays are opened by 
  public:
   explicit VariantStorageManager(const std::string& workspace, size_t segment_size = 10u * 1024u * 1024u) : m_workspace(workspace), m_segment_size(segment_size) {}
   const std::string& get_workspace() const { return m_workspace; }
+  size_t get_segment_size() const { return m_segment_size; }
   void close_array(int) {}
  private:
   std::string m_workspace;
