@@ -1711,6 +1711,7 @@ __global__ void __launch_bounds__(kAsmRows) k_bcf_write(CombinePlan pl, const ui
   __shared__ __attribute__((aligned(16))) char s_entry[kAsmRows * kBcfEntryCap];
   __shared__ __attribute__((aligned(16))) char s_image[kBcfImageBytes + 16];
   __shared__ uint2 s_rows[kBcfBatch][kAsmRows];
+  __shared__ uint8_t s_changed[kAsmRows];     // the lanes (samples) whose entry changed at this record, in lane order
   const int64_t unit = xcd_aware_unit<1>(((np + kBcfRun - 1) / kBcfRun) * (int64_t)nchunks);
   if (unit < 0) return;
   // order[0 .. np): the page's records in (block, type) order - along a run of one type the layout and most entries stay the same
@@ -1735,6 +1736,10 @@ __global__ void __launch_bounds__(kAsmRows) k_bcf_write(CombinePlan pl, const ui
   // BCF type, place in the image (sample 0) - what the one-sample-at-a-time format below needs
   uint32_t e_q = 0, e_j = 0, e_t = 0, e_dst = 0;
   uint32_t n_elems = 0;                 // elements per sample (0: more than 64, the lanes-are-samples format is used)
+  // the same per GROUP of lanes: the wavefront is cut into 64 >> g_shift groups of (1 << g_shift) >= n_elems lanes and every group
+  // formats another changed sample in the same pass; lane l of a group is that sample's l-th output element
+  uint32_t g_q = 0, g_j = 0, g_t = 0, g_dst = 0, g_first = 0, g_rest = 0, g_per = 0, g_shift = 0;
+  bool g_ok = false;
   uint32_t desc_g[kBcfImageSets], desc_nv[kBcfImageSets];
 #pragma unroll
   for (int sidx = 0; sidx < kBcfImageSets; ++sidx) { desc_g[sidx] = 0; desc_nv[sidx] = 0; }
@@ -1841,6 +1846,15 @@ __global__ void __launch_bounds__(kAsmRows) k_bcf_write(CombinePlan pl, const ui
               e_dst = (uint32_t)__builtin_amdgcn_readlane((int)q_reg, q) + e_j * (uint32_t)bcf_type_width((int)e_t);
             }
           }
+        if (n_elems) {
+          g_shift = n_elems > 1u ? 32u - (uint32_t)__builtin_clz(n_elems - 1u) : 0u;      // uniform
+          const int el = lane & ((1 << g_shift) - 1);
+          g_ok = (uint32_t)el < n_elems;
+          g_q = (uint32_t)__shfl((int)e_q, el, 64); g_j = (uint32_t)__shfl((int)e_j, el, 64);
+          g_t = (uint32_t)__shfl((int)e_t, el, 64); g_dst = (uint32_t)__shfl((int)e_dst, el, 64);
+          g_first = (uint32_t)__shfl((int)q_first, (int)g_q, 64); g_rest = (uint32_t)__shfl((int)q_rest, (int)g_q, 64);
+          g_per = (uint32_t)__shfl((int)q_per, (int)g_q, 64);
+        }
       }
     }
     if (fits) {
@@ -1848,33 +1862,35 @@ __global__ void __launch_bounds__(kAsmRows) k_bcf_write(CombinePlan pl, const ui
       const bool need = live && (!same || key != img_key);
       const uint64_t need_mask = __ballot(need);
       if (need_mask && same && n_elems && whole) {
-        // Few samples changed (a lane or two per step): one sample at a time, lane e = its e-th output element.  The sample's
-        // element counts come from its entry's summary (lane q), the offsets of its fields inside the entry from a short serial
-        // walk (4-byte fields are 4-byte aligned), then every lane fetches, converts and stores its own element.
-        for (uint64_t rem = need_mask; rem; rem &= rem - 1ull) {   // uniform
-          const int L = __builtin_ctzll(rem);
-          const uint32_t dyL = (uint32_t)__builtin_amdgcn_readlane((int)d.y, L);
+        // Few samples changed (a few lanes per step): a group of lanes per changed sample, lane l of the group = its l-th output
+        // element; 64 >> g_shift samples per pass.  The offset of the element's field inside the sample's entry comes from a walk
+        // over the entry's summary (4-byte fields are 4-byte aligned), then every lane fetches, converts and stores its own element.
+        if (need) s_changed[__popcll(need_mask & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        const int n_changed = __popcll(need_mask);
+        const int per_pass = 64 >> g_shift;
+        for (int p0 = 0; p0 < n_changed; p0 += per_pass) {        // uniform
+          const int r = p0 + (lane >> g_shift);
+          const bool act = g_ok && r < n_changed;
+          const int L = act ? (int)s_changed[r] : lane;
+          const uint32_t dyL = (uint32_t)__shfl((int)d.y, L, 64);
           const char* const slotL = s_entry + L * kBcfEntryCap;
-          uint32_t n_vec = 0;                                     // lane q: elements the sample has for field q
-          if (dyL && lane < nf) n_vec = bcf_summary_n(reinterpret_cast<const uint16_t*>(slotL)[lane]);
-          uint32_t body_vec = 0, b = bcf_summary_bytes(nf);
+          uint32_t b = bcf_summary_bytes(nf), body = 0, n = 0;
           for (int q = 0; q < nf; ++q) {                           // uniform
-            const uint32_t es = (uint32_t)__builtin_amdgcn_readlane((int)q_es, q), nq = (uint32_t)__builtin_amdgcn_readlane((int)n_vec, q);
+            const uint32_t es = (uint32_t)__builtin_amdgcn_readlane((int)q_es, q);
+            const uint32_t nq = dyL ? bcf_summary_n(reinterpret_cast<const uint16_t*>(slotL)[q]) : 0u;
             if (es == 4u) b = (b + 3u) & ~3u;
-            if (lane == q) body_vec = b;
+            if ((uint32_t)q == g_q) { body = b; n = nq; }
             b += nq * es;
           }
-          if ((uint32_t)lane < n_elems) {
-            const uint32_t n = (uint32_t)__shfl((int)n_vec, (int)e_q, 64), body = (uint32_t)__shfl((int)body_vec, (int)e_q, 64);
-            const uint32_t first = (uint32_t)__shfl((int)q_first, (int)e_q, 64), rest = (uint32_t)__shfl((int)q_rest, (int)e_q, 64);
-            const uint32_t per = (uint32_t)__shfl((int)q_per, (int)e_q, 64);
-            char* const out = s_image + e_dst + (uint32_t)L * per;
-            if (e_t == GDB_BT_CHAR) {
-              out[0] = e_j < n ? slotL[body + e_j] : (char)(e_j == 0 ? first : rest);
+          if (act) {
+            char* const out = s_image + g_dst + (uint32_t)L * g_per;
+            if (g_t == GDB_BT_CHAR) {
+              out[0] = g_j < n ? slotL[body + g_j] : (char)(g_j == 0 ? g_first : g_rest);
             } else {
-              const uint32_t v = e_j < n ? *reinterpret_cast<const uint32_t*>(slotL + body + 4u * e_j) : (e_j == 0 ? first : rest);
-              if (e_t == GDB_BT_INT8) out[0] = (int32_t)v == GDB_BCF_INT32_MISSING ? (char)0x80 : (int32_t)v == GDB_BCF_INT32_VECTOR_END ? (char)0x81 : (char)v;
-              else if (e_t == GDB_BT_INT16)
+              const uint32_t v = g_j < n ? *reinterpret_cast<const uint32_t*>(slotL + body + 4u * g_j) : (g_j == 0 ? g_first : g_rest);
+              if (g_t == GDB_BT_INT8) out[0] = (int32_t)v == GDB_BCF_INT32_MISSING ? (char)0x80 : (int32_t)v == GDB_BCF_INT32_VECTOR_END ? (char)0x81 : (char)v;
+              else if (g_t == GDB_BT_INT16)
                 *reinterpret_cast<uint16_t*>(out) = (int32_t)v == GDB_BCF_INT32_MISSING ? (uint16_t)0x8000u : (int32_t)v == GDB_BCF_INT32_VECTOR_END ? (uint16_t)0x8001u : (uint16_t)v;
               else *reinterpret_cast<uint32_t*>(out) = v;
             }
@@ -1907,8 +1923,18 @@ __global__ void __launch_bounds__(kAsmRows) k_bcf_write(CombinePlan pl, const ui
       for (int sidx = 0; sidx < kBcfImageSets; ++sidx) {
         if ((uint32_t)sidx >= nsets) break;              // uniform
         const char* lw = s_image + 16u * ((uint32_t)lane + 64u * (uint32_t)sidx);
-        if (desc_nv[sidx] == 16u) reinterpret_cast<PackedU128*>(gbase + desc_g[sidx])->v = *reinterpret_cast<const u32x4*>(lw);
-        else for (uint32_t j = 0; j < desc_nv[sidx]; ++j) gbase[desc_g[sidx] + j] = lw[j];
+        // (the last word of a field's region holds 1..15 bytes: 8 + 4 + 2 + 1, four predicated stores - a byte loop ran its 15
+        // iterations in nearly every step, for the one lane per field that has such a word)
+        const uint32_t nv = desc_nv[sidx];
+        char* const g = gbase + desc_g[sidx];
+        if (nv == 16u) reinterpret_cast<PackedU128*>(g)->v = *reinterpret_cast<const u32x4*>(lw);
+        else if (nv) {
+          uint32_t o = 0;
+          if (nv & 8u) { reinterpret_cast<PackedU64*>(g)->v = *reinterpret_cast<const uint64_t*>(lw); o = 8u; }
+          if (nv & 4u) { reinterpret_cast<PackedU32*>(g + o)->v = *reinterpret_cast<const uint32_t*>(lw + o); o += 4u; }
+          if (nv & 2u) { reinterpret_cast<PackedU16*>(g + o)->v = *reinterpret_cast<const uint16_t*>(lw + o); o += 2u; }
+          if (nv & 1u) g[o] = lw[o];
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       continue;
