@@ -2301,6 +2301,22 @@ __global__ void k_gather_var(const uint64_t* list, int64_t K, const uint32_t* of
   for (uint32_t b = 0; b < n; ++b) d[b] = s[b];
 }
 
+// The contents of a part read from a fragment file are checked where they arrive (the header of the file is validated at open, but a
+// damaged column must not send a later kernel out of bounds): rows inside the query's rows, END >= begin, cells in (begin, row) order
+__global__ void k_fragment_part_check(const int32_t* __restrict__ row, const int64_t* __restrict__ begin, const int64_t* __restrict__ end, int64_t n, int32_t nrows, uint32_t* err) {
+  const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= n) return;
+  bool bad = row[d] < 0 || row[d] >= nrows || end[d] < begin[d];
+  if (d > 0 && (begin[d] < begin[d - 1] || (begin[d] == begin[d - 1] && row[d] <= row[d - 1]))) bad = true;
+  if (bad) atomicOr(err, (uint32_t)GDB_ERR_CELL_STREAM);
+}
+// ... and the n + 1 offsets of a variable-length column (already rebased to the part): from 0 to `total` elements, never decreasing
+__global__ void k_fragment_offsets_check(const uint32_t* __restrict__ off, int64_t n, uint32_t total, uint32_t* err) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  const bool bad = (i == 0 && off[0] != 0u) || (i == n && off[n] != total) || (i < n && off[i + 1] < off[i]);
+  if (bad) atomicOr(err, (uint32_t)GDB_ERR_CELL_STREAM);
+}
 __global__ void k_copy_offsets(const uint32_t* src, int64_t n, uint32_t base, uint32_t* dst) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[i] + base;
@@ -3465,7 +3481,7 @@ DevicePipeline::FragmentWindow DevicePipeline::append_fragment_cells(int64_t c0,
   // the file; ALL tiles of the window (every field) are inflated by ONE launch of k_inflate_tiles (one thread per tile: the more
   // tiles in flight, the better the serial decoding of each is hidden), then the ranges are copied out of the inflated tiles.
   struct InflateCopy { void* dev; uint64_t from, bytes; };
-  struct Rebase { uint32_t* off; uint32_t delta; };
+  struct Rebase { uint32_t* off; uint32_t delta, total; };
   std::vector<Rebase> rebase;
   std::vector<uint64_t> job_in(1, 0);
   std::vector<uint32_t> job_want;
@@ -3503,9 +3519,18 @@ DevicePipeline::FragmentWindow DevicePipeline::append_fragment_cells(int64_t c0,
                        (int64_t)njobs, S.inflate_out.p, S.inflate_scratch.p, S.err.p);
     for (auto& c : copies) HIP_CHECK(hipMemcpyAsync(c.dev, S.inflate_out.p + c.from, c.bytes, hipMemcpyDeviceToDevice, st));
     HIP_CHECK(hipStreamSynchronize(st));                          // (the host vectors above are read by the copies)
+    if (S.read_back(S.err.p) != 0u) {
+      for (void* b : part.bufs) (void)hipFree(b);
+      throw std::runtime_error(F.path + ": a compressed tile does not inflate to its size (corrupt file)");
+    }
   };
-  auto rebase_offsets = [&]() { for (auto& r : rebase) hipLaunchKernelGGL(k_copy_offsets, dim3(blocks_for(n + 1)), dim3(kBlock), 0, st, (const uint32_t*)r.off, n + 1, r.delta, r.off); };
-  if (F.compressed) HIP_CHECK(hipMemsetAsync(S.err.p, 0, sizeof(uint32_t), st));
+  auto rebase_offsets = [&]() {
+    for (auto& r : rebase) {
+      hipLaunchKernelGGL(k_copy_offsets, dim3(blocks_for(n + 1)), dim3(kBlock), 0, st, (const uint32_t*)r.off, n + 1, r.delta, r.off);
+      hipLaunchKernelGGL(k_fragment_offsets_check, dim3(blocks_for(n + 1)), dim3(kBlock), 0, st, (const uint32_t*)r.off, n, r.total, S.err.p);
+    }
+  };
+  HIP_CHECK(hipMemsetAsync(S.err.p, 0, sizeof(uint32_t), st));
   for (const FragmentFile::Field& fd : F.fields) {
     const int f = fd.plan_field;
     if (f < 0) continue;
@@ -3516,7 +3541,7 @@ DevicePipeline::FragmentWindow DevicePipeline::append_fragment_cells(int64_t c0,
       if (o1 < o0 || (uint64_t)o1 * (uint64_t)fd.elem_size > fd.data_bytes) throw std::runtime_error(F.path + ": corrupt offsets in a variable-length column");
       uint32_t* off = (uint32_t*)alloc(((size_t)n + 1) * 4);
       section_to_device(fd.off, off, (uint64_t)c0 * 4, ((uint64_t)n + 1) * 4);
-      rebase.push_back(Rebase{off, (uint32_t)(0u - o0)});        // (rebased to the part once the tiles are inflated)
+      rebase.push_back(Rebase{off, (uint32_t)(0u - o0), o1 - o0});   // (rebased to the part once the tiles are inflated)
       const uint64_t bytes = (uint64_t)(o1 - o0) * (uint64_t)fd.elem_size;
       void* data = alloc((size_t)bytes);
       section_to_device(fd.data, data, (uint64_t)o0 * (uint64_t)fd.elem_size, bytes);
@@ -3532,6 +3557,7 @@ DevicePipeline::FragmentWindow DevicePipeline::append_fragment_cells(int64_t c0,
   }
   inflate_all();
   rebase_offsets();
+  hipLaunchKernelGGL(k_fragment_part_check, dim3(blocks_for(n)), dim3(kBlock), 0, st, (const int32_t*)row, (const int64_t*)begin, (const int64_t*)end, n, (int32_t)S.hp.plan.num_query_rows, S.err.p);
   // boundary markers whose column falls into this window
   {
     size_t m0 = F.marker_cursor;
@@ -3547,9 +3573,9 @@ DevicePipeline::FragmentWindow DevicePipeline::append_fragment_cells(int64_t c0,
     }
   }
   HIP_CHECK(hipStreamSynchronize(st));
-  if (F.compressed && S.read_back(S.err.p) != 0u) {
+  if (S.read_back(S.err.p) != 0u) {
     for (void* b : part.bufs) (void)hipFree(b);
-    throw std::runtime_error(F.path + ": a compressed tile does not inflate to its size (corrupt file)");
+    throw std::runtime_error(F.path + ": the columns of the fragment file are damaged (cells out of order, rows outside the query's rows or offsets that do not match the data)");
   }
   S.parts.push_back(part);
   return w;

@@ -1375,6 +1375,63 @@ def test_compressed_fragment_file_is_inflated_on_the_device(gdb, tmp_path, monke
 
 
 @pytest.mark.gpu
+def test_damaged_fragment_columns_are_refused(gdb, tmp_path):
+    """The header of a fragment file is validated at open; its columns are checked on the device where they arrive: cells out of
+    (begin, row) order, a row outside the query's rows, END before begin or offsets of a variable-length column that decrease are an
+    error at load, not an out-of-bounds read in a later kernel."""
+    import struct
+    N, B, L = 40, 10_000_000, 6_000
+    cells, nc = _synth_cells(N, B, L)
+    q = helpers.synth_query(tmp_path, N, B, B + L - 1)
+    e = gdb.CombineEngine(q)
+    e.stage_cells(cells)
+    good = tmp_path / "good.gdbamd"
+    e.save_fragment(good)
+    e.close()
+    blob = good.read_bytes()
+    assert blob[:8] == b"GDBAMDF2" and struct.unpack_from("<I", blob, 8)[0] == 2
+    nfields, C, M = struct.unpack_from("<Iqq", blob, 12)
+    at = 88
+    fields = []
+    for _ in range(nfields):
+        var, es, name_len, fixed_num, data_bytes = struct.unpack_from("<BBHiQ", blob, at)
+        at += 16 + name_len
+        fields.append((var, data_bytes))
+    al = lambda x: (x + 63) & ~63
+    row_at = al(at); begin_at = al(row_at + C * 4); end_at = al(begin_at + C * 8); marker_at = al(end_at + C * 8)
+    at = marker_at + M * 8
+    off_at = None
+    for var, data_bytes in fields:
+        if var:
+            at = al(at)
+            if off_at is None:
+                off_at = at
+            at += (C + 1) * 4
+        at = al(at) + data_bytes
+    assert at == len(blob) and off_at is not None and C > 20
+
+    def refused(mutate, what):
+        bad = bytearray(blob)
+        mutate(bad)
+        path = tmp_path / "bad.gdbamd"
+        path.write_bytes(bytes(bad))
+        e = gdb.CombineEngine(q)
+        with pytest.raises(gdb.GenomicsDBException, match="damaged|corrupt|do not match"):
+            e.load_fragment(path)
+        e.close()
+
+    e = gdb.CombineEngine(q)
+    e.load_fragment(good)                                   # (the undamaged file loads)
+    e.close()
+    refused(lambda b: struct.pack_into("<q", b, begin_at + 8 * 10, B - 5), "a cell out of order")
+    refused(lambda b: struct.pack_into("<i", b, row_at + 4 * 7, N + 3), "a row outside the query")
+    refused(lambda b: struct.pack_into("<i", b, row_at + 4 * 7, -2), "a negative row")
+    refused(lambda b: struct.pack_into("<q", b, end_at + 8 * 12, 17), "END before begin")
+    o11 = struct.unpack_from("<I", blob, off_at + 4 * 11)[0]
+    refused(lambda b: struct.pack_into("<I", b, off_at + 4 * 10, o11 + 40), "offsets that decrease")
+
+
+@pytest.mark.gpu
 def test_host_walk_and_device_walk_stage_the_same_cells(gdb, tmp_path, monkeypatch):
     """GDBAMD_HOST_WALK=1 (the walk of the cell sizes by one host thread, kept for comparison) and the device walk cut the windows at
     the same cells: same stream from cells.bin in windows of a ninth of the file"""
