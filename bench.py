@@ -45,7 +45,15 @@ def main():
                          "(GDBAMD_STAGE_BUDGET_MB) with carry-over; one pass over --interval-bp, --steps / --warmup are ignored")
     ap.add_argument("--no-stream", action="store_true", help="skip the end-to-end leg through the query stream (gdb_mi355_read)")
     ap.add_argument("--cpu-sample-bp", type=int, default=12000, help="columns of the bounded CPU-baseline sample (~15 s of oracle time)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rank set-up, partition arithmetic and the cross-rank reduction only, no device work and no number: "
+                         "lets the CPU suite check the N-rank launch (the line says \"dry_run\": true and carries value null)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched bare (`python bench.py --gpus N`): become N ranks, one per GPU, like `mpirun -n N gt_mpi_gather`
+        # (gt_mpi_gather.cc:415-425: rank -> column partition); the ranks' stdout is this process's stdout
+        return relaunch_ranks(args.gpus)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -60,6 +68,8 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
         else:
             dist.init_process_group(backend=backend)
+    if args.dry_run:
+        return dry_run(args, rank, world, backend)
     torch.cuda.set_device(device_index)
 
     import genomicsdb_amd
@@ -160,6 +170,39 @@ def main():
             out["cpu_baseline"] = cpu_baseline(N, args.cpu_sample_bp, tmp)
     if out is not None:
         print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def relaunch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU of this node"""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.stdout.flush()
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        sys.exit(rc)
+
+
+def dry_run(args, rank, world, backend):
+    """what the ranks share besides the scan: who owns which columns, max-over-ranks time, sums of the counters"""
+    import torch.distributed as dist
+    from genomicsdb_amd import dist as gdist
+    B, E = gdist.synthetic_partition(rank, 10_000_000, args.interval_bp)
+    dt, (cols, ranks) = gdist.aggregate(0.001 * (rank + 1), [E - B + 1, 1])
+    if rank == 0:
+        print(json.dumps({"metric": "combined-gVCF positions/sec", "value": None, "unit": "positions/s", "n_gpus": world, "dry_run": True,
+                          "steps": args.steps, "warmup": args.warmup, "scaling": "weak", "ranks_reporting": int(ranks),
+                          "columns_all_ranks": int(cols), "max_over_ranks_s": dt, "backend": backend}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -97,3 +97,103 @@ def gather_interval(engine, begin, end, arena_bytes=None, dst=0):
         pages = [t.clone() for t in engine.page_tensors(begin, end, arena_bytes)]
         local = torch.cat(pages) if pages else empty()
     return ordered_concat_tensors(local, dst=dst)
+
+
+def paged_concat(pages, sink, page_bytes, dst=0, ring_slots=3, device=None):
+    """Ordered concatenation of the ranks' page streams with BOUNDED memory on every rank: the single-stream view of the P
+    per-partition outputs of `mpirun -n P gt_mpi_gather` (gt_mpi_gather.cc:322-366 writes P files; a combined stream is those
+    files back to back in rank = column order).
+
+    pages: this rank's pages, an iterable of 1-D uint8 tensors of at most `page_bytes` bytes each (HBM pages under "nccl" =
+    RCCL over xGMI, host tensors under "gloo"); a page need only stay valid until the next one is asked for.
+    sink(t): called on rank `dst` once per page, in rank order and in each rank's page order; `t` is valid during the call only.
+
+    Rank `dst` never holds more than ring_slots pages of other ranks (a ring of receive buffers that is reused), a sending rank
+    never more than ring_slots copies of its own pages: a rank keeps scanning while its earlier pages wait for the root, and
+    stops when its ring is full.  Every page travels as an 8-byte header (its size; 0 closes the rank's stream) followed by
+    the bytes, point to point; there is no collective and no tensor of the size of a whole body anywhere (the round-2
+    gather_interval needed the sum of all bodies on the root).  Returns the number of bytes handed to `sink` (root) / sent."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        total = 0
+        for t in pages:
+            sink(t)
+            total += int(t.numel())
+        return total
+    world, rank = dist.get_world_size(), dist.get_rank()
+    ring_slots = max(2, int(ring_slots))
+    if rank != dst:
+        ring, hdrs, pending, total, k = [], [], [], 0, 0
+        for t in pages:
+            n = int(t.numel())
+            if n == 0:
+                continue
+            if n > page_bytes:
+                raise ValueError("page of %d bytes exceeds page_bytes %d" % (n, page_bytes))
+            slot = k % ring_slots
+            if len(ring) <= slot:
+                ring.append(torch.empty(page_bytes, dtype=torch.uint8, device=t.device))
+                hdrs.append(torch.zeros(1, dtype=torch.int64, device=t.device))
+            elif len(pending) >= ring_slots:          # the slot's previous page must have left
+                for w in pending.pop(0):
+                    w.wait()
+            ring[slot][:n].copy_(t)                   # the engine's arena is reused by the next page:
+            if t.is_cuda:                             # the copy (torch's stream) must be over before the engine (its own
+                torch.cuda.current_stream(t.device).synchronize()   # stream) is asked for the next one
+            hdrs[slot].fill_(n)
+            pending.append((dist.isend(hdrs[slot], dst=dst), dist.isend(ring[slot][:n], dst=dst)))
+            total += n
+            k += 1
+        for ws in pending:
+            for w in ws:
+                w.wait()
+        end = torch.zeros(1, dtype=torch.int64, device=device if device is not None else (ring[0].device if ring else None))
+        dist.send(end, dst=dst)
+        return total
+    total = 0
+    for t in pages:                                   # the root's own pages go straight to the sink where they lie
+        if int(t.numel()):
+            sink(t)
+            total += int(t.numel())
+    dev = device
+    ring, inflight, k = [], [], 0                     # inflight: (work, view) in arrival order
+    hdr = None
+    for r in range(world):
+        if r == dst:
+            continue
+        while True:
+            if hdr is None:
+                hdr = torch.zeros(1, dtype=torch.int64, device=dev)
+            dist.recv(hdr, src=r)
+            n = int(hdr.item())
+            if n == 0:
+                break
+            if n > page_bytes:
+                raise ValueError("rank %d announced a page of %d bytes, page_bytes is %d" % (r, n, page_bytes))
+            if len(inflight) >= ring_slots - 1 and len(ring) >= ring_slots:   # free the oldest slot: its page goes to the sink now
+                w, view = inflight.pop(0)
+                w.wait()
+                sink(view)
+                total += int(view.numel())
+            slot = k % ring_slots
+            if len(ring) <= slot:
+                ring.append(torch.empty(page_bytes, dtype=torch.uint8, device=dev))
+            view = ring[slot][:n]
+            inflight.append((dist.irecv(view, src=r), view))
+            k += 1
+    for w, view in inflight:
+        w.wait()
+        sink(view)
+        total += int(view.numel())
+    return total
+
+
+def gather_interval_paged(engine, begin, end, sink, page_bytes=1 << 30, dst=0, ring_slots=3):
+    """produce-combined-VCF over all ranks with bounded memory: every rank scans + combines its own column interval on its GPU
+    page by page (pages of at most page_bytes, left in HBM), rank `dst`'s sink sees the pages of all partitions in column order
+    (see paged_concat).  At the width of BASELINE configs[3] (100 000 samples: ~9 MB of text per record) a body does not fit any
+    single tensor; this is the form of the concat that still works there."""
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    return paged_concat(engine.page_tensors(begin, end, page_bytes), sink, page_bytes, dst=dst, ring_slots=ring_slots, device=dev)

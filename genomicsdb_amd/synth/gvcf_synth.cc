@@ -13,6 +13,9 @@
 //                  SB 4 x U[0,40]; rank-sum INFOs round(N(0,1),3); MQ round(U[40,60],2); RAW_MQ = MQ^2*DP; MQ0 = 0;
 //                  INFO DP = DP; QUAL round(U[30,3000],2)
 //   reference base(pos) = "ACGT"[hash(seed, pos) & 3]
+//   genome mode (gdbsynth_set_contigs, BASELINE configs[3]): columns are the flattened genome of a contig table (tiledb_column_offset,
+//   length); no record crosses the end of its contig (reference blocks are cut there, a deletion that would cross becomes an SNV)
+//   and every sample begins a new record at the first column of the next contig - as separate per-contig gVCF records would
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -81,6 +84,17 @@ struct Synth {
   int32_t filter_id = 1, filter_id2 = 0;
   bool with_id = false;
   uint64_t mode_hash(int32_t row, int64_t begin, uint64_t salt) const { return hash2(seed ^ salt, (uint64_t)begin * 0x9E3779B97F4A7C15ull + (uint64_t)row); }
+  // genome mode: contig table in column space, sorted by offset; empty = one unbounded contig
+  std::vector<std::pair<int64_t, int64_t>> contigs;   // (offset, length)
+  // end (exclusive) of the contig holding column p; a column in a gap between contigs is moved to the next contig's offset
+  int64_t contig_end(int64_t& p) const {
+    if (contigs.empty()) return INT64_MAX;
+    size_t lo = 0, hi = contigs.size();
+    while (lo < hi) { size_t mid = (lo + hi) >> 1; if (contigs[mid].first <= p) lo = mid + 1; else hi = mid; }
+    if (lo > 0 && p < contigs[lo - 1].first + contigs[lo - 1].second) return contigs[lo - 1].first + contigs[lo - 1].second;
+    if (lo < contigs.size()) { p = contigs[lo].first; return contigs[lo].first + contigs[lo].second; }
+    return INT64_MAX;   // behind the last contig: unbounded (the caller's [B, B+L) ends the stream)
+  }
   bool in_dense(int64_t p) const { return dense_len > 0 && p >= dense_begin && p < dense_begin + dense_len; }
   bool is_hot(int64_t p) const { return in_dense(p) && (p % hot_stride) == 0; }
 
@@ -90,6 +104,7 @@ struct Synth {
     Rng& g = rng[row];
     memset(&r, 0, sizeof(r));
     r.row = row;
+    const int64_t cend = contig_end(pos[row]);   // (may move pos[row] out of a gap)
     r.begin = pos[row];
     const bool hot = is_hot(r.begin);
     if (!hot && g.below(8) != 0) {  // reference block
@@ -101,6 +116,7 @@ struct Synth {
         int64_t nh = ((r.begin / hot_stride) + 1) * hot_stride;
         if (in_dense(nh) && r.begin + len > nh) len = nh - r.begin;
       }
+      if (r.begin + len > cend) len = cend - r.begin;
       r.kind = 0;
       r.end = r.begin + len - 1;
       r.reflen = 1; r.ref[0] = base(r.begin);
@@ -117,6 +133,7 @@ struct Synth {
       if (hot) { K = dense_K; t = 99; }   // insertion from the dense pool
       int pick = (int)g.below((uint32_t)K);
       uint64_t ah = hash2(site, (uint64_t)pick + 17);
+      if (t >= 85 && t < 93 && r.begin + 2 + (int64_t)(ah % 9) > cend) t = 0;   // a deletion would run over the contig's end
       char rb = base(r.begin);
       if (t < 85) {  // SNV
         r.kind = 1; r.end = r.begin; r.reflen = 1; r.ref[0] = rb;
@@ -238,7 +255,9 @@ struct Synth {
       cnt[(size_t)t].assign((size_t)ncols, 0); bytes[(size_t)t].assign((size_t)ncols, 0);
       Rec r;
       for (int32_t row = r0; row < r1; ++row)
-        while (pos[row] < col_end) {
+        while (true) {
+          contig_end(pos[row]);            // (moves a position out of a gap between contigs before the chunk bound is looked at)
+          if (pos[row] >= col_end) break;
           next_record(row, r);
           if (with_id) r.idlen |= 0x80;
           out.push_back(r);
@@ -298,6 +317,13 @@ void* gdbsynth_create(uint64_t seed, int32_t n_samples, int64_t B, int64_t L) {
   return s;
 }
 void gdbsynth_destroy(void* h) { delete (Synth*)h; }
+// genome mode: n contigs as (tiledb_column_offset, length) pairs; call before the first chunk
+void gdbsynth_set_contigs(void* h, const int64_t* offsets, const int64_t* lengths, int32_t n) {
+  Synth* s = (Synth*)h;
+  s->contigs.clear();
+  for (int32_t i = 0; i < n; ++i) s->contigs.emplace_back(offsets[i], lengths[i]);
+  std::sort(s->contigs.begin(), s->contigs.end());
+}
 void gdbsynth_set_rank_sum_scale(void* h, double scale) { ((Synth*)h)->rs_scale = scale > 0 ? scale : 1000.0; }
 void gdbsynth_set_modes(void* h, int overlap_permille, int filter_permille, int filter2_permille, int id_permille, int filter_id, int filter_id2, int with_id) {
   Synth* s = (Synth*)h;

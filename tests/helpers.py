@@ -146,10 +146,11 @@ def oracle_run_synth(query, cells, seed, buffer_limit=0, with_header=True):
     return txt, nrec.value, secs.value
 
 
-def synth_query(tmpdir, n_samples, begin, end, with_id=False):
-    """query JSON for the synthetic workload (vcf_attributes_order, vid.json schema, one contig)"""
+def synth_query(tmpdir, n_samples, begin, end, with_id=False, contigs=None):
+    """query JSON for the synthetic workload (vcf_attributes_order, vid.json schema; one contig unless contigs =
+    [(name, tiledb_column_offset, length), ...])"""
     from genomicsdb_amd import synth
-    vp, cp = synth.write_metadata(str(tmpdir), n_samples, os.path.join(GOLDEN, "inputs", "vid.json"), with_id=with_id)
+    vp, cp = synth.write_metadata(str(tmpdir), n_samples, os.path.join(GOLDEN, "inputs", "vid.json"), with_id=with_id, contigs=contigs)
     return {
         "vid_mapping_file": vp, "callset_mapping_file": cp,
         "vcf_header_filename": os.path.join(GOLDEN, "inputs", "template_vcf_header.vcf"),

@@ -132,3 +132,72 @@ def test_two_ranks_import_their_partitions_and_concat():
         off += struct.unpack_from("<Q", cells, off + 16)[0]
         ncells_full += 1
     assert nc0 + nc1 > ncells_full          # the replayed intervals exist in both partitions
+
+
+def _paged_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from genomicsdb_amd import dist as gdist
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        import random
+        rnd = random.Random(77 + rank)
+        # rank r "scans" its partition into pages of at most 1000 bytes: 0 pages on rank 1, a different number elsewhere;
+        # one reused buffer stands for the engine's arena (a page is only valid until the next one is asked for)
+        npages = 0 if rank == 1 else 5 + 4 * rank
+        arena = torch.empty(1000, dtype=torch.uint8)
+        mine = []
+
+        def pages():
+            for k in range(npages):
+                n = rnd.randint(1, 1000)
+                arena[:n] = torch.tensor([(rank * 50 + k + i) % 251 for i in range(n)], dtype=torch.uint8)
+                mine.append(bytes(arena[:n].numpy().tobytes()))
+                yield arena[:n]
+        got = []
+        live = {"max": 0}
+        total = gdist.paged_concat(pages(), lambda t: got.append(bytes(t.numpy().tobytes())), page_bytes=1000, dst=0, ring_slots=3)
+        assert total == sum(len(m) for m in mine) if rank else True
+        q.put((rank, mine, got, total))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_paged_concat_is_ordered_and_bounded():
+    """three ranks, pages of different counts (one rank has none): the root's sink sees every page of every rank, in rank and
+    page order, through a ring of three receive buffers (no tensor of the size of a body exists anywhere)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_paged_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = [pg for _, mine, _, _ in res for pg in mine]
+    assert res[0][2] == want and len(want) == 5 + 13
+    assert res[0][3] == sum(len(p) for p in want)
+    assert res[1][2] == [] and res[2][2] == []
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it becomes two ranks (torch.distributed.run, 127.0.0.1) and rank 0
+    reports n_gpus = 2; --dry-run keeps the device out of it (no GPU in the CPU suite), the backend is gloo"""
+    import subprocess
+    env = dict(os.environ, GDBAMD_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--interval-bp", "1000"],
+                       capture_output=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_reporting"] == 2 and out["dry_run"] is True and out["value"] is None
+    assert out["columns_all_ranks"] == 2000 and abs(out["max_over_ranks_s"] - 0.002) < 1e-9

@@ -76,3 +76,44 @@ def test_tied_zero_medians_follow_the_library_selection(tmp_path):
     got, errbits = helpers.hostsim_run(q, cells, with_header=False, rows_per_chunk=64, records_per_run=8)
     assert errbits == 0
     assert got == want
+
+
+SMALL_GENOME = [("1", 0, 3000), ("2", 3000, 500), ("3", 3500, 4000), ("X", 7500, 1200), ("MT", 8700, 1300)]
+
+
+def test_generator_genome_mode_never_crosses_a_contig_end():
+    import struct
+    from genomicsdb_amd import synth
+    g = synth.Generator(12, 0, 10_000, contigs=SMALL_GENOME)
+    cells, nc = g.chunk_bytes(10_000)
+    off, begins_at = 0, {c[1]: 0 for c in SMALL_GENOME}
+    while off < len(cells):
+        row, col, sz, end = struct.unpack_from("<qqQq", cells, off)
+        ctg = [c for c in SMALL_GENOME if c[1] <= col < c[1] + c[2]]
+        assert len(ctg) == 1 and end < ctg[0][1] + ctg[0][2]
+        if col in begins_at:
+            begins_at[col] += 1
+        off += sz
+    assert all(v == 12 for v in begins_at.values())     # every sample starts anew at every contig's first column
+
+
+def test_hostsim_matches_oracle_across_contig_boundaries(tmp_path):
+    """BASELINE configs[3] shape at test size: the columns are a flattened genome of five contigs; the query interval
+    crosses four contig boundaries.  CHROM / POS / END are contig-relative (broad_combined_gvcf.cc:772-791,903-909)."""
+    from genomicsdb_amd import synth
+    N = 23
+    g = synth.Generator(N, 0, 10_000, contigs=SMALL_GENOME)
+    cells, nc = g.chunk_bytes(10_000)
+    q = helpers.synth_query(tmp_path, N, 1500, 9500, contigs=SMALL_GENOME)
+    want, nrec, _ = helpers.oracle_run(q, cells, with_header=False)
+    chroms = [l.split(b"\t", 1)[0] for l in want.split(b"\n") if l]
+    assert [c for i, c in enumerate(chroms) if i == 0 or chroms[i - 1] != c] == [b"1", b"2", b"3", b"X", b"MT"]
+    got, errbits = helpers.hostsim_run(q, cells, with_header=False, rows_per_chunk=16, records_per_run=7)
+    assert errbits == 0
+    assert got == want
+    # the END tag of the last record of contig "2" (500 long) is contig-relative
+    last2 = [l for l in want.split(b"\n") if l.startswith(b"2\t")][-1]
+    assert b"END=500" in last2 or last2.split(b"\t")[1] == b"500"
+    hdr, _, _ = helpers.oracle_run(q, cells)
+    for name, _, ln in SMALL_GENOME:
+        assert b"##contig=<ID=%s,length=%d>" % (name.encode(), ln) in hdr

@@ -37,9 +37,21 @@ for case in range(ncases):
     if rnd.random() < 0.3: modes["filter_permille"] = rnd.choice([100, 500]); opts["produce_FILTER_field"] = True
     with_id = rnd.random() < 0.3
     if with_id: modes["id_permille"] = rnd.choice([100, 600]); modes["with_id"] = True
-    g = synth.Generator(N, B, off + L + 2500, seed=gseed, dense=dense, rank_sum_scale=rs_scale, **modes)
+    # genome mode: the columns of the array are cut into contigs of random lengths (one boundary every few hundred columns), so
+    # the query interval and the pieces below cross contig ends; CHROM / POS / END turn contig-relative
+    contigs = None
+    if rnd.random() < 0.35:
+        contigs, at, i = [], 0, 0
+        span = B + off + L + 2500
+        first = B - rnd.randint(0, 3) * 1000          # the first boundary may lie before, at or behind the array's first column
+        while at < span + 10:
+            ln = first if i == 0 and first > 0 else rnd.choice([1, 2, 37, 150, 400, 1500, 5000])
+            contigs.append(("c%d" % i, at, ln)); at += ln; i += 1
+        if rnd.random() < 0.5:
+            contigs = contigs[::-1]                   # vid order need not be offset order
+    g = synth.Generator(N, B, off + L + 2500, seed=gseed, dense=dense, rank_sum_scale=rs_scale, contigs=contigs, **modes)
     cells, nc = g.chunk_bytes(B + off + L + 2500)
-    q = helpers.synth_query(tmp, N, qb, qe, with_id=with_id)
+    q = helpers.synth_query(tmp, N, qb, qe, with_id=with_id, contigs=contigs)
     q.update(opts)
     want, nrec, _ = helpers.oracle_run_synth(q, cells, gseed, with_header=False)
     eng = genomicsdb_amd.CombineEngine(q)
@@ -74,6 +86,6 @@ for case in range(ncases):
     eng.close()
     if not ok:
         bad += 1
-        print("MISMATCH case %d: N=%d L=%d B=%d off=%d seed=%d dense=%s rs_scale=%s opts=%s modes=%s arena=%d parts=%d records %d/%d" % (case, N, L, B, off, gseed, dense, rs_scale, opts, modes, arena, nparts, st.num_records, nrec), flush=True)
+        print("MISMATCH case %d: N=%d L=%d B=%d off=%d seed=%d dense=%s rs_scale=%s opts=%s modes=%s contigs=%s arena=%d parts=%d records %d/%d" % (case, N, L, B, off, gseed, dense, rs_scale, opts, modes, (len(contigs) if contigs else None), arena, nparts, st.num_records, nrec), flush=True)
 print("fuzz: %d cases, %d mismatches, %.0f s" % (ncases, bad, time.time() - t00))
 sys.exit(1 if bad else 0)
