@@ -1,5 +1,7 @@
 #include "genomicsdb_operators.h"
 
+#include <typeinfo>
+
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -55,8 +57,25 @@ struct VariantQueryProcessor::Engine {
   std::string format;
   bool use_missing = false, header_done = false;
   unsigned max_alt = 0;
-  std::vector<uint8_t> host;      // page -> host bounce
+  // drain: pages are assembled alternately in the pipeline's two arenas; the finished one leaves in chunks over a copy stream
+  // into two pinned buffers while the page behind it is being assembled (the C ABI's ring, at the size this caller needs)
+  static constexpr size_t kChunk = (size_t)64 << 20;
+  hipStream_t copy = nullptr;
+  hipEvent_t chunk_done[2] = {nullptr, nullptr}, arena_read[2] = {nullptr, nullptr};
+  uint8_t* pin[2] = {nullptr, nullptr};
+  size_t pin_cap[2] = {0, 0};
+  int toggle = 0;
+  bool next_valid = false;
+  DevicePipeline::PageTicket next;
+  ~Engine() {
+    if (copy) (void)hipStreamSynchronize(copy);
+    eng.reset();
+    for (int i = 0; i < 2; ++i) { if (chunk_done[i]) (void)hipEventDestroy(chunk_done[i]); if (arena_read[i]) (void)hipEventDestroy(arena_read[i]); if (pin[i]) (void)hipHostFree(pin[i]); }
+    if (copy) (void)hipStreamDestroy(copy);
+  }
 };
+
+#define OPS_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) throw GenomicsDBDeviceException(std::string(#expr) + " failed: " + hipGetErrorString(_e)); } while (0)
 
 VariantQueryProcessor::VariantQueryProcessor(VariantStorageManager* sm, const std::string& array_name, const VidMapper&) : m_storage_manager(sm), m_array_name(array_name) {
   if (!sm) throw VariantOperationException("VariantQueryProcessor needs a VariantStorageManager");
@@ -69,11 +88,15 @@ void VariantQueryProcessor::do_query_bookkeeping(const VariantArraySchema&, Vari
 
 void VariantQueryProcessor::scan_and_operate(const int, const VariantQueryConfig& query_config, SingleVariantOperatorBase& variant_operator, unsigned column_interval_idx,
                                              bool, VariantQueryProcessorScanState* scan_state) const {
-  auto* gvcf = dynamic_cast<BroadCombinedGVCFOperator*>(&variant_operator);
+  // The built-in is recognised by its EXACT type: a class derived from BroadCombinedGVCFOperator may override operate() (or any
+  // of the protected hooks the reference's operator calls per record), and nothing here would ever call it - it is refused like
+  // any other per-record operator instead of silently getting the built-in's semantics.
+  auto* gvcf = typeid(variant_operator) == typeid(BroadCombinedGVCFOperator) ? static_cast<BroadCombinedGVCFOperator*>(&variant_operator) : nullptr;
   auto* batched = dynamic_cast<BatchedVariantOperatorBase*>(&variant_operator);
   if (!gvcf && !batched)
-    throw VariantOperationException("this operator's per-record operate() cannot run on the device path; the built-in BroadCombinedGVCFOperator is recognised, "
-                                    "other operators take pages through BatchedVariantOperatorBase::operate_on_page()");
+    throw VariantOperationException("this operator's per-record operate() cannot run on the device path; the built-in BroadCombinedGVCFOperator (the class itself, not a "
+                                    "class derived from it) is recognised, other operators take pages through BatchedVariantOperatorBase::operate_on_page()");
+  if (batched) gvcf = nullptr;
   const std::string format = gvcf ? gvcf->get_vcf_adapter().get_output_format() : std::string();
   const bool use_missing = gvcf && gvcf->use_missing_values_only_not_vector_end();
   if (!m_engine || m_engine->format != format || m_engine->use_missing != use_missing) {
@@ -85,15 +108,16 @@ void VariantQueryProcessor::scan_and_operate(const int, const VariantQueryConfig
     m_engine->eng.reset(new CombineEngine(query_config, device, format, use_missing, gvcf ? gvcf->get_max_diploid_alt_alleles_that_can_be_genotyped() : 0u));
     m_engine->eng->open_array(m_storage_manager->get_workspace() + "/" + m_array_name);
   }
-  CombineEngine& eng = *m_engine->eng;
+  Engine& E = *m_engine;
+  CombineEngine& eng = *E.eng;
   VariantQueryProcessorScanState local_state;
   VariantQueryProcessorScanState& st = scan_state ? *scan_state : local_state;
-  if (gvcf && !m_engine->header_done) {       // the reference's operator constructor writes the header through its adapter
+  if (gvcf && !E.header_done) {       // the reference's operator constructor writes the header through its adapter
     const HostPlan& hp = eng.plan();
     const auto* ser = dynamic_cast<VCFSerializedBufferAdapter*>(&gvcf->get_vcf_adapter());
     const std::string h = hp.plan.bcf_mode ? hp.bcf_header_bytes(ser ? ser->keep_idx_fields_in_bcf_header() : true) : hp.header_text;
     gvcf->get_vcf_adapter().handoff((const uint8_t*)h.data(), h.size());
-    m_engine->header_done = true;
+    E.header_done = true;
   }
   const VariantQueryConfig& qc = eng.query_config();
   const unsigned nint = std::max(1u, qc.get_num_column_intervals());
@@ -103,10 +127,15 @@ void VariantQueryProcessor::scan_and_operate(const int, const VariantQueryConfig
     st.m_piece_begin = qc.get_num_column_intervals() ? qc.get_column_begin(column_interval_idx) : 0;
     st.m_interval_end = qc.get_num_column_intervals() ? qc.get_column_end(column_interval_idx) : INT64_MAX - 1;
     st.m_piece_active = false;
+    E.next_valid = false;
   }
   const uint64_t page_bytes = gvcf && dynamic_cast<VCFSerializedBufferAdapter*>(&gvcf->get_vcf_adapter()) ? std::max<uint64_t>(1, query_config.get_combined_vcf_records_buffer_size_limit())
                                                                                                           : (uint64_t)256 << 20;
   DevicePipeline& pipe = eng.pipeline();
+  if (!E.copy) {
+    OPS_HIP(hipStreamCreateWithFlags(&E.copy, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) { OPS_HIP(hipEventCreateWithFlags(&E.chunk_done[i], hipEventDisableTiming)); OPS_HIP(hipEventCreateWithFlags(&E.arena_read[i], hipEventDisableTiming)); }
+  }
   for (;;) {
     if (!st.m_piece_active) {
       if (st.m_piece_begin > st.m_interval_end) { st.m_done = true; return; }
@@ -117,16 +146,46 @@ void VariantQueryProcessor::scan_and_operate(const int, const VariantQueryConfig
       pipe.prepare_interval(st.m_piece_begin, pe);
       st.m_piece_begin = pe + 1;             // (the piece in flight is remembered by the pipeline)
       st.m_piece_active = true;
+      E.next_valid = false;
     }
-    const char* dev = nullptr;
-    uint64_t nb = 0;
-    if (!pipe.next_page(page_bytes, &dev, &nb)) { st.m_piece_active = false; continue; }
-    if (batched) batched->operate_on_page(dev, nb, qc.get_num_column_intervals() ? qc.get_column_begin(column_interval_idx) : 0, st.m_interval_end);
+    DevicePipeline::PageTicket page;
+    if (E.next_valid) { page = E.next; E.next_valid = false; }
+    else if (pipe.begin_page(page_bytes, E.toggle, &page)) E.toggle ^= 1;
+    else { st.m_piece_active = false; continue; }
+    pipe.finish_page(page);
+    // the page behind it is assembled in the other arena while this one is handed over
+    if (pipe.begin_page(page_bytes, E.toggle, &E.next)) { E.toggle ^= 1; E.next_valid = true; }
+    else st.m_piece_active = false;          // the piece is exhausted; the page in hand is its last
+    if (batched) batched->operate_on_page(page.dev, page.nbytes, qc.get_num_column_intervals() ? qc.get_column_begin(column_interval_idx) : 0, st.m_interval_end);
     else {
-      m_engine->host.resize((size_t)nb);
-      if (nb && hipMemcpy(m_engine->host.data(), dev, (size_t)nb, hipMemcpyDeviceToHost) != hipSuccess) throw GenomicsDBDeviceException("page copy to host failed");
-      gvcf->get_vcf_adapter().handoff(m_engine->host.data(), (size_t)nb);
-      if (gvcf->overflow()) return;          // the caller drains the buffer and comes back (scan state: not at the end)
+      // device -> pinned host in chunks on the copy stream, two buffers: chunk k + 1 is in flight while chunk k is handed off
+      const uint64_t nb = page.nbytes;
+      int k = 0;
+      uint64_t prev_len = 0;
+      for (uint64_t off = 0; off < nb; off += Engine::kChunk, ++k) {
+        const int slot = k & 1;
+        const size_t len = (size_t)std::min<uint64_t>(Engine::kChunk, nb - off);
+        if (E.pin_cap[slot] < len) {
+          if (E.pin[slot]) OPS_HIP(hipHostFree(E.pin[slot]));
+          E.pin[slot] = nullptr; E.pin_cap[slot] = 0;
+          const size_t want = std::min(Engine::kChunk, std::max<size_t>(len, (size_t)1 << 20));
+          OPS_HIP(hipHostMalloc((void**)&E.pin[slot], want, hipHostMallocDefault));
+          E.pin_cap[slot] = want;
+        }
+        OPS_HIP(hipMemcpyAsync(E.pin[slot], page.dev + off, len, hipMemcpyDeviceToHost, E.copy));
+        OPS_HIP(hipEventRecord(E.chunk_done[slot], E.copy));
+        if (k > 0) { OPS_HIP(hipEventSynchronize(E.chunk_done[slot ^ 1])); gvcf->get_vcf_adapter().handoff(E.pin[slot ^ 1], (size_t)prev_len); }
+        prev_len = len;
+      }
+      if (k > 0) {
+        OPS_HIP(hipEventRecord(E.arena_read[page.arena & 1], E.copy));      // the arena may be written again once the last chunk has left
+        pipe.set_arena_release_event(page.arena, E.arena_read[page.arena & 1]);
+        OPS_HIP(hipEventSynchronize(E.chunk_done[(k - 1) & 1]));
+        gvcf->get_vcf_adapter().handoff(E.pin[(k - 1) & 1], (size_t)prev_len);
+      }
+      // The reference's scan pauses on overflow() only when the caller passed a scan state to come back with (query_variants.cc:
+      // 453-468); without one there is nowhere to resume from, so the interval runs to its end.
+      if (scan_state && gvcf->overflow()) return;
     }
   }
 }

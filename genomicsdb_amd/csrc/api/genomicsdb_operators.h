@@ -182,6 +182,8 @@ using genomicsdb_amd::GenomicsDBBCFGenerator;
 using genomicsdb_amd::GenomicsDBImportConfig;
 using genomicsdb_amd::RWBuffer;
 using genomicsdb_amd::SingleVariantOperatorBase;
+using genomicsdb_amd::Variant;
+using genomicsdb_amd::VariantArraySchema;
 using genomicsdb_amd::VariantOperationException;
 using genomicsdb_amd::VariantQueryConfig;
 using genomicsdb_amd::VariantQueryProcessor;

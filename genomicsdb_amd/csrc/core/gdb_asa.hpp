@@ -82,13 +82,41 @@ GDB_HD void asa_entry(const AsaCall& a, int j, bool allele_dep, bool alt_only, c
 template <class Sink> GDB_HD void put_fixed3(Sink& s, float f, uint32_t* err) {
   const uint32_t u = gdb_f2u(f);
   const uint32_t ex = (u >> 23) & 0xFFu, mant = u & 0x7FFFFFu;
-  if (ex == 0xFFu) { *err |= GDB_ERR_FLOAT_RANGE; return; }
+  if (ex == 0xFFu) {                             // what the reference's stream (std::fixed on a double) prints: [-]inf / [-]nan
+    if (u >> 31) s.put('-');
+    if (mant) { s.put('n'); s.put('a'); s.put('n'); } else { s.put('i'); s.put('n'); s.put('f'); }
+    return;
+  }
   const uint64_t m = ex ? (uint64_t)(mant | 0x800000u) : (uint64_t)mant;
   const int e = ex ? (int)ex - 150 : -149;
   const uint64_t M = m * 1000u;                  // < 2^34
   uint64_t N;
   if (e >= 0) {
-    if (e > 29) { *err |= GDB_ERR_FLOAT_RANGE; return; }
+    if (e > 29) {
+      // an integer of up to 128 bits (m * 2^e, e <= 104): its exact decimal digits, then ".000".  Five 32-bit limbs, divided by
+      // 10^9 until nothing is left (a float sum that overflowed the 53-bit range prints like this in the reference too)
+      uint32_t limb[5] = {0, 0, 0, 0, 0};
+      {
+        const int word = e >> 5, bit = e & 31;
+        const uint64_t lo = m << bit;            // m < 2^24: fits 56 bits
+        limb[word] = (uint32_t)lo;
+        if (word + 1 < 5) limb[word + 1] = (uint32_t)(lo >> 32);
+      }
+      uint32_t chunk[5];
+      int nchunk = 0;
+      for (;;) {
+        uint64_t rem = 0;
+        bool any = false;
+        for (int i = 4; i >= 0; --i) { const uint64_t cur = (rem << 32) | limb[i]; limb[i] = (uint32_t)(cur / 1000000000u); rem = cur % 1000000000u; any |= limb[i] != 0; }
+        chunk[nchunk++] = (uint32_t)rem;
+        if (!any) break;
+      }
+      if (u >> 31) s.put('-');
+      put_i64(s, (int64_t)chunk[nchunk - 1]);
+      for (int c = nchunk - 2; c >= 0; --c) { uint32_t d = 100000000u, v = chunk[c]; for (int k = 0; k < 9; ++k) { s.put((char)('0' + v / d)); v %= d; d /= 10u; } }
+      s.put('.'); s.put('0'); s.put('0'); s.put('0');
+      return;
+    }
     N = M << e;
   } else {
     const int sh = -e;

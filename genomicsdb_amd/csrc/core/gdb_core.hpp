@@ -518,6 +518,66 @@ GDB_HD float gdb_nth_element_libstdcxx(float* a, int64_t n, int64_t nth) {
   for (int64_t m = n; m > 1; m >>= 1) ++depth;     // std::__lg(n) * 2
   return gdb_introselect_libstdcxx(a, n, nth, 2 * depth);
 }
+// ---- FILTER union: the iteration order of libstdc++'s std::unordered_set<int> ------------------------------------------------------
+// The reference unites the FILTER ids of the live calls in a std::unordered_set<int> (one RANGE insert per call) and writes them
+// in the set's iteration order (broad_combined_gvcf.cc:846-874), so the order of several different ids in a record is a property
+// of the C++ library - like the tied medians above.  Restated here for libstdc++ (GCC 11, hashtable_policy.h / hashtable.h /
+// hashtable_c++0x.cc), checked insertion-sequence-for-insertion-sequence against the library on the host
+// (tests/hostsim: hostsim_uset_order, tests/test_filter_union_order.py):
+//   * std::hash<int> is the identity, bucket = (size_t)key % bucket_count;
+//   * the elements form one singly linked list in which the elements of a bucket are adjacent; a new element goes IN FRONT of
+//     its bucket's first element, or to the head of the whole list when its bucket is empty (_M_insert_bucket_begin);
+//   * a rehash re-inserts the elements in list order by the same rule (_M_rehash_aux, unique keys);
+//   * bucket counts come from _Prime_rehash_policy (max load factor 1): _M_need_rehash(n_bkt, n_elt, 1) per new element,
+//     "start with 11" when nothing is allocated, growth factor 2, _M_next_bkt = small table below 14, else the next prime.
+struct GdbUSetOrder {
+  int32_t key[GDB_MAX_FILTER_IDS];   // list order = iteration order
+  int32_t n, nbkt;
+  uint64_t next_resize;
+  bool overflow;
+};
+GDB_HD void gdb_uset_init(GdbUSetOrder& s) { s.n = 0; s.nbkt = 1; s.next_resize = 0; s.overflow = false; }
+GDB_HD uint64_t gdb_uset_next_bkt(GdbUSetOrder& s, uint64_t n) {
+  const unsigned char fast[14] = {2, 2, 2, 3, 5, 5, 7, 7, 11, 11, 11, 11, 13, 13};
+  if (n < 14) { if (n == 0) return 1; s.next_resize = fast[n]; return fast[n]; }
+  const uint16_t primes[] = {17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 67, 71, 73, 79, 83, 89, 97, 103, 109, 113, 127, 137, 139, 149, 157, 167, 179, 193, 199,
+                             211, 227, 241, 257, 277, 281, 283, 293, 307, 311, 313, 337, 347, 353, 359, 379, 389, 401, 409, 419, 431, 433, 449, 457, 461, 463, 467, 479, 487, 491, 499,
+                             503, 509, 521, 523, 541};
+  for (unsigned i = 0; i < sizeof(primes) / sizeof(primes[0]); ++i) if (primes[i] >= n) { s.next_resize = primes[i]; return primes[i]; }
+  s.overflow = true;             // a range hint beyond anything a FILTER vector can have
+  return n;
+}
+GDB_HD void gdb_uset_place(int32_t* list, int n, int32_t key, uint64_t nbkt) {   // n elements in list; key is not among them
+  const uint64_t b = (uint64_t)(int64_t)key % nbkt;
+  int at = 0;
+  for (int i = 0; i < n; ++i) if ((uint64_t)(int64_t)list[i] % nbkt == b) { at = i; break; }
+  for (int j = n; j > at; --j) list[j] = list[j - 1];
+  list[at] = key;
+}
+GDB_HD void gdb_uset_insert_range(GdbUSetOrder& s, const int32_t* p, int count) {
+  const uint64_t hint = 1;       // (GCC 11: a range insert into a container with unique keys is a loop of single inserts, hashtable_policy.h:900-906)
+  for (int i = 0; i < count; ++i) {
+    const int32_t k = p[i];
+    bool found = false;
+    for (int j = 0; j < s.n; ++j) found |= s.key[j] == k;
+    if (found) continue;
+    if (s.n >= GDB_MAX_FILTER_IDS) { s.overflow = true; return; }
+    if ((uint64_t)s.n + hint > s.next_resize) {     // _M_need_rehash
+      const uint64_t want = (uint64_t)s.n + hint;
+      const uint64_t min_bkts = s.next_resize ? want : (want > 11 ? want : 11);
+      if (min_bkts >= (uint64_t)s.nbkt) {
+        const uint64_t nb = gdb_uset_next_bkt(s, (min_bkts + 1 > (uint64_t)s.nbkt * 2) ? min_bkts + 1 : (uint64_t)s.nbkt * 2);
+        int32_t old[GDB_MAX_FILTER_IDS];
+        for (int j = 0; j < s.n; ++j) old[j] = s.key[j];
+        for (int j = 0; j < s.n; ++j) gdb_uset_place(s.key, j, old[j], nb);
+        s.nbkt = (int32_t)nb;
+      } else s.next_resize = (uint64_t)s.nbkt;
+    }
+    gdb_uset_place(s.key, s.n, k, (uint64_t)s.nbkt);
+    ++s.n;
+  }
+}
+
 // scratch of the (rare) tied-zero medians: reduce_scalar takes n_valid floats per use; capacity = passes x float median
 // fields x heavy incidences, so it cannot run out
 struct TieScratch {
@@ -809,6 +869,21 @@ template <class Sink> GDB_HD void bcf_enc_vint(Sink& s, const int32_t* a, int n)
   const int t = bcf_int_type(mn, mx);
   bcf_enc_size(s, n, t);
   for (int i = 0; i < n; ++i) bcf_put_int(s, a[i], t);
+}
+
+// the record's FILTER ids in the order the reference writes them: one range insert per live call with a valid FILTER field, in
+// call order (broad_combined_gvcf.cc:852-861)
+template <class Ctx>
+GDB_HD_NOINLINE void filter_union_order(const Ctx& cx, int64_t hb, int64_t he, GdbUSetOrder& us, uint32_t* err) {
+  gdb_uset_init(us);
+  for (int64_t t = hb; t < he; ++t) {
+    const int64_t c = cx.hl.cell[t];
+    if (!field_valid(cx.cm, c, cx.pl.f_FILTER)) continue;
+    int n;
+    const int32_t* p = cell_field<int32_t>(cx.fr, cx.pl, cx.pl.f_FILTER, c, n);
+    gdb_uset_insert_range(us, p, n);
+  }
+  if (us.overflow) *err |= GDB_ERR_TOO_MANY_FILTER_IDS;
 }
 
 GDB_HD int find_contig(const QueryWindow& qw, int64_t pos) {  // VidMapper::get_contig_location
@@ -1186,9 +1261,21 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
           const int32_t* p = cell_field<int32_t>(cx.fr, pl, pl.f_FILTER, c, n);
           for (int i = 0; i < n; ++i) { if (first_id < 0) first_id = p[i]; else if (p[i] != first_id) multi = true; }
         }
-      if (multi) *err |= GDB_ERR_INTERNAL;
-      const int32_t hid = (first_id >= 0 && first_id < cx.names.n_filter_names) ? cx.names.filter_bcf_id[first_id] : -1;
-      if (hid >= 0) bcf_enc_int1(sink, hid); else sink.put((char)0);
+      if (multi) {   // typed vector of the header ids in the set's order (bcf_update_filter -> bcf_enc_vint)
+        GdbUSetOrder us;
+        filter_union_order(cx, hb, he, us, err);
+        int32_t hids[GDB_MAX_FILTER_IDS];
+        int nh = 0;
+        for (int i = 0; i < us.n; ++i) {
+          const int32_t id = us.key[i];
+          const int32_t hid = (id >= 0 && id < cx.names.n_filter_names) ? cx.names.filter_bcf_id[id] : -1;
+          if (hid >= 0) hids[nh++] = hid;
+        }
+        bcf_enc_vint(sink, hids, nh);
+      } else {
+        const int32_t hid = (first_id >= 0 && first_id < cx.names.n_filter_names) ? cx.names.filter_bcf_id[first_id] : -1;
+        if (hid >= 0) bcf_enc_int1(sink, hid); else sink.put((char)0);
+      }
     }
     // INFO: END, reducers in query order, DP
     uint32_t n_info = 0;
@@ -1285,7 +1372,7 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
     } else sink.put('.');
   }
   sink.put('\t');
-  // FILTER (union over live calls; only single-id unions are order-pinned)
+  // FILTER (union over live calls, in the iteration order of the reference's std::unordered_set<int>)
   {
     int first_id = -1;
     bool multi = false;
@@ -1298,8 +1385,19 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
         const int32_t* p = cell_field<int32_t>(cx.fr, pl, pl.f_FILTER, c, n);
         for (int i = 0; i < n; ++i) { if (first_id < 0) first_id = p[i]; else if (p[i] != first_id) multi = true; }
       }
-    if (multi) *err |= GDB_ERR_INTERNAL;
-    if (first_id >= 0 && first_id < cx.names.n_filter_names && cx.names.filter_name_len[first_id] > 0)
+    if (multi) {     // several different ids: the order is the library's (gdb_uset_insert_range); rare, so a pass of its own
+      GdbUSetOrder us;
+      filter_union_order(cx, hb, he, us, err);
+      bool any = false;
+      for (int i = 0; i < us.n; ++i) {
+        const int32_t id = us.key[i];
+        if (!(id >= 0 && id < cx.names.n_filter_names && cx.names.filter_name_len[id] > 0)) continue;   // ids without a header line are dropped
+        if (any) sink.put(';');
+        sink.write(cx.names.text + cx.names.filter_name_off[id], cx.names.filter_name_len[id]);
+        any = true;
+      }
+      if (!any) sink.put('.');
+    } else if (first_id >= 0 && first_id < cx.names.n_filter_names && cx.names.filter_name_len[first_id] > 0)
       sink.write(cx.names.text + cx.names.filter_name_off[first_id], cx.names.filter_name_len[first_id]);
     else sink.put('.');
   }

@@ -25,10 +25,11 @@
 #define GDB_MAX_INFO_FIELDS 24
 #define GDB_MAX_FORMAT_FIELDS 24
 #define GDB_MAX_MERGED_ALLELES 128  // per record (REF included)
-#define GDB_MAX_INPUT_ALLELES 32    // per cell (REF included)
+#define GDB_MAX_INPUT_ALLELES 64    // per cell (REF included)
 #define GDB_MAX_PLOIDY 8            // general-ploidy genotype enumeration (G-length fields, min-PL genotype)
 #define GDB_MAX_INFO_VECTOR 64       // elements of an element_wise_sum INFO vector
 #define GDB_MAX_ID_TOKENS 16        // distinct ';'-separated ID tokens per output record
+#define GDB_MAX_FILTER_IDS 16       // distinct FILTER ids united in one output record
 #define GDB_MAX_HISTOGRAM_FIELDS 8  // composite (bins, counts) INFO fields reduced with histogram_sum
 
 // htslib / TileDB sentinels (reference include/vcf/vcf.h:59-218)
@@ -58,7 +59,8 @@ enum GdbErr {
   GDB_ERR_INTERNAL = 1u << 6,
   GDB_ERR_TOO_MANY_ID_TOKENS = 1u << 7,               // more than GDB_MAX_ID_TOKENS distinct ID tokens in one record
   GDB_ERR_INFO_VECTOR_TOO_LONG = 1u << 8,             // element_wise_sum over more than GDB_MAX_INFO_VECTOR elements
-  GDB_ERR_CELL_STREAM = 1u << 9                       // malformed / unsorted binary cell stream at staging
+  GDB_ERR_CELL_STREAM = 1u << 9,                      // malformed / unsorted binary cell stream at staging
+  GDB_ERR_TOO_MANY_FILTER_IDS = 1u << 10              // more than GDB_MAX_FILTER_IDS distinct FILTER ids in one record
 };
 
 struct GdbFieldDesc {

@@ -73,13 +73,25 @@ void GenomicsDBImportConfig::read_from_json(const mini_json::Value& j, int rank)
     std::string ws = m_workspaces.size() == 1 ? m_workspaces[0] : "", an = m_array_names.size() == 1 ? m_array_names[0] : "";
     bool per_part_ws = false, per_part_an = false;
     std::vector<std::string> wsv(cp.Size(), ws), anv(cp.Size(), an);
+    // a TileDB column, or a contig position { "chr1" : 5 } / { "chr1" : [5, 6] } (1-based; json_config.cc:359-375), for which
+    // the vid mapping the loader JSON names is read (once)
+    VidMapper vid;
+    auto contig_column = [&](const mini_json::Value& o) {
+      if (!o.IsObject()) throw GenomicsDBConfigException("column partition bound must be a TileDB column or { contig : position }");
+      if (!vid.is_initialized()) {
+        if (!m_vid_mapping_file.empty()) vid.parse_vid_json(mini_json::parse_file(m_vid_mapping_file));
+        else if (j.HasMember("vid_mapping")) vid.parse_vid_json(j["vid_mapping"]);
+        else throw GenomicsDBConfigException("contig-style column partition bounds need \"vid_mapping_file\" (or \"vid_mapping\") in the loader JSON");
+      }
+      return interval_from_object(o, vid).first;
+    };
     for (size_t i = 0; i < cp.Size(); ++i) {
       const auto& d = cp[i];
       ColumnRange r(0, INT64_MAX - 1);
       if (!d.HasMember("begin")) throw GenomicsDBConfigException("column partition without \"begin\"");
       if (d["begin"].IsInt64()) r.first = d["begin"].GetInt64();
-      else throw GenomicsDBConfigException("contig-style partition begins need the vid mapping; use TileDB columns");
-      if (d.HasMember("end") && d["end"].IsInt64()) r.second = d["end"].GetInt64();
+      else r.first = contig_column(d["begin"]);
+      if (d.HasMember("end")) r.second = d["end"].IsInt64() ? d["end"].GetInt64() : contig_column(d["end"]);
       if (r.first > r.second) std::swap(r.first, r.second);
       m_column_partitions.push_back(r);
       if (d.HasMember("workspace")) { wsv[i] = d["workspace"].GetString(); per_part_ws = true; }

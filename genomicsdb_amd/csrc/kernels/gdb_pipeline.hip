@@ -31,6 +31,21 @@
 
 namespace genomicsdb_amd {
 
+// error bits (GdbErr, core/gdb_types.h) spelled out for the exception text
+static std::string err_bits_text(uint32_t bits) {
+  static const char* names[] = {"an interval is overlapped by one of the same sample that is neither a reference block nor a deletion",
+                                "more than GDB_MAX_MERGED_ALLELES alleles in one record", "more than GDB_MAX_INPUT_ALLELES alleles in one cell",
+                                "ploidy above GDB_MAX_PLOIDY", "a float outside the range whose text is pinned", "page arena overflow", "internal inconsistency",
+                                "more than GDB_MAX_ID_TOKENS distinct ID tokens in one record", "an element_wise_sum INFO vector longer than GDB_MAX_INFO_VECTOR",
+                                "malformed or unsorted cell stream", "more than GDB_MAX_FILTER_IDS distinct FILTER ids in one record"};
+  std::string out = "device error bits " + std::to_string(bits) + " (";
+  bool first = true;
+  for (unsigned b = 0; b < 32; ++b)
+    if (bits & (1u << b)) { if (!first) out += "; "; first = false; out += b < sizeof(names) / sizeof(names[0]) ? names[b] : "unknown"; }
+  return out + "; limits: include/genomicsdb_amd.h, GdbErr: core/gdb_types.h)";
+}
+
+
 #define HIP_CHECK(expr)                                                                                            \
   do {                                                                                                             \
     hipError_t _e = (expr);                                                                                        \
@@ -496,8 +511,11 @@ __global__ void __launch_bounds__(kBlock) k_site_huge(const SiteCtx* __restrict_
       if (fa.i > 63u) s_flags[1] = 1;                          // more tokens than the position key holds: serial walk
     }
     __syncthreads();
+    // a record that goes back to the serial walk (table overflow, a call with more tokens than the position key holds) takes no
+    // further part: its table is not trustworthy, the passes below would read merged[] entries nobody wrote (uniform per record)
+    const bool skip_a = (s_flags[0] | s_flags[1]) != 0;
     // ---- merged order = ascending first position; representatives -----------------------------------------------------------------
-    for (int s = tid; s < kHugeTable; s += kBlock) {
+    for (int s = tid; s < kHugeTable && !skip_a; s += kBlock) {
       if (tab_hash[s] == kHugeEmpty) continue;
       const uint32_t mine = tab_order[s];
       int rank = 0;
@@ -513,8 +531,9 @@ __global__ void __launch_bounds__(kBlock) k_site_huge(const SiteCtx* __restrict_
     __syncthreads();
     const int nmerged = min(1 + s_nocc, GDB_MAX_MERGED_ALLELES - 1);
     const int num_merged = nmerged + (cx.pc.nr_cnt[k] > 0 ? 1 : 0);
+    const bool skip_b = (s_flags[0] | s_flags[1]) != 0;        // (read behind the barrier: uniform)
     // ---- pass C: LUTs, flags, min-PL genotypes; <NON_REF> last -----------------------------------------------------------------------
-    for (int64_t t = hb + tid; t < he; t += kBlock) {
+    for (int64_t t = hb + tid; t < he && !skip_b; t += kBlock) {
       HugeLookup fc{tb, o.merged, mref, mref_len, &s_flags[1]};
       site_merge_call(cx, t, s_k, mref, mref_len, true, fc, &e);
       const int64_t c = cx.hl.cell[t];
@@ -555,7 +574,7 @@ __global__ void __launch_bounds__(kBlock) k_site_huge(const SiteCtx* __restrict_
       o.mref = mref; o.mref_len = mref_len; o.nmerged = nmerged;
       o.filter_first_id = (do_filter && s_filter != ~0ull) ? (int32_t)(uint32_t)s_filter : -1;
       o.filter_multi = s_flags[2]; o.any_id = s_flags[3];
-      o.fallback = (s_flags[0] || s_flags[1]) ? 1 : 0;
+      o.fallback = (s_flags[0] || s_flags[1] || s_flags[2]) ? 1 : 0;   // several different FILTER ids: their order needs the calls in sequence (filter_union_order)
     }
     // ---- scalar reducers over the gathered per-call values (ScalarPre) ---------------------------------------------------------------
     if (cx.pre.enabled)
@@ -3360,7 +3379,11 @@ FragmentFileMeta DevicePipeline::open_fragment_file(const std::string& path, con
   if (version != 2 && version != 3) fail("unsupported fragment file version");
   ff->compressed = version == 3;
   if (nfields == 0 || nfields > 4096) fail("implausible number of fields");
-  if (C < 0 || M < 0 || (uint64_t)C > ff->file_size / 20 + 1 || (uint64_t)M > ff->file_size / 8 + 1) fail("implausible cell / marker count");
+  // a raw file stores 20 bytes of coordinates per cell and 8 per marker; a compressed one (version 3) may store up to DEFLATE's
+  // maximum ratio (1032 : 1) less - regular data does get well below 20 stored bytes per cell; truncation is caught section by
+  // section through the tile index below
+  const uint64_t ratio = ff->compressed ? 1032 : 1;
+  if (C < 0 || M < 0 || (uint64_t)C / ratio > ff->file_size / 20 + 1 || (uint64_t)M / ratio > ff->file_size / 8 + 1) fail("implausible cell / marker count");
   if (num_rows != S.hp.plan.num_query_rows) fail("fragment file was written for another set of query rows");
   if (expected_schema_hash && meta.schema_hash != expected_schema_hash) fail("fragment file was written under another vid / callset mapping (stale)");
   struct FileField { FragFieldHdr h; std::string name; };
@@ -3471,6 +3494,12 @@ DevicePipeline::FragmentWindow DevicePipeline::append_fragment_cells(int64_t c0,
   Impl::Part part;
   memset(&part.v, 0, sizeof(part.v));
   part.v.ncells = n;
+  // every way out of this function other than the push at its end (corrupt offsets, a corrupt tile index, a read beyond a section,
+  // a failing HIP call) gives the part's device buffers back: a damaged file must not cost HBM for the life of the process
+  struct PartGuard {
+    Impl::Part& p; bool keep = false;
+    ~PartGuard() { if (!keep) { for (void* b : p.bufs) (void)hipFree(b); p.bufs.clear(); } }
+  } guard{part};
   auto alloc = [&](size_t bytes) -> void* { void* d = nullptr; HIP_CHECK(hipMalloc(&d, std::max<size_t>(bytes, 16))); part.bufs.push_back(d); return d; };
   void* row = alloc((size_t)n * 4); void* begin = alloc((size_t)n * 8); void* end = alloc((size_t)n * 8);
   part.v.row = (const int32_t*)row; part.v.begin = (const int64_t*)begin; part.v.end = (const int64_t*)end;
@@ -3520,7 +3549,6 @@ DevicePipeline::FragmentWindow DevicePipeline::append_fragment_cells(int64_t c0,
     for (auto& c : copies) HIP_CHECK(hipMemcpyAsync(c.dev, S.inflate_out.p + c.from, c.bytes, hipMemcpyDeviceToDevice, st));
     HIP_CHECK(hipStreamSynchronize(st));                          // (the host vectors above are read by the copies)
     if (S.read_back(S.err.p) != 0u) {
-      for (void* b : part.bufs) (void)hipFree(b);
       throw std::runtime_error(F.path + ": a compressed tile does not inflate to its size (corrupt file)");
     }
   };
@@ -3574,10 +3602,10 @@ DevicePipeline::FragmentWindow DevicePipeline::append_fragment_cells(int64_t c0,
   }
   HIP_CHECK(hipStreamSynchronize(st));
   if (S.read_back(S.err.p) != 0u) {
-    for (void* b : part.bufs) (void)hipFree(b);
     throw std::runtime_error(F.path + ": the columns of the fragment file are damaged (cells out of order, rows outside the query's rows or offsets that do not match the data)");
   }
   S.parts.push_back(part);
+  guard.keep = true;
   return w;
 }
 
@@ -3716,7 +3744,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   stats.num_records = P;
   if (P == 0) {
     stats.err_bits = S.read_back(S.err.p);
-    if (stats.err_bits) throw GenomicsDBDeviceException("device error bits " + std::to_string(stats.err_bits));
+    if (stats.err_bits) throw GenomicsDBDeviceException(err_bits_text(stats.err_bits));
     return;
   }
   if (P >= (1ll << 31)) throw GenomicsDBDeviceException("more than 2^31 records in one interval: split the query interval");
@@ -4041,7 +4069,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   HIP_CHECK(hipEventElapsedTime(&stats.ms_sweep, ev[0], ev[1]));
   HIP_CHECK(hipEventElapsedTime(&stats.ms_site, ev[1], ev[2]));
   HIP_CHECK(hipEventElapsedTime(&stats.ms_size, ev[2], ev[3]));
-  if (eb) throw GenomicsDBDeviceException("device error bits " + std::to_string(eb) + " (see GdbErr in gdb_types.h)");
+  if (eb) throw GenomicsDBDeviceException(err_bits_text(eb));
   S.iv.max_record_bytes = totals[1];
   S.iv.P = P; S.iv.nchunks = nchunks; S.iv.kp = 0;
   S.iv.sx = sx; S.iv.ex = ex; S.iv.ri = ri; S.iv.so = so; S.iv.rec = rec; S.iv.ac = ac; S.iv.resolved_whole = resolved_whole;
@@ -4182,7 +4210,7 @@ void DevicePipeline::finish_page(const PageTicket& ticket) {
   iv.stats.ms_write_kernel_avg = iv.write_kernel_ms / iv.stats.write_launches;
   iv.stats.pages++;
   iv.stats.ms_total = iv.stats.ms_sweep + iv.stats.ms_site + iv.stats.ms_size + iv.stats.ms_write;
-  if (iv.stats.err_bits) throw GenomicsDBDeviceException("device error bits " + std::to_string(iv.stats.err_bits) + " (see GdbErr in gdb_types.h)");
+  if (iv.stats.err_bits) throw GenomicsDBDeviceException(err_bits_text(iv.stats.err_bits));
 }
 
 void DevicePipeline::set_arena_release_event(int arena_idx, void* hip_event) { m_->arena_release[arena_idx & 1] = (hipEvent_t)hip_event; }

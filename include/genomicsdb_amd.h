@@ -18,6 +18,22 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* ---- limits of this build that the reference does not have ------------------------------------------------------------
+ * The reference's per-record tables resize (include/utils/lut.h:65-343); the device's are fixed (core/gdb_types.h, the
+ * values below mirror it and tests/test_capi_cpu.py checks that they agree).  A query that needs more is refused when its
+ * plan is built (GenomicsDBException naming the limit) or, for data-dependent limits, ends with an error that spells the
+ * limit out ("device error bits ...") - never with truncated output. */
+#define GDBAMD_MAX_QUERIED_FIELDS 48        /* attributes of one query (plan time) */
+#define GDBAMD_MAX_INFO_FIELDS 24           /* ... of which INFO */
+#define GDBAMD_MAX_FORMAT_FIELDS 24         /* ... of which FORMAT */
+#define GDBAMD_MAX_MERGED_ALLELES 128       /* alleles of one output record, REF and <NON_REF> included (data) */
+#define GDBAMD_MAX_INPUT_ALLELES 64         /* alleles of one input cell, REF included (data) */
+#define GDBAMD_MAX_PLOIDY 8                 /* general-ploidy genotype enumeration for G-length fields (data) */
+#define GDBAMD_MAX_INFO_VECTOR 64           /* elements of an element_wise_sum INFO vector (data) */
+#define GDBAMD_MAX_ID_TOKENS 16             /* distinct ';'-separated ID tokens united in one record (data) */
+#define GDBAMD_MAX_FILTER_IDS 16            /* distinct FILTER ids united in one record (data) */
+#define GDBAMD_MAX_HISTOGRAM_FIELDS 8       /* (bins, counts) INFO fields reduced with histogram_sum (plan time) */
+
 #ifdef __cplusplus
 extern "C" {
 #endif

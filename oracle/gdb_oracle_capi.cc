@@ -126,6 +126,39 @@ int oracle_run_query_synthetic_reference(const char* query_json_text, const uint
 
 void oracle_free(char* p) { free(p); }
 
+// ---- common-mode check of the two utilities the oracle shares with the product (csrc/common/mini_json.hpp, gz_text.hpp): the
+// tests compare them with Python's json / gzip modules on every fixture file (tests/test_common_utils.py) ----------------------
+static void json_dump(const mini_json::Value& v, std::string& o) {
+  using V = mini_json::Value;
+  char buf[64];
+  switch (v.type) {
+    case V::Null: o += "n"; break;
+    case V::Bool: o += v.b ? "t" : "f"; break;
+    case V::Int: snprintf(buf, sizeof buf, "i%lld", (long long)v.i); o += buf; break;
+    case V::Double: snprintf(buf, sizeof buf, "d%.17g", v.d); o += buf; break;
+    case V::String: o += "s"; for (unsigned char c : v.s) { snprintf(buf, sizeof buf, "%02x", c); o += buf; } break;
+    case V::Array: o += "["; for (auto& e : v.arr) { json_dump(e, o); o += ","; } o += "]"; break;
+    case V::Object: o += "{"; for (auto& kv : v.obj) { for (unsigned char c : kv.first) { snprintf(buf, sizeof buf, "%02x", c); o += buf; } o += ":"; json_dump(kv.second, o); o += ","; } o += "}"; break;
+  }
+}
+// canonical dump of the parsed document (members in document order); *out malloc'ed
+int oracle_json_dump(const char* text, char** out, uint64_t* out_len, char* err, uint64_t errlen) {
+  try {
+    std::string o;
+    json_dump(mini_json::parse(text), o);
+    *out = (char*)malloc(o.size() + 1); memcpy(*out, o.data(), o.size()); (*out)[o.size()] = 0; *out_len = o.size();
+    return 0;
+  } catch (const std::exception& e) { if (err && errlen) snprintf(err, errlen, "%s", e.what()); return 1; }
+}
+// the bytes gz_text::read_all gives for a (possibly gzip / BGZF compressed) file
+int oracle_gz_read_all(const char* path, char** out, uint64_t* out_len, char* err, uint64_t errlen) {
+  try {
+    std::string o = gz_text::read_all(path);
+    *out = (char*)malloc(o.size() + 1); memcpy(*out, o.data(), o.size()); (*out)[o.size()] = 0; *out_len = o.size();
+    return 0;
+  } catch (const std::exception& e) { if (err && errlen) snprintf(err, errlen, "%s", e.what()); return 1; }
+}
+
 // format_float exposed for the float-format unit tests
 int oracle_format_float(float v, char* buf, uint64_t buflen) {
   std::string s;

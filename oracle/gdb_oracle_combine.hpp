@@ -470,7 +470,7 @@ class BroadCombinedGVCFOperator : public SingleVariantOperatorBase {
     for (auto& a : remapped_variant_.common_fields[1].alt) rec_.alleles.push_back(IS_NON_REF_ALLELE(a) ? g_vcf_NON_REF : a);
     if (qc.produce_FILTER_field && qc.is_defined_query_idx_for_known_field_enum(GVCF_FILTER_IDX)) {
       unsigned fq = qc.get_query_idx_for_known_field_enum(GVCF_FILTER_IDX);
-      std::unordered_set<int> filter_idx_set;  // iteration order = libstdc++ unordered_set (only 1-element sets are pinned)
+      std::unordered_set<int> filter_idx_set;  // iteration order = libstdc++'s (the product restates it: gdb_core.hpp gdb_uset_insert_range)
       for (auto& call : variant.calls) {
         if (!call.is_valid) continue;
         const Field& f = call.fields[fq];

@@ -44,7 +44,33 @@ class CountingOperator : public BatchedVariantOperatorBase {
   uint64_t bytes = 0; int pages = 0;
 };
 
+// a class derived from the built-in with its own per-record operate(): must be refused too (nothing would ever call it)
+class MyDerivedGVCFOperator : public BroadCombinedGVCFOperator {
+ public:
+  using BroadCombinedGVCFOperator::BroadCombinedGVCFOperator;
+  void operate(Variant&, const VariantQueryConfig&) override { ++calls; }
+  int calls = 0;
+};
+
 int main(int argc, char** argv) {
+  if (argc >= 3 && std::string(argv[1]) == "--operator-selftest") {
+    // host only (the refusals come before any device work): which operators does the device scan accept?
+    try {
+      VariantQueryConfig query_config;
+      query_config.read_from_file(argv[2], 0);
+      VCFAdapter vcf_adapter;
+      VariantStorageManager sm("/nonexistent-workspace", 10u * 1024u * 1024u);
+      VariantQueryProcessor qp(&sm, "nonexistent-array", query_config.get_vid_mapper());
+      qp.do_query_bookkeeping(qp.get_array_schema(), query_config, query_config.get_vid_mapper(), true);
+      MyPerRecordOperator mine(&query_config.get_vid_mapper());
+      MyDerivedGVCFOperator derived(vcf_adapter, query_config.get_vid_mapper(), query_config);
+      int refused = 0;
+      try { qp.scan_and_operate(qp.get_array_descriptor(), query_config, mine, 0, true, 0); } catch (const VariantOperationException&) { refused |= 1; }
+      try { qp.scan_and_operate(qp.get_array_descriptor(), query_config, derived, 0, true, 0); } catch (const VariantOperationException&) { refused |= 2; }
+      std::cout << "refused " << refused << " derived_calls " << derived.calls << "\n";
+      return refused == 3 ? 0 : 1;
+    } catch (const std::exception& e) { std::cerr << e.what() << "\n"; return -2; }
+  }
   if (argc < 2) { std::cerr << "usage: gt_mpi_gather_shaped <query.json> [page_size]\n"; return -1; }
   if (std::string(argv[1]) == "--config-selftest" && argc >= 5) {
     // host only: loader + query JSON the way GenomicsDBBCFGenerator reads them (genomicsdb_bcf_generator.cc:44-53), then the ranges left

@@ -4,6 +4,7 @@
 // plain serial loops on the CPU, with std::sort / serial scans standing in for the device sorts and scans.
 // Purpose: debug the index arithmetic of the device pipeline in a container without a GPU and keep a CPU
 // regression of it next to the oracle.  The shipped library (libgenomicsdb_amd.so) contains no such path.
+#include <unordered_set>
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -239,6 +240,35 @@ int hostsim_genotype_map(const int32_t* m2i, int num_merged, int nr_in, int ploi
   const int n = (int)tr.n;
   for (int i = 0; i < n && i < cap; ++i) { int32_t v; memcpy(&v, buf.data() + 4 * i, 4); out[i] = v == GDB_BCF_INT32_MISSING ? -1 : v; }
   return n;
+}
+
+// gdb_core.hpp's restatement of the iteration order of libstdc++'s std::unordered_set<int> against the library itself:
+// `nranges` range inserts (lens[r] ids each, flattened in ids).  out_mine / out_lib receive the two orders; returns the set's size,
+// -1 when the restatement reports an overflow (more than GDB_MAX_FILTER_IDS distinct ids / a bucket count off its table)
+int hostsim_uset_order(const int32_t* ids, const int32_t* lens, int nranges, int32_t* out_mine, int32_t* out_lib, int cap) {
+  GdbUSetOrder us;
+  gdb_uset_init(us);
+  std::unordered_set<int> lib;
+  const int32_t* p = ids;
+  for (int r = 0; r < nranges; ++r) {
+    gdb_uset_insert_range(us, p, lens[r]);
+    lib.insert(p, p + lens[r]);
+    p += lens[r];
+  }
+  int n = 0;
+  for (int v : lib) { if (n < cap) out_lib[n] = v; ++n; }
+  if (us.overflow) return -1;
+  for (int i = 0; i < us.n && i < cap; ++i) out_mine[i] = us.key[i];
+  return us.n == n ? n : -2;
+}
+
+// gdb_asa.hpp's "%.3f" of a float (exact integer arithmetic on the mantissa) for the formatting test
+int hostsim_fixed3(float v, char* buf, uint64_t cap) {
+  struct S { char* p; uint64_t cap, n; void put(char c) { if (n + 1 < cap) p[n] = c; ++n; } void write(const char* q, int k) { for (int i = 0; i < k; ++i) put(q[i]); } } s{buf, cap, 0};
+  uint32_t err = 0;
+  put_fixed3(s, v, &err);
+  if (s.n < cap) buf[s.n] = 0;
+  return err ? -1 : (int)s.n;
 }
 
 }  // extern "C"

@@ -118,3 +118,50 @@ def test_query_ranges_are_subset_by_the_loader_partition(tmp_path):
         r = subprocess.run([exe, "--config-selftest", str(tmp_path / "q.json"), str(tmp_path / "l.json"), str(rank)], capture_output=True, text=True, env=env)
         assert r.returncode == 0, r.stderr
         assert r.stdout == text
+
+
+def test_operators_derived_from_the_builtin_are_refused(tmp_path):
+    """scan_and_operate recognises BroadCombinedGVCFOperator by its exact type: a derived class with its own operate() would
+    silently get the built-in's semantics otherwise.  The refusal comes before any device work, so it runs here."""
+    import json
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "compat")])
+    exe = os.path.join(ROOT, "tests", "compat", "gt_mpi_gather_shaped")
+    q, _ = helpers.query_json("t0_1_2.json", "vid.json", {"query_column_ranges": [[[0, 100000]]]}, "query")
+    (tmp_path / "q.json").write_text(json.dumps(q))
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "genomicsdb_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([exe, "--operator-selftest", str(tmp_path / "q.json")], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.strip() == "refused 3 derived_calls 0"
+
+
+def test_contig_style_column_partitions(tmp_path):
+    """column_partitions whose begin / end are contig positions ({"chr": p} / {"chr": [b, e]}, 1-based; json_config.cc:359-375)
+    are turned into TileDB columns with the loader's vid mapping; ends still derive from the next sorted begin"""
+    import json
+    from genomicsdb_amd import dist as gdist
+    vid = os.path.join(helpers.GOLDEN, "inputs", "vid.json")
+    offs = {k: v["tiledb_column_offset"] for k, v in json.load(open(vid))["contigs"].items()}
+    loader = {"vid_mapping_file": vid, "callset_mapping_file": "unused",
+              "column_partitions": [{"begin": {"1": 1}}, {"begin": {"2": 1}}, {"begin": {"X": [100, 200]}, "end": {"Y": 50}}, {"begin": 2000000000}]}
+    txt = json.dumps(loader)
+    assert gdist.column_partition(txt, 0) == (0, offs["2"] - 1)
+    assert gdist.column_partition(txt, 1) == (offs["2"], 2000000000 - 1)
+    assert gdist.column_partition(txt, 3) == (2000000000, offs["X"] + 99 - 1)
+    assert gdist.column_partition(txt, 2) == (offs["X"] + 99, offs["Y"] + 49)
+    bad = dict(loader, column_partitions=[{"begin": {"no_such_contig": 1}}])
+    with pytest.raises(RuntimeError, match="Invalid contig name"):
+        gdist.column_partition(json.dumps(bad), 0)
+    novid = {"column_partitions": [{"begin": {"1": 5}}]}
+    with pytest.raises(RuntimeError, match="vid_mapping"):
+        gdist.column_partition(json.dumps(novid), 0)
+
+
+def test_limits_in_the_public_header_match_the_device_tables():
+    """include/genomicsdb_amd.h lists the limits the reference does not have; they are the device's (core/gdb_types.h)"""
+    pub = dict(re.findall(r"#define GDBAMD_(MAX_\w+) (\d+)", open(os.path.join(ROOT, "include", "genomicsdb_amd.h")).read()))
+    dev = dict(re.findall(r"#define GDB_(MAX_\w+) (\d+)", open(os.path.join(ROOT, "genomicsdb_amd", "csrc", "core", "gdb_types.h")).read()))
+    assert len(pub) >= 10
+    names = {"MAX_QUERIED_FIELDS": "MAX_FIELDS"}
+    for k, v in pub.items():
+        assert dev[names.get(k, k)] == v, k

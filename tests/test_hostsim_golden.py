@@ -164,3 +164,31 @@ def test_allele_specific_annotations_fuzz(seed):
     assert errbits == 0
     assert nrec >= 30 and want.count(b"AS_RAW_MQ=") > 10 and want.count(b"AS_RAW_MQRankSum=") > 10
     assert got == want
+
+
+def test_fixed3_matches_printf_on_every_class_of_float():
+    """allele-specific annotations print with std::fixed << setprecision(3) (genomicsdb_multid_vector_field / stringify_2D_vector);
+    the device does it with integer arithmetic on the float's mantissa: checked against C's "%.3f" of the same float - ties,
+    denormals, sums beyond 2^53 (exact integers of up to 39 digits), infinities and NaNs included"""
+    import ctypes
+    import random
+    import struct
+    lib = helpers.hostsim_lib()
+    lib.hostsim_fixed3.argtypes = [ctypes.c_float, ctypes.c_char_p, ctypes.c_uint64]
+    libc = ctypes.CDLL(None)
+    libc.snprintf.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_double]
+    rnd = random.Random(3)
+    bits = [0, 0x80000000, 1, 0x007FFFFF, 0x00800000, 0x3A83126F, 0x3F000000, 0x3A03126F, 0x7F7FFFFF, 0xFF7FFFFF, 0x7F800000, 0xFF800000,
+            0x7FC00000, 0x5A000000, 0x5A800001, 0x5F000000, 0x7E967699, 0x4B000000, 0x4B7FFFFF, 0x3F8020C5, 0x3B03126F, 0x3A83126E]
+    bits += [rnd.getrandbits(32) for _ in range(20000)]
+    bits += [struct.unpack("<I", struct.pack("<f", k / 2000.0))[0] for k in range(-3000, 3000)]      # exact ties at the third decimal
+    for b in bits:
+        f = struct.unpack("<f", struct.pack("<I", b))[0]
+        mine = ctypes.create_string_buffer(128)
+        n = lib.hostsim_fixed3(ctypes.c_float(f), mine, 128)
+        want = ctypes.create_string_buffer(128)
+        libc.snprintf(want, 128, b"%.3f", ctypes.c_double(f))
+        w = want.value
+        if f != f:
+            w = b"-nan" if b >> 31 else b"nan"      # (a NaN's sign survives the float -> double conversion; glibc prints it)
+        assert n >= 0 and mine.value == w, (hex(b), mine.value, w)
