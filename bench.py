@@ -166,6 +166,7 @@ def main():
         if not args.no_stream and world == 1 and not args.bcf:         # the boundary GATK drives: header + body through gdb_mi355_read
             eng.close()                                                 # (the timed engine's HBM - fragment, 48 GB arena, tables - is given back first)
             out["stream_end_to_end"] = stream_end_to_end(N, B, min(W, Lbp), tmp, expect_body_bytes=None)
+            out["stream_end_to_end_bgzf"] = stream_end_to_end(N, B, min(W, Lbp), tmp, expect_body_bytes=None, output_format="z")
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(N, args.cpu_sample_bp, tmp)
     if out is not None:
@@ -298,7 +299,7 @@ def run_streamed(args, rank, world, device_index, backend):
         dist.destroy_process_group()
 
 
-def stream_end_to_end(N, B, W, tmp, expect_body_bytes=None):
+def stream_end_to_end(N, B, W, tmp, expect_body_bytes=None, output_format=None):
     """SURVEY 8(d) timing protocol, the part behind the device: t_stage (cells in host memory -> columnar fragment in HBM),
     t_drain and the end-to-end rate of the C-ABI query stream (gdb_mi355_init_from_memory / gdb_mi355_read, the six JNI entry
     points' twin) over one W-bp window of the same workload.  The caller's buffer is pinned host memory; the stream assembles
@@ -321,7 +322,7 @@ def stream_end_to_end(N, B, W, tmp, expect_body_bytes=None):
     gen = synth.Generator(N, B, W)
     ptr, nbytes, ncells = gen.next_chunk(B + W)
     t0 = time.time()
-    s = genomicsdb_amd.GenomicsDBQueryStream(query_json=q, cells=(ptr, nbytes), buffer_capacity=1 << 20)
+    s = genomicsdb_amd.GenomicsDBQueryStream(query_json=q, cells=(ptr, nbytes), buffer_capacity=1 << 20, output_format=output_format)
     t_stage = time.time() - t0
     cap = 256 << 20
     dst = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
@@ -349,11 +350,18 @@ def stream_end_to_end(N, B, W, tmp, expect_body_bytes=None):
     p2, n2, _ = gen2.next_chunk(B + W)
     eng.stage_cells_begin(); eng.stage_cells_append(p2, n2); eng.stage_cells_end()
     _, est = eng.run_interval(B, B + W - 1, arena_bytes=48 << 30, fetch=False)
-    ok = int(est.bytes_out) == body
+    ok = int(est.bytes_out) == body or output_format in ("z", "b")
     recs = int(est.num_records)
     pcie_bound = 63.0   # GB/s, PCIe Gen5 x16 spec (MI355X_MICROARCH.md)
+    eng.close()
+    extra = {}
+    if output_format in ("z", "b"):
+        extra = {"output_format": output_format, "uncompressed_body_bytes": int(est.bytes_out), "compression_ratio": int(est.bytes_out) / max(1, body),
+                 "uncompressed_GBps": int(est.bytes_out) / t_read / 1e9}
     return {
-        "what": "header + body of one %d bp window of the same workload through gdb_mi355_read into a pinned 256 MiB buffer" % W,
+        **extra,
+        "what": ("header + body of one %d bp window of the same workload through gdb_mi355_read into a pinned 256 MiB buffer" % W) +
+                (" as BGZF blocks deflated on the device (vcf_output_format \"%s\")" % output_format if output_format in ("z", "b") else ""),
         "positions_per_sec": recs / t_read, "GBps": total / t_read / 1e9, "frac_of_pcie_spec": total / t_read / 1e9 / pcie_bound,
         "t_stage_s": t_stage, "stage_GBps": nbytes / t_stage / 1e9, "cells": int(ncells), "cell_bytes": int(nbytes),
         "t_drain_s": t_read, "t_first_byte_s": t_first, "bytes": int(total), "records": recs,

@@ -5,4 +5,4 @@ the HIP kernels.  Mirrors the reference's caller-facing objects:
   GenomicsDBQueryStream  ~ com.intel.genomicsdb.reader.GenomicsDBQueryStream (JNI stream over GenomicsDBBCFGenerator)
   CombineEngine          ~ VariantQueryProcessor::scan_and_operate + BroadCombinedGVCFOperator on one column partition
 """
-from .api import CombineEngine, GenomicsDBQueryStream, GenomicsDBException, import_cells  # noqa: F401
+from .api import CombineEngine, GenomicsDBQueryStream, GenomicsDBException, import_cells, bgzf_compress, BGZF_EOF  # noqa: F401

@@ -28,8 +28,26 @@ class GenomicsDBQueryStream:
 
     def __init__(self, loader_json_file=None, query_json_file=None, chr="", start=0, end=0, rank=0, buffer_capacity=1048576,
                  segment_size=1048576, is_bcf=False, produce_header_only=False, query_json=None, cells=None,
-                 use_missing_values_only_not_vector_end=False, keep_idx_fields_in_bcf_header=True):
+                 use_missing_values_only_not_vector_end=False, keep_idx_fields_in_bcf_header=True, output_format=None):
+        """output_format (the reference's vcf_output_format: "", "bu", "z", "b") overrides is_bcf when given"""
         L = _lib.lib()
+        if output_format is not None:
+            fmt = output_format.encode()
+            if query_json is not None:
+                txt = query_json if isinstance(query_json, str) else json.dumps(query_json)
+                if isinstance(cells, tuple):
+                    self._cells = None
+                    self._h = L.gdb_mi355_init_from_memory_output_format(txt.encode(), ctypes.cast(cells[0], ctypes.c_char_p), cells[1], buffer_capacity, int(produce_header_only),
+                                                                         fmt, int(use_missing_values_only_not_vector_end), int(keep_idx_fields_in_bcf_header))
+                else:
+                    self._cells = bytes(cells or b"")
+                    self._h = L.gdb_mi355_init_from_memory_output_format(txt.encode(), self._cells, len(self._cells), buffer_capacity, int(produce_header_only), fmt,
+                                                                         int(use_missing_values_only_not_vector_end), int(keep_idx_fields_in_bcf_header))
+            else:
+                self._h = L.gdb_mi355_init_output_format((loader_json_file or "").encode(), (query_json_file or "").encode(), chr.encode(), start, end, rank, buffer_capacity,
+                                                         segment_size, fmt, int(produce_header_only), int(use_missing_values_only_not_vector_end), int(keep_idx_fields_in_bcf_header))
+            _check(self._h, "GenomicsDBQueryStream init")
+            return
         if query_json is not None:
             txt = query_json if isinstance(query_json, str) else json.dumps(query_json)
             if isinstance(cells, tuple):      # (host address, nbytes): cells that already lie in native memory (synthetic generator)
@@ -96,10 +114,13 @@ class GenomicsDBQueryStream:
 class CombineEngine:
     """One column partition on one GPU: stage cells (or adopt device columns), run query intervals."""
 
-    def __init__(self, query_json, device=0, is_bcf=False, use_missing_values_only_not_vector_end=False):
+    def __init__(self, query_json, device=0, is_bcf=False, use_missing_values_only_not_vector_end=False, output_format=None):
         L = _lib.lib()
         txt = query_json if isinstance(query_json, str) else json.dumps(query_json)
-        self._e = L.gdbamd_engine_create_format(txt.encode(), device, int(is_bcf), int(use_missing_values_only_not_vector_end))
+        if output_format is not None:
+            self._e = L.gdbamd_engine_create_output_format(txt.encode(), device, output_format.encode(), int(use_missing_values_only_not_vector_end))
+        else:
+            self._e = L.gdbamd_engine_create_format(txt.encode(), device, int(is_bcf), int(use_missing_values_only_not_vector_end))
         _check(self._e, "CombineEngine create")
         self._keep = []
 
@@ -260,3 +281,18 @@ def import_cells(vid_mapping_file, callset_mapping_file, file_root="", treat_del
         return ctypes.string_at(p.value, n.value), nc.value
     finally:
         L.gdbamd_free(p)
+
+
+def bgzf_compress(data):
+    """BGZF blocks (no EOF block) of `data`, deflated by the device kernels (kernels/gdb_bgzf.hip); returns (bytes, kernel ms)"""
+    L = _lib.lib()
+    data = bytes(data)
+    cap = L.gdbamd_bgzf_bound(len(data))
+    dst = ctypes.create_string_buffer(cap)
+    n = ctypes.c_uint64()
+    ms = ctypes.c_float()
+    _check(L.gdbamd_bgzf_compress(data, len(data), dst, cap, ctypes.byref(n), ctypes.byref(ms)) == 0, "bgzf_compress")
+    return dst.raw[:n.value], ms.value
+
+
+BGZF_EOF = bytes([0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0])

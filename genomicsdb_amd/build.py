@@ -17,6 +17,7 @@ TOOLS = {"gt_mpi_gather": TOOL, "vcf2tiledb": os.path.join(PKG, "vcf2tiledb")}
 
 SOURCES = [
     "kernels/gdb_pipeline.hip",
+    "kernels/gdb_bgzf.hip",
     "host/vid_mapper.cc",
     "host/variant_query_config.cc",
     "host/combine_plan.cc",

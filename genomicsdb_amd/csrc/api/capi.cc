@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "genomicsdb_bcf_generator.h"
+#include "../kernels/gdb_bgzf.h"
 #include "../host/vcf_importer.h"
 
 using namespace genomicsdb_amd;
@@ -40,6 +41,23 @@ void* gdb_mi355_init_from_memory_format(const char* query_json_text, const uint8
                                         int use_missing, int keep_idx) {
   return guarded([&]() -> void* {
     return new GenomicsDBBCFGenerator(std::string(query_json_text), cells, nbytes, buffer_capacity, produce_header_only != 0, is_bcf ? "bu" : "", is_bcf && use_missing, keep_idx != 0);
+  }, (void*)nullptr);
+}
+void* gdb_mi355_init_output_format(const char* loader_json_file, const char* query_json_file, const char* chr, int start, int end, int rank, uint64_t buffer_capacity,
+                                   uint64_t segment_size, const char* output_format, int produce_header_only, int use_missing, int keep_idx) {
+  return guarded([&]() -> void* {
+    const std::string fmt = output_format ? output_format : "";
+    const bool bcf = fmt == "bu" || fmt == "b";
+    return new GenomicsDBBCFGenerator(loader_json_file ? loader_json_file : "", query_json_file ? query_json_file : "", chr, start, end, rank, buffer_capacity,
+                                      segment_size, fmt.c_str(), produce_header_only != 0, bcf && use_missing, bcf && keep_idx);
+  }, (void*)nullptr);
+}
+void* gdb_mi355_init_from_memory_output_format(const char* query_json_text, const uint8_t* cells, uint64_t nbytes, uint64_t buffer_capacity, int produce_header_only,
+                                               const char* output_format, int use_missing, int keep_idx) {
+  return guarded([&]() -> void* {
+    const std::string fmt = output_format ? output_format : "";
+    const bool bcf = fmt == "bu" || fmt == "b";
+    return new GenomicsDBBCFGenerator(std::string(query_json_text), cells, nbytes, buffer_capacity, produce_header_only != 0, fmt.c_str(), bcf && use_missing, keep_idx != 0);
   }, (void*)nullptr);
 }
 uint64_t gdb_mi355_close(void* h) { delete (GenomicsDBBCFGenerator*)h; return 0; }
@@ -87,6 +105,35 @@ void* gdbamd_engine_create_format(const char* query_json_text, int device, int i
     return e;
   }, (void*)nullptr);
 }
+void* gdbamd_engine_create_output_format(const char* query_json_text, int device, const char* output_format, int use_missing) {
+  return guarded([&]() -> void* {
+    const std::string fmt = output_format ? output_format : "";
+    auto* e = new EngineHandle;
+    e->eng.reset(new CombineEngine(mini_json::parse(query_json_text), device, nullptr, 0, fmt, (fmt == "bu" || fmt == "b") && use_missing));
+    return e;
+  }, (void*)nullptr);
+}
+// BGZF blocks of n host bytes, compressed by the device kernels (a utility and the test hook of kernels/gdb_bgzf.hip)
+int gdbamd_bgzf_compress(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t dst_cap, uint64_t* dst_len, float* ms_kernels) {
+  return guarded([&]() -> int {
+    if (DevicePipeline::device_count() <= 0) throw GenomicsDBDeviceException("no HIP device visible");
+    const uint64_t bound = bgzf_bound(n);
+    char* d = nullptr;
+    if (hipMalloc((void**)&d, (size_t)bound + 64) != hipSuccess) throw GenomicsDBDeviceException("hipMalloc failed");
+    uint64_t got = 0;
+    try {
+      if (n && hipMemcpy(d, src, (size_t)n, hipMemcpyHostToDevice) != hipSuccess) throw GenomicsDBDeviceException("copy to the device failed");
+      BgzfDeviceCompressor c;
+      got = c.compress(d, n, d, nullptr, ms_kernels);
+      if (got > dst_cap) throw GenomicsDBDeviceException("destination too small: " + std::to_string(got) + " bytes needed");
+      if (got && hipMemcpy(dst, d, (size_t)got, hipMemcpyDeviceToHost) != hipSuccess) throw GenomicsDBDeviceException("copy from the device failed");
+    } catch (...) { (void)hipFree(d); throw; }
+    (void)hipFree(d);
+    *dst_len = got;
+    return 0;
+  }, -1);
+}
+uint64_t gdbamd_bgzf_bound(uint64_t n) { return bgzf_bound(n); }
 void gdbamd_engine_destroy(void* e) { delete (EngineHandle*)e; }
 int gdbamd_engine_num_fields(void* e) { return e ? ((EngineHandle*)e)->eng->plan().plan.nfields : -1; }
 const char* gdbamd_engine_field_name(void* e, int f) {
@@ -188,6 +235,7 @@ int gdbamd_engine_run_interval(void* e, int64_t qb, int64_t qe, uint64_t arena_b
       out->num_record_types = s.num_record_types; out->reserved0 = 0;
       out->num_text_slots = s.num_text_slots; out->text_pool_bytes = s.text_pool_bytes;
       out->num_remap_elements = s.num_remap_elements;
+      out->bytes_compressed = s.bytes_compressed; out->ms_compress = s.ms_compress; out->reserved1 = 0;
     }
     return 0;
   }, 1);

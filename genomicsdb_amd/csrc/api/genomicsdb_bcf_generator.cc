@@ -1,4 +1,5 @@
 #include "genomicsdb_bcf_generator.h"
+#include "../kernels/gdb_bgzf.h"
 
 #include <hip/hip_runtime_api.h>
 
@@ -327,7 +328,14 @@ GenomicsDBBCFGenerator::GenomicsDBBCFGenerator(const std::string& query_json_tex
 void GenomicsDBBCFGenerator::common_init(bool produce_header_only, bool keep_idx_fields_in_bcf_header) {
   m_produce_header_only = produce_header_only;
   // first bytes = header (vcf_adapter.cc:475-488): the VCF text, or "BCF\2\2" + length + text (IDX keys kept or dropped) + NUL
-  const std::string h = m_engine->plan().plan.bcf_mode ? m_engine->plan().bcf_header_bytes(keep_idx_fields_in_bcf_header) : m_engine->plan().header_text;
+  std::string h = m_engine->plan().plan.bcf_mode ? m_engine->plan().bcf_header_bytes(keep_idx_fields_in_bcf_header) : m_engine->plan().header_text;
+  if (m_engine->plan().bgzf) {
+    // "z" / "b": the header is a BGZF block of its own (zlib on the host, a few KB); the body follows as blocks compressed on the
+    // device; the empty EOF block ends the stream (SAM specification 4.1.2; htslib's bgzf_close writes it)
+    h = bgzf_compress_host(h);
+    if (produce_header_only) h.append((const char*)kBgzfEofBlock, sizeof(kBgzfEofBlock));
+    else m_trailer.assign((const char*)kBgzfEofBlock, sizeof(kBgzfEofBlock));
+  }
   m_header.assign(h.begin(), h.end());
   m_next_read_idx = 0;
   if (produce_header_only) m_done = true;
@@ -429,7 +437,22 @@ void GenomicsDBBCFGenerator::fill_ring() {
       const auto t0 = std::chrono::steady_clock::now();
       const bool more = advance_page();
       m_drain.seconds_producing += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      if (!more) return;
+      if (!more) {
+        if (!m_trailer.empty()) {     // the bytes that close the stream (BGZF: the EOF block) travel as a last ring slot
+          RingSlot& slot = m_ring[(m_ring_head + m_ring_count) % m_ring.size()];
+          if (slot.cap < m_trailer.size()) {
+            if (slot.host) GEN_HIP(hipHostFree(slot.host));
+            slot.host = nullptr; slot.cap = 0;
+            GEN_HIP(hipHostMalloc((void**)&slot.host, 4096, hipHostMallocDefault));
+            slot.cap = 4096;
+          }
+          memcpy(slot.host, m_trailer.data(), m_trailer.size());
+          slot.len = m_trailer.size(); slot.waited = true;       // (host bytes: nothing to wait for)
+          ++m_ring_count;
+          m_trailer.clear();
+        }
+        return;
+      }
       if (m_page.nbytes == 0) { m_page_valid = false; continue; }
     }
     if (!m_copy_stream) {

@@ -122,6 +122,7 @@ class GenomicsDBBCFGenerator {
   std::unique_ptr<CombineEngine> m_engine;
   size_t m_buffer_capacity;
   std::vector<uint8_t> m_header;  // first bytes of the stream
+  std::string m_trailer;          // last bytes of the stream (BGZF output formats: the EOF block), handed out once the pages are through
   size_t m_next_read_idx = 0;     // into the header while it lasts, then into the ring's head slot
   std::vector<RingSlot> m_ring;
   size_t m_ring_head = 0, m_ring_count = 0, m_slot_bytes = 0;

@@ -1,4 +1,5 @@
 #include "genomicsdb_operators.h"
+#include "../kernels/gdb_bgzf.h"
 
 #include <typeinfo>
 
@@ -12,7 +13,11 @@
 namespace genomicsdb_amd {
 
 // ---- adapters -----------------------------------------------------------------------------------------------------------------
-VCFAdapter::~VCFAdapter() { if (m_out && m_owns_out) fclose(m_out); else if (m_out) fflush(m_out); }
+VCFAdapter::~VCFAdapter() {
+  // BGZF output ("z" / "b"): the file ends with the empty EOF block, as htslib's bgzf_close leaves it
+  if (m_out && m_wrote_bytes && (m_output_format == "z" || m_output_format == "b")) (void)fwrite(kBgzfEofBlock, 1, sizeof(kBgzfEofBlock), m_out);
+  if (m_out && m_owns_out) fclose(m_out); else if (m_out) fflush(m_out);
+}
 
 void VCFAdapter::initialize(const VariantQueryConfig& qc) {
   m_output_format = qc.get_vcf_output_format();
@@ -25,6 +30,7 @@ void VCFAdapter::initialize(const VariantQueryConfig& qc) {
 void VCFAdapter::handoff(const uint8_t* bytes, size_t n) {
   if (!m_out) throw VCFAdapterException("VCFAdapter::initialize() has not opened an output");
   if (n && fwrite(bytes, 1, n, m_out) != n) throw VCFAdapterException("short write");
+  if (n) m_wrote_bytes = true;
 }
 void VCFSerializedBufferAdapter::handoff(const uint8_t* bytes, size_t n) {
   if (!m_rw_buffer) throw VCFAdapterException("VCFSerializedBufferAdapter: set_buffer() first");
@@ -115,7 +121,8 @@ void VariantQueryProcessor::scan_and_operate(const int, const VariantQueryConfig
   if (gvcf && !E.header_done) {       // the reference's operator constructor writes the header through its adapter
     const HostPlan& hp = eng.plan();
     const auto* ser = dynamic_cast<VCFSerializedBufferAdapter*>(&gvcf->get_vcf_adapter());
-    const std::string h = hp.plan.bcf_mode ? hp.bcf_header_bytes(ser ? ser->keep_idx_fields_in_bcf_header() : true) : hp.header_text;
+    std::string h = hp.plan.bcf_mode ? hp.bcf_header_bytes(ser ? ser->keep_idx_fields_in_bcf_header() : true) : hp.header_text;
+    if (hp.bgzf) h = bgzf_compress_host(h);      // "z" / "b": the header is a BGZF block of its own; the adapter writes the EOF block when it closes
     gvcf->get_vcf_adapter().handoff((const uint8_t*)h.data(), h.size());
     E.header_done = true;
   }

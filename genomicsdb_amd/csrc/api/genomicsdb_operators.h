@@ -59,7 +59,7 @@ class VCFAdapter {
  protected:
   bool m_open_output;
   FILE* m_out = nullptr;
-  bool m_owns_out = false;
+  bool m_owns_out = false, m_wrote_bytes = false;
   std::string m_output_format;
   size_t m_buffer_limit = 1048576u;
 };

@@ -282,9 +282,12 @@ HostPlan build_combine_plan(const VariantQueryConfig& qc, const std::string& tmp
       for (auto& c : ctg_dict) if (c.first == name) g.rid = c.second;
     }
   }
-  pl.bcf_mode = output_format == "bu" ? 1 : 0;
-  if (!output_format.empty() && output_format != "bu")
-    throw UnsupportedOnDeviceException("VCF output format \"" + output_format + "\": this build streams text VCF (\"\") or uncompressed BCF2 (\"bu\")");
+  // "": VCF text, "bu": uncompressed BCF2, "z": BGZF-compressed VCF text, "b": BGZF-compressed BCF2 (the modes htslib's hts_open
+  // takes behind "w": vcf_adapter.cc:358-363); "v" is htslib's explicit spelling of uncompressed text
+  pl.bcf_mode = (output_format == "bu" || output_format == "b") ? 1 : 0;
+  hp.bgzf = output_format == "z" || output_format == "b";
+  if (!(output_format.empty() || output_format == "v" || output_format == "bu" || output_format == "z" || output_format == "b"))
+    throw UnsupportedOnDeviceException("VCF output format \"" + output_format + "\": known formats are \"\" (VCF text), \"z\" (BGZF-compressed VCF), \"bu\" (BCF2) and \"b\" (BGZF-compressed BCF2)");
   pl.use_missing_values_not_vector_end = use_missing_values_not_vector_end ? 1 : 0;
   pl.bcf_n_sample = sites_only ? 0 : (int32_t)qc.get_num_rows_to_query();
   if (pl.bcf_mode && pl.bcf_end_id < 0) throw BroadCombinedGVCFException("BCF output needs an INFO END line in the header");

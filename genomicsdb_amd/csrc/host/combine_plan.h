@@ -21,6 +21,7 @@ class BroadCombinedGVCFException : public std::runtime_error {
 
 struct HostPlan {
   CombinePlan plan;
+  bool bgzf = false;                     // output formats "z" / "b": the stream is BGZF-compressed (on the device, kernels/gdb_bgzf.hip)
   std::vector<std::string> field_names;  // plan field idx -> array attribute name
   std::string header_text;               // template "##" lines + added lines + #CHROM line
   // BCF2 ("bu") flavour of the stream: "BCF\2\2", l_text, the same text with an IDX key on every FILTER / INFO / FORMAT / contig
@@ -37,7 +38,7 @@ struct HostPlan {
   std::string contig_names;
 };
 
-// output_format "" / "z": VCF text; "bu": BCF2 records.  use_missing_values_not_vector_end: the JNI flag for htsjdk.
+// output_format "": VCF text; "bu": BCF2 records; "z" / "b": the same two as BGZF blocks (genomicsdb_config_base.cc:34,156-165).  use_missing_values_not_vector_end: the JNI flag for htsjdk.
 HostPlan build_combine_plan(const VariantQueryConfig& qc, const std::string& template_header_text, const std::string& output_format = "",
                             bool use_missing_values_not_vector_end = false);
 

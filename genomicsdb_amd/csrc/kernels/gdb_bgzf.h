@@ -1,0 +1,48 @@
+// gdb_bgzf.h - BGZF (blocked gzip) output of the combined-gVCF stream, compressed ON THE DEVICE.
+//
+// The reference's VCFAdapter opens its output through htslib with mode "w" + vcf_output_format: "z" = BGZF-compressed VCF text,
+// "b" = BGZF-compressed BCF2 (reference src/main/cpp/src/vcf/vcf_adapter.cc:340-372, src/config/genomicsdb_config_base.cc:34,
+// 156-165).  Here the finished page (text or BCF2 records, in HBM) is cut into 8 / 16 KiB pieces, every piece becomes one BGZF
+// block - gzip member with the 'BC' extra field, RFC 1952 + the SAM specification section 4.1 - deflated by ONE wavefront
+// (LZ77 over the piece held in LDS + fixed-Huffman codes, RFC 1951), and only the compressed bytes leave the GPU: the stream is
+// PCIe-bound, so this is the lever on what a caller sees (the same page assembly, ~7x fewer bytes over the link).
+// Compressed bytes are not comparable with htslib's (any valid DEFLATE of the same bytes is a valid file); parity is defined
+// on the inflated stream, which equals the "" / "bu" stream byte for byte, and on the BGZF framing (EOF block included).
+#pragma once
+#include <cstdint>
+#include <string>
+
+namespace genomicsdb_amd {
+
+// uncompressed bytes per block: 64 lanes x 128 or 256 bytes (GDBAMD_BGZF_BLOCK = 8192 / 16384; smaller blocks leave room for more
+// resident wavefronts, larger ones find a little more to match)
+uint32_t bgzf_block_input();
+constexpr uint32_t kBgzfHeaderBytes = 18, kBgzfTrailerBytes = 8;
+extern const unsigned char kBgzfEofBlock[28];               // the empty block that ends every BGZF file
+
+// worst case of the compressed stream of n bytes (every block stored: 5 bytes of DEFLATE framing + header + trailer)
+inline uint64_t bgzf_bound(uint64_t n) {
+  const uint64_t nblocks = (n + 8192 - 1) / 8192;
+  return n + nblocks * (kBgzfHeaderBytes + kBgzfTrailerBytes + 5) + 64;
+}
+
+// BGZF blocks of a host buffer (the VCF / BCF header; zlib on the host - a few KB once per stream)
+std::string bgzf_compress_host(const std::string& bytes);
+
+class BgzfDeviceCompressor {
+ public:
+  BgzfDeviceCompressor();
+  ~BgzfDeviceCompressor();
+  BgzfDeviceCompressor(const BgzfDeviceCompressor&) = delete;
+  BgzfDeviceCompressor& operator=(const BgzfDeviceCompressor&) = delete;
+  // Enqueues on `hip_stream` (a hipStream_t) the compression of the n bytes at dev_src (16-byte aligned, device memory) into
+  // consecutive BGZF blocks at dev_dst (device memory of at least bgzf_bound(n) bytes; MAY BE dev_src itself: the packed stream
+  // is written only after every piece has been read), then waits for the stream and returns the number of bytes at dev_dst.
+  // ms_kernels (optional): device time of the two kernels.
+  uint64_t compress(const char* dev_src, uint64_t n, char* dev_dst, void* hip_stream, float* ms_kernels = nullptr);
+  struct Impl;
+ private:
+  Impl* m_;
+};
+
+}  // namespace genomicsdb_amd

@@ -1,0 +1,427 @@
+// gdb_bgzf.hip - BGZF blocks deflated on the device (see gdb_bgzf.h).
+//
+// k_bgzf_deflate: one wavefront = one block of <= 16 320 input bytes, held in LDS together with a 2 048-entry hash table of the
+// most recent position of every 4-byte group and a ring of output words.  The wavefront takes 64 consecutive positions per step:
+//   * every lane hashes the 4 bytes at its position, reads the candidate the table holds (a position of an earlier step) and
+//     leaves its own position there;
+//   * every lane measures its match against the candidate with 8-byte LDS compares (<= 258 bytes, never past the block's end);
+//   * the greedy parse of RFC 1951's usual compressors - take the match if it is >= 4 bytes, else a literal, continue behind
+//     it - is a chain through the 64 positions that the scalar unit follows with v_readlane (a few tokens per step: a match
+//     skips ~20 positions);
+//   * the lanes at token starts encode their token with the FIXED Huffman code (literal 8-9 bits; length code + extra bits,
+//     5-bit distance code + extra bits, <= 31 bits, all by arithmetic - no tables), a DPP scan of the bit counts places them,
+//     and they are OR-ed into the ring; full halves of the ring leave as coalesced stores.
+// A block that does not shrink is written as a stored block.  The CRC-32 of the block's input is taken in the same kernel: every
+// lane runs the table-driven CRC (slicing-by-4) over its own 255 bytes, advances it over the bytes behind its piece with a
+// per-lane precomputed GF(2) operator (4 x 256 words per lane) and the 64 contributions are XOR-ed (the CRC register is linear
+// in its start value and the message).
+// k_bgzf_pack: headers ('BC' extra field with the block size), payloads and trailers (CRC-32, input size) at their final,
+// exclusive-scanned offsets.
+#include "gdb_bgzf.h"
+
+#include <hip/hip_runtime.h>
+#include <zlib.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+
+#include <rocprim/device/device_scan.hpp>
+
+namespace genomicsdb_amd {
+
+const unsigned char kBgzfEofBlock[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+#define BGZF_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) throw std::runtime_error(std::string("BGZF: ") + #expr + " failed: " + hipGetErrorString(_e)); } while (0)
+
+namespace {
+
+constexpr int kProbe = 16;                         // bytes every position compares against its candidate (a multiple of 8)
+constexpr int kRingWords = 256, kFlushWords = 128; // (a step adds at most 64 tokens x 31 bits = 62 words)
+constexpr uint32_t kSlotBytes = 17408;            // room for the payload of one block while it is being produced (a block that grows is cut off early)
+constexpr uint32_t kNoCand = 0xFFFFu;
+
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+
+__device__ __forceinline__ uint32_t lds_read_u32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ uint64_t lds_read_u64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_xor(uint32_t v) {
+  for (int off = 32; off; off >>= 1) v ^= (uint32_t)__shfl_xor((int)v, off, 64);
+  return v;
+}
+
+// fixed Huffman code of a literal / length symbol (RFC 1951 3.2.6), already bit-reversed for the LSB-first stream
+__device__ __forceinline__ void fixed_litlen(uint32_t sym, uint32_t& bits, uint32_t& nb) {
+  uint32_t code;
+  if (sym < 144u) { code = 0x30u + sym; nb = 8; }
+  else if (sym < 256u) { code = 0x190u + (sym - 144u); nb = 9; }
+  else if (sym < 280u) { code = sym - 256u; nb = 7; }
+  else { code = 0xC0u + (sym - 280u); nb = 8; }
+  bits = __brev(code) >> (32u - nb);
+}
+
+template <int kBgzfBlockInput>
+__global__ void __launch_bounds__(64) k_bgzf_deflate(const uint8_t* __restrict__ src, uint64_t n_total, uint8_t* __restrict__ slots, uint32_t* __restrict__ csize,
+                                                     uint64_t* __restrict__ bsize, uint32_t* __restrict__ crc_out, const uint32_t* __restrict__ crc_slice,
+                                                     const uint32_t* __restrict__ crc_shift) {
+  const uint64_t blk = blockIdx.x;
+  const uint64_t base = blk * (uint64_t)kBgzfBlockInput;
+  const uint32_t n = (uint32_t)((n_total - base) < (uint64_t)kBgzfBlockInput ? (n_total - base) : (uint64_t)kBgzfBlockInput);
+  const int lane = threadIdx.x;
+  __shared__ uint4 in4[kBgzfBlockInput / 16 + 3];             // 48 bytes of zeros behind the block: the probes read up to 39 bytes past a position
+  constexpr int kHashBits = kBgzfBlockInput > 8192 ? 11 : 10;
+  constexpr int kPiece = kBgzfBlockInput / 64;                 // bytes of the block whose CRC a lane takes
+  __shared__ uint32_t table32[(1 << kHashBits) / 2 + 2];      // (+ a spare slot for the positions behind the block's end)
+  __shared__ uint32_t ring[kRingWords];
+  uint8_t* const in = reinterpret_cast<uint8_t*>(in4);
+  uint16_t* const table = reinterpret_cast<uint16_t*>(table32);
+  // ---- the piece into LDS (zero behind its end: the 8-byte compares read up to 7 bytes past it) -------------------------------------
+  const uint8_t* const blk_src = src + base;
+  for (uint32_t q = lane; q < kBgzfBlockInput / 16 + 3; q += 64) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (q * 16u + 16u <= n) v = reinterpret_cast<const uint4*>(blk_src)[q];
+    else if (q * 16u < n) {
+      uint32_t w[4] = {0, 0, 0, 0};
+      for (uint32_t b = q * 16u; b < n; ++b) w[(b & 15u) >> 2] |= (uint32_t)blk_src[b] << (8u * (b & 3u));
+      v = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    in4[q] = v;
+  }
+  for (uint32_t q = lane; q < (1u << kHashBits) / 2 + 2; q += 64) table32[q] = 0xFFFFFFFFu;
+  for (uint32_t q = lane; q < kRingWords; q += 64) ring[q] = (q == 0) ? 3u : 0u;      // BFINAL = 1, BTYPE = 01 (fixed Huffman)
+  __syncthreads();
+  uint32_t* const out_words = reinterpret_cast<uint32_t*>(slots + blk * (uint64_t)kSlotBytes);
+  uint32_t bitpos = 3, flushed = 0;
+  uint32_t p = 0;
+  int e = 0;
+  bool gave_up = false;
+  while (p < n) {                                             // uniform
+    // The body of a step is written without branches on per-lane conditions (every such branch costs exec-mask bookkeeping on
+    // the scalar unit, and this kernel is bound by the instructions it issues - SQ counters, profiles/r3_*): positions behind
+    // the block's end hash the zero padding into a spare table slot and come out with no candidate.
+    const uint32_t q = p + (uint32_t)lane;
+    const bool can_hash = q + 4u <= n;
+    const uint64_t own0 = lds_read_u64(in + q);               // the position's first 8 bytes: hash input, first compare word, literal
+    const uint32_t h = can_hash ? ((uint32_t)own0 * 2654435761u) >> (32 - kHashBits) : (1u << kHashBits);
+    const uint32_t cand_raw = table[h];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     // every lane has read the table before any lane writes it
+    table[h] = (uint16_t)q;
+    const bool has_cand = can_hash && cand_raw != kNoCand;
+    const uint32_t cand = has_cand ? cand_raw : 0u;
+    // Every lane measures its match only up to kProbe = 32 bytes, all four 8-byte compares in flight at once: nearly every
+    // position of a text like this one lies INSIDE a long match of an earlier position, so full-length compares in all lanes
+    // are wasted on positions the parse never visits (and the slowest lane sets the wavefront's time).  The few tokens the
+    // parse takes with a probe that ran to its end are extended by the whole wavefront, 64 bytes per step, in the chain walk.
+    uint32_t L;
+    {
+      const uint64_t x0 = lds_read_u64(in + cand) ^ own0;
+      uint32_t k = (uint32_t)kProbe;
+      if (kProbe > 16) {
+        const uint64_t x2 = lds_read_u64(in + cand + 16) ^ lds_read_u64(in + q + 16), x3 = lds_read_u64(in + cand + 24) ^ lds_read_u64(in + q + 24);
+        k = x3 ? 24u + ((uint32_t)__builtin_ctzll(x3) >> 3) : k;
+        k = x2 ? 16u + ((uint32_t)__builtin_ctzll(x2) >> 3) : k;
+      }
+      if (kProbe > 8) {
+        const uint64_t x1 = lds_read_u64(in + cand + 8) ^ lds_read_u64(in + q + 8);
+        k = x1 ? 8u + ((uint32_t)__builtin_ctzll(x1) >> 3) : k;
+      }
+      k = x0 ? ((uint32_t)__builtin_ctzll(x0) >> 3) : k;
+      const uint32_t room = n > q ? n - q : 0u;               // (the zero padding behind the block never extends a match)
+      k = k < room ? k : room;
+      L = (has_cand && k >= 4u) ? k : 0u;
+    }
+    // ---- greedy parse: the chain of token starts through this step's positions (scalar) --------------------------------------------
+    const int lim = (n - p) < 64u ? (int)(n - p) : 64;
+    uint64_t sel = 0;
+    int cur = e;
+    while (cur < lim) {
+      uint32_t Lc = (uint32_t)__builtin_amdgcn_readlane((int)L, cur);
+      if (Lc == (uint32_t)kProbe) {                              // uniform: the probe ran to its end - how far does the match really go?
+        const uint32_t cpos = (uint32_t)__builtin_amdgcn_readlane((int)cand, cur), qpos = p + (uint32_t)cur;
+        const uint32_t mx = (n - qpos) < 258u ? (n - qpos) : 258u;
+        uint32_t k = (uint32_t)kProbe;
+        while (k < mx) {
+          const uint32_t j = k + (uint32_t)lane;
+          const bool differ = j < mx && in[cpos + j] != in[qpos + j];
+          const uint64_t m = __ballot(differ);
+          if (m) { k += (uint32_t)__builtin_ctzll(m); break; }
+          k += 64;
+        }
+        Lc = k < mx ? k : mx;
+        if (lane == cur) L = Lc;
+      }
+      sel |= 1ull << cur;
+      cur += Lc ? (int)Lc : 1;
+    }
+    e = cur - 64;
+    // ---- tokens -> bits --------------------------------------------------------------------------------------------------------
+    const bool mine = (sel >> lane) & 1ull;
+    uint32_t bits, nb;
+    {
+      // both encodings are computed by every lane, then one is picked (no divergent branches)
+      const uint32_t l = L - 3u;                               // (garbage when L == 0: not used then)
+      const uint32_t leb = l < 8u ? 0u : (31u - (uint32_t)__clz(l | 8u)) - 2u;
+      uint32_t lsym = l < 8u ? 257u + l : 261u + 4u * leb + ((l >> leb) & 3u);
+      uint32_t lextra = l & ((1u << leb) - 1u);
+      uint32_t lextra_bits = leb;
+      if (L == 258u) { lsym = 285u; lextra = 0; lextra_bits = 0; }
+      const uint32_t lit = (uint32_t)own0 & 0xFFu;
+      const uint32_t sym = L ? lsym : lit;
+      uint32_t sb, sn;
+      fixed_litlen(sym, sb, sn);
+      const uint32_t d = q - cand - 1u;
+      const uint32_t deb = d < 4u ? 0u : (31u - (uint32_t)__clz(d | 4u)) - 1u;
+      const uint32_t dsym = d < 4u ? d : 2u * deb + 2u + ((d >> deb) & 1u);
+      const uint32_t dextra = d & ((1u << deb) - 1u);
+      uint32_t mb = sb | (lextra << sn), mn = sn + lextra_bits;
+      mb |= (__brev(dsym) >> 27) << mn; mn += 5u;
+      mb |= dextra << mn; mn += deb;
+      bits = L ? mb : sb;
+      nb = mine ? (L ? mn : sn) : 0u;
+    }
+    const uint32_t incl = wave_incl_scan(nb);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (mine) {
+      const uint32_t off = bitpos + incl - nb;
+      const uint32_t w = off >> 5, sh = off & 31u;
+      atomicOr(&ring[w & (kRingWords - 1)], bits << sh);
+      const uint32_t hi = sh ? (bits >> (32u - sh)) : 0u;
+      if (hi) atomicOr(&ring[(w + 1u) & (kRingWords - 1)], hi);
+    }
+    bitpos += total;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if ((bitpos >> 3) > n) { gave_up = true; break; }         // uniform: the block is not shrinking, it will be stored
+    while ((bitpos >> 5) - flushed >= (uint32_t)kFlushWords) {   // uniform: full words leave, their ring slots are zeroed for reuse
+      for (uint32_t i = lane; i < (uint32_t)kFlushWords; i += 64) {
+        const uint32_t slot = (flushed + i) & (kRingWords - 1);
+        out_words[flushed + i] = ring[slot];
+        ring[slot] = 0;
+      }
+      flushed += kFlushWords;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+    p += 64;
+    while (e >= 64) { e -= 64; p += 64; }                     // a match that covers whole steps: nothing to do there
+  }
+  uint32_t payload;
+  if (!gave_up) {
+    bitpos += 7;                                              // end of block: symbol 256 = seven zero bits
+    payload = (bitpos + 7u) >> 3;
+    if (payload >= n + 5u) gave_up = true;
+  }
+  if (!gave_up) {
+    const uint32_t nwords = (bitpos + 31u) >> 5;
+    for (uint32_t i = flushed + lane; i < nwords; i += 64) out_words[i] = ring[i & (kRingWords - 1)];
+  } else {
+    // stored block: 0x01 (BFINAL, BTYPE 00, padding), LEN, NLEN, the bytes
+    uint8_t* o = slots + blk * (uint64_t)kSlotBytes;
+    if (lane == 0) { o[0] = 1; o[1] = (uint8_t)(n & 0xFFu); o[2] = (uint8_t)(n >> 8); o[3] = (uint8_t)(~n & 0xFFu); o[4] = (uint8_t)((~n >> 8) & 0xFFu); }
+    for (uint32_t i = lane; i < n; i += 64) o[5 + i] = in[i];
+    payload = n + 5u;
+  }
+  // ---- CRC-32 of the block's input --------------------------------------------------------------------------------------------
+  uint32_t crc;
+  const uint32_t* T0 = crc_slice, *T1 = crc_slice + 256, *T2 = crc_slice + 512, *T3 = crc_slice + 768;
+  if (n == kBgzfBlockInput) {
+    uint32_t r = lane == 0 ? 0xFFFFFFFFu : 0u;
+    const uint8_t* pc = in + (uint32_t)kPiece * (uint32_t)lane;
+    for (int i = 0; i < kPiece / 4; ++i) {
+      const uint32_t x = r ^ lds_read_u32(pc + 4 * i);
+      r = T3[x & 0xFFu] ^ T2[(x >> 8) & 0xFFu] ^ T1[(x >> 16) & 0xFFu] ^ T0[x >> 24];
+    }
+    const uint32_t* S = crc_shift + (size_t)lane * 1024;      // this lane's contribution after the bytes behind its piece
+    const uint32_t c = S[r & 0xFFu] ^ S[256 + ((r >> 8) & 0xFFu)] ^ S[512 + ((r >> 16) & 0xFFu)] ^ S[768 + (r >> 24)];
+    crc = wave_xor(c) ^ 0xFFFFFFFFu;
+  } else {
+    uint32_t r = 0xFFFFFFFFu;                                  // the short last block of a page: one lane, serially
+    if (lane == 0) {
+      uint32_t i = 0;
+      for (; i + 4 <= n; i += 4) { const uint32_t x = r ^ lds_read_u32(in + i); r = T3[x & 0xFFu] ^ T2[(x >> 8) & 0xFFu] ^ T1[(x >> 16) & 0xFFu] ^ T0[x >> 24]; }
+      for (; i < n; ++i) r = T0[(r ^ in[i]) & 0xFFu] ^ (r >> 8);
+    }
+    crc = r ^ 0xFFFFFFFFu;
+  }
+  if (lane == 0) { csize[blk] = payload; bsize[blk] = (uint64_t)payload + kBgzfHeaderBytes + kBgzfTrailerBytes; crc_out[blk] = crc; }
+}
+
+__global__ void __launch_bounds__(64) k_bgzf_pack(const uint8_t* __restrict__ slots, const uint32_t* __restrict__ csize, const uint64_t* __restrict__ boff,
+                                                  const uint32_t* __restrict__ crc, uint64_t n_total, uint8_t* __restrict__ dst, uint32_t kBgzfBlockInput) {
+  const uint64_t blk = blockIdx.x;
+  const int lane = threadIdx.x;
+  const uint32_t c = csize[blk];
+  uint8_t* o = dst + boff[blk];
+  const uint64_t base = blk * (uint64_t)kBgzfBlockInput;
+  const uint32_t n = (uint32_t)((n_total - base) < (uint64_t)kBgzfBlockInput ? (n_total - base) : (uint64_t)kBgzfBlockInput);
+  const uint32_t bs = c + kBgzfHeaderBytes + kBgzfTrailerBytes - 1u;      // BSIZE = total block size - 1
+  if (lane < 18) {
+    const uint8_t hdr[18] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, (uint8_t)(bs & 0xFFu), (uint8_t)(bs >> 8)};
+    o[lane] = hdr[lane];
+  } else if (lane < 26) {
+    const uint32_t v = lane < 22 ? crc[blk] : n;
+    o[kBgzfHeaderBytes + c + (uint32_t)(lane - 18)] = (uint8_t)((v >> (8 * ((lane - 18) & 3))) & 0xFFu);
+  }
+  // payload: aligned words of the destination assembled from two aligned source words (the slot is 16-byte aligned, the destination not)
+  const uint8_t* s = slots + blk * (uint64_t)kSlotBytes;
+  uint8_t* d = o + kBgzfHeaderBytes;
+  const uint32_t head = (uint32_t)((4u - ((uintptr_t)d & 3u)) & 3u) < c ? (uint32_t)((4u - ((uintptr_t)d & 3u)) & 3u) : c;
+  if ((uint32_t)lane < head) d[lane] = s[lane];
+  const uint32_t nw = (c - head) >> 2;
+  const uint32_t* sw = reinterpret_cast<const uint32_t*>(s);
+  uint32_t* dw = reinterpret_cast<uint32_t*>(d + head);
+  for (uint32_t i = lane; i < nw; i += 64) {
+    const uint32_t lo = sw[i], hi = sw[i + 1];                // (the slot has room behind the payload)
+    dw[i] = head ? __builtin_amdgcn_alignbyte(hi, lo, head) : lo;
+  }
+  const uint32_t tail_at = head + (nw << 2);
+  if ((uint32_t)lane < c - tail_at) d[tail_at + lane] = s[tail_at + lane];
+}
+
+// ---- CRC-32 tables (reflected polynomial 0xEDB88320, the gzip CRC) -------------------------------------------------------------
+void build_crc_tables(std::vector<uint32_t>& slice, std::vector<uint32_t>& shift, int piece) {
+  slice.assign(4 * 256, 0);
+  for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1; slice[i] = c; }
+  for (uint32_t i = 0; i < 256; ++i) for (int t = 1; t < 4; ++t) { const uint32_t prev = slice[(t - 1) * 256 + i]; slice[t * 256 + i] = (prev >> 8) ^ slice[prev & 0xFFu]; }
+  // Z = the register after one zero byte; Z255 = after `piece` of them (one lane's share of a block), as the images of the 32 unit vectors
+  auto zero_byte = [&](uint32_t r) { return slice[r & 0xFFu] ^ (r >> 8); };
+  uint32_t z255[32];
+  for (int j = 0; j < 32; ++j) { uint32_t r = 1u << j; for (int k = 0; k < piece; ++k) r = zero_byte(r); z255[j] = r; }
+  auto apply = [&](const uint32_t* cols, uint32_t v) { uint32_t o = 0; for (int j = 0; j < 32; ++j) if ((v >> j) & 1u) o ^= cols[j]; return o; };
+  // lane i is followed by 63 - i pieces: A_63 = identity, A_i = A_(i+1) o Z255
+  shift.assign((size_t)64 * 1024, 0);
+  uint32_t cols[32];
+  for (int j = 0; j < 32; ++j) cols[j] = 1u << j;
+  for (int lane = 63; lane >= 0; --lane) {
+    for (int t = 0; t < 4; ++t)
+      for (uint32_t b = 0; b < 256; ++b) shift[(size_t)lane * 1024 + t * 256 + b] = apply(cols, b << (8 * t));
+    uint32_t next[32];
+    for (int j = 0; j < 32; ++j) next[j] = apply(cols, z255[j]);   // A_(lane-1)(e_j) = A_lane(Z255(e_j))
+    memcpy(cols, next, sizeof(cols));
+  }
+}
+
+}  // namespace
+
+uint32_t bgzf_block_input() {
+  static const uint32_t v = []() { const char* e = getenv("GDBAMD_BGZF_BLOCK"); return (e && atoi(e) == 16384) ? 16384u : (e && atoi(e) == 8192) ? 8192u : 8192u; }();
+  return v;
+}
+
+std::string bgzf_compress_host(const std::string& bytes) {
+  std::string out;
+  const size_t kHostBlock = 0xff00;                            // htslib's BGZF_BLOCK_SIZE
+  for (size_t at = 0; at < bytes.size(); at += kHostBlock) {
+    const size_t n = std::min<size_t>(kHostBlock, bytes.size() - at);
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("BGZF: deflateInit2 failed");
+    std::vector<unsigned char> buf(deflateBound(&zs, (uLong)n) + 16);
+    zs.next_in = (Bytef*)bytes.data() + at; zs.avail_in = (uInt)n;
+    zs.next_out = buf.data(); zs.avail_out = (uInt)buf.size();
+    const int rc = deflate(&zs, Z_FINISH);
+    const size_t c = buf.size() - zs.avail_out;
+    deflateEnd(&zs);
+    if (rc != Z_STREAM_END) throw std::runtime_error("BGZF: deflate failed");
+    const uint32_t bs = (uint32_t)(c + kBgzfHeaderBytes + kBgzfTrailerBytes - 1);
+    if (bs > 0xFFFFu) throw std::runtime_error("BGZF: block too large");
+    const unsigned char hdr[18] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, (unsigned char)(bs & 0xFFu), (unsigned char)(bs >> 8)};
+    out.append((const char*)hdr, 18);
+    out.append((const char*)buf.data(), c);
+    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef*)bytes.data() + at, (uInt)n), isize = (uint32_t)n;
+    out.append((const char*)&crc, 4);
+    out.append((const char*)&isize, 4);
+  }
+  return out;
+}
+
+struct BgzfDeviceCompressor::Impl {
+  uint32_t* d_slice = nullptr; uint32_t* d_shift = nullptr; uint32_t block = 0;
+  uint8_t* slots = nullptr; size_t slots_cap = 0;
+  uint32_t* csize = nullptr; uint32_t* crc = nullptr; uint64_t* bsize = nullptr; uint64_t* boff = nullptr; size_t blocks_cap = 0;
+  void* temp = nullptr; size_t temp_cap = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  void release() {
+    for (void* p : {(void*)d_slice, (void*)d_shift, (void*)slots, (void*)csize, (void*)crc, (void*)bsize, (void*)boff, temp}) if (p) (void)hipFree(p);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+  }
+};
+
+BgzfDeviceCompressor::BgzfDeviceCompressor() : m_(new Impl) {}
+BgzfDeviceCompressor::~BgzfDeviceCompressor() { m_->release(); delete m_; }
+
+uint64_t BgzfDeviceCompressor::compress(const char* dev_src, uint64_t n, char* dev_dst, void* hip_stream, float* ms_kernels) {
+  if (ms_kernels) *ms_kernels = 0;
+  if (n == 0) return 0;
+  if ((uintptr_t)dev_src & 15u) throw std::runtime_error("BGZF: the page is not 16-byte aligned");
+  Impl& S = *m_;
+  hipStream_t st = (hipStream_t)hip_stream;
+  if (!S.d_slice) {
+    std::vector<uint32_t> slice, shift;
+    S.block = bgzf_block_input();
+    build_crc_tables(slice, shift, (int)S.block / 64);
+    BGZF_HIP(hipMalloc((void**)&S.d_slice, slice.size() * 4));
+    BGZF_HIP(hipMalloc((void**)&S.d_shift, shift.size() * 4));
+    BGZF_HIP(hipMemcpy(S.d_slice, slice.data(), slice.size() * 4, hipMemcpyHostToDevice));
+    BGZF_HIP(hipMemcpy(S.d_shift, shift.data(), shift.size() * 4, hipMemcpyHostToDevice));
+    BGZF_HIP(hipEventCreate(&S.ev0));
+    BGZF_HIP(hipEventCreate(&S.ev1));
+  }
+  const uint32_t kBgzfBlockInput = S.block;
+  const uint64_t nblocks = (n + kBgzfBlockInput - 1) / kBgzfBlockInput;
+  if (nblocks >= (1ull << 31)) throw std::runtime_error("BGZF: page too large");
+  if (S.blocks_cap < nblocks + 1) {
+    BGZF_HIP(hipStreamSynchronize(st));
+    for (void* p : {(void*)S.csize, (void*)S.crc, (void*)S.bsize, (void*)S.boff}) if (p) (void)hipFree(p);
+    const size_t cap = (size_t)nblocks + (size_t)(nblocks >> 3) + 64;
+    BGZF_HIP(hipMalloc((void**)&S.csize, cap * 4)); BGZF_HIP(hipMalloc((void**)&S.crc, cap * 4));
+    BGZF_HIP(hipMalloc((void**)&S.bsize, cap * 8)); BGZF_HIP(hipMalloc((void**)&S.boff, cap * 8));
+    S.blocks_cap = cap;
+  }
+  const size_t need_slots = (size_t)nblocks * kSlotBytes + 64;
+  if (S.slots_cap < need_slots) {
+    BGZF_HIP(hipStreamSynchronize(st));
+    if (S.slots) (void)hipFree(S.slots);
+    S.slots = nullptr; S.slots_cap = 0;
+    BGZF_HIP(hipMalloc((void**)&S.slots, need_slots + (need_slots >> 4)));
+    S.slots_cap = need_slots + (need_slots >> 4);
+  }
+  BGZF_HIP(hipEventRecord(S.ev0, st));
+  if (kBgzfBlockInput == 16384u)
+    hipLaunchKernelGGL(k_bgzf_deflate<16384>, dim3((unsigned)nblocks), dim3(64), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.bsize, S.crc, (const uint32_t*)S.d_slice,
+                       (const uint32_t*)S.d_shift);
+  else
+    hipLaunchKernelGGL(k_bgzf_deflate<8192>, dim3((unsigned)nblocks), dim3(64), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.bsize, S.crc, (const uint32_t*)S.d_slice,
+                       (const uint32_t*)S.d_shift);
+  BGZF_HIP(hipMemsetAsync(S.bsize + nblocks, 0, sizeof(uint64_t), st));
+  size_t bytes = 0;
+  BGZF_HIP(rocprim::exclusive_scan(nullptr, bytes, S.bsize, S.boff, (uint64_t)0, (size_t)nblocks + 1, rocprim::plus<uint64_t>(), st));
+  if (S.temp_cap < bytes) {
+    BGZF_HIP(hipStreamSynchronize(st));
+    if (S.temp) (void)hipFree(S.temp);
+    BGZF_HIP(hipMalloc(&S.temp, bytes + 256));
+    S.temp_cap = bytes + 256;
+  }
+  BGZF_HIP(rocprim::exclusive_scan(S.temp, bytes, S.bsize, S.boff, (uint64_t)0, (size_t)nblocks + 1, rocprim::plus<uint64_t>(), st));
+  hipLaunchKernelGGL(k_bgzf_pack, dim3((unsigned)nblocks), dim3(64), 0, st, (const uint8_t*)S.slots, (const uint32_t*)S.csize, (const uint64_t*)S.boff, (const uint32_t*)S.crc, n,
+                     (uint8_t*)dev_dst, kBgzfBlockInput);
+  BGZF_HIP(hipEventRecord(S.ev1, st));
+  uint64_t total = 0;
+  BGZF_HIP(hipMemcpyAsync(&total, S.boff + nblocks, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  BGZF_HIP(hipStreamSynchronize(st));
+  if (ms_kernels) BGZF_HIP(hipEventElapsedTime(ms_kernels, S.ev0, S.ev1));
+  return total;
+}
+
+}  // namespace genomicsdb_amd

@@ -38,6 +38,8 @@ struct IntervalStats {
   int64_t num_text_slots = 0;     // (cell, type) + (record, variant call) + no-call texts
   int64_t text_pool_bytes = 0;
   uint64_t num_remap_elements = 0; // sum over re-indexed records of (calls with PL) x (merged genotypes)
+  uint64_t bytes_compressed = 0;   // BGZF output formats: bytes of the pages after compression (bytes_out stays the uncompressed size)
+  float ms_compress = 0;           // device time of the compression kernels
 };
 
 // what the engine needs to know about a staged fragment besides the columns
@@ -112,7 +114,9 @@ class DevicePipeline {
   // the same in two steps (asynchronous page production, two arenas): see gdb_pipeline.hip
   struct PageTicket { int arena = 0; const char* dev = nullptr; uint64_t nbytes = 0; void* done_event = nullptr; };   // done_event: hipEvent_t recorded behind the page's kernels
   bool begin_page(uint64_t arena_bytes, int arena_idx, PageTicket* ticket);
-  void finish_page(const PageTicket& ticket);
+  // waits for the page's kernels; for the BGZF output formats ("z" / "b") the page is then compressed in place on the device
+  // (kernels/gdb_bgzf.hip) and ticket.nbytes becomes the size of the compressed page
+  void finish_page(PageTicket& ticket);
   // hip_event (hipEvent_t) marks the consumer's last read of the arena; the next begin_page() into it waits for the event on the compute stream
   void set_arena_release_event(int arena_idx, void* hip_event);
   const IntervalStats& interval_stats() const;

@@ -28,6 +28,7 @@
 #include "../core/gdb_stages.hpp"
 #include "../core/gdb_bcf.hpp"
 #include "gdb_pipeline.h"
+#include "gdb_bgzf.h"
 
 namespace genomicsdb_amd {
 
@@ -2389,6 +2390,7 @@ struct DevicePipeline::Impl {
   DevBuf<uint32_t> lut_len, i2m_off; DevBuf<int8_t> i2m, gt_override; DevBuf<uint8_t> iflags;
   DevBuf<uint8_t> num_alleles, rflags; DevBuf<uint32_t> fmt_mask, prefix_len; DevBuf<char> site_staging, spill_buf; DevBuf<int32_t> spill_chunk; DevBuf<unsigned int> spill_next;
   DevBuf<uint64_t> chunk_size, chunk_off, rec_off; DevBuf<unsigned long long> max_record;
+  std::unique_ptr<BgzfDeviceCompressor> bgzf;   // output formats "z" / "b"
   DevBuf<char> arena[2], temp;       // two output arenas: a consumer drains one while the next page is assembled into the other
   DevBuf<uint32_t> err; DevBuf<int32_t> counters;
   int ctx_slot = -1;                 // this pipeline's element of c_ex
@@ -4113,9 +4115,10 @@ bool DevicePipeline::begin_page(uint64_t arena_bytes, int arena_idx, PageTicket*
     page_bytes = rec_off[(size_t)ke] - page_base;
   }
   if (S.arena_release[ai]) { HIP_CHECK(hipStreamWaitEvent(st, S.arena_release[ai], 0)); S.arena_release[ai] = nullptr; }
-  if (S.arena[ai].cap < page_bytes + 64) {   // (re)allocation frees memory a copy may still read: the stream has to be idle
+  if (S.arena[ai].cap < (S.hp.bgzf ? bgzf_bound(page_bytes) : page_bytes) + 64) {   // (re)allocation frees memory a copy may still read: the stream has to be idle
     HIP_CHECK(hipStreamSynchronize(st));
-    S.arena[ai].ensure(std::min<uint64_t>(arena_cap, iv.stats.bytes_out) + 64);
+    const uint64_t want = std::min<uint64_t>(arena_cap, iv.stats.bytes_out);
+    S.arena[ai].ensure((S.hp.bgzf ? bgzf_bound(want) : want) + 64);      // (a page of incompressible bytes grows by the block framing)
   }
   char* const arena = S.arena[ai].p;
   const int64_t np = ke - kp;
@@ -4195,7 +4198,7 @@ bool DevicePipeline::begin_page(uint64_t arena_bytes, int arena_idx, PageTicket*
   return true;
 }
 
-void DevicePipeline::finish_page(const PageTicket& ticket) {
+void DevicePipeline::finish_page(PageTicket& ticket) {
   Impl& S = *m_;
   Impl::IntervalState& iv = S.iv;
   hipEvent_t* w = S.ev_page[ticket.arena & 1];
@@ -4211,6 +4214,14 @@ void DevicePipeline::finish_page(const PageTicket& ticket) {
   iv.stats.pages++;
   iv.stats.ms_total = iv.stats.ms_sweep + iv.stats.ms_site + iv.stats.ms_size + iv.stats.ms_write;
   if (iv.stats.err_bits) throw GenomicsDBDeviceException(err_bits_text(iv.stats.err_bits));
+  if (S.hp.bgzf && ticket.nbytes) {     // "z" / "b": only compressed bytes leave the GPU
+    if (!S.bgzf) S.bgzf.reset(new BgzfDeviceCompressor);
+    float ms = 0;
+    ticket.nbytes = S.bgzf->compress(ticket.dev, ticket.nbytes, const_cast<char*>(ticket.dev), (void*)S.stream, &ms);
+    iv.stats.bytes_compressed += ticket.nbytes;
+    iv.stats.ms_compress += ms;
+    iv.stats.ms_total += ms;
+  }
 }
 
 void DevicePipeline::set_arena_release_event(int arena_idx, void* hip_event) { m_->arena_release[arena_idx & 1] = (hipEvent_t)hip_event; }

@@ -55,6 +55,17 @@ void* gdb_mi355_init_from_memory(const char* query_json_text, const uint8_t* cel
                                  int produce_header_only);
 void* gdb_mi355_init_from_memory_format(const char* query_json_text, const uint8_t* cells, uint64_t cells_nbytes, uint64_t buffer_capacity,
                                         int produce_header_only, int is_bcf, int use_missing_values_only_not_vector_end, int keep_idx_fields_in_bcf_header);
+/* The same two with the reference's vcf_output_format string instead of the JNI's is_bcf flag: "" VCF text, "bu" BCF2, and the
+ * BGZF-compressed flavours "z" (VCF text) / "b" (BCF2) that its VCFAdapter writes through htslib (vcf_adapter.cc:340-372,
+ * genomicsdb_config_base.cc:34,156-165).  "z" / "b": header = one BGZF block (host), body = BGZF blocks of 16 320 input bytes
+ * deflated ON THE DEVICE (only compressed bytes cross PCIe), then the 28-byte EOF block.  The compressed bytes are this build's
+ * own; the inflated stream equals the "" / "bu" stream. */
+void* gdb_mi355_init_output_format(const char* loader_json_file, const char* query_json_file, const char* chr, int start, int end, int rank,
+                                   uint64_t buffer_capacity, uint64_t segment_size, const char* output_format, int produce_header_only,
+                                   int use_missing_values_only_not_vector_end, int keep_idx_fields_in_bcf_header);
+void* gdb_mi355_init_from_memory_output_format(const char* query_json_text, const uint8_t* cells, uint64_t cells_nbytes, uint64_t buffer_capacity,
+                                               int produce_header_only, const char* output_format, int use_missing_values_only_not_vector_end,
+                                               int keep_idx_fields_in_bcf_header);
 uint64_t gdb_mi355_close(void* handle);                         /* jniGenomicsDBClose */
 uint64_t gdb_mi355_get_num_bytes_available(void* handle);       /* jniGenomicsDBGetNumBytesAvailable: buffer capacity */
 int gdb_mi355_read_next_byte(void* handle);                     /* jniGenomicsDBReadNextByte: byte or -1 */
@@ -85,6 +96,8 @@ typedef struct gdbamd_interval_stats {
   int32_t num_record_types, reserved0;   /* entry text table: distinct record types, slots, pool bytes */
   int64_t num_text_slots, text_pool_bytes;
   uint64_t num_remap_elements;           /* sum over re-indexed records of (calls with PL) x (merged genotypes): the PL remap work */
+  uint64_t bytes_compressed;             /* output formats "z" / "b": bytes of the pages after BGZF compression (bytes_out: before) */
+  float ms_compress; int32_t reserved1;  /* device time of the compression kernels */
 } gdbamd_interval_stats;
 
 /* one attribute column in device memory; off == NULL for fixed-length attributes */
@@ -92,6 +105,10 @@ typedef struct gdbamd_device_column { const void* data; const uint32_t* off; } g
 
 void* gdbamd_engine_create(const char* query_json_text, int device);          /* NULL on error */
 void* gdbamd_engine_create_format(const char* query_json_text, int device, int is_bcf, int use_missing_values_only_not_vector_end);  /* pages hold BCF2 records */
+void* gdbamd_engine_create_output_format(const char* query_json_text, int device, const char* output_format, int use_missing_values_only_not_vector_end);  /* "", "bu", "z", "b": with "z" / "b" the pages hold BGZF blocks (no header, no EOF block) */
+/* n host bytes as BGZF blocks (no EOF block), compressed by the device kernels; gdbamd_bgzf_bound(n) bytes of dst always suffice */
+int gdbamd_bgzf_compress(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t dst_cap, uint64_t* dst_len, float* ms_kernels);
+uint64_t gdbamd_bgzf_bound(uint64_t n);
 void gdbamd_engine_destroy(void* engine);
 int gdbamd_engine_num_fields(void* engine);                                     /* plan fields = staged attribute columns */
 const char* gdbamd_engine_field_name(void* engine, int f);                      /* array attribute name of plan field f */

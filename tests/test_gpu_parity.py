@@ -52,10 +52,10 @@ def test_stream_small_pages(gdb, case, monkeypatch):
 
 
 def test_unsupported_configurations_fail_loudly(gdb, tmp_path):
-    """compressed BCF is not produced by this build: errors, never silent fallbacks"""
+    """an output format htslib does not know: an error, never a silent fallback ("z" / "b" are written: tests/test_bgzf.py)"""
     case = CASES[0]
     qj, _ = helpers.query_json(case[1], case[2], case[3], case[5])
-    qj["vcf_output_format"] = "b"     # BGZF-compressed BCF: only "" (text) and "bu" are streamed
+    qj["vcf_output_format"] = "zz"
     import subprocess, os, json as _json
     qf = tmp_path / "q.json"
     (tmp_path / "ws" / "a").mkdir(parents=True)
