@@ -44,6 +44,8 @@ def main():
                     help="c3 shape: the array is NOT resident - its cells pass through HBM in column windows of the staging budget "
                          "(GDBAMD_STAGE_BUDGET_MB) with carry-over; one pass over --interval-bp, --steps / --warmup are ignored")
     ap.add_argument("--no-stream", action="store_true", help="skip the end-to-end leg through the query stream (gdb_mi355_read)")
+    ap.add_argument("--no-c3", action="store_true", help="skip the c3-shape leg (10 000 samples streamed through HBM in column windows)")
+    ap.add_argument("--c3-bp", type=int, default=10_000_000, help="columns of the c3-shape leg (10 000 samples: 14.6 GB of cells per Mb, generated into host memory first)")
     ap.add_argument("--cpu-sample-bp", type=int, default=12000, help="columns of the bounded CPU-baseline sample (~15 s of oracle time)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rank set-up, partition arithmetic and the cross-rank reduction only, no device work and no number: "
@@ -167,6 +169,17 @@ def main():
             eng.close()                                                 # (the timed engine's HBM - fragment, 48 GB arena, tables - is given back first)
             out["stream_end_to_end"] = stream_end_to_end(N, B, min(W, Lbp), tmp, expect_body_bytes=None)
             out["stream_end_to_end_bgzf"] = stream_end_to_end(N, B, min(W, Lbp), tmp, expect_body_bytes=None, output_format="z")
+        if not args.no_c3 and world == 1 and not args.bcf:
+            # BASELINE configs[2] shape in the default line: 10 000 samples, the array does NOT fit next to the working buffers and
+            # passes through HBM in column windows with carry-over; the input path (host memory -> HBM) is inside the timed region
+            import copy
+            try:
+                eng.close()
+            except Exception:
+                pass
+            a3 = copy.copy(args)
+            a3.samples, a3.interval_bp, a3.window_bp, a3.arena_mb = 10000, args.c3_bp, 50_000, 49152
+            out["c3_streamed"] = run_streamed(a3, 0, 1, device_index, backend, source="memory", emit=False)
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(N, args.cpu_sample_bp, tmp)
     if out is not None:
@@ -208,7 +221,7 @@ def dry_run(args, rank, world, backend):
         dist.destroy_process_group()
 
 
-def run_streamed(args, rank, world, device_index, backend):
+def run_streamed(args, rank, world, device_index, backend, source="callback", emit=True):
     """BASELINE configs[2] shape (10 000 samples x chr1): the cells do not fit HBM next to the working buffers, so they are
     handed to the engine chunk by chunk (here straight from the synthetic generator, as a cell callback), staged in column
     windows of the staging budget, and the intervals still live at a window's end are carried into the next window on the
@@ -239,7 +252,30 @@ def run_streamed(args, rank, world, device_index, backend):
         state["bytes"] += n
         state["cells"] += nc
         return p, n
-    eng.open_cell_callback(next_chunk)
+    t_pregen = 0.0
+    keep = None
+    if source == "memory":
+        # the array in host memory first (untimed): what is timed is host memory -> HBM staging (window w + 1 while window w
+        # computes) + scan + combine; the generator is not part of the path being measured
+        import numpy as np
+        tg = time.time()
+        cap = int(N * Lbp / 106.0 * 160.0 * 1.10) + (64 << 20)       # ~153 bytes per cell, one cell per ~106 bp and sample
+        keep = np.empty(cap, dtype=np.uint8)
+        at = 0
+        while True:
+            r = next_chunk()
+            if r is None:
+                break
+            if at + r[1] > cap:
+                raise RuntimeError("c3 leg: the generated cells exceed the estimated buffer")
+            ctypes.memmove(keep.ctypes.data + at, r[0], r[1])
+            at += r[1]
+        keep = keep[:at]
+        t_pregen = time.time() - tg
+        state["gen_s"] = 0.0
+        eng.open_memory_cells((keep.ctypes.data, keep.nbytes))
+    else:
+        eng.open_cell_callback(next_chunk)
     eng.set_reference(B, synth.reference(B, Lbp + 4096))
     arena = args.arena_mb << 20
     if world > 1:
@@ -294,9 +330,15 @@ def run_streamed(args, rank, world, device_index, backend):
             "roofline": {"bound": "hbm", "kernel": "k_assemble_write", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_launch": alg, "avg_launch_ms": avg_ms, "launches": int(launches)},
         }
+        out["config"]["source"] = "host memory (generated before the timed region, %.1f s)" % t_pregen if source == "memory" else "cell callback (generator inside the timed region)"
+        out["config"]["overlapped_staging"] = os.environ.get("GDBAMD_OVERLAP_STAGING", "1") != "0"
+        eng.close()
+        if not emit:
+            return out
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 and emit:
         dist.destroy_process_group()
+    return None
 
 
 def stream_end_to_end(N, B, W, tmp, expect_body_bytes=None, output_format=None):

@@ -203,7 +203,7 @@ int gdbamd_engine_staged_info(void* e, int64_t* ncells, uint64_t* reference_cell
   return 0;
 }
 int gdbamd_engine_set_reference(void* e, int64_t begin, const char* bases, uint64_t len) {
-  return guarded([&]() -> int { ((EngineHandle*)e)->eng->pipeline().set_reference_window(begin, std::string(bases, len)); return 0; }, 1);
+  return guarded([&]() -> int { ((EngineHandle*)e)->eng->set_reference_window(begin, std::string(bases, len)); return 0; }, 1);
 }
 
 namespace {

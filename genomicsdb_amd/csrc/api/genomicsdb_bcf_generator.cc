@@ -24,6 +24,7 @@ CombineEngine::CombineEngine(const mini_json::Value& query_json, int device, con
   std::string tmpl;
   if (!m_qc.get_vcf_header_filename().empty()) tmpl = mini_json::read_text_file(m_qc.get_vcf_header_filename());
   m_hp = build_combine_plan(m_qc, tmpl, output_format, use_missing_values_only_not_vector_end);
+  m_device = device;
   m_pipe.reset(new DevicePipeline(m_hp, device));
   if (!m_qc.get_reference_genome().empty()) m_ref.initialize(m_qc.get_reference_genome());
 }
@@ -35,6 +36,7 @@ CombineEngine::CombineEngine(const VariantQueryConfig& query_config, int device,
   std::string tmpl;
   if (!m_qc.get_vcf_header_filename().empty()) tmpl = mini_json::read_text_file(m_qc.get_vcf_header_filename());
   m_hp = build_combine_plan(m_qc, tmpl, output_format, use_missing_values_only_not_vector_end);
+  m_device = device;
   m_pipe.reset(new DevicePipeline(m_hp, device));
   if (!m_qc.get_reference_genome().empty()) m_ref.initialize(m_qc.get_reference_genome());
 }
@@ -46,6 +48,7 @@ void CombineEngine::stage_cells(const uint8_t* cells, uint64_t nbytes) {
 }
 
 void CombineEngine::stage_cells_begin() {
+  (void)join_prefetch(false);
   reference_cell_bytes = 0; num_cells = 0; has_cells = false; min_begin = INT64_MAX; max_end = 0;
   if (m_src.fd >= 0) { ::close(m_src.fd); m_src.fd = -1; }
   m_src.kind = SRC_NONE;
@@ -100,6 +103,7 @@ void CombineEngine::save_fragment(const std::string& path, bool compress) {
   m_pipe->save_fragment(path, meta, compress);
 }
 void CombineEngine::load_fragment(const std::string& path) {
+  (void)join_prefetch(false);
   // the file holds QUERY row indices: it only fits a query over all rows of the array in callset order
   const VariantQueryConfig& qc = m_qc;
   for (uint64_t q = 0; q < qc.get_num_rows_to_query(); ++q)
@@ -111,6 +115,7 @@ void CombineEngine::load_fragment(const std::string& path) {
 
 // ---- windowed array access ------------------------------------------------------------------------------------------------
 CombineEngine::~CombineEngine() {
+  try { (void)join_prefetch(false); } catch (...) {}
   if (m_src.fd >= 0) ::close(m_src.fd);
   if (m_src.chunk) (void)hipHostFree(m_src.chunk);
 }
@@ -122,6 +127,7 @@ uint64_t CombineEngine::staging_budget_bytes() const {
 }
 
 void CombineEngine::open_memory_cells(const uint8_t* cells, uint64_t nbytes) {
+  (void)join_prefetch(false);
   if (m_src.fd >= 0) ::close(m_src.fd);
   const Source keep = m_src;
   m_src = Source();
@@ -131,6 +137,7 @@ void CombineEngine::open_memory_cells(const uint8_t* cells, uint64_t nbytes) {
 }
 
 void CombineEngine::open_cell_callback(CellChunkFn fn, void* user) {
+  (void)join_prefetch(false);
   if (m_src.fd >= 0) ::close(m_src.fd);
   const Source keep = m_src;
   m_src = Source();
@@ -140,6 +147,7 @@ void CombineEngine::open_cell_callback(CellChunkFn fn, void* user) {
 }
 
 void CombineEngine::open_array(const std::string& dir) {
+  (void)join_prefetch(false);
   if (m_src.fd >= 0) ::close(m_src.fd);
   const Source keep = m_src;
   m_src = Source();
@@ -175,14 +183,20 @@ void CombineEngine::open_array(const std::string& dir) {
 
 void CombineEngine::rewind_source() {
   m_src.cursor = 0; m_src.cell_cursor = 0; m_src.window_valid = false; m_src.eof = false; m_src.cov = Coverage{INT64_MIN, INT64_MIN};
+  m_src.pending_valid = false; m_window_eof = false;
   reference_cell_bytes = 0; num_cells = 0; has_cells = false;
   if (m_src.kind != SRC_FRAGMENT_FILE) { min_begin = INT64_MAX; max_end = 0; }
 }
 
-void CombineEngine::advance_window() {
+// Stages the next column window of the source into `dst`; the cells still live at `carry_from` come from the fragment `carry_src`
+// holds (dst itself, or - overlapped staging - the pipeline that is computing on the previous window).  Touches the source's
+// cursors and `r` only: the engine's counters and the coverage are updated by whoever takes the window into use.
+void CombineEngine::stage_window(DevicePipeline& dst, DevicePipeline& carry_src, int64_t carry_from, StagedWindow& r) {
   Source& S = m_src;
-  const int64_t carry_from = S.window_valid ? S.cov.hi + 1 : INT64_MIN;
-  m_pipe->begin_staging(carry_from);
+  DevicePipeline* const m_pipe = &dst;                      // (everything below stages into dst)
+  uint64_t& reference_cell_bytes = r.reference_cell_bytes;
+  int64_t& min_begin = r.min_begin; int64_t& max_end = r.max_end;
+  dst.begin_staging_from(carry_src, carry_from);
   const uint64_t budget = staging_budget_bytes();
   int64_t next_begin = INT64_MAX, new_cells = 0;
   if (S.kind == SRC_FRAGMENT_FILE) {
@@ -258,23 +272,84 @@ void CombineEngine::advance_window() {
     if (S.eof) next_begin = INT64_MAX;
   }
   m_pipe->finish_staging();
-  num_cells += new_cells;
-  has_cells = new_cells + m_pipe->carried_cells() > 0;
-  if (carry_from != INT64_MIN && min_begin != INT64_MAX) min_begin = std::min(min_begin, carry_from);
+  r.new_cells = new_cells;
+  r.has_cells = new_cells + m_pipe->carried_cells() > 0;
+  r.carry_from = carry_from;
+  r.hi = next_begin == INT64_MAX ? INT64_MAX - 1 : next_begin - 1;
+  r.eof = S.eof;
+}
+
+void CombineEngine::take_window(const StagedWindow& r) {
+  Source& S = m_src;
+  reference_cell_bytes += r.reference_cell_bytes;
+  num_cells += r.new_cells;
+  has_cells = r.has_cells;
+  if (r.min_begin != INT64_MAX) min_begin = std::min(min_begin, r.min_begin);
+  max_end = std::max(max_end, r.max_end);
+  if (r.carry_from != INT64_MIN && min_begin != INT64_MAX) min_begin = std::min(min_begin, r.carry_from);
   S.cov.lo = S.window_valid ? S.cov.hi + 1 : INT64_MIN;
-  S.cov.hi = next_begin == INT64_MAX ? INT64_MAX - 1 : next_begin - 1;
+  S.cov.hi = r.hi;
   S.window_valid = true;
+  m_window_eof = r.eof;
   ++windows_staged;
 }
+
+// Overlapped staging: while the caller computes on the window in m_pipe, a thread stages the next one into m_pipe2 (its own HIP
+// stream, device blocks from its own pool, carried cells read from m_pipe's fragment); cover() then only swaps the two.  For the
+// sources that are parsed on the way in (cells.bin, cells in memory, cell callback); GDBAMD_OVERLAP_STAGING=0 switches it off.
+bool CombineEngine::overlap_enabled() const {
+  if (const char* e = getenv("GDBAMD_OVERLAP_STAGING")) if (*e == '0') return false;
+  return m_src.kind == SRC_CELLS_FILE || m_src.kind == SRC_CELLS_MEMORY || m_src.kind == SRC_CALLBACK;
+}
+void CombineEngine::start_prefetch() {
+  if (m_prefetch.joinable() || m_src.eof || !overlap_enabled()) return;
+  if (!m_pipe2) m_pipe2.reset(new DevicePipeline(m_hp, m_device));
+  (void)layout();                                            // (built here, not on the thread)
+  const int64_t carry_from = m_src.cov.hi + 1;
+  m_next = StagedWindow();
+  m_prefetch_error = nullptr;
+  m_prefetch = std::thread([this, carry_from]() {
+    try { stage_window(*m_pipe2, *m_pipe, carry_from, m_next); }
+    catch (...) { m_prefetch_error = std::current_exception(); }
+  });
+}
+bool CombineEngine::join_prefetch(bool take) {
+  if (!m_prefetch.joinable()) return false;
+  m_prefetch.join();
+  if (m_prefetch_error) { std::exception_ptr e = m_prefetch_error; m_prefetch_error = nullptr; std::rethrow_exception(e); }
+  if (!take) return false;
+  std::swap(m_pipe, m_pipe2);
+  ++pipeline_generation;
+  if (m_user_ref && !m_pipe_has_user_ref[pipeline_generation & 1]) { m_pipe->set_reference_window(m_user_ref_begin, m_user_ref_bases); m_pipe_has_user_ref[pipeline_generation & 1] = true; }
+  take_window(m_next);
+  return true;
+}
+
+void CombineEngine::advance_window() {
+  if (join_prefetch(true)) { start_prefetch(); return; }
+  StagedWindow r;
+  stage_window(*m_pipe, *m_pipe, m_src.window_valid ? m_src.cov.hi + 1 : INT64_MIN, r);
+  take_window(r);
+  start_prefetch();
+}
+
 
 CombineEngine::Coverage CombineEngine::cover(int64_t column) {
   if (m_src.kind == SRC_NONE) return Coverage{INT64_MIN, INT64_MAX - 1};   // staged by hand (stage_cells*, load_fragment, adopt): all of it
   if (m_src.window_valid && column < m_src.cov.lo) {                       // an earlier interval than the current window: start over
     if (m_src.kind == SRC_CALLBACK) throw GenomicsDBConfigException("a cell callback source is read once, front to back");
+    (void)join_prefetch(false);                                              // (a window staged ahead is dropped with the cursors)
     rewind_source();
   }
-  while (!m_src.window_valid || (column > m_src.cov.hi && !m_src.eof)) advance_window();
+  // (m_window_eof: the window in use is the source's last one; m_src.eof may already be true for the one being staged ahead)
+  while (!m_src.window_valid || (column > m_src.cov.hi && !m_window_eof)) advance_window();
   return m_src.cov;
+}
+
+void CombineEngine::set_reference_window(int64_t begin, const std::string& bases) {
+  m_user_ref = true; m_user_ref_begin = begin; m_user_ref_bases = bases;
+  m_pipe->set_reference_window(begin, bases);
+  m_pipe_has_user_ref[pipeline_generation & 1] = true; m_pipe_has_user_ref[(pipeline_generation + 1) & 1] = false;
 }
 
 void CombineEngine::stage_reference_for(int64_t qb, int64_t qe) {
@@ -374,7 +449,7 @@ uint64_t GenomicsDBBCFGenerator::device_page_bytes() const {
 // Makes m_page the next page of the stream (kernels complete) and starts the assembly of the one behind it.
 bool GenomicsDBBCFGenerator::advance_page() {
   if (m_done) return false;
-  DevicePipeline& pipe = m_engine->pipeline();
+  // (m_engine->pipeline() is looked up at every use: cover() may swap the engine's two pipelines - overlapped staging)
   VariantQueryConfig& qc = m_engine->query_config();
   const unsigned nint = std::max(1u, qc.get_num_column_intervals());
   const uint64_t page_cap = device_page_bytes();
@@ -395,29 +470,30 @@ bool GenomicsDBBCFGenerator::advance_page() {
       const auto t0 = now();
       const CombineEngine::Coverage cov = m_engine->cover(m_piece_begin);
       const auto t1 = now();
-      const int64_t pe = pipe.split_point(m_piece_begin, std::min(qe, cov.hi), max_window_columns());
+      const int64_t pe = m_engine->pipeline().split_point(m_piece_begin, std::min(qe, cov.hi), max_window_columns());
       const auto t2 = now();
       m_engine->stage_reference_for(m_piece_begin, pe);
       const auto t3 = now();
-      pipe.prepare_interval(m_piece_begin, pe);
+      m_engine->pipeline().prepare_interval(m_piece_begin, pe);
       if (trace) fprintf(stderr, "[gdbamd stream] piece [%lld, %lld]: cover %.3f s, split_point %.3f s, reference %.3f s, prepare_interval %.3f s\n", (long long)m_piece_begin, (long long)pe,
                          secs(t0, t1), secs(t1, t2), secs(t2, t3), secs(t3, now()));
       m_piece_end = pe;
       m_interval_end = qe;
       m_interval_active = true;
     }
-    if (pipe.begin_page(page_cap, m_arena_toggle, &m_page)) { m_arena_toggle ^= 1; have = true; }
+    if (m_engine->pipeline().begin_page(page_cap, m_arena_toggle, &m_page)) { m_arena_toggle ^= 1; have = true; }
     else {
       m_interval_active = false;
       if (m_piece_end >= m_interval_end) { ++m_query_column_interval_idx; m_piece_begin = INT64_MIN; }
       else m_piece_begin = m_piece_end + 1;
     }
   }
-  pipe.finish_page(m_page);
+  m_engine->pipeline().finish_page(m_page);
+  m_page_owner = &m_engine->pipeline();
   // the page behind it goes into the other arena while this one drains (pages of the next piece follow once this piece is done:
   // prepare_interval needs the host)
   if (m_interval_active) {
-    if (pipe.begin_page(page_cap, m_arena_toggle, &m_next_page)) { m_arena_toggle ^= 1; m_next_valid = true; }
+    if (m_engine->pipeline().begin_page(page_cap, m_arena_toggle, &m_next_page)) { m_arena_toggle ^= 1; m_next_valid = true; }
     else {
       m_interval_active = false;
       if (m_piece_end >= m_interval_end) { ++m_query_column_interval_idx; m_piece_begin = INT64_MIN; }
@@ -478,7 +554,7 @@ void GenomicsDBBCFGenerator::fill_ring() {
     m_page_off += n;
     if (m_page_off >= m_page.nbytes) {   // last chunk of the page: the arena may be overwritten once this copy is through
       GEN_HIP(hipEventRecord((hipEvent_t)m_arena_read[m_page.arena], (hipStream_t)m_copy_stream));
-      m_engine->pipeline().set_arena_release_event(m_page.arena, m_arena_read[m_page.arena]);
+      m_page_owner->set_arena_release_event(m_page.arena, m_arena_read[m_page.arena]);   // (the pipeline that assembled the page: the engine may have swapped since)
       m_page_valid = false;
     }
   }

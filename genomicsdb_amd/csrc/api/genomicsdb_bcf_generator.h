@@ -3,7 +3,9 @@
 // combined-gVCF body of every query column interval, produced in batches of at most buffer_capacity bytes.
 #pragma once
 #include <memory>
+#include <exception>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../kernels/gdb_pipeline.h"
@@ -52,8 +54,12 @@ class CombineEngine {
   Coverage cover(int64_t column);                               // stages windows until `column` is covered
   uint64_t staging_budget_bytes() const;
   int64_t windows_staged = 0;
+  uint64_t pipeline_generation = 0;   // counts the swaps of the two pipelines (overlapped staging): pipeline() is another object afterwards
   int64_t num_cells = 0;
   void stage_reference_for(int64_t qb, int64_t qe);
+  // reference bases given by the caller for columns [begin, begin + bases.size()): kept, so that the pipeline a later window is
+  // staged into (overlapped staging) sees them too
+  void set_reference_window(int64_t begin, const std::string& bases);
   uint64_t reference_cell_bytes = 0;
   int64_t min_begin = 0, max_end = 0;
   bool has_cells = false;
@@ -61,7 +67,9 @@ class CombineEngine {
  private:
   VariantQueryConfig m_qc;
   HostPlan m_hp;
-  std::unique_ptr<DevicePipeline> m_pipe;
+  std::unique_ptr<DevicePipeline> m_pipe;       // the pipeline whose fragment is in use
+  std::unique_ptr<DevicePipeline> m_pipe2;      // overlapped staging: the next column window is staged here meanwhile
+  int m_device = 0;
   std::unique_ptr<CellStreamLayout> m_layout;   // attribute order, plan-field map, row map of the binary cell stream
   ReferenceGenomeInfo m_ref;
   const CellStreamLayout& layout();
@@ -82,6 +90,22 @@ class CombineEngine {
   } m_src;
   void rewind_source();
   void advance_window();
+  // one staged column window, before it is taken into use
+  struct StagedWindow {
+    int64_t hi = INT64_MIN, carry_from = INT64_MIN, new_cells = 0, min_begin = INT64_MAX, max_end = 0;
+    uint64_t reference_cell_bytes = 0;
+    bool has_cells = false, eof = false;
+  };
+  void stage_window(DevicePipeline& dst, DevicePipeline& carry_src, int64_t carry_from, StagedWindow& r);
+  void take_window(const StagedWindow& r);
+  bool overlap_enabled() const;
+  void start_prefetch();
+  bool join_prefetch(bool take);
+  std::thread m_prefetch;
+  std::exception_ptr m_prefetch_error;
+  StagedWindow m_next;
+  bool m_window_eof = false;
+  bool m_user_ref = false, m_pipe_has_user_ref[2] = {false, false}; int64_t m_user_ref_begin = 0; std::string m_user_ref_bases;
 };
 
 class GenomicsDBBCFGenerator {
@@ -129,6 +153,7 @@ class GenomicsDBBCFGenerator {
   void* m_copy_stream = nullptr;                  // hipStream_t
   void* m_arena_read[2] = {nullptr, nullptr};     // hipEvent_t: last copy out of arena i
   DevicePipeline::PageTicket m_page, m_next_page;
+  DevicePipeline* m_page_owner = nullptr;
   bool m_page_valid = false, m_next_valid = false;
   uint64_t m_page_off = 0;
   int m_arena_toggle = 0;

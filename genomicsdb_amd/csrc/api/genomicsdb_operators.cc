@@ -138,7 +138,7 @@ void VariantQueryProcessor::scan_and_operate(const int, const VariantQueryConfig
   }
   const uint64_t page_bytes = gvcf && dynamic_cast<VCFSerializedBufferAdapter*>(&gvcf->get_vcf_adapter()) ? std::max<uint64_t>(1, query_config.get_combined_vcf_records_buffer_size_limit())
                                                                                                           : (uint64_t)256 << 20;
-  DevicePipeline& pipe = eng.pipeline();
+  // (eng.pipeline() is looked up at every use: cover() may swap the engine's two pipelines - overlapped staging)
   if (!E.copy) {
     OPS_HIP(hipStreamCreateWithFlags(&E.copy, hipStreamNonBlocking));
     for (int i = 0; i < 2; ++i) { OPS_HIP(hipEventCreateWithFlags(&E.chunk_done[i], hipEventDisableTiming)); OPS_HIP(hipEventCreateWithFlags(&E.arena_read[i], hipEventDisableTiming)); }
@@ -148,20 +148,20 @@ void VariantQueryProcessor::scan_and_operate(const int, const VariantQueryConfig
       if (st.m_piece_begin > st.m_interval_end) { st.m_done = true; return; }
       const CombineEngine::Coverage cov = eng.cover(st.m_piece_begin);
       const int64_t n = std::max<int64_t>(1, (int64_t)eng.plan().plan.num_query_rows);
-      const int64_t pe = pipe.split_point(st.m_piece_begin, std::min(st.m_interval_end, cov.hi), std::max<int64_t>(1000, (int64_t)(48ll << 30) / (n * 64)));
+      const int64_t pe = eng.pipeline().split_point(st.m_piece_begin, std::min(st.m_interval_end, cov.hi), std::max<int64_t>(1000, (int64_t)(48ll << 30) / (n * 64)));
       eng.stage_reference_for(st.m_piece_begin, pe);
-      pipe.prepare_interval(st.m_piece_begin, pe);
+      eng.pipeline().prepare_interval(st.m_piece_begin, pe);
       st.m_piece_begin = pe + 1;             // (the piece in flight is remembered by the pipeline)
       st.m_piece_active = true;
       E.next_valid = false;
     }
     DevicePipeline::PageTicket page;
     if (E.next_valid) { page = E.next; E.next_valid = false; }
-    else if (pipe.begin_page(page_bytes, E.toggle, &page)) E.toggle ^= 1;
+    else if (eng.pipeline().begin_page(page_bytes, E.toggle, &page)) E.toggle ^= 1;
     else { st.m_piece_active = false; continue; }
-    pipe.finish_page(page);
+    eng.pipeline().finish_page(page);
     // the page behind it is assembled in the other arena while this one is handed over
-    if (pipe.begin_page(page_bytes, E.toggle, &E.next)) { E.toggle ^= 1; E.next_valid = true; }
+    if (eng.pipeline().begin_page(page_bytes, E.toggle, &E.next)) { E.toggle ^= 1; E.next_valid = true; }
     else st.m_piece_active = false;          // the piece is exhausted; the page in hand is its last
     if (batched) batched->operate_on_page(page.dev, page.nbytes, qc.get_num_column_intervals() ? qc.get_column_begin(column_interval_idx) : 0, st.m_interval_end);
     else {
@@ -186,7 +186,7 @@ void VariantQueryProcessor::scan_and_operate(const int, const VariantQueryConfig
       }
       if (k > 0) {
         OPS_HIP(hipEventRecord(E.arena_read[page.arena & 1], E.copy));      // the arena may be written again once the last chunk has left
-        pipe.set_arena_release_event(page.arena, E.arena_read[page.arena & 1]);
+        eng.pipeline().set_arena_release_event(page.arena, E.arena_read[page.arena & 1]);
         OPS_HIP(hipEventSynchronize(E.chunk_done[(k - 1) & 1]));
         gvcf->get_vcf_adapter().handoff(E.pin[(k - 1) & 1], (size_t)prev_len);
       }

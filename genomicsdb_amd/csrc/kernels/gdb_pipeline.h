@@ -66,6 +66,9 @@ class DevicePipeline {
   // carry_from != INT64_MIN: the cells of the fragment staged so far whose intervals reach column carry_from (at most one per
   // sample) open the new fragment - windowed streaming of an array larger than the staging budget
   void begin_staging(int64_t carry_from = INT64_MIN);
+  // the same, with the carried cells taken from the fragment `source` (another pipeline of the same plan and device) has staged;
+  // `source` may go on computing on that fragment meanwhile (overlapped staging of the next column window)
+  void begin_staging_from(DevicePipeline& source, int64_t carry_from);
   int64_t carried_cells() const;
   void append_fragment(const HostFragment& hf);
   // the same from the reference's binary cell stream: the bytes are copied to HBM as they are and taken apart there

@@ -59,6 +59,28 @@ namespace {
 constexpr int kBlock = 256;          // threads per workgroup = 4 wavefronts of 64
 constexpr int kCountSpread = 64;     // addresses a device-wide counter is spread over
 
+// Device blocks of the staging path (the parts of a fragment being staged, the merged fragment) are kept and handed out again:
+// hipFree synchronises the whole device, and with a second pipeline staging the next column window while this one computes
+// (CombineEngine's overlapped staging) a free on the staging thread would wait for - and serialise with - the page kernels.
+struct BlockPool {
+  struct Block { void* p; size_t cap; bool used; };
+  std::vector<Block> blocks;
+  void* get(size_t bytes) {
+    bytes = std::max<size_t>(bytes, 256);
+    int best = -1;
+    for (size_t i = 0; i < blocks.size(); ++i)
+      if (!blocks[i].used && blocks[i].cap >= bytes && (best < 0 || blocks[i].cap < blocks[(size_t)best].cap)) best = (int)i;
+    if (best >= 0 && blocks[(size_t)best].cap <= 2 * bytes + ((size_t)4 << 20)) { blocks[(size_t)best].used = true; return blocks[(size_t)best].p; }
+    void* d = nullptr;
+    const size_t cap = (bytes + bytes / 8 + 255) & ~(size_t)255;
+    HIP_CHECK(hipMalloc(&d, cap));
+    blocks.push_back(Block{d, cap, true});
+    return d;
+  }
+  void put(void* p) { for (auto& b : blocks) if (b.p == p) { b.used = false; return; } if (p) (void)hipFree(p); }
+  void release_all() { for (auto& b : blocks) (void)hipFree(b.p); blocks.clear(); }
+};
+
 template <class T> struct DevBuf {   // grow-only device allocation
   T* p = nullptr;
   size_t cap = 0;
@@ -2509,7 +2531,9 @@ struct DevicePipeline::Impl {
   // the change-list flavour keeps the interval's order for all its pages (pages that do not fall on order blocks re-sort `order`)
   DevBuf<int32_t> order_iv; bool order_iv_valid = false;
   DevBuf<uint2> ev_init, ev_buf; DevBuf<uint32_t> ev_count;
-  void free_owned() { for (void* p : owned) (void)hipFree(p); owned.clear(); }
+  BlockPool blocks;
+  void free_owned() { for (void* p : owned) blocks.put(p); owned.clear(); }
+  void free_parts() { for (auto& p : parts) for (void* b : p.bufs) blocks.put(b); parts.clear(); }
 };
 
 int DevicePipeline::device_count() {
@@ -2554,7 +2578,8 @@ DevicePipeline::~DevicePipeline() {
   if (!m_) return;
   if (m_->stream) (void)hipStreamSynchronize(m_->stream);
   m_->free_owned();
-  for (auto& p : m_->parts) for (void* b : p.bufs) (void)hipFree(b);
+  m_->free_parts();
+  m_->blocks.release_all();
   for (auto& e : m_->ev_prep) if (e) (void)hipEventDestroy(e);
   for (auto& a : m_->ev_page) for (auto& e : a) if (e) (void)hipEventDestroy(e);
   if (m_->hb) (void)hipHostFree(m_->hb);
@@ -2571,8 +2596,7 @@ void DevicePipeline::stage_fragment(const HostFragment& hf) {
   memset(&v, 0, sizeof(v));
   v.ncells = hf.ncells();
   auto up = [&](const void* src, size_t bytes) -> void* {
-    void* d = nullptr;
-    HIP_CHECK(hipMalloc(&d, std::max<size_t>(bytes, 16)));
+    void* d = m_->blocks.get(bytes);
     m_->owned.push_back(d);
     if (bytes) HIP_CHECK(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
     return d;
@@ -2591,19 +2615,24 @@ void DevicePipeline::stage_fragment(const HostFragment& hf) {
   m_->classified = false;
 }
 
-void DevicePipeline::begin_staging(int64_t carry_from) {
+void DevicePipeline::begin_staging(int64_t carry_from) { begin_staging_from(*this, carry_from); }
+
+// The same with the carried intervals taken from the fragment ANOTHER pipeline (of the same plan, on the same device) has staged:
+// that pipeline keeps computing on its fragment - nothing of it is written - while this one stages the next column window.
+void DevicePipeline::begin_staging_from(DevicePipeline& source, int64_t carry_from) {
   Impl& S = *m_;
-  for (auto& p : S.parts) for (void* b : p.bufs) (void)hipFree(b);
-  S.parts.clear();
+  Impl& SRC = *source.m_;
+  S.free_parts();
   S.carried_cells = 0;
-  if (carry_from == INT64_MIN || S.fr.ncells == 0) return;
+  if (carry_from == INT64_MIN || SRC.fr.ncells == 0) return;
   // ---- the staged fragment's live intervals at carry_from become the first part of the next fragment ---------------------
   HIP_CHECK(hipSetDevice(S.device));
   hipStream_t st = S.stream;
   const int nf = S.hp.plan.nfields;
   const int32_t N = S.hp.plan.num_query_rows;
-  if ((int)S.col_elem_size.size() < nf || !S.owns_fragment) throw GenomicsDBDeviceException("carry-over needs a fragment staged by this pipeline");
-  const FragmentView fr = S.fr;
+  if ((int)SRC.col_elem_size.size() < nf || !SRC.owns_fragment) throw GenomicsDBDeviceException("carry-over needs a fragment staged by a pipeline");
+  if (&SRC != &S) { S.col_elem_size = SRC.col_elem_size; S.col_var = SRC.col_var; S.col_fixed_num = SRC.col_fixed_num; }
+  const FragmentView fr = SRC.fr;
   const int64_t C = fr.ncells;
   S.carry_last.ensure((size_t)N + 1); S.carry_keys.ensure((size_t)N + 1); S.carry_sorted.ensure((size_t)N + 1); S.cwin.ensure(4);
   HIP_CHECK(hipMemsetAsync(S.carry_last.p, 0xFF, (size_t)N * sizeof(long long), st));
@@ -2616,7 +2645,7 @@ void DevicePipeline::begin_staging(int64_t carry_from) {
   Impl::Part part;
   memset(&part.v, 0, sizeof(part.v));
   part.v.ncells = K;
-  auto alloc = [&](size_t bytes) -> void* { void* d = nullptr; HIP_CHECK(hipMalloc(&d, std::max<size_t>(bytes, 16))); part.bufs.push_back(d); return d; };
+  auto alloc = [&](size_t bytes) -> void* { void* d = S.blocks.get(bytes); part.bufs.push_back(d); return d; };
   const uint64_t* list = S.carry_sorted.p;
   int32_t* row = (int32_t*)alloc((size_t)K * 4); int64_t* begin = (int64_t*)alloc((size_t)K * 8); int64_t* end = (int64_t*)alloc((size_t)K * 8);
   hipLaunchKernelGGL(k_gather_coords, dim3(blocks_for(K)), dim3(kBlock), 0, st, list, K, fr.row, fr.begin, fr.end, row, begin, end);
@@ -2660,8 +2689,7 @@ void DevicePipeline::append_fragment(const HostFragment& hf) {
   memset(&part.v, 0, sizeof(part.v));
   part.v.ncells = hf.ncells();
   auto up = [&](const void* src, size_t bytes) -> void* {
-    void* d = nullptr;
-    HIP_CHECK(hipMalloc(&d, std::max<size_t>(bytes, 16)));
+    void* d = m_->blocks.get(bytes);
     part.bufs.push_back(d);
     if (bytes) HIP_CHECK(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
     return d;
@@ -2862,8 +2890,7 @@ DevicePipeline::CellStreamInfo DevicePipeline::append_cells(const uint8_t* cells
   memset(&part.v, 0, sizeof(part.v));
   part.v.ncells = nkept;
   if (nkept == 0) {   // markers only (no cell of a queried row in this part)
-    void* d = nullptr;
-    HIP_CHECK(hipMalloc(&d, (size_t)nmark * 8));
+    void* d = S.blocks.get((size_t)nmark * 8);
     part.bufs.push_back(d);
     hipLaunchKernelGGL(k_cells_markers, dim3(blocks_for(n)), dim3(kBlock), 0, st, (const uint32_t*)S.raw_mark.p, (const uint32_t*)S.raw_mdest.p, (const int64_t*)S.raw_begin.p, n, (int64_t*)d);
     HIP_CHECK(hipStreamSynchronize(st));
@@ -2872,7 +2899,7 @@ DevicePipeline::CellStreamInfo DevicePipeline::append_cells(const uint8_t* cells
     S.parts.push_back(part);
     return info;
   }
-  auto alloc = [&](size_t bytes) -> void* { void* d = nullptr; HIP_CHECK(hipMalloc(&d, std::max<size_t>(bytes, 16))); part.bufs.push_back(d); return d; };
+  auto alloc = [&](size_t bytes) -> void* { void* d = S.blocks.get(bytes); part.bufs.push_back(d); return d; };
   int32_t* row = (int32_t*)alloc((size_t)nkept * 4); int64_t* begin = (int64_t*)alloc((size_t)nkept * 8); int64_t* end = (int64_t*)alloc((size_t)nkept * 8);
   part.v.row = row; part.v.begin = begin; part.v.end = end;
   if (nmark > 0) {
@@ -2906,7 +2933,7 @@ DevicePipeline::CellStreamInfo DevicePipeline::append_cells(const uint8_t* cells
     HIP_CHECK(rocprim::reduce(t, bytes, end, S.span_max.p, (int64_t)INT64_MIN, (size_t)nkept, rocprim::maximum<int64_t>(), st));
   }
   S.read_back_many({{&info.min_begin, begin, sizeof(int64_t)}, {&info.max_end, S.span_max.p, sizeof(int64_t)}, {&eb, S.err.p, sizeof(uint32_t)}});
-  if (eb) { for (void* b : part.bufs) (void)hipFree(b); throw std::runtime_error("cells are not in column-major (col,row) order"); }
+  if (eb) { for (void* b : part.bufs) S.blocks.put(b); throw std::runtime_error("cells are not in column-major (col,row) order"); }
   S.parts.push_back(part);
   if (trace) {
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
@@ -2925,13 +2952,15 @@ void DevicePipeline::finish_staging() {
   int64_t C = 0;
   for (auto& p : S.parts) C += p.v.ncells;
   v.ncells = C;
-  auto alloc = [&](size_t bytes) -> void* { void* d = nullptr; HIP_CHECK(hipMalloc(&d, std::max<size_t>(bytes, 16))); S.owned.push_back(d); return d; };
+  auto alloc = [&](size_t bytes) -> void* { void* d = S.blocks.get(bytes); S.owned.push_back(d); return d; };
   int32_t* row = (int32_t*)alloc((size_t)C * 4); int64_t* begin = (int64_t*)alloc((size_t)C * 8); int64_t* end = (int64_t*)alloc((size_t)C * 8);
   int64_t at = 0;
   for (auto& p : S.parts) {
-    HIP_CHECK(hipMemcpy(row + at, p.v.row, (size_t)p.v.ncells * 4, hipMemcpyDeviceToDevice));
-    HIP_CHECK(hipMemcpy(begin + at, p.v.begin, (size_t)p.v.ncells * 8, hipMemcpyDeviceToDevice));
-    HIP_CHECK(hipMemcpy(end + at, p.v.end, (size_t)p.v.ncells * 8, hipMemcpyDeviceToDevice));
+    // (copies on the pipeline's own stream: a synchronous hipMemcpy runs on the null stream, which waits for - and holds up -
+    // every other pipeline's stream)
+    HIP_CHECK(hipMemcpyAsync(row + at, p.v.row, (size_t)p.v.ncells * 4, hipMemcpyDeviceToDevice, S.stream));
+    HIP_CHECK(hipMemcpyAsync(begin + at, p.v.begin, (size_t)p.v.ncells * 8, hipMemcpyDeviceToDevice, S.stream));
+    HIP_CHECK(hipMemcpyAsync(end + at, p.v.end, (size_t)p.v.ncells * 8, hipMemcpyDeviceToDevice, S.stream));
     at += p.v.ncells;
   }
   v.row = row; v.begin = begin; v.end = end;
@@ -2944,7 +2973,7 @@ void DevicePipeline::finish_staging() {
     size_t byte_at = 0;
     int64_t cell_at = 0;
     for (auto& p : S.parts) {
-      if (p.data_bytes[f]) HIP_CHECK(hipMemcpy(data + byte_at, p.v.col[f].data, p.data_bytes[f], hipMemcpyDeviceToDevice));
+      if (p.data_bytes[f]) HIP_CHECK(hipMemcpyAsync(data + byte_at, p.v.col[f].data, p.data_bytes[f], hipMemcpyDeviceToDevice, S.stream));
       if (off && p.v.ncells > 0) {
         const uint64_t base_elems = byte_at / (size_t)S.col_elem_size[f];
         if (base_elems + p.data_bytes[f] / (size_t)S.col_elem_size[f] >= (1ull << 32)) throw GenomicsDBDeviceException("variable-length column exceeds 2^32 elements: stage a narrower column interval");
@@ -2961,12 +2990,11 @@ void DevicePipeline::finish_staging() {
     for (auto& p : S.parts) M += p.v.nmarkers;
     int64_t* mk = (int64_t*)alloc((size_t)M * 8);
     int64_t at_m = 0;
-    for (auto& p : S.parts) { if (p.v.nmarkers) HIP_CHECK(hipMemcpy(mk + at_m, p.v.marker_begin, (size_t)p.v.nmarkers * 8, hipMemcpyDeviceToDevice)); at_m += p.v.nmarkers; }
+    for (auto& p : S.parts) { if (p.v.nmarkers) HIP_CHECK(hipMemcpyAsync(mk + at_m, p.v.marker_begin, (size_t)p.v.nmarkers * 8, hipMemcpyDeviceToDevice, S.stream)); at_m += p.v.nmarkers; }
     v.nmarkers = M; v.marker_begin = mk;
   }
   HIP_CHECK(hipStreamSynchronize(S.stream));
-  for (auto& p : S.parts) for (void* b : p.bufs) (void)hipFree(b);
-  S.parts.clear();
+  S.free_parts();
   S.fr = v;
   S.owns_fragment = true;
   S.classified = false;
@@ -3499,10 +3527,10 @@ DevicePipeline::FragmentWindow DevicePipeline::append_fragment_cells(int64_t c0,
   // every way out of this function other than the push at its end (corrupt offsets, a corrupt tile index, a read beyond a section,
   // a failing HIP call) gives the part's device buffers back: a damaged file must not cost HBM for the life of the process
   struct PartGuard {
-    Impl::Part& p; bool keep = false;
-    ~PartGuard() { if (!keep) { for (void* b : p.bufs) (void)hipFree(b); p.bufs.clear(); } }
-  } guard{part};
-  auto alloc = [&](size_t bytes) -> void* { void* d = nullptr; HIP_CHECK(hipMalloc(&d, std::max<size_t>(bytes, 16))); part.bufs.push_back(d); return d; };
+    Impl::Part& p; BlockPool& pool; bool keep = false;
+    ~PartGuard() { if (!keep) { for (void* b : p.bufs) pool.put(b); p.bufs.clear(); } }
+  } guard{part, S.blocks};
+  auto alloc = [&](size_t bytes) -> void* { void* d = S.blocks.get(bytes); part.bufs.push_back(d); return d; };
   void* row = alloc((size_t)n * 4); void* begin = alloc((size_t)n * 8); void* end = alloc((size_t)n * 8);
   part.v.row = (const int32_t*)row; part.v.begin = (const int64_t*)begin; part.v.end = (const int64_t*)end;
   const int nf = S.hp.plan.nfields;
@@ -3630,7 +3658,10 @@ void DevicePipeline::adopt_fragment(const FragmentView& v) {
 void DevicePipeline::set_reference_window(int64_t begin, const std::string& bases) {
   HIP_CHECK(hipSetDevice(m_->device));
   m_->ref_bases.ensure(std::max<size_t>(bases.size(), 1));
-  if (!bases.empty()) HIP_CHECK(hipMemcpy(m_->ref_bases.p, bases.data(), bases.size(), hipMemcpyHostToDevice));
+  if (!bases.empty()) {
+    HIP_CHECK(hipMemcpyAsync(m_->ref_bases.p, bases.data(), bases.size(), hipMemcpyHostToDevice, m_->stream));
+    HIP_CHECK(hipStreamSynchronize(m_->stream));
+  }
   m_->ref_begin = begin;
   m_->ref_len = (int64_t)bases.size();
 }
