@@ -1215,7 +1215,7 @@ k_assemble_size(AsmCtx a, const int32_t* __restrict__ order, int64_t n, int32_t 
   }
 }
 
-constexpr int kTextChunks = 5;       // 16-byte chunks of a slot kept in registers
+constexpr int kTextChunks = 8;       // 16-byte chunks of a slot kept in registers
 struct SlotText { uint4 x[kTextChunks]; };
 
 // Page assembly: one wavefront = `run` records x 64 samples (one chunk), one wavefront per workgroup (no s_barrier).
@@ -3075,15 +3075,37 @@ __device__ __forceinline__ int inflate_construct(const InflateCode& h, const uin
   for (int sym = 0; sym < n; ++sym) if (length[sym] != 0) h.symbol[offs[length[sym]]++] = (uint16_t)sym;
   return left;
 }
+// The copy of a match by the eight lanes of a tile: byte i of the copy is the byte at (at - dist) + (i mod dist) - for dist >= len
+// that is the plain copy, for an overlapping match (dist < len) the repeating pattern the byte-by-byte definition produces.
+// All source bytes lie in front of `at`, so the lanes need no order among themselves; the LDS unit keeps the wavefront's
+// instructions in order, so the literal stores before and the reads after are seen.
+__device__ __forceinline__ void inflate_copy_match(uint8_t* o, uint32_t at, uint32_t len, uint32_t dist, int sub) {
+  const uint8_t* src = o + at - dist;
+  if (dist >= len) { for (uint32_t i = (uint32_t)sub; i < len; i += 8) o[at + i] = src[i]; }
+  else { for (uint32_t i = (uint32_t)sub; i < len; i += 8) o[at + i] = src[i % dist]; }
+}
 // job t: compressed bytes [in_off[t], in_off[t + 1]) of `comp` -> want[t] bytes at out + t * kFragTile
-__global__ void k_inflate_tiles(const uint8_t* __restrict__ comp, const uint64_t* __restrict__ in_off, const uint32_t* __restrict__ want_bytes, int64_t ntiles, uint8_t* __restrict__ out,
-                                uint8_t* __restrict__ scratch, uint32_t* err) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= ntiles) return;
+//
+// One wavefront inflates EIGHT tiles, eight lanes per tile, each tile's output in its own 8 KiB of LDS.  The round-2 kernel had one
+// lane per tile writing its output to global memory a byte at a time and copying matches through it - every copied byte a
+// dependent global load behind a global store (63 GB/s out).  Now the eight lanes of a tile all follow the tile's bit stream (the
+// same loads, the same decisions: no divergence inside the group, nothing to broadcast), a literal is stored by the group's first
+// lane, a match is copied by all eight from LDS to LDS - byte i of it is out[at - dist + i mod dist], whatever the overlap, so
+// the eight lanes take every eighth byte - and the finished tile leaves LDS as coalesced 16-byte stores.  The bit-serial part of
+// DEFLATE stays serial per tile; what the wavefront shares is the cost of everything around it.
+constexpr int kInflateGroup = 8;                  // lanes per tile
+constexpr int kInflateTilesPerWave = 64 / kInflateGroup;
+__global__ void __launch_bounds__(64) k_inflate_tiles(const uint8_t* __restrict__ comp, const uint64_t* __restrict__ in_off, const uint32_t* __restrict__ want_bytes, int64_t ntiles,
+                                                      uint8_t* __restrict__ out, uint8_t* __restrict__ scratch, uint32_t* err) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds_out[kInflateTilesPerWave][kFragTile];
+  const int sub = threadIdx.x & (kInflateGroup - 1), grp = threadIdx.x / kInflateGroup;
+  const int64_t t_raw = (int64_t)blockIdx.x * kInflateTilesPerWave + grp;
+  const bool have = t_raw < ntiles;
+  const int64_t t = have ? t_raw : ntiles - 1;     // (idle groups shadow the last tile and write nothing)
   uint8_t* const lengths = scratch + (uint64_t)t * kInflateScratch;                                       // [320]
   const InflateCode lencode{reinterpret_cast<uint16_t*>(lengths + 320), reinterpret_cast<uint16_t*>(lengths + 320) + 16};
   const InflateCode distcode{lencode.symbol + 288, lencode.symbol + 288 + 16};
-  uint8_t* const o = out + (uint64_t)t * kFragTile;
+  uint8_t* const o = &lds_out[grp][0];
   const uint32_t want = want_bytes[t];
   InflateBits b{comp + in_off[t], comp + in_off[t + 1], 0ull, 0};
   uint32_t at = 0;
@@ -3099,7 +3121,7 @@ __global__ void k_inflate_tiles(const uint8_t* __restrict__ comp, const uint64_t
       if (b.n < 32) { bad = true; break; }
       const uint32_t len = b.get(16), nlen = b.get(16);
       if ((len ^ nlen) != 0xFFFFu || at + len > want) { bad = true; break; }
-      for (uint32_t i = 0; i < len; ++i) { b.refill(); if (b.n < 8) { bad = true; break; } o[at++] = (uint8_t)b.get(8); }
+      for (uint32_t i = 0; i < len; ++i) { b.refill(); if (b.n < 8) { bad = true; break; } const uint8_t v = (uint8_t)b.get(8); if (sub == 0) o[at] = v; ++at; }
     } else if (type == 1) {                            // fixed Huffman codes
       for (;;) {
         b.refill();
@@ -3118,7 +3140,7 @@ __global__ void k_inflate_tiles(const uint8_t* __restrict__ comp, const uint64_t
           }
         }
         if (b.n < 0) { bad = true; break; }
-        if (sym < 256u) { if (at >= want) { bad = true; break; } o[at++] = (uint8_t)sym; continue; }
+        if (sym < 256u) { if (at >= want) { bad = true; break; } if (sub == 0) o[at] = (uint8_t)sym; ++at; continue; }
         if (sym == 256u) break;
         if (sym > 285u) { bad = true; break; }
         b.refill();
@@ -3129,7 +3151,8 @@ __global__ void k_inflate_tiles(const uint8_t* __restrict__ comp, const uint64_t
         b.refill();
         const uint32_t dist = kInfDistBase[dc] + b.get(kInfDistExtra[dc]);
         if (b.n < 0 || dist > at || at + len > want) { bad = true; break; }
-        for (uint32_t i = 0; i < len; ++i, ++at) o[at] = o[at - dist];
+        inflate_copy_match(o, at, len, dist, sub);
+        at += len;
       }
     } else if (type == 2) {                            // dynamic codes: read the code lengths, build both tables, decode
       b.refill();
@@ -3168,7 +3191,7 @@ __global__ void k_inflate_tiles(const uint8_t* __restrict__ comp, const uint64_t
       for (;;) {
         const int sym = inflate_decode(b, lencode);
         if (sym < 0) { bad = true; break; }
-        if (sym < 256) { if (at >= want) { bad = true; break; } o[at++] = (uint8_t)sym; continue; }
+        if (sym < 256) { if (at >= want) { bad = true; break; } if (sub == 0) o[at] = (uint8_t)sym; ++at; continue; }
         if (sym == 256) break;
         if (sym > 285) { bad = true; break; }
         b.refill();
@@ -3179,11 +3202,23 @@ __global__ void k_inflate_tiles(const uint8_t* __restrict__ comp, const uint64_t
         b.refill();
         const uint32_t dist = kInfDistBase[dc] + b.get(kInfDistExtra[dc]);
         if (b.n < 0 || dist > at || at + len > want) { bad = true; break; }
-        for (uint32_t i = 0; i < len; ++i, ++at) o[at] = o[at - dist];
+        inflate_copy_match(o, at, len, dist, sub);
+        at += len;
       }
     } else bad = true;                                 // the reserved block type
   }
-  if (bad || at != want) atomicOr(err, (uint32_t)GDB_ERR_CELL_STREAM);
+  if (have && sub == 0 && (bad || at != want)) atomicOr(err, (uint32_t)GDB_ERR_CELL_STREAM);
+  // ---- the tiles leave LDS: 16 bytes per lane and store, whole wavefront per tile ---------------------------------------------------
+  __syncthreads();
+  for (int g = 0; g < kInflateTilesPerWave; ++g) {
+    const int64_t tg = (int64_t)blockIdx.x * kInflateTilesPerWave + g;
+    if (tg >= ntiles) break;
+    const uint32_t wn = want_bytes[tg];
+    uint8_t* const dst = out + (uint64_t)tg * kFragTile;
+    const uint32_t nq = wn >> 4;
+    for (uint32_t q = threadIdx.x; q < nq; q += 64) reinterpret_cast<uint4*>(dst)[q] = reinterpret_cast<const uint4*>(&lds_out[g][0])[q];
+    for (uint32_t i = (nq << 4) + threadIdx.x; i < wn; i += 64) dst[i] = lds_out[g][i];
+  }
 }
 
 const char kFragMagic[8] = {'G', 'D', 'B', 'A', 'M', 'D', 'F', '2'};
@@ -3574,7 +3609,7 @@ DevicePipeline::FragmentWindow DevicePipeline::append_fragment_cells(int64_t c0,
     for (auto& fr : file_ranges) { F.to_device(S.inflate_in.p + at_in, fr.first, fr.second, st); at_in += fr.second; }
     HIP_CHECK(hipMemcpyAsync(S.inflate_off.p, job_in.data(), (size_t)(njobs + 1) * 8, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(S.inflate_want.p, job_want.data(), (size_t)njobs * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_inflate_tiles, dim3(blocks_for((int64_t)njobs, 64)), dim3(64), 0, st, (const uint8_t*)S.inflate_in.p, (const uint64_t*)S.inflate_off.p, (const uint32_t*)S.inflate_want.p,
+    hipLaunchKernelGGL(k_inflate_tiles, dim3(blocks_for((int64_t)njobs, kInflateTilesPerWave)), dim3(64), 0, st, (const uint8_t*)S.inflate_in.p, (const uint64_t*)S.inflate_off.p, (const uint32_t*)S.inflate_want.p,
                        (int64_t)njobs, S.inflate_out.p, S.inflate_scratch.p, S.err.p);
     for (auto& c : copies) HIP_CHECK(hipMemcpyAsync(c.dev, S.inflate_out.p + c.from, c.bytes, hipMemcpyDeviceToDevice, st));
     HIP_CHECK(hipStreamSynchronize(st));                          // (the host vectors above are read by the copies)
