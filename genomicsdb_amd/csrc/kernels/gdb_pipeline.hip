@@ -930,24 +930,40 @@ struct SlotTable {
   uint32_t light_base;    // = kMaxTypes: slots [0,kMaxTypes) are the no-call texts per type
   uint32_t heavy_base;
   uint32_t row_base;      // slots of (untabled record, sample): row_base + u * N + row
+  uint32_t* ovf16_w;      // the same array, written by pass 0 for the texts it places itself (bump allocation, below)
+  unsigned int* bump;     // per shard (kBumpShards x 4, workgroup -> shard by blockIdx: one hot counter would queue up ~10^6 atomics):
+                          // [0] units taken from the shard's part of the overflow pool, [1] long texts not placed, [2] their units, [3] long texts in all
+  uint32_t bump_cap;      // units of ONE shard's part of the overflow pool (0: pass 0 places nothing, every long text waits for pass 1)
   int32_t ctx;            // this pipeline's slot of c_ex
   int32_t bcf;            // entries are binary (gdb_bcf.hpp) instead of text
 };
 // PASS 0: ONE run of the field emitters gives the length of the text and, when it fits kSlotStride bytes (nearly always),
 // the text itself: formatted into a lane-private LDS strip, it leaves as 16-byte stores into the lane's inline slot.
-// PASS 1: only the texts longer than an inline slot are formatted again, straight into the overflow pool.
+// A text longer than an inline slot that still fits the strip (STRIPW words per lane: 128 or 256 bytes) is placed by pass 0 too:
+// the wavefront adds up the 16-byte units its long texts need, takes them from the overflow pool with ONE atomic and every lane
+// stores its text there - at the width of BASELINE configs[2] (10 000 samples, ~6 merged alleles per record) half of all texts
+// are between 128 and 256 bytes, and formatting them a second time (pass 1) was 5 ms of a 33 ms window.
+// PASS 1: only when pass 0 could not place every long text (longer than the strip, or the pool ran out): all texts longer than
+// an inline slot are formatted again, straight into an overflow pool sized by a scan of their lengths.
 // One template, four enumerations (types / plain cells x met types / heavy incidences / samples of untabled records).
-template <int PASS> __device__ __forceinline__ void slot_fill(const SlotTable& st, uint32_t s, const RecordInfo& rinfo, int64_t c, uint32_t* e) {
+constexpr int kStripWordsWide = 256 / 4 + 1;
+constexpr uint32_t kSlotUnplaced = 0xFFFFFFFFu;   // ovf16 of a long text that has no place yet
+constexpr int kBumpShards = 16;
+// pass 1 formats: every long text (scan mode, bump_cap == 0: the places come from a scan over all lengths) or only the ones pass 0
+// could not place (bump mode)
+__device__ __forceinline__ bool slot_needs_pass1(const SlotTable& st, uint32_t s) {
+  return st.len[s] > (uint32_t)kSlotStride && (st.bump_cap == 0u || st.ovf16[s] == kSlotUnplaced);
+}
+template <int PASS, int STRIPW> __device__ __forceinline__ uint32_t slot_fill(const SlotTable& st, uint32_t s, const RecordInfo& rinfo, int64_t c, uint32_t* mine, uint32_t* e) {
+  uint32_t len = 0;
   if (PASS == 0) {
-    uint32_t len = 0;
+    constexpr uint32_t cap = (uint32_t)(STRIPW - 1) * 4u;
     if (rinfo.fmt_mask) {
-      __shared__ uint32_t strip[kSlotBlock * kStripWords];
-      uint32_t* mine = strip + threadIdx.x * kStripWords;
       gdb_lds_char* txt = (gdb_lds_char*)mine;
-      if (st.bcf) len = entry_bin_lds_capped(st.ctx, rinfo, c, txt, (uint32_t)kSlotStride, e);
+      if (st.bcf) len = entry_bin_lds_capped(st.ctx, rinfo, c, txt, cap, e);
       else {
       *txt = '\t';
-      len = 1u + entry_store_lds_capped(st.ctx, rinfo, c, txt + 1, (uint32_t)kSlotStride - 1u, e);
+      len = 1u + entry_store_lds_capped(st.ctx, rinfo, c, txt + 1, cap - 1u, e);
       }
       if (len <= (uint32_t)kSlotStride) {
         uint4* dst = reinterpret_cast<uint4*>(st.pool + (size_t)s * kSlotStride);
@@ -955,19 +971,65 @@ template <int PASS> __device__ __forceinline__ void slot_fill(const SlotTable& s
       }
     }
     st.len[s] = len;
-  } else if (st.len[s] > (uint32_t)kSlotStride) {
-    char* dst = st.pool_ovf + (size_t)st.ovf16[s] * 16;
-    if (st.bcf) { entry_bin_store(st.ctx, rinfo, c, dst, e); return; }
+  } else if (slot_needs_pass1(st, s)) {
+    uint32_t off = st.ovf16[s];
+    if (st.bump_cap) {                                           // bump mode: the few texts pass 0 left take their place now
+      const uint32_t sh = blockIdx.x & (kBumpShards - 1);        // (the same shard as in pass 0: the host has made room for them there)
+      off = sh * st.bump_cap + atomicAdd(&st.bump[sh * 4], (st.len[s] + 15u) >> 4);
+      st.ovf16_w[s] = off;
+    }
+    char* dst = st.pool_ovf + (size_t)off * 16;
+    if (st.bcf) { entry_bin_store(st.ctx, rinfo, c, dst, e); return 0; }
     *dst = '\t';
     entry_store(st.ctx, rinfo, c, dst + 1, e);
   }
+  return len;
 }
-template <int PASS> __global__ void k_slots_nocall(SlotTable st, SiteOut so, const int32_t* type_rep, int ntypes, uint32_t* err) {
+// pass 0, behind slot_fill, by EVERY lane of the wavefront (active: the lane has a slot): place the long texts that fit the strip
+template <int STRIPW> __device__ __forceinline__ void slot_place_long(const SlotTable& st, bool active, uint32_t s, uint32_t len, const uint32_t* mine) {
+  constexpr uint32_t cap = (uint32_t)(STRIPW - 1) * 4u;
+  const bool is_long = active && len > (uint32_t)kSlotStride;
+  if (!__any((int)is_long)) return;                             // uniform
+  const bool fits = is_long && st.bump_cap != 0u && len <= cap;
+  const uint32_t units = fits ? (len + 15u) >> 4 : 0u;
+  const uint32_t incl = wave_inclusive_scan_dpp(units);
+  const uint32_t total = wave_total(incl);
+  unsigned int* const cnt = st.bump + (blockIdx.x & (kBumpShards - 1)) * 4;
+  const uint32_t shard_base = (blockIdx.x & (kBumpShards - 1)) * st.bump_cap;
+  uint32_t base = 0;
+  if (total) {                                                   // uniform
+    if ((threadIdx.x & 63) == 0) base = atomicAdd(&cnt[0], total);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+  }
+  bool placed = false;
+  if (fits) {
+    const uint32_t off = base + incl - units;
+    if (off + units <= st.bump_cap) {
+      uint4* dst = reinterpret_cast<uint4*>(st.pool_ovf + (size_t)(shard_base + off) * 16);
+      for (uint32_t q = 0; q < units; ++q) dst[q] = make_uint4(mine[4 * q], mine[4 * q + 1], mine[4 * q + 2], mine[4 * q + 3]);
+      st.ovf16_w[s] = shard_base + off;
+      placed = true;
+    }
+  }
+  const bool left = is_long && !placed;
+  if (left) st.ovf16_w[s] = kSlotUnplaced;
+  const uint64_t longs = __ballot(is_long), failed = __ballot(left);
+  const uint32_t lu = failed ? wave_total(wave_inclusive_scan_dpp(left ? (len + 15u) >> 4 : 0u)) : 0u;
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&cnt[3], (unsigned int)__popcll(longs));
+    if (failed) { atomicAdd(&cnt[1], (unsigned int)__popcll(failed)); atomicAdd(&cnt[2], lu); }
+  }
+}
+template <int PASS, int STRIPW> __global__ void k_slots_nocall(SlotTable st, SiteOut so, const int32_t* type_rep, int ntypes, uint32_t* err) {
+  __shared__ uint32_t strip[kSlotBlock * STRIPW];
+  uint32_t* mine = strip + threadIdx.x * STRIPW;
   const int t = threadIdx.x;
-  if (blockIdx.x || t >= kMaxTypes) return;
-  uint32_t e = 0;
-  if (t < ntypes) slot_fill<PASS>(st, (uint32_t)t, load_record_info(so, c_ex[st.ctx].hl, type_rep[t]), -1, &e);
-  else if (PASS == 0) st.len[t] = 0;
+  if (blockIdx.x) return;
+  uint32_t e = 0, len = 0;
+  const bool live = t < ntypes && t < kMaxTypes;
+  if (live) len = slot_fill<PASS, STRIPW>(st, (uint32_t)t, load_record_info(so, c_ex[st.ctx].hl, type_rep[t]), -1, mine, &e);
+  else if (PASS == 0 && t < kMaxTypes) st.len[t] = 0;
+  if (PASS == 0) slot_place_long<STRIPW>(st, live, (uint32_t)t, len, mine);
   if (e) atomicOr(err, e);
 }
 // Plain cells: one thread per (cell, type) slot, so every lane formats a text (a cell meets ~5 of the ~60 types of an
@@ -980,44 +1042,69 @@ __global__ void k_slot_cells(const uint32_t* tbase, const uint32_t* nslots, int6
   const uint32_t b = tbase[i], m = nslots[i];
   for (uint32_t q = 0; q < m; ++q) slot_cell[b + q] = (uint32_t)i;
 }
-template <int PASS> __global__ void k_slots_light(SlotTable st, SiteOut so, const int32_t* type_rep, const uint64_t* tmask, const uint32_t* tbase,
+template <int PASS, int STRIPW> __global__ void k_slots_light(SlotTable st, SiteOut so, const int32_t* type_rep, const uint64_t* tmask, const uint32_t* tbase,
                                                       const uint32_t* slot_cell, int64_t c_base, int64_t SL, uint32_t* err) {
+  __shared__ uint32_t strip[kSlotBlock * STRIPW];
+  uint32_t* mine = strip + threadIdx.x * STRIPW;
   const int64_t sidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = sidx < SL;
   const uint32_t s = st.light_base + (uint32_t)(live ? sidx : 0);
-  if (PASS == 1) { if (!__any((int)(live && st.len[s] > (uint32_t)kSlotStride))) return; }
-  if (!live) return;
-  const uint32_t i = slot_cell[sidx];
-  uint64_t m = tmask[i];
-  for (uint32_t q = (uint32_t)sidx - tbase[i]; q; --q) m &= m - 1;     // the slot's rank among the cell's types -> its type
-  const int t = __builtin_ctzll(m);
-  uint32_t e = 0;
-  slot_fill<PASS>(st, s, load_record_info(so, c_ex[st.ctx].hl, type_rep[t]), c_base + (int64_t)i, &e);
+  if (PASS == 1) { if (!__any((int)(live && slot_needs_pass1(st, s)))) return; }
+  uint32_t e = 0, len = 0;
+  if (live) {
+    const uint32_t i = slot_cell[sidx];
+    uint64_t m = tmask[i];
+    for (uint32_t q = (uint32_t)sidx - tbase[i]; q; --q) m &= m - 1;     // the slot's rank among the cell's types -> its type
+    const int t = __builtin_ctzll(m);
+    len = slot_fill<PASS, STRIPW>(st, s, load_record_info(so, c_ex[st.ctx].hl, type_rep[t]), c_base + (int64_t)i, mine, &e);
+  }
+  if (PASS == 0) slot_place_long<STRIPW>(st, live, s, len, mine);
   if (e) atomicOr(err, e);
 }
-template <int PASS> __global__ void k_slots_heavy(SlotTable st, SiteOut so, const uint64_t* inc_keys_sorted, const int64_t* inc_cell, int64_t T, int64_t nrows,
+template <int PASS, int STRIPW> __global__ void k_slots_heavy(SlotTable st, SiteOut so, const uint64_t* inc_keys_sorted, const int64_t* inc_cell, int64_t T, int64_t nrows,
                                                  uint32_t* err) {
+  __shared__ uint32_t strip[kSlotBlock * STRIPW];
+  uint32_t* mine = strip + threadIdx.x * STRIPW;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= T) return;
-  uint32_t e = 0;
-  const int64_t k = (int64_t)(inc_keys_sorted[i] / (uint64_t)nrows);
-  slot_fill<PASS>(st, st.heavy_base + (uint32_t)i, load_record_info(so, c_ex[st.ctx].hl, k), inc_cell[i], &e);
+  const bool live = i < T;
+  uint32_t e = 0, len = 0;
+  const uint32_t s = st.heavy_base + (uint32_t)(live ? i : 0);
+  if (live) {
+    const int64_t k = (int64_t)(inc_keys_sorted[i] / (uint64_t)nrows);
+    len = slot_fill<PASS, STRIPW>(st, s, load_record_info(so, c_ex[st.ctx].hl, k), inc_cell[i], mine, &e);
+  }
+  if (PASS == 0) slot_place_long<STRIPW>(st, live, s, len, mine);
   if (e) atomicOr(err, e);
 }
-template <int PASS> __global__ void k_slots_untabled(SlotTable st, SiteOut so, RowIndex ri, RecordTable rec, const int32_t* urec, int64_t U, int32_t N, uint32_t* err) {
+template <int PASS, int STRIPW> __global__ void k_slots_untabled(SlotTable st, SiteOut so, RowIndex ri, RecordTable rec, const int32_t* urec, int64_t U, int32_t N, uint32_t* err) {
+  __shared__ uint32_t strip[kSlotBlock * STRIPW];
+  uint32_t* mine = strip + threadIdx.x * STRIPW;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= U * (int64_t)N) return;
-  const int64_t u = i / N;
-  const int32_t row = (int32_t)(i - u * N);
-  const int64_t k = urec[u];
-  uint32_t e = 0;
-  RowWalker w;
-  w.init(ri, row, rec.start[k]);
-  const int64_t c = w.live(ri, c_ex[st.ctx].cm, rec.start[k]);
-  const uint32_t s = st.row_base + (uint32_t)i;
-  if (c >= 0 && (c_ex[st.ctx].cm.cflags[c] & GDB_CF_HEAVY)) { if (PASS == 0) st.len[s] = 0; }   // heavy calls have their incidence slot
-  else slot_fill<PASS>(st, s, load_record_info(so, c_ex[st.ctx].hl, k), c, &e);
+  const bool in_range = i < U * (int64_t)N;
+  uint32_t e = 0, len = 0;
+  bool live = false;
+  const uint32_t s = st.row_base + (uint32_t)(in_range ? i : 0);
+  if (in_range) {
+    const int64_t u = i / N;
+    const int32_t row = (int32_t)(i - u * N);
+    const int64_t k = urec[u];
+    RowWalker w;
+    w.init(ri, row, rec.start[k]);
+    const int64_t c = w.live(ri, c_ex[st.ctx].cm, rec.start[k]);
+    if (c >= 0 && (c_ex[st.ctx].cm.cflags[c] & GDB_CF_HEAVY)) { if (PASS == 0) st.len[s] = 0; }   // heavy calls have their incidence slot
+    else { len = slot_fill<PASS, STRIPW>(st, s, load_record_info(so, c_ex[st.ctx].hl, k), c, mine, &e); live = true; }
+  }
+  if (PASS == 0) slot_place_long<STRIPW>(st, live, s, len, mine);
   if (e) atomicOr(err, e);
+}
+// the overflow pool has grown: shard sh's part moved from sh * old_su to sh * new_su (units); placed texts keep their offset inside the part
+__global__ void k_slot_rebase(const uint32_t* len, uint32_t* ovf16, int64_t S, uint32_t old_su, uint32_t new_su) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S || len[s] <= (uint32_t)kSlotStride) return;
+  const uint32_t o = ovf16[s];
+  if (o == kSlotUnplaced) return;
+  const uint32_t sh = o / old_su;
+  ovf16[s] = sh * new_su + (o - sh * old_su);
 }
 __global__ void k_slot_units(const uint32_t* len, int64_t S, uint32_t* units) {   // overflow-pool units of every slot
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2413,6 +2500,9 @@ struct DevicePipeline::Impl {
   DevBuf<uint8_t> num_alleles, rflags; DevBuf<uint32_t> fmt_mask, prefix_len; DevBuf<char> site_staging, spill_buf; DevBuf<int32_t> spill_chunk; DevBuf<unsigned int> spill_next;
   DevBuf<uint64_t> chunk_size, chunk_off, rec_off; DevBuf<unsigned long long> max_record;
   std::unique_ptr<BgzfDeviceCompressor> bgzf;   // output formats "z" / "b"
+  DevBuf<unsigned int> slot_bump;               // pass 0's bump allocator of the overflow text pool: next unit, texts it could not place
+  bool long_texts_seen = false;                 // an interval of this pipeline had texts longer than an inline slot
+  uint64_t pool_ovf_need = 0;                   // most 16-byte units of overflow texts an interval has needed so far
   DevBuf<char> arena[2], temp;       // two output arenas: a consumer drains one while the next page is assembled into the other
   DevBuf<uint32_t> err; DevBuf<int32_t> counters;
   int ctx_slot = -1;                 // this pipeline's element of c_ex
@@ -4043,31 +4133,78 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   S.slot_len.ensure(NS + 1); S.slot_units.ensure(NS + 1); S.slot_off.ensure(NS + 1); S.slot_desc.ensure(NS + 1);
   if (NS * (uint64_t)(kSlotStride / 16) >= (uint64_t)kOverflowBit) throw GenomicsDBDeviceException("entry text table exceeds 32 GiB: split the query interval");
   S.pool.ensure((size_t)NS * kSlotStride + 64);
-  SlotTable stt{S.slot_len.p, S.slot_off.p, S.pool.p, nullptr, (uint32_t)kMaxTypes, (uint32_t)(kMaxTypes + SL), (uint32_t)(kMaxTypes + SL + (uint64_t)T), (int32_t)S.ctx_slot, pl.bcf_mode};
+  // Long texts (more than an inline slot): pass 0 places the ones that fit its LDS strip itself, out of an overflow pool that is
+  // sized from what earlier intervals of this pipeline needed (grow-only).  The wide strip (256 bytes per lane, half the resident
+  // wavefronts) is used once an interval has shown long texts; GDBAMD_SLOT_STRIP = 128 / 256 forces one.
+  S.slot_bump.ensure(kBumpShards * 4);
+  HIP_CHECK(hipMemsetAsync(S.slot_bump.p, 0, kBumpShards * 4 * sizeof(unsigned int), st));
+  bool wide = S.long_texts_seen;
+  if (const char* e = getenv("GDBAMD_SLOT_STRIP")) wide = atoi(e) >= 256;
+  // the overflow pool in kBumpShards equal parts; a part holds what its shard needed at most so far, and an eighth more
+  auto shard_units_of = [&](size_t cap_bytes) { return (uint32_t)std::min<uint64_t>((uint64_t)(cap_bytes > 64 ? (cap_bytes - 64) / 16 : 0) / kBumpShards, ((uint64_t)kOverflowBit - 1) / kBumpShards); };
+  if (wide) S.pool_ovf.ensure(std::max<size_t>((size_t)kBumpShards * ((size_t)S.pool_ovf_need * 16 + ((size_t)S.pool_ovf_need * 16 >> 3)), (size_t)1 << 20) + 64);
+  SlotTable stt{S.slot_len.p, S.slot_off.p, S.pool.p, S.pool_ovf.p, (uint32_t)kMaxTypes, (uint32_t)(kMaxTypes + SL), (uint32_t)(kMaxTypes + SL + (uint64_t)T), S.slot_off.p, S.slot_bump.p,
+                wide ? shard_units_of(S.pool_ovf.cap) : 0u, (int32_t)S.ctx_slot, pl.bcf_mode};
   STAGE("k_slots<0>");
-  hipLaunchKernelGGL(k_slots_nocall<0>, dim3(1), dim3(kMaxTypes), 0, st, stt, so, S.type_rep.p, ntypes, S.err.p);
+#define GDB_SLOT_KERNELS(PASSN, W) do { \
+  hipLaunchKernelGGL((k_slots_nocall<PASSN, W>), dim3(1), dim3(kMaxTypes), 0, st, stt, so, S.type_rep.p, ntypes, S.err.p); \
+  if (SL > 0) hipLaunchKernelGGL((k_slots_light<PASSN, W>), dim3(blocks_for((int64_t)SL, kSlotBlock)), dim3(kSlotBlock), 0, st, stt, so, S.type_rep.p, S.tmask.p, S.tbase.p, (const uint32_t*)S.slot_cell.p, c_base, (int64_t)SL, S.err.p); \
+  if (T > 0) hipLaunchKernelGGL((k_slots_heavy<PASSN, W>), dim3(blocks_for(T, 64)), dim3(64), 0, st, stt, so, S.inc_keys_sorted.p, S.inc_vals_sorted.p, T, (int64_t)N, S.err.p); \
+  if (UR > 0) hipLaunchKernelGGL((k_slots_untabled<PASSN, W>), dim3(blocks_for(UR * N, 64)), dim3(64), 0, st, stt, so, ri, rec, S.urec.p, UR, N, S.err.p); \
+} while (0)
   if (SL > 0) {
     S.slot_cell.ensure(SL + 1);
     hipLaunchKernelGGL(k_slot_cells, dim3(blocks_for(CW)), dim3(kBlock), 0, st, (const uint32_t*)S.tbase.p, (const uint32_t*)S.nslots.p, CW, S.slot_cell.p);
-    hipLaunchKernelGGL(k_slots_light<0>, dim3(blocks_for((int64_t)SL, kSlotBlock)), dim3(kSlotBlock), 0, st, stt, so, S.type_rep.p, S.tmask.p, S.tbase.p, (const uint32_t*)S.slot_cell.p, c_base, (int64_t)SL, S.err.p);
   }
-  if (T > 0) hipLaunchKernelGGL(k_slots_heavy<0>, dim3(blocks_for(T, 64)), dim3(64), 0, st, stt, so, S.inc_keys_sorted.p, S.inc_vals_sorted.p, T, (int64_t)N, S.err.p);
-  if (UR > 0) hipLaunchKernelGGL(k_slots_untabled<0>, dim3(blocks_for(UR * N, 64)), dim3(64), 0, st, stt, so, ri, rec, S.urec.p, UR, N, S.err.p);
-  hipLaunchKernelGGL(k_slot_units, dim3(blocks_for((int64_t)NS)), dim3(kBlock), 0, st, S.slot_len.p, (int64_t)NS, S.slot_units.p);
-  S.excl_scan(S.slot_units.p, S.slot_off.p, (size_t)NS);
-  const uint64_t pool_units = (uint64_t)S.read_back_sum(S.slot_off.p + (NS - 1), S.slot_units.p + (NS - 1));
-  if (pool_units >= (uint64_t)kOverflowBit) throw GenomicsDBDeviceException("entry text overflow pool exceeds 32 GiB: split the query interval");
-  S.pool_ovf.ensure((size_t)pool_units * 16 + 64);
-  stt.pool_ovf = S.pool_ovf.p;
-  STAGE("k_slots<1>");
-  if (pool_units > 0) {   // some text is longer than an inline slot
-  hipLaunchKernelGGL(k_slots_nocall<1>, dim3(1), dim3(kMaxTypes), 0, st, stt, so, S.type_rep.p, ntypes, S.err.p);
-  if (SL > 0)
-    hipLaunchKernelGGL(k_slots_light<1>, dim3(blocks_for((int64_t)SL, kSlotBlock)), dim3(kSlotBlock), 0, st, stt, so, S.type_rep.p, S.tmask.p, S.tbase.p, (const uint32_t*)S.slot_cell.p, c_base, (int64_t)SL, S.err.p);
-
-  if (T > 0) hipLaunchKernelGGL(k_slots_heavy<1>, dim3(blocks_for(T, 64)), dim3(64), 0, st, stt, so, S.inc_keys_sorted.p, S.inc_vals_sorted.p, T, (int64_t)N, S.err.p);
-  if (UR > 0) hipLaunchKernelGGL(k_slots_untabled<1>, dim3(blocks_for(UR * N, 64)), dim3(64), 0, st, stt, so, ri, rec, S.urec.p, UR, N, S.err.p);
+  if (wide) GDB_SLOT_KERNELS(0, kStripWordsWide); else GDB_SLOT_KERNELS(0, kStripWords);
+  unsigned int bump_sh[kBumpShards * 4];
+  S.read_back_many({{bump_sh, S.slot_bump.p, sizeof(bump_sh)}});
+  uint64_t left_texts = 0, long_texts = 0, shard_need = 0, total_units = 0;   // (per shard: units taken - also the ones that ran past its part - plus units still wanted)
+  for (int sh = 0; sh < kBumpShards; ++sh) {
+    left_texts += bump_sh[sh * 4 + 1]; long_texts += bump_sh[sh * 4 + 3];
+    shard_need = std::max<uint64_t>(shard_need, (uint64_t)bump_sh[sh * 4] + bump_sh[sh * 4 + 2]);
+    total_units += (uint64_t)bump_sh[sh * 4] + bump_sh[sh * 4 + 2];
   }
+  uint64_t pool_units = total_units;
+  if (shard_need * kBumpShards >= (uint64_t)kOverflowBit) throw GenomicsDBDeviceException("entry text overflow pool exceeds 32 GiB: split the query interval");
+  constexpr uint64_t kBumpLimit = 1u << 21;          // more texts than this left for pass 1: their places come from a scan (one atomic each would queue up)
+  if (left_texts > 0 && left_texts <= kBumpLimit) {
+    // room in every shard's part for the texts pass 0 left, behind what it has placed there (kept when the pool has to grow)
+    const uint32_t old_su = stt.bump_cap;
+    if ((uint64_t)old_su < shard_need) {
+      const uint64_t su = shard_need + (shard_need >> 3) + 4;
+      const size_t ncap = (size_t)su * 16 * kBumpShards + 64;
+      char* np = nullptr;
+      HIP_CHECK(hipMalloc((void**)&np, ncap));
+      for (int sh = 0; sh < kBumpShards && old_su; ++sh) {
+        const size_t keep = (size_t)std::min<uint64_t>(bump_sh[sh * 4], old_su) * 16;      // (a counter runs past its part when a request did not fit)
+        if (keep) HIP_CHECK(hipMemcpyAsync(np + (size_t)sh * su * 16, S.pool_ovf.p + (size_t)sh * old_su * 16, keep, hipMemcpyDeviceToDevice, st));
+      }
+      if (old_su) {   // the texts pass 0 placed move with their shard: their descriptors follow
+        hipLaunchKernelGGL(k_slot_rebase, dim3(blocks_for((int64_t)NS)), dim3(kBlock), 0, st, (const uint32_t*)S.slot_len.p, S.slot_off.p, (int64_t)NS, old_su, (uint32_t)su);
+      }
+      HIP_CHECK(hipStreamSynchronize(st));
+      if (S.pool_ovf.p) (void)hipFree(S.pool_ovf.p);
+      S.pool_ovf.p = np; S.pool_ovf.cap = ncap;
+    }
+    stt.pool_ovf = S.pool_ovf.p;
+    stt.bump_cap = shard_units_of(S.pool_ovf.cap);
+    STAGE("k_slots<1>");
+    GDB_SLOT_KERNELS(1, kStripWords);
+  } else if (left_texts > 0) {
+    hipLaunchKernelGGL(k_slot_units, dim3(blocks_for((int64_t)NS)), dim3(kBlock), 0, st, S.slot_len.p, (int64_t)NS, S.slot_units.p);
+    S.excl_scan(S.slot_units.p, S.slot_off.p, (size_t)NS);
+    pool_units = (uint64_t)S.read_back_sum(S.slot_off.p + (NS - 1), S.slot_units.p + (NS - 1));
+    if (pool_units >= (uint64_t)kOverflowBit) throw GenomicsDBDeviceException("entry text overflow pool exceeds 32 GiB: split the query interval");
+    S.pool_ovf.ensure((size_t)pool_units * 16 + 64);
+    stt.pool_ovf = S.pool_ovf.p;
+    stt.bump_cap = 0;
+    STAGE("k_slots<1>");
+    GDB_SLOT_KERNELS(1, kStripWords);   // every text longer than an inline slot is formatted again, into its scanned place
+  }
+#undef GDB_SLOT_KERNELS
+  S.long_texts_seen = long_texts * 16 > NS;    // the wide strip of pass 0 pays when a sixteenth of the texts is long
+  S.pool_ovf_need = std::max<uint64_t>(S.pool_ovf_need, shard_need);   // (units per shard)
   hipLaunchKernelGGL(k_slot_desc, dim3(blocks_for((int64_t)NS)), dim3(kBlock), 0, st, S.slot_len.p, S.slot_off.p, (int64_t)NS, S.slot_desc.p);
   stats.num_record_types = ntypes;
   stats.num_text_slots = (int64_t)NS;

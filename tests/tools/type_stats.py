@@ -14,8 +14,9 @@ ptr, nbytes, nc = g.next_chunk(B + L + 3000)
 e = genomicsdb_amd.CombineEngine(q)
 e.stage_cells_begin(); e.stage_cells_append(ptr, nbytes); e.stage_cells_end()
 e.set_reference(B, synth.reference(B, L + 4096))
-e.run_interval(B, B + L - 1, arena_bytes=40 << 30, fetch=False)
-_, st = e.run_interval(B, B + L - 1, arena_bytes=40 << 30, fetch=False)
+for it in range(4):
+    _, st = e.run_interval(B, B + L - 1, arena_bytes=40 << 30, fetch=False)
+    print("run %d phases ms: sweep %.1f site %.1f size %.1f write %.1f (kernel %.2f)" % (it, st.ms_sweep, st.ms_site, st.ms_size, st.ms_write, st.ms_write_kernel_avg))
 T = st.num_heavy_incidences
 print("N %d L %d: records %d cells_in_window %d heavy incidences %d (%.1f per record) types %d text slots %d (%.2f per cell) pool %.2f GB bytes_out %.2f GB"
       % (N, L, st.num_records, st.num_cells_in_window, T, T / max(1, st.num_records), st.num_record_types, st.num_text_slots, st.num_text_slots / max(1, st.num_cells_in_window),
