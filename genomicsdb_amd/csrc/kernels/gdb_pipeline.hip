@@ -429,12 +429,12 @@ constexpr int kHugeRecord = 256;          // variant calls from which a record c
 constexpr int kMaxHugeRecords = 8192;
 constexpr int kHugeTable = 512;           // LDS hash table slots (at most 127 distinct alleles per record)
 constexpr uint32_t kHugeEmpty = 0xFFFFFFFFu;
-__global__ void k_huge_records(const int64_t* hbase, int64_t P, int32_t* huge_index, int32_t* huge_list, int32_t* counter) {
+__global__ void k_huge_records(const int64_t* hbase, int64_t P, int32_t threshold, int32_t* huge_index, int32_t* huge_list, int32_t* counter) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= P) return;
   const int64_t n = hbase[k + 1] - hbase[k];
   int32_t idx = -1;
-  if (n > kHugeRecord) { idx = atomicAdd(counter, 1); if (idx < kMaxHugeRecords) huge_list[idx] = (int32_t)k; else idx = -1; }
+  if (n > threshold) { idx = atomicAdd(counter, 1); if (idx < kMaxHugeRecords) huge_list[idx] = (int32_t)k; else idx = -1; }
   huge_index[k] = idx;
 }
 struct HugeTable { uint32_t* hash; uint32_t* order; int16_t* midx; int32_t* overflow; };
@@ -475,7 +475,10 @@ struct HugeLookup {          // pass C: merged index of every candidate
     return 1;
   }
 };
-__global__ void __launch_bounds__(kBlock) k_site_huge(const SiteCtx* __restrict__ sxp, const int32_t* __restrict__ huge_list, const int32_t* __restrict__ counter,
+// (1 024 lanes per hot record: at the stated size of BASELINE configs[4] a record has 50 000 calls and a 2 kb piece holds 40 such
+// records - fewer than there are CUs - so the lanes of ONE record are what fills the device)
+constexpr int kHugeBlock = 1024;
+__global__ void __launch_bounds__(kHugeBlock) k_site_huge(const SiteCtx* __restrict__ sxp, const int32_t* __restrict__ huge_list, const int32_t* __restrict__ counter,
                                                       HugeSiteOut* __restrict__ out, uint32_t* err) {
   const SiteCtx& cx = *sxp;
   const CombinePlan& pl = cx.pl;
@@ -507,9 +510,9 @@ __global__ void __launch_bounds__(kBlock) k_site_huge(const SiteCtx* __restrict_
       s_nocc = 0;
       s_filter = ~0ull;
     }
-    for (int s = tid; s < kHugeTable; s += kBlock) { tab_hash[s] = kHugeEmpty; tab_order[s] = 0xFFFFFFFFu; tab_midx[s] = 0; }
+    for (int s = tid; s < kHugeTable; s += kHugeBlock) { tab_hash[s] = kHugeEmpty; tab_order[s] = 0xFFFFFFFFu; tab_midx[s] = 0; }
     __syncthreads();
-    for (int64_t t = hb + tid; t < he; t += kBlock) {
+    for (int64_t t = hb + tid; t < he; t += kHugeBlock) {
       const int64_t c = cx.hl.cell[t];
       if (cx.fr.begin[c] != s_k || !field_valid(cx.cm, c, pl.f_REF)) continue;
       int n;
@@ -528,7 +531,7 @@ __global__ void __launch_bounds__(kBlock) k_site_huge(const SiteCtx* __restrict_
     const int mref_len = s_mref_len;
     HugeTable tb{tab_hash, tab_order, tab_midx, &s_flags[0]};
     // ---- pass A: candidates -> table ---------------------------------------------------------------------------------------------
-    for (int64_t t = hb + tid; t < he; t += kBlock) {
+    for (int64_t t = hb + tid; t < he; t += kHugeBlock) {
       HugeInsert fa{tb, (uint32_t)(t - hb) << 6, 0u};
       site_merge_call(cx, t, s_k, mref, mref_len, false, fa, &e);
       if (fa.i > 63u) s_flags[1] = 1;                          // more tokens than the position key holds: serial walk
@@ -538,7 +541,7 @@ __global__ void __launch_bounds__(kBlock) k_site_huge(const SiteCtx* __restrict_
     // further part: its table is not trustworthy, the passes below would read merged[] entries nobody wrote (uniform per record)
     const bool skip_a = (s_flags[0] | s_flags[1]) != 0;
     // ---- merged order = ascending first position; representatives -----------------------------------------------------------------
-    for (int s = tid; s < kHugeTable && !skip_a; s += kBlock) {
+    for (int s = tid; s < kHugeTable && !skip_a; s += kHugeBlock) {
       if (tab_hash[s] == kHugeEmpty) continue;
       const uint32_t mine = tab_order[s];
       int rank = 0;
@@ -556,7 +559,7 @@ __global__ void __launch_bounds__(kBlock) k_site_huge(const SiteCtx* __restrict_
     const int num_merged = nmerged + (cx.pc.nr_cnt[k] > 0 ? 1 : 0);
     const bool skip_b = (s_flags[0] | s_flags[1]) != 0;        // (read behind the barrier: uniform)
     // ---- pass C: LUTs, flags, min-PL genotypes; <NON_REF> last -----------------------------------------------------------------------
-    for (int64_t t = hb + tid; t < he && !skip_b; t += kBlock) {
+    for (int64_t t = hb + tid; t < he && !skip_b; t += kHugeBlock) {
       HugeLookup fc{tb, o.merged, mref, mref_len, &s_flags[1]};
       site_merge_call(cx, t, s_k, mref, mref_len, true, fc, &e);
       const int64_t c = cx.hl.cell[t];
@@ -572,7 +575,7 @@ __global__ void __launch_bounds__(kBlock) k_site_huge(const SiteCtx* __restrict_
     // ---- FILTER union, ID presence ----------------------------------------------------------------------------------------------------
     const bool do_filter = pl.produce_FILTER_field && pl.f_FILTER >= 0;
     if (do_filter || pl.f_ID >= 0)
-      for (int64_t t = hb + tid; t < he; t += kBlock) {
+      for (int64_t t = hb + tid; t < he; t += kHugeBlock) {
         const int64_t c = cx.hl.cell[t];
         if (pl.f_ID >= 0 && field_valid(cx.cm, c, pl.f_ID)) s_flags[3] = 1;
         if (do_filter && field_valid(cx.cm, c, pl.f_FILTER)) {
@@ -584,7 +587,7 @@ __global__ void __launch_bounds__(kBlock) k_site_huge(const SiteCtx* __restrict_
     __syncthreads();
     if (do_filter && s_filter != ~0ull) {
       const int32_t first_id = (int32_t)(uint32_t)s_filter;
-      for (int64_t t = hb + tid; t < he; t += kBlock) {
+      for (int64_t t = hb + tid; t < he; t += kHugeBlock) {
         const int64_t c = cx.hl.cell[t];
         if (!field_valid(cx.cm, c, pl.f_FILTER)) continue;
         int n;
@@ -613,7 +616,7 @@ __global__ void __launch_bounds__(kBlock) k_site_huge(const SiteCtx* __restrict_
         __syncthreads();
         unsigned long long nvalid = 0, nbelow = 0, nneg0 = 0, npos0 = 0;
         int32_t isum = 0;
-        for (int64_t t = hb + tid; t < he; t += kBlock) {
+        for (int64_t t = hb + tid; t < he; t += kHugeBlock) {
           const uint32_t u = val[t];
           if (u == missing) continue;
           ++nvalid;
@@ -633,7 +636,7 @@ __global__ void __launch_bounds__(kBlock) k_site_huge(const SiteCtx* __restrict_
           float fsum = 0.0f;
           for (int64_t t0 = hb; t0 < he; t0 += 2048) {             // uniform
             const int64_t m = min((int64_t)2048, he - t0);
-            for (int64_t j = tid; j < m; j += kBlock) s_stage[j] = val[t0 + j];
+            for (int64_t j = tid; j < m; j += kHugeBlock) s_stage[j] = val[t0 + j];
             __syncthreads();
             if (tid == 0) for (int64_t j = 0; j < m; ++j) { const uint32_t u = s_stage[j]; if (u != missing) fsum += __uint_as_float(u); }
             __syncthreads();
@@ -648,10 +651,10 @@ __global__ void __launch_bounds__(kBlock) k_site_huge(const SiteCtx* __restrict_
           __syncthreads();
           for (int pass = 0; pass < 4; ++pass) {                  // uniform
             const int shift = 24 - 8 * pass;
-            s_hist[tid] = 0;                                       // (kBlock == 256)
+            if (tid < 256) s_hist[tid] = 0;
             __syncthreads();
             const uint32_t prefix = s_prefix, mask = s_mask;
-            for (int64_t t = hb + tid; t < he; t += kBlock) {
+            for (int64_t t = hb + tid; t < he; t += kHugeBlock) {
               const uint32_t u = val[t];
               if (u == missing) continue;
               const uint32_t key = is_float ? gdb_orderable_bits(__uint_as_float(u)) : gdb_orderable_bits((int32_t)u);
@@ -667,7 +670,7 @@ __global__ void __launch_bounds__(kBlock) k_site_huge(const SiteCtx* __restrict_
             __syncthreads();
           }
           const uint32_t want = s_prefix;
-          for (int64_t t = hb + tid; t < he; t += kBlock) {       // among equal values the first call supplies the bits
+          for (int64_t t = hb + tid; t < he; t += kHugeBlock) {       // among equal values the first call supplies the bits
             const uint32_t u = val[t];
             if (u == missing) continue;
             const uint32_t key = is_float ? gdb_orderable_bits(__uint_as_float(u)) : gdb_orderable_bits((int32_t)u);
@@ -4064,12 +4067,17 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   HugeSites huge;
   memset(&huge, 0, sizeof(huge));
   SiteCtx sx0{fr, pl, cm, rec, hl, pc, nt, qw, so, med, big, tie, pre, huge};
-  if (T > (int64_t)kHugeRecord && !getenv("GDBAMD_NO_HUGE_SITES")) {
+  // Which records get a workgroup of their own: the ones with more than kHugeRecord variant calls - and, when the interval's records
+  // carry many calls on average (tens of thousands of samples: BASELINE configs[4] has ~100 calls on every record and a few
+  // thousand records per piece, i.e. a few dozen wavefronts of one-thread-per-record walks of 100 calls each), every record with
+  // more than 24.
+  const int32_t huge_threshold = (P > 0 && T / P >= 24 && P <= (int64_t)kMaxHugeRecords) ? 24 : kHugeRecord;
+  if (T > (int64_t)huge_threshold && !getenv("GDBAMD_NO_HUGE_SITES")) {
     S.huge_index.ensure((size_t)P); S.huge_list.ensure(kMaxHugeRecords); S.huge_out.ensure(kMaxHugeRecords); S.d_sx0.ensure(1);
     HIP_CHECK(hipMemcpyAsync(S.d_sx0.p, &sx0, sizeof(SiteCtx), hipMemcpyHostToDevice, st));
     STAGE("k_site_huge");
-    hipLaunchKernelGGL(k_huge_records, dim3(blocks_for(P)), dim3(kBlock), 0, st, (const int64_t*)S.hbase.p, P, S.huge_index.p, S.huge_list.p, S.counters.p + 3);
-    hipLaunchKernelGGL(k_site_huge, dim3(1024), dim3(kBlock), 0, st, (const SiteCtx*)S.d_sx0.p, (const int32_t*)S.huge_list.p, (const int32_t*)(S.counters.p + 3), S.huge_out.p, S.err.p);
+    hipLaunchKernelGGL(k_huge_records, dim3(blocks_for(P)), dim3(kBlock), 0, st, (const int64_t*)S.hbase.p, P, huge_threshold, S.huge_index.p, S.huge_list.p, S.counters.p + 3);
+    hipLaunchKernelGGL(k_site_huge, dim3(1024), dim3(kHugeBlock), 0, st, (const SiteCtx*)S.d_sx0.p, (const int32_t*)S.huge_list.p, (const int32_t*)(S.counters.p + 3), S.huge_out.p, S.err.p);
     huge.index = S.huge_index.p; huge.out = S.huge_out.p; huge.enabled = 1;
   }
   SiteCtx sx{fr, pl, cm, rec, hl, pc, nt, qw, so, med, big, tie, pre, huge};
