@@ -469,7 +469,7 @@ def _oracle_partition(args):
 
 def cpu_baseline(N, sample_bp, tmp):
     """the CPU oracle (single-threaded restatement of the reference algorithm) on a bounded sample of the same workload:
-    (i) one core / one partition (the figure in "value"), (ii) min(32, cores) partitions in parallel, one process each, like
+    (i) one core / one partition (the figure in "value"), (ii) min(128, cores / 2) partitions in parallel, one process each, like
     the reference's one-rank-per-partition MPI runs"""
     import multiprocessing as mp
     B = 10_000_000
@@ -480,7 +480,7 @@ def cpu_baseline(N, sample_bp, tmp):
                      % (N, sample_bp, nrec, secs, nbytes),
            "host_cpus": os.cpu_count(), "cpu_model": _cpu_model()}
     try:
-        P = max(1, min(32, (os.cpu_count() or 1) // 2))
+        P = max(1, min(128, (os.cpu_count() or 1) // 2))     # min(P, cores): one rank per partition, half the host's hardware threads
         par_bp = max(1000, sample_bp // 3)
         for i in range(P):
             os.makedirs(os.path.join(tmp, "p%d" % (i + 1)), exist_ok=True)

@@ -3168,37 +3168,25 @@ __device__ __forceinline__ int inflate_construct(const InflateCode& h, const uin
   for (int sym = 0; sym < n; ++sym) if (length[sym] != 0) h.symbol[offs[length[sym]]++] = (uint16_t)sym;
   return left;
 }
-// The copy of a match by the eight lanes of a tile: byte i of the copy is the byte at (at - dist) + (i mod dist) - for dist >= len
-// that is the plain copy, for an overlapping match (dist < len) the repeating pattern the byte-by-byte definition produces.
-// All source bytes lie in front of `at`, so the lanes need no order among themselves; the LDS unit keeps the wavefront's
-// instructions in order, so the literal stores before and the reads after are seen.
-__device__ __forceinline__ void inflate_copy_match(uint8_t* o, uint32_t at, uint32_t len, uint32_t dist, int sub) {
-  const uint8_t* src = o + at - dist;
-  if (dist >= len) { for (uint32_t i = (uint32_t)sub; i < len; i += 8) o[at + i] = src[i]; }
-  else { for (uint32_t i = (uint32_t)sub; i < len; i += 8) o[at + i] = src[i % dist]; }
+// The copy of a match: 8 bytes per load / store while the distance allows it (a copy with dist >= 8 never reads a byte its own
+// current 8-byte store writes; bytes written by EARLIER stores of the same lane are seen - the vector memory pipeline keeps one
+// lane's accesses to an address in order, which the byte-by-byte loop of round 2 relied on as well).  The byte loop made every
+// copied byte a global load behind a global store - one memory round trip per byte, the largest item of the kernel's time.
+__device__ __forceinline__ void inflate_copy_match(uint8_t* o, uint32_t at, uint32_t len, uint32_t dist) {
+  uint32_t i = 0;
+  if (dist >= 8u)
+    for (; i + 8u <= len; i += 8u) { uint64_t w; __builtin_memcpy(&w, o + at - dist + i, 8); __builtin_memcpy(o + at + i, &w, 8); }
+  for (; i < len; ++i) o[at + i] = o[at + i - dist];
 }
 // job t: compressed bytes [in_off[t], in_off[t + 1]) of `comp` -> want[t] bytes at out + t * kFragTile
-//
-// One wavefront inflates EIGHT tiles, eight lanes per tile, each tile's output in its own 8 KiB of LDS.  The round-2 kernel had one
-// lane per tile writing its output to global memory a byte at a time and copying matches through it - every copied byte a
-// dependent global load behind a global store (63 GB/s out).  Now the eight lanes of a tile all follow the tile's bit stream (the
-// same loads, the same decisions: no divergence inside the group, nothing to broadcast), a literal is stored by the group's first
-// lane, a match is copied by all eight from LDS to LDS - byte i of it is out[at - dist + i mod dist], whatever the overlap, so
-// the eight lanes take every eighth byte - and the finished tile leaves LDS as coalesced 16-byte stores.  The bit-serial part of
-// DEFLATE stays serial per tile; what the wavefront shares is the cost of everything around it.
-constexpr int kInflateGroup = 8;                  // lanes per tile
-constexpr int kInflateTilesPerWave = 64 / kInflateGroup;
-__global__ void __launch_bounds__(64) k_inflate_tiles(const uint8_t* __restrict__ comp, const uint64_t* __restrict__ in_off, const uint32_t* __restrict__ want_bytes, int64_t ntiles,
-                                                      uint8_t* __restrict__ out, uint8_t* __restrict__ scratch, uint32_t* err) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds_out[kInflateTilesPerWave][kFragTile];
-  const int sub = threadIdx.x & (kInflateGroup - 1), grp = threadIdx.x / kInflateGroup;
-  const int64_t t_raw = (int64_t)blockIdx.x * kInflateTilesPerWave + grp;
-  const bool have = t_raw < ntiles;
-  const int64_t t = have ? t_raw : ntiles - 1;     // (idle groups shadow the last tile and write nothing)
+__global__ void k_inflate_tiles(const uint8_t* __restrict__ comp, const uint64_t* __restrict__ in_off, const uint32_t* __restrict__ want_bytes, int64_t ntiles, uint8_t* __restrict__ out,
+                                uint8_t* __restrict__ scratch, uint32_t* err) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntiles) return;
   uint8_t* const lengths = scratch + (uint64_t)t * kInflateScratch;                                       // [320]
   const InflateCode lencode{reinterpret_cast<uint16_t*>(lengths + 320), reinterpret_cast<uint16_t*>(lengths + 320) + 16};
   const InflateCode distcode{lencode.symbol + 288, lencode.symbol + 288 + 16};
-  uint8_t* const o = &lds_out[grp][0];
+  uint8_t* const o = out + (uint64_t)t * kFragTile;
   const uint32_t want = want_bytes[t];
   InflateBits b{comp + in_off[t], comp + in_off[t + 1], 0ull, 0};
   uint32_t at = 0;
@@ -3214,7 +3202,7 @@ __global__ void __launch_bounds__(64) k_inflate_tiles(const uint8_t* __restrict_
       if (b.n < 32) { bad = true; break; }
       const uint32_t len = b.get(16), nlen = b.get(16);
       if ((len ^ nlen) != 0xFFFFu || at + len > want) { bad = true; break; }
-      for (uint32_t i = 0; i < len; ++i) { b.refill(); if (b.n < 8) { bad = true; break; } const uint8_t v = (uint8_t)b.get(8); if (sub == 0) o[at] = v; ++at; }
+      for (uint32_t i = 0; i < len; ++i) { b.refill(); if (b.n < 8) { bad = true; break; } o[at++] = (uint8_t)b.get(8); }
     } else if (type == 1) {                            // fixed Huffman codes
       for (;;) {
         b.refill();
@@ -3233,7 +3221,7 @@ __global__ void __launch_bounds__(64) k_inflate_tiles(const uint8_t* __restrict_
           }
         }
         if (b.n < 0) { bad = true; break; }
-        if (sym < 256u) { if (at >= want) { bad = true; break; } if (sub == 0) o[at] = (uint8_t)sym; ++at; continue; }
+        if (sym < 256u) { if (at >= want) { bad = true; break; } o[at++] = (uint8_t)sym; continue; }
         if (sym == 256u) break;
         if (sym > 285u) { bad = true; break; }
         b.refill();
@@ -3244,7 +3232,7 @@ __global__ void __launch_bounds__(64) k_inflate_tiles(const uint8_t* __restrict_
         b.refill();
         const uint32_t dist = kInfDistBase[dc] + b.get(kInfDistExtra[dc]);
         if (b.n < 0 || dist > at || at + len > want) { bad = true; break; }
-        inflate_copy_match(o, at, len, dist, sub);
+        inflate_copy_match(o, at, len, dist);
         at += len;
       }
     } else if (type == 2) {                            // dynamic codes: read the code lengths, build both tables, decode
@@ -3284,7 +3272,7 @@ __global__ void __launch_bounds__(64) k_inflate_tiles(const uint8_t* __restrict_
       for (;;) {
         const int sym = inflate_decode(b, lencode);
         if (sym < 0) { bad = true; break; }
-        if (sym < 256) { if (at >= want) { bad = true; break; } if (sub == 0) o[at] = (uint8_t)sym; ++at; continue; }
+        if (sym < 256) { if (at >= want) { bad = true; break; } o[at++] = (uint8_t)sym; continue; }
         if (sym == 256) break;
         if (sym > 285) { bad = true; break; }
         b.refill();
@@ -3295,23 +3283,12 @@ __global__ void __launch_bounds__(64) k_inflate_tiles(const uint8_t* __restrict_
         b.refill();
         const uint32_t dist = kInfDistBase[dc] + b.get(kInfDistExtra[dc]);
         if (b.n < 0 || dist > at || at + len > want) { bad = true; break; }
-        inflate_copy_match(o, at, len, dist, sub);
+        inflate_copy_match(o, at, len, dist);
         at += len;
       }
     } else bad = true;                                 // the reserved block type
   }
-  if (have && sub == 0 && (bad || at != want)) atomicOr(err, (uint32_t)GDB_ERR_CELL_STREAM);
-  // ---- the tiles leave LDS: 16 bytes per lane and store, whole wavefront per tile ---------------------------------------------------
-  __syncthreads();
-  for (int g = 0; g < kInflateTilesPerWave; ++g) {
-    const int64_t tg = (int64_t)blockIdx.x * kInflateTilesPerWave + g;
-    if (tg >= ntiles) break;
-    const uint32_t wn = want_bytes[tg];
-    uint8_t* const dst = out + (uint64_t)tg * kFragTile;
-    const uint32_t nq = wn >> 4;
-    for (uint32_t q = threadIdx.x; q < nq; q += 64) reinterpret_cast<uint4*>(dst)[q] = reinterpret_cast<const uint4*>(&lds_out[g][0])[q];
-    for (uint32_t i = (nq << 4) + threadIdx.x; i < wn; i += 64) dst[i] = lds_out[g][i];
-  }
+  if (bad || at != want) atomicOr(err, (uint32_t)GDB_ERR_CELL_STREAM);
 }
 
 const char kFragMagic[8] = {'G', 'D', 'B', 'A', 'M', 'D', 'F', '2'};
@@ -3702,7 +3679,7 @@ DevicePipeline::FragmentWindow DevicePipeline::append_fragment_cells(int64_t c0,
     for (auto& fr : file_ranges) { F.to_device(S.inflate_in.p + at_in, fr.first, fr.second, st); at_in += fr.second; }
     HIP_CHECK(hipMemcpyAsync(S.inflate_off.p, job_in.data(), (size_t)(njobs + 1) * 8, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(S.inflate_want.p, job_want.data(), (size_t)njobs * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_inflate_tiles, dim3(blocks_for((int64_t)njobs, kInflateTilesPerWave)), dim3(64), 0, st, (const uint8_t*)S.inflate_in.p, (const uint64_t*)S.inflate_off.p, (const uint32_t*)S.inflate_want.p,
+    hipLaunchKernelGGL(k_inflate_tiles, dim3(blocks_for((int64_t)njobs, 64)), dim3(64), 0, st, (const uint8_t*)S.inflate_in.p, (const uint64_t*)S.inflate_off.p, (const uint32_t*)S.inflate_want.p,
                        (int64_t)njobs, S.inflate_out.p, S.inflate_scratch.p, S.err.p);
     for (auto& c : copies) HIP_CHECK(hipMemcpyAsync(c.dev, S.inflate_out.p + c.from, c.bytes, hipMemcpyDeviceToDevice, st));
     HIP_CHECK(hipStreamSynchronize(st));                          // (the host vectors above are read by the copies)

@@ -21,7 +21,7 @@ g = synth.Generator(N, B, L + 3000, dense=(B, L, 50, K))
 eng.stage_cells_begin()
 col, ncells, nbytes_all = B, 0, 0
 while col < B + L + 3000:
-    col = min(B + L + 3000, col + 20000)
+    col = min(B + L + 3000, col + 4000)      # (a chunk stays below 4 GB: the size walk on the device counts in 32 bits)
     ptr, nbytes, nc = g.next_chunk(col)
     eng.stage_cells_append(ptr, nbytes); ncells += nc; nbytes_all += nbytes
 eng.stage_cells_end()
