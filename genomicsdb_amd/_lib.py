@@ -17,7 +17,14 @@ class IntervalStats(ctypes.Structure):
                 ("num_record_types", ctypes.c_int32), ("reserved0", ctypes.c_int32),
                 ("num_text_slots", ctypes.c_int64), ("text_pool_bytes", ctypes.c_int64),
                 ("num_remap_elements", ctypes.c_uint64), ("bytes_compressed", ctypes.c_uint64), ("ms_compress", ctypes.c_float),
-                ("reserved1", ctypes.c_int32)]
+                ("reserved1", ctypes.c_int32), ("gt_profile_stats", ctypes.c_uint64 * 6)]
+
+    # names of the reference's GTProfileStats counters (query_variants.h:67-124), in enum order
+    GT_STAT_NAMES = ("GT_NUM_CELLS", "GT_NUM_CELLS_IN_LEFT_SWEEP", "GT_NUM_VALID_CELLS_IN_QUERY", "GT_NUM_ATTR_CELLS_ACCESSED",
+                     "GT_NUM_PQ_FLUSHES_DUE_TO_OVERLAPPING_CELLS", "GT_NUM_OPERATOR_INVOCATIONS")
+
+    def gt_profile(self):
+        return dict(zip(self.GT_STAT_NAMES, (int(v) for v in self.gt_profile_stats)))
 
 
 class StreamStats(ctypes.Structure):

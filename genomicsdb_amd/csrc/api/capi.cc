@@ -236,6 +236,7 @@ int gdbamd_engine_run_interval(void* e, int64_t qb, int64_t qe, uint64_t arena_b
       out->num_text_slots = s.num_text_slots; out->text_pool_bytes = s.text_pool_bytes;
       out->num_remap_elements = s.num_remap_elements;
       out->bytes_compressed = s.bytes_compressed; out->ms_compress = s.ms_compress; out->reserved1 = 0;
+      for (int i = 0; i < GDBAMD_GT_NUM_STATS; ++i) out->gt_profile_stats[i] = s.gt_profile[i];
     }
     return 0;
   }, 1);

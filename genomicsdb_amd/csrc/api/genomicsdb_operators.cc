@@ -7,10 +7,30 @@
 
 #include <algorithm>
 #include <climits>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 
 namespace genomicsdb_amd {
+
+const char* GTProfileStats::stat_name(unsigned i) {
+  static const char* const names[GT_NUM_STATS] = {"GT_NUM_CELLS", "GT_NUM_CELLS_IN_LEFT_SWEEP", "GT_NUM_VALID_CELLS_IN_QUERY", "GT_NUM_ATTR_CELLS_ACCESSED",
+                                                  "GT_NUM_PQ_FLUSHES_DUE_TO_OVERLAPPING_CELLS", "GT_NUM_OPERATOR_INVOCATIONS"};
+  return i < GT_NUM_STATS ? names[i] : "";
+}
+void GTProfileStats::print_stats(FILE* f) const {    // (reference: GTProfileStats::print_stats, query_variants.cc:90-110)
+  fprintf(f, "stat_name,sum,sum_sq,mean,std-dev\n");
+  for (unsigned i = 0; i < GT_NUM_STATS; ++i) {
+    fprintf(f, "%s,%llu,%.6g", stat_name(i), (unsigned long long)m_sum[i], m_sum_sq[i]);
+    if (m_num_queries == 0) fprintf(f, ",*,*\n");
+    else {
+      const double mean = (double)m_sum[i] / (double)m_num_queries;
+      double var = m_sum_sq[i] / (double)m_num_queries - mean * mean;
+      if (var < 0) var = -var;
+      fprintf(f, ",%.6g,%.6g\n", mean, std::sqrt(var));
+    }
+  }
+}
 
 // ---- adapters -----------------------------------------------------------------------------------------------------------------
 VCFAdapter::~VCFAdapter() {
@@ -151,6 +171,11 @@ void VariantQueryProcessor::scan_and_operate(const int, const VariantQueryConfig
       const int64_t pe = eng.pipeline().split_point(st.m_piece_begin, std::min(st.m_interval_end, cov.hi), std::max<int64_t>(1000, (int64_t)(48ll << 30) / (n * 64)));
       eng.stage_reference_for(st.m_piece_begin, pe);
       eng.pipeline().prepare_interval(st.m_piece_begin, pe);
+      {
+        const IntervalStats& is = eng.pipeline().interval_stats();
+        for (unsigned i = 0; i < GTProfileStats::GT_NUM_STATS; ++i) m_stats.update_stat(i, is.gt_profile[i]);
+        m_stats.increment_num_queries();
+      }
       st.m_piece_begin = pe + 1;             // (the piece in flight is remembered by the pipeline)
       st.m_piece_active = true;
       E.next_valid = false;

@@ -142,6 +142,30 @@ class BatchedVariantOperatorBase : public SingleVariantOperatorBase {
   virtual void operate_on_page(const char* device_ptr, uint64_t nbytes, int64_t column_begin, int64_t column_end) = 0;
 };
 
+// The reference's profiling counters (include/genomicsdb/query_variants.h:67-124, printed by scan_and_operate under -DDO_PROFILING),
+// same enum names; filled from the device's per-interval counters (gdbamd_interval_stats.gt_profile_stats, include/genomicsdb_amd.h)
+// after every piece of a scan, always on.
+class GTProfileStats {
+ public:
+  enum GTStatIdx {
+    GT_NUM_CELLS = 0, GT_NUM_CELLS_IN_LEFT_SWEEP, GT_NUM_VALID_CELLS_IN_QUERY, GT_NUM_ATTR_CELLS_ACCESSED,
+    GT_NUM_PQ_FLUSHES_DUE_TO_OVERLAPPING_CELLS, GT_NUM_OPERATOR_INVOCATIONS, GT_NUM_STATS
+  };
+  void update_stat(unsigned stat_idx, uint64_t value) {
+    if (stat_idx >= GT_NUM_STATS) return;
+    m_sum[stat_idx] += value; m_sum_sq[stat_idx] += (double)value * (double)value;
+  }
+  void increment_num_queries() { ++m_num_queries; }
+  uint64_t get_stat(unsigned stat_idx) const { return stat_idx < GT_NUM_STATS ? m_sum[stat_idx] : 0; }
+  uint64_t get_num_queries() const { return m_num_queries; }
+  static const char* stat_name(unsigned stat_idx);
+  void print_stats(FILE* fptr = stderr) const;      // "stat_name,sum,sum_sq,mean,std-dev" lines as the reference prints them
+ private:
+  uint64_t m_sum[GT_NUM_STATS] = {0, 0, 0, 0, 0, 0};
+  double m_sum_sq[GT_NUM_STATS] = {0, 0, 0, 0, 0, 0};
+  uint64_t m_num_queries = 0;
+};
+
 class VariantQueryProcessorScanState {           // where a scan stands between two scan_and_operate calls of one column interval
  public:
   bool end() const { return m_done; }
@@ -164,7 +188,9 @@ class VariantQueryProcessor {
   // operator's buffer has overflowed (scan state says whether the interval is done), otherwise it runs the interval to its end.
   void scan_and_operate(const int ad, const VariantQueryConfig& query_config, SingleVariantOperatorBase& variant_operator, unsigned column_interval_idx = 0u,
                         bool handle_spanning_deletions = false, VariantQueryProcessorScanState* scan_state = 0) const;
+  const GTProfileStats& get_profile_stats() const { return m_stats; }   // summed over every piece of every scan of this processor
  private:
+  mutable GTProfileStats m_stats;
   VariantStorageManager* m_storage_manager;
   std::string m_array_name;
   VariantArraySchema m_schema;
@@ -180,6 +206,7 @@ using genomicsdb_amd::BroadCombinedGVCFOperator;
 using genomicsdb_amd::GA4GHOperator;
 using genomicsdb_amd::GenomicsDBBCFGenerator;
 using genomicsdb_amd::GenomicsDBImportConfig;
+using genomicsdb_amd::GTProfileStats;
 using genomicsdb_amd::RWBuffer;
 using genomicsdb_amd::SingleVariantOperatorBase;
 using genomicsdb_amd::Variant;

@@ -40,7 +40,11 @@ struct IntervalStats {
   uint64_t num_remap_elements = 0; // sum over re-indexed records of (calls with PL) x (merged genotypes)
   uint64_t bytes_compressed = 0;   // BGZF output formats: bytes of the pages after compression (bytes_out stays the uncompressed size)
   float ms_compress = 0;           // device time of the compression kernels
+  // the reference's GTProfileStats counters (query_variants.h:67-124), per interval; see include/genomicsdb_amd.h
+  uint64_t gt_profile[6] = {0, 0, 0, 0, 0, 0};
 };
+enum GTStatIdx { GT_NUM_CELLS = 0, GT_NUM_CELLS_IN_LEFT_SWEEP, GT_NUM_VALID_CELLS_IN_QUERY, GT_NUM_ATTR_CELLS_ACCESSED,
+                 GT_NUM_PQ_FLUSHES_DUE_TO_OVERLAPPING_CELLS, GT_NUM_OPERATOR_INVOCATIONS, GT_NUM_STATS };
 
 // what the engine needs to know about a staged fragment besides the columns
 struct FragmentFileMeta {

@@ -289,6 +289,13 @@ __global__ void k_cell_ranges(FragmentView fr, CombinePlan pl, CellMeta cm, Reco
   // one atomic per wavefront, spread over kCountSpread addresses (same-address atomics serialise in L2: ~10 ns each)
   const uint64_t m = __ballot(live);
   if (lane == 0 && m) atomicAdd(in_window_count + 16 + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & (kCountSpread - 1)), (int32_t)__popcll(m));
+  // GTProfileStats (query_variants.h:67-124): cells the left sweep contributes (begin before the interval, live at its first
+  // column) and cells cut short by the next cell of their sample (the reference flushes its PQ there); both are rare
+  bool left = false, cut = false;
+  if (live) { const int64_t c = c_base + i; left = fr.begin[c] < qb; cut = cm.eff_end[c] < fr.end[c]; }
+  const uint64_t ml = __ballot(left), mc = __ballot(cut);
+  if (lane == 0 && ml) atomicAdd(in_window_count + 4, (int32_t)__popcll(ml));
+  if (lane == 0 && mc) atomicAdd(in_window_count + 5, (int32_t)__popcll(mc));
 }
 __global__ void k_incidence_fill(FragmentView fr, CellMeta cm, const int64_t* hoff, int64_t c_base, int64_t n, int64_t nrows, uint64_t* keys, int64_t* vals) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -3929,9 +3936,16 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   hipLaunchKernelGGL(k_unpack_counts, dim3(blocks_for(stride)), dim3(kBlock), 0, st, pk, nf, stride, da);
   S.excl_scan(S.heavy_count.p, S.hoff.p, (size_t)CW);
   int64_t T_a = 0, T_b = 0;
-  int32_t n_in_window = 0, spread[kCountSpread];
-  S.read_back_many({{&T_a, S.hoff.p + (CW - 1), sizeof(int64_t)}, {&T_b, S.heavy_count.p + (CW - 1), sizeof(int64_t)}, {spread, S.counters.p + 16, sizeof(spread)}});
+  int32_t n_in_window = 0, spread[kCountSpread], sweep_counts[2] = {0, 0};
+  S.read_back_many({{&T_a, S.hoff.p + (CW - 1), sizeof(int64_t)}, {&T_b, S.heavy_count.p + (CW - 1), sizeof(int64_t)}, {spread, S.counters.p + 16, sizeof(spread)},
+                    {sweep_counts, S.counters.p + 4, sizeof(sweep_counts)}});
   for (int i = 0; i < kCountSpread; ++i) n_in_window += spread[i];
+  stats.gt_profile[GT_NUM_CELLS] = (uint64_t)CW;
+  stats.gt_profile[GT_NUM_CELLS_IN_LEFT_SWEEP] = (uint64_t)sweep_counts[0];
+  stats.gt_profile[GT_NUM_VALID_CELLS_IN_QUERY] = (uint64_t)n_in_window;
+  stats.gt_profile[GT_NUM_ATTR_CELLS_ACCESSED] = (uint64_t)n_in_window * (uint64_t)pl.nfields;
+  stats.gt_profile[GT_NUM_PQ_FLUSHES_DUE_TO_OVERLAPPING_CELLS] = (uint64_t)sweep_counts[1];
+  stats.gt_profile[GT_NUM_OPERATOR_INVOCATIONS] = (uint64_t)P;
   const int64_t T = T_a + T_b;
   stats.num_heavy_incidences = T;
   stats.num_cells_in_window = n_in_window;

@@ -98,7 +98,16 @@ typedef struct gdbamd_interval_stats {
   uint64_t num_remap_elements;           /* sum over re-indexed records of (calls with PL) x (merged genotypes): the PL remap work */
   uint64_t bytes_compressed;             /* output formats "z" / "b": bytes of the pages after BGZF compression (bytes_out: before) */
   float ms_compress; int32_t reserved1;  /* device time of the compression kernels */
+  /* the six counters of the reference's GTProfileStats (src/main/cpp/include/genomicsdb/query_variants.h:67-124, -DDO_PROFILING),
+   * indexed by the enum below; counted per interval on the device.  The reference counts cell VISITS of its iterators; here every
+   * cell is touched once per interval, so: NUM_CELLS = cells of the staged window considered for the interval, IN_LEFT_SWEEP =
+   * cells that begin before the interval and are still live at its first column (what gt_get_column has to find),
+   * VALID_CELLS_IN_QUERY = cells that contribute to at least one record, ATTR_CELLS_ACCESSED = those x queried attributes,
+   * PQ_FLUSHES_DUE_TO_OVERLAPPING_CELLS = cells cut short by the next cell of their own sample, OPERATOR_INVOCATIONS = records */
+  uint64_t gt_profile_stats[6];
 } gdbamd_interval_stats;
+enum { GDBAMD_GT_NUM_CELLS = 0, GDBAMD_GT_NUM_CELLS_IN_LEFT_SWEEP, GDBAMD_GT_NUM_VALID_CELLS_IN_QUERY, GDBAMD_GT_NUM_ATTR_CELLS_ACCESSED,
+       GDBAMD_GT_NUM_PQ_FLUSHES_DUE_TO_OVERLAPPING_CELLS, GDBAMD_GT_NUM_OPERATOR_INVOCATIONS, GDBAMD_GT_NUM_STATS };
 
 /* one attribute column in device memory; off == NULL for fixed-length attributes */
 typedef struct gdbamd_device_column { const void* data; const uint32_t* off; } gdbamd_device_column;

@@ -111,6 +111,7 @@ int main(int argc, char** argv) {
       qp.scan_and_operate(qp.get_array_descriptor(), query_config, counter, 0, true, 0);
       std::cerr << "per-record operator refused: " << (refused ? "yes" : "no") << ", batched hook: " << counter.pages << " pages, " << counter.bytes << " bytes\n";
     }
+    if (getenv("GDBAMD_PRINT_PROFILE")) qp.get_profile_stats().print_stats(stderr);   // (the reference prints them under -DDO_PROFILING, query_variants.cc:455-459)
     sm.close_array(qp.get_array_descriptor());
   } catch (const std::exception& e) {
     std::cerr << "gt_mpi_gather_shaped: " << e.what() << "\n";

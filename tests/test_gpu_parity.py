@@ -1132,6 +1132,14 @@ def test_reference_shaped_cpp_caller_produces_the_golden(gdb, tmp_path):
         assert r.stdout == helpers.golden_text(golden)
     r = subprocess.run([tool, str(qf), "0", "more"], capture_output=True, timeout=120)
     assert r.returncode == 0 and b"per-record operator refused: yes" in r.stderr and b"batched hook: 1 pages" in r.stderr
+    # the reference's profiling counters, as GTProfileStats::print_stats prints them (three samples, 5 begin-cells, 4 records)
+    r = subprocess.run([tool, str(qf), "0"], capture_output=True, timeout=120, env=dict(os.environ, GDBAMD_PRINT_PROFILE="1"))
+    assert r.returncode == 0 and r.stdout == helpers.golden_text(golden)
+    lines = r.stderr.decode().splitlines()
+    assert "stat_name,sum,sum_sq,mean,std-dev" in lines
+    stat = {l.split(",")[0]: l.split(",")[1:] for l in lines if l.startswith("GT_NUM_")}
+    assert stat["GT_NUM_CELLS"][0] == "5" and stat["GT_NUM_OPERATOR_INVOCATIONS"][0] == "4" and stat["GT_NUM_VALID_CELLS_IN_QUERY"][:2] == ["5", "25"]
+    assert stat["GT_NUM_CELLS_IN_LEFT_SWEEP"][0] == "0" and len(stat) == 6
 
 
 @pytest.mark.gpu
