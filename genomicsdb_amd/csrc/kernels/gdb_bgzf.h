@@ -40,6 +40,12 @@ class BgzfDeviceCompressor {
   // is written only after every piece has been read), then waits for the stream and returns the number of bytes at dev_dst.
   // ms_kernels (optional): device time of the two kernels.
   uint64_t compress(const char* dev_src, uint64_t n, char* dev_dst, void* hip_stream, float* ms_kernels = nullptr);
+  // The same in two halves, so that the host need not wait between the kernels that produce a page and the ones that compress it:
+  // enqueue() only queues work on the stream (n > 0), finish() waits for it and returns the size.  Two jobs (slot 0 / 1) may be
+  // queued behind each other on ONE stream; cancel() forgets a queued job whose result nobody will ask for.
+  void enqueue(int slot, const char* dev_src, uint64_t n, char* dev_dst, void* hip_stream);
+  uint64_t finish(int slot, float* ms_kernels = nullptr);
+  void cancel(int slot);
   struct Impl;
  private:
   Impl* m_;

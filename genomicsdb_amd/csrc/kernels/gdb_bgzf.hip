@@ -350,22 +350,26 @@ struct BgzfDeviceCompressor::Impl {
   uint8_t* slots = nullptr; size_t slots_cap = 0;
   uint32_t* csize = nullptr; uint32_t* crc = nullptr; uint64_t* bsize = nullptr; uint64_t* boff = nullptr; size_t blocks_cap = 0;
   void* temp = nullptr; size_t temp_cap = 0;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // two jobs may be queued behind each other on one stream (the stream's two page arenas); they share the scratch buffers -
+  // stream order keeps them apart - and have their own events and their own pinned word for the size of the result
+  struct Job { hipEvent_t ev0 = nullptr, ev1 = nullptr, done = nullptr; bool pending = false; } job[2];
+  uint64_t* h_total = nullptr;          // pinned, [2]
   void release() {
     for (void* p : {(void*)d_slice, (void*)d_shift, (void*)slots, (void*)csize, (void*)crc, (void*)bsize, (void*)boff, temp}) if (p) (void)hipFree(p);
-    if (ev0) (void)hipEventDestroy(ev0);
-    if (ev1) (void)hipEventDestroy(ev1);
+    for (Job& j : job) for (hipEvent_t e : {j.ev0, j.ev1, j.done}) if (e) (void)hipEventDestroy(e);
+    if (h_total) (void)hipHostFree(h_total);
   }
 };
 
 BgzfDeviceCompressor::BgzfDeviceCompressor() : m_(new Impl) {}
 BgzfDeviceCompressor::~BgzfDeviceCompressor() { m_->release(); delete m_; }
 
-uint64_t BgzfDeviceCompressor::compress(const char* dev_src, uint64_t n, char* dev_dst, void* hip_stream, float* ms_kernels) {
-  if (ms_kernels) *ms_kernels = 0;
-  if (n == 0) return 0;
-  if ((uintptr_t)dev_src & 15u) throw std::runtime_error("BGZF: the page is not 16-byte aligned");
+void BgzfDeviceCompressor::enqueue(int slot, const char* dev_src, uint64_t n, char* dev_dst, void* hip_stream) {
+  slot &= 1;
   Impl& S = *m_;
+  // (a job still pending in this slot was abandoned by its owner: the new one simply queues behind it)
+  if (n == 0) throw std::runtime_error("BGZF: empty input");
+  if ((uintptr_t)dev_src & 15u) throw std::runtime_error("BGZF: the page is not 16-byte aligned");
   hipStream_t st = (hipStream_t)hip_stream;
   if (!S.d_slice) {
     std::vector<uint32_t> slice, shift;
@@ -375,12 +379,17 @@ uint64_t BgzfDeviceCompressor::compress(const char* dev_src, uint64_t n, char* d
     BGZF_HIP(hipMalloc((void**)&S.d_shift, shift.size() * 4));
     BGZF_HIP(hipMemcpy(S.d_slice, slice.data(), slice.size() * 4, hipMemcpyHostToDevice));
     BGZF_HIP(hipMemcpy(S.d_shift, shift.data(), shift.size() * 4, hipMemcpyHostToDevice));
-    BGZF_HIP(hipEventCreate(&S.ev0));
-    BGZF_HIP(hipEventCreate(&S.ev1));
+    for (Impl::Job& j : S.job) {
+      BGZF_HIP(hipEventCreate(&j.ev0));
+      BGZF_HIP(hipEventCreate(&j.ev1));
+      BGZF_HIP(hipEventCreateWithFlags(&j.done, hipEventDisableTiming));
+    }
+    BGZF_HIP(hipHostMalloc((void**)&S.h_total, 2 * sizeof(uint64_t), hipHostMallocDefault));
   }
   const uint32_t kBgzfBlockInput = S.block;
   const uint64_t nblocks = (n + kBgzfBlockInput - 1) / kBgzfBlockInput;
   if (nblocks >= (1ull << 31)) throw std::runtime_error("BGZF: page too large");
+  // (growing a scratch buffer frees memory the other queued job may still use: the stream has to be idle for that)
   if (S.blocks_cap < nblocks + 1) {
     BGZF_HIP(hipStreamSynchronize(st));
     for (void* p : {(void*)S.csize, (void*)S.crc, (void*)S.bsize, (void*)S.boff}) if (p) (void)hipFree(p);
@@ -397,14 +406,6 @@ uint64_t BgzfDeviceCompressor::compress(const char* dev_src, uint64_t n, char* d
     BGZF_HIP(hipMalloc((void**)&S.slots, need_slots + (need_slots >> 4)));
     S.slots_cap = need_slots + (need_slots >> 4);
   }
-  BGZF_HIP(hipEventRecord(S.ev0, st));
-  if (kBgzfBlockInput == 16384u)
-    hipLaunchKernelGGL(k_bgzf_deflate<16384>, dim3((unsigned)nblocks), dim3(64), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.bsize, S.crc, (const uint32_t*)S.d_slice,
-                       (const uint32_t*)S.d_shift);
-  else
-    hipLaunchKernelGGL(k_bgzf_deflate<8192>, dim3((unsigned)nblocks), dim3(64), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.bsize, S.crc, (const uint32_t*)S.d_slice,
-                       (const uint32_t*)S.d_shift);
-  BGZF_HIP(hipMemsetAsync(S.bsize + nblocks, 0, sizeof(uint64_t), st));
   size_t bytes = 0;
   BGZF_HIP(rocprim::exclusive_scan(nullptr, bytes, S.bsize, S.boff, (uint64_t)0, (size_t)nblocks + 1, rocprim::plus<uint64_t>(), st));
   if (S.temp_cap < bytes) {
@@ -413,15 +414,42 @@ uint64_t BgzfDeviceCompressor::compress(const char* dev_src, uint64_t n, char* d
     BGZF_HIP(hipMalloc(&S.temp, bytes + 256));
     S.temp_cap = bytes + 256;
   }
+  Impl::Job& J = S.job[slot];
+  BGZF_HIP(hipEventRecord(J.ev0, st));
+  if (kBgzfBlockInput == 16384u)
+    hipLaunchKernelGGL(k_bgzf_deflate<16384>, dim3((unsigned)nblocks), dim3(64), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.bsize, S.crc, (const uint32_t*)S.d_slice,
+                       (const uint32_t*)S.d_shift);
+  else
+    hipLaunchKernelGGL(k_bgzf_deflate<8192>, dim3((unsigned)nblocks), dim3(64), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.bsize, S.crc, (const uint32_t*)S.d_slice,
+                       (const uint32_t*)S.d_shift);
+  BGZF_HIP(hipMemsetAsync(S.bsize + nblocks, 0, sizeof(uint64_t), st));
   BGZF_HIP(rocprim::exclusive_scan(S.temp, bytes, S.bsize, S.boff, (uint64_t)0, (size_t)nblocks + 1, rocprim::plus<uint64_t>(), st));
   hipLaunchKernelGGL(k_bgzf_pack, dim3((unsigned)nblocks), dim3(64), 0, st, (const uint8_t*)S.slots, (const uint32_t*)S.csize, (const uint64_t*)S.boff, (const uint32_t*)S.crc, n,
                      (uint8_t*)dev_dst, kBgzfBlockInput);
-  BGZF_HIP(hipEventRecord(S.ev1, st));
-  uint64_t total = 0;
-  BGZF_HIP(hipMemcpyAsync(&total, S.boff + nblocks, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-  BGZF_HIP(hipStreamSynchronize(st));
-  if (ms_kernels) BGZF_HIP(hipEventElapsedTime(ms_kernels, S.ev0, S.ev1));
-  return total;
+  BGZF_HIP(hipEventRecord(J.ev1, st));
+  BGZF_HIP(hipMemcpyAsync(S.h_total + slot, S.boff + nblocks, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  BGZF_HIP(hipEventRecord(J.done, st));
+  J.pending = true;
+}
+
+uint64_t BgzfDeviceCompressor::finish(int slot, float* ms_kernels) {
+  slot &= 1;
+  Impl& S = *m_;
+  Impl::Job& J = S.job[slot];
+  if (!J.pending) throw std::runtime_error("BGZF: no job queued in this slot");
+  J.pending = false;
+  BGZF_HIP(hipEventSynchronize(J.done));
+  if (ms_kernels) BGZF_HIP(hipEventElapsedTime(ms_kernels, J.ev0, J.ev1));
+  return S.h_total[slot];
+}
+
+void BgzfDeviceCompressor::cancel(int slot) { m_->job[slot & 1].pending = false; }
+
+uint64_t BgzfDeviceCompressor::compress(const char* dev_src, uint64_t n, char* dev_dst, void* hip_stream, float* ms_kernels) {
+  if (ms_kernels) *ms_kernels = 0;
+  if (n == 0) return 0;
+  enqueue(0, dev_src, n, dev_dst, hip_stream);
+  return finish(0, ms_kernels);
 }
 
 }  // namespace genomicsdb_amd

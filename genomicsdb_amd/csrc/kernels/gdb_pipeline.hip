@@ -709,11 +709,21 @@ __global__ void __launch_bounds__(kHugeBlock) k_site_huge(const SiteCtx* __restr
 constexpr int kSiteStride = 256;                   // staging bytes per record
 constexpr int kSiteStripWords = kSiteStride / 4 + 1;
 constexpr int kSpillChunks = 32768;                 // spill pool: 64 MB of 2 KB chunks for the tails of longer fixed columns
-__global__ void __launch_bounds__(64) k_site_size(const SiteCtx* __restrict__ sxp, char* __restrict__ staging, SpillPool spill, int32_t* __restrict__ spill_chunk, uint32_t* err) {
+// The lanes of a wavefront wait for the record with the most variant calls among their 64: records are dealt out in the order of
+// their call counts (`order`, a radix sort over 8-bit keys), so that a wavefront's records cost about the same.
+__global__ void k_site_order_keys(const int64_t* __restrict__ hbase, int64_t P, uint32_t* __restrict__ key, int32_t* __restrict__ val) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= P) return;
+  const int64_t n = hbase[k + 1] - hbase[k];
+  key[k] = (uint32_t)(n > 255 ? 255 : n);
+  val[k] = (int32_t)k;
+}
+__global__ void __launch_bounds__(64) k_site_size(const SiteCtx* __restrict__ sxp, const int32_t* __restrict__ order, char* __restrict__ staging, SpillPool spill, int32_t* __restrict__ spill_chunk, uint32_t* err) {
   const SiteCtx& sx = *sxp;
   __shared__ uint32_t strip[64 * kSiteStripWords];
   int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= sx.rec.npos) return;
+  if (order) k = order[k];
   uint32_t e = 0;
   uint32_t* mine = strip + threadIdx.x * kSiteStripWords;
   LdsSpillSink cs((gdb_lds_char*)mine, (uint32_t)kSiteStride, spill);
@@ -2510,11 +2520,19 @@ struct DevicePipeline::Impl {
   DevBuf<uint8_t> num_alleles, rflags; DevBuf<uint32_t> fmt_mask, prefix_len; DevBuf<char> site_staging, spill_buf; DevBuf<int32_t> spill_chunk; DevBuf<unsigned int> spill_next;
   DevBuf<uint64_t> chunk_size, chunk_off, rec_off; DevBuf<unsigned long long> max_record;
   std::unique_ptr<BgzfDeviceCompressor> bgzf;   // output formats "z" / "b"
+  // "z" / "b": the compression of a page is queued right behind the kernels that assemble it (finish_page only collects the size),
+  // so the device works on page k + 1 - assembly and compression - while the host hands out page k
+  void queue_compression(int ai, char* arena, uint64_t page_bytes) {
+    if (!hp.bgzf || page_bytes == 0) return;
+    if (!bgzf) bgzf.reset(new BgzfDeviceCompressor);
+    bgzf->enqueue(ai, arena, page_bytes, arena, (void*)stream);
+  }
   DevBuf<unsigned int> slot_bump;               // pass 0's bump allocator of the overflow text pool: next unit, texts it could not place
   bool long_texts_seen = false;                 // an interval of this pipeline had texts longer than an inline slot
   uint64_t pool_ovf_need = 0;                   // most 16-byte units of overflow texts an interval has needed so far
   DevBuf<char> arena[2], temp;       // two output arenas: a consumer drains one while the next page is assembled into the other
   DevBuf<uint32_t> err; DevBuf<int32_t> counters;
+  DevBuf<uint32_t> site_key, site_key_sorted; DevBuf<int32_t> site_ord_in, site_ord;
   int ctx_slot = -1;                 // this pipeline's element of c_ex
   // persistent events (no create / destroy per interval) and one pinned block for every scalar that comes back to the host
   hipEvent_t ev_prep[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -4078,7 +4096,17 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   S.site_staging.ensure((size_t)P * kSiteStride + 64);
   S.spill_buf.ensure((size_t)kSpillChunks * kSpillChunk); S.spill_chunk.ensure((size_t)P); S.spill_next.ensure(1);
   HIP_CHECK(hipMemsetAsync(S.spill_next.p, 0, sizeof(unsigned int), st));
-  hipLaunchKernelGGL(k_site_size, dim3(blocks_for(P, 64)), dim3(64), 0, st, S.d_sx.p, S.site_staging.p, SpillPool{S.spill_buf.p, S.spill_next.p, (uint32_t)kSpillChunks}, S.spill_chunk.p, S.err.p);
+  const int32_t* site_order = nullptr;
+  {
+    static const bool sorted_sites = !(getenv("GDBAMD_SITE_ORDER") && atoi(getenv("GDBAMD_SITE_ORDER")) == 0);
+    if (sorted_sites && P >= 4096) {
+      S.site_key.ensure((size_t)P); S.site_key_sorted.ensure((size_t)P); S.site_ord_in.ensure((size_t)P); S.site_ord.ensure((size_t)P);
+      hipLaunchKernelGGL(k_site_order_keys, dim3(blocks_for(P)), dim3(kBlock), 0, st, (const int64_t*)S.hbase.p, P, S.site_key.p, S.site_ord_in.p);
+      S.sort_pairs(S.site_key.p, S.site_key_sorted.p, S.site_ord_in.p, S.site_ord.p, (size_t)P, 8);
+      site_order = S.site_ord.p;
+    }
+  }
+  hipLaunchKernelGGL(k_site_size, dim3(blocks_for(P, 64)), dim3(64), 0, st, S.d_sx.p, site_order, S.site_staging.p, SpillPool{S.spill_buf.p, S.spill_next.p, (uint32_t)kSpillChunks}, S.spill_chunk.p, S.err.p);
   S.remap_total.ensure(1);
   HIP_CHECK(hipMemsetAsync(S.remap_total.p, 0, sizeof(unsigned long long), st));
   for (int i = 0; i < pl.n_format; ++i)
@@ -4342,7 +4370,7 @@ bool DevicePipeline::begin_page(uint64_t arena_bytes, int arena_idx, PageTicket*
     HIP_CHECK(hipMemcpyAsync(&S.hb->page_err[ai], S.err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipEventRecord(w[3], st));
     iv.kp = ke;
-    ticket->arena = ai; ticket->dev = arena; ticket->nbytes = page_bytes; ticket->done_event = (void*)w[3];
+    ticket->arena = ai; ticket->dev = arena; ticket->nbytes = page_bytes; ticket->done_event = (void*)w[3]; S.queue_compression(ai, arena, page_bytes);
     return true;
   }
   STAGE("k_site_write");
@@ -4366,7 +4394,7 @@ bool DevicePipeline::begin_page(uint64_t arena_bytes, int arena_idx, PageTicket*
       HIP_CHECK(hipMemcpyAsync(&S.hb->page_err[ai], S.err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipEventRecord(w[3], st));
       iv.kp = ke;
-      ticket->arena = ai; ticket->dev = arena; ticket->nbytes = page_bytes; ticket->done_event = (void*)w[3];
+      ticket->arena = ai; ticket->dev = arena; ticket->nbytes = page_bytes; ticket->done_event = (void*)w[3]; S.queue_compression(ai, arena, page_bytes);
       return true;
     }
   }
@@ -4396,7 +4424,7 @@ bool DevicePipeline::begin_page(uint64_t arena_bytes, int arena_idx, PageTicket*
   HIP_CHECK(hipMemcpyAsync(&S.hb->page_err[ai], S.err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipEventRecord(w[3], st));
   iv.kp = ke;
-  ticket->arena = ai; ticket->dev = arena; ticket->nbytes = page_bytes; ticket->done_event = (void*)w[3];
+  ticket->arena = ai; ticket->dev = arena; ticket->nbytes = page_bytes; ticket->done_event = (void*)w[3]; S.queue_compression(ai, arena, page_bytes);
   return true;
 }
 
@@ -4417,9 +4445,8 @@ void DevicePipeline::finish_page(PageTicket& ticket) {
   iv.stats.ms_total = iv.stats.ms_sweep + iv.stats.ms_site + iv.stats.ms_size + iv.stats.ms_write;
   if (iv.stats.err_bits) throw GenomicsDBDeviceException(err_bits_text(iv.stats.err_bits));
   if (S.hp.bgzf && ticket.nbytes) {     // "z" / "b": only compressed bytes leave the GPU
-    if (!S.bgzf) S.bgzf.reset(new BgzfDeviceCompressor);
     float ms = 0;
-    ticket.nbytes = S.bgzf->compress(ticket.dev, ticket.nbytes, const_cast<char*>(ticket.dev), (void*)S.stream, &ms);
+    ticket.nbytes = S.bgzf->finish(ticket.arena, &ms);       // (queued by begin_page)
     iv.stats.bytes_compressed += ticket.nbytes;
     iv.stats.ms_compress += ms;
     iv.stats.ms_total += ms;

@@ -1,4 +1,4 @@
-"""device BGZF compression of the c2 text: ratio and kernel throughput (GPU box).  usage: bgzf_bench.py [samples] [bp]"""
+"""device BGZF compression of the c2 text: ratio and kernel throughput (GPU box).  usage: bgzf_bench.py [samples] [bp] [formats, e.g. z or -,z,bu,b]"""
 import os, sys, tempfile, time, gzip
 _ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, "tests"))
@@ -11,7 +11,8 @@ tmp = tempfile.mkdtemp()
 q = helpers.synth_query(tmp, N, B, B + L - 1)
 g = synth.Generator(N, B, L + 3000)
 ptr, nbytes, nc = g.next_chunk(B + L + 3000)
-for fmt in ("", "z", "bu", "b"):
+FORMATS = sys.argv[3].split(",") if len(sys.argv) > 3 else ["", "z", "bu", "b"]   # ("-" = VCF text)
+for fmt in ["" if f == "-" else f for f in FORMATS]:
     eng = genomicsdb_amd.CombineEngine(q, output_format=fmt)
     eng.stage_cells_begin(); eng.stage_cells_append(ptr, nbytes); eng.stage_cells_end()
     eng.set_reference(B, synth.reference(B, L + 4096))
