@@ -14,7 +14,7 @@
 
 namespace genomicsdb_amd {
 
-// uncompressed bytes per block: 64 lanes x 128 or 256 bytes (GDBAMD_BGZF_BLOCK = 8192 / 16384; smaller blocks leave room for more
+// uncompressed bytes per block: 64 lanes x 64, 128 or 256 bytes (GDBAMD_BGZF_BLOCK = 4096 / 8192 / 16384; smaller blocks leave room for more
 // resident wavefronts, larger ones find a little more to match)
 uint32_t bgzf_block_input();
 constexpr uint32_t kBgzfHeaderBytes = 18, kBgzfTrailerBytes = 8;
@@ -22,7 +22,7 @@ extern const unsigned char kBgzfEofBlock[28];               // the empty block t
 
 // worst case of the compressed stream of n bytes (every block stored: 5 bytes of DEFLATE framing + header + trailer)
 inline uint64_t bgzf_bound(uint64_t n) {
-  const uint64_t nblocks = (n + 8192 - 1) / 8192;
+  const uint64_t nblocks = (n + 4096 - 1) / 4096;      // (the smallest block size there is)
   return n + nblocks * (kBgzfHeaderBytes + kBgzfTrailerBytes + 5) + 64;
 }
 

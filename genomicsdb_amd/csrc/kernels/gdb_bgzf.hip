@@ -40,8 +40,10 @@ namespace {
 
 constexpr int kProbe = 16;                         // bytes every position compares against its candidate (a multiple of 8)
 constexpr int kRingWords = 256, kFlushWords = 128; // (a step adds at most 64 tokens x 31 bits = 62 words)
-constexpr uint32_t kSlotBytes = 17408;            // room for the payload of one block while it is being produced (a block that grows is cut off early)
+// room for the payload of one block while it is being produced (a block that grows is cut off early, at most one ring flush beyond its input size)
+__host__ __device__ constexpr uint32_t slot_bytes(uint32_t block_input) { return block_input + 1024u; }
 constexpr uint32_t kNoCand = 0xFFFFu;
+constexpr uint32_t kTokQueue = 128;
 
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
 
@@ -81,10 +83,12 @@ __global__ void __launch_bounds__(64) k_bgzf_deflate(const uint8_t* __restrict__
   const uint32_t n = (uint32_t)((n_total - base) < (uint64_t)kBgzfBlockInput ? (n_total - base) : (uint64_t)kBgzfBlockInput);
   const int lane = threadIdx.x;
   __shared__ uint4 in4[kBgzfBlockInput / 16 + 3];             // 48 bytes of zeros behind the block: the probes read up to 39 bytes past a position
-  constexpr int kHashBits = kBgzfBlockInput > 8192 ? 11 : 10;
+  constexpr int kHashBits = kBgzfBlockInput > 8192 ? 11 : kBgzfBlockInput > 4096 ? 10 : 9;
+  constexpr uint32_t kSlotBytes = slot_bytes((uint32_t)kBgzfBlockInput);
   constexpr int kPiece = kBgzfBlockInput / 64;                 // bytes of the block whose CRC a lane takes
   __shared__ uint32_t table32[(1 << kHashBits) / 2 + 2];      // (+ a spare slot for the positions behind the block's end)
   __shared__ uint32_t ring[kRingWords];
+  __shared__ uint32_t tokq[kTokQueue];                        // tokens waiting to be encoded (< 64 before a step, < 128 after it)
   uint8_t* const in = reinterpret_cast<uint8_t*>(in4);
   uint16_t* const table = reinterpret_cast<uint16_t*>(table32);
   // ---- the piece into LDS (zero behind its end: the 8-byte compares read up to 7 bytes past it) -------------------------------------
@@ -107,6 +111,58 @@ __global__ void __launch_bounds__(64) k_bgzf_deflate(const uint8_t* __restrict__
   uint32_t p = 0;
   int e = 0;
   bool gave_up = false;
+  uint32_t qhead = 0, qtail = 0;                               // token queue (uniform counters)
+  // ---- tokens -> bits: the next `ntok` <= 64 tokens of the queue, one per lane ----------------------------------------------------------
+  // (the kernel is bound by the instructions it issues - SQ counters, profiles/r3_*: a step of 64 positions yields ~6 tokens, so
+  // encoding per step kept 58 lanes busy with nothing; now the Huffman arithmetic, the scan and the ring update run once per 64 tokens)
+  auto emit_tokens = [&](uint32_t ntok) {
+    const uint32_t tok = tokq[(qhead + (uint32_t)lane) & (kTokQueue - 1)];
+    const bool mine = (uint32_t)lane < ntok;
+    qhead += ntok;
+    const uint32_t L = tok & 511u, d = (tok >> 9) & 0x7FFFu, lit = tok >> 24;
+    uint32_t bits, nb;
+    {
+      // both encodings are computed by every lane, then one is picked (no divergent branches)
+      const uint32_t l = L - 3u;                               // (garbage when L == 0: not used then)
+      const uint32_t leb = l < 8u ? 0u : (31u - (uint32_t)__clz(l | 8u)) - 2u;
+      uint32_t lsym = l < 8u ? 257u + l : 261u + 4u * leb + ((l >> leb) & 3u);
+      uint32_t lextra = l & ((1u << leb) - 1u);
+      uint32_t lextra_bits = leb;
+      if (L == 258u) { lsym = 285u; lextra = 0; lextra_bits = 0; }
+      const uint32_t sym = L ? lsym : lit;
+      uint32_t sb, sn;
+      fixed_litlen(sym, sb, sn);
+      const uint32_t deb = d < 4u ? 0u : (31u - (uint32_t)__clz(d | 4u)) - 1u;
+      const uint32_t dsym = d < 4u ? d : 2u * deb + 2u + ((d >> deb) & 1u);
+      const uint32_t dextra = d & ((1u << deb) - 1u);
+      uint32_t mb = sb | (lextra << sn), mn = sn + lextra_bits;
+      mb |= (__brev(dsym) >> 27) << mn; mn += 5u;
+      mb |= dextra << mn; mn += deb;
+      bits = L ? mb : sb;
+      nb = mine ? (L ? mn : sn) : 0u;
+    }
+    const uint32_t incl = wave_incl_scan(nb);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (mine) {
+      const uint32_t off = bitpos + incl - nb;
+      const uint32_t w = off >> 5, sh = off & 31u;
+      atomicOr(&ring[w & (kRingWords - 1)], bits << sh);
+      const uint32_t hi = sh ? (bits >> (32u - sh)) : 0u;
+      if (hi) atomicOr(&ring[(w + 1u) & (kRingWords - 1)], hi);
+    }
+    bitpos += total;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if ((bitpos >> 3) > n) { gave_up = true; return; }        // uniform: the block is not shrinking, it will be stored
+    while ((bitpos >> 5) - flushed >= (uint32_t)kFlushWords) {   // uniform: full words leave, their ring slots are zeroed for reuse
+      for (uint32_t i = lane; i < (uint32_t)kFlushWords; i += 64) {
+        const uint32_t slot = (flushed + i) & (kRingWords - 1);
+        out_words[flushed + i] = ring[slot];
+        ring[slot] = 0;
+      }
+      flushed += kFlushWords;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+  };
   while (p < n) {                                             // uniform
     // The body of a step is written without branches on per-lane conditions (every such branch costs exec-mask bookkeeping on
     // the scalar unit, and this kernel is bound by the instructions it issues - SQ counters, profiles/r3_*): positions behind
@@ -143,10 +199,20 @@ __global__ void __launch_bounds__(64) k_bgzf_deflate(const uint8_t* __restrict__
       L = (has_cand && k >= 4u) ? k : 0u;
     }
     // ---- greedy parse: the chain of token starts through this step's positions (scalar) --------------------------------------------
+    // A run of literals up to the next position that has a match is taken in one go (one bit trick on the ballot of the matches).
     const int lim = (n - p) < 64u ? (int)(n - p) : 64;
+    const uint64_t has_match = __ballot(L != 0u);
     uint64_t sel = 0;
     int cur = e;
     while (cur < lim) {
+      const uint64_t rest = has_match >> cur;
+      if (!(rest & 1ull)) {
+        int run = rest ? (int)__builtin_ctzll(rest) : 64;
+        run = run < lim - cur ? run : lim - cur;
+        sel |= (run >= 64 ? ~0ull : ((1ull << run) - 1ull)) << cur;
+        cur += run;
+        continue;
+      }
       uint32_t Lc = (uint32_t)__builtin_amdgcn_readlane((int)L, cur);
       if (Lc == (uint32_t)kProbe) {                              // uniform: the probe ran to its end - how far does the match really go?
         const uint32_t cpos = (uint32_t)__builtin_amdgcn_readlane((int)cand, cur), qpos = p + (uint32_t)cur;
@@ -163,58 +229,26 @@ __global__ void __launch_bounds__(64) k_bgzf_deflate(const uint8_t* __restrict__
         if (lane == cur) L = Lc;
       }
       sel |= 1ull << cur;
-      cur += Lc ? (int)Lc : 1;
+      cur += (int)Lc;
     }
     e = cur - 64;
-    // ---- tokens -> bits --------------------------------------------------------------------------------------------------------
-    const bool mine = (sel >> lane) & 1ull;
-    uint32_t bits, nb;
+    // ---- the step's tokens join the queue: (length, distance - 1, literal) in one word --------------------------------------------------
     {
-      // both encodings are computed by every lane, then one is picked (no divergent branches)
-      const uint32_t l = L - 3u;                               // (garbage when L == 0: not used then)
-      const uint32_t leb = l < 8u ? 0u : (31u - (uint32_t)__clz(l | 8u)) - 2u;
-      uint32_t lsym = l < 8u ? 257u + l : 261u + 4u * leb + ((l >> leb) & 3u);
-      uint32_t lextra = l & ((1u << leb) - 1u);
-      uint32_t lextra_bits = leb;
-      if (L == 258u) { lsym = 285u; lextra = 0; lextra_bits = 0; }
-      const uint32_t lit = (uint32_t)own0 & 0xFFu;
-      const uint32_t sym = L ? lsym : lit;
-      uint32_t sb, sn;
-      fixed_litlen(sym, sb, sn);
-      const uint32_t d = q - cand - 1u;
-      const uint32_t deb = d < 4u ? 0u : (31u - (uint32_t)__clz(d | 4u)) - 1u;
-      const uint32_t dsym = d < 4u ? d : 2u * deb + 2u + ((d >> deb) & 1u);
-      const uint32_t dextra = d & ((1u << deb) - 1u);
-      uint32_t mb = sb | (lextra << sn), mn = sn + lextra_bits;
-      mb |= (__brev(dsym) >> 27) << mn; mn += 5u;
-      mb |= dextra << mn; mn += deb;
-      bits = L ? mb : sb;
-      nb = mine ? (L ? mn : sn) : 0u;
-    }
-    const uint32_t incl = wave_incl_scan(nb);
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    if (mine) {
-      const uint32_t off = bitpos + incl - nb;
-      const uint32_t w = off >> 5, sh = off & 31u;
-      atomicOr(&ring[w & (kRingWords - 1)], bits << sh);
-      const uint32_t hi = sh ? (bits >> (32u - sh)) : 0u;
-      if (hi) atomicOr(&ring[(w + 1u) & (kRingWords - 1)], hi);
-    }
-    bitpos += total;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    if ((bitpos >> 3) > n) { gave_up = true; break; }         // uniform: the block is not shrinking, it will be stored
-    while ((bitpos >> 5) - flushed >= (uint32_t)kFlushWords) {   // uniform: full words leave, their ring slots are zeroed for reuse
-      for (uint32_t i = lane; i < (uint32_t)kFlushWords; i += 64) {
-        const uint32_t slot = (flushed + i) & (kRingWords - 1);
-        out_words[flushed + i] = ring[slot];
-        ring[slot] = 0;
-      }
-      flushed += kFlushWords;
+      const bool mine = (sel >> lane) & 1ull;
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(sel >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sel, 0u));
+      const uint32_t tok = L | (((q - cand - 1u) & 0x7FFFu) << 9) | (((uint32_t)own0 & 0xFFu) << 24);
+      if (mine) tokq[(qtail + rank) & (kTokQueue - 1)] = tok;
+      qtail += (uint32_t)__builtin_popcountll(sel);
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+    if (qtail - qhead >= 64u) {                                // uniform: 64 tokens are encoded at a time (all lanes busy)
+      emit_tokens(64u);
+      if (gave_up) break;
     }
     p += 64;
     while (e >= 64) { e -= 64; p += 64; }                     // a match that covers whole steps: nothing to do there
   }
+  if (!gave_up && qtail != qhead) emit_tokens(qtail - qhead);
   uint32_t payload;
   if (!gave_up) {
     bitpos += 7;                                              // end of block: symbol 256 = seven zero bits
@@ -273,7 +307,7 @@ __global__ void __launch_bounds__(64) k_bgzf_pack(const uint8_t* __restrict__ sl
     o[kBgzfHeaderBytes + c + (uint32_t)(lane - 18)] = (uint8_t)((v >> (8 * ((lane - 18) & 3))) & 0xFFu);
   }
   // payload: aligned words of the destination assembled from two aligned source words (the slot is 16-byte aligned, the destination not)
-  const uint8_t* s = slots + blk * (uint64_t)kSlotBytes;
+  const uint8_t* s = slots + blk * (uint64_t)slot_bytes(kBgzfBlockInput);
   uint8_t* d = o + kBgzfHeaderBytes;
   const uint32_t head = (uint32_t)((4u - ((uintptr_t)d & 3u)) & 3u) < c ? (uint32_t)((4u - ((uintptr_t)d & 3u)) & 3u) : c;
   if ((uint32_t)lane < head) d[lane] = s[lane];
@@ -314,7 +348,7 @@ void build_crc_tables(std::vector<uint32_t>& slice, std::vector<uint32_t>& shift
 }  // namespace
 
 uint32_t bgzf_block_input() {
-  static const uint32_t v = []() { const char* e = getenv("GDBAMD_BGZF_BLOCK"); return (e && atoi(e) == 16384) ? 16384u : (e && atoi(e) == 8192) ? 8192u : 8192u; }();
+  static const uint32_t v = []() { const char* e = getenv("GDBAMD_BGZF_BLOCK"); const int v = e ? atoi(e) : 0; return v == 16384 ? 16384u : v == 4096 ? 4096u : 8192u; }();
   return v;
 }
 
@@ -398,7 +432,7 @@ void BgzfDeviceCompressor::enqueue(int slot, const char* dev_src, uint64_t n, ch
     BGZF_HIP(hipMalloc((void**)&S.bsize, cap * 8)); BGZF_HIP(hipMalloc((void**)&S.boff, cap * 8));
     S.blocks_cap = cap;
   }
-  const size_t need_slots = (size_t)nblocks * kSlotBytes + 64;
+  const size_t need_slots = (size_t)nblocks * slot_bytes(kBgzfBlockInput) + 64;
   if (S.slots_cap < need_slots) {
     BGZF_HIP(hipStreamSynchronize(st));
     if (S.slots) (void)hipFree(S.slots);
@@ -418,6 +452,9 @@ void BgzfDeviceCompressor::enqueue(int slot, const char* dev_src, uint64_t n, ch
   BGZF_HIP(hipEventRecord(J.ev0, st));
   if (kBgzfBlockInput == 16384u)
     hipLaunchKernelGGL(k_bgzf_deflate<16384>, dim3((unsigned)nblocks), dim3(64), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.bsize, S.crc, (const uint32_t*)S.d_slice,
+                       (const uint32_t*)S.d_shift);
+  else if (kBgzfBlockInput == 4096u)
+    hipLaunchKernelGGL(k_bgzf_deflate<4096>, dim3((unsigned)nblocks), dim3(64), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.bsize, S.crc, (const uint32_t*)S.d_slice,
                        (const uint32_t*)S.d_shift);
   else
     hipLaunchKernelGGL(k_bgzf_deflate<8192>, dim3((unsigned)nblocks), dim3(64), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.bsize, S.crc, (const uint32_t*)S.d_slice,

@@ -90,7 +90,8 @@ def test_device_deflate_on_hostile_inputs(gdb):
         if name == "text":                                   # (columns of random numbers: little to find besides the separators)
             assert len(comp) * 1.7 < len(data), name
         if name in ("random", "one block exactly", "two blocks exactly"):
-            assert len(comp) <= len(data) + 31 * ((len(data) + 8191) // 8192), name         # stored blocks: framing only
+            blk = int(os.environ.get("GDBAMD_BGZF_BLOCK", "8192"))
+            assert len(comp) <= len(data) + 31 * ((len(data) + blk - 1) // blk), name         # stored blocks: framing only
     with gzip.open(os.path.join(helpers.GOLDEN, "inputs", "chr1_10MB.fasta.gz"), "rb") as f:
         fasta = f.read()[:3_000_000]
     comp, _ = _check_roundtrip(gdb, fasta)
