@@ -2298,12 +2298,43 @@ __device__ __forceinline__ bool walk_plausible(const uint8_t* __restrict__ cells
   const uint64_t row = load_u64_unaligned(cells + p), col = load_u64_unaligned(cells + p + 8);
   return row < nrows && (int64_t)col >= 0;
 }
-__global__ void k_walk_candidates(const uint8_t* __restrict__ cells, uint64_t nbytes, uint64_t nrows, uint64_t nwords, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ word_count) {
-  const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one byte position per lane, one bitmap word per wavefront
-  uint64_t size;
-  const bool c = p < nbytes && walk_plausible(cells, p, nbytes, nrows, size);
-  const uint64_t m = __ballot(c);
-  if ((threadIdx.x & 63) == 0 && (p >> 6) < nwords) { bitmap[p >> 6] = m; word_count[p >> 6] = (uint32_t)__popcll(m); }
+// 16 byte positions per lane, out of three aligned 16-byte loads (a load per position at a byte stride of one costs the texture
+// path 64 different addresses per instruction: 4.1 ms per 270 MB chunk, the longest kernel of the input path): the header
+// fields of position j are funnel-shifted (v_alignbyte) out of the twelve words in registers; four lanes make one bitmap word.
+__global__ void __launch_bounds__(256) k_walk_candidates(const uint8_t* __restrict__ cells, uint64_t nbytes, uint64_t nrows, uint64_t nwords, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ word_count) {
+  const uint64_t lane_base = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16u;     // (cells is 16-byte aligned and padded with 64 zero bytes)
+  uint32_t mask = 0;
+  if (lane_base < nbytes) {
+    const uint4* src = reinterpret_cast<const uint4*>(cells + lane_base);
+    const uint4 a = src[0], b = src[1], c = src[2];
+    const uint32_t D[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int q = j >> 2;
+      const uint32_t sh = (uint32_t)(j & 3);
+      // size = bytes [j + 16, j + 24): the most selective test (most positions stop here)
+      const uint32_t slo = sh ? __builtin_amdgcn_alignbyte(D[q + 5], D[q + 4], sh) : D[q + 4];
+      const uint32_t shi = sh ? __builtin_amdgcn_alignbyte(D[q + 6], D[q + 5], sh) : D[q + 5];
+      bool ok = shi == 0u && slo >= 32u && slo < (1u << 31) && lane_base + (uint64_t)j + 32u <= nbytes;
+      if (ok) {
+        const uint32_t rlo = sh ? __builtin_amdgcn_alignbyte(D[q + 1], D[q], sh) : D[q];
+        const uint32_t rhi = sh ? __builtin_amdgcn_alignbyte(D[q + 2], D[q + 1], sh) : D[q + 1];
+        const uint32_t chi = sh ? __builtin_amdgcn_alignbyte(D[q + 4], D[q + 3], sh) : D[q + 3];      // bytes [j + 12, j + 16): the column's high word
+        ok = (((uint64_t)rhi << 32) | rlo) < nrows && (int32_t)chi >= 0;
+        // A header must also POINT at a header (or past the buffer's end): a true cell always does, a look-alike inside a payload
+        // of small integers rarely - without this test a c2 chunk has ~10 candidates per cell, and every round of the pointer
+        // doubling below pays for them.  (A stream whose chain breaks is still found out: the cell before the break loses its successor.)
+        const uint64_t s = lane_base + (uint64_t)j + slo;
+        if (ok && s + 32u <= nbytes) { uint64_t size2; ok = walk_plausible(cells, s, nbytes, nrows, size2); }
+      }
+      mask |= (ok ? 1u : 0u) << j;
+    }
+  }
+  unsigned long long v = (unsigned long long)mask << (16u * (threadIdx.x & 3u));
+  v |= __shfl_xor(v, 1, 64);
+  v |= __shfl_xor(v, 2, 64);
+  const uint64_t word = lane_base >> 6;
+  if ((threadIdx.x & 3u) == 0u && word < nwords) { bitmap[word] = v; word_count[word] = (uint32_t)__popcll(v); }
 }
 __global__ void k_walk_successors(const uint8_t* __restrict__ cells, uint64_t nbytes, uint64_t nwords, const uint64_t* __restrict__ bitmap, const uint32_t* __restrict__ word_rank,
                                   uint32_t M, uint64_t* __restrict__ pos, uint32_t* __restrict__ succ) {
@@ -2496,7 +2527,25 @@ __global__ void k_gather_record_offsets(const uint64_t* chunk_off, int nchunks, 
 struct DevicePipeline::Impl {
   HostPlan hp;
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;        // the stream in use: stream_compute, or stream_stage between begin_staging_from() and finish_staging()
+  hipStream_t stream_compute = nullptr, stream_stage = nullptr;
+  // A window staged ahead (overlapped staging) shares the GPU with the other pipeline's page assembly, whose kernels fill every CU
+  // for milliseconds: the short staging kernels (1 ms per 270 MB chunk) run on a stream of higher priority so that the staging
+  // thread's many small round trips do not queue up behind them.  Measured (c3 shape, 5 Mb, alternating on one box): the staging
+  // thread waits less (0.88 -> 0.69 s) and the page assembly takes as much longer (1.77 -> 1.68 M positions/s of device time):
+  // 1.27 vs 1.28 M positions/s end to end - no gain, so it is off unless GDBAMD_STAGE_PRIORITY=1.
+  void use_stage_stream() {
+    static const bool on = getenv("GDBAMD_STAGE_PRIORITY") && atoi(getenv("GDBAMD_STAGE_PRIORITY")) != 0;
+    if (!on) return;
+    if (!stream_stage) {
+      int least = 0, greatest = 0;
+      HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      HIP_CHECK(hipStreamCreateWithPriority(&stream_stage, hipStreamDefault, greatest));
+    }
+    HIP_CHECK(hipStreamSynchronize(stream_compute));     // (idle by now: the pipeline's last page was handed over before its buffers are reused)
+    stream = stream_stage;
+  }
+  void use_compute_stream() { stream = stream_compute; }
   // staged fragment
   FragmentView fr;
   bool owns_fragment = false;
@@ -2665,7 +2714,8 @@ DevicePipeline::DevicePipeline(const HostPlan& hp, int device) : m_(new Impl) {
   m_->device = device;
   if (device_count() <= 0) { delete m_; throw GenomicsDBDeviceException("no HIP device visible: the variant-combine path has no CPU fallback"); }
   HIP_CHECK(hipSetDevice(device));
-  HIP_CHECK(hipStreamCreate(&m_->stream));
+  HIP_CHECK(hipStreamCreate(&m_->stream_compute));
+  m_->stream = m_->stream_compute;
   memset(&m_->fr, 0, sizeof(m_->fr));
   auto up = [&](auto& buf, const auto* src, size_t n) {
     buf.ensure(std::max<size_t>(n, 1));
@@ -2702,7 +2752,8 @@ DevicePipeline::~DevicePipeline() {
   for (auto& a : m_->ev_page) for (auto& e : a) if (e) (void)hipEventDestroy(e);
   if (m_->hb) (void)hipHostFree(m_->hb);
   if (m_->ctx_slot >= 0) { std::lock_guard<std::mutex> g(g_ctx_slot_mutex); g_ctx_slot_used[m_->ctx_slot] = false; }
-  if (m_->stream) (void)hipStreamDestroy(m_->stream);
+  if (m_->stream_compute) (void)hipStreamDestroy(m_->stream_compute);
+  if (m_->stream_stage) (void)hipStreamDestroy(m_->stream_stage);
   delete m_;
   m_ = nullptr;
 }
@@ -2742,6 +2793,8 @@ void DevicePipeline::begin_staging_from(DevicePipeline& source, int64_t carry_fr
   Impl& SRC = *source.m_;
   S.free_parts();
   S.carried_cells = 0;
+  HIP_CHECK(hipSetDevice(S.device));
+  S.use_stage_stream();
   if (carry_from == INT64_MIN || SRC.fr.ncells == 0) return;
   // ---- the staged fragment's live intervals at carry_from become the first part of the next fragment ---------------------
   HIP_CHECK(hipSetDevice(S.device));
@@ -2902,13 +2955,15 @@ DevicePipeline::CellStreamInfo DevicePipeline::append_cells(const uint8_t* cells
     HIP_CHECK(hipMemcpyAsync(S.raw_off.p, walked->data(), (size_t)(n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
   } else {
     S.raw_cells.ensure(nbytes + 64);
+    const auto th0 = std::chrono::steady_clock::now();
     HIP_CHECK(hipMemcpyAsync(S.raw_cells.p, cells, nbytes, hipMemcpyHostToDevice, st));
+    if (trace) { HIP_CHECK(hipStreamSynchronize(st)); fprintf(stderr, "[gdbamd stage] host -> device %.1f MB in %.4f s\n", nbytes / 1e6, std::chrono::duration<double>(std::chrono::steady_clock::now() - th0).count()); }
     HIP_CHECK(hipMemsetAsync(S.raw_cells.p + nbytes, 0, 64, st));
     const uint64_t nwords = (nbytes + 63) >> 6;
     S.walk_bitmap.ensure(nwords + 1); S.walk_wcount.ensure(nwords + 1); S.walk_wrank.ensure(nwords + 1); S.walk_out.ensure(8);
     HIP_CHECK(hipMemsetAsync(S.walk_out.p, 0, 4 * sizeof(uint64_t), st));
-    const unsigned pos_blocks = (unsigned)((nbytes + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_walk_candidates, dim3(pos_blocks), dim3(kBlock), 0, st, (const uint8_t*)S.raw_cells.p, nbytes, (uint64_t)1 << 40, nwords, S.walk_bitmap.p, S.walk_wcount.p);
+    const unsigned pos_blocks = (unsigned)((nwords * 4u + 255u) / 256u);      // 16 positions per lane, 4 lanes per bitmap word
+    hipLaunchKernelGGL(k_walk_candidates, dim3(pos_blocks), dim3(256), 0, st, (const uint8_t*)S.raw_cells.p, nbytes, (uint64_t)1 << 40, nwords, S.walk_bitmap.p, S.walk_wcount.p);
     HIP_CHECK(hipMemsetAsync(S.walk_wcount.p + nwords, 0, sizeof(uint32_t), st));
     S.excl_scan((const uint32_t*)S.walk_wcount.p, S.walk_wrank.p, (size_t)nwords + 1);
     const uint32_t M = S.read_back(S.walk_wrank.p + nwords);
@@ -3112,6 +3167,7 @@ void DevicePipeline::finish_staging() {
     v.nmarkers = M; v.marker_begin = mk;
   }
   HIP_CHECK(hipStreamSynchronize(S.stream));
+  S.use_compute_stream();
   S.free_parts();
   S.fr = v;
   S.owns_fragment = true;
