@@ -120,6 +120,7 @@ inline int event_run_length() { const char* e = getenv("GDBAMD_EV_RUN"); return 
 inline bool events_enabled() { const char* e = getenv("GDBAMD_EVENTS"); return e && *e && *e != '0'; }
 // wavefronts (= neighbouring 64-sample chunks) per workgroup of the page assembly: 4 measured best on the store-only model
 inline int write_waves_per_group() { const char* e = getenv("GDBAMD_WRITE_WAVES"); return e && *e ? atoi(e) : 1; }
+inline bool slot_regroup() { static const bool v = []() { const char* e = getenv("GDBAMD_SLOT_REGROUP"); return !(e && *e == '0'); }(); return v; }
 inline bool xcd_aware_numbering() { const char* e = getenv("GDBAMD_XCD_AWARE"); return !(e && *e == '0'); }
 inline int write_image_kb() { const char* e = getenv("GDBAMD_WRITE_IMAGE_KB"); return e && *e ? atoi(e) : 8; }
 inline int order_block_log2() {
@@ -791,7 +792,7 @@ __global__ void k_site_write(const SiteCtx* __restrict__ sxp, const char* __rest
 // Per-interval context in constant memory: plan, column pointers, per-cell metadata pointers.  Uniform accesses to it are
 // scalar loads through the scalar cache (a by-reference argument would turn each of them into a vector memory instruction).
 // One slot per pipeline (leased for the pipeline's lifetime): the handles of one process no longer take turns on a single symbol.
-constexpr int kCtxSlots = 16;
+constexpr int kCtxSlots = GDB_MAX_PIPELINES_PER_PROCESS;
 __constant__ EntryCtx c_ex[kCtxSlots];
 static std::mutex g_ctx_slot_mutex;
 static bool g_ctx_slot_used[kCtxSlots];
@@ -1062,22 +1063,50 @@ __global__ void k_slot_cells(const uint32_t* tbase, const uint32_t* nslots, int6
   const uint32_t b = tbase[i], m = nslots[i];
   for (uint32_t q = 0; q < m; ++q) slot_cell[b + q] = (uint32_t)i;
 }
-template <int PASS, int STRIPW> __global__ void k_slots_light(SlotTable st, SiteOut so, const int32_t* type_rep, const uint64_t* tmask, const uint32_t* tbase,
-                                                      const uint32_t* slot_cell, int64_t c_base, int64_t SL, uint32_t* err) {
-  __shared__ uint32_t strip[kSlotBlock * STRIPW];
+// (cell, type) slots of plain cells.  Consecutive slots are the types of one cell, so a wavefront of 64 consecutive slots mixes cheap
+// types (reference-only records: three genotypes) with dear ones (PL re-indexed to 6 - 10 genotypes, AD, SB) and every lane waits
+// for the dearest: pass 0 regroups the 256 slots of a workgroup by type first (counting sort in LDS), which gives each of its four
+// wavefronts one to three types.
+constexpr int kLightBlock = 256;
+template <int PASS, int STRIPW> __global__ void __launch_bounds__(kLightBlock) k_slots_light(SlotTable st, SiteOut so, const int32_t* type_rep, const uint64_t* tmask, const uint32_t* tbase,
+                                                      const uint32_t* slot_cell, int64_t c_base, int64_t SL, int regroup, uint32_t* err) {
+  __shared__ uint32_t strip[kLightBlock * STRIPW];
+  __shared__ uint32_t tcount[kMaxTypes + 1], job[kLightBlock];
   uint32_t* mine = strip + threadIdx.x * STRIPW;
-  const int64_t sidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = sidx < SL;
-  const uint32_t s = st.light_base + (uint32_t)(live ? sidx : 0);
-  if (PASS == 1) { if (!__any((int)(live && slot_needs_pass1(st, s)))) return; }
-  uint32_t e = 0, len = 0;
+  int64_t sidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool live = sidx < SL;
+  if (PASS == 1) { if (!__any((int)(live && slot_needs_pass1(st, st.light_base + (uint32_t)(live ? sidx : 0))))) return; }
+  uint32_t i = 0;
+  int t = kMaxTypes;                                          // (slots behind the table's end sort last)
   if (live) {
-    const uint32_t i = slot_cell[sidx];
+    i = slot_cell[sidx];
     uint64_t m = tmask[i];
     for (uint32_t q = (uint32_t)sidx - tbase[i]; q; --q) m &= m - 1;     // the slot's rank among the cell's types -> its type
-    const int t = __builtin_ctzll(m);
-    len = slot_fill<PASS, STRIPW>(st, s, load_record_info(so, c_ex[st.ctx].hl, type_rep[t]), c_base + (int64_t)i, mine, &e);
+    t = __builtin_ctzll(m);
   }
+  if (PASS == 0 && regroup) {                                 // uniform
+    if (threadIdx.x <= (unsigned)kMaxTypes) tcount[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t r = atomicAdd(&tcount[t], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const uint32_t v = tcount[threadIdx.x];
+      const uint32_t incl = wave_inclusive_scan_dpp(v);
+      tcount[threadIdx.x] = incl - v;
+      if (threadIdx.x == 63) tcount[kMaxTypes] = incl;
+    }
+    __syncthreads();
+    job[tcount[t] + r] = threadIdx.x | ((uint32_t)t << 16);
+    __syncthreads();
+    const uint32_t jb = job[threadIdx.x];
+    sidx = (int64_t)blockIdx.x * blockDim.x + (jb & 0xFFFFu);
+    t = (int)(jb >> 16);
+    live = sidx < SL;
+    if (live) i = slot_cell[sidx];
+  }
+  const uint32_t s = st.light_base + (uint32_t)(live ? sidx : 0);
+  uint32_t e = 0, len = 0;
+  if (live) len = slot_fill<PASS, STRIPW>(st, s, load_record_info(so, c_ex[st.ctx].hl, type_rep[t]), c_base + (int64_t)i, mine, &e);
   if (PASS == 0) slot_place_long<STRIPW>(st, live, s, len, mine);
   if (e) atomicOr(err, e);
 }
@@ -4231,7 +4260,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   STAGE("k_slots<0>");
 #define GDB_SLOT_KERNELS(PASSN, W) do { \
   hipLaunchKernelGGL((k_slots_nocall<PASSN, W>), dim3(1), dim3(kMaxTypes), 0, st, stt, so, S.type_rep.p, ntypes, S.err.p); \
-  if (SL > 0) hipLaunchKernelGGL((k_slots_light<PASSN, W>), dim3(blocks_for((int64_t)SL, kSlotBlock)), dim3(kSlotBlock), 0, st, stt, so, S.type_rep.p, S.tmask.p, S.tbase.p, (const uint32_t*)S.slot_cell.p, c_base, (int64_t)SL, S.err.p); \
+  if (SL > 0) hipLaunchKernelGGL((k_slots_light<PASSN, W>), dim3(blocks_for((int64_t)SL, kLightBlock)), dim3(kLightBlock), 0, st, stt, so, S.type_rep.p, S.tmask.p, S.tbase.p, (const uint32_t*)S.slot_cell.p, c_base, (int64_t)SL, slot_regroup() ? 1 : 0, S.err.p); \
   if (T > 0) hipLaunchKernelGGL((k_slots_heavy<PASSN, W>), dim3(blocks_for(T, 64)), dim3(64), 0, st, stt, so, S.inc_keys_sorted.p, S.inc_vals_sorted.p, T, (int64_t)N, S.err.p); \
   if (UR > 0) hipLaunchKernelGGL((k_slots_untabled<PASSN, W>), dim3(blocks_for(UR * N, 64)), dim3(64), 0, st, stt, so, ri, rec, S.urec.p, UR, N, S.err.p); \
 } while (0)
