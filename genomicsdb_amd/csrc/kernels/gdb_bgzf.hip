@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -85,7 +86,7 @@ __global__ void __launch_bounds__(64) k_bgzf_deflate(const uint8_t* __restrict__
   __shared__ uint4 in4[kBgzfBlockInput / 16 + 3];             // 48 bytes of zeros behind the block: the probes read up to 39 bytes past a position
   constexpr int kHashBits = kBgzfBlockInput > 8192 ? 11 : kBgzfBlockInput > 4096 ? 10 : 9;
   constexpr uint32_t kSlotBytes = slot_bytes((uint32_t)kBgzfBlockInput);
-  constexpr int kPiece = kBgzfBlockInput / 64;                 // bytes of the block whose CRC a lane takes
+  constexpr int kPieceWords = kBgzfBlockInput / 256 + 1;       // dwords of the block whose CRC a lane takes: an ODD count, so that the lanes' reads fall into different banks
   __shared__ uint32_t table32[(1 << kHashBits) / 2 + 2];      // (+ a spare slot for the positions behind the block's end)
   __shared__ uint32_t ring[kRingWords];
   __shared__ uint32_t tokq[kTokQueue];                        // tokens waiting to be encoded (< 64 before a step, < 128 after it)
@@ -169,31 +170,40 @@ __global__ void __launch_bounds__(64) k_bgzf_deflate(const uint8_t* __restrict__
     // the block's end hash the zero padding into a spare table slot and come out with no candidate.
     const uint32_t q = p + (uint32_t)lane;
     const bool can_hash = q + 4u <= n;
-    const uint64_t own0 = lds_read_u64(in + q);               // the position's first 8 bytes: hash input, first compare word, literal
-    const uint32_t h = can_hash ? ((uint32_t)own0 * 2654435761u) >> (32 - kHashBits) : (1u << kHashBits);
+    // LDS accesses are aligned dwords only: a ds_read_b64 off its natural alignment is replayed at 64 LDS cycles per wave
+    // instruction (2 when aligned), and with four of them per step the kernel was bound by the LDS array (SQ_LDS_IDX_ACTIVE at
+    // 90 % of the kernel's cycles).  A lane reads the five aligned dwords around its position and funnel-shifts its 16 bytes out
+    // of them (v_alignbyte); the same for the candidate.
+    const uint32_t* const in32 = reinterpret_cast<const uint32_t*>(in);
+    uint32_t w0, w1, w2, w3;                                    // the position's first 16 bytes: hash input, compare words, literal
+    {
+      const uint32_t wq = q >> 2, sh = q & 3u;
+      const uint32_t o0 = in32[wq], o1 = in32[wq + 1], o2 = in32[wq + 2], o3 = in32[wq + 3], o4 = in32[wq + 4];
+      w0 = __builtin_amdgcn_alignbyte(o1, o0, sh); w1 = __builtin_amdgcn_alignbyte(o2, o1, sh);
+      w2 = __builtin_amdgcn_alignbyte(o3, o2, sh); w3 = __builtin_amdgcn_alignbyte(o4, o3, sh);
+    }
+    const uint32_t h = can_hash ? (w0 * 2654435761u) >> (32 - kHashBits) : (1u << kHashBits);
     const uint32_t cand_raw = table[h];
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     // every lane has read the table before any lane writes it
     table[h] = (uint16_t)q;
     const bool has_cand = can_hash && cand_raw != kNoCand;
     const uint32_t cand = has_cand ? cand_raw : 0u;
-    // Every lane measures its match only up to kProbe = 32 bytes, all four 8-byte compares in flight at once: nearly every
-    // position of a text like this one lies INSIDE a long match of an earlier position, so full-length compares in all lanes
-    // are wasted on positions the parse never visits (and the slowest lane sets the wavefront's time).  The few tokens the
-    // parse takes with a probe that ran to its end are extended by the whole wavefront, 64 bytes per step, in the chain walk.
+    // Every lane measures its match only up to kProbe = 16 bytes: nearly every position of a text like this one lies INSIDE a
+    // long match of an earlier position, so full-length compares in all lanes are wasted on positions the parse never visits
+    // (and the slowest lane sets the wavefront's time).  The few tokens the parse takes with a probe that ran to its end are
+    // extended by the whole wavefront, 64 bytes per step, in the chain walk.
     uint32_t L;
     {
-      const uint64_t x0 = lds_read_u64(in + cand) ^ own0;
+      static_assert(kProbe == 16, "the probe compares four dwords");
+      const uint32_t cw = cand >> 2, csh = cand & 3u;
+      const uint32_t c0 = in32[cw], c1 = in32[cw + 1], c2 = in32[cw + 2], c3 = in32[cw + 3], c4 = in32[cw + 4];
+      const uint32_t x0 = __builtin_amdgcn_alignbyte(c1, c0, csh) ^ w0, x1 = __builtin_amdgcn_alignbyte(c2, c1, csh) ^ w1;
+      const uint32_t x2 = __builtin_amdgcn_alignbyte(c3, c2, csh) ^ w2, x3 = __builtin_amdgcn_alignbyte(c4, c3, csh) ^ w3;
       uint32_t k = (uint32_t)kProbe;
-      if (kProbe > 16) {
-        const uint64_t x2 = lds_read_u64(in + cand + 16) ^ lds_read_u64(in + q + 16), x3 = lds_read_u64(in + cand + 24) ^ lds_read_u64(in + q + 24);
-        k = x3 ? 24u + ((uint32_t)__builtin_ctzll(x3) >> 3) : k;
-        k = x2 ? 16u + ((uint32_t)__builtin_ctzll(x2) >> 3) : k;
-      }
-      if (kProbe > 8) {
-        const uint64_t x1 = lds_read_u64(in + cand + 8) ^ lds_read_u64(in + q + 8);
-        k = x1 ? 8u + ((uint32_t)__builtin_ctzll(x1) >> 3) : k;
-      }
-      k = x0 ? ((uint32_t)__builtin_ctzll(x0) >> 3) : k;
+      k = x3 ? 12u + ((uint32_t)__builtin_ctz(x3) >> 3) : k;
+      k = x2 ? 8u + ((uint32_t)__builtin_ctz(x2) >> 3) : k;
+      k = x1 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3) : k;
+      k = x0 ? ((uint32_t)__builtin_ctz(x0) >> 3) : k;
       const uint32_t room = n > q ? n - q : 0u;               // (the zero padding behind the block never extends a match)
       k = k < room ? k : room;
       L = (has_cand && k >= 4u) ? k : 0u;
@@ -236,7 +246,7 @@ __global__ void __launch_bounds__(64) k_bgzf_deflate(const uint8_t* __restrict__
     {
       const bool mine = (sel >> lane) & 1ull;
       const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(sel >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sel, 0u));
-      const uint32_t tok = L | (((q - cand - 1u) & 0x7FFFu) << 9) | (((uint32_t)own0 & 0xFFu) << 24);
+      const uint32_t tok = L | (((q - cand - 1u) & 0x7FFFu) << 9) | ((w0 & 0xFFu) << 24);
       if (mine) tokq[(qtail + rank) & (kTokQueue - 1)] = tok;
       qtail += (uint32_t)__builtin_popcountll(sel);
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -269,10 +279,14 @@ __global__ void __launch_bounds__(64) k_bgzf_deflate(const uint8_t* __restrict__
   uint32_t crc;
   const uint32_t* T0 = crc_slice, *T1 = crc_slice + 256, *T2 = crc_slice + 512, *T3 = crc_slice + 768;
   if (n == kBgzfBlockInput) {
+    // (pieces of 128 bytes put every lane's dword i into the same LDS bank: a 64-way conflict per read; with 33 dwords per lane
+    // - the last lanes get the short rest, or nothing - the lanes of a group hit different banks)
     uint32_t r = lane == 0 ? 0xFFFFFFFFu : 0u;
-    const uint8_t* pc = in + (uint32_t)kPiece * (uint32_t)lane;
-    for (int i = 0; i < kPiece / 4; ++i) {
-      const uint32_t x = r ^ lds_read_u32(pc + 4 * i);
+    const uint32_t* const words = reinterpret_cast<const uint32_t*>(in);
+    const uint32_t w_begin = (uint32_t)kPieceWords * (uint32_t)lane;
+    const uint32_t w_end = w_begin + (uint32_t)kPieceWords < (uint32_t)(kBgzfBlockInput / 4) ? w_begin + (uint32_t)kPieceWords : (uint32_t)(kBgzfBlockInput / 4);
+    for (uint32_t i = w_begin; i < w_end; ++i) {
+      const uint32_t x = r ^ words[i];
       r = T3[x & 0xFFu] ^ T2[(x >> 8) & 0xFFu] ^ T1[(x >> 16) & 0xFFu] ^ T0[x >> 24];
     }
     const uint32_t* S = crc_shift + (size_t)lane * 1024;      // this lane's contribution after the bytes behind its piece
@@ -323,25 +337,25 @@ __global__ void __launch_bounds__(64) k_bgzf_pack(const uint8_t* __restrict__ sl
 }
 
 // ---- CRC-32 tables (reflected polynomial 0xEDB88320, the gzip CRC) -------------------------------------------------------------
-void build_crc_tables(std::vector<uint32_t>& slice, std::vector<uint32_t>& shift, int piece) {
+void build_crc_tables(std::vector<uint32_t>& slice, std::vector<uint32_t>& shift, int block_bytes) {
   slice.assign(4 * 256, 0);
   for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1; slice[i] = c; }
   for (uint32_t i = 0; i < 256; ++i) for (int t = 1; t < 4; ++t) { const uint32_t prev = slice[(t - 1) * 256 + i]; slice[t * 256 + i] = (prev >> 8) ^ slice[prev & 0xFFu]; }
-  // Z = the register after one zero byte; Z255 = after `piece` of them (one lane's share of a block), as the images of the 32 unit vectors
+  // lane i takes the dwords [i * pw, min((i + 1) * pw, nw)) of a full block (pw = nw / 64 + 1, as in the kernel) and is followed by
+  // behind(i) bytes: its register has to be advanced over that many zero bytes.  cols = the images of the 32 unit vectors under
+  // "advance over k zero bytes", stepped from k = 0 upwards; a lane's table is written when k reaches its count.
   auto zero_byte = [&](uint32_t r) { return slice[r & 0xFFu] ^ (r >> 8); };
-  uint32_t z255[32];
-  for (int j = 0; j < 32; ++j) { uint32_t r = 1u << j; for (int k = 0; k < piece; ++k) r = zero_byte(r); z255[j] = r; }
-  auto apply = [&](const uint32_t* cols, uint32_t v) { uint32_t o = 0; for (int j = 0; j < 32; ++j) if ((v >> j) & 1u) o ^= cols[j]; return o; };
-  // lane i is followed by 63 - i pieces: A_63 = identity, A_i = A_(i+1) o Z255
-  shift.assign((size_t)64 * 1024, 0);
+  const int nw = block_bytes / 4, pw = nw / 64 + 1;
+  std::vector<int> behind(64);
+  for (int lane = 0; lane < 64; ++lane) { const int end = std::min((lane + 1) * pw, nw), begin = std::min(lane * pw, nw); behind[lane] = begin < end ? 4 * (nw - end) : -1; }
+  shift.assign((size_t)64 * 1024, 0);      // (a lane without dwords contributes nothing: its register stays 0, any table will do)
   uint32_t cols[32];
   for (int j = 0; j < 32; ++j) cols[j] = 1u << j;
-  for (int lane = 63; lane >= 0; --lane) {
-    for (int t = 0; t < 4; ++t)
-      for (uint32_t b = 0; b < 256; ++b) shift[(size_t)lane * 1024 + t * 256 + b] = apply(cols, b << (8 * t));
-    uint32_t next[32];
-    for (int j = 0; j < 32; ++j) next[j] = apply(cols, z255[j]);   // A_(lane-1)(e_j) = A_lane(Z255(e_j))
-    memcpy(cols, next, sizeof(cols));
+  auto apply = [&](uint32_t v) { uint32_t o = 0; for (int j = 0; j < 32; ++j) if ((v >> j) & 1u) o ^= cols[j]; return o; };
+  for (int k = 0; k <= block_bytes; ++k) {
+    for (int lane = 0; lane < 64; ++lane) if (behind[lane] == k)
+      for (int t = 0; t < 4; ++t) for (uint32_t b = 0; b < 256; ++b) shift[(size_t)lane * 1024 + t * 256 + b] = apply(b << (8 * t));
+    for (int j = 0; j < 32; ++j) cols[j] = zero_byte(cols[j]);
   }
 }
 
@@ -408,7 +422,7 @@ void BgzfDeviceCompressor::enqueue(int slot, const char* dev_src, uint64_t n, ch
   if (!S.d_slice) {
     std::vector<uint32_t> slice, shift;
     S.block = bgzf_block_input();
-    build_crc_tables(slice, shift, (int)S.block / 64);
+    build_crc_tables(slice, shift, (int)S.block);
     BGZF_HIP(hipMalloc((void**)&S.d_slice, slice.size() * 4));
     BGZF_HIP(hipMalloc((void**)&S.d_shift, shift.size() * 4));
     BGZF_HIP(hipMemcpy(S.d_slice, slice.data(), slice.size() * 4, hipMemcpyHostToDevice));
