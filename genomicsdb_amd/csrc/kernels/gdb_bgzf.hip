@@ -40,11 +40,14 @@ const unsigned char kBgzfEofBlock[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 
 namespace {
 
 constexpr int kProbe = 16;                         // bytes every position compares against its candidate (a multiple of 8)
-constexpr int kRingWords = 256, kFlushWords = 128; // (a step adds at most 64 tokens x 31 bits = 62 words)
+constexpr int kRingWords = 128, kFlushWords = 64;  // (64 tokens x 31 bits = 62 words at most join the < 64 words that wait: < 126)
 // room for the payload of one block while it is being produced (a block that grows is cut off early, at most one ring flush beyond its input size)
 __host__ __device__ constexpr uint32_t slot_bytes(uint32_t block_input) { return block_input + 1024u; }
 constexpr uint32_t kNoCand = 0xFFFFu;
 constexpr uint32_t kTokQueue = 128;
+#ifndef GDBAMD_BGZF_HASH_BITS_8K
+#define GDBAMD_BGZF_HASH_BITS_8K 10
+#endif
 
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
 
@@ -84,7 +87,7 @@ __global__ void __launch_bounds__(64) k_bgzf_deflate(const uint8_t* __restrict__
   const uint32_t n = (uint32_t)((n_total - base) < (uint64_t)kBgzfBlockInput ? (n_total - base) : (uint64_t)kBgzfBlockInput);
   const int lane = threadIdx.x;
   __shared__ uint4 in4[kBgzfBlockInput / 16 + 3];             // 48 bytes of zeros behind the block: the probes read up to 39 bytes past a position
-  constexpr int kHashBits = kBgzfBlockInput > 8192 ? 11 : kBgzfBlockInput > 4096 ? 10 : 9;
+  constexpr int kHashBits = kBgzfBlockInput > 8192 ? 11 : kBgzfBlockInput > 4096 ? GDBAMD_BGZF_HASH_BITS_8K : 9;
   constexpr uint32_t kSlotBytes = slot_bytes((uint32_t)kBgzfBlockInput);
   constexpr int kPieceWords = kBgzfBlockInput / 256 + 1;       // dwords of the block whose CRC a lane takes: an ODD count, so that the lanes' reads fall into different banks
   __shared__ uint32_t table32[(1 << kHashBits) / 2 + 2];      // (+ a spare slot for the positions behind the block's end)

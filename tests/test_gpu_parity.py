@@ -628,8 +628,9 @@ def test_empty_inputs(gdb, tmp_path):
 def test_two_handles_in_two_threads(gdb, tmp_path):
     """the reference's threading rule at the boundary: one handle per thread, several handles per process.  Two engines with
     different queries work at the same time from two host threads (ctypes releases the GIL); each must produce what it
-    produces alone (the per-interval context in constant memory is one symbol per process and is handed over under a lock;
-    this test exercises the threaded use, it does not prove the lock: the race window is a few hundred microseconds)."""
+    produces alone.  Every pipeline owns ONE element of the per-interval context array in constant memory for its lifetime
+    (nothing is handed over, there is no lock to prove): with the two plans differing in their FORMAT fields, a kernel of one
+    engine reading the other's element would print the other's columns, in every one of the 12 x 2 concurrent intervals."""
     import hashlib
     import threading
     from genomicsdb_amd import synth
@@ -669,6 +670,23 @@ def test_two_handles_in_two_threads(gdb, tmp_path):
     assert errors == []
     for e, _ in engines:
         e.close()
+
+
+def test_pipelines_per_process_limit_is_reported(gdb, tmp_path):
+    """GDBAMD_MAX_PIPELINES_PER_PROCESS = 16 (include/genomicsdb_amd.h): the 17th engine alive at a time is refused with a message
+    that names the limit; closing one makes room again"""
+    q = helpers.synth_query(tmp_path, 5, 10_000_000, 10_000_100)
+    engines = []
+    try:
+        for i in range(16):
+            engines.append(gdb.CombineEngine(q))
+        with pytest.raises(gdb.GenomicsDBException, match="16 device pipelines"):
+            gdb.CombineEngine(q)
+        engines.pop().close()
+        engines.append(gdb.CombineEngine(q))
+    finally:
+        for e in engines:
+            e.close()
 
 
 # ---- arrays larger than the staging budget: column windows streamed through HBM with carry-over ----------------------------
