@@ -11,6 +11,8 @@ cp $r/traffic/traffic_by_kernel.json ${p}_pmc_traffic_by_kernel.json
 grep -v "amdgpu.ids" $r/bgzf_bench.txt > ${p}_bgzf_bench.txt
 cp $r/type_stats.txt ${p}_c3_width_window_type_stats.txt
 ( grep -n "passed\|failed" $r/gpu_tests.log; tail -1 $r/smoke.log ) > ${p}_gpu_tests_and_smoke.txt
+[ -f $r/bgzf_sq_counters.txt ] && cp $r/bgzf_sq_counters.txt ${p}_bgzf_sq_counters.txt
+[ -f $r/frag_bench.txt ] && cp $r/frag_bench.txt ${p}_fragment_load.txt
 python3 tests/tools/make_traffic_json.py $r/traffic/traffic_by_kernel.json > /dev/null
 python3 - "$r/bench_line.json" "${p}_bench_line.json" <<'PY'
 import json, sys
