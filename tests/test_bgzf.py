@@ -85,8 +85,8 @@ def test_device_deflate_on_hostile_inputs(gdb):
     }
     for name, data in cases.items():
         comp, _ = _check_roundtrip(gdb, data)
-        if name in ("zeros", "period 255"):
-            assert len(comp) * 20 < len(data), name
+        if name in ("zeros", "period 255"):     # (every block starts with its own 255 literals: small blocks find less)
+            assert len(comp) * (20 if int(os.environ.get("GDBAMD_BGZF_BLOCK", "8192")) >= 8192 else 10) < len(data), name
         if name == "text":                                   # (columns of random numbers: little to find besides the separators)
             assert len(comp) * 1.7 < len(data), name
         if name in ("random", "one block exactly", "two blocks exactly"):
