@@ -1,20 +1,22 @@
 // gdb_bgzf.hip - BGZF blocks deflated on the device (see gdb_bgzf.h).
 //
-// k_bgzf_deflate: one wavefront = one block of <= 16 320 input bytes, held in LDS together with a 2 048-entry hash table of the
-// most recent position of every 4-byte group and a ring of output words.  The wavefront takes 64 consecutive positions per step:
+// k_bgzf_deflate: one wavefront = one block of 4 / 8 / 16 KiB of input (8 by default), held in LDS together with a 512- / 1 024- /
+// 2 048-entry hash table of the most recent position of every 4-byte group, a queue of tokens and a ring of output words
+// (11.3 KB for 8 KiB blocks: 14 wavefronts per CU).  The wavefront takes 64 consecutive positions per step:
 //   * every lane hashes the 4 bytes at its position, reads the candidate the table holds (a position of an earlier step) and
 //     leaves its own position there;
-//   * every lane measures its match against the candidate with 8-byte LDS compares (<= 258 bytes, never past the block's end);
+//   * every lane measures its match against the candidate over 16 bytes; ALL LDS accesses are aligned dwords that are
+//     funnel-shifted in registers (v_alignbyte): an 8-byte LDS read off its natural alignment is replayed at 64 cycles;
 //   * the greedy parse of RFC 1951's usual compressors - take the match if it is >= 4 bytes, else a literal, continue behind
-//     it - is a chain through the 64 positions that the scalar unit follows with v_readlane (a few tokens per step: a match
-//     skips ~20 positions);
-//   * the lanes at token starts encode their token with the FIXED Huffman code (literal 8-9 bits; length code + extra bits,
-//     5-bit distance code + extra bits, <= 31 bits, all by arithmetic - no tables), a DPP scan of the bit counts places them,
-//     and they are OR-ed into the ring; full halves of the ring leave as coalesced stores.
+//     it - is a chain through the 64 positions that the scalar unit follows with v_readlane (runs of literals in one go; a match
+//     whose 16-byte probe ran to its end is extended by the whole wavefront, 64 bytes per ballot, up to 258 bytes);
+//   * the tokens are compacted into the queue, and 64 at a time are encoded with the FIXED Huffman code (literal 8-9 bits; length
+//     code + extra bits, 5-bit distance code + extra bits, <= 31 bits, all by arithmetic - no tables), placed by a DPP scan of
+//     the bit counts and OR-ed into the ring; full halves of the ring leave as coalesced stores.
 // A block that does not shrink is written as a stored block.  The CRC-32 of the block's input is taken in the same kernel: every
-// lane runs the table-driven CRC (slicing-by-4) over its own 255 bytes, advances it over the bytes behind its piece with a
-// per-lane precomputed GF(2) operator (4 x 256 words per lane) and the 64 contributions are XOR-ed (the CRC register is linear
-// in its start value and the message).
+// lane runs the table-driven CRC (slicing-by-4) over its own 33 dwords (an odd count: the lanes' reads fall into different LDS
+// banks), advances it over the bytes behind its piece with a per-lane precomputed GF(2) operator (4 x 256 words per lane) and the
+// 64 contributions are XOR-ed (the CRC register is linear in its start value and the message).
 // k_bgzf_pack: headers ('BC' extra field with the block size), payloads and trailers (CRC-32, input size) at their final,
 // exclusive-scanned offsets.
 #include "gdb_bgzf.h"
