@@ -35,6 +35,8 @@ for case in range(ncases):
     modes = {}
     if rnd.random() < 0.4: modes["overlap_permille"] = rnd.choice([30, 150, 400])
     if rnd.random() < 0.3: modes["filter_permille"] = rnd.choice([100, 500]); opts["produce_FILTER_field"] = True
+    if "filter_permille" in modes and rnd.random() < 0.5:     # a second id: unions of different ids, written in libstdc++'s set order
+        modes["filter2_permille"] = rnd.choice([100, 400]); modes["filter_id"] = rnd.choice([0, 1]); modes["filter_id2"] = 1 - modes["filter_id"]
     with_id = rnd.random() < 0.3
     if with_id: modes["id_permille"] = rnd.choice([100, 600]); modes["with_id"] = True
     # genome mode: the columns of the array are cut into contigs of random lengths (one boundary every few hundred columns), so
@@ -74,6 +76,9 @@ for case in range(ncases):
     eng.set_reference(B, synth.reference(B, off + L + 4096, seed=gseed))
     got, st = eng.run_interval(qb, qe, arena_bytes=arena)
     ok = got == want and st.num_records == nrec
+    if not ok and os.environ.get("FUZZ_VERBOSE"):
+        k = next((i for i in range(min(len(got), len(want))) if got[i] != want[i]), -1)
+        print("  whole interval: got %d bytes, want %d, first difference at %d: %r / %r" % (len(got), len(want), k, got[max(0, k - 60):k + 30], want[max(0, k - 60):k + 30]))
     if rnd.random() < 0.3:   # the same interval in pieces cut before cell begins: byte-identical by construction
         maxc = rnd.choice([25, 100, 400])
         pieces, cur = [], qb
@@ -82,8 +87,28 @@ for case in range(ncases):
             body, _ = eng.run_interval(cur, pe, arena_bytes=arena)
             pieces.append(body)
             cur = pe + 1
+        if ok and b"".join(pieces) != want and os.environ.get("FUZZ_VERBOSE"):
+            j = b"".join(pieces)
+            k = next((i for i in range(min(len(j), len(want))) if j[i] != want[i]), -1)
+            print("  pieces (max %d columns, %d pieces): got %d bytes, want %d, first difference at %d: %r / %r" % (maxc, len(pieces), len(j), len(want), k, j[max(0, k - 80):k + 40], want[max(0, k - 80):k + 40]))
         ok = ok and b"".join(pieces) == want
     eng.close()
+    if ok and rnd.random() < 0.25:   # the same interval as BGZF blocks deflated on the device: the inflated stream is the text
+        import zlib
+        ez = genomicsdb_amd.CombineEngine(q, output_format="z")
+        ez.stage_cells(cells)
+        ez.set_reference(B, synth.reference(B, off + L + 4096, seed=gseed))
+        zbody, _ = ez.run_interval(qb, qe, arena_bytes=max(arena, 1 << 16))
+        ez.close()
+        out, rest = [], zbody
+        while rest:
+            d = zlib.decompressobj(31)
+            out.append(d.decompress(rest)); rest = d.unused_data
+        ok = b"".join(out) == want
+        if not ok:
+            j = b"".join(out)
+            k = next((i for i in range(min(len(j), len(want))) if j[i] != want[i]), -1)
+            print("  BGZF check: inflated %d bytes, text %d bytes, %d blocks, first difference at %d: %r / %r" % (len(j), len(want), len(out), k, j[max(0, k - 20):k + 20], want[max(0, k - 20):k + 20]))
     if not ok:
         bad += 1
         print("MISMATCH case %d: N=%d L=%d B=%d off=%d seed=%d dense=%s rs_scale=%s opts=%s modes=%s contigs=%s arena=%d parts=%d records %d/%d" % (case, N, L, B, off, gseed, dense, rs_scale, opts, modes, (len(contigs) if contigs else None), arena, nparts, st.num_records, nrec), flush=True)
