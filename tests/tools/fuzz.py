@@ -109,6 +109,31 @@ for case in range(ncases):
             j = b"".join(out)
             k = next((i for i in range(min(len(j), len(want))) if j[i] != want[i]), -1)
             print("  BGZF check: inflated %d bytes, text %d bytes, %d blocks, first difference at %d: %r / %r" % (len(j), len(want), len(out), k, j[max(0, k - 20):k + 20], want[max(0, k - 20):k + 20]))
+    if ok and rnd.random() < 0.25:   # the same array streamed through HBM in windows of a random staging budget (carry-over of the live
+        import ctypes                  # intervals on the device, the next window staged by the prefetch thread while this one computes)
+        budget = rnd.choice([1, 3000, 40_000, 400_000])
+        os.environ["GDBAMD_STAGE_BUDGET_BYTES"] = str(budget)
+        try:
+            ew = genomicsdb_amd.CombineEngine(q)
+            buf = ctypes.create_string_buffer(cells, len(cells))
+            ew.open_memory_cells((ctypes.addressof(buf), len(cells)))
+            ew.set_reference(B, synth.reference(B, off + L + 4096, seed=gseed))
+            parts, cur, nwin = [], qb, 0
+            while cur <= qe:
+                lo, hi = ew.cover(cur)
+                nwin += 1
+                end = min(qe, hi)
+                body, _ = ew.run_interval(cur, end, arena_bytes=arena)
+                parts.append(body)
+                cur = end + 1
+            ew.close()
+        finally:
+            del os.environ["GDBAMD_STAGE_BUDGET_BYTES"]
+        ok = b"".join(parts) == want
+        if not ok:
+            j = b"".join(parts)
+            k = next((i for i in range(min(len(j), len(want))) if j[i] != want[i]), -1)
+            print("  windowed (budget %d, %d windows): got %d bytes, want %d, first difference at %d: %r / %r" % (budget, nwin, len(j), len(want), k, j[max(0, k - 60):k + 30], want[max(0, k - 60):k + 30]))
     if not ok:
         bad += 1
         print("MISMATCH case %d: N=%d L=%d B=%d off=%d seed=%d dense=%s rs_scale=%s opts=%s modes=%s contigs=%s arena=%d parts=%d records %d/%d" % (case, N, L, B, off, gseed, dense, rs_scale, opts, modes, (len(contigs) if contigs else None), arena, nparts, st.num_records, nrec), flush=True)
