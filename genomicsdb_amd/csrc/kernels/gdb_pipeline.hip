@@ -1834,7 +1834,7 @@ __global__ void k_bcf_shared(const SiteCtx* __restrict__ sxp, const char* __rest
 // (collect_and_extend_fields, variant_field_handler.cc:846-866) into an LDS image of the 64 samples' values, and the wavefront
 // moves the image to the record with aligned 16-byte stores.
 struct __attribute__((packed)) PackedU16 { uint16_t v; };
-constexpr int kBcfEntryCap = 128;    // bytes of an entry kept in the lane's LDS slot (the rest is read from the pool)
+constexpr int kBcfEntryCap = 96;     // bytes of an entry kept in the lane's LDS slot (the rest is read from the pool)
 constexpr int kBcfImageSample = 32;  // bytes per sample and field that go through the LDS image (longer vectors: direct stores)
 // one sample's cnt values of a field of BCF type t, from its entry (n elements at `in`) to `out`.  first / rest: what stands where
 // the call has no element (the first position of an empty vector, every other one).  The two pointers are LDS or global by
@@ -1871,7 +1871,7 @@ __global__ void k_bcf_same_layout(const int32_t* __restrict__ order, const uint3
   same[idx] = eq ? 1 : 0;
 }
 struct __attribute__((packed)) PackedU128 { u32x4 v; };
-constexpr int kBcfImageBytes = 4096;     // LDS image of the FORMAT values of one (record, 64-sample chunk), every field a 16-byte aligned region
+constexpr int kBcfImageBytes = 3072;     // LDS image of the FORMAT values of one (record, 64-sample chunk), every field a 16-byte aligned region
 constexpr int kBcfImageSets = kBcfImageBytes / (16 * kAsmRows);
 constexpr int kBcfBatch = 4;             // records whose resolved rows are fetched together
 // One wavefront = a run of records x 64 samples.
@@ -1883,7 +1883,11 @@ constexpr int kBcfBatch = 4;             // records whose resolved rows are fetc
 // the only thing that differs).  Per-field constants live in lanes (lane q = q-th field of the record) and reach the field loop
 // through v_readlane; everything the loop needs from memory arrives one record ahead as vector loads.
 // SLOW PATH (long vectors): field by field through a 2 KB image with aligned stores, or straight to the page.
-__global__ void __launch_bounds__(kAsmRows) k_bcf_write(CombinePlan pl, const uint2* __restrict__ resolved, const char* __restrict__ pool, const char* __restrict__ pool_ovf,
+// Resident wavefronts are what this kernel runs on (a step is a chain of LDS round trips): 96-byte entry slots, a 3 KiB image and at
+// most 128 registers (amdgpu_waves_per_eu) make it 14 per CU instead of 11 - 18.1 -> 14.3 ms on the c2 window.  (With 129 registers
+// the register file allowed 12, which is why smaller slots alone changed nothing in round 2; a 2 KiB image sends c2's records down
+// the slow path, 2 instead of 4 rows per batch costs more than the 15th wavefront brings.)
+__global__ void __launch_bounds__(kAsmRows) __attribute__((amdgpu_waves_per_eu(4))) k_bcf_write(CombinePlan pl, const uint2* __restrict__ resolved, const char* __restrict__ pool, const char* __restrict__ pool_ovf,
                                                       const uint32_t* __restrict__ fmt_mask, const int32_t* __restrict__ order, const uint8_t* __restrict__ same_layout, int64_t np, int nchunks,
                                                       int F, int32_t N, BcfLayout lay, const uint64_t* __restrict__ rec_off, uint64_t page_base, char* __restrict__ arena) {
   __shared__ __attribute__((aligned(16))) char s_entry[kAsmRows * kBcfEntryCap];
