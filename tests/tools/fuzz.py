@@ -109,6 +109,21 @@ for case in range(ncases):
             j = b"".join(out)
             k = next((i for i in range(min(len(j), len(want))) if j[i] != want[i]), -1)
             print("  BGZF check: inflated %d bytes, text %d bytes, %d blocks, first difference at %d: %r / %r" % (len(j), len(want), len(out), k, j[max(0, k - 20):k + 20], want[max(0, k - 20):k + 20]))
+    if ok and rnd.random() < 0.2:    # the same interval as BCF2 records, decoded by the tests' own reader back to text
+        import struct
+        eb = genomicsdb_amd.CombineEngine(q, output_format="bu")
+        eb.stage_cells(cells)
+        eb.set_reference(B, synth.reference(B, off + L + 4096, seed=gseed))
+        bbody, _ = eb.run_interval(qb, qe, arena_bytes=max(arena, 1 << 16))
+        htext = eb.header
+        eb.close()
+        if not htext.endswith(b"\x00"): htext += b"\x00"
+        stream = b"BCF\x02\x02" + struct.pack("<I", len(htext)) + htext + bbody
+        dec = b"".join(l + b"\n" for l in helpers.bcf_stream_to_text(stream).split(b"\n") if l and not l.startswith(b"#"))
+        ok = dec == want
+        if not ok:
+            k = next((i for i in range(min(len(dec), len(want))) if dec[i] != want[i]), -1)
+            print("  BCF2 check: decoded %d bytes, text %d bytes, first difference at %d: %r / %r" % (len(dec), len(want), k, dec[max(0, k - 60):k + 30], want[max(0, k - 60):k + 30]))
     if ok and rnd.random() < 0.25:   # the same array streamed through HBM in windows of a random staging budget (carry-over of the live
         import ctypes                  # intervals on the device, the next window staged by the prefetch thread while this one computes)
         budget = rnd.choice([1, 3000, 40_000, 400_000])
