@@ -1728,6 +1728,8 @@ __global__ void __launch_bounds__(kAsmRows) k_bcf_field_meta(const uint2* __rest
   const int W = (F + 1) >> 1;
   uint32_t held = 0xFFFFFFFFu;        // the entry whose first 16 bytes are in h
   u32x4 h = {0u, 0u, 0u, 0u};
+  uint32_t prev_key = 0xFFFFFFFFu, mine = 0;
+  int prev_words = -1;
   // records in (block, type) order (`order`, like the text assembly): along a run the samples keep their entries
   int32_t my_k = 0;
   for (int64_t i = k0; i < k1; ++i) {                    // uniform
@@ -1737,8 +1739,14 @@ __global__ void __launch_bounds__(kAsmRows) k_bcf_field_meta(const uint2* __rest
     const uint2 d = resolved[rc * kAsmRows + lane];
     const char* src = ((d.x & kOverflowBit) ? pool_ovf : pool) + (size_t)(d.x & ~kOverflowBit) * 16;
     const int words = (__popc(fmt_mask[k]) + 1) >> 1;
+    // a record whose 64 samples all keep the entries of the record before it (a third of the steps along a type run) has its
+    // summary maxima too: the reductions below are skipped
+    const uint32_t key = d.y ? d.x : 0xFFFFFFFEu;
+    const bool same = words == prev_words && !__any((int)(key != prev_key));
+    prev_key = key; prev_words = words;
+    if (same) { if (lane < words) part[rc * W + lane] = mine; continue; }
     if (d.y && d.x != held) { h = *reinterpret_cast<const u32x4*>(src); held = d.x; }   // (entries are 16-byte aligned and padded)
-    uint32_t mine = 0;
+    mine = 0;
     for (int w0 = 0; w0 < words; w0 += 4) {               // uniform
       u32x4 v = {0u, 0u, 0u, 0u};
       if (d.y) v = w0 == 0 ? h : *reinterpret_cast<const u32x4*>(src + 4 * w0);
