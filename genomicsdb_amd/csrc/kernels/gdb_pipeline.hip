@@ -707,8 +707,14 @@ __global__ void __launch_bounds__(kHugeBlock) k_site_huge(const SiteCtx* __restr
 // Pass 0 runs the record logic ONCE: allele merge, LUTs, per-record flags - and the text of the fixed columns, formatted
 // through a capped LDS sink into a lane-private strip and parked in a fixed-stride staging slot.  The page pass then only
 // copies the parked text (records whose fixed columns exceed the slot - long allele lists - are formatted again).
-constexpr int kSiteStride = 256;                   // staging bytes per record
-constexpr int kSiteStripWords = kSiteStride / 4 + 1;
+constexpr int kSiteStride = 256;                   // distance of two records' staging slots
+// bytes of the fixed columns that are parked (the rest goes to the spill pool): this is also the lane's LDS strip, and the site pass is
+// a latency-bound kernel of one wavefront per workgroup - 192 instead of 256 bytes per lane make it 12 instead of 9 wavefronts per CU
+#ifndef GDBAMD_SITE_CAP
+#define GDBAMD_SITE_CAP 192
+#endif
+constexpr int kSiteCap = GDBAMD_SITE_CAP;
+constexpr int kSiteStripWords = kSiteCap / 4 + 1;
 constexpr int kSpillChunks = 32768;                 // spill pool: 64 MB of 2 KB chunks for the tails of longer fixed columns
 // The lanes of a wavefront wait for the record with the most variant calls among their 64: records are dealt out in the order of
 // their call counts (`order`, a radix sort over 8-bit keys), so that a wavefront's records cost about the same.
@@ -727,12 +733,12 @@ __global__ void __launch_bounds__(64) k_site_size(const SiteCtx* __restrict__ sx
   if (order) k = order[k];
   uint32_t e = 0;
   uint32_t* mine = strip + threadIdx.x * kSiteStripWords;
-  LdsSpillSink cs((gdb_lds_char*)mine, (uint32_t)kSiteStride, spill);
+  LdsSpillSink cs((gdb_lds_char*)mine, (uint32_t)kSiteCap, spill);
   site_emit(sx, k, cs, true, &e);
   sx.so.prefix_len[k] = cs.n;
   // longer texts: the tail lies in a chunk of the spill pool (or, when that did not work out, the page pass formats the record again)
-  spill_chunk[k] = (cs.n > (uint32_t)kSiteStride && cs.complete()) ? cs.chunk : -1;
-  const uint32_t nstaged = min(cs.n, (uint32_t)kSiteStride);
+  spill_chunk[k] = (cs.n > (uint32_t)kSiteCap && cs.complete()) ? cs.chunk : -1;
+  const uint32_t nstaged = min(cs.n, (uint32_t)kSiteCap);
   uint4* dst = reinterpret_cast<uint4*>(staging + (size_t)k * kSiteStride);
   for (uint32_t q = 0; (q << 4) < nstaged; ++q) dst[q] = make_uint4(mine[4 * q], mine[4 * q + 1], mine[4 * q + 2], mine[4 * q + 3]);
   if (e) atomicOr(err, e);
@@ -749,7 +755,7 @@ __global__ void __launch_bounds__(256) k_site_copy(const uint32_t* __restrict__ 
   const uint32_t n = prefix_len[k];
   char* rec = arena + (chunk_off[k * nchunks] - page_base);
   if (lane == 0) arena[chunk_off[(k + 1) * nchunks] - page_base - 1] = '\n';
-  if (n > (uint32_t)kSiteStride) return;        // k_site_write formats or un-spills these
+  if (n > (uint32_t)kSiteCap) return;           // k_site_write formats or un-spills these
   const uint32_t a = (uint32_t)((uintptr_t)rec & 3u);
   const uint32_t cur = reinterpret_cast<const uint32_t*>(staging + (size_t)k * kSiteStride)[lane];
   uint32_t prev = (uint32_t)__shfl_up((int)cur, 1);
@@ -773,13 +779,13 @@ __global__ void k_site_write(const SiteCtx* __restrict__ sxp, const char* __rest
   uint32_t e = 0;
   char* dst = arena + (chunk_off[k * nchunks] - page_base);
   const uint32_t n = sx.so.prefix_len[k];
-  if (n <= (uint32_t)kSiteStride) {
+  if (n <= (uint32_t)kSiteCap) {
     return;                                     // parked whole in its staging slot: k_site_copy has written it (and the '\n')
   } else if (spill_chunk[k] >= 0) {
     const char* src = staging + (size_t)k * kSiteStride;
-    for (uint32_t i = 0; i < (uint32_t)kSiteStride; ++i) dst[i] = src[i];
+    for (uint32_t i = 0; i < (uint32_t)kSiteCap; ++i) dst[i] = src[i];
     const char* tail = spill_buf + (size_t)spill_chunk[k] * kSpillChunk;
-    for (uint32_t i = kSiteStride; i < n; ++i) dst[i] = tail[i - kSiteStride];
+    for (uint32_t i = kSiteCap; i < n; ++i) dst[i] = tail[i - kSiteCap];
   } else {
     ByteSink bs(dst);
     site_emit(sx, k, bs, false, &e);
@@ -1812,14 +1818,14 @@ __global__ void k_bcf_shared(const SiteCtx* __restrict__ sxp, const char* __rest
   bcf_put_u32(head, lay.l_indiv[k]);
   char* dst = rec + 8;
   uint32_t e = 0;
-  if (n <= (uint32_t)kSiteStride) {
+  if (n <= (uint32_t)kSiteCap) {
     const char* src = staging + (size_t)k * kSiteStride;
     for (uint32_t i = 0; i < n; ++i) dst[i] = src[i];
   } else if (spill_chunk[k] >= 0) {
     const char* src = staging + (size_t)k * kSiteStride;
-    for (uint32_t i = 0; i < (uint32_t)kSiteStride; ++i) dst[i] = src[i];
+    for (uint32_t i = 0; i < (uint32_t)kSiteCap; ++i) dst[i] = src[i];
     const char* tail = spill_buf + (size_t)spill_chunk[k] * kSpillChunk;
-    for (uint32_t i = kSiteStride; i < n; ++i) dst[i] = tail[i - kSiteStride];
+    for (uint32_t i = kSiteCap; i < n; ++i) dst[i] = tail[i - kSiteCap];
   } else {
     ByteSink bs(dst);
     site_emit(sx, k, bs, false, &e);
