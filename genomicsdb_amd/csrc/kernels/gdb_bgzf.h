@@ -14,7 +14,7 @@
 
 namespace genomicsdb_amd {
 
-// uncompressed bytes per block: 64 lanes x 64, 128 or 256 bytes (GDBAMD_BGZF_BLOCK = 4096 / 8192 / 16384; smaller blocks leave room for more
+// uncompressed bytes per block: 64 lanes x 64, 128 or 256 bytes (GDBAMD_BGZF_BLOCK = 4096 / 6144 / 8192 / 16384; smaller blocks leave room for more
 // resident wavefronts, larger ones find a little more to match)
 uint32_t bgzf_block_input();
 constexpr uint32_t kBgzfHeaderBytes = 18, kBgzfTrailerBytes = 8;

@@ -367,7 +367,7 @@ void build_crc_tables(std::vector<uint32_t>& slice, std::vector<uint32_t>& shift
 }  // namespace
 
 uint32_t bgzf_block_input() {
-  static const uint32_t v = []() { const char* e = getenv("GDBAMD_BGZF_BLOCK"); const int v = e ? atoi(e) : 0; return v == 16384 ? 16384u : v == 4096 ? 4096u : 8192u; }();
+  static const uint32_t v = []() { const char* e = getenv("GDBAMD_BGZF_BLOCK"); const int v = e ? atoi(e) : 0; return v == 16384 ? 16384u : v == 4096 ? 4096u : v == 6144 ? 6144u : 8192u; }();
   return v;
 }
 
@@ -471,6 +471,9 @@ void BgzfDeviceCompressor::enqueue(int slot, const char* dev_src, uint64_t n, ch
   BGZF_HIP(hipEventRecord(J.ev0, st));
   if (kBgzfBlockInput == 16384u)
     hipLaunchKernelGGL(k_bgzf_deflate<16384>, dim3((unsigned)nblocks), dim3(64), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.bsize, S.crc, (const uint32_t*)S.d_slice,
+                       (const uint32_t*)S.d_shift);
+  else if (kBgzfBlockInput == 6144u)
+    hipLaunchKernelGGL(k_bgzf_deflate<6144>, dim3((unsigned)nblocks), dim3(64), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.bsize, S.crc, (const uint32_t*)S.d_slice,
                        (const uint32_t*)S.d_shift);
   else if (kBgzfBlockInput == 4096u)
     hipLaunchKernelGGL(k_bgzf_deflate<4096>, dim3((unsigned)nblocks), dim3(64), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.bsize, S.crc, (const uint32_t*)S.d_slice,

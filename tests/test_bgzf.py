@@ -59,7 +59,7 @@ def _check_roundtrip(gdb, data):
     assert b"".join(r for _, r in blocks) == data
     if len(blocks) > 1:
         blk = len(blocks[0][1])
-        assert blk in (4096, 8192, 16384)                            # GDBAMD_BGZF_BLOCK
+        assert blk in (4096, 6144, 8192, 16384)                            # GDBAMD_BGZF_BLOCK
         assert len(blocks) == (len(data) + blk - 1) // blk and all(len(r) == blk for _, r in blocks[:-1])
     return comp, ms
 
