@@ -709,9 +709,11 @@ __global__ void __launch_bounds__(kHugeBlock) k_site_huge(const SiteCtx* __restr
 // copies the parked text (records whose fixed columns exceed the slot - long allele lists - are formatted again).
 constexpr int kSiteStride = 256;                   // distance of two records' staging slots
 // bytes of the fixed columns that are parked (the rest goes to the spill pool): this is also the lane's LDS strip, and the site pass is
-// a latency-bound kernel of one wavefront per workgroup - 192 instead of 256 bytes per lane make it 12 instead of 9 wavefronts per CU
+// a latency-bound kernel of one wavefront per workgroup.  192 instead of 256 bytes per lane make it 12 instead of 9 wavefronts per CU
+// and the c2 site phase 2.48 instead of 2.76 ms - but the spill path (byte-wise, one thread per record) is a cliff: with 160 bytes the
+// same phase takes 9.1 ms, and c2's fixed columns (~170 bytes at variant sites) are not far below 192.  256 keeps the distance.
 #ifndef GDBAMD_SITE_CAP
-#define GDBAMD_SITE_CAP 192
+#define GDBAMD_SITE_CAP 256
 #endif
 constexpr int kSiteCap = GDBAMD_SITE_CAP;
 constexpr int kSiteStripWords = kSiteCap / 4 + 1;
