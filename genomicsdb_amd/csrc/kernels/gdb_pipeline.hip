@@ -118,6 +118,9 @@ inline uint64_t resolved_budget_bytes() {
 inline int event_run_length() { const char* e = getenv("GDBAMD_EV_RUN"); return e && *e ? std::max(1, std::min(64, atoi(e))) : 32; }
 // (off by default: measured slower than the dense matrix, with scalar loads of the changes and with vector loads + v_readlane)
 inline bool events_enabled() { const char* e = getenv("GDBAMD_EVENTS"); return e && *e && *e != '0'; }
+// GDBAMD_MATRIX=1: text pages through the dense (record, sample) matrix of rounds 1-3 instead of the matrix-free kernels (A/B runs; BCF always uses the matrix)
+inline bool matrix_forced() { const char* e = getenv("GDBAMD_MATRIX"); return e && *e && *e != '0'; }
+inline int write2_run_length() { const char* e = getenv("GDBAMD_RUN_W2"); return e && *e ? std::max(1, atoi(e)) : 64; }
 // wavefronts (= neighbouring 64-sample chunks) per workgroup of the page assembly: 4 measured best on the store-only model
 inline int write_waves_per_group() { const char* e = getenv("GDBAMD_WRITE_WAVES"); return e && *e ? atoi(e) : 1; }
 inline bool slot_regroup() { static const bool v = []() { const char* e = getenv("GDBAMD_SLOT_REGROUP"); return !(e && *e == '0'); }(); return v; }
@@ -938,19 +941,15 @@ __global__ void k_cell_types(const uint32_t* cflags, const int32_t* k_lo, const 
   tmask[i] = m;
   nslots[i] = (uint32_t)__popcll(m);
 }
-__global__ void k_inc_pos(const uint64_t* inc_keys_sorted, const int64_t* inc_cell, const int64_t* hoff, const int32_t* k_lo, int64_t c_base, int64_t T,
-                          int64_t nrows, uint32_t* inc_pos) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= T) return;
-  const int64_t c = inc_cell[i];
-  const int64_t k = (int64_t)(inc_keys_sorted[i] / (uint64_t)nrows);
-  inc_pos[hoff[c - c_base] + (k - k_lo[c])] = (uint32_t)i;
-}
-
 constexpr int kSlotBlock = 64;     // threads per workgroup of the slot kernels
 constexpr int kSlotStride = 128;   // bytes of an inline slot: slot s lives at pool + s * kSlotStride; longer texts go to the overflow pool
 constexpr int kStripWords = kSlotStride / 4 + 1;   // LDS words per lane: odd stride, no bank conflicts between lanes
 constexpr uint32_t kOverflowBit = 0x80000000u;     // descriptor offsets with this bit are 16-byte units into the overflow pool
+// Text mode: the last 8 bytes of an inline slot are its TAG {u32 where, u32 len}: where = 0 (the text is the slot's first len
+// bytes, len <= kInlineText) or kOverflowBit | 16-byte unit of the overflow pool.  The matrix-free page assembly (k_write2) needs
+// nothing but the slot number to fetch a text: the tag arrives with the slot's own cache line.  BCF entries keep all 128 bytes.
+constexpr int kSlotTagAt = kSlotStride - 8;
+constexpr int kInlineText = kSlotTagAt;
 struct SlotTable {
   uint32_t* len;          // [S]  entry bytes incl. the leading tab; 0: the record has no FORMAT columns
   const uint32_t* ovf16;  // [S]  overflow-pool offset in 16-byte units (exclusive scan; only meaningful for len > kSlotStride)
@@ -965,6 +964,10 @@ struct SlotTable {
   uint32_t bump_cap;      // units of ONE shard's part of the overflow pool (0: pass 0 places nothing, every long text waits for pass 1)
   int32_t ctx;            // this pipeline's slot of c_ex
   int32_t bcf;            // entries are binary (gdb_bcf.hpp) instead of text
+  uint32_t inline_max;    // longest entry that stays in its inline slot: kInlineText (text, tagged slots) or kSlotStride (BCF)
+  // heavy slots are numbered in FILL order (cell by cell, record by record: hoff[cell] + k - k_lo[cell]), so that a walker names the
+  // slot of a heavy call from its registers, without the fill-order -> (record, row)-order table of earlier rounds
+  const int64_t* hoff; const int32_t* k_lo; int64_t c_base;
 };
 // PASS 0: ONE run of the field emitters gives the length of the text and, when it fits kSlotStride bytes (nearly always),
 // the text itself: formatted into a lane-private LDS strip, it leaves as 16-byte stores into the lane's inline slot.
@@ -981,7 +984,7 @@ constexpr int kBumpShards = 16;
 // pass 1 formats: every long text (scan mode, bump_cap == 0: the places come from a scan over all lengths) or only the ones pass 0
 // could not place (bump mode)
 __device__ __forceinline__ bool slot_needs_pass1(const SlotTable& st, uint32_t s) {
-  return st.len[s] > (uint32_t)kSlotStride && (st.bump_cap == 0u || st.ovf16[s] == kSlotUnplaced);
+  return st.len[s] > st.inline_max && (st.bump_cap == 0u || st.ovf16[s] == kSlotUnplaced);
 }
 template <int PASS, int STRIPW> __device__ __forceinline__ uint32_t slot_fill(const SlotTable& st, uint32_t s, const RecordInfo& rinfo, int64_t c, uint32_t* mine, uint32_t* e) {
   uint32_t len = 0;
@@ -994,9 +997,15 @@ template <int PASS, int STRIPW> __device__ __forceinline__ uint32_t slot_fill(co
       *txt = '\t';
       len = 1u + entry_store_lds_capped(st.ctx, rinfo, c, txt + 1, cap - 1u, e);
       }
-      if (len <= (uint32_t)kSlotStride) {
+      if (len <= st.inline_max) {
         uint4* dst = reinterpret_cast<uint4*>(st.pool + (size_t)s * kSlotStride);
-        for (uint32_t q = 0; (q << 4) < len; ++q) dst[q] = make_uint4(mine[4 * q], mine[4 * q + 1], mine[4 * q + 2], mine[4 * q + 3]);
+        uint32_t nq = (len + 15u) >> 4;
+        if (!st.bcf) {                                             // the tag leaves with the slot's last 16 bytes
+          mine[kSlotTagAt / 4] = 0u; mine[kSlotTagAt / 4 + 1] = len;
+          dst[kSlotStride / 16 - 1] = make_uint4(mine[kSlotStride / 4 - 4], mine[kSlotStride / 4 - 3], mine[kSlotStride / 4 - 2], mine[kSlotStride / 4 - 1]);
+          if (nq > (uint32_t)(kSlotStride / 16 - 1)) nq = kSlotStride / 16 - 1;
+        }
+        for (uint32_t q = 0; q < nq; ++q) dst[q] = make_uint4(mine[4 * q], mine[4 * q + 1], mine[4 * q + 2], mine[4 * q + 3]);
       }
     }
     st.len[s] = len;
@@ -1017,7 +1026,7 @@ template <int PASS, int STRIPW> __device__ __forceinline__ uint32_t slot_fill(co
 // pass 0, behind slot_fill, by EVERY lane of the wavefront (active: the lane has a slot): place the long texts that fit the strip
 template <int STRIPW> __device__ __forceinline__ void slot_place_long(const SlotTable& st, bool active, uint32_t s, uint32_t len, const uint32_t* mine) {
   constexpr uint32_t cap = (uint32_t)(STRIPW - 1) * 4u;
-  const bool is_long = active && len > (uint32_t)kSlotStride;
+  const bool is_long = active && len > st.inline_max;
   if (!__any((int)is_long)) return;                             // uniform
   const bool fits = is_long && st.bump_cap != 0u && len <= cap;
   const uint32_t units = fits ? (len + 15u) >> 4 : 0u;
@@ -1125,10 +1134,12 @@ template <int PASS, int STRIPW> __global__ void k_slots_heavy(SlotTable st, Site
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < T;
   uint32_t e = 0, len = 0;
-  const uint32_t s = st.heavy_base + (uint32_t)(live ? i : 0);
+  uint32_t s = st.heavy_base;
   if (live) {
     const int64_t k = (int64_t)(inc_keys_sorted[i] / (uint64_t)nrows);
-    len = slot_fill<PASS, STRIPW>(st, s, load_record_info(so, c_ex[st.ctx].hl, k), inc_cell[i], mine, &e);
+    const int64_t c = inc_cell[i];
+    s += (uint32_t)(st.hoff[c - st.c_base] + (k - (int64_t)st.k_lo[c]));
+    len = slot_fill<PASS, STRIPW>(st, s, load_record_info(so, c_ex[st.ctx].hl, k), c, mine, &e);
   }
   if (PASS == 0) slot_place_long<STRIPW>(st, live, s, len, mine);
   if (e) atomicOr(err, e);
@@ -1155,50 +1166,61 @@ template <int PASS, int STRIPW> __global__ void k_slots_untabled(SlotTable st, S
   if (e) atomicOr(err, e);
 }
 // the overflow pool has grown: shard sh's part moved from sh * old_su to sh * new_su (units); placed texts keep their offset inside the part
-__global__ void k_slot_rebase(const uint32_t* len, uint32_t* ovf16, int64_t S, uint32_t old_su, uint32_t new_su) {
+__global__ void k_slot_rebase(const uint32_t* len, uint32_t* ovf16, int64_t S, uint32_t old_su, uint32_t new_su, uint32_t inline_max) {
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= S || len[s] <= (uint32_t)kSlotStride) return;
+  if (s >= S || len[s] <= inline_max) return;
   const uint32_t o = ovf16[s];
   if (o == kSlotUnplaced) return;
   const uint32_t sh = o / old_su;
   ovf16[s] = sh * new_su + (o - sh * old_su);
 }
-__global__ void k_slot_units(const uint32_t* len, int64_t S, uint32_t* units) {   // overflow-pool units of every slot
+__global__ void k_slot_units(const uint32_t* len, int64_t S, uint32_t* units, uint32_t inline_max) {   // overflow-pool units of every slot
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s < S) units[s] = len[s] > (uint32_t)kSlotStride ? (len[s] + 15u) >> 4 : 0u;
+  if (s < S) units[s] = len[s] > inline_max ? (len[s] + 15u) >> 4 : 0u;
 }
-__global__ void k_slot_desc(const uint32_t* len, const uint32_t* ovf16, int64_t S, uint2* desc) {
+// descriptors (off16, len) of all slots (desc != nullptr: the matrix kernels and the BCF path read them) and, in text mode
+// (tag_pool != nullptr), the tags of the slots the formatting pass did not tag itself: empty entries and overflow texts, whose
+// final place is only known here (after pass 1 / a grown pool)
+__global__ void k_slot_desc(const uint32_t* len, const uint32_t* ovf16, int64_t S, uint2* desc, char* tag_pool, uint32_t inline_max) {
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s < S) desc[s] = len[s] > (uint32_t)kSlotStride ? make_uint2(kOverflowBit | ovf16[s], len[s]) : make_uint2((uint32_t)s * (kSlotStride / 16), len[s]);
+  if (s >= S) return;
+  const uint32_t l = len[s];
+  const bool is_long = l > inline_max;
+  if (desc) desc[s] = is_long ? make_uint2(kOverflowBit | ovf16[s], l) : make_uint2((uint32_t)s * (kSlotStride / 16), l);
+  if (tag_pool && (is_long || l == 0u)) *reinterpret_cast<uint2*>(tag_pool + (size_t)s * kSlotStride + kSlotTagAt) = make_uint2(is_long ? (kOverflowBit | ovf16[s]) : 0u, l);
 }
 
 // ---- assembly ------------------------------------------------------------------------------------------------------
-// Row-major walk list: what a lane needs when its sample moves to the next cell, in ONE 32-byte element.  begin / eff_end /
-// heavy are properties of the staged fragment; base / aux are refreshed per interval for the cells of the window.
+// Row-major walk list: what a lane needs when its sample moves to the next cell, in ONE 32-byte element.  eff_end / heavy are
+// properties of the staged fragment; the rest is refreshed per interval for the cells of the window and stamped with the
+// interval's epoch (a cell outside the window keeps the stamp of an earlier interval: it is dead for every record of this one).
 struct __attribute__((aligned(16))) WalkCell {
-  int64_t begin;
   int64_t eff_end;
-  uint64_t aux;     // plain cell: bitmask of the record types it has slots for; heavy cell: its first record (k_lo)
-  uint32_t base;    // plain cell: first slot (relative to light_base); heavy cell: first incidence in fill order
-  uint32_t heavy;
+  uint64_t aux;     // plain cell: bitmask of the record types it has slots for; heavy cell: unused
+  int32_t k_lo, k_hi;   // records the cell is live in (k_lo < 0: none)
+  uint32_t base;    // plain cell: first slot (relative to light_base); heavy cell: first slot of its calls (relative to heavy_base; record k: base + k - k_lo)
+  uint32_t flags;   // bit 0: heavy; bits 8..31: epoch of the interval that filled k_lo / k_hi / base / aux
 };
-__global__ void k_walk_static(const int64_t* perm, const int64_t* rm_begin, const int64_t* eff_end, const uint32_t* cflags, int64_t C, WalkCell* walk, int64_t* inv) {
+constexpr uint32_t kWalkHeavy = 1u;
+__global__ void k_walk_static(const int64_t* perm, const int64_t* eff_end, const uint32_t* cflags, int64_t C, WalkCell* walk, int64_t* inv) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= C) return;
   const int64_t c = perm[j];
   WalkCell w;
-  w.begin = rm_begin[j]; w.eff_end = eff_end[c]; w.aux = 0; w.base = 0; w.heavy = (cflags[c] & GDB_CF_HEAVY) ? 1u : 0u;
+  w.eff_end = eff_end[c]; w.aux = 0; w.k_lo = -1; w.k_hi = -1; w.base = 0; w.flags = (cflags[c] & GDB_CF_HEAVY) ? kWalkHeavy : 0u;
   walk[j] = w;
   inv[c] = j;
 }
-__global__ void k_walk_window(const int64_t* inv, const uint32_t* cflags, const int64_t* hoff, const int32_t* k_lo, const uint32_t* tbase, const uint64_t* tmask,
-                              int64_t c_base, int64_t n, WalkCell* walk) {
+__global__ void k_walk_window(const int64_t* inv, const uint32_t* cflags, const int64_t* hoff, const int32_t* k_lo, const int32_t* k_hi, const uint32_t* tbase, const uint64_t* tmask,
+                              int64_t c_base, int64_t n, uint32_t epoch, WalkCell* walk) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int64_t c = c_base + i;
   WalkCell* w = walk + inv[c];
-  if (cflags[c] & GDB_CF_HEAVY) { w->base = (uint32_t)hoff[i]; w->aux = (uint64_t)(int64_t)k_lo[c]; }
-  else { w->base = tbase[i]; w->aux = tmask[i]; }
+  const bool heavy = (cflags[c] & GDB_CF_HEAVY) != 0;
+  const uint4 tail = make_uint4((uint32_t)k_lo[c], (uint32_t)k_hi[c], heavy ? (uint32_t)hoff[i] : tbase[i], (epoch << 8) | (heavy ? kWalkHeavy : 0u));
+  w->aux = heavy ? 0ull : tmask[i];
+  *reinterpret_cast<uint4*>(&w->k_lo) = tail;
 }
 
 struct AsmCtx {
@@ -1210,7 +1232,6 @@ struct AsmCtx {
   const uint32_t* prefix_len; // [P] bytes of the fixed columns of a record (chunk 0 starts behind them)
   const uint2* desc;        // [S] (off16, len)
   const char* pool;
-  const uint32_t* inc_pos;  // [T]  fill order -> (record,row) order
   const uint32_t* ubase;    // [P]  rank of a record among those with an untabled type
   uint32_t light_base, heavy_base, row_base;
   int32_t nrows;
@@ -1222,11 +1243,12 @@ struct SlotWalker {
   int64_t j, j_end, next_begin, cur_end;
   uint64_t aux;
   uint32_t base;
+  int32_t k_lo;
   bool heavy;
   __device__ __forceinline__ void load(const AsmCtx& a) {
     const WalkCell w = a.walk[j];
-    next_begin = (j + 1 < j_end) ? a.walk[j + 1].begin : INT64_MAX;
-    cur_end = w.eff_end; aux = w.aux; base = w.base; heavy = w.heavy != 0;
+    next_begin = (j + 1 < j_end) ? a.rm_begin[j + 1] : INT64_MAX;
+    cur_end = w.eff_end; aux = w.aux; base = w.base; k_lo = w.k_lo; heavy = (w.flags & kWalkHeavy) != 0;
   }
   __device__ __forceinline__ void init(const AsmCtx& a, int32_t row, int64_t s0) {
     const int64_t j_begin = a.row_ptr[row];
@@ -1235,13 +1257,13 @@ struct SlotWalker {
     while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a.rm_begin[mid] <= s0) lo = mid + 1; else hi = mid; }
     j = lo - 1;
     if (j >= j_begin) load(a);
-    else { cur_end = INT64_MIN; heavy = false; aux = 0; base = 0; next_begin = (j + 1 < j_end) ? a.rm_begin[j + 1] : INT64_MAX; }
+    else { cur_end = INT64_MIN; heavy = false; aux = 0; base = 0; k_lo = 0; next_begin = (j + 1 < j_end) ? a.rm_begin[j + 1] : INT64_MAX; }
   }
   __device__ __forceinline__ void advance(const AsmCtx& a, int64_t s) { while (next_begin <= s) { ++j; load(a); } }
   // (a cell that ended before the window keeps stale base/aux, but it is dead for every record of the window)
   __device__ __forceinline__ uint32_t slot(const AsmCtx& a, int64_t k, int64_t s, uint32_t t, int32_t row) const {
     const bool dead = s > cur_end;
-    if (!dead && heavy) return a.heavy_base + a.inc_pos[base + (uint32_t)(k - (int64_t)aux)];
+    if (!dead && heavy) return a.heavy_base + base + (uint32_t)(k - (int64_t)k_lo);
     if (t == kUntabledType) return a.row_base + a.ubase[k] * (uint32_t)a.nrows + (uint32_t)row;
     if (dead) return t;
     return a.light_base + base + (uint32_t)__popcll(aux & ((1ull << t) - 1ull));
@@ -1469,6 +1491,295 @@ k_assemble_write(const char* __restrict__ pool, const char* __restrict__ pool_ov
         cp.finish();
         // One wavefront per workgroup: the LDS unit runs its instructions in order, so the image only needs a compiler-level
         // fence (wavefront scope emits no s_waitcnt: outstanding matrix loads and page stores keep flying across records).
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        const char* img = lds_buf + al;
+        uint32_t head = (16u - al) & 15u;
+        if (head > pass_total) head = pass_total;
+        const uint32_t nwords = (pass_total - head) >> 4;
+        const uint32_t tail_at = head + (nwords << 4);
+        if ((uint32_t)lane < head) gdst[lane] = img[lane];
+        const uint4* lsrc = reinterpret_cast<const uint4*>(img + head);
+        uint4* gw = reinterpret_cast<uint4*>(gdst + head);
+        for (uint32_t wq = lane; wq < nwords; wq += kAsmRows) gw[wq] = lsrc[wq];
+        if ((uint32_t)lane < pass_total - tail_at) gdst[tail_at + lane] = img[tail_at + lane];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        l0 = l1;
+        base_off += pass_total;
+      }
+    }
+  }
+}
+
+// ---- matrix-free sizing and page assembly (text output) -------------------------------------------------------------------------
+// The (record, sample) matrix of the kernels above costs 8 bytes per pair twice (written by the sizing pass, read back by the page
+// pass: 2 x 8.2 GB per 1 Mb window of 1 000 samples) and a sizing pass that touches every pair.  Neither is needed:
+//  * a sample's entry changes only where its live cell (or the gap between two cells) changes: a PIECE.  Along a run of same-type
+//    records a lane keeps `valid_until`, the last record its present entry holds for; the common step is one compare.
+//  * record sizes are sums over pieces, not over pairs: k_size2 adds every piece's length as a +/- pair into a difference array
+//    over the type-ordered records of a block (LDS) and scans it - O(cells x types met), not O(records x samples).
+//  * the page pass (k_write2) walks the pieces itself; a slot's text and its length arrive together (the slot's tag, kSlotTagAt).
+struct PieceCtx {
+  const int64_t* row_ptr;     // [N+1] row-major ranges
+  const int64_t* rm_begin;    // [C]   begin column in row-major order
+  const WalkCell* walk;       // [C]
+  const int64_t* rec_start;   // [P]
+  const uint8_t* rtype;       // [P]
+  const uint32_t* ubase;      // [P]   rank of a record among those with an untabled type
+  const uint32_t* occ;        // [kMaxTypes][P+1]  records of a type before k (rows share one scan: only differences inside a row mean something)
+  const uint32_t* slot_len;   // [S]
+  const uint32_t* prefix_len; // [P]
+  uint32_t light_base, heavy_base, row_base, epoch;
+  int32_t nrows;
+  int64_t P;
+};
+struct PieceWalker {
+  int64_t j, j_end;          // walk[j] is the cell held in nxt (j >= j_end: none left)
+  int32_t valid_until;       // last record the lane's present slot holds for
+  int32_t cur_klo, cur_khi;  // the cell the sample is in, if k <= cur_khi
+  uint32_t cur_slot;         // plain cell: its slot for the run's type; heavy cell: the slot of record cur_klo
+  uint32_t cur_heavy;
+  // raw copy of walk[j], requested when the walker moved into walk[j - 1]: it has arrived long before it is looked at
+  int32_t nxt_klo, nxt_khi; uint32_t nxt_base, nxt_flags; uint64_t nxt_aux;
+  __device__ __forceinline__ void request(const PieceCtx& a) {
+    if (j < j_end) {
+      const WalkCell* w = a.walk + j;
+      const uint4 tail = *reinterpret_cast<const uint4*>(&w->k_lo);
+      nxt_aux = w->aux; nxt_klo = (int32_t)tail.x; nxt_khi = (int32_t)tail.y; nxt_base = tail.z; nxt_flags = tail.w;
+    } else { nxt_aux = 0; nxt_klo = INT32_MAX; nxt_khi = INT32_MAX; nxt_base = 0; nxt_flags = a.epoch << 8; }
+  }
+  // s0 = start of the first record the lane will be asked about
+  __device__ __forceinline__ void init(const PieceCtx& a, int32_t row, int64_t s0) {
+    const int64_t j_begin = a.row_ptr[row];
+    j_end = a.row_ptr[row + 1];
+    int64_t lo = j_begin, hi = j_end;                            // last cell with begin <= s0: the only one that can be live there
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a.rm_begin[mid] <= s0) lo = mid + 1; else hi = mid; }
+    j = lo - 1;
+    const bool found = j >= j_begin;
+    if (!found) j = j_begin;
+    valid_until = INT32_MIN; cur_klo = 0; cur_khi = -1; cur_slot = 0; cur_heavy = 0;
+    request(a);
+    // a cell that begins before the window (stale stamp) cannot reach it; every cell behind it begins inside or behind the window
+    if (found && (nxt_flags >> 8) != a.epoch) { ++j; request(a); }
+  }
+  // slot of (row, record k of type t); k > valid_until on entry, k does not decrease between calls
+  __device__ __forceinline__ uint32_t move(const PieceCtx& a, int32_t k, uint32_t t, int32_t row) {
+    const bool tabled = t != kUntabledType;
+    for (;;) {
+      if (k <= cur_khi) break;                                   // inside the cell entered below (or a heavy cell's next record)
+      if ((nxt_flags >> 8) != a.epoch) { nxt_klo = INT32_MAX; nxt_khi = INT32_MAX; nxt_flags = a.epoch << 8; }   // begins behind the window: nothing further is live
+      if (nxt_klo < 0) { ++j; request(a); continue; }            // in the window, but live in no record
+      if (k < nxt_klo) {                                         // between two cells: the type's no-call entry
+        valid_until = tabled ? nxt_klo - 1 : k;
+        return tabled ? t : a.row_base + a.ubase[k] * (uint32_t)a.nrows + (uint32_t)row;
+      }
+      cur_klo = nxt_klo; cur_khi = nxt_khi; cur_heavy = nxt_flags & kWalkHeavy;
+      cur_slot = cur_heavy ? a.heavy_base + nxt_base : a.light_base + nxt_base + (uint32_t)__popcll(nxt_aux & (tabled ? (1ull << t) - 1ull : 0ull));
+      ++j; request(a);
+    }
+    if (cur_heavy) { valid_until = k; return cur_slot + (uint32_t)(k - cur_klo); }
+    if (!tabled) { valid_until = k; return a.row_base + a.ubase[k] * (uint32_t)a.nrows + (uint32_t)row; }
+    valid_until = cur_khi;
+    return cur_slot;
+  }
+};
+
+// Sizing: one wavefront = kSizeBlock consecutive records x 64 samples.  Inside the block the records are ranked by (type, index)
+// (position p = adj[t] + occ[t][k]); a plain cell's slot for type t holds for the type-t records of [k_lo, k_hi], a contiguous
+// range of positions: +len - nocall at its first, -(len - nocall) behind its last.  Heavy calls and the samples of untabled
+// records have a slot per record.  Every record starts from (#samples of the chunk) x (no-call length of its type).
+constexpr int kSizeBlock = 1024;
+__global__ void __launch_bounds__(kAsmRows)
+k_size2(PieceCtx a, int nchunks, uint64_t* __restrict__ chunk_size) {
+  __shared__ uint32_t diff[kSizeBlock + 2];
+  __shared__ int32_t adj[kMaxTypes + 1];
+  __shared__ uint32_t nolen[kMaxTypes + 1];
+  const int lane = threadIdx.x;
+  const int64_t sub = blockIdx.x / (unsigned)nchunks;
+  const int ch = (int)(blockIdx.x % (unsigned)nchunks);
+  const int64_t k0 = sub * kSizeBlock, k1 = min(a.P, k0 + (int64_t)kSizeBlock);
+  const int nrec = (int)(k1 - k0);
+  for (int i = lane; i < kSizeBlock + 2; i += kAsmRows) diff[i] = 0;
+  {
+    const uint32_t* row = a.occ + (int64_t)lane * (a.P + 1);     // (kMaxTypes == 64 lanes: lane t counts type t)
+    const uint32_t o0 = row[k0], cnt = row[k1] - o0;
+    const uint32_t incl = wave_inclusive_scan_dpp(cnt);
+    adj[lane] = (int32_t)(incl - cnt) - (int32_t)o0;
+    nolen[lane] = a.slot_len[lane];
+    if (lane == 63) { adj[kMaxTypes] = (int32_t)incl - (int32_t)a.ubase[k0]; nolen[kMaxTypes] = 0; }   // untabled records rank behind the tabled ones
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  const int32_t r = ch * kAsmRows + lane;
+  if (r < a.nrows) {
+    const int64_t j_begin = a.row_ptr[r], j_end = a.row_ptr[r + 1];
+    const int64_t s0 = a.rec_start[k0];
+    int64_t lo = j_begin, hi = j_end;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a.rm_begin[mid] <= s0) lo = mid + 1; else hi = mid; }
+    int64_t j = lo - 1;
+    bool may_be_stale = j >= j_begin;                            // (the cell found may begin before the window: skipped, see PieceWalker::init)
+    if (!may_be_stale) j = j_begin;
+    for (; j < j_end; ++j) {
+      const WalkCell* wp = a.walk + j;
+      const uint4 tail = *reinterpret_cast<const uint4*>(&wp->k_lo);
+      const int32_t klo = (int32_t)tail.x, khi = (int32_t)tail.y;
+      const bool stale = (tail.w >> 8) != a.epoch;
+      if (stale) { if (may_be_stale) { may_be_stale = false; continue; } break; }
+      may_be_stale = false;
+      if (klo < 0) continue;
+      if ((int64_t)klo >= k1) break;
+      if ((int64_t)khi < k0) continue;
+      const int64_t ka = max((int64_t)klo, k0), kb = min((int64_t)khi, k1 - 1);
+      if (tail.w & kWalkHeavy) {
+        for (int64_t k = ka; k <= kb; ++k) {
+          const uint32_t t = a.rtype[k];
+          const uint32_t tt = t == kUntabledType ? (uint32_t)kMaxTypes : t;
+          const uint32_t d = a.slot_len[a.heavy_base + tail.z + (uint32_t)(k - klo)] - nolen[tt];
+          const uint32_t p = (uint32_t)(adj[tt] + (int32_t)(t == kUntabledType ? a.ubase[k] : a.occ[(int64_t)t * (a.P + 1) + k]));
+          atomicAdd(&diff[p], d); atomicAdd(&diff[p + 1], 0u - d);
+        }
+      } else {
+        uint64_t m = wp->aux;
+        uint32_t sl = a.light_base + tail.z;
+        while (m) {
+          const int t = __builtin_ctzll(m);
+          m &= m - 1;
+          const uint32_t d = a.slot_len[sl++] - nolen[t];
+          const uint32_t* row = a.occ + (int64_t)t * (a.P + 1);
+          const uint32_t pa = (uint32_t)(adj[t] + (int32_t)row[ka]), pb = (uint32_t)(adj[t] + (int32_t)row[kb + 1]);
+          atomicAdd(&diff[pa], d); atomicAdd(&diff[pb], 0u - d);
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  uint32_t carry = 0;
+  for (int b = 0; b < nrec; b += kAsmRows) {                     // uniform
+    const uint32_t v = diff[b + lane];
+    const uint32_t incl = wave_inclusive_scan_dpp(v) + carry;
+    diff[b + lane] = incl;
+    carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  const uint32_t rows_here = (uint32_t)min(kAsmRows, a.nrows - ch * kAsmRows);
+  for (int i = lane; i < nrec; i += kAsmRows) {
+    const int64_t k = k0 + i;
+    const uint32_t t = a.rtype[k];
+    uint64_t size;
+    if (t != kUntabledType) size = (uint64_t)diff[adj[t] + (int32_t)a.occ[(int64_t)t * (a.P + 1) + k]] + (uint64_t)rows_here * nolen[t];
+    else {
+      size = diff[adj[kMaxTypes] + (int32_t)a.ubase[k]];
+      const uint32_t* rl = a.slot_len + a.row_base + (uint64_t)a.ubase[k] * (uint32_t)a.nrows + (uint32_t)(ch * kAsmRows);
+      for (uint32_t q = 0; q < rows_here; ++q) size += rl[q];    // (the slot of a sample with a heavy call here is empty)
+    }
+    if (ch == 0) size += a.prefix_len[k];
+    if (ch == nchunks - 1) size += 1;                            // '\n'
+    chunk_size[k * nchunks + ch] = size;
+  }
+}
+
+// Page assembly without the matrix: k_assemble_write's image / flush loop, fed by a PieceWalker per lane.
+template <int WAVES, int kWaveLds> __global__ void __launch_bounds__(kAsmRows * WAVES)
+k_write2(PieceCtx a, const char* __restrict__ pool, const char* __restrict__ pool_ovf, const int32_t* __restrict__ order, int64_t n, int nchunks, int run,
+         const uint64_t* __restrict__ chunk_off, uint64_t page_base, char* __restrict__ arena, int xcd_aware) {
+  const int64_t unit = xcd_aware_unit<WAVES>(((n + run - 1) / run) * (int64_t)nchunks, xcd_aware);
+  if (unit < 0) return;
+  const int64_t ib = (unit / nchunks) * run;
+  const int64_t ie = min(n, ib + (int64_t)run);
+  const int ch = (int)(unit % nchunks);
+  const int lane = threadIdx.x & 63;
+  const int32_t r = ch * kAsmRows + lane;
+  const bool has_row = r < a.nrows;
+  __shared__ __attribute__((aligned(16))) char lds_all[WAVES][kWaveLds + 16 + kScrapBytes];
+  char* const lds_buf = &lds_all[threadIdx.x >> 6][0];
+  const char* cur_src = pool;
+  uint32_t cur_len = 0;
+  SlotText txt;
+#pragma unroll
+  for (int q = 0; q < kTextChunks; ++q) txt.x[q] = make_uint4(0, 0, 0, 0);
+  PieceWalker w;
+  w.j = 0; w.j_end = 0; w.valid_until = INT32_MAX; w.cur_klo = 0; w.cur_khi = -1; w.cur_slot = 0; w.cur_heavy = 0;
+  w.nxt_klo = INT32_MAX; w.nxt_khi = INT32_MAX; w.nxt_base = 0; w.nxt_flags = 0; w.nxt_aux = 0;
+  uint32_t prev_t = 0xFFFFFFFFu;
+  for (int64_t i0 = ib; i0 < ie; i0 += 64) {                // uniform
+    const int cnt = (int)min((int64_t)64, ie - i0);
+    int32_t my_k = 0; int64_t my_dst = 0; uint32_t my_t = 0;
+    if (lane < cnt) {
+      my_k = order[i0 + lane];
+      my_t = a.rtype[my_k];
+      my_dst = (int64_t)(chunk_off[(int64_t)my_k * nchunks + ch] - page_base) + (ch == 0 ? a.prefix_len[my_k] : 0u);
+    }
+    for (int jj = 0; jj < cnt; ++jj) {                      // uniform
+      const int32_t k = __builtin_amdgcn_readlane(my_k, jj);
+      const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)my_t, jj);
+      if (t != prev_t) {                                    // uniform: the run starts, or its records change type
+        prev_t = t;
+        if (has_row) w.init(a, r, a.rec_start[k]);
+      }
+      if (has_row && k > w.valid_until) {                   // the sample's entry changes here: name the slot, fetch its line
+        const uint32_t sl = w.move(a, k, t, r);
+        const char* src = pool + (size_t)sl * kSlotStride;
+#pragma unroll
+        for (int q = 0; q < kTextChunks; ++q) txt.x[q] = *reinterpret_cast<const uint4*>(src + (q << 4));
+        const uint32_t where = txt.x[kTextChunks - 1].z;
+        cur_len = txt.x[kTextChunks - 1].w;
+        if (where & kOverflowBit) {                         // longer than an inline slot: the text lies in the overflow pool
+          src = pool_ovf + (size_t)(where & ~kOverflowBit) * 16;
+#pragma unroll
+          for (int q = 0; q < kTextChunks; ++q) txt.x[q] = load_chunk(src, q, cur_len);
+        }
+        cur_src = src;
+      }
+      const uint32_t len = cur_len;
+      const uint32_t inc = wave_inclusive_scan_dpp(len);
+      const uint32_t excl = inc - len;
+      const uint32_t total = wave_total(inc);
+      if (total == 0) continue;                             // uniform: no FORMAT columns in this record
+      char* const grec = arena + readlane64(my_dst, jj);
+      uint32_t l0 = 0, base_off = 0;
+      while (base_off < total) {                            // uniform
+        char* gdst = grec + base_off;
+        const uint32_t al = (uint32_t)((uintptr_t)gdst & 15u);
+        const bool fits = (uint32_t)lane >= l0 && al + (inc - base_off) <= (uint32_t)kWaveLds;
+        const uint64_t fit_mask = __ballot(fits) >> l0;     // inc is non-decreasing: the fitting lanes are a run starting at l0
+        const uint32_t len_l0 = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)(l0 < 64u ? l0 : 63u));
+        if (!(fit_mask & 1ull) || len_l0 > (uint32_t)kCooperativeEntry) {   // a long text (or one that exceeds the image): the whole wavefront copies it
+          const char* big_src = (const char*)(uintptr_t)readlane64((int64_t)(uintptr_t)cur_src, (int)l0);   // (pool slots are 16-byte aligned)
+          const uint32_t big_len = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)l0);
+          uint32_t head = (16u - al) & 15u;                 // bytes up to the first 16-byte boundary of the destination
+          if (head > big_len) head = big_len;
+          if ((uint32_t)lane < head) gdst[lane] = big_src[lane];
+          const uint32_t nwords = (big_len - head) >> 4;
+          uint4* gw = reinterpret_cast<uint4*>(gdst + head);
+          for (uint32_t wq = lane; wq < nwords; wq += kAsmRows) {   // aligned 16-byte stores, source words assembled from two aligned loads
+            const char* sp = big_src + head + ((size_t)wq << 4);
+            const uint4 lo = *reinterpret_cast<const uint4*>((uintptr_t)sp & ~(uintptr_t)15);
+            const uint4 hi = *reinterpret_cast<const uint4*>(((uintptr_t)sp & ~(uintptr_t)15) + 16);
+            const uint32_t sh = (uint32_t)((uintptr_t)sp & 15u);
+            const uint32_t ww[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            uint32_t o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const uint32_t x = ww[(sh >> 2) + q], y = ww[(sh >> 2) + q + 1 < 8 ? (sh >> 2) + q + 1 : 7];
+              o[q] = __builtin_amdgcn_alignbyte(y, x, sh & 3u);
+            }
+            gw[wq] = make_uint4(o[0], o[1], o[2], o[3]);
+          }
+          const uint32_t tail_at = head + (nwords << 4);
+          if ((uint32_t)lane < big_len - tail_at) gdst[tail_at + lane] = big_src[tail_at + lane];
+          base_off = (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)l0);
+          ++l0;
+          continue;
+        }
+        const uint32_t nfit = fit_mask == ~0ull ? 64u - l0 : (uint32_t)__builtin_ctzll(~fit_mask);
+        const uint32_t l1 = l0 + nfit;
+        const uint32_t pass_total = (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)(l1 - 1)) - base_off;
+        const bool mine = (uint32_t)lane >= l0 && (uint32_t)lane < l1;
+        SlotCopy cp;
+        cp.begin((gdb_lds_char*)lds_buf + al + (excl - base_off), mine ? len : 0u, (gdb_lds_char*)lds_buf + kWaveLds + 16 + 4 * lane);
+        cp.chunk(0, txt.x[0]);
+#pragma unroll
+        for (int q = 1; q < kTextChunks; ++q) if (__any((int)cp.needs(q))) cp.chunk(q, txt.x[q]);
+        for (uint32_t q = kTextChunks; __any((int)cp.needs(q)); ++q) cp.chunk(q, load_chunk(cur_src, q, mine ? len : 0u));
+        cp.finish();
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         const char* img = lds_buf + al;
         uint32_t head = (16u - al) & 15u;
@@ -2667,6 +2978,7 @@ struct DevicePipeline::Impl {
   // entry text table
   DevBuf<unsigned long long> type_hkeys; DevBuf<int32_t> type_hrep, type_rep; DevBuf<uint8_t> type_hid, rtype;
   DevBuf<WalkCell> walk; DevBuf<int64_t> walk_inv;
+  uint32_t walk_epoch = 0;           // stamp of the interval whose cells the walk list describes (24 bits; 0: none yet)
   // cell-stream staging (append_cells)
   DevBuf<uint8_t> raw_cells; DevBuf<uint64_t> raw_off; DevBuf<int32_t> raw_row_map, raw_qrow; DevBuf<uint32_t> raw_keep, raw_dest, raw_len, raw_voff, raw_mark, raw_mdest;
   DevBuf<int64_t> raw_begin, raw_end;
@@ -2678,7 +2990,7 @@ struct DevicePipeline::Impl {
   DevBuf<uint2> resolved;          // (pool offset, length) of every (record, sample): whole interval, or one page when that exceeds the budget
   DevBuf<uint32_t> type_occ;
   DevBuf<uint32_t> untabled, ubase; DevBuf<int32_t> urec, iota, order; DevBuf<uint32_t> order_keys, order_keys_sorted;
-  DevBuf<uint64_t> tmask; DevBuf<uint32_t> nslots, tbase, inc_pos, slot_len, slot_units, slot_off; DevBuf<uint2> slot_desc; DevBuf<char> pool, pool_ovf;
+  DevBuf<uint64_t> tmask; DevBuf<uint32_t> nslots, tbase, slot_len, slot_units, slot_off; DevBuf<uint2> slot_desc; DevBuf<char> pool, pool_ovf;
   bool classified = false;
   struct Part { FragmentView v; std::vector<size_t> data_bytes; std::vector<void*> bufs; };
   std::vector<Part> parts;
@@ -2692,8 +3004,8 @@ struct DevicePipeline::Impl {
     float write_kernel_ms = 0;
     std::vector<uint64_t> rec_off;
     IntervalStats stats;
-    SiteCtx sx; EntryCtx ex; RowIndex ri; SiteOut so; RecordTable rec; AsmCtx ac;
-    bool resolved_whole = false;
+    SiteCtx sx; EntryCtx ex; RowIndex ri; SiteOut so; RecordTable rec; AsmCtx ac; PieceCtx pc2;
+    bool resolved_whole = false, piece_path = false;
     bool bcf = false; int bcf_F = 0; BcfLayout lay{nullptr, nullptr, nullptr, nullptr};
     bool events = false; int evrun = 0; EventBuf eb{nullptr, nullptr, nullptr, 0};
   } iv;
@@ -3983,7 +4295,8 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
     }
     S.walk.ensure(C); S.walk_inv.ensure(C);
     STAGE("k_walk_static");
-    hipLaunchKernelGGL(k_walk_static, dim3(blocks_for(C)), dim3(kBlock), 0, st, S.perm.p, S.rm_begin.p, S.eff_end.p, S.cflags.p, C, S.walk.p, S.walk_inv.p);
+    hipLaunchKernelGGL(k_walk_static, dim3(blocks_for(C)), dim3(kBlock), 0, st, S.perm.p, S.eff_end.p, S.cflags.p, C, S.walk.p, S.walk_inv.p);
+    S.walk_epoch = 0;
     S.max_span = S.read_back(S.span_max.p);
     S.classified = true;
   }
@@ -4281,8 +4594,6 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   if (UR > 0) hipLaunchKernelGGL(k_untabled_records, dim3(blocks_for(P)), dim3(kBlock), 0, st, S.untabled.p, S.ubase.p, P, S.urec.p);
   const uint64_t NS = (uint64_t)kMaxTypes + SL + (uint64_t)T + (uint64_t)UR * (uint64_t)N;
   if (NS >= (1ull << 32)) throw GenomicsDBDeviceException("entry text table exceeds 2^32 slots: split the query interval");
-  S.inc_pos.ensure(T + 1);
-  if (T > 0) hipLaunchKernelGGL(k_inc_pos, dim3(blocks_for(T)), dim3(kBlock), 0, st, S.inc_keys_sorted.p, S.inc_vals_sorted.p, S.hoff.p, S.k_lo.p, c_base, T, (int64_t)N, S.inc_pos.p);
   S.slot_len.ensure(NS + 1); S.slot_units.ensure(NS + 1); S.slot_off.ensure(NS + 1); S.slot_desc.ensure(NS + 1);
   if (NS * (uint64_t)(kSlotStride / 16) >= (uint64_t)kOverflowBit) throw GenomicsDBDeviceException("entry text table exceeds 32 GiB: split the query interval");
   S.pool.ensure((size_t)NS * kSlotStride + 64);
@@ -4297,7 +4608,8 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   auto shard_units_of = [&](size_t cap_bytes) { return (uint32_t)std::min<uint64_t>((uint64_t)(cap_bytes > 64 ? (cap_bytes - 64) / 16 : 0) / kBumpShards, ((uint64_t)kOverflowBit - 1) / kBumpShards); };
   if (wide) S.pool_ovf.ensure(std::max<size_t>((size_t)kBumpShards * ((size_t)S.pool_ovf_need * 16 + ((size_t)S.pool_ovf_need * 16 >> 3)), (size_t)1 << 20) + 64);
   SlotTable stt{S.slot_len.p, S.slot_off.p, S.pool.p, S.pool_ovf.p, (uint32_t)kMaxTypes, (uint32_t)(kMaxTypes + SL), (uint32_t)(kMaxTypes + SL + (uint64_t)T), S.slot_off.p, S.slot_bump.p,
-                wide ? shard_units_of(S.pool_ovf.cap) : 0u, (int32_t)S.ctx_slot, pl.bcf_mode};
+                wide ? shard_units_of(S.pool_ovf.cap) : 0u, (int32_t)S.ctx_slot, pl.bcf_mode, pl.bcf_mode ? (uint32_t)kSlotStride : (uint32_t)kInlineText,
+                (const int64_t*)S.hoff.p, (const int32_t*)S.k_lo.p, c_base};
   STAGE("k_slots<0>");
 #define GDB_SLOT_KERNELS(PASSN, W) do { \
   hipLaunchKernelGGL((k_slots_nocall<PASSN, W>), dim3(1), dim3(kMaxTypes), 0, st, stt, so, S.type_rep.p, ntypes, S.err.p); \
@@ -4334,7 +4646,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
         if (keep) HIP_CHECK(hipMemcpyAsync(np + (size_t)sh * su * 16, S.pool_ovf.p + (size_t)sh * old_su * 16, keep, hipMemcpyDeviceToDevice, st));
       }
       if (old_su) {   // the texts pass 0 placed move with their shard: their descriptors follow
-        hipLaunchKernelGGL(k_slot_rebase, dim3(blocks_for((int64_t)NS)), dim3(kBlock), 0, st, (const uint32_t*)S.slot_len.p, S.slot_off.p, (int64_t)NS, old_su, (uint32_t)su);
+        hipLaunchKernelGGL(k_slot_rebase, dim3(blocks_for((int64_t)NS)), dim3(kBlock), 0, st, (const uint32_t*)S.slot_len.p, S.slot_off.p, (int64_t)NS, old_su, (uint32_t)su, stt.inline_max);
       }
       HIP_CHECK(hipStreamSynchronize(st));
       if (S.pool_ovf.p) (void)hipFree(S.pool_ovf.p);
@@ -4345,7 +4657,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
     STAGE("k_slots<1>");
     GDB_SLOT_KERNELS(1, kStripWords);
   } else if (left_texts > 0) {
-    hipLaunchKernelGGL(k_slot_units, dim3(blocks_for((int64_t)NS)), dim3(kBlock), 0, st, S.slot_len.p, (int64_t)NS, S.slot_units.p);
+    hipLaunchKernelGGL(k_slot_units, dim3(blocks_for((int64_t)NS)), dim3(kBlock), 0, st, S.slot_len.p, (int64_t)NS, S.slot_units.p, stt.inline_max);
     S.excl_scan(S.slot_units.p, S.slot_off.p, (size_t)NS);
     pool_units = (uint64_t)S.read_back_sum(S.slot_off.p + (NS - 1), S.slot_units.p + (NS - 1));
     if (pool_units >= (uint64_t)kOverflowBit) throw GenomicsDBDeviceException("entry text overflow pool exceeds 32 GiB: split the query interval");
@@ -4358,23 +4670,31 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
 #undef GDB_SLOT_KERNELS
   S.long_texts_seen = long_texts * 16 > NS;    // the wide strip of pass 0 pays when a sixteenth of the texts is long
   S.pool_ovf_need = std::max<uint64_t>(S.pool_ovf_need, shard_need);   // (units per shard)
-  hipLaunchKernelGGL(k_slot_desc, dim3(blocks_for((int64_t)NS)), dim3(kBlock), 0, st, S.slot_len.p, S.slot_off.p, (int64_t)NS, S.slot_desc.p);
+  const bool piece_path = !pl.bcf_mode && !matrix_forced() && !events_enabled();   // matrix-free sizing + page assembly
+  hipLaunchKernelGGL(k_slot_desc, dim3(blocks_for((int64_t)NS)), dim3(kBlock), 0, st, S.slot_len.p, S.slot_off.p, (int64_t)NS, piece_path ? (uint2*)nullptr : S.slot_desc.p,
+                     pl.bcf_mode ? (char*)nullptr : S.pool.p, stt.inline_max);
   stats.num_record_types = ntypes;
   stats.num_text_slots = (int64_t)NS;
   stats.text_pool_bytes = (int64_t)(NS * kSlotStride + pool_units * 16);
   STAGE("k_walk_window");
-  hipLaunchKernelGGL(k_walk_window, dim3(blocks_for(CW)), dim3(kBlock), 0, st, S.walk_inv.p, S.cflags.p, S.hoff.p, S.k_lo.p, S.tbase.p, S.tmask.p, c_base, CW, S.walk.p);
-  AsmCtx ac{S.row_ptr.p, S.rm_begin.p, S.walk.p, S.rstart.p, S.rtype.p, S.prefix_len.p, S.slot_desc.p, S.pool.p, S.inc_pos.p, S.ubase.p,
+  if (++S.walk_epoch >= (1u << 24)) {   // the stamp wrapped: wipe the old ones
+    hipLaunchKernelGGL(k_walk_static, dim3(blocks_for(C)), dim3(kBlock), 0, st, S.perm.p, S.eff_end.p, S.cflags.p, C, S.walk.p, S.walk_inv.p);
+    S.walk_epoch = 1;
+  }
+  hipLaunchKernelGGL(k_walk_window, dim3(blocks_for(CW)), dim3(kBlock), 0, st, S.walk_inv.p, S.cflags.p, S.hoff.p, S.k_lo.p, S.k_hi.p, S.tbase.p, S.tmask.p, c_base, CW, S.walk_epoch, S.walk.p);
+  AsmCtx ac{S.row_ptr.p, S.rm_begin.p, S.walk.p, S.rstart.p, S.rtype.p, S.prefix_len.p, S.slot_desc.p, S.pool.p, S.ubase.p,
             (uint32_t)kMaxTypes, (uint32_t)(kMaxTypes + SL), (uint32_t)(kMaxTypes + SL + (uint64_t)T), N};
+  PieceCtx pc2{S.row_ptr.p, S.rm_begin.p, S.walk.p, S.rstart.p, S.rtype.p, S.ubase.p, S.type_occ.p, S.slot_len.p, S.prefix_len.p,
+               (uint32_t)kMaxTypes, (uint32_t)(kMaxTypes + SL), (uint32_t)(kMaxTypes + SL + (uint64_t)T), S.walk_epoch, N, P};
   // ---- S8b sample-column sizes + offsets ---------------------------------------------------------------------------
   const int run = size_run_length();
   const unsigned run_blocks = (unsigned)((P + run - 1) / run);
   STAGE("k_assemble_size");
-  S.order_by_type(0, P);
+  if (!piece_path) S.order_by_type(0, P);
   const uint64_t resolved_bytes = (uint64_t)P * nchunks * kAsmRows * sizeof(uint2);
   bool use_events = false;
   EventBuf ebuf{nullptr, nullptr, nullptr, 0};
-  const bool resolved_whole = pl.bcf_mode || (resolved_bytes <= resolved_budget_bytes() && !(events_enabled() && ((1 << order_block_log2()) % event_run_length()) == 0));
+  const bool resolved_whole = !piece_path && (pl.bcf_mode || (resolved_bytes <= resolved_budget_bytes() && !(events_enabled() && ((1 << order_block_log2()) % event_run_length()) == 0)));
   if (resolved_whole) S.resolved.ensure((size_t)P * nchunks * kAsmRows);
   S.max_record.ensure(1);
   HIP_CHECK(hipMemsetAsync(S.max_record.p, 0, sizeof(unsigned long long), st));
@@ -4406,6 +4726,10 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
     S.order_iv.ensure((size_t)P);
     HIP_CHECK(hipMemcpyAsync(S.order_iv.p, S.order.p, (size_t)P * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     S.order_iv_valid = true;
+  } else if (piece_path) {
+    const uint64_t units = (uint64_t)((P + kSizeBlock - 1) / kSizeBlock) * (uint64_t)nchunks;
+    if (units >= (1ull << 31)) throw GenomicsDBDeviceException("more than 2^31 (record block, sample chunk) units in one interval: split the query interval");
+    hipLaunchKernelGGL(k_size2, dim3((unsigned)units), dim3(kAsmRows), 0, st, pc2, nchunks, S.chunk_size.p);
   } else
   hipLaunchKernelGGL(k_assemble_size, dim3(run_blocks * (unsigned)nchunks), dim3(kAsmRows), 0, st, ac, S.order.p, P, N, nchunks, run, S.chunk_size.p,
                      resolved_whole ? S.resolved.p : nullptr, (int64_t)0);
@@ -4430,7 +4754,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   if (eb) throw GenomicsDBDeviceException(err_bits_text(eb));
   S.iv.max_record_bytes = totals[1];
   S.iv.P = P; S.iv.nchunks = nchunks; S.iv.kp = 0;
-  S.iv.sx = sx; S.iv.ex = ex; S.iv.ri = ri; S.iv.so = so; S.iv.rec = rec; S.iv.ac = ac; S.iv.resolved_whole = resolved_whole;
+  S.iv.sx = sx; S.iv.ex = ex; S.iv.ri = ri; S.iv.so = so; S.iv.rec = rec; S.iv.ac = ac; S.iv.pc2 = pc2; S.iv.piece_path = piece_path; S.iv.resolved_whole = resolved_whole;
   S.iv.bcf = pl.bcf_mode != 0; S.iv.bcf_F = bcf_F; S.iv.lay = lay;
   S.iv.events = use_events; S.iv.evrun = ebuf.run; S.iv.eb = ebuf;
   S.iv.active = true;
@@ -4524,10 +4848,28 @@ bool DevicePipeline::begin_page(uint64_t arena_bytes, int arena_idx, PageTicket*
       return true;
     }
   }
-  const int wrun = write_run_length();
+  const int wrun = iv.piece_path ? write2_run_length() : write_run_length();
   S.order_by_type(kp, np);
   const unsigned wruns = (unsigned)((np + wrun - 1) / wrun);
   const dim3 wgrid(wruns * (unsigned)iv.nchunks);
+  if (iv.piece_path) {
+    HIP_CHECK(hipEventRecord(w[1], st));
+#define GDB_LAUNCH_WRITE2(W, L) hipLaunchKernelGGL((k_write2<W, L>), dim3((wgrid.x + (W) - 1u) / (W)), dim3(kAsmRows * (W)), 0, st, iv.pc2, (const char*)S.pool.p, (const char*)S.pool_ovf.p, \
+    (const int32_t*)S.order.p, np, iv.nchunks, wrun, (const uint64_t*)S.chunk_off.p, page_base, arena, xcd_aware_numbering() ? 1 : 0)
+    const int ww = write_waves_per_group(), wl = write_image_kb();
+    if (ww >= 4 && wl <= 4) GDB_LAUNCH_WRITE2(4, 4096);
+    else if (ww >= 4) GDB_LAUNCH_WRITE2(4, 8192);
+    else if (wl <= 4) GDB_LAUNCH_WRITE2(1, 4096);
+    else if (wl <= 6) GDB_LAUNCH_WRITE2(1, 6144);
+    else GDB_LAUNCH_WRITE2(1, 8192);
+#undef GDB_LAUNCH_WRITE2
+    HIP_CHECK(hipEventRecord(w[2], st));
+    HIP_CHECK(hipMemcpyAsync(&S.hb->page_err[ai], S.err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipEventRecord(w[3], st));
+    iv.kp = ke;
+    ticket->arena = ai; ticket->dev = arena; ticket->nbytes = page_bytes; ticket->done_event = (void*)w[3]; S.queue_compression(ai, arena, page_bytes);
+    return true;
+  }
   if (!iv.resolved_whole) {   // the interval's matrix exceeded the budget: resolve this page's records now
     S.resolved.ensure((size_t)np * iv.nchunks * kAsmRows);
     hipLaunchKernelGGL(k_assemble_size, wgrid, dim3(kAsmRows), 0, st, iv.ac, S.order.p, np, N, iv.nchunks, wrun, (uint64_t*)nullptr, S.resolved.p, kp);
