@@ -118,8 +118,12 @@ inline uint64_t resolved_budget_bytes() {
 inline int event_run_length() { const char* e = getenv("GDBAMD_EV_RUN"); return e && *e ? std::max(1, std::min(64, atoi(e))) : 32; }
 // (off by default: measured slower than the dense matrix, with scalar loads of the changes and with vector loads + v_readlane)
 inline bool events_enabled() { const char* e = getenv("GDBAMD_EVENTS"); return e && *e && *e != '0'; }
-// GDBAMD_MATRIX=1: text pages through the dense (record, sample) matrix of rounds 1-3 instead of the matrix-free kernels (A/B runs; BCF always uses the matrix)
-inline bool matrix_forced() { const char* e = getenv("GDBAMD_MATRIX"); return e && *e && *e != '0'; }
+// How an interval's sample columns are sized and assembled (GDBAMD_ASM_PATH, read per interval; measured in DESIGN.md section 5):
+//   0 (default)  the sizing pass of rounds 1-3 (k_assemble_size: every (record, sample) pair walked, sizes and matrix in one pass), pages by k_assemble_write
+//   1            text only: sizes from pieces (k_size2), no matrix at all, the page pass walks the pieces itself (k_write2)
+//   2            sizes from pieces (k_size2), the matrix from a piece walker per lane (k_fill2), pages by k_assemble_write / the BCF kernels
+inline int asm_path_wanted() { const char* e = getenv("GDBAMD_ASM_PATH"); return e && *e ? std::max(0, std::min(2, atoi(e))) : 0; }
+inline int fill_run_length() { const char* e = getenv("GDBAMD_RUN_F"); return e && *e ? std::max(1, atoi(e)) : 128; }
 inline int write2_run_length() { const char* e = getenv("GDBAMD_RUN_W2"); return e && *e ? std::max(1, atoi(e)) : 64; }
 // wavefronts (= neighbouring 64-sample chunks) per workgroup of the page assembly: 4 measured best on the store-only model
 inline int write_waves_per_group() { const char* e = getenv("GDBAMD_WRITE_WAVES"); return e && *e ? atoi(e) : 1; }
@@ -949,7 +953,8 @@ constexpr uint32_t kOverflowBit = 0x80000000u;     // descriptor offsets with th
 // bytes, len <= kInlineText) or kOverflowBit | 16-byte unit of the overflow pool.  The matrix-free page assembly (k_write2) needs
 // nothing but the slot number to fetch a text: the tag arrives with the slot's own cache line.  BCF entries keep all 128 bytes.
 constexpr int kSlotTagAt = kSlotStride - 8;
-constexpr int kInlineText = kSlotTagAt;
+constexpr int kText2Chunks = 8;                        // 16-byte chunks of a slot k_write2 keeps in registers (the last one holds the tag)
+constexpr int kInlineText = kSlotTagAt;                // = 120
 struct SlotTable {
   uint32_t* len;          // [S]  entry bytes incl. the leading tab; 0: the record has no FORMAT columns
   const uint32_t* ovf16;  // [S]  overflow-pool offset in 16-byte units (exclusive scan; only meaningful for len > kSlotStride)
@@ -1199,26 +1204,46 @@ struct __attribute__((aligned(16))) WalkCell {
   uint64_t aux;     // plain cell: bitmask of the record types it has slots for; heavy cell: unused
   int32_t k_lo, k_hi;   // records the cell is live in (k_lo < 0: none)
   uint32_t base;    // plain cell: first slot (relative to light_base); heavy cell: first slot of its calls (relative to heavy_base; record k: base + k - k_lo)
-  uint32_t flags;   // bit 0: heavy; bits 8..31: epoch of the interval that filled k_lo / k_hi / base / aux
+  uint32_t flags;   // bit 0: heavy; bits 1..3: 16-byte chunks that hold the longest inline text of the cell's slots (<= 7; the tag sits in the 8th);
+                    // bits 8..31: epoch of the interval that filled k_lo / k_hi / base / aux
 };
 constexpr uint32_t kWalkHeavy = 1u;
-__global__ void k_walk_static(const int64_t* perm, const int64_t* eff_end, const uint32_t* cflags, int64_t C, WalkCell* walk, int64_t* inv) {
+constexpr int kWalkChunksShift = 1;
+constexpr uint32_t kWalkChunksMask = 7u;
+// (an overflow text: only its tag is read from the slot; bytes 112 .. 119 of an inline text arrive with the tag's chunk)
+__device__ __forceinline__ uint32_t inline_chunks(uint32_t len) { return len <= (uint32_t)kInlineText ? min((len + 15u) >> 4, kWalkChunksMask) : 0u; }
+// Cell j of the row-major order (row r) sits at walk[j + r]: behind the cells of every row there is one SENTINEL element that never
+// carries an interval's stamp - a walker that runs off its row's end reads "nothing further is live" instead of checking a bound.
+__global__ void k_walk_static(const int64_t* perm, const int32_t* row, const int64_t* row_ptr, int32_t N, const int64_t* eff_end, const uint32_t* cflags, int64_t C, WalkCell* walk, int64_t* inv) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= C) return;
-  const int64_t c = perm[j];
   WalkCell w;
-  w.eff_end = eff_end[c]; w.aux = 0; w.k_lo = -1; w.k_hi = -1; w.base = 0; w.flags = (cflags[c] & GDB_CF_HEAVY) ? kWalkHeavy : 0u;
-  walk[j] = w;
-  inv[c] = j;
+  w.aux = 0; w.k_lo = -1; w.k_hi = -1; w.base = 0;
+  if (j < C) {
+    const int64_t c = perm[j];
+    const int64_t at = j + row[c];
+    w.eff_end = eff_end[c]; w.flags = (cflags[c] & GDB_CF_HEAVY) ? kWalkHeavy : 0u;
+    walk[at] = w;
+    inv[c] = at;
+  } else if (j < C + N) {
+    const int64_t r = j - C;
+    w.eff_end = INT64_MIN; w.flags = 0;
+    walk[row_ptr[r + 1] + r] = w;
+  }
 }
 __global__ void k_walk_window(const int64_t* inv, const uint32_t* cflags, const int64_t* hoff, const int32_t* k_lo, const int32_t* k_hi, const uint32_t* tbase, const uint64_t* tmask,
-                              int64_t c_base, int64_t n, uint32_t epoch, WalkCell* walk) {
+                              const uint32_t* slot_len, uint32_t light_base, uint32_t heavy_base, int64_t c_base, int64_t n, uint32_t epoch, WalkCell* walk) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int64_t c = c_base + i;
   WalkCell* w = walk + inv[c];
   const bool heavy = (cflags[c] & GDB_CF_HEAVY) != 0;
-  const uint4 tail = make_uint4((uint32_t)k_lo[c], (uint32_t)k_hi[c], heavy ? (uint32_t)hoff[i] : tbase[i], (epoch << 8) | (heavy ? kWalkHeavy : 0u));
+  uint32_t chunks = 0;
+  if (k_lo[c] >= 0) {
+    const uint32_t first = heavy ? heavy_base + (uint32_t)hoff[i] : light_base + tbase[i];
+    const uint32_t cnt = heavy ? (uint32_t)(k_hi[c] - k_lo[c] + 1) : (uint32_t)__popcll(tmask[i]);
+    for (uint32_t q = 0; q < cnt; ++q) chunks = max(chunks, inline_chunks(slot_len[first + q]));
+  }
+  const uint4 tail = make_uint4((uint32_t)k_lo[c], (uint32_t)k_hi[c], heavy ? (uint32_t)hoff[i] : tbase[i], (epoch << 8) | (chunks << kWalkChunksShift) | (heavy ? kWalkHeavy : 0u));
   w->aux = heavy ? 0ull : tmask[i];
   *reinterpret_cast<uint4*>(&w->k_lo) = tail;
 }
@@ -1243,14 +1268,15 @@ struct SlotWalker {
   int64_t j, j_end, next_begin, cur_end;
   uint64_t aux;
   uint32_t base;
-  int32_t k_lo;
+  int32_t k_lo, row_;
   bool heavy;
   __device__ __forceinline__ void load(const AsmCtx& a) {
-    const WalkCell w = a.walk[j];
+    const WalkCell w = a.walk[j + row_];
     next_begin = (j + 1 < j_end) ? a.rm_begin[j + 1] : INT64_MAX;
     cur_end = w.eff_end; aux = w.aux; base = w.base; k_lo = w.k_lo; heavy = (w.flags & kWalkHeavy) != 0;
   }
   __device__ __forceinline__ void init(const AsmCtx& a, int32_t row, int64_t s0) {
+    row_ = row;
     const int64_t j_begin = a.row_ptr[row];
     j_end = a.row_ptr[row + 1];
     int64_t lo = j_begin, hi = j_end;  // last j with rm_begin[j] <= s0
@@ -1497,11 +1523,15 @@ k_assemble_write(const char* __restrict__ pool, const char* __restrict__ pool_ov
         if (head > pass_total) head = pass_total;
         const uint32_t nwords = (pass_total - head) >> 4;
         const uint32_t tail_at = head + (nwords << 4);
-        if ((uint32_t)lane < head) gdst[lane] = img[lane];
         const uint4* lsrc = reinterpret_cast<const uint4*>(img + head);
         uint4* gw = reinterpret_cast<uint4*>(gdst + head);
         for (uint32_t wq = lane; wq < nwords; wq += kAsmRows) gw[wq] = lsrc[wq];
-        if ((uint32_t)lane < pass_total - tail_at) gdst[tail_at + lane] = img[tail_at + lane];
+        {   // the bytes in front of the first and behind the last 16-byte word in ONE store instruction: lanes 0-15 head, 16-31 tail
+          const uint32_t li = (uint32_t)lane & 15u;
+          const bool is_tail = (lane & 16) != 0;
+          const uint32_t at = is_tail ? tail_at + li : li;
+          if (lane < 32 && li < (is_tail ? pass_total - tail_at : head)) gdst[at] = img[at];
+        }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         l0 = l1;
         base_off += pass_total;
@@ -1528,58 +1558,71 @@ struct PieceCtx {
   const uint32_t* occ;        // [kMaxTypes][P+1]  records of a type before k (rows share one scan: only differences inside a row mean something)
   const uint32_t* slot_len;   // [S]
   const uint32_t* prefix_len; // [P]
+  int32_t* jhint;             // [ceil(P / kHintStep)][N]  first cell of a row (relative to row_ptr) that can be live at or behind record h * kHintStep: left by
+                              // k_size2, which walks every row once anyway; the page pass starts a run there instead of searching the row
   uint32_t light_base, heavy_base, row_base, epoch;
   int32_t nrows;
   int64_t P;
 };
+constexpr int kHintStep = 256;
 struct PieceWalker {
-  int64_t j, j_end;          // walk[j] is the cell held in nxt (j >= j_end: none left)
+  // W = the cell the walker stands at (walk[j]); Wn = walk[j + 1], requested when the walker moved on to W: it has arrived long
+  // before it is looked at.  x = k_lo, y = k_hi, w = flags; W.z = the cell's slot for the run's record type (heavy: of record k_lo),
+  // Wn.z = base.  `next` = the cell behind Wn.
+  const WalkCell* next;
   int32_t valid_until;       // last record the lane's present slot holds for
-  int32_t cur_klo, cur_khi;  // the cell the sample is in, if k <= cur_khi
-  uint32_t cur_slot;         // plain cell: its slot for the run's type; heavy cell: the slot of record cur_klo
-  uint32_t cur_heavy;
-  // raw copy of walk[j], requested when the walker moved into walk[j - 1]: it has arrived long before it is looked at
-  int32_t nxt_klo, nxt_khi; uint32_t nxt_base, nxt_flags; uint64_t nxt_aux;
-  __device__ __forceinline__ void request(const PieceCtx& a) {
-    if (j < j_end) {
-      const WalkCell* w = a.walk + j;
-      const uint4 tail = *reinterpret_cast<const uint4*>(&w->k_lo);
-      nxt_aux = w->aux; nxt_klo = (int32_t)tail.x; nxt_khi = (int32_t)tail.y; nxt_base = tail.z; nxt_flags = tail.w;
-    } else { nxt_aux = 0; nxt_klo = INT32_MAX; nxt_khi = INT32_MAX; nxt_base = 0; nxt_flags = a.epoch << 8; }
+  u32x4 W, Wn; uint64_t Wnaux;
+  __device__ __forceinline__ void request(const PieceCtx& a) {   // Wn <- *next (no wait here; behind the row's cells lies its sentinel)
+    Wn = *reinterpret_cast<const u32x4*>(&next->k_lo); Wnaux = next->aux;
+    ++next;
   }
-  // s0 = start of the first record the lane will be asked about
-  __device__ __forceinline__ void init(const PieceCtx& a, int32_t row, int64_t s0) {
-    const int64_t j_begin = a.row_ptr[row];
-    j_end = a.row_ptr[row + 1];
-    int64_t lo = j_begin, hi = j_end;                            // last cell with begin <= s0: the only one that can be live there
-    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a.rm_begin[mid] <= s0) lo = mid + 1; else hi = mid; }
-    j = lo - 1;
-    const bool found = j >= j_begin;
-    if (!found) j = j_begin;
-    valid_until = INT32_MIN; cur_klo = 0; cur_khi = -1; cur_slot = 0; cur_heavy = 0;
+  // W <- Wn, then the cell behind it is requested WITHOUT a wait.  Real moves, pinned in front of the loads: left to itself the
+  // compiler renames instead - W takes over Wn's registers, the new Wn is loaded somewhere else and copied back at the end of the
+  // block, behind an s_waitcnt vmcnt(0) that the copy then needs.
+  // A cell stamped by another interval begins behind the window (the hint never points in front of it): nothing further is live.
+  __device__ __forceinline__ void advance(const PieceCtx& a, uint64_t below) {
+    uint32_t wx, wy, wz, ww, alo, ahi;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(wx) : "v"(Wn.x));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(wy) : "v"(Wn.y));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(wz) : "v"(Wn.z));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(ww) : "v"(Wn.w));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(alo) : "v"((uint32_t)Wnaux));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(ahi) : "v"((uint32_t)(Wnaux >> 32)));
+    __builtin_amdgcn_sched_barrier(0);
     request(a);
-    // a cell that begins before the window (stale stamp) cannot reach it; every cell behind it begins inside or behind the window
-    if (found && (nxt_flags >> 8) != a.epoch) { ++j; request(a); }
+    const bool fresh = (ww >> 8) == a.epoch;
+    W.x = fresh ? wx : (uint32_t)INT32_MAX; W.y = fresh ? wy : (uint32_t)INT32_MAX; W.w = ww;
+    W.z = (ww & kWalkHeavy) ? a.heavy_base + wz : a.light_base + wz + (uint32_t)__popc(alo & (uint32_t)below) + (uint32_t)__popc(ahi & (uint32_t)(below >> 32));
   }
-  // slot of (row, record k of type t); k > valid_until on entry, k does not decrease between calls
-  __device__ __forceinline__ uint32_t move(const PieceCtx& a, int32_t k, uint32_t t, int32_t row) {
+  // k = the first record the lane will be asked about: every cell in front of the hinted one is dead from record (k / kHintStep) * kHintStep on
+  __device__ __forceinline__ void init(const PieceCtx& a, int32_t row, int32_t k, uint64_t below) {
+    next = a.walk + (a.row_ptr[row] + row + (int64_t)a.jhint[(int64_t)(k / kHintStep) * a.nrows + row]);
+    valid_until = INT32_MIN;
+    request(a);
+    advance(a, below);   // (reads what was requested: the wait for it stays here, in the rare block)
+    asm volatile("; Wn has arrived" : : "v"(Wn.x), "v"(Wn.w), "v"((uint32_t)Wnaux), "v"((uint32_t)(Wnaux >> 32)));   // ... and so does the wait for the second request
+  }
+  __device__ __forceinline__ bool behind(int32_t k) const { return k > (int32_t)W.y || (int32_t)W.x < 0; }   // W ended before k, or is live in no record
+  // slot of (row, record k of type t); k > valid_until on entry, k does not decrease between calls.
+  // The vector-memory counter of gfx9 is one in-order queue of loads AND stores: a wait for anything waits for the page stores of
+  // the previous record too.  So the first advance is peeled out of the loop: what it reads (Wn) was requested a whole piece ago
+  // and has been waited for together with that piece's text - the compiler puts no s_waitcnt in front of it; only the rare
+  // further steps (a cell passed over: nothing of the run's type inside it) wait for the request they have just made.
+  // nq: 16-byte chunks of the slot that hold its text if it is an inline one
+  __device__ __forceinline__ uint32_t move(const PieceCtx& a, int32_t k, uint32_t t, uint64_t below, int32_t row, uint32_t nocall_chunks, uint32_t& nq) {
     const bool tabled = t != kUntabledType;
-    for (;;) {
-      if (k <= cur_khi) break;                                   // inside the cell entered below (or a heavy cell's next record)
-      if ((nxt_flags >> 8) != a.epoch) { nxt_klo = INT32_MAX; nxt_khi = INT32_MAX; nxt_flags = a.epoch << 8; }   // begins behind the window: nothing further is live
-      if (nxt_klo < 0) { ++j; request(a); continue; }            // in the window, but live in no record
-      if (k < nxt_klo) {                                         // between two cells: the type's no-call entry
-        valid_until = tabled ? nxt_klo - 1 : k;
-        return tabled ? t : a.row_base + a.ubase[k] * (uint32_t)a.nrows + (uint32_t)row;
-      }
-      cur_klo = nxt_klo; cur_khi = nxt_khi; cur_heavy = nxt_flags & kWalkHeavy;
-      cur_slot = cur_heavy ? a.heavy_base + nxt_base : a.light_base + nxt_base + (uint32_t)__popcll(nxt_aux & (tabled ? (1ull << t) - 1ull : 0ull));
-      ++j; request(a);
+    if (behind(k)) {
+      advance(a, below);
+      while (behind(k)) advance(a, below);
     }
-    if (cur_heavy) { valid_until = k; return cur_slot + (uint32_t)(k - cur_klo); }
-    if (!tabled) { valid_until = k; return a.row_base + a.ubase[k] * (uint32_t)a.nrows + (uint32_t)row; }
-    valid_until = cur_khi;
-    return cur_slot;
+    const bool heavy = (W.w & kWalkHeavy) != 0, inside = k >= (int32_t)W.x;
+    nq = (W.w >> kWalkChunksShift) & kWalkChunksMask;
+    if (!tabled) valid_until = k;                                // records of untabled types: one slot per (record, sample)
+    else if (!inside) { valid_until = (int32_t)W.x - 1; nq = nocall_chunks; return t; }   // between two cells: the type's no-call entry
+    else valid_until = heavy ? k : (int32_t)W.y;
+    if (inside && heavy) return W.z + (uint32_t)(k - (int32_t)W.x);
+    if (!tabled) { nq = kWalkChunksMask; return a.row_base + a.ubase[k] * (uint32_t)a.nrows + (uint32_t)row; }
+    return W.z;
   }
 };
 
@@ -1594,8 +1637,10 @@ k_size2(PieceCtx a, int nchunks, uint64_t* __restrict__ chunk_size) {
   __shared__ int32_t adj[kMaxTypes + 1];
   __shared__ uint32_t nolen[kMaxTypes + 1];
   const int lane = threadIdx.x;
-  const int64_t sub = blockIdx.x / (unsigned)nchunks;
-  const int ch = (int)(blockIdx.x % (unsigned)nchunks);
+  // the chunk wavefronts of a record block read the same lines of `occ`: keep them on one XCD (one L2), next to each other in time
+  const int64_t unit = xcd_aware_unit<1>((int64_t)gridDim.x);
+  const int64_t sub = unit / nchunks;
+  const int ch = (int)(unit % nchunks);
   const int64_t k0 = sub * kSizeBlock, k1 = min(a.P, k0 + (int64_t)kSizeBlock);
   const int nrec = (int)(k1 - k0);
   for (int i = lane; i < kSizeBlock + 2; i += kAsmRows) diff[i] = 0;
@@ -1615,16 +1660,18 @@ k_size2(PieceCtx a, int nchunks, uint64_t* __restrict__ chunk_size) {
     int64_t lo = j_begin, hi = j_end;
     while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a.rm_begin[mid] <= s0) lo = mid + 1; else hi = mid; }
     int64_t j = lo - 1;
-    bool may_be_stale = j >= j_begin;                            // (the cell found may begin before the window: skipped, see PieceWalker::init)
-    if (!may_be_stale) j = j_begin;
+    bool may_be_stale = j >= j_begin;                            // (the cell found may begin before the window - stale stamp -: it cannot reach it; every
+    if (!may_be_stale) j = j_begin;                              //  cell behind it begins inside or behind the window)
+    int64_t hint_k = k0;                                         // next record a hint is due for
     for (; j < j_end; ++j) {
-      const WalkCell* wp = a.walk + j;
+      const WalkCell* wp = a.walk + j + r;
       const uint4 tail = *reinterpret_cast<const uint4*>(&wp->k_lo);
       const int32_t klo = (int32_t)tail.x, khi = (int32_t)tail.y;
       const bool stale = (tail.w >> 8) != a.epoch;
       if (stale) { if (may_be_stale) { may_be_stale = false; continue; } break; }
       may_be_stale = false;
       if (klo < 0) continue;
+      for (; hint_k <= (int64_t)khi && hint_k < k1; hint_k += kHintStep) a.jhint[(hint_k / kHintStep) * a.nrows + r] = (int32_t)(j - j_begin);
       if ((int64_t)klo >= k1) break;
       if ((int64_t)khi < k0) continue;
       const int64_t ka = max((int64_t)klo, k0), kb = min((int64_t)khi, k1 - 1);
@@ -1649,6 +1696,7 @@ k_size2(PieceCtx a, int nchunks, uint64_t* __restrict__ chunk_size) {
         }
       }
     }
+    for (; hint_k < k1; hint_k += kHintStep) a.jhint[(hint_k / kHintStep) * a.nrows + r] = (int32_t)(j - j_begin);   // (nothing live further on: the cell the walk stopped at)
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   uint32_t carry = 0;
@@ -1676,11 +1724,70 @@ k_size2(PieceCtx a, int nchunks, uint64_t* __restrict__ chunk_size) {
   }
 }
 
+// The (record, sample) matrix for k_assemble_write / the BCF kernels, from a PieceWalker per lane: what k_assemble_size leaves, at half
+// its instructions per step (the kernels of this file are bound by the instructions they issue: ~4.4 cycles of a SIMD each) - one
+// compare where nothing changes, no position arithmetic, no incidence look-up, no scan (the sizes come from k_size2).  The descriptor
+// of a lane that changes at record jj + 1 is requested during step jj and taken at the head of step jj + 1.
+__global__ void __launch_bounds__(kAsmRows)
+k_fill2(PieceCtx a, const uint2* __restrict__ desc, const int32_t* __restrict__ order, int64_t n, int nchunks, int run, uint2* __restrict__ resolved, int64_t resolved_base) {
+  const int64_t unit = xcd_aware_unit<1>(((n + run - 1) / run) * (int64_t)nchunks);
+  if (unit < 0) return;
+  const int64_t ib = (unit / nchunks) * run;
+  const int64_t ie = min(n, ib + (int64_t)run);
+  const int ch = (int)(unit % nchunks);
+  const int lane = threadIdx.x;
+  const int32_t r = ch * kAsmRows + lane;
+  const bool has_row = r < a.nrows;
+  PieceWalker w;
+  w.next = a.walk; w.valid_until = INT32_MAX; w.W = u32x4{0, 0, 0, 0}; w.Wn = u32x4{0, 0, 0, 0}; w.Wnaux = 0;
+  uint64_t below = 0;
+  uint32_t prev_t = 0xFFFFFFFFu;
+  uint2 cur = make_uint2(0, 0), nxt = make_uint2(0, 0);
+  bool changed = false;
+  auto request = [&](int32_t k, uint32_t t) {
+    if (t != prev_t) {                                      // uniform: the run starts, or its records change type
+      prev_t = t;
+      below = t != kUntabledType ? (1ull << t) - 1ull : 0ull;
+      if (has_row) w.init(a, r, k, below);
+    }
+    changed = has_row && k > w.valid_until;
+    if (changed) { uint32_t nq; nxt = desc[w.move(a, k, t, below, r, 0u, nq)]; }
+  };
+  for (int64_t i0 = ib; i0 < ie; i0 += 64) {                // uniform
+    const int cnt = (int)min((int64_t)64, ie - i0);
+    int32_t my_k = 0; uint32_t my_t = 0;
+    if (lane < cnt) { my_k = order[i0 + lane]; my_t = a.rtype[my_k]; }
+    request(__builtin_amdgcn_readlane(my_k, 0), (uint32_t)__builtin_amdgcn_readlane((int)my_t, 0));
+    for (int jj = 0; jj < cnt; ++jj) {                      // uniform
+      if (changed) cur = nxt;
+      const int64_t k = __builtin_amdgcn_readlane(my_k, jj);
+      uint2* const row = resolved + ((k - resolved_base) * nchunks + ch) * kAsmRows;
+      if (jj + 1 < cnt) request(__builtin_amdgcn_readlane(my_k, jj + 1), (uint32_t)__builtin_amdgcn_readlane((int)my_t, jj + 1));
+      else changed = false;
+      row[lane] = cur;
+    }
+  }
+}
+
+// 16 bytes into the registers the lane's text already lives in, as an instruction the compiler does not know to be a load: left to
+// itself it gives a text requested ahead (below) registers of its own next to the text still in use - 181 instead of 97 for the
+// kernel, two wavefronts per SIMD instead of four.  The price: the compiler does not wait for these loads either; text_arrived()
+// does, and ties the wait to the registers so that nothing that reads them can be moved in front of it.
+template <int OFF> __device__ __forceinline__ void load16_in_place(u32x4& d, const char* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2 ; in-place text" : "+v"(d) : "v"(p), "n"(OFF) : "memory");   // (the marker: tests/tools/check_inplace_loads.py)
+}
+template <int N> struct TextRegs { u32x4 x[N]; };
+__device__ __forceinline__ void text_arrived() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ uint4 as_uint4(const u32x4& v) { return make_uint4(v.x, v.y, v.z, v.w); }
 // Page assembly without the matrix: k_assemble_write's image / flush loop, fed by a PieceWalker per lane.
 template <int WAVES, int kWaveLds> __global__ void __launch_bounds__(kAsmRows * WAVES)
 k_write2(PieceCtx a, const char* __restrict__ pool, const char* __restrict__ pool_ovf, const int32_t* __restrict__ order, int64_t n, int nchunks, int run,
          const uint64_t* __restrict__ chunk_off, uint64_t page_base, char* __restrict__ arena, int xcd_aware) {
-  const int64_t unit = xcd_aware_unit<WAVES>(((n + run - 1) / run) * (int64_t)nchunks, xcd_aware);
+  const int dbg = xcd_aware >> 1;                            // timing experiments only (GDBAMD_W2_DBG): 1 = no walk behind a run's first record, 2 = slots are named but not fetched, 32 = no request ahead
+  const int64_t unit = xcd_aware_unit<WAVES>(((n + run - 1) / run) * (int64_t)nchunks, xcd_aware & 1);
   if (unit < 0) return;
   const int64_t ib = (unit / nchunks) * run;
   const int64_t ie = min(n, ib + (int64_t)run);
@@ -1690,15 +1797,65 @@ k_write2(PieceCtx a, const char* __restrict__ pool, const char* __restrict__ poo
   const bool has_row = r < a.nrows;
   __shared__ __attribute__((aligned(16))) char lds_all[WAVES][kWaveLds + 16 + kScrapBytes];
   char* const lds_buf = &lds_all[threadIdx.x >> 6][0];
-  const char* cur_src = pool;
-  uint32_t cur_len = 0;
-  SlotText txt;
+  uint32_t cur_where = 0, cur_len = 0;                      // the tag of the lane's present slot (an inline text is wholly in txt)
+  TextRegs<kText2Chunks> txt;
 #pragma unroll
-  for (int q = 0; q < kTextChunks; ++q) txt.x[q] = make_uint4(0, 0, 0, 0);
+  for (int q = 0; q < kText2Chunks; ++q) txt.x[q] = u32x4{0, 0, 0, 0};
   PieceWalker w;
-  w.j = 0; w.j_end = 0; w.valid_until = INT32_MAX; w.cur_klo = 0; w.cur_khi = -1; w.cur_slot = 0; w.cur_heavy = 0;
-  w.nxt_klo = INT32_MAX; w.nxt_khi = INT32_MAX; w.nxt_base = 0; w.nxt_flags = 0; w.nxt_aux = 0;
-  uint32_t prev_t = 0xFFFFFFFFu;
+  w.next = a.walk; w.valid_until = INT32_MAX; w.W = u32x4{0, 0, 0, 0}; w.Wn = u32x4{0, 0, 0, 0}; w.Wnaux = 0;
+  uint64_t below = 0;                                       // record types in front of the run's one (bit mask: a plain cell's slot = its base + how many of them it meets)
+  uint32_t prev_t = 0xFFFFFFFFu, nocall_chunks = 0;
+  uint64_t pending = 0;                                     // lanes that have asked for a slot's line and not looked at it yet
+  // A step has two halves.  REQUEST (record jj): samples whose entry changes there name their slot and ask for its line - nothing
+  // waits.  TAKE + build + flush: the tags are read (here the loads are waited for), the image is built and written.  The request
+  // for record jj + 1 is made between the build and the flush of record jj: the texts of the lanes that change are dead once the
+  // image stands, and the random-access latency of the new ones (what this kernel would otherwise sit out on nearly every
+  // record: ~1.6 us against 2.5 us for everything else in the step) passes while the image is flushed.
+  auto request = [&](int32_t k, uint32_t t) {
+    if (t != prev_t) {                                      // uniform: the run starts, or its records change type
+      prev_t = t;
+      nocall_chunks = t != kUntabledType ? inline_chunks(a.slot_len[t]) : 0u;
+      below = t != kUntabledType ? (1ull << t) - 1ull : 0ull;
+      if (has_row) w.init(a, r, k, below);
+    }
+    const bool need = has_row && k > w.valid_until && !((dbg & 2) && w.valid_until != INT32_MIN);
+    if (need) {                                             // the sample's entry changes here: name the slot, ask for its tag and text
+      uint32_t nq;
+      const uint32_t sl = w.move(a, k, t, below, r, nocall_chunks, nq);
+      if (dbg & 1) w.valid_until = INT32_MAX;
+      const char* src = pool + (size_t)((dbg & 64) && w.valid_until != INT32_MIN && cur_len ? t : sl) * kSlotStride;   // (64: every later fetch reads the type's no-call slot: a line that is always in the cache)
+      // (the kernel is bound by the instructions it issues: four chunks without asking, the other three behind one test - not a test per chunk)
+      load16_in_place<112>(txt.x[7], src);
+      load16_in_place<0>(txt.x[0], src);
+      load16_in_place<16>(txt.x[1], src);
+      load16_in_place<32>(txt.x[2], src);
+      load16_in_place<48>(txt.x[3], src);
+      if (nq > 4u) {
+        load16_in_place<64>(txt.x[4], src);
+        load16_in_place<80>(txt.x[5], src);
+        load16_in_place<96>(txt.x[6], src);
+      }
+    }
+    pending = __ballot(need);
+  };
+  // the image of one pass (<= kWaveLds bytes of a record's chunk, with the destination's alignment) -> page
+  auto flush = [&](char* gdst, uint32_t al, uint32_t pass_total) {
+    const char* img = lds_buf + al;
+    uint32_t head = (16u - al) & 15u;
+    if (head > pass_total) head = pass_total;
+    const uint32_t nwords = (pass_total - head) >> 4;
+    const uint32_t tail_at = head + (nwords << 4);
+    const uint4* lsrc = reinterpret_cast<const uint4*>(img + head);
+    uint4* gw = reinterpret_cast<uint4*>(gdst + head);
+    for (uint32_t wq = lane; wq < nwords; wq += kAsmRows) gw[wq] = lsrc[wq];
+    {   // the bytes in front of the first and behind the last 16-byte word in ONE store instruction: lanes 0-15 head, 16-31 tail
+      const uint32_t li = (uint32_t)lane & 15u;
+      const bool is_tail = (lane & 16) != 0;
+      const uint32_t at = is_tail ? tail_at + li : li;
+      if (lane < 32 && li < (is_tail ? pass_total - tail_at : head)) gdst[at] = img[at];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  };
   for (int64_t i0 = ib; i0 < ie; i0 += 64) {                // uniform
     const int cnt = (int)min((int64_t)64, ie - i0);
     int32_t my_k = 0; int64_t my_dst = 0; uint32_t my_t = 0;
@@ -1707,42 +1864,41 @@ k_write2(PieceCtx a, const char* __restrict__ pool, const char* __restrict__ poo
       my_t = a.rtype[my_k];
       my_dst = (int64_t)(chunk_off[(int64_t)my_k * nchunks + ch] - page_base) + (ch == 0 ? a.prefix_len[my_k] : 0u);
     }
+    request(__builtin_amdgcn_readlane(my_k, 0), (uint32_t)__builtin_amdgcn_readlane((int)my_t, 0));
     for (int jj = 0; jj < cnt; ++jj) {                      // uniform
-      const int32_t k = __builtin_amdgcn_readlane(my_k, jj);
-      const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)my_t, jj);
-      if (t != prev_t) {                                    // uniform: the run starts, or its records change type
-        prev_t = t;
-        if (has_row) w.init(a, r, a.rec_start[k]);
-      }
-      if (has_row && k > w.valid_until) {                   // the sample's entry changes here: name the slot, fetch its line
-        const uint32_t sl = w.move(a, k, t, r);
-        const char* src = pool + (size_t)sl * kSlotStride;
+      if (pending) {                                        // uniform
+        text_arrived();
+        if (((pending >> lane) & 1ull) && !((dbg & 64) && cur_len)) {   // take the tag
+          cur_where = txt.x[kText2Chunks - 1].z;
+          cur_len = txt.x[kText2Chunks - 1].w;
+          if (cur_where & kOverflowBit) {                   // longer than an inline slot: the text lies in the overflow pool
+            const char* src = pool_ovf + (size_t)(cur_where & ~kOverflowBit) * 16;
 #pragma unroll
-        for (int q = 0; q < kTextChunks; ++q) txt.x[q] = *reinterpret_cast<const uint4*>(src + (q << 4));
-        const uint32_t where = txt.x[kTextChunks - 1].z;
-        cur_len = txt.x[kTextChunks - 1].w;
-        if (where & kOverflowBit) {                         // longer than an inline slot: the text lies in the overflow pool
-          src = pool_ovf + (size_t)(where & ~kOverflowBit) * 16;
-#pragma unroll
-          for (int q = 0; q < kTextChunks; ++q) txt.x[q] = load_chunk(src, q, cur_len);
+            for (int q = 0; q < kText2Chunks; ++q) { const uint4 v = load_chunk(src, q, cur_len); txt.x[q] = u32x4{v.x, v.y, v.z, v.w}; }
+          }
         }
-        cur_src = src;
+        pending = 0;
       }
       const uint32_t len = cur_len;
       const uint32_t inc = wave_inclusive_scan_dpp(len);
       const uint32_t excl = inc - len;
       const uint32_t total = wave_total(inc);
-      if (total == 0) continue;                             // uniform: no FORMAT columns in this record
       char* const grec = arena + readlane64(my_dst, jj);
+      // The chunk normally fits one LDS image.  Wider chunks (long PL vectors) go out in passes over consecutive lane ranges that
+      // fit; only a single entry larger than the image is copied straight from the pool.  The flush of a pass is put off until the
+      // next one is about to build (the image is about to be overwritten) or, for the last one, until the next record's request is out.
       uint32_t l0 = 0, base_off = 0;
+      bool built = false;
+      char* f_dst = grec; uint32_t f_al = 0, f_total = 0;
       while (base_off < total) {                            // uniform
+        if (built) { flush(f_dst, f_al, f_total); built = false; }
         char* gdst = grec + base_off;
         const uint32_t al = (uint32_t)((uintptr_t)gdst & 15u);
         const bool fits = (uint32_t)lane >= l0 && al + (inc - base_off) <= (uint32_t)kWaveLds;
         const uint64_t fit_mask = __ballot(fits) >> l0;     // inc is non-decreasing: the fitting lanes are a run starting at l0
         const uint32_t len_l0 = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)(l0 < 64u ? l0 : 63u));
         if (!(fit_mask & 1ull) || len_l0 > (uint32_t)kCooperativeEntry) {   // a long text (or one that exceeds the image): the whole wavefront copies it
-          const char* big_src = (const char*)(uintptr_t)readlane64((int64_t)(uintptr_t)cur_src, (int)l0);   // (pool slots are 16-byte aligned)
+          const char* big_src = pool_ovf + (size_t)((uint32_t)__builtin_amdgcn_readlane((int)cur_where, (int)l0) & ~kOverflowBit) * 16;   // (only overflow texts are this long)
           const uint32_t big_len = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)l0);
           uint32_t head = (16u - al) & 15u;                 // bytes up to the first 16-byte boundary of the destination
           if (head > big_len) head = big_len;
@@ -1775,26 +1931,23 @@ k_write2(PieceCtx a, const char* __restrict__ pool, const char* __restrict__ poo
         const bool mine = (uint32_t)lane >= l0 && (uint32_t)lane < l1;
         SlotCopy cp;
         cp.begin((gdb_lds_char*)lds_buf + al + (excl - base_off), mine ? len : 0u, (gdb_lds_char*)lds_buf + kWaveLds + 16 + 4 * lane);
-        cp.chunk(0, txt.x[0]);
+        cp.chunk(0, as_uint4(txt.x[0]));
 #pragma unroll
-        for (int q = 1; q < kTextChunks; ++q) if (__any((int)cp.needs(q))) cp.chunk(q, txt.x[q]);
-        for (uint32_t q = kTextChunks; __any((int)cp.needs(q)); ++q) cp.chunk(q, load_chunk(cur_src, q, mine ? len : 0u));
+        for (int q = 1; q < kText2Chunks; ++q) if (__any((int)cp.needs(q))) cp.chunk(q, as_uint4(txt.x[q]));
+        if (__any((int)cp.needs(kText2Chunks))) {           // texts longer than the registers hold: overflow texts
+          const char* cur_src = pool_ovf + (size_t)(cur_where & ~kOverflowBit) * 16;
+          for (uint32_t q = kText2Chunks; __any((int)cp.needs(q)); ++q) cp.chunk(q, load_chunk(cur_src, q, mine ? len : 0u));
+        }
         cp.finish();
+        // One wavefront per workgroup: the LDS unit runs its instructions in order, so the image only needs a compiler-level
+        // fence (wavefront scope emits no s_waitcnt: outstanding loads and page stores keep flying across records).
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        const char* img = lds_buf + al;
-        uint32_t head = (16u - al) & 15u;
-        if (head > pass_total) head = pass_total;
-        const uint32_t nwords = (pass_total - head) >> 4;
-        const uint32_t tail_at = head + (nwords << 4);
-        if ((uint32_t)lane < head) gdst[lane] = img[lane];
-        const uint4* lsrc = reinterpret_cast<const uint4*>(img + head);
-        uint4* gw = reinterpret_cast<uint4*>(gdst + head);
-        for (uint32_t wq = lane; wq < nwords; wq += kAsmRows) gw[wq] = lsrc[wq];
-        if ((uint32_t)lane < pass_total - tail_at) gdst[tail_at + lane] = img[tail_at + lane];
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        built = true; f_dst = gdst; f_al = al; f_total = pass_total;
         l0 = l1;
         base_off += pass_total;
       }
+      if (jj + 1 < cnt) request(__builtin_amdgcn_readlane(my_k, jj + 1), (uint32_t)__builtin_amdgcn_readlane((int)my_t, jj + 1));
+      if (built) flush(f_dst, f_al, f_total);
     }
   }
 }
@@ -2978,6 +3131,7 @@ struct DevicePipeline::Impl {
   // entry text table
   DevBuf<unsigned long long> type_hkeys; DevBuf<int32_t> type_hrep, type_rep; DevBuf<uint8_t> type_hid, rtype;
   DevBuf<WalkCell> walk; DevBuf<int64_t> walk_inv;
+  DevBuf<int32_t> jhint;
   uint32_t walk_epoch = 0;           // stamp of the interval whose cells the walk list describes (24 bits; 0: none yet)
   // cell-stream staging (append_cells)
   DevBuf<uint8_t> raw_cells; DevBuf<uint64_t> raw_off; DevBuf<int32_t> raw_row_map, raw_qrow; DevBuf<uint32_t> raw_keep, raw_dest, raw_len, raw_voff, raw_mark, raw_mdest;
@@ -3005,7 +3159,7 @@ struct DevicePipeline::Impl {
     std::vector<uint64_t> rec_off;
     IntervalStats stats;
     SiteCtx sx; EntryCtx ex; RowIndex ri; SiteOut so; RecordTable rec; AsmCtx ac; PieceCtx pc2;
-    bool resolved_whole = false, piece_path = false;
+    bool resolved_whole = false, piece_path = false; int asm_path = 0;
     bool bcf = false; int bcf_F = 0; BcfLayout lay{nullptr, nullptr, nullptr, nullptr};
     bool events = false; int evrun = 0; EventBuf eb{nullptr, nullptr, nullptr, 0};
   } iv;
@@ -4293,9 +4447,9 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
       void* t = S.temp_storage(bytes);
       HIP_CHECK(rocprim::reduce(t, bytes, S.span.p, S.span_max.p, (int64_t)0, (size_t)C, rocprim::maximum<int64_t>(), st));
     }
-    S.walk.ensure(C); S.walk_inv.ensure(C);
+    S.walk.ensure(C + N + 2); S.walk_inv.ensure(C);
     STAGE("k_walk_static");
-    hipLaunchKernelGGL(k_walk_static, dim3(blocks_for(C)), dim3(kBlock), 0, st, S.perm.p, S.eff_end.p, S.cflags.p, C, S.walk.p, S.walk_inv.p);
+    hipLaunchKernelGGL(k_walk_static, dim3(blocks_for(C + N)), dim3(kBlock), 0, st, S.perm.p, fr.row, S.row_ptr.p, N, S.eff_end.p, S.cflags.p, C, S.walk.p, S.walk_inv.p);
     S.walk_epoch = 0;
     S.max_span = S.read_back(S.span_max.p);
     S.classified = true;
@@ -4670,7 +4824,8 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
 #undef GDB_SLOT_KERNELS
   S.long_texts_seen = long_texts * 16 > NS;    // the wide strip of pass 0 pays when a sixteenth of the texts is long
   S.pool_ovf_need = std::max<uint64_t>(S.pool_ovf_need, shard_need);   // (units per shard)
-  const bool piece_path = !pl.bcf_mode && !matrix_forced() && !events_enabled();   // matrix-free sizing + page assembly
+  const int asm_path = events_enabled() ? 0 : (pl.bcf_mode && asm_path_wanted() == 1) ? 2 : asm_path_wanted();
+  const bool piece_path = asm_path == 1;   // matrix-free page assembly
   hipLaunchKernelGGL(k_slot_desc, dim3(blocks_for((int64_t)NS)), dim3(kBlock), 0, st, S.slot_len.p, S.slot_off.p, (int64_t)NS, piece_path ? (uint2*)nullptr : S.slot_desc.p,
                      pl.bcf_mode ? (char*)nullptr : S.pool.p, stt.inline_max);
   stats.num_record_types = ntypes;
@@ -4678,13 +4833,15 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   stats.text_pool_bytes = (int64_t)(NS * kSlotStride + pool_units * 16);
   STAGE("k_walk_window");
   if (++S.walk_epoch >= (1u << 24)) {   // the stamp wrapped: wipe the old ones
-    hipLaunchKernelGGL(k_walk_static, dim3(blocks_for(C)), dim3(kBlock), 0, st, S.perm.p, S.eff_end.p, S.cflags.p, C, S.walk.p, S.walk_inv.p);
+    hipLaunchKernelGGL(k_walk_static, dim3(blocks_for(C + N)), dim3(kBlock), 0, st, S.perm.p, fr.row, S.row_ptr.p, N, S.eff_end.p, S.cflags.p, C, S.walk.p, S.walk_inv.p);
     S.walk_epoch = 1;
   }
-  hipLaunchKernelGGL(k_walk_window, dim3(blocks_for(CW)), dim3(kBlock), 0, st, S.walk_inv.p, S.cflags.p, S.hoff.p, S.k_lo.p, S.k_hi.p, S.tbase.p, S.tmask.p, c_base, CW, S.walk_epoch, S.walk.p);
+  hipLaunchKernelGGL(k_walk_window, dim3(blocks_for(CW)), dim3(kBlock), 0, st, S.walk_inv.p, S.cflags.p, S.hoff.p, S.k_lo.p, S.k_hi.p, S.tbase.p, S.tmask.p,
+                     (const uint32_t*)S.slot_len.p, (uint32_t)kMaxTypes, (uint32_t)(kMaxTypes + SL), c_base, CW, S.walk_epoch, S.walk.p);
   AsmCtx ac{S.row_ptr.p, S.rm_begin.p, S.walk.p, S.rstart.p, S.rtype.p, S.prefix_len.p, S.slot_desc.p, S.pool.p, S.ubase.p,
             (uint32_t)kMaxTypes, (uint32_t)(kMaxTypes + SL), (uint32_t)(kMaxTypes + SL + (uint64_t)T), N};
-  PieceCtx pc2{S.row_ptr.p, S.rm_begin.p, S.walk.p, S.rstart.p, S.rtype.p, S.ubase.p, S.type_occ.p, S.slot_len.p, S.prefix_len.p,
+  S.jhint.ensure((size_t)((P + kHintStep - 1) / kHintStep) * (size_t)N + 1);
+  PieceCtx pc2{S.row_ptr.p, S.rm_begin.p, S.walk.p, S.rstart.p, S.rtype.p, S.ubase.p, S.type_occ.p, S.slot_len.p, S.prefix_len.p, S.jhint.p,
                (uint32_t)kMaxTypes, (uint32_t)(kMaxTypes + SL), (uint32_t)(kMaxTypes + SL + (uint64_t)T), S.walk_epoch, N, P};
   // ---- S8b sample-column sizes + offsets ---------------------------------------------------------------------------
   const int run = size_run_length();
@@ -4700,8 +4857,16 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   HIP_CHECK(hipMemsetAsync(S.max_record.p, 0, sizeof(unsigned long long), st));
   BcfLayout lay{nullptr, nullptr, nullptr, nullptr};
   const int bcf_F = std::max(1, pl.n_format);
+  const uint64_t size2_units = (uint64_t)((P + kSizeBlock - 1) / kSizeBlock) * (uint64_t)nchunks;
+  if (asm_path != 0 && size2_units >= (1ull << 31)) throw GenomicsDBDeviceException("more than 2^31 (record block, sample chunk) units in one interval: split the query interval");
+  const int frun = fill_run_length();
+  const unsigned fill_units = (unsigned)(((P + frun - 1) / frun) * nchunks);
   if (pl.bcf_mode) {
     // BCF2: resolve the (record, sample) matrix, reduce the entries' summaries to vector length + type per (record, field), size the records
+    if (asm_path == 2) {   // (k_size2 for the walkers' starting points; its text sizes mean nothing here)
+      hipLaunchKernelGGL(k_size2, dim3((unsigned)size2_units), dim3(kAsmRows), 0, st, pc2, nchunks, S.chunk_size.p);
+      hipLaunchKernelGGL(k_fill2, dim3(fill_units), dim3(kAsmRows), 0, st, pc2, (const uint2*)S.slot_desc.p, (const int32_t*)S.order.p, P, nchunks, frun, S.resolved.p, (int64_t)0);
+    } else
     hipLaunchKernelGGL(k_assemble_size, dim3(run_blocks * (unsigned)nchunks), dim3(kAsmRows), 0, st, ac, S.order.p, P, N, nchunks, run, (uint64_t*)nullptr, S.resolved.p, (int64_t)0);
     S.bcf_part.ensure(nchunk_total * (size_t)bcf_F + 1); S.bcf_fmeta.ensure((size_t)P * bcf_F + 1); S.bcf_foff.ensure((size_t)P * bcf_F + 1); S.bcf_lindiv.ensure((size_t)P + 1);
     S.bcf_rec_size.ensure((size_t)P + 2);
@@ -4726,10 +4891,10 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
     S.order_iv.ensure((size_t)P);
     HIP_CHECK(hipMemcpyAsync(S.order_iv.p, S.order.p, (size_t)P * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     S.order_iv_valid = true;
-  } else if (piece_path) {
-    const uint64_t units = (uint64_t)((P + kSizeBlock - 1) / kSizeBlock) * (uint64_t)nchunks;
-    if (units >= (1ull << 31)) throw GenomicsDBDeviceException("more than 2^31 (record block, sample chunk) units in one interval: split the query interval");
-    hipLaunchKernelGGL(k_size2, dim3((unsigned)units), dim3(kAsmRows), 0, st, pc2, nchunks, S.chunk_size.p);
+  } else if (asm_path != 0) {
+    hipLaunchKernelGGL(k_size2, dim3((unsigned)size2_units), dim3(kAsmRows), 0, st, pc2, nchunks, S.chunk_size.p);
+    if (asm_path == 2 && resolved_whole)
+      hipLaunchKernelGGL(k_fill2, dim3(fill_units), dim3(kAsmRows), 0, st, pc2, (const uint2*)S.slot_desc.p, (const int32_t*)S.order.p, P, nchunks, frun, S.resolved.p, (int64_t)0);
   } else
   hipLaunchKernelGGL(k_assemble_size, dim3(run_blocks * (unsigned)nchunks), dim3(kAsmRows), 0, st, ac, S.order.p, P, N, nchunks, run, S.chunk_size.p,
                      resolved_whole ? S.resolved.p : nullptr, (int64_t)0);
@@ -4754,7 +4919,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   if (eb) throw GenomicsDBDeviceException(err_bits_text(eb));
   S.iv.max_record_bytes = totals[1];
   S.iv.P = P; S.iv.nchunks = nchunks; S.iv.kp = 0;
-  S.iv.sx = sx; S.iv.ex = ex; S.iv.ri = ri; S.iv.so = so; S.iv.rec = rec; S.iv.ac = ac; S.iv.pc2 = pc2; S.iv.piece_path = piece_path; S.iv.resolved_whole = resolved_whole;
+  S.iv.sx = sx; S.iv.ex = ex; S.iv.ri = ri; S.iv.so = so; S.iv.rec = rec; S.iv.ac = ac; S.iv.pc2 = pc2; S.iv.piece_path = piece_path; S.iv.asm_path = asm_path; S.iv.resolved_whole = resolved_whole;
   S.iv.bcf = pl.bcf_mode != 0; S.iv.bcf_F = bcf_F; S.iv.lay = lay;
   S.iv.events = use_events; S.iv.evrun = ebuf.run; S.iv.eb = ebuf;
   S.iv.active = true;
@@ -4855,8 +5020,9 @@ bool DevicePipeline::begin_page(uint64_t arena_bytes, int arena_idx, PageTicket*
   if (iv.piece_path) {
     HIP_CHECK(hipEventRecord(w[1], st));
 #define GDB_LAUNCH_WRITE2(W, L) hipLaunchKernelGGL((k_write2<W, L>), dim3((wgrid.x + (W) - 1u) / (W)), dim3(kAsmRows * (W)), 0, st, iv.pc2, (const char*)S.pool.p, (const char*)S.pool_ovf.p, \
-    (const int32_t*)S.order.p, np, iv.nchunks, wrun, (const uint64_t*)S.chunk_off.p, page_base, arena, xcd_aware_numbering() ? 1 : 0)
+    (const int32_t*)S.order.p, np, iv.nchunks, wrun, (const uint64_t*)S.chunk_off.p, page_base, arena, (xcd_aware_numbering() ? 1 : 0) | (w2dbg << 1))
     const int ww = write_waves_per_group(), wl = write_image_kb();
+    const int w2dbg = getenv("GDBAMD_W2_DBG") ? atoi(getenv("GDBAMD_W2_DBG")) : 0;
     if (ww >= 4 && wl <= 4) GDB_LAUNCH_WRITE2(4, 4096);
     else if (ww >= 4) GDB_LAUNCH_WRITE2(4, 8192);
     else if (wl <= 4) GDB_LAUNCH_WRITE2(1, 4096);
@@ -4872,6 +5038,11 @@ bool DevicePipeline::begin_page(uint64_t arena_bytes, int arena_idx, PageTicket*
   }
   if (!iv.resolved_whole) {   // the interval's matrix exceeded the budget: resolve this page's records now
     S.resolved.ensure((size_t)np * iv.nchunks * kAsmRows);
+    if (iv.asm_path == 2) {
+      const int frun = fill_run_length();
+      hipLaunchKernelGGL(k_fill2, dim3((unsigned)(((np + frun - 1) / frun) * iv.nchunks)), dim3(kAsmRows), 0, st, iv.pc2, (const uint2*)S.slot_desc.p, (const int32_t*)S.order.p, np, iv.nchunks, frun,
+                         S.resolved.p, kp);
+    } else
     hipLaunchKernelGGL(k_assemble_size, wgrid, dim3(kAsmRows), 0, st, iv.ac, S.order.p, np, N, iv.nchunks, wrun, (uint64_t*)nullptr, S.resolved.p, kp);
   }
   HIP_CHECK(hipEventRecord(w[1], st));   // [w1, w2] brackets the page-assembly kernel alone (its duration feeds the roofline figure)
