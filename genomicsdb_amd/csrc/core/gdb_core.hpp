@@ -239,39 +239,117 @@ template <class Sink> GDB_HD void put_i32(Sink& s, int32_t v) {
   if (v < 0) { s.put('-'); put_u32(s, 0u - (uint32_t)v); } else put_u32(s, (uint32_t)v);
 }
 
-// Float text as the goldens pin it (htslib-fork kputd flavour, see oracle/gdb_oracle_combine.hpp format_float).
-// Returns false when the value is outside the range this path reproduces exactly.
-template <class Sink> GDB_HD bool put_float(Sink& s, float f) {
-  double d = (double)f;
-  if (d == 0) { if (gdb_f2u(f) >> 31) s.put('-'); s.put('0'); return true; }
-  if (d < 0) { s.put('-'); d = -d; }
-  if (!(d >= 0.0001 && d <= 999999)) {
-    // "%g" branch: exact 6-significant-digit scientific form for 1e6 <= d < 2^63
-    if (!(d > 999999 && d < 9.2e18)) return false;
-    uint64_t I = (uint64_t)d;
-    double frac = d - (double)I;
-    int nd = 0;
-    { uint64_t t = I; while (t) { ++nd; t /= 10; } }
-    uint64_t pw = 1;
-    for (int i = 0; i < nd - 6; ++i) pw *= 10;
-    uint64_t q = I / pw, rem = I % pw, half = pw / 2;
-    bool up;
-    if (pw == 1) up = frac > 0.5 || (frac == 0.5 && (q & 1));  // exactly 6 integer digits
-    else up = rem > half || (rem == half && (frac > 0 || (q & 1)));
-    if (up) ++q;
-    int ex = nd - 1;
-    if (q >= 1000000) { q /= 10; ++ex; }
-    char dg[6];
-    for (int i = 5; i >= 0; --i) { dg[i] = (char)('0' + q % 10); q /= 10; }
-    int last = 5;
-    while (last > 0 && dg[last] == '0') --last;
+// ---- "%g" of a float, exactly --------------------------------------------------------------------------------------------------
+// htslib's kputd hands every value outside [0.0001, 999999] to printf("%g") (vcf.c / kstring.c; the oracle calls snprintf).  "%g" is
+// fully specified by the C standard: the value - here a float, i.e. exactly M * 2^e2 with M < 2^24 - is rounded to P = 6 significant
+// decimal digits (glibc rounds the EXACT value, ties to even); if the decimal exponent X of the rounded value satisfies
+// -4 <= X < P the style is fixed, else scientific with at least two exponent digits; trailing zeros of the fraction (and a
+// point with nothing behind it) are removed.  All arithmetic below is integer: a 224-bit register holds M * 10^k (k <= 50 for the
+// smallest subnormal, 2^-149 = 1.4e-45) or M * 2^e2 (e2 <= 104: 3.4e38 < 2^128).
+struct GdbBig { uint32_t w[7]; };
+GDB_HD void gdb_big_mul10(GdbBig& b) {
+  uint64_t c = 0;
+  for (int i = 0; i < 7; ++i) { const uint64_t t = (uint64_t)b.w[i] * 10u + c; b.w[i] = (uint32_t)t; c = t >> 32; }
+}
+GDB_HD uint32_t gdb_big_divmod10(GdbBig& b) {
+  uint64_t r = 0;
+  for (int i = 6; i >= 0; --i) { const uint64_t t = (r << 32) | b.w[i]; b.w[i] = (uint32_t)(t / 10u); r = t % 10u; }
+  return (uint32_t)r;
+}
+GDB_HD bool gdb_big_is_zero(const GdbBig& b) { uint32_t o = 0; for (int i = 0; i < 7; ++i) o |= b.w[i]; return o == 0; }
+GDB_HD uint32_t gdb_big_bit(const GdbBig& b, int i) { return i >= 0 && i < 224 ? (b.w[i >> 5] >> (i & 31)) & 1u : 0u; }
+GDB_HD bool gdb_big_any_below(const GdbBig& b, int n) {   // any of bits [0, n)
+  uint32_t o = 0;
+  for (int i = 0; i < 7; ++i) {
+    const int lo = i * 32;
+    if (n >= lo + 32) o |= b.w[i]; else if (n > lo) o |= b.w[i] & ((1u << (n - lo)) - 1u);
+  }
+  return o != 0;
+}
+GDB_HD GdbBig gdb_big_shr(const GdbBig& b, int n) {
+  GdbBig r;
+  const int ws = n >> 5, bs = n & 31;
+  for (int i = 0; i < 7; ++i) {
+    const uint32_t lo = i + ws < 7 ? b.w[i + ws] : 0u, hi = i + ws + 1 < 7 ? b.w[i + ws + 1] : 0u;
+    r.w[i] = bs ? (lo >> bs) | (hi << (32 - bs)) : lo;
+  }
+  return r;
+}
+GDB_HD bool gdb_big_below(const GdbBig& b, uint32_t v) { uint32_t o = 0; for (int i = 1; i < 7; ++i) o |= b.w[i]; return o == 0 && b.w[0] < v; }
+// q = the six significant digits (100000 .. 999999), X = decimal exponent of the rounded value, for M * 2^e2 (M > 0)
+GDB_HD void gdb_round_6_digits(uint32_t M, int e2, uint32_t& q, int& X) {
+  GdbBig N;
+  for (int i = 0; i < 7; ++i) N.w[i] = 0;
+  N.w[0] = M;
+  bool up;
+  if (e2 >= 0 || !gdb_big_below(gdb_big_shr(N, -e2), 100000u)) {
+    // at least six integer digits: I = floor(value); digits are dropped from I, the fraction only breaks ties
+    int s = 0;
+    if (e2 >= 0) { const int ws = e2 >> 5, bs = e2 & 31; N.w[ws] = M << bs; N.w[0] = ws ? 0u : N.w[0]; if (bs && ws + 1 < 7) N.w[ws + 1] = M >> (32 - bs); }
+    else s = -e2;
+    GdbBig I = gdb_big_shr(N, s);
+    const bool half_bit = s > 0 && gdb_big_bit(N, s - 1);
+    bool sticky = s > 1 && gdb_big_any_below(N, s - 1);
+    int dropped = 0;
+    uint32_t last = 0;
+    while (!gdb_big_below(I, 1000000u)) { if (dropped) sticky = sticky || last != 0; else sticky = sticky || half_bit; last = gdb_big_divmod10(I); ++dropped; }
+    q = I.w[0];
+    if (dropped) up = last > 5u || (last == 5u && (sticky || (q & 1u)));
+    else up = half_bit && (sticky || (q & 1u));
+    X = 5 + dropped;
+  } else {
+    // value < 100000: scale by 10^k until floor(value * 10^k) has six digits; what lies below the binary point decides the rounding
+    const int s = -e2;
+    int k = 0;
+    while (gdb_big_below(gdb_big_shr(N, s), 100000u)) { gdb_big_mul10(N); ++k; }
+    q = gdb_big_shr(N, s).w[0];
+    const bool half_bit = gdb_big_bit(N, s - 1) != 0, sticky = s > 1 && gdb_big_any_below(N, s - 1);
+    up = half_bit && (sticky || (q & 1u));
+    X = 5 - k;
+  }
+  if (up && ++q == 1000000u) { q = 100000u; ++X; }
+}
+// |f| as "%g" prints it (f finite, not zero)
+template <class Sink> GDB_HD void put_float_g(Sink& s, float f) {
+  const uint32_t u = gdb_f2u(f) & 0x7FFFFFFFu;
+  const uint32_t ex = u >> 23, man = u & 0x7FFFFFu;
+  uint32_t q; int X;
+  gdb_round_6_digits(ex ? man | 0x800000u : man, ex ? (int)ex - 150 : -149, q, X);
+  char dg[6];
+  for (int i = 5; i >= 0; --i) { dg[i] = (char)('0' + q % 10u); q /= 10u; }
+  int last = 5;
+  while (last > 0 && dg[last] == '0') --last;
+  if (X < -4 || X >= 6) {
     s.put(dg[0]);
     if (last > 0) { s.put('.'); for (int i = 1; i <= last; ++i) s.put(dg[i]); }
-    s.put('e'); s.put('+');
-    if (ex < 10) s.put('0');
-    put_u64(s, (uint64_t)ex);
+    s.put('e');
+    uint32_t ax = (uint32_t)(X < 0 ? -X : X);
+    s.put(X < 0 ? '-' : '+');
+    if (ax < 10u) s.put('0');
+    put_u64(s, ax);
+  } else if (X >= 0) {
+    for (int i = 0; i <= X; ++i) s.put(dg[i]);
+    if (last > X) { s.put('.'); for (int i = X + 1; i <= last; ++i) s.put(dg[i]); }
+  } else {
+    s.put('0'); s.put('.');
+    for (int i = 0; i < -X - 1; ++i) s.put('0');
+    for (int i = 0; i <= last; ++i) s.put(dg[i]);
+  }
+}
+
+// Float text as htslib's kputd writes it (see oracle/gdb_oracle_combine.hpp format_float): its own six-digit rule inside
+// [0.0001, 999999], printf("%g") of the magnitude outside - every float has a text, none is refused.
+template <class Sink> GDB_HD bool put_float(Sink& s, float f) {
+  const uint32_t bits = gdb_f2u(f);
+  if ((bits & 0x7F800000u) == 0x7F800000u) {   // kputd: "d < 0" writes the sign of -inf itself; a NaN fails every comparison and reaches "%g" as it is (glibc: "-nan" with the sign bit)
+    if (bits >> 31) s.put('-');
+    if (bits & 0x7FFFFFu) { s.put('n'); s.put('a'); s.put('n'); } else { s.put('i'); s.put('n'); s.put('f'); }
     return true;
   }
+  double d = (double)f;
+  if (d == 0) { if (bits >> 31) s.put('-'); s.put('0'); return true; }
+  if (d < 0) { s.put('-'); d = -d; }
+  if (!(d >= 0.0001 && d <= 999999)) { put_float_g(s, f); return true; }
   uint64_t i = (uint64_t)(d * 10000000000.0);
   if (d < 0.001) i += 5; else if (d < 0.01) i += 50; else if (d < 0.1) i += 500; else if (d < 1) i += 5000;
   else if (d < 10) i += 50000; else if (d < 100) i += 500000; else if (d < 1000) i += 5000000;
@@ -757,7 +835,7 @@ GDB_HD int elem_pack_text(float, uint64_t&) { return 0; }
 template <class Sink> GDB_HD void put_elem(Sink& s, int32_t v, uint32_t*) { if (elem_is_missing(v)) s.put('.'); else put_i32(s, v); }
 template <class Sink> GDB_HD void put_elem(Sink& s, float v, uint32_t* err) {
   if (elem_is_missing(v)) s.put('.');
-  else if (!put_float(s, v)) *err |= GDB_ERR_FLOAT_RANGE;
+  else put_float(s, v);
 }
 
 // element_wise_sum / concatenate INFO combiners (handle_VCF_field_combine_operation, broad_combined_gvcf.cc:374-429;
@@ -1368,7 +1446,7 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
   {
     float q;
     if (pl.qual_combine_op != GDB_OP_UNKNOWN && pl.f_QUAL >= 0 && reduce_scalar<float>(cx, k, pl.f_QUAL, pl.qual_combine_op, true, q, err)) {
-      if (!put_float(sink, q)) *err |= GDB_ERR_FLOAT_RANGE;
+      put_float(sink, q);
     } else sink.put('.');
   }
   sink.put('\t');
@@ -1421,7 +1499,7 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
         if (any) sink.put(';');
         sink.write(cx.names.text + cx.names.field_name_off[f], cx.names.field_name_len[f]);
         sink.put('=');
-        if (!put_float(sink, v)) *err |= GDB_ERR_FLOAT_RANGE;
+        put_float(sink, v);
       } else {
         int32_t v;
         if (!reduce_scalar<int32_t>(cx, k, f, fd.combine_op, false, v, err)) continue;

@@ -55,7 +55,7 @@ enum GdbErr {
   GDB_ERR_TOO_MANY_MERGED_ALLELES = 1u << 1,
   GDB_ERR_TOO_MANY_INPUT_ALLELES = 1u << 2,
   GDB_ERR_UNSUPPORTED_PLOIDY = 1u << 3,               // ploidy above GDB_MAX_PLOIDY
-  GDB_ERR_FLOAT_RANGE = 1u << 4,                      // float text outside the pinned kputd range
+  GDB_ERR_FLOAT_RANGE = 1u << 4,                      // retired (round 4: put_float prints every float, "%g" restated exactly); the bit stays reserved
   GDB_ERR_ARENA_OVERFLOW = 1u << 5,
   GDB_ERR_INTERNAL = 1u << 6,
   GDB_ERR_TOO_MANY_ID_TOKENS = 1u << 7,               // more than GDB_MAX_ID_TOKENS distinct ID tokens in one record

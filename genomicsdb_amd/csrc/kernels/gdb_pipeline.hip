@@ -36,7 +36,7 @@ namespace genomicsdb_amd {
 static std::string err_bits_text(uint32_t bits) {
   static const char* names[] = {"an interval is overlapped by one of the same sample that is neither a reference block nor a deletion",
                                 "more than GDB_MAX_MERGED_ALLELES alleles in one record", "more than GDB_MAX_INPUT_ALLELES alleles in one cell",
-                                "ploidy above GDB_MAX_PLOIDY", "a float outside the range whose text is pinned", "page arena overflow", "internal inconsistency",
+                                "ploidy above GDB_MAX_PLOIDY", "(retired: every float has a text since round 4)", "page arena overflow", "internal inconsistency",
                                 "more than GDB_MAX_ID_TOKENS distinct ID tokens in one record", "an element_wise_sum INFO vector longer than GDB_MAX_INFO_VECTOR",
                                 "malformed or unsorted cell stream", "more than GDB_MAX_FILTER_IDS distinct FILTER ids in one record"};
   std::string out = "device error bits " + std::to_string(bits) + " (";

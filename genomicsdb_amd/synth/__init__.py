@@ -38,7 +38,7 @@ class Generator:
     """cells of N samples over [B, B+L), handed out in column chunks (column-major order inside and across chunks)"""
 
     def __init__(self, n_samples, B, L, seed=SEED, dense=None, rank_sum_scale=None, overlap_permille=0, filter_permille=0, filter2_permille=0,
-                 id_permille=0, filter_id=1, filter_id2=0, with_id=False, contigs=None):
+                 id_permille=0, filter_id=1, filter_id2=0, with_id=False, contigs=None, float_stress_permille=0):
         """dense = (begin, length, hot_stride, K): BASELINE.json configs[4]-style region where every sample starts an
         insertion, drawn from a pool of K alleles, at every multiple of hot_stride
         contigs = [(name, tiledb_column_offset, length), ...] (genome mode, BASELINE.json configs[3]): columns are the flattened
@@ -53,6 +53,9 @@ class Generator:
             offs = (ctypes.c_int64 * n)(*[c[1] for c in contigs])
             lens = (ctypes.c_int64 * n)(*[c[2] for c in contigs])
             lib().gdbsynth_set_contigs(self._h, offs, lens, n)
+        if float_stress_permille:   # floats outside the everyday range on that share of the variant calls (tiny, huge, subnormal, +inf, NaN)
+            lib().gdbsynth_set_float_stress.argtypes = [ctypes.c_void_p, ctypes.c_int]
+            lib().gdbsynth_set_float_stress(self._h, int(float_stress_permille))
         if rank_sum_scale:      # rank sums rounded to 1 / scale instead of 1 / 1000: many tied medians, -0 and +0 included
             lib().gdbsynth_set_rank_sum_scale(self._h, float(rank_sum_scale))
         if overlap_permille or filter_permille or filter2_permille or id_permille or with_id:

@@ -18,6 +18,7 @@
 //   and every sample begins a new record at the first column of the next contig - as separate per-contig gVCF records would
 #include <algorithm>
 #include <cmath>
+#include <limits>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -74,6 +75,7 @@ struct Synth {
   // every position that is a multiple of hot_stride, with its ALT drawn from a site pool of dense_K insertion alleles
   int64_t dense_begin = 0, dense_len = 0, hot_stride = 50;
   int dense_K = 0;
+  int float_stress_permille = 0;   // share of the variant calls whose floats leave the everyday range: below 1e-4, above 1e6 / 2^63, subnormal, +inf, NaN
   double rs_scale = 1000.0;   // rank sums are rounded to 1 / rs_scale (coarse scales make tied medians, zeros of both signs included)
   // optional modes, all off by default (the plain stream stays byte-identical): decisions come from a hash of (seed, row, begin),
   // not from the per-sample stream.  overlap: the next record of a sample begins INSIDE a reference block / deletion (the scan's
@@ -159,6 +161,19 @@ struct Synth {
       r.mq = (float)(std::round((40.0 + 20.0 * g.unit()) * 100.0) / 100.0);
       r.raw_mq = r.mq * r.mq * (float)r.dp;
       r.qual = (float)(std::round((30.0 + 2970.0 * g.unit()) * 100.0) / 100.0);
+      if (float_stress_permille > 0) {
+        const uint64_t h = mode_hash(row, r.begin, 0xf10a7f10a7ull);
+        if ((int)(h % 1000) < float_stress_permille) {
+          switch ((h >> 12) % 6) {
+            case 0: for (int i = 0; i < 4; ++i) r.rs[i] *= 1e-6f; r.qual = 5e-5f; break;
+            case 1: for (int i = 0; i < 4; ++i) r.rs[i] *= 1e24f; r.qual = 1e25f; r.raw_mq = 3e38f; break;
+            case 2: r.qual = std::numeric_limits<float>::infinity(); r.mq = 1.5e-7f; break;
+            case 3: { uint32_t nanbits = 0x7FC00000u; memcpy(&r.qual, &nanbits, 4); r.mq = 1e-10f; break; }
+            case 4: for (int i = 0; i < 4; ++i) r.rs[i] = (i & 1) ? 1e-41f : -3e-39f; r.qual = 9.9999994e-5f; break;
+            default: r.qual = 999999.06f; r.mq = 1234567.0f; r.raw_mq = 1.8446744e19f; break;
+          }
+        }
+      }
       for (int i = 0; i < 4; ++i) r.sb[i] = g.range(0, 40);
       int called = r.hom ? 2 : 1;  // genotype index of 1/1 = 2, 0/1 = 1
       for (int i = 0; i < 6; ++i) r.pl[i] = (i == called) ? 0 : g.range(10, 10000);
@@ -324,6 +339,7 @@ void gdbsynth_set_contigs(void* h, const int64_t* offsets, const int64_t* length
   for (int32_t i = 0; i < n; ++i) s->contigs.emplace_back(offsets[i], lengths[i]);
   std::sort(s->contigs.begin(), s->contigs.end());
 }
+void gdbsynth_set_float_stress(void* h, int permille) { ((Synth*)h)->float_stress_permille = permille; }
 void gdbsynth_set_rank_sum_scale(void* h, double scale) { ((Synth*)h)->rs_scale = scale > 0 ? scale : 1000.0; }
 void gdbsynth_set_modes(void* h, int overlap_permille, int filter_permille, int filter2_permille, int id_permille, int filter_id, int filter_id2, int with_id) {
   Synth* s = (Synth*)h;

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <cmath>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -269,6 +270,40 @@ int hostsim_fixed3(float v, char* buf, uint64_t cap) {
   put_fixed3(s, v, &err);
   if (s.n < cap) buf[s.n] = 0;
   return err ? -1 : (int)s.n;
+}
+
+// gdb_core.hpp's put_float (kputd's rule inside [0.0001, 999999], an exact "%g" outside) on a whole array of bit patterns: the
+// texts come back NUL-separated; *mismatch = index of the first one that differs from what the C library prints through kputd's
+// own logic (sign, then "%g" of the magnitude; -1: none).  One call checks millions of patterns.
+int64_t hostsim_put_float_check(const uint32_t* bits, int64_t n, char* first_bad_mine, char* first_bad_libc, uint64_t cap) {
+  struct S { char* p; uint64_t cap, n; void put(char c) { if (n + 1 < cap) p[n] = c; ++n; } void write(const char* q, int k) { for (int i = 0; i < k; ++i) put(q[i]); } };
+  for (int64_t i = 0; i < n; ++i) {
+    float f; memcpy(&f, &bits[i], 4);
+    char mine[64], libc[64];
+    S s{mine, sizeof(mine), 0};
+    put_float(s, f);
+    mine[s.n < sizeof(mine) ? s.n : sizeof(mine) - 1] = 0;
+    // kputd (htslib kstring.c), restated with the C library doing "%g": what the reference prints
+    double d = f;
+    int at = 0;
+    if (d == 0) snprintf(libc, sizeof(libc), "%s", std::signbit(d) ? "-0" : "0");
+    else {
+      if (d < 0) { libc[at++] = '-'; d = -d; }
+      if (!(d >= 0.0001 && d <= 999999)) snprintf(libc + at, sizeof(libc) - at, "%g", d);
+      else { libc[at] = 0; strcpy(libc, mine); }   // (the six-digit rule is pinned by the goldens and the oracle tests)
+    }
+    if (strcmp(mine, libc) != 0) {
+      snprintf(first_bad_mine, cap, "%s", mine); snprintf(first_bad_libc, cap, "%s", libc);
+      return i;
+    }
+  }
+  return -1;
+}
+int hostsim_put_float(float v, char* buf, uint64_t cap) {
+  struct S { char* p; uint64_t cap, n; void put(char c) { if (n + 1 < cap) p[n] = c; ++n; } void write(const char* q, int k) { for (int i = 0; i < k; ++i) put(q[i]); } } s{buf, cap, 0};
+  put_float(s, v);
+  if (s.n < cap) buf[s.n] = 0;
+  return (int)s.n;
 }
 
 }  // extern "C"
