@@ -47,6 +47,10 @@ def main():
     ap.add_argument("--no-c3", action="store_true", help="skip the c3-shape leg (10 000 samples streamed through HBM in column windows)")
     ap.add_argument("--c3-bp", type=int, default=10_000_000, help="columns of the c3-shape leg (10 000 samples: 14.6 GB of cells per Mb, generated into host memory first)")
     ap.add_argument("--cpu-sample-bp", type=int, default=12000, help="columns of the bounded CPU-baseline sample (~15 s of oracle time)")
+    ap.add_argument("--concat", action="store_true",
+                    help="N > 1: after the timed steps every rank's pages of one window go to rank 0 in column order (dist.gather_interval_paged: the single-stream "
+                         "view of the partitions' outputs); the line carries \"concat\": bytes, GB/s, how long the root and the senders were blocked")
+    ap.add_argument("--concat-format", default="z", help="output format of the --concat leg's engine: \"z\" (BGZF blocks, ~6 x fewer bytes over the links) or \"\"")
     ap.add_argument("--dry-run", action="store_true",
                     help="rank set-up, partition arithmetic and the cross-rank reduction only, no device work and no number: "
                          "lets the CPU suite check the N-rank launch (the line says \"dry_run\": true and carries value null)")
@@ -137,6 +141,26 @@ def main():
 
     dt, (recs_all, cells_all, bo_all, bi_all) = gdist.aggregate(dt, [recs, cells_in, bytes_out, bytes_in], device="cuda" if backend == "nccl" else None)
 
+    concat = None
+    if args.concat and world > 1 and not args.bcf:
+        # the single-stream view: one window per rank as BGZF pages (blocks concatenate) to rank 0 over RCCL / xGMI, in column order
+        eng.close()
+        ec = genomicsdb_amd.CombineEngine(q, device=device_index, output_format=args.concat_format)
+        gen2 = synth.Generator(N, B, W)
+        ec.stage_cells_begin()
+        col = B
+        while col < B + W:
+            col = min(B + W, col + 1_000_000)
+            ptr, nbytes, _ = gen2.next_chunk(col)
+            ec.stage_cells_append(ptr, nbytes)
+        ec.stage_cells_end()
+        ec.set_reference(B, synth.reference(B, W + 4096))
+        barrier()
+        dev = torch.device("cuda", device_index)
+        concat = concat_leg(ec.page_tensors(B, B + W - 1, 1 << 30), 1 << 30, rank, world, dev)
+        if concat is not None:
+            concat["output_format"] = args.concat_format
+        ec.close()
     out = None
     if rank == 0:
         # roofline of the dominant kernel: algorithmic bytes of one k_assemble_write launch / its average duration
@@ -165,6 +189,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None if args.bcf else pmc_traffic(N, W, arena),
                          "alg_bytes_per_launch": alg_bytes_per_launch, "avg_launch_ms": avg_ms, "launches": int(launches)},
         }
+        if concat is not None:
+            out["concat"] = concat
         if not args.no_stream and world == 1 and not args.bcf:         # the boundary GATK drives: header + body through gdb_mi355_read
             eng.close()                                                 # (the timed engine's HBM - fragment, 48 GB arena, tables - is given back first)
             out["stream_end_to_end"] = stream_end_to_end(N, B, min(W, Lbp), tmp, expect_body_bytes=None)
@@ -213,12 +239,45 @@ def dry_run(args, rank, world, backend):
     from genomicsdb_amd import dist as gdist
     B, E = gdist.synthetic_partition(rank, 10_000_000, args.interval_bp)
     dt, (cols, ranks) = gdist.aggregate(0.001 * (rank + 1), [E - B + 1, 1])
+    concat = None
+    if args.concat:   # the accounting of the concat leg on synthetic pages: rank r has 8 pages of (r + 1) MiB, every byte = its rank
+        import torch
+        page = (rank + 1) << 20
+        concat = concat_leg((torch.full((page,), rank, dtype=torch.uint8) for _ in range(8)), 3 << 20, rank, world, None,
+                            check=lambda t, st: st.__setitem__("ok", st.get("ok", True) and int(t[0]) >= st.get("last", 0)) or st.__setitem__("last", int(t[0])))
     if rank == 0:
-        print(json.dumps({"metric": "combined-gVCF positions/sec", "value": None, "unit": "positions/s", "n_gpus": world, "dry_run": True,
-                          "steps": args.steps, "warmup": args.warmup, "scaling": "weak", "ranks_reporting": int(ranks),
-                          "columns_all_ranks": int(cols), "max_over_ranks_s": dt, "backend": backend}), flush=True)
+        out = {"metric": "combined-gVCF positions/sec", "value": None, "unit": "positions/s", "n_gpus": world, "dry_run": True,
+               "steps": args.steps, "warmup": args.warmup, "scaling": "weak", "ranks_reporting": int(ranks),
+               "columns_all_ranks": int(cols), "max_over_ranks_s": dt, "backend": backend}
+        if concat is not None:
+            out["concat"] = concat
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def concat_leg(pages, page_bytes, rank, world, device, check=None):
+    """every rank's pages to rank 0 in column order through dist.paged_concat; rank 0 returns the accounting: bytes and pages the sink saw,
+    seconds, GB/s, how long the root waited for the rank it was draining and the longest any sender waited for a free slot"""
+    from genomicsdb_amd import dist as gdist
+    st, seen = {}, {"pages": 0}
+
+    def sink(t):
+        seen["pages"] += 1
+        if check is not None:
+            check(t, seen)
+    gdist.paged_concat(pages, sink, page_bytes, dst=0, ring_slots=3, device=device, stats=st)
+    _, (sender_blocked,) = gdist.aggregate(0.0, [0.0], device=device) if world == 1 else (0.0, [0.0])
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([st["blocked_s"] if rank != 0 else 0.0], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        sender_blocked = float(t.item())
+    if rank != 0:
+        return None
+    return {"ranks": world, "bytes": int(st["bytes"]), "pages": seen["pages"], "seconds": st["seconds"], "GBps": st["bytes"] / max(st["seconds"], 1e-9) / 1e9,
+            "root_blocked_s": st["blocked_s"], "max_sender_blocked_s": sender_blocked, "page_bytes": page_bytes, "ordered": bool(seen.get("ok", True))}
 
 
 def run_streamed(args, rank, world, device_index, backend, source="callback", emit=True):

@@ -204,6 +204,20 @@ class CombineEngine:
     def set_reference(self, begin, bases):
         _check(_lib.lib().gdbamd_engine_set_reference(self._e, begin, bases, len(bases)) == 0, "set_reference")
 
+    def column_histogram(self, hist_begin, hist_end, bin_size, counts=None):
+        """ColumnHistogramOperator on the device: numpy uint64 counts[(hist_end - hist_begin) // bin_size + 1] of the staged begin-cells by
+        begin column (counts given: added to, for arrays streamed in windows)"""
+        import numpy as np
+        nbins = (hist_end - hist_begin) // bin_size + 1
+        acc = counts is not None
+        if counts is None:
+            counts = np.zeros(nbins, dtype=np.uint64)
+        assert counts.dtype == np.uint64 and counts.size == nbins and counts.flags["C_CONTIGUOUS"]
+        L = _lib.lib()
+        L.gdbamd_engine_column_histogram.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int]
+        _check(L.gdbamd_engine_column_histogram(self._e, hist_begin, hist_end, bin_size, counts.ctypes.data, nbins, int(acc)) == 0, "column_histogram")
+        return counts
+
     def split_point(self, begin, end, max_columns):
         """last column of the first piece of [begin, end] that can be run on its own with byte-identical output"""
         pe = ctypes.c_int64()

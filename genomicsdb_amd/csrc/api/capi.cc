@@ -49,7 +49,7 @@ void* gdb_mi355_init_output_format(const char* loader_json_file, const char* que
     const std::string fmt = output_format ? output_format : "";
     const bool bcf = fmt == "bu" || fmt == "b";
     return new GenomicsDBBCFGenerator(loader_json_file ? loader_json_file : "", query_json_file ? query_json_file : "", chr, start, end, rank, buffer_capacity,
-                                      segment_size, fmt.c_str(), produce_header_only != 0, bcf && use_missing, bcf && keep_idx);
+                                      segment_size, fmt.c_str(), produce_header_only != 0, bcf && use_missing, bcf && keep_idx, true);
   }, (void*)nullptr);
 }
 void* gdb_mi355_init_from_memory_output_format(const char* query_json_text, const uint8_t* cells, uint64_t nbytes, uint64_t buffer_capacity, int produce_header_only,
@@ -263,6 +263,32 @@ int gdbamd_engine_next_page(void* e, uint64_t arena_bytes, const void** dev_ptr,
 
 int gdbamd_engine_split_point(void* engine, int64_t qb, int64_t qe, int64_t max_columns, int64_t* piece_end) {
   try { *piece_end = ((EngineHandle*)engine)->eng->pipeline().split_point(qb, qe, max_columns); return 0; } catch (const std::exception& e) { g_last_error = e.what(); return -1; }
+}
+int gdbamd_engine_column_histogram(void* engine, uint64_t hist_begin, uint64_t hist_end, uint64_t bin_size, uint64_t* counts, uint64_t nbins, int accumulate) {
+  try { ((EngineHandle*)engine)->eng->pipeline().column_histogram(hist_begin, hist_end, bin_size, counts, nbins, accumulate != 0); return 0; } catch (const std::exception& e) { g_last_error = e.what(); return -1; }
+}
+// ColumnHistogramOperator::equi_partition_and_print_bins (variant_operations.cc:769-796), the text it prints; returns its length (dst may be NULL), -1 when
+// num_parts >= nbins (the reference prints a complaint and returns false)
+int64_t gdbamd_equi_partition_text(const uint64_t* counts, uint64_t nbins, uint64_t hist_begin, uint64_t bin_size, uint64_t num_parts, char* dst, uint64_t cap) {
+  if (num_parts >= nbins || num_parts == 0) return -1;
+  unsigned long long total = 0;
+  for (uint64_t i = 0; i < nbins; ++i) total += counts[i];
+  const double per = (double)total / (double)num_parts;
+  std::string out;
+  char line[160];
+  snprintf(line, sizeof(line), "Total %llu #bins %llu count/bins %.1f\n", total, (unsigned long long)num_parts, per);
+  out += line;
+  for (uint64_t i = 0; i < nbins;) {
+    uint64_t j = i;
+    unsigned long long cur = 0;
+    for (; (double)cur < per && j < nbins; cur += counts[j], ++j) {}
+    snprintf(line, sizeof(line), "%llu,%llu,%llu\n", (unsigned long long)(hist_begin + i * bin_size), (unsigned long long)(hist_begin + j * bin_size - 1), cur);
+    out += line;
+    i = j;
+  }
+  out += "\n";
+  if (dst && cap) { const size_t n = std::min<size_t>(out.size(), (size_t)cap); memcpy(dst, out.data(), n); }
+  return (int64_t)out.size();
 }
 int gdbamd_engine_save_fragment(void* engine, const char* path) {
   try { ((EngineHandle*)engine)->eng->save_fragment(path); return 0; } catch (const std::exception& e) { g_last_error = e.what(); return -1; }

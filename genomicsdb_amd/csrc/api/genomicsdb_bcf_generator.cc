@@ -346,6 +346,18 @@ CombineEngine::Coverage CombineEngine::cover(int64_t column) {
   return m_src.cov;
 }
 
+void CombineEngine::column_histogram(uint64_t hist_begin, uint64_t hist_end, uint64_t bin_size, std::vector<uint64_t>& counts) {
+  if (bin_size == 0 || hist_end < hist_begin) throw GenomicsDBConfigException("column histogram: empty range or bin size 0");
+  counts.assign((size_t)((hist_end - hist_begin) / bin_size + 1), 0);
+  int64_t col = INT64_MIN;
+  for (;;) {                                                      // window by window; a window's carried-over cells are not counted again
+    const Coverage cov = cover(col);
+    m_pipe->column_histogram(hist_begin, hist_end, bin_size, counts.data(), counts.size(), true);
+    if (m_src.kind == SRC_NONE || m_window_eof || cov.hi >= INT64_MAX - 1) break;
+    col = cov.hi + 1;
+  }
+}
+
 void CombineEngine::set_reference_window(int64_t begin, const std::string& bases) {
   m_user_ref = true; m_user_ref_begin = begin; m_user_ref_bases = bases;
   m_pipe->set_reference_window(begin, bases);
@@ -361,8 +373,12 @@ void CombineEngine::stage_reference_for(int64_t qb, int64_t qe) {
 
 GenomicsDBBCFGenerator::GenomicsDBBCFGenerator(const std::string& loader_config_file, const std::string& query_config_file, const char* chr,
                                                const int start, const int end, int my_rank, size_t buffer_capacity, size_t, const char* output_format,
-                                               const bool produce_header_only, const bool use_missing_values_only_not_vector_end, const bool keep_idx_fields_in_bcf_header)
+                                               const bool produce_header_only, const bool use_missing_values_only_not_vector_end, const bool keep_idx_fields_in_bcf_header,
+                                               const bool bgzf_stream)
     : m_buffer_capacity(buffer_capacity) {
+  std::string fmt = output_format ? output_format : "";
+  if (!bgzf_stream) { if (fmt == "z") fmt = ""; else if (fmt == "b") fmt = "bu"; }   // (VCFSerializedBufferAdapter never compresses, vcf_adapter.cc:475-505)
+  output_format = fmt.c_str();
   GenomicsDBImportConfig loader;
   if (!loader_config_file.empty()) loader.read_from_file(loader_config_file, my_rank);
   // one process per GPU: the device is the launcher's LOCAL_RANK (torchrun / mpirun wrappers export it), else GDBAMD_DEVICE, else 0

@@ -52,6 +52,8 @@ class CombineEngine {
   void open_cell_callback(CellChunkFn fn, void* user);
   struct Coverage { int64_t lo, hi; };                          // every query position in [lo, hi] sees all its live cells in the staged fragment
   Coverage cover(int64_t column);                               // stages windows until `column` is covered
+  // ColumnHistogramOperator over the whole array source (all its column windows, front to back): counts[(hist_end - hist_begin) / bin_size + 1]
+  void column_histogram(uint64_t hist_begin, uint64_t hist_end, uint64_t bin_size, std::vector<uint64_t>& counts);
   uint64_t staging_budget_bytes() const;
   int64_t windows_staged = 0;
   uint64_t pipeline_generation = 0;   // counts the swaps of the two pipelines (overlapped staging): pipeline() is another object afterwards
@@ -113,7 +115,12 @@ class GenomicsDBBCFGenerator {
   GenomicsDBBCFGenerator(const std::string& loader_config_file, const std::string& query_config_file, const char* chr, const int start,
                          const int end, int my_rank = 0, size_t buffer_capacity = 1048576u, size_t tiledb_segment_size = 1048576u,
                          const char* output_format = "bu", const bool produce_header_only = false,
-                         const bool use_missing_values_only_not_vector_end = false, const bool keep_idx_fields_in_bcf_header = true);
+                         const bool use_missing_values_only_not_vector_end = false, const bool keep_idx_fields_in_bcf_header = true,
+                         const bool bgzf_stream = false);
+  // bgzf_stream: the reference's stream object serialises through VCFSerializedBufferAdapter, which never compresses - bcf_hdr_serialize /
+  // bcf_serialize look at m_is_bcf only (vcf_adapter.cc:475-505): "z" gives plain VCF text there and "b" plain BCF2.  So this constructor (the
+  // reference's signature) reads "z" as "" and "b" as "bu" unless bgzf_stream says the caller wants the build's extension, BGZF blocks deflated
+  // on the device (gdb_mi355_init_output_format, gt_mpi_gather -O z: what the file-writing VCFAdapter of the reference produces)
   // in-memory flavour: query JSON text + begin-cells (reference binary-cell layout)
   GenomicsDBBCFGenerator(const std::string& query_json_text, const uint8_t* cells, uint64_t nbytes, size_t buffer_capacity, bool produce_header_only,
                          const char* output_format = "", bool use_missing_values_only_not_vector_end = false, bool keep_idx_fields_in_bcf_header = true);
@@ -132,6 +139,7 @@ class GenomicsDBBCFGenerator {
   // drain statistics of the stream (bench: t_drain, end-to-end rate)
   struct DrainStats { uint64_t pages = 0, chunks = 0, bytes = 0; double seconds_waiting_for_copies = 0, seconds_producing = 0; };
   const DrainStats& drain_stats() const { return m_drain; }
+  CombineEngine& engine() { return *m_engine; }   // (gt_mpi_gather --produce-histogram counts the array's cells through it)
  private:
   void common_init(bool produce_header_only, bool keep_idx_fields_in_bcf_header = true);
   // Stream machinery: the device assembles pages of up to device_page_bytes() (independent of the caller's buffer_capacity)

@@ -123,7 +123,10 @@ void VariantQueryProcessor::scan_and_operate(const int, const VariantQueryConfig
     throw VariantOperationException("this operator's per-record operate() cannot run on the device path; the built-in BroadCombinedGVCFOperator (the class itself, not a "
                                     "class derived from it) is recognised, other operators take pages through BatchedVariantOperatorBase::operate_on_page()");
   if (batched) gvcf = nullptr;
-  const std::string format = gvcf ? gvcf->get_vcf_adapter().get_output_format() : std::string();
+  std::string format = gvcf ? gvcf->get_vcf_adapter().get_output_format() : std::string();
+  // the buffer adapter of the reference never compresses: bcf_hdr_serialize / bcf_serialize only look at m_is_bcf (vcf_adapter.cc:475-505),
+  // so "z" is plain VCF text and "b" plain BCF2 in an RWBuffer; BGZF is for the file-writing VCFAdapter (which also writes the EOF block)
+  if (gvcf && dynamic_cast<VCFSerializedBufferAdapter*>(&gvcf->get_vcf_adapter())) { if (format == "z") format = ""; else if (format == "b") format = "bu"; }
   const bool use_missing = gvcf && gvcf->use_missing_values_only_not_vector_end();
   if (!m_engine || m_engine->format != format || m_engine->use_missing != use_missing) {
     m_engine.reset(new Engine);

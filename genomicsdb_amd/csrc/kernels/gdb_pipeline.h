@@ -117,6 +117,9 @@ class DevicePipeline {
   void prepare_interval(int64_t qb, int64_t qe);
   // last column of the first piece of [qb, qe] that can be processed on its own with byte-identical output (cut before a cell begin)
   int64_t split_point(int64_t qb, int64_t qe, int64_t max_columns);
+  // ColumnHistogramOperator (variant_operations.cc:732-767) over the staged fragment's begin-cells: counts[(end - begin) / bin_size + 1];
+  // accumulate: add to what counts holds (an array streamed in windows is counted window by window)
+  void column_histogram(uint64_t hist_begin, uint64_t hist_end, uint64_t bin_size, uint64_t* counts, uint64_t nbins, bool accumulate = false);
   bool next_page(uint64_t arena_bytes, const char** dev_ptr, uint64_t* nbytes);
   // the same in two steps (asynchronous page production, two arenas): see gdb_pipeline.hip
   struct PageTicket { int arena = 0; const char* dev = nullptr; uint64_t nbytes = 0; void* done_event = nullptr; };   // done_event: hipEvent_t recorded behind the page's kernels

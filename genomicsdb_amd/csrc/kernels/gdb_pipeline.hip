@@ -4406,6 +4406,42 @@ int64_t DevicePipeline::split_point(int64_t qb, int64_t qe, int64_t max_columns)
   return (cut == INT64_MAX || cut > qe) ? qe : cut - 1;
 }
 
+// ColumnHistogramOperator on the device (variant_operations.cc:732-767): every staged begin-cell counts for the bin of its begin column,
+// begin <= hist_begin in bin 0, begin >= hist_end in the last one.  One atomic per run of equal bins inside a wavefront (the cells
+// are sorted by begin: neighbouring lanes nearly always share their bin).
+__global__ void k_column_histogram(const int64_t* __restrict__ begin, int64_t C, uint64_t hist_begin, uint64_t hist_end, uint64_t bin_size, uint64_t nbins, unsigned long long* __restrict__ counts) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  uint64_t bin = ~0ull;
+  if (c < C) {
+    const uint64_t b = (uint64_t)begin[c];
+    bin = b <= hist_begin ? 0ull : b >= hist_end ? nbins - 1 : (b - hist_begin) / bin_size;
+  }
+  const uint64_t prev = __shfl_up(bin, 1, 64);
+  const bool head = lane == 0 || prev != bin;
+  const uint64_t heads = __ballot(head);
+  if (head && bin != ~0ull) {
+    const uint64_t above = lane == 63 ? 0ull : heads >> (lane + 1);
+    const int run = above ? __builtin_ctzll(above) + 1 : 64 - lane;
+    atomicAdd(&counts[bin], (unsigned long long)run);
+  }
+}
+void DevicePipeline::column_histogram(uint64_t hist_begin, uint64_t hist_end, uint64_t bin_size, uint64_t* counts, uint64_t nbins, bool accumulate) {
+  Impl& S = *m_;
+  if (bin_size == 0 || hist_end < hist_begin || nbins != (hist_end - hist_begin) / bin_size + 1) throw GenomicsDBDeviceException("column_histogram: #bins must be (end - begin) / bin_size + 1");
+  HIP_CHECK(hipSetDevice(S.device));
+  DevBuf<unsigned long long> d;
+  d.ensure(nbins);
+  if (accumulate) HIP_CHECK(hipMemcpyAsync(d.p, counts, nbins * sizeof(uint64_t), hipMemcpyHostToDevice, S.stream));
+  else HIP_CHECK(hipMemsetAsync(d.p, 0, nbins * sizeof(uint64_t), S.stream));
+  // (the cells carried over from the previous column window open the fragment: they were counted with their own window)
+  const int64_t first = std::min<int64_t>(S.carried_cells, S.fr.ncells), n = S.fr.ncells - first;
+  if (n > 0)
+    hipLaunchKernelGGL(k_column_histogram, dim3(blocks_for(n)), dim3(kBlock), 0, S.stream, S.fr.begin + first, n, hist_begin, hist_end, bin_size, nbins, d.p);
+  HIP_CHECK(hipMemcpyAsync(counts, d.p, nbins * sizeof(uint64_t), hipMemcpyDeviceToHost, S.stream));
+  HIP_CHECK(hipStreamSynchronize(S.stream));
+}
+
 void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   Impl& S = *m_;
   S.iv = Impl::IntervalState();

@@ -19,7 +19,8 @@
 
 using namespace genomicsdb_amd;
 
-enum { ARGS_IDX_PRODUCE_BROAD_GVCF = 1000, ARGS_IDX_VERSION, ARGS_IDX_UNSUPPORTED };
+enum { ARGS_IDX_PRODUCE_BROAD_GVCF = 1000, ARGS_IDX_PRODUCE_HISTOGRAM, ARGS_IDX_VERSION, ARGS_IDX_UNSUPPORTED };
+extern "C" int64_t gdbamd_equi_partition_text(const uint64_t* counts, uint64_t nbins, uint64_t hist_begin, uint64_t bin_size, uint64_t num_parts, char* dst, uint64_t cap);
 
 static int launcher_rank() {
   for (const char* name : {"OMPI_COMM_WORLD_RANK", "PMI_RANK", "PMIX_RANK", "SLURM_PROCID", "RANK"})
@@ -33,12 +34,12 @@ int main(int argc, char** argv) {
       {"loader-json-config", 1, 0, 'l'}, {"segment-size", 1, 0, 's'}, {"array", 1, 0, 'A'},
       {"produce-Broad-GVCF", 0, 0, ARGS_IDX_PRODUCE_BROAD_GVCF}, {"version", 0, 0, ARGS_IDX_VERSION},
       {"skip-query-on-root", 0, 0, ARGS_IDX_UNSUPPORTED}, {"produce-interesting-positions", 0, 0, ARGS_IDX_UNSUPPORTED},
-      {"produce-histogram", 0, 0, ARGS_IDX_UNSUPPORTED}, {"print-calls", 0, 0, ARGS_IDX_UNSUPPORTED}, {"print-csv", 0, 0, ARGS_IDX_UNSUPPORTED},
+      {"produce-histogram", 0, 0, ARGS_IDX_PRODUCE_HISTOGRAM}, {"print-calls", 0, 0, ARGS_IDX_UNSUPPORTED}, {"print-csv", 0, 0, ARGS_IDX_UNSUPPORTED},
       {"print-AC", 0, 0, ARGS_IDX_UNSUPPORTED}, {0, 0, 0, 0}};
   std::string json_config, loader_json, output_format;
   size_t page_size = 0, segment_size = 10u * 1024u * 1024u;
   int rank = launcher_rank();
-  bool produce_gvcf = false;
+  bool produce_gvcf = false, produce_histogram = false;
   int c;
   while ((c = getopt_long(argc, argv, "j:l:w:A:p:O:s:r:", long_options, NULL)) >= 0) {
     switch (c) {
@@ -50,14 +51,36 @@ int main(int argc, char** argv) {
       case 'l': loader_json = optarg; break;
       case 'w': case 'A': std::cerr << "-w / -A: give workspace and array in the JSON files\n"; return -1;
       case ARGS_IDX_PRODUCE_BROAD_GVCF: produce_gvcf = true; break;
+      case ARGS_IDX_PRODUCE_HISTOGRAM: produce_histogram = true; break;
       case ARGS_IDX_VERSION: std::cout << "genomicsdb_amd (MI355X variant-combine path) for GenomicsDB 0.10.2 query JSON\n"; return 0;
-      case ARGS_IDX_UNSUPPORTED: std::cerr << "this build implements --produce-Broad-GVCF only\n"; return -1;
+      case ARGS_IDX_UNSUPPORTED: std::cerr << "this build implements --produce-Broad-GVCF and --produce-histogram only\n"; return -1;
       default: std::cerr << "Unknown command line argument\n"; return -1;
     }
   }
-  if (json_config.empty() || !produce_gvcf) {
-    std::cerr << "Usage: gt_mpi_gather -j <query.json> [-l <loader.json>] [-r rank] [-p page_size] [-O output_format] --produce-Broad-GVCF\n";
+  if (json_config.empty() || !(produce_gvcf || produce_histogram)) {
+    std::cerr << "Usage: gt_mpi_gather -j <query.json> [-l <loader.json>] [-r rank] [-p page_size] [-O output_format] --produce-Broad-GVCF | --produce-histogram\n";
     return -1;
+  }
+  if (produce_histogram) {
+    // produce_column_histogram (tools/src/gt_mpi_gather.cc:404-411, :600): cells per 100 columns of [0, 4e9), then the partitions of about equal
+    // cell count for 128, 64, ... 2 ranks - the column_partitions a loader JSON should carry for that many ranks.  Counted on the GPU.
+    try {
+      GenomicsDBBCFGenerator gen(loader_json, json_config, "", 0, 0, rank, (size_t)1u << 20, segment_size, "", true, false, true);
+      const uint64_t hb = 0, he = 4000000000ull, bin = 100;
+      std::vector<uint64_t> counts;
+      gen.engine().column_histogram(hb, he, bin, counts);
+      for (uint64_t parts : {128ull, 64ull, 32ull, 16ull, 8ull, 4ull, 2ull}) {
+        const int64_t n = gdbamd_equi_partition_text(counts.data(), counts.size(), hb, bin, parts, nullptr, 0);
+        if (n < 0) { std::cerr << "Requested #equi bins is smaller than allocated bin counts vector, returning\n"; continue; }
+        std::string text((size_t)n, '\0');
+        gdbamd_equi_partition_text(counts.data(), counts.size(), hb, bin, parts, &text[0], (uint64_t)n);
+        std::cout << text;
+      }
+    } catch (const std::exception& e) {
+      std::cerr << "gt_mpi_gather: " << e.what() << "\n";
+      return -1;
+    }
+    return 0;
   }
   try {
     // output file: "vcf_output_filename" (string, or list indexed by rank) else stdout  (json_config.cc:586-607)
@@ -77,7 +100,8 @@ int main(int argc, char** argv) {
     // -p is the reference's combined_vcf_records_buffer_size_limit: here it also sizes the pages the device assembles
     if (page_size) setenv("GDBAMD_DEVICE_PAGE_BYTES", std::to_string(page_size).c_str(), 1);
     const auto t0 = std::chrono::steady_clock::now();
-    GenomicsDBBCFGenerator gen(loader_json, json_config, "", 0, 0, rank, capacity, segment_size, output_format.c_str(), false, false, true);
+    GenomicsDBBCFGenerator gen(loader_json, json_config, "", 0, 0, rank, capacity, segment_size, output_format.c_str(), false, false, true,
+                               true);   // (-O z / b: BGZF like the reference's file-writing VCFAdapter, vcf_adapter.cc:340-372)
     std::vector<uint8_t> buf(std::max<size_t>(capacity, 1u << 20));
     size_t total = 0;
     while (!gen.end()) {

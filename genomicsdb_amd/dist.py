@@ -99,45 +99,93 @@ def gather_interval(engine, begin, end, arena_bytes=None, dst=0):
     return ordered_concat_tensors(local, dst=dst)
 
 
-def paged_concat(pages, sink, page_bytes, dst=0, ring_slots=3, device=None):
+def equi_partition(counts, hist_begin, bin_size, num_parts):
+    """ColumnHistogramOperator::equi_partition_and_print_bins (variant_operations.cc:769-796): [(first_column, last_column, cells)] of about
+    equal cell count, and the text the reference prints for them.  counts: numpy uint64 (CombineEngine.column_histogram)"""
+    import numpy as np
+    counts = np.ascontiguousarray(counts, dtype=np.uint64)
+    L = _lib.lib()
+    L.gdbamd_equi_partition_text.restype = ctypes.c_int64
+    L.gdbamd_equi_partition_text.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_uint64]
+    n = L.gdbamd_equi_partition_text(counts.ctypes.data, counts.size, hist_begin, bin_size, num_parts, None, 0)
+    if n < 0:
+        raise ValueError("more partitions (%d) than histogram bins (%d)" % (num_parts, counts.size))
+    buf = ctypes.create_string_buffer(n)
+    L.gdbamd_equi_partition_text(counts.ctypes.data, counts.size, hist_begin, bin_size, num_parts, buf, n)
+    text = buf.raw[:n].decode()
+    parts = [tuple(int(x) for x in ln.split(",")) for ln in text.split("\n")[1:] if ln]
+    return parts, text
+
+
+def balanced_partition(counts, hist_begin, bin_size, rank, world):
+    """(begin, end) of rank's column partition when the loader JSON lists none: the reference's own recipe - count the cells
+    per column bin (gt_mpi_gather --produce-histogram) and cut where the running count passes total / world.  The greedy cut of
+    equi_partition_and_print_bins may come out with fewer lines than ranks when the load is lumpy; the last ranks then share the last
+    line's columns evenly."""
+    parts, _ = equi_partition(counts, hist_begin, bin_size, world)
+    if len(parts) >= world:
+        parts = parts[:world - 1] + [(parts[world - 1][0], parts[-1][1], sum(p[2] for p in parts[world - 1:]))]
+        b, e, _ = parts[rank]
+        return b, e
+    if rank < len(parts) - 1:
+        return parts[rank][0], parts[rank][1]
+    b, e, _ = parts[-1]
+    k, m = rank - (len(parts) - 1), world - (len(parts) - 1)
+    w = (e - b + 1) // m
+    return b + k * w, (e if k == m - 1 else b + (k + 1) * w - 1)
+
+
+def paged_concat(pages, sink, page_bytes, dst=0, ring_slots=3, device=None, stats=None):
     """Ordered concatenation of the ranks' page streams with BOUNDED memory on every rank: the single-stream view of the P
     per-partition outputs of `mpirun -n P gt_mpi_gather` (gt_mpi_gather.cc:322-366 writes P files; a combined stream is those
     files back to back in rank = column order).
 
     pages: this rank's pages, an iterable of 1-D uint8 tensors of at most `page_bytes` bytes each (HBM pages under "nccl" =
-    RCCL over xGMI, host tensors under "gloo"); a page need only stay valid until the next one is asked for.
+    RCCL over xGMI, host tensors under "gloo"); a page need only stay valid until the next one is asked for.  BGZF pages (an
+    engine created with output format "z" / "b") concatenate like any others - blocks are self-contained - and are ~6 x smaller.
     sink(t): called on rank `dst` once per page, in rank order and in each rank's page order; `t` is valid during the call only.
 
-    Rank `dst` never holds more than ring_slots pages of other ranks (a ring of receive buffers that is reused), a sending rank
-    never more than ring_slots copies of its own pages: a rank keeps scanning while its earlier pages wait for the root, and
-    stops when its ring is full.  Every page travels as an 8-byte header (its size; 0 closes the rank's stream) followed by
-    the bytes, point to point; there is no collective and no tensor of the size of a whole body anywhere (the round-2
-    gather_interval needed the sum of all bodies on the root).  Returns the number of bytes handed to `sink` (root) / sent."""
+    A sending rank keeps ring_slots copies of its own pages in flight and stops scanning when they are full.  Rank `dst` receives
+    from ALL ranks at once: every sender has its own ring of ring_slots receive buffers there (world x ring_slots x page_bytes on the
+    root: 24 GiB for 8 ranks, 3 slots, 1 GiB pages), so while rank r is being drained the ranks behind it can park that many pages
+    at the root on top of their own ring instead of stalling after theirs.  Every page travels as an 8-byte header (its size; 0
+    closes the rank's stream) followed by the bytes, point to point; there is no collective and no tensor of the size of a
+    whole body anywhere.  Returns the number of bytes handed to `sink` (root) / sent.  stats (a dict, optional) receives
+    "bytes", "seconds", "blocked_s" (sender: waiting for a free slot; root: waiting for a page of the rank being drained)."""
+    import time
     import torch
     import torch.distributed as dist
+    t_begin = time.time()
+    blocked = 0.0
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         total = 0
         for t in pages:
             sink(t)
             total += int(t.numel())
+        if stats is not None:
+            stats.update(bytes=total, seconds=time.time() - t_begin, blocked_s=0.0)
         return total
     world, rank = dist.get_world_size(), dist.get_rank()
     ring_slots = max(2, int(ring_slots))
     if rank != dst:
         ring, hdrs, pending, total, k = [], [], [], 0, 0
+        dev = device
         for t in pages:
             n = int(t.numel())
             if n == 0:
                 continue
             if n > page_bytes:
                 raise ValueError("page of %d bytes exceeds page_bytes %d" % (n, page_bytes))
+            dev = t.device
             slot = k % ring_slots
             if len(ring) <= slot:
                 ring.append(torch.empty(page_bytes, dtype=torch.uint8, device=t.device))
                 hdrs.append(torch.zeros(1, dtype=torch.int64, device=t.device))
             elif len(pending) >= ring_slots:          # the slot's previous page must have left
+                t0 = time.time()
                 for w in pending.pop(0):
                     w.wait()
+                blocked += time.time() - t0
             ring[slot][:n].copy_(t)                   # the engine's arena is reused by the next page:
             if t.is_cuda:                             # the copy (torch's stream) must be over before the engine (its own
                 torch.cuda.current_stream(t.device).synchronize()   # stream) is asked for the next one
@@ -148,52 +196,80 @@ def paged_concat(pages, sink, page_bytes, dst=0, ring_slots=3, device=None):
         for ws in pending:
             for w in ws:
                 w.wait()
-        end = torch.zeros(1, dtype=torch.int64, device=device if device is not None else (ring[0].device if ring else None))
+        end = torch.zeros(1, dtype=torch.int64, device=dev)   # (device=None with no page sent: a host tensor - fine under gloo; GPU backends pass `device`)
         dist.send(end, dst=dst)
+        if stats is not None:
+            stats.update(bytes=total, seconds=time.time() - t_begin, blocked_s=blocked)
         return total
-    total = 0
-    for t in pages:                                   # the root's own pages go straight to the sink where they lie
-        if int(t.numel()):
-            sink(t)
-            total += int(t.numel())
+    # ---- root: one receiver thread per sender, all of them fed concurrently; the sink is served strictly in rank order ----
+    # (threads, not polling: gloo's irecv only completes inside wait(), and a wait with a timeout closes the pair)
+    import queue
+    import threading
     dev = device
-    ring, inflight, k = [], [], 0                     # inflight: (work, view) in arrival order
-    hdr = None
+    total = 0
+
+    def receiver(src, out_q, free):
+        try:
+            if dev is not None and getattr(dev, "type", "cpu") == "cuda":
+                torch.cuda.set_device(dev)
+            hdr = torch.zeros(1, dtype=torch.int64, device=dev)
+            ring, k = [], 0
+            while True:
+                free.acquire()                          # a buffer the sink has given back (ring_slots of them)
+                dist.recv(hdr, src=src)
+                n = int(hdr.item())
+                if n == 0:
+                    out_q.put(None)
+                    return
+                if n > page_bytes:
+                    raise ValueError("rank %d announced a page of %d bytes, page_bytes is %d" % (src, n, page_bytes))
+                slot = k % ring_slots
+                k += 1
+                if len(ring) <= slot:
+                    ring.append(torch.empty(page_bytes, dtype=torch.uint8, device=dev))
+                view = ring[slot][:n]
+                dist.recv(view, src=src)
+                out_q.put(view)
+        except BaseException as e:                      # noqa: BLE001 - handed to the thread that drains
+            out_q.put(e)
+
+    rx = {}
     for r in range(world):
+        if r != dst:
+            qr, free = queue.Queue(), threading.Semaphore(ring_slots)
+            th = threading.Thread(target=receiver, args=(r, qr, free), daemon=True)
+            th.start()
+            rx[r] = (qr, free, th)
+    for r in range(world):                            # rank (= column) order, the root's own pages in their place
         if r == dst:
+            for t in pages:
+                if int(t.numel()):
+                    sink(t)
+                    total += int(t.numel())
             continue
+        qr, free, th = rx[r]
         while True:
-            if hdr is None:
-                hdr = torch.zeros(1, dtype=torch.int64, device=dev)
-            dist.recv(hdr, src=r)
-            n = int(hdr.item())
-            if n == 0:
+            t0 = time.time()
+            item = qr.get()
+            blocked += time.time() - t0
+            if item is None:
                 break
-            if n > page_bytes:
-                raise ValueError("rank %d announced a page of %d bytes, page_bytes is %d" % (r, n, page_bytes))
-            if len(inflight) >= ring_slots - 1 and len(ring) >= ring_slots:   # free the oldest slot: its page goes to the sink now
-                w, view = inflight.pop(0)
-                w.wait()
-                sink(view)
-                total += int(view.numel())
-            slot = k % ring_slots
-            if len(ring) <= slot:
-                ring.append(torch.empty(page_bytes, dtype=torch.uint8, device=dev))
-            view = ring[slot][:n]
-            inflight.append((dist.irecv(view, src=r), view))
-            k += 1
-    for w, view in inflight:
-        w.wait()
-        sink(view)
-        total += int(view.numel())
+            if isinstance(item, BaseException):
+                raise item
+            sink(item)
+            total += int(item.numel())
+            free.release()
+        th.join()
+    if stats is not None:
+        stats.update(bytes=total, seconds=time.time() - t_begin, blocked_s=blocked)
     return total
 
 
-def gather_interval_paged(engine, begin, end, sink, page_bytes=1 << 30, dst=0, ring_slots=3):
+def gather_interval_paged(engine, begin, end, sink, page_bytes=1 << 30, dst=0, ring_slots=3, stats=None):
     """produce-combined-VCF over all ranks with bounded memory: every rank scans + combines its own column interval on its GPU
     page by page (pages of at most page_bytes, left in HBM), rank `dst`'s sink sees the pages of all partitions in column order
     (see paged_concat).  At the width of BASELINE configs[3] (100 000 samples: ~9 MB of text per record) a body does not fit any
     single tensor; this is the form of the concat that still works there."""
     import torch
     dev = torch.device("cuda", torch.cuda.current_device())
-    return paged_concat(engine.page_tensors(begin, end, page_bytes), sink, page_bytes, dst=dst, ring_slots=ring_slots, device=dev)
+    return paged_concat(engine.page_tensors(begin, end, page_bytes), sink, page_bytes, dst=dst, ring_slots=ring_slots, device=dev, stats=stats)

@@ -138,6 +138,14 @@ int gdbamd_engine_adopt_device_fragment(void* engine, int64_t ncells, const int3
  * sits right before a cell begin >= column_begin + max_columns (the reference's sweep closes its interval at every cell
  * begin, query_variants.cc:478-505).  *piece_end = column_end when the interval is narrow enough or no cell begins in between. */
 int gdbamd_engine_split_point(void* engine, int64_t column_begin, int64_t column_end, int64_t max_columns, int64_t* piece_end);
+/* ColumnHistogramOperator (src/main/cpp/src/query_operations/variant_operations.cc:732-767; gt_mpi_gather --produce-histogram, tools/src/gt_mpi_gather.cc:404-411):
+ * the staged begin-cells counted on the device by the bin of their begin column.  nbins must be (hist_end - hist_begin) / bin_size + 1; a cell beginning at or
+ * before hist_begin counts for bin 0, one at or behind hist_end for the last bin.  accumulate != 0 adds to what counts holds (arrays streamed in windows). */
+int gdbamd_engine_column_histogram(void* engine, uint64_t hist_begin, uint64_t hist_end, uint64_t bin_size, uint64_t* counts, uint64_t nbins, int accumulate);
+/* ColumnHistogramOperator::equi_partition_and_print_bins (variant_operations.cc:769-796): the text the reference prints - "Total T #bins P count/bins X.X", one
+ * "first_column,last_column,count" line per partition of about equal cell count, an empty line.  Returns the text's length (dst may be NULL), -1 when
+ * num_parts >= nbins.  The lines are what column_partitions of a loader JSON should be for P ranks of equal load. */
+int64_t gdbamd_equi_partition_text(const uint64_t* counts, uint64_t nbins, uint64_t hist_begin, uint64_t bin_size, uint64_t num_parts, char* dst, uint64_t cap);
 /* the staged fragment as a columnar file, and back: file -> HBM copies without parsing.  gdb_mi355_init opens
  * <workspace>/<array>/fragment.gdbamd when present (else cells.bin).  This is the build's own format (the
  * Intel TileDB fork's on-disk format of the reference, variant_storage_manager.cc:61-153, is not available). */

@@ -12,6 +12,11 @@ import vcf2cells  # noqa: E402
 from golden_cases import VCF_ATTRIBUTES_ORDER  # noqa: E402
 
 INT64_MAX = 2**63 - 1
+
+
+def _bytes_at(addr, n):
+    """ctypes.string_at takes a C int: outputs of 2 GiB and more (100 000 samples: 4.5 MB and more per record) need the long way"""
+    return ctypes.string_at(addr, n) if n < (1 << 31) else bytes((ctypes.c_ubyte * n).from_address(addr))
 _cells_cache = {}
 
 
@@ -87,7 +92,7 @@ def oracle_run(query, cells, partition_begin=0, partition_end=INT64_MAX - 1, buf
                               ctypes.byref(secs), err, 4096)
     if rc != 0:
         raise RuntimeError("oracle: " + err.value.decode())
-    txt = ctypes.string_at(out.value, n.value)
+    txt = _bytes_at(out.value, n.value)
     lib.oracle_free(out)
     return txt, nrec.value, secs.value
 
@@ -120,7 +125,7 @@ def hostsim_run(query, cells, with_header=True, rows_per_chunk=2, records_per_ru
                                records_per_run, ctypes.byref(out), ctypes.byref(n), ctypes.byref(errbits), err, 4096)
     if rc != 0:
         raise RuntimeError("hostsim: " + err.value.decode())
-    txt = ctypes.string_at(out.value, n.value)
+    txt = _bytes_at(out.value, n.value)
     lib.hostsim_free(out)
     return txt, errbits.value
 
@@ -141,7 +146,7 @@ def oracle_run_synth(query, cells, seed, buffer_limit=0, with_header=True):
             ctypes.byref(n), ctypes.byref(nrec), ctypes.byref(secs), err, 4096)
     if rc != 0:
         raise RuntimeError("oracle: " + err.value.decode())
-    txt = ctypes.string_at(out.value, n.value)
+    txt = _bytes_at(out.value, n.value)
     lib.oracle_free(out)
     return txt, nrec.value, secs.value
 

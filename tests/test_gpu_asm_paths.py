@@ -64,8 +64,8 @@ def test_untabled_types_and_tiny_pages(gdb, tmp_path, monkeypatch, path, max_typ
     eng.set_reference(B, synth.reference(B, L + 4096))
     got, st = eng.run_interval(B + 500, B + 500 + L - 1, arena_bytes=1 << 20)
     assert st.num_records == nrec and got == want
-    got, st = eng.run_interval(B + 500, B + 500 + L - 1, arena_bytes=1)          # one record per page
-    assert st.pages == nrec and got == want
+    got, st = eng.run_interval(B + 500, B + 500 + L - 1, arena_bytes=1)          # pages of the largest record's size: one or two records each
+    assert st.pages > nrec // 2 and got == want
     monkeypatch.setenv("GDBAMD_RESOLVED_MB", "0")                                 # (path 2: the matrix page by page)
     got, st = eng.run_interval(B + 500, B + 500 + L - 1, arena_bytes=1 << 16)
     assert st.pages > 5 and got == want

@@ -151,6 +151,107 @@ def test_partitions_per_rank_and_paged_concat(world):
     assert any(b in (o for _, o, _ in GENOME) for b, _ in out["partitions"][1:])
 
 
+def test_c4_in_miniature_100000_rows_8_partitions():
+    """BASELINE.json configs[3] as ONE workload at test size: 100 000 samples x a whole (scaled-down) genome of six contigs x 8 column
+    partitions on 8 ranks (gloo: they share the box's GPU), the partitions cut by the reference's recipe - ColumnHistogramOperator on the
+    device + equi_partition_and_print_bins -, every rank's pages (4.5 MB of text per record) through the ordered paged concat to rank 0,
+    byte-identical there to the oracle run over the same partitioning; the partitions' cell counts are balanced"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, GDBAMD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(helpers.ROOT, "tests", "tools", "c4_sanity.py"), "100000", str(64 << 20), "60"],
+                       capture_output=True, timeout=1500, env=env)
+    assert r.returncode == 0, (r.stdout.decode()[-1500:], r.stderr.decode()[-3000:])
+    out = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert out["ok"] and out["ranks"] == 8 and len(out["partitions"]) == 8
+    assert out["contigs_in_order"] == ["1", "2", "3", "X", "Y", "MT"]
+    assert out["max_page"] <= 64 << 20 and out["pages"] >= 16                        # a record is 4.5 - 22 MB of text: a few per page
+    per, ideal = out["cells_per_partition"], out["cells"] / 8.0
+    assert sum(per) == out["cells"]
+    # the greedy cut closes a partition with the bin that takes it over total / P: no partition exceeds the ideal by more than one bin
+    assert max(per[:-1]) <= ideal + out["largest_bin"]
+
+
+def test_partitions_from_the_histogram_are_within_5_percent(gdb, tmp_path):
+    """genome-mode input with many columns per partition: 300 samples, 16 500 columns, 8 partitions from the device histogram (bins of 10
+    columns): every partition's cell count within 5 % of total / 8; the histogram itself equals numpy's over the cells' begin columns"""
+    import struct
+    import numpy as np
+    from genomicsdb_amd import synth, dist as gdist
+    N = 300
+    g = synth.Generator(N, 0, END, contigs=GENOME)
+    cells, _ = g.chunk_bytes(END)
+    q = helpers.synth_query(tmp_path, N, 0, END - 1, contigs=GENOME)
+    e = gdb.CombineEngine(q)
+    e.stage_cells(cells)
+    cols, off = [], 0
+    while off < len(cells):
+        _, col, sz = struct.unpack_from("<qqQ", cells, off)
+        cols.append(col); off += sz
+    for b0, b1, bin_size in ((0, END - 1, 10), (2000, 9999, 100), (0, 4_000_000_000, 1_000_000)):
+        got = e.column_histogram(b0, b1, bin_size)
+        idx = np.array([0 if c <= b0 else (len(got) - 1 if c >= b1 else (c - b0) // bin_size) for c in cols])
+        want = np.bincount(idx, minlength=len(got)).astype(np.uint64)
+        assert (got == want).all(), (b0, b1, bin_size)
+    counts = e.column_histogram(0, END - 1, 10)
+    spans = [gdist.balanced_partition(counts, 0, 10, r, 8) for r in range(8)]
+    assert spans[0][0] == 0 and all(spans[i][1] + 1 == spans[i + 1][0] for i in range(7))
+    per = [int(counts[b // 10:(e_ + 1) // 10].sum()) for b, e_ in spans]
+    assert sum(per) == len(cols)
+    assert all(abs(p - len(cols) / 8.0) <= 0.05 * len(cols) / 8.0 for p in per), per
+    e.close()
+
+
+def test_gt_mpi_gather_produce_histogram(gdb, tmp_path):
+    """the reference's `gt_mpi_gather --produce-histogram` (tools/src/gt_mpi_gather.cc:404-411, :600): cells per 100 columns of [0, 4e9) and
+    the equal-load partitions for 128 ... 2 ranks, in the text of ColumnHistogramOperator::equi_partition_and_print_bins; counted on the GPU,
+    checked against the same arithmetic in Python over the cells' begin columns"""
+    import struct
+    from golden_cases import CASES
+    case = [c for c in CASES if c[0] == "t0_1_2_vcf_at_0"][0]
+    _, callsets, vid, ov, golden, mode = case
+    cells = helpers.cells_for(callsets, vid)
+    q, _ = helpers.query_json(callsets, vid, ov, mode)
+    ws = tmp_path / "ws"
+    (ws / "t0_1_2").mkdir(parents=True)
+    (ws / "t0_1_2" / "cells.bin").write_bytes(cells)
+    q["workspace"] = str(ws); q["array"] = "t0_1_2"
+    qf = tmp_path / "query.json"
+    qf.write_text(json.dumps(q))
+    r = subprocess.run([os.path.join(helpers.ROOT, "genomicsdb_amd", "gt_mpi_gather"), "-j", str(qf), "--produce-histogram"], capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    cols, off = [], 0
+    while off < len(cells):
+        _, col, sz = struct.unpack_from("<qqQ", cells, off)
+        cols.append(col); off += sz
+    nbins = 4_000_000_000 // 100 + 1
+    hist = {}
+    for c in cols:
+        b = 0 if c <= 0 else (nbins - 1 if c >= 4_000_000_000 else c // 100)
+        hist[b] = hist.get(b, 0) + 1
+    want = ""
+    for parts in (128, 64, 32, 16, 8, 4, 2):
+        per = len(cols) / parts
+        want += "Total %d #bins %d count/bins %.1f\n" % (len(cols), parts, per)
+        i, keys = 0, sorted(hist)
+        while i < nbins:
+            cur, j = 0, i
+            while cur < per and j < nbins:      # (skipping over empty bins in one step: they add nothing)
+                nxt = next((k for k in keys if k >= j), None)
+                if nxt is None:
+                    j = nbins
+                    break
+                cur += hist[nxt]
+                j = nxt + 1
+            want += "%d,%d,%d\n" % (i * 100, j * 100 - 1, cur)
+            i = j
+        want += "\n"
+    assert r.stdout.decode() == want
+
+
 def test_rccl_paged_concat_one_rank(gdb, tmp_path):
     """the same concat over the "nccl" backend (= RCCL) with the pages in HBM; one GPU here, so one rank: device buffers and
     the page pull are exercised, ordering across ranks by the gloo runs above and tests/test_multi_rank_cpu.py"""

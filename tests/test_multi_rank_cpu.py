@@ -134,7 +134,7 @@ def test_two_ranks_import_their_partitions_and_concat():
     assert nc0 + nc1 > ncells_full          # the replayed intervals exist in both partitions
 
 
-def _paged_worker(rank, world, port, q):
+def _paged_worker(rank, world, port, q, dst=0):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -159,8 +159,10 @@ def _paged_worker(rank, world, port, q):
                 yield arena[:n]
         got = []
         live = {"max": 0}
-        total = gdist.paged_concat(pages(), lambda t: got.append(bytes(t.numpy().tobytes())), page_bytes=1000, dst=0, ring_slots=3)
-        assert total == sum(len(m) for m in mine) if rank else True
+        stats = {}
+        total = gdist.paged_concat(pages(), lambda t: got.append(bytes(t.numpy().tobytes())), page_bytes=1000, dst=dst, ring_slots=3, stats=stats)
+        assert total == sum(len(m) for m in mine) if rank != dst else True
+        assert stats["bytes"] == total and stats["seconds"] >= stats["blocked_s"] >= 0.0
         q.put((rank, mine, got, total))
     finally:
         dist.destroy_process_group()
@@ -184,6 +186,61 @@ def test_paged_concat_is_ordered_and_bounded():
     assert res[0][2] == want and len(want) == 5 + 13
     assert res[0][3] == sum(len(p) for p in want)
     assert res[1][2] == [] and res[2][2] == []
+
+
+def test_paged_concat_to_another_root_keeps_rank_order():
+    """dst = 2 of 3: the stream is still rank 0, rank 1, rank 2 (the root's own pages in their place, not first)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_paged_worker, args=(r, 3, port, q, 2)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = [pg for _, mine, _, _ in res for pg in mine]
+    assert res[2][2] == want and res[0][2] == [] and res[1][2] == []
+    assert res[2][3] == sum(len(p) for p in want)
+
+
+def test_equi_partition_prints_what_the_reference_prints():
+    """ColumnHistogramOperator::equi_partition_and_print_bins (variant_operations.cc:769-796) on a histogram small enough to do by hand:
+    bins of 100 columns from 1000, counts 5 1 1 1 8 0 0 4 -> total 20; 2 parts of 10.0: bins 0-4 (16 >= 10 after the 5th), then 5-7 (4);
+    4 parts of 5.0: [0], [1-4] (11), [5-7] (4)"""
+    import numpy as np
+    from genomicsdb_amd import dist as gdist
+    counts = np.array([5, 1, 1, 1, 8, 0, 0, 4], dtype=np.uint64)
+    parts, text = gdist.equi_partition(counts, 1000, 100, 2)
+    assert text == "Total 20 #bins 2 count/bins 10.0\n1000,1499,16\n1500,1799,4\n\n"
+    assert parts == [(1000, 1499, 16), (1500, 1799, 4)]
+    parts, text = gdist.equi_partition(counts, 1000, 100, 4)
+    assert text == "Total 20 #bins 4 count/bins 5.0\n1000,1099,5\n1100,1499,11\n1500,1799,4\n\n"
+    with pytest.raises(ValueError):
+        gdist.equi_partition(counts, 1000, 100, 8)
+    # every rank gets a partition, the partitions tile the histogram's columns in order
+    for world in (2, 3, 4, 5):
+        spans = [gdist.balanced_partition(counts, 1000, 100, r, world) for r in range(world)]
+        assert spans[0][0] == 1000 and spans[-1][1] == 1799
+        assert all(spans[i][1] + 1 == spans[i + 1][0] for i in range(world - 1)), spans
+
+
+def test_bench_concat_leg_accounts_for_every_byte():
+    """`bench.py --gpus 3 --concat --dry-run`: the ranks' (synthetic) pages go through dist.paged_concat to rank 0; the line carries
+    the bytes, the rate and how long ranks were blocked"""
+    import subprocess
+    env = dict(os.environ, GDBAMD_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--dry-run", "--concat", "--interval-bp", "1000"],
+                       capture_output=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    out = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][0])
+    c = out["concat"]
+    assert c["ranks"] == 3 and c["bytes"] == sum((r + 1) * 8 * (1 << 20) for r in range(3)) and c["pages"] == 8 * 3
+    assert c["GBps"] > 0 and c["root_blocked_s"] >= 0 and c["max_sender_blocked_s"] >= 0 and c["ordered"] is True
 
 
 def test_bench_launches_its_own_ranks():
