@@ -17,12 +17,12 @@ struct RunResult { std::string text; uint64_t num_records = 0; uint64_t num_cell
 
 RunResult run_query(const std::string& query_json_text, const uint8_t* cells, uint64_t nbytes, int64_t partition_begin, int64_t partition_end,
                     uint64_t buffer_limit, bool with_header, const ReferenceGenome* external_ref) {
-  mini_json::Value q = mini_json::parse(query_json_text);
+  oracle_json::Value q = oracle_json::parse(query_json_text);
   VidMapper vid;
-  if (q.HasMember("vid_mapping_file")) vid.load_vid(mini_json::parse_file(q["vid_mapping_file"].GetString()));
+  if (q.HasMember("vid_mapping_file")) vid.load_vid(oracle_json::parse_file(q["vid_mapping_file"].GetString()));
   else if (q.HasMember("vid_mapping")) vid.load_vid(q["vid_mapping"]);
   else throw OracleException("query JSON needs vid_mapping_file or vid_mapping");
-  if (q.HasMember("callset_mapping_file")) vid.load_callsets(mini_json::parse_file(q["callset_mapping_file"].GetString()));
+  if (q.HasMember("callset_mapping_file")) vid.load_callsets(oracle_json::parse_file(q["callset_mapping_file"].GetString()));
   else if (q.HasMember("callset_mapping") || q.HasMember("callsets")) vid.load_callsets(q);
   else throw OracleException("query JSON needs callset_mapping_file or callset_mapping");
   VariantArray array;
@@ -33,7 +33,7 @@ RunResult run_query(const std::string& query_json_text, const uint8_t* cells, ui
   qc.read_query_json(q, vid, 0);
   qc.do_query_bookkeeping(array.schema, vid, array.num_rows, 0);
   std::string tmpl;
-  if (!qc.vcf_header_filename.empty()) tmpl = mini_json::read_text_file(qc.vcf_header_filename);
+  if (!qc.vcf_header_filename.empty()) tmpl = oracle_json::read_text_file(qc.vcf_header_filename);
   ReferenceGenome ref_local;
   const ReferenceGenome* ref = external_ref;
   if (!ref && !qc.reference_genome.empty()) { ref_local.load_fasta(qc.reference_genome); ref = &ref_local; }
@@ -97,9 +97,9 @@ int oracle_run_query_synthetic_reference(const char* query_json_text, const uint
     // the generator's bases are a function of the COLUMN (flattened genome); the operator asks by (contig, position in contig)
     std::map<std::string, int64_t> contig_offset;
     {
-      mini_json::Value q = mini_json::parse(query_json_text);
+      oracle_json::Value q = oracle_json::parse(query_json_text);
       VidMapper vid;
-      if (q.HasMember("vid_mapping_file")) vid.load_vid(mini_json::parse_file(q["vid_mapping_file"].GetString()));
+      if (q.HasMember("vid_mapping_file")) vid.load_vid(oracle_json::parse_file(q["vid_mapping_file"].GetString()));
       else if (q.HasMember("vid_mapping")) vid.load_vid(q["vid_mapping"]);
       for (auto& c : vid.contigs) contig_offset[c.name] = c.offset;
     }
@@ -126,10 +126,10 @@ int oracle_run_query_synthetic_reference(const char* query_json_text, const uint
 
 void oracle_free(char* p) { free(p); }
 
-// ---- common-mode check of the two utilities the oracle shares with the product (csrc/common/mini_json.hpp, gz_text.hpp): the
-// tests compare them with Python's json / gzip modules on every fixture file (tests/test_common_utils.py) ----------------------
-static void json_dump(const mini_json::Value& v, std::string& o) {
-  using V = mini_json::Value;
+// ---- the oracle's own JSON / gzip readers (oracle_json.hpp; nothing is shared with the product since round 4) laid open to the tests, which
+// compare them with Python's json / gzip modules on every fixture file (tests/test_common_utils.py; the product's readers: tests/hostsim) ----
+static void json_dump(const oracle_json::Value& v, std::string& o) {
+  using V = oracle_json::Value;
   char buf[64];
   switch (v.type) {
     case V::Null: o += "n"; break;
@@ -145,15 +145,15 @@ static void json_dump(const mini_json::Value& v, std::string& o) {
 int oracle_json_dump(const char* text, char** out, uint64_t* out_len, char* err, uint64_t errlen) {
   try {
     std::string o;
-    json_dump(mini_json::parse(text), o);
+    json_dump(oracle_json::parse(text), o);
     *out = (char*)malloc(o.size() + 1); memcpy(*out, o.data(), o.size()); (*out)[o.size()] = 0; *out_len = o.size();
     return 0;
   } catch (const std::exception& e) { if (err && errlen) snprintf(err, errlen, "%s", e.what()); return 1; }
 }
-// the bytes gz_text::read_all gives for a (possibly gzip / BGZF compressed) file
+// the bytes oracle_json::gz_read_all gives for a (possibly gzip / BGZF compressed) file
 int oracle_gz_read_all(const char* path, char** out, uint64_t* out_len, char* err, uint64_t errlen) {
   try {
-    std::string o = gz_text::read_all(path);
+    std::string o = oracle_json::gz_read_all(path);
     *out = (char*)malloc(o.size() + 1); memcpy(*out, o.data(), o.size()); (*out)[o.size()] = 0; *out_len = o.size();
     return 0;
   } catch (const std::exception& e) { if (err && errlen) snprintf(err, errlen, "%s", e.what()); return 1; }
@@ -187,8 +187,8 @@ int oracle_genotype_map(const int64_t* lut_m2i, unsigned num_merged, int non_ref
 #ifdef ORACLE_MAIN
 int main(int argc, char** argv) {
   if (argc < 3) { fprintf(stderr, "usage: %s <query.json> <cells.bin> [buffer_limit]\n", argv[0]); return 2; }
-  std::string q = mini_json::read_text_file(argv[1]);
-  std::string cells = mini_json::read_text_file(argv[2]);
+  std::string q = oracle_json::read_text_file(argv[1]);
+  std::string cells = oracle_json::read_text_file(argv[2]);
   uint64_t lim = argc > 3 ? strtoull(argv[3], nullptr, 10) : 0;
   try {
     RunResult rr = run_query(q, (const uint8_t*)cells.data(), cells.size(), 0, INT64_MAX - 1, lim, true, nullptr);

@@ -25,7 +25,7 @@
 #include <unordered_set>
 
 #include "gdb_oracle_scan.hpp"
-#include "gz_text.hpp"
+#include "oracle_json.hpp"
 
 namespace gdb_oracle {
 
@@ -381,7 +381,7 @@ inline void vcf_format(const BcfRecord& r, std::string& s) {
 class ReferenceGenome {
  public:
   void load_fasta(const std::string& path) {
-    std::string txt = gz_text::read_all(path);
+    std::string txt = oracle_json::gz_read_all(path);
     size_t p = 0;
     std::string* cur = nullptr;
     while (p < txt.size()) {

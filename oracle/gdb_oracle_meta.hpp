@@ -22,7 +22,7 @@
 #include <unordered_map>
 #include <vector>
 
-#include "mini_json.hpp"
+#include "oracle_json.hpp"
 
 namespace gdb_oracle {
 
@@ -206,13 +206,13 @@ class VidMapper {
     return false;
   }
 
-  void load_vid(const mini_json::Value& doc) {
+  void load_vid(const oracle_json::Value& doc) {
     ORACLE_VERIFY(doc.HasMember("contigs"));
     const auto& cc = doc["contigs"];
     ORACLE_VERIFY(cc.IsObject() || cc.IsArray());
     size_t nc = cc.Size();
     for (size_t i = 0; i < nc; ++i) {
-      const mini_json::Value& d = cc.IsArray() ? cc[i] : cc.obj[i].second;
+      const oracle_json::Value& d = cc.IsArray() ? cc[i] : cc.obj[i].second;
       ContigInfo ci;
       if (cc.IsArray()) {
         for (const char* k : {"name", "contig_name", "chromosome_name"})
@@ -229,7 +229,7 @@ class VidMapper {
     ORACLE_VERIFY(doc.HasMember("fields"));
     const auto& fc = doc["fields"];
     for (size_t i = 0; i < fc.Size(); ++i) {
-      const mini_json::Value& d = fc.IsArray() ? fc[i] : fc.obj[i].second;
+      const oracle_json::Value& d = fc.IsArray() ? fc[i] : fc.obj[i].second;
       std::string name = fc.IsArray() ? (d.HasMember("name") ? d["name"].GetString() : d["field_name"].GetString())
                                       : fc.obj[i].first;
       if (field_name_to_idx.count(name)) throw OracleException("Duplicate field name " + name);
@@ -300,10 +300,10 @@ class VidMapper {
     return get_field_info(fi->name + "_tuple_element_" + std::to_string(tuple_element_index));
   }
 
-  void load_callsets(const mini_json::Value& doc) {
-    const mini_json::Value& cs = doc.HasMember("callsets") ? doc["callsets"] : doc["callset_mapping"]["callsets"];
+  void load_callsets(const oracle_json::Value& doc) {
+    const oracle_json::Value& cs = doc.HasMember("callsets") ? doc["callsets"] : doc["callset_mapping"]["callsets"];
     for (size_t i = 0; i < cs.Size(); ++i) {
-      const mini_json::Value& d = cs.IsArray() ? cs[i] : cs.obj[i].second;
+      const oracle_json::Value& d = cs.IsArray() ? cs[i] : cs.obj[i].second;
       std::string name;
       if (cs.IsArray()) {
         for (const char* k : {"sample_name", "name", "callset_name"}) if (d.HasMember(k)) name = d[k].GetString();
@@ -334,7 +334,7 @@ class VidMapper {
     if (s == "histogram_sum") return OP_HISTOGRAM_SUM;
     throw OracleException("Unknown VCF field combine operation " + s + " specified for field " + field);
   }
-  static void parse_length(const std::string& name, const mini_json::Value& v, FieldInfo& f) {
+  static void parse_length(const std::string& name, const oracle_json::Value& v, FieldInfo& f) {
     if (v.IsInt64()) { f.ld = VL_FIXED; f.num_elements = (unsigned)v.GetInt64(); return; }
     if (v.IsString()) {  // vid_mapper.cc:802-830
       std::string up = v.GetString();
@@ -484,7 +484,7 @@ class QueryConfig {
   }
 
   // JSONConfigBase::read_from_file (json_config.cc:195-658), the keys the scan/combine path reads
-  void read_query_json(const mini_json::Value& j, const VidMapper& vid, int rank = 0) {
+  void read_query_json(const oracle_json::Value& j, const VidMapper& vid, int rank = 0) {
     if (j.HasMember("scan_full")) {
       scan_full = true;
     } else if (j.HasMember("query_column_ranges")) {
@@ -493,7 +493,7 @@ class QueryConfig {
       size_t idx = q1.Size() == 1 ? 0 : (size_t)rank;
       ORACLE_VERIFY(idx < q1.Size());
       const auto& e = q1[idx];
-      const mini_json::Value* q2 = &e;
+      const oracle_json::Value* q2 = &e;
       if (e.IsObject()) {
         if (e.MemberCount() == 0) q2 = nullptr;
         else q2 = e.HasMember("range_list") ? &e["range_list"] : &e["column_or_interval_list"];
@@ -539,7 +539,7 @@ class QueryConfig {
       const auto& q1 = j["query_row_ranges"];
       size_t idx = q1.Size() == 1 ? 0 : (size_t)rank;
       const auto& e = q1[idx];
-      const mini_json::Value& q2 = e.IsArray() ? e : e["range_list"];
+      const oracle_json::Value& q2 = e.IsArray() ? e : e["range_list"];
       std::vector<int64_t> rows;
       for (size_t k = 0; k < q2.Size(); ++k) {
         const auto& q3 = q2[k];

@@ -18,6 +18,7 @@
 #include "../../genomicsdb_amd/csrc/host/combine_plan.h"
 #include "../../genomicsdb_amd/csrc/host/fragment.h"
 #include "../../genomicsdb_amd/csrc/host/reference_genome.h"
+#include "../../genomicsdb_amd/csrc/common/gz_text.hpp"
 
 using namespace genomicsdb_amd;
 
@@ -304,6 +305,37 @@ int hostsim_put_float(float v, char* buf, uint64_t cap) {
   put_float(s, v);
   if (s.n < cap) buf[s.n] = 0;
   return (int)s.n;
+}
+
+// the PRODUCT's JSON / gzip readers (csrc/common/mini_json.hpp, gz_text.hpp) laid open to the tests the same way the oracle lays open its own
+// (oracle/oracle_json.hpp): both are compared with Python's json / gzip modules (tests/test_common_utils.py)
+static void hostsim_json_dump_value(const mini_json::Value& v, std::string& o) {
+  using V = mini_json::Value;
+  char buf[64];
+  switch (v.type) {
+    case V::Null: o += "n"; break;
+    case V::Bool: o += v.b ? "t" : "f"; break;
+    case V::Int: snprintf(buf, sizeof buf, "i%lld", (long long)v.i); o += buf; break;
+    case V::Double: snprintf(buf, sizeof buf, "d%.17g", v.d); o += buf; break;
+    case V::String: o += "s"; for (unsigned char c : v.s) { snprintf(buf, sizeof buf, "%02x", c); o += buf; } break;
+    case V::Array: o += "["; for (auto& e : v.arr) { hostsim_json_dump_value(e, o); o += ","; } o += "]"; break;
+    case V::Object: o += "{"; for (auto& kv : v.obj) { for (unsigned char c : kv.first) { snprintf(buf, sizeof buf, "%02x", c); o += buf; } o += ":"; hostsim_json_dump_value(kv.second, o); o += ","; } o += "}"; break;
+  }
+}
+int hostsim_json_dump(const char* text, char** out, uint64_t* out_len, char* err, uint64_t errlen) {
+  try {
+    std::string o;
+    hostsim_json_dump_value(mini_json::parse(text), o);
+    *out = (char*)malloc(o.size() + 1); memcpy(*out, o.data(), o.size()); (*out)[o.size()] = 0; *out_len = o.size();
+    return 0;
+  } catch (const std::exception& e) { if (err && errlen) snprintf(err, errlen, "%s", e.what()); return 1; }
+}
+int hostsim_gz_read_all(const char* path, char** out, uint64_t* out_len, char* err, uint64_t errlen) {
+  try {
+    std::string o = gz_text::read_all(path);
+    *out = (char*)malloc(o.size() + 1); memcpy(*out, o.data(), o.size()); (*out)[o.size()] = 0; *out_len = o.size();
+    return 0;
+  } catch (const std::exception& e) { if (err && errlen) snprintf(err, errlen, "%s", e.what()); return 1; }
 }
 
 }  // extern "C"

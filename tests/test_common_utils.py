@@ -1,6 +1,7 @@
-"""The oracle and the product share two format-agnostic utilities (csrc/common/mini_json.hpp, gz_text.hpp): a parsing bug there
-would be common-mode - invisible to every product-vs-oracle comparison.  Here both are checked against independent
-implementations (Python's json and gzip modules) on every fixture file of the tree and on hostile hand-made inputs."""
+"""JSON and (b)gzip readers.  Until round 3 the oracle read its files through the product's csrc/common/mini_json.hpp and gz_text.hpp: a
+misreading there would have been common to checker and checked.  Now the oracle has readers of its own (oracle/oracle_json.hpp, written
+independently); here BOTH pairs are compared with Python's json and gzip modules on every fixture file of the tree and on hostile hand-made
+inputs - the oracle's through liboracle_gvcf.so, the product's through the kernel-body harness tests/hostsim."""
 import ctypes
 import glob
 import gzip
@@ -39,17 +40,42 @@ class _Obj:
         self.pairs = pairs
 
 
-def _dump_native(text):
-    lib = helpers.oracle_lib()
-    lib.oracle_json_dump.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p, ctypes.c_uint64]
+def _native(which, kind):
+    """(function, free) of the oracle's / the product's reader"""
+    if which == "oracle":
+        lib = helpers.oracle_lib()
+        return getattr(lib, "oracle_json_dump" if kind == "json" else "oracle_gz_read_all"), lib.oracle_free
+    lib = helpers.hostsim_lib()
+    return getattr(lib, "hostsim_json_dump" if kind == "json" else "hostsim_gz_read_all"), lib.hostsim_free
+
+
+def _dump_one(which, text):
+    fn, free = _native(which, "json")
+    fn.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p, ctypes.c_uint64]
+    free.argtypes = [ctypes.c_void_p]
     out, n = ctypes.c_void_p(), ctypes.c_uint64()
     err = ctypes.create_string_buffer(512)
-    rc = lib.oracle_json_dump(text if isinstance(text, bytes) else text.encode("utf-8"), ctypes.byref(out), ctypes.byref(n), err, 512)
+    rc = fn(text if isinstance(text, bytes) else text.encode("utf-8"), ctypes.byref(out), ctypes.byref(n), err, 512)
     if rc != 0:
         raise ValueError(err.value.decode())
     s = ctypes.string_at(out.value, n.value).decode()
-    lib.oracle_free(out)
+    free(out)
     return s
+
+
+def _dump_native(text):
+    """both readers must succeed and agree (or both refuse)"""
+    res = []
+    for which in ("oracle", "product"):
+        try:
+            res.append(_dump_one(which, text))
+        except ValueError as e:
+            res.append(e)
+    if isinstance(res[0], ValueError) or isinstance(res[1], ValueError):
+        assert isinstance(res[0], ValueError) and isinstance(res[1], ValueError), res
+        raise res[0]
+    assert res[0] == res[1]
+    return res[0]
 
 
 JSON_FILES = sorted(glob.glob(os.path.join(FIXTURES, "*.json")) + glob.glob(os.path.join(FIXTURES, "callsets", "*.json")))
@@ -86,16 +112,20 @@ def test_mini_json_refuses_what_python_refuses(doc):
 
 
 def _gz_native(path):
-    lib = helpers.oracle_lib()
-    lib.oracle_gz_read_all.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p, ctypes.c_uint64]
-    out, n = ctypes.c_void_p(), ctypes.c_uint64()
-    err = ctypes.create_string_buffer(512)
-    rc = lib.oracle_gz_read_all(os.fsencode(path), ctypes.byref(out), ctypes.byref(n), err, 512)
-    if rc != 0:
-        raise ValueError(err.value.decode())
-    b = ctypes.string_at(out.value, n.value)
-    lib.oracle_free(out)
-    return b
+    got = []
+    for which in ("oracle", "product"):
+        fn, free = _native(which, "gz")
+        fn.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p, ctypes.c_uint64]
+        free.argtypes = [ctypes.c_void_p]
+        out, n = ctypes.c_void_p(), ctypes.c_uint64()
+        err = ctypes.create_string_buffer(512)
+        rc = fn(os.fsencode(path), ctypes.byref(out), ctypes.byref(n), err, 512)
+        if rc != 0:
+            raise ValueError(err.value.decode())
+        got.append(ctypes.string_at(out.value, n.value))
+        free(out)
+    assert got[0] == got[1]
+    return got[0]
 
 
 GZ_FILES = sorted(glob.glob(os.path.join(FIXTURES, "**", "*.gz"), recursive=True))
@@ -119,3 +149,12 @@ def test_gz_text_plain_multi_member_and_empty(tmp_path):
     e = tmp_path / "empty.gz"
     e.write_bytes(gzip.compress(b""))
     assert _gz_native(str(e)) == b""
+
+
+def test_the_oracle_includes_nothing_of_the_product():
+    """the dependency direction the round-3 review asked for: oracle/ builds from its own files alone"""
+    odir = os.path.join(helpers.ROOT, "oracle")
+    for fn in os.listdir(odir):
+        if fn.endswith((".hpp", ".cc", ".h")) or fn == "Makefile":
+            text = open(os.path.join(odir, fn)).read()
+            assert "genomicsdb_amd/csrc" not in text and '#include "mini_json.hpp"' not in text and '#include "gz_text.hpp"' not in text, fn
