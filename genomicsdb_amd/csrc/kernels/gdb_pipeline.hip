@@ -62,6 +62,9 @@ constexpr int kCountSpread = 64;     // addresses a device-wide counter is sprea
 // Device blocks of the staging path (the parts of a fragment being staged, the merged fragment) are kept and handed out again:
 // hipFree synchronises the whole device, and with a second pipeline staging the next column window while this one computes
 // (CombineEngine's overlapped staging) a free on the staging thread would wait for - and serialise with - the page kernels.
+// (put() keeps the memory: after finish_staging the blocks of the parts stay with the pool next to the merged fragment, and an engine over a
+//  windowed source owns two pipelines with a pool each - resident HBM for staging is up to ~4 x one window of GDBAMD_STAGE_BUDGET_MB; a block
+//  more than twice a request + 4 MB large is not handed out for it.  Size the budget with that factor in mind.)
 struct BlockPool {
   struct Block { void* p; size_t cap; bool used; };
   std::vector<Block> blocks;
@@ -4826,7 +4829,10 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   if (left_texts > 0 && left_texts <= kBumpLimit) {
     // room in every shard's part for the texts pass 0 left, behind what it has placed there (kept when the pool has to grow)
     const uint32_t old_su = stt.bump_cap;
-    if ((uint64_t)old_su < shard_need) {
+    // (pass 0 with the narrow strip places nothing - old_su == 0 -: the pool of an earlier interval is taken as it is when it is large enough;
+    //  a hipFree would synchronise the whole device and stall the other pipeline's overlapped staging once per interval)
+    const bool reuse = old_su == 0 && (uint64_t)shard_units_of(S.pool_ovf.cap) >= shard_need;
+    if ((uint64_t)old_su < shard_need && !reuse) {
       const uint64_t su = shard_need + (shard_need >> 3) + 4;
       const size_t ncap = (size_t)su * 16 * kBumpShards + 64;
       char* np = nullptr;

@@ -59,7 +59,7 @@ void* gdb_mi355_init_from_memory_format(const char* query_json_text, const uint8
                                         int produce_header_only, int is_bcf, int use_missing_values_only_not_vector_end, int keep_idx_fields_in_bcf_header);
 /* The same two with the reference's vcf_output_format string instead of the JNI's is_bcf flag: "" VCF text, "bu" BCF2, and the
  * BGZF-compressed flavours "z" (VCF text) / "b" (BCF2) that its VCFAdapter writes through htslib (vcf_adapter.cc:340-372,
- * genomicsdb_config_base.cc:34,156-165).  "z" / "b": header = one BGZF block (host), body = BGZF blocks of 16 320 input bytes
+ * genomicsdb_config_base.cc:34,156-165).  "z" / "b": header = one BGZF block (host), body = BGZF blocks of 8 192 input bytes (GDBAMD_BGZF_BLOCK = 4096 / 6144 / 8192 / 16384)
  * deflated ON THE DEVICE (only compressed bytes cross PCIe), then the 28-byte EOF block.  The compressed bytes are this build's
  * own; the inflated stream equals the "" / "bu" stream. */
 void* gdb_mi355_init_output_format(const char* loader_json_file, const char* query_json_file, const char* chr, int start, int end, int rank,

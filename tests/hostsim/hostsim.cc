@@ -307,6 +307,19 @@ int hostsim_put_float(float v, char* buf, uint64_t cap) {
   return (int)s.n;
 }
 
+// the typed-value encoder of the BCF2 path (gdb_core.hpp: bcf_enc_vint / bcf_enc_size / bcf_enc_int1) for the byte-level known answers of
+// tests/test_bcf_typed_values.py (derived from the BCFv2.2 specification, not from the tests' own decoder)
+int hostsim_bcf_enc_vint(const int32_t* a, int n, uint8_t* out, int cap) {
+  struct S { uint8_t* p; int cap, n; void put(char c) { if (n < cap) p[n] = (uint8_t)c; ++n; } } s{out, cap, 0};
+  bcf_enc_vint(s, a, n);
+  return s.n;
+}
+int hostsim_bcf_enc_size(int size, int type, uint8_t* out, int cap) {
+  struct S { uint8_t* p; int cap, n; void put(char c) { if (n < cap) p[n] = (uint8_t)c; ++n; } } s{out, cap, 0};
+  bcf_enc_size(s, size, type);
+  return s.n == bcf_enc_size_bytes(size) ? s.n : -1;
+}
+
 // the PRODUCT's JSON / gzip readers (csrc/common/mini_json.hpp, gz_text.hpp) laid open to the tests the same way the oracle lays open its own
 // (oracle/oracle_json.hpp): both are compared with Python's json / gzip modules (tests/test_common_utils.py)
 static void hostsim_json_dump_value(const mini_json::Value& v, std::string& o) {
