@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--no-c3", action="store_true", help="skip the c3-shape leg (10 000 samples streamed through HBM in column windows)")
     ap.add_argument("--c3-bp", type=int, default=10_000_000, help="columns of the c3-shape leg (10 000 samples: 14.6 GB of cells per Mb, generated into host memory first)")
     ap.add_argument("--cpu-sample-bp", type=int, default=12000, help="columns of the bounded CPU-baseline sample (~15 s of oracle time)")
+    ap.add_argument("--c3-full", action="store_true",
+                    help="BASELINE.json configs[2] at its stated size: 10 000 samples x whole chr1 (249 250 621 bp, ~3.6 TB of cells) streamed through HBM in one pass "
+                         "(= --samples 10000 --interval-bp 249250621 --window-bp 50000 --stream-input); ~15 minutes, most of it the synthetic generator")
     ap.add_argument("--concat", action="store_true",
                     help="N > 1: after the timed steps every rank's pages of one window go to rank 0 in column order (dist.gather_interval_paged: the single-stream "
                          "view of the partitions' outputs); the line carries \"concat\": bytes, GB/s, how long the root and the senders were blocked")
@@ -55,6 +58,8 @@ def main():
                     help="rank set-up, partition arithmetic and the cross-rank reduction only, no device work and no number: "
                          "lets the CPU suite check the N-rank launch (the line says \"dry_run\": true and carries value null)")
     args = ap.parse_args()
+    if args.c3_full:
+        args.samples, args.interval_bp, args.window_bp, args.stream_input = 10000, 249_250_621, 50_000, True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # launched bare (`python bench.py --gpus N`): become N ranks, one per GPU, like `mpirun -n N gt_mpi_gather`

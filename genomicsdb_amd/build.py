@@ -24,6 +24,7 @@ SOURCES = [
     "host/fragment.cc",
     "host/reference_genome.cc",
     "host/vcf_importer.cc",
+    "host/vcf_index.cc",
     "api/genomicsdb_bcf_generator.cc",
     "api/genomicsdb_operators.cc",
     "api/capi.cc",

@@ -9,6 +9,7 @@
 #include "genomicsdb_bcf_generator.h"
 #include "../kernels/gdb_bgzf.h"
 #include "../host/vcf_importer.h"
+#include "../host/vcf_index.h"
 
 using namespace genomicsdb_amd;
 
@@ -289,6 +290,9 @@ int64_t gdbamd_equi_partition_text(const uint64_t* counts, uint64_t nbins, uint6
   out += "\n";
   if (dst && cap) { const size_t n = std::min<size_t>(out.size(), (size_t)cap); memcpy(dst, out.data(), n); }
   return (int64_t)out.size();
+}
+int gdbamd_build_output_index(const char* path, int is_bcf) {
+  try { if (is_bcf) build_csi_index(path); else build_tbi_index(path); return 0; } catch (const std::exception& e) { g_last_error = e.what(); return -1; }
 }
 int gdbamd_engine_save_fragment(void* engine, const char* path) {
   try { ((EngineHandle*)engine)->eng->save_fragment(path); return 0; } catch (const std::exception& e) { g_last_error = e.what(); return -1; }

@@ -1,4 +1,5 @@
 #include "genomicsdb_operators.h"
+#include "../host/vcf_index.h"
 #include "../kernels/gdb_bgzf.h"
 
 #include <typeinfo>
@@ -37,6 +38,11 @@ VCFAdapter::~VCFAdapter() {
   // BGZF output ("z" / "b"): the file ends with the empty EOF block, as htslib's bgzf_close leaves it
   if (m_out && m_wrote_bytes && (m_output_format == "z" || m_output_format == "b")) (void)fwrite(kBgzfEofBlock, 1, sizeof(kBgzfEofBlock), m_out);
   if (m_out && m_owns_out) fclose(m_out); else if (m_out) fflush(m_out);
+  // "index_output_VCF": the reference builds the index here, from the finished file (vcf_adapter.cc:275-295: tbx_index_build for "z", bcf_index_build(.., 14) for "b")
+  if (m_out && m_owns_out && m_index_output && m_wrote_bytes && (m_output_format == "z" || m_output_format == "b")) {
+    try { if (m_output_format == "z") build_tbi_index(m_output_filename); else build_csi_index(m_output_filename); }
+    catch (const std::exception& e) { fprintf(stderr, "WARNING: error in creating index for output file %s: %s\n", m_output_filename.c_str(), e.what()); }
+  }
 }
 
 void VCFAdapter::initialize(const VariantQueryConfig& qc) {
@@ -46,6 +52,7 @@ void VCFAdapter::initialize(const VariantQueryConfig& qc) {
   const std::string& fn = qc.get_vcf_output_filename();
   if (fn.empty() || fn == "-") { m_out = stdout; m_owns_out = false; }
   else { m_out = fopen(fn.c_str(), "wb"); m_owns_out = true; if (!m_out) throw VCFAdapterException("cannot open " + fn); }
+  m_output_filename = fn; m_index_output = qc.index_output_VCF();
 }
 void VCFAdapter::handoff(const uint8_t* bytes, size_t n) {
   if (!m_out) throw VCFAdapterException("VCFAdapter::initialize() has not opened an output");

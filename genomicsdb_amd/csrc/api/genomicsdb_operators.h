@@ -59,8 +59,8 @@ class VCFAdapter {
  protected:
   bool m_open_output;
   FILE* m_out = nullptr;
-  bool m_owns_out = false, m_wrote_bytes = false;
-  std::string m_output_format;
+  bool m_owns_out = false, m_wrote_bytes = false, m_index_output = false;   // m_index_output: "index_output_VCF" (.tbi / .csi when the file closes)
+  std::string m_output_format, m_output_filename;
   size_t m_buffer_limit = 1048576u;
 };
 class VCFSerializedBufferAdapter : public VCFAdapter {

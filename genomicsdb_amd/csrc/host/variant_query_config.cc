@@ -1,4 +1,8 @@
 #include "variant_query_config.h"
+#include <cstdlib>
+#include <cstdio>
+#include <set>
+#include <mutex>
 
 #include <algorithm>
 #include <climits>
@@ -229,7 +233,20 @@ void VariantQueryConfig::read_from_json(const mini_json::Value& j, int rank, con
   m_produce_GT_field = flag("produce_GT_field");
   m_produce_FILTER_field = flag("produce_FILTER_field");
   m_sites_only_query = flag("sites_only_query");
+  m_index_output_VCF = flag("index_output_VCF");   // json_config.cc:648: a .tbi ("z") / .csi ("b") next to the output file
   m_produce_GT_with_min_PL_value_for_spanning_deletions = flag("produce_GT_with_min_PL_value_for_spanning_deletions");
+  // Keys of the reference's query JSON (json_config.cc) that are accepted here and change nothing: said once per key and process, on stderr,
+  // instead of being swallowed (GDBAMD_QUIET_JSON=1 silences it).  segment_size sizes TileDB's read buffers (this build stages column windows of
+  // GDBAMD_STAGE_BUDGET_MB instead).
+  if (j.IsObject() && !getenv("GDBAMD_QUIET_JSON")) {
+    static std::mutex mu;
+    static std::set<std::string> told;
+    for (const char* k : {"segment_size", "query_filter", "num_parallel_vcf_files", "size_per_column_partition", "lb_callset_row_idx", "ub_callset_row_idx"}) {
+      if (!j.HasMember(k)) continue;
+      std::lock_guard<std::mutex> g(mu);
+      if (told.insert(k).second) fprintf(stderr, "[genomicsdb_amd] warning: query JSON key \"%s\" is accepted and ignored by this build\n", k);
+    }
+  }
 }
 
 void VariantQueryConfig::add_attribute_to_query(const std::string& name) {

@@ -74,6 +74,7 @@ class VariantQueryConfig {
   bool produce_GT_field() const { return m_produce_GT_field; }
   bool produce_FILTER_field() const { return m_produce_FILTER_field; }
   bool sites_only_query() const { return m_sites_only_query; }
+  bool index_output_VCF() const { return m_index_output_VCF; }
   bool produce_GT_with_min_PL_value_for_spanning_deletions() const { return m_produce_GT_with_min_PL_value_for_spanning_deletions; }
   unsigned get_max_diploid_alt_alleles_that_can_be_genotyped() const { return m_max_diploid_alt_alleles_that_can_be_genotyped; }
   void set_max_diploid_alt_alleles_that_can_be_genotyped(unsigned v) { m_max_diploid_alt_alleles_that_can_be_genotyped = v; }
@@ -104,7 +105,7 @@ class VariantQueryConfig {
   bool m_scan_whole_array = false, m_query_all_rows = true;
   std::vector<int64_t> m_query_rows;
   int64_t m_num_rows_in_array = 0, m_smallest_row_idx = 0;
-  bool m_produce_GT_field = false, m_produce_FILTER_field = false, m_sites_only_query = false;
+  bool m_produce_GT_field = false, m_produce_FILTER_field = false, m_sites_only_query = false, m_index_output_VCF = false;
   bool m_produce_GT_with_min_PL_value_for_spanning_deletions = false;
   unsigned m_max_diploid_alt_alleles_that_can_be_genotyped = 50;
   size_t m_combined_vcf_records_buffer_size_limit = 1048576u;

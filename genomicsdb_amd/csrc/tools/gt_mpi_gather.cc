@@ -16,6 +16,7 @@
 
 #include "../api/genomicsdb_bcf_generator.h"
 #include "../common/mini_json.hpp"
+#include "../host/vcf_index.h"
 
 using namespace genomicsdb_amd;
 
@@ -85,8 +86,10 @@ int main(int argc, char** argv) {
   try {
     // output file: "vcf_output_filename" (string, or list indexed by rank) else stdout  (json_config.cc:586-607)
     std::string out_name;
+    bool index_output = false;
     {
       mini_json::Value q = mini_json::parse_file(json_config);
+      index_output = q.IsObject() && q.HasMember("index_output_VCF") && q["index_output_VCF"].GetBool();
       if (q.IsObject() && q.HasMember("vcf_output_filename")) {
         const mini_json::Value& v = q["vcf_output_filename"];
         if (v.IsString()) out_name = v.GetString();
@@ -111,6 +114,10 @@ int main(int argc, char** argv) {
       total += n;
     }
     if (out != stdout) fclose(out); else fflush(stdout);
+    if (out != stdout && index_output && (output_format == "z" || output_format == "b")) {   // vcf_adapter.cc:275-295: the index from the finished file
+      try { if (output_format == "z") build_tbi_index(out_name); else build_csi_index(out_name); }
+      catch (const std::exception& e) { std::cerr << "WARNING: error in creating index for output file " << out_name << ": " << e.what() << "\n"; }
+    }
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::cerr << "GENOMICSDB_TIMER,Rank," << rank << ",scan_and_produce_Broad_GVCF,Wall-clock time(s)," << secs << ",bytes," << total << "\n";
   } catch (const std::exception& e) {

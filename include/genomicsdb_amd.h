@@ -142,6 +142,10 @@ int gdbamd_engine_split_point(void* engine, int64_t column_begin, int64_t column
  * the staged begin-cells counted on the device by the bin of their begin column.  nbins must be (hist_end - hist_begin) / bin_size + 1; a cell beginning at or
  * before hist_begin counts for bin 0, one at or behind hist_end for the last bin.  accumulate != 0 adds to what counts holds (arrays streamed in windows). */
 int gdbamd_engine_column_histogram(void* engine, uint64_t hist_begin, uint64_t hist_end, uint64_t bin_size, uint64_t* counts, uint64_t nbins, int accumulate);
+/* "index_output_VCF" (src/main/cpp/src/config/json_config.cc:648, src/main/cpp/src/vcf/vcf_adapter.cc:275-295): the index htslib builds from a finished BGZF
+ * file - <path>.tbi for a bgzip'ed VCF (tbx_index_build with the VCF preset), <path>.csi with min_shift 14 for a BGZF BCF2 file (bcf_index_build(.., 14)).
+ * The file-writing VCFAdapter and gt_mpi_gather call it when the query JSON says "index_output_VCF": true and the format is "z" / "b". */
+int gdbamd_build_output_index(const char* path, int is_bcf);
 /* ColumnHistogramOperator::equi_partition_and_print_bins (variant_operations.cc:769-796): the text the reference prints - "Total T #bins P count/bins X.X", one
  * "first_column,last_column,count" line per partition of about equal cell count, an empty line.  Returns the text's length (dst may be NULL), -1 when
  * num_parts >= nbins.  The lines are what column_partitions of a loader JSON should be for P ranks of equal load. */
