@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--no-c3", action="store_true", help="skip the c3-shape leg (10 000 samples streamed through HBM in column windows)")
     ap.add_argument("--c3-bp", type=int, default=10_000_000, help="columns of the c3-shape leg (10 000 samples: 14.6 GB of cells per Mb, generated into host memory first)")
     ap.add_argument("--cpu-sample-bp", type=int, default=12000, help="columns of the bounded CPU-baseline sample (~15 s of oracle time)")
+    ap.add_argument("--base", type=int, default=10_000_000, help="first column of rank 0's partition")
     ap.add_argument("--c3-full", action="store_true",
                     help="BASELINE.json configs[2] at its stated size: 10 000 samples x whole chr1 (249 250 621 bp, ~3.6 TB of cells) streamed through HBM in one pass "
                          "(= --samples 10000 --interval-bp 249250621 --window-bp 50000 --stream-input); ~15 minutes, most of it the synthetic generator")
@@ -59,7 +60,7 @@ def main():
                          "lets the CPU suite check the N-rank launch (the line says \"dry_run\": true and carries value null)")
     args = ap.parse_args()
     if args.c3_full:
-        args.samples, args.interval_bp, args.window_bp, args.stream_input = 10000, 249_250_621, 50_000, True
+        args.samples, args.interval_bp, args.window_bp, args.stream_input, args.base = 10000, 249_250_621, 50_000, True, 0   # (contig 1 of the vid: columns 0 .. 249 250 620)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # launched bare (`python bench.py --gpus N`): become N ranks, one per GPU, like `mpirun -n N gt_mpi_gather`
@@ -92,7 +93,7 @@ def main():
     from genomicsdb_amd import dist as gdist
     if args.stream_input:
         return run_streamed(args, rank, world, device_index, backend)
-    B, _ = gdist.synthetic_partition(rank, 10_000_000, Lbp)  # every rank scans its own column partition of the same shape
+    B, _ = gdist.synthetic_partition(rank, args.base, Lbp)  # every rank scans its own column partition of the same shape
     nwin = max(1, Lbp // W)
     total_steps = args.steps + args.warmup
     need_bp = min(Lbp, W * min(nwin, total_steps))  # stage only the windows the run will touch
@@ -298,7 +299,7 @@ def run_streamed(args, rank, world, device_index, backend, source="callback", em
     from genomicsdb_amd import dist as gdist
     import helpers
     N, Lbp, W = args.samples, args.interval_bp, max(1, min(args.window_bp, args.interval_bp))
-    B, _ = gdist.synthetic_partition(rank, 10_000_000, Lbp)
+    B, _ = gdist.synthetic_partition(rank, args.base, Lbp)
     tmp = tempfile.mkdtemp(prefix="gdbamd_bench_")
     q = helpers.synth_query(tmp, N, B, B + Lbp - 1)
     eng = genomicsdb_amd.CombineEngine(q, device=device_index)

@@ -591,6 +591,50 @@ GDB_HD float gdb_introselect_libstdcxx(float* a, int64_t n, int64_t nth, int dep
   }
   return a[nth];
 }
+// The same selection with every partition step written as DATA-PARALLEL operations - what one workgroup of k_site_huge runs for a record
+// of tens of thousands of calls whose median is a zero of either sign (one thread needs seconds for 2 000 such records).  The Hoare sweep
+// of __unguarded_partition moves two pointers towards each other and swaps what they stop at; neither pointer ever reads a position the
+// other has written before they cross, so the sweep is determined by two lists taken from the array as it stands: L = positions
+// (ascending) the left pointer stops at, !(a[i] < pivot), and R = positions (descending) the right pointer stops at, !(pivot < a[i]).
+// Pair k is swapped while L[k] < R[k]; with m such pairs the sweep returns L[m] if the left pointer reaches it before the swapped
+// region (L[m] < R[m - 1]), else R[m - 1], where a value that is not below the pivot now lies.  posL / posR: scratch of n entries each.
+// Here the lists are built by plain loops (the host-side statement the tests compare with the library, permutation for permutation);
+// the kernel builds them with workgroup scans.
+GDB_HD int64_t gdb_partition_by_lists(float* a, int64_t first, int64_t last, uint32_t* posL, uint32_t* posR) {
+  const float pivot = a[first];
+  int64_t nl = 0, nr = 0;
+  for (int64_t i = first + 1; i < last; ++i) if (!(a[i] < pivot)) posL[nl++] = (uint32_t)i;
+  for (int64_t i = last - 1; i > first; --i) if (!(pivot < a[i])) posR[nr++] = (uint32_t)i;
+  int64_t m = 0;
+  const int64_t both = nl < nr ? nl : nr;
+  while (m < both && posL[m] < posR[m]) ++m;
+  for (int64_t k = 0; k < m; ++k) gdb_swapf(a, posL[k], posR[k]);
+  return (m < nl && (m == 0 || posL[m] < posR[m - 1])) ? (int64_t)posL[m] : (int64_t)posR[m - 1];
+}
+GDB_HD void gdb_median3_to_first(float* a, int64_t first, int64_t last) {   // __move_median_to_first(first, first + 1, mid, last - 1)
+  const int64_t mid = first + (last - first) / 2, x = first + 1, y = mid, z = last - 1;
+  if (a[x] < a[y]) {
+    if (a[y] < a[z]) gdb_swapf(a, first, y);
+    else if (a[x] < a[z]) gdb_swapf(a, first, z);
+    else gdb_swapf(a, first, x);
+  } else if (a[x] < a[z]) gdb_swapf(a, first, x);
+  else if (a[y] < a[z]) gdb_swapf(a, first, z);
+  else gdb_swapf(a, first, y);
+}
+GDB_HD float gdb_nth_element_by_lists(float* a, int64_t n, int64_t nth, uint32_t* posL, uint32_t* posR) {
+  int depth = 0;
+  for (int64_t m = n; m > 1; m >>= 1) ++depth;
+  depth *= 2;
+  int64_t first = 0, last = n;
+  while (last - first > 3) {
+    if (depth == 0) return gdb_introselect_libstdcxx(a + first, last - first, nth - first, 0);   // (heap select: sequential by nature, and never reached by real data)
+    --depth;
+    gdb_median3_to_first(a, first, last);
+    const int64_t cut = gdb_partition_by_lists(a, first, last, posL, posR);
+    if (cut <= nth) first = cut; else last = cut;
+  }
+  return gdb_introselect_libstdcxx(a + first, last - first, nth - first, 1);   // (at most three elements left: the insertion sort)
+}
 GDB_HD float gdb_nth_element_libstdcxx(float* a, int64_t n, int64_t nth) {
   int depth = 0;
   for (int64_t m = n; m > 1; m >>= 1) ++depth;     // std::__lg(n) * 2

@@ -496,6 +496,76 @@ struct HugeLookup {          // pass C: merged index of every candidate
 // (1 024 lanes per hot record: at the stated size of BASELINE configs[4] a record has 50 000 calls and a 2 kb piece holds 40 such
 // records - fewer than there are CUs - so the lanes of ONE record are what fills the device)
 constexpr int kHugeBlock = 1024;
+// exclusive scan of one value per thread over the workgroup of k_site_huge (16 wavefronts); s_w: 17 LDS words
+__device__ __forceinline__ uint32_t huge_block_scan(uint32_t v, uint32_t* s_w, uint32_t& total) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const uint32_t incl = wave_inclusive_scan_dpp(v);
+  if (lane == 63) s_w[wv] = incl;
+  __syncthreads();
+  if (tid == 0) { uint32_t acc = 0; for (int i = 0; i < kHugeBlock / 64; ++i) { const uint32_t x = s_w[i]; s_w[i] = acc; acc += x; } s_w[kHugeBlock / 64] = acc; }
+  __syncthreads();
+  const uint32_t r = s_w[wv] + incl - v;
+  total = s_w[kHugeBlock / 64];
+  __syncthreads();
+  return r;
+}
+// The zero the reference's std::nth_element leaves at the middle when -0 and +0 tie there, by the whole workgroup: gdb_nth_element_by_lists
+// (gdb_core.hpp: libstdc++'s introselect with every Hoare sweep stated as two position lists, pairwise swaps and one comparison for the
+// cut) with the lists built by workgroup scans.  One thread walking the 50 000 calls of a hot site of BASELINE configs[4] took 1.3 ms per
+// record and field; 2 000 such records were 2.7 s of a 4.0 s run.  val[hb .. he): the calls' values in call order (`missing`: none);
+// a / posL / posR: scratch of nvalid entries each.  Every thread returns the selected value's bits.
+__device__ uint32_t huge_tie_median(const uint32_t* __restrict__ val, int64_t hb, int64_t he, uint32_t missing, float* a, uint32_t* posL, uint32_t* posR,
+                                    uint32_t* s_w, uint32_t* s_m, uint32_t* s_res) {
+  const int tid = threadIdx.x;
+  uint32_t total;
+  {   // the valid values, in call order
+    const int64_t ninc = he - hb, per = (ninc + kHugeBlock - 1) / kHugeBlock;
+    const int64_t b = hb + min(ninc, (int64_t)tid * per), e = hb + min(ninc, (int64_t)(tid + 1) * per);
+    uint32_t cnt = 0;
+    for (int64_t t = b; t < e; ++t) cnt += val[t] != missing;
+    uint32_t at = huge_block_scan(cnt, s_w, total);
+    for (int64_t t = b; t < e; ++t) { const uint32_t u = val[t]; if (u != missing) a[at++] = __uint_as_float(u); }
+  }
+  __syncthreads();
+  const int64_t n = total, nth = n / 2;
+  int depth = 0;
+  for (int64_t m = n; m > 1; m >>= 1) ++depth;
+  depth *= 2;
+  int64_t first = 0, last = n;
+  while (last - first > 3) {                                   // uniform
+    if (depth == 0) break;                                     // (heap select: left to one thread below)
+    --depth;
+    if (tid == 0) { gdb_median3_to_first(a, first, last); *s_m = 0u; }
+    __syncthreads();
+    const float pivot = a[first];
+    const int64_t len = last - first - 1, per = (len + kHugeBlock - 1) / kHugeBlock;
+    const int64_t b = first + 1 + min(len, (int64_t)tid * per), e = first + 1 + min(len, (int64_t)(tid + 1) * per);
+    uint32_t cl = 0, cr = 0;
+    for (int64_t i = b; i < e; ++i) { const float v = a[i]; cl += !(v < pivot); cr += !(pivot < v); }
+    uint32_t nl, nr;
+    uint32_t atl = huge_block_scan(cl, s_w, nl);
+    const uint32_t fwd = huge_block_scan(cr, s_w, nr);
+    uint32_t atr = nr - fwd - cr;                              // right stops in front of mine in the descending list: those of the segments behind
+    for (int64_t i = b; i < e; ++i) if (!(a[i] < pivot)) posL[atl++] = (uint32_t)i;
+    for (int64_t i = e - 1; i >= b; --i) if (!(pivot < a[i])) posR[atr++] = (uint32_t)i;
+    __syncthreads();
+    const uint32_t both = min(nl, nr);
+    uint32_t mine = 0;
+    for (uint32_t k = tid; k < both; k += kHugeBlock) mine += posL[k] < posR[k];
+    if (mine) atomicAdd(s_m, mine);
+    __syncthreads();
+    const uint32_t m = *s_m;                                   // (posL ascends, posR descends: the pairs that swap are the first m)
+    for (uint32_t k = tid; k < m; k += kHugeBlock) { const uint32_t i = posL[k], j = posR[k]; const float x = a[i]; a[i] = a[j]; a[j] = x; }
+    const int64_t cut = (m < nl && (m == 0 || posL[m] < posR[m - 1])) ? (int64_t)posL[m] : (int64_t)posR[m - 1];
+    __syncthreads();
+    if (cut <= nth) first = cut; else last = cut;
+  }
+  if (tid == 0) *s_res = __float_as_uint(gdb_introselect_libstdcxx(a + first, last - first, nth - first, last - first > 3 ? 0 : 1));
+  __syncthreads();
+  const uint32_t r = *s_res;
+  __syncthreads();
+  return r;
+}
 __global__ void __launch_bounds__(kHugeBlock) k_site_huge(const SiteCtx* __restrict__ sxp, const int32_t* __restrict__ huge_list, const int32_t* __restrict__ counter,
                                                       HugeSiteOut* __restrict__ out, uint32_t* err) {
   const SiteCtx& cx = *sxp;
@@ -510,6 +580,8 @@ __global__ void __launch_bounds__(kHugeBlock) k_site_huge(const SiteCtx* __restr
   __shared__ uint32_t s_hist[256], s_prefix, s_mask, s_first_t;
   __shared__ long long s_rank;
   __shared__ uint32_t s_stage[2048];
+  __shared__ uint32_t s_scan_w[kHugeBlock / 64 + 1], s_tie_m, s_tie_res;
+  __shared__ unsigned long long s_tie_at;
   const int tid = threadIdx.x;
   const int count = min(*counter, kMaxHugeRecords);
   uint32_t e = 0;
@@ -698,7 +770,18 @@ __global__ void __launch_bounds__(kHugeBlock) k_site_huge(const SiteCtx* __restr
           if (s_first_t != 0xFFFFFFFFu) {
             median_bits = val[hb + s_first_t];
             const bool zero = is_float && (median_bits << 1) == 0u;
-            median_ok = (zero && s_cnt[2] && s_cnt[3]) ? 2 : 1;   // zeros of both signs: the reference's nth_element decides (reduce_scalar)
+            median_ok = (zero && s_cnt[2] && s_cnt[3]) ? 2 : 1;   // zeros of both signs: the reference's nth_element decides
+          }
+          if (median_ok == 2 && cx.tie.buf) {                   // uniform: ... and this workgroup runs it (else: reduce_scalar, one thread)
+            if (tid == 0) s_tie_at = atomicAdd(cx.tie.used, 3ull * (unsigned long long)total_valid);
+            __syncthreads();
+            const unsigned long long at = s_tie_at;
+            if (at + 3ull * (unsigned long long)total_valid <= cx.tie.capacity) {
+              float* a = cx.tie.buf + at;
+              median_bits = huge_tie_median(val, hb, he, missing, a, (uint32_t*)(a + total_valid), (uint32_t*)(a + 2 * total_valid), s_scan_w, &s_tie_m, &s_tie_res);
+              median_ok = 1;
+            }
+            __syncthreads();
           }
         }
         if (tid == 0) {
@@ -4676,7 +4759,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
     int nf = (pl.qual_combine_op == GDB_OP_MEDIAN && pl.f_QUAL >= 0) ? 1 : 0;
     for (int i = 0; i < pl.n_info; ++i) if (pl.field[pl.info_field[i]].combine_op == GDB_OP_MEDIAN && pl.field[pl.info_field[i]].elem == GDB_ET_FLOAT) ++nf;
     if (nf && T > 0) {
-      tie.capacity = 2ull * (uint64_t)nf * (uint64_t)T;
+      tie.capacity = 5ull * (uint64_t)nf * (uint64_t)T;       // (3 per value for a record whose workgroup selects, 1 when a thread does; both at most once per field)
       S.tie_buf.ensure((size_t)tie.capacity + 4); S.tie_used.ensure(1);
       HIP_CHECK(hipMemsetAsync(S.tie_used.p, 0, sizeof(unsigned long long), st));
       tie.buf = S.tie_buf.p; tie.used = S.tie_used.p;

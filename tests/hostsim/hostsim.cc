@@ -307,6 +307,17 @@ int hostsim_put_float(float v, char* buf, uint64_t cap) {
   return (int)s.n;
 }
 
+// gdb_nth_element_by_lists (the data-parallel statement of libstdc++'s introselect that k_site_huge runs) against std::nth_element itself:
+// 1 = same selected value (bit for bit) AND same permutation left behind
+int hostsim_nth_by_lists_same(const float* values, int64_t n, int64_t nth) {
+  std::vector<float> a(values, values + n), b(values, values + n);
+  std::vector<uint32_t> pl((size_t)n + 1), pr((size_t)n + 1);
+  const float mine = gdb_nth_element_by_lists(a.data(), n, nth, pl.data(), pr.data());
+  std::nth_element(b.begin(), b.begin() + nth, b.end());
+  if (memcmp(&mine, &b[(size_t)nth], 4) != 0) return 0;
+  return memcmp(a.data(), b.data(), (size_t)n * sizeof(float)) == 0 ? 1 : 0;
+}
+
 // the typed-value encoder of the BCF2 path (gdb_core.hpp: bcf_enc_vint / bcf_enc_size / bcf_enc_int1) for the byte-level known answers of
 // tests/test_bcf_typed_values.py (derived from the BCFv2.2 specification, not from the tests' own decoder)
 int hostsim_bcf_enc_vint(const int32_t* a, int n, uint8_t* out, int cap) {

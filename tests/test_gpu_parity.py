@@ -487,6 +487,35 @@ def test_c5_50000_samples_hot_site_matches_oracle(gdb, tmp_path, monkeypatch):
     eng.close()
 
 
+def test_c5_twenty_hot_sites_of_50000_calls_with_tied_zero_medians(gdb, tmp_path, monkeypatch):
+    """BASELINE.json configs[4]'s sample count, 20 hot sites (every sample starts an insertion every 50 columns), rank sums rounded to
+    halves: every median of every hot site is a zero with both signs present, i.e. what is printed ("0" / "-0") is whichever zero libstdc++'s
+    introselect leaves at the middle of 50 000 values.  The workgroup of k_site_huge runs that selection itself (huge_tie_median: the Hoare
+    sweeps as position lists built by scans); the bytes must be the oracle's (whose nth_element IS the library's), and the same with the
+    one-thread walk forced"""
+    from genomicsdb_amd import synth
+    N, B, L = 50_000, 10_000_000, 1000
+    g = synth.Generator(N, B, L + 2600, dense=(B, L, 50, 64), rank_sum_scale=2.0)
+    cells, nc = g.chunk_bytes(B + L + 2600)
+    g.close()
+    sites = [B + 50 * i for i in range(1, 21)]
+    q = helpers.synth_query(tmp_path, N, B, B + L - 1)
+    q["query_column_ranges"] = [[[s_, s_] for s_ in sites]]
+    q["max_diploid_alt_alleles_that_can_be_genotyped"] = 10      # (PL / GT dropped at these sites: the test is about the INFO medians)
+    want, nrec, _ = helpers.oracle_run_synth(q, cells, synth.SEED, with_header=False)
+    infos = [l.split(b"\t")[7] for l in want.split(b"\n") if l]
+    assert nrec == 20 and sum(i.count(b"=-0;") + i.count(b"=-0\t") + i.endswith(b"=-0") for i in infos) >= 5 and sum(b"RankSum=0;" in i for i in infos) >= 5
+    eng = gdb.CombineEngine(q)
+    eng.stage_cells(cells)
+    eng.set_reference(B, synth.reference(B, L + 4096))
+    got = b"".join(eng.run_interval(s_, s_, arena_bytes=1 << 30)[0] for s_ in sites)
+    assert got == want
+    monkeypatch.setenv("GDBAMD_NO_HUGE_SITES", "1")
+    got2 = b"".join(eng.run_interval(s_, s_, arena_bytes=1 << 30)[0] for s_ in sites[:3])
+    assert got2 == b"".join(want.splitlines(True)[:3])
+    eng.close()
+
+
 @pytest.mark.parametrize("n_samples,scale", [(40, 1.0), (333, 2.0), (333, 1.0)])
 def test_tied_medians_print_the_zero_the_reference_selects(gdb, tmp_path, monkeypatch, n_samples, scale):
     """rank sums rounded to 1 / scale: most medians are ties and many of them zeros of both signs.  The per-thread medians
