@@ -201,6 +201,8 @@ def main():
             eng.close()                                                 # (the timed engine's HBM - fragment, 48 GB arena, tables - is given back first)
             out["stream_end_to_end"] = stream_end_to_end(N, B, min(W, Lbp), tmp, expect_body_bytes=None)
             out["stream_end_to_end_bgzf"] = stream_end_to_end(N, B, min(W, Lbp), tmp, expect_body_bytes=None, output_format="z")
+            # BCF2, what GATK4's GenomicsDBFeatureReader decodes: uncompressed ("bu", the JNI's is_bcf stream) and as BGZF blocks ("b")
+            out["stream_end_to_end_bcf"] = {fmt: stream_end_to_end(N, B, min(W, Lbp), tmp, expect_body_bytes=None, output_format=fmt) for fmt in ("bu", "b")}
         if not args.no_c3 and world == 1 and not args.bcf:
             # BASELINE configs[2] shape in the default line: 10 000 samples, the array does NOT fit next to the working buffers and
             # passes through HBM in column windows with carry-over; the input path (host memory -> HBM) is inside the timed region
@@ -456,6 +458,12 @@ def stream_end_to_end(N, B, W, tmp, expect_body_bytes=None, output_format=None):
     gen2 = synth.Generator(N, B, W)
     p2, n2, _ = gen2.next_chunk(B + W)
     eng.stage_cells_begin(); eng.stage_cells_append(p2, n2); eng.stage_cells_end()
+    if output_format in ("bu", "b"):      # the engine's own page accounting in the stream's format ("b": before compression)
+        eng.close()
+        eng = genomicsdb_amd.CombineEngine(q, device=torch.cuda.current_device(), is_bcf=True)
+        gen2 = synth.Generator(N, B, W)
+        p2, n2, _ = gen2.next_chunk(B + W)
+        eng.stage_cells_begin(); eng.stage_cells_append(p2, n2); eng.stage_cells_end()
     _, est = eng.run_interval(B, B + W - 1, arena_bytes=48 << 30, fetch=False)
     ok = int(est.bytes_out) == body if output_format not in ("z", "b") else None    # (compressed: checked on a sample below)
     recs = int(est.num_records)

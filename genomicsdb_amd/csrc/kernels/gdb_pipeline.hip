@@ -125,7 +125,8 @@ inline bool events_enabled() { const char* e = getenv("GDBAMD_EVENTS"); return e
 //   0 (default)  the sizing pass of rounds 1-3 (k_assemble_size: every (record, sample) pair walked, sizes and matrix in one pass), pages by k_assemble_write
 //   1            text only: sizes from pieces (k_size2), no matrix at all, the page pass walks the pieces itself (k_write2)
 //   2            sizes from pieces (k_size2), the matrix from a piece walker per lane (k_fill2), pages by k_assemble_write / the BCF kernels
-inline int asm_path_wanted() { const char* e = getenv("GDBAMD_ASM_PATH"); return e && *e ? std::max(0, std::min(2, atoi(e))) : 0; }
+//   3            text only: sizes from pieces (k_size2), piece lists (k_plist), pages by k_write3 (no matrix, no walking in the page pass)
+inline int asm_path_wanted() { const char* e = getenv("GDBAMD_ASM_PATH"); return e && *e ? std::max(0, std::min(3, atoi(e))) : 0; }
 inline int fill_run_length() { const char* e = getenv("GDBAMD_RUN_F"); return e && *e ? std::max(1, atoi(e)) : 128; }
 inline int write2_run_length() { const char* e = getenv("GDBAMD_RUN_W2"); return e && *e ? std::max(1, atoi(e)) : 64; }
 // wavefronts (= neighbouring 64-sample chunks) per workgroup of the page assembly: 4 measured best on the store-only model
@@ -1810,6 +1811,73 @@ k_size2(PieceCtx a, int nchunks, uint64_t* __restrict__ chunk_size) {
   }
 }
 
+// ---- piece lists --------------------------------------------------------------------------------------------------------------------
+// k_write2 above pays for deciding, record by record and lane by lane, what the next piece is (stale cells, cells without a record of the
+// run's type, gaps, heavy calls: ~130 instructions of a wavefront on nearly every record - and these kernels are bound by the instructions
+// they issue).  The decisions do not depend on the page being assembled, so they are made ONCE per interval, per piece: for every block of
+// kSizeBlock records, every tabled record type t and every sample row r a LIST of entries (first record it holds from, where the entry's
+// text lies, its length), in record order:
+//   * a plain cell contributes one entry per type it has a slot for, from the first record of the block it is live in;
+//   * a heavy call one entry per record, in the list of that record's type;
+//   * wherever no cell is live (between two cells, in front of the first, behind the last) every type gets the no-call entry;
+//   * a list ends with an entry that never begins (INT32_MAX).
+// Every record of type t in the block therefore has an entry of list (block, t, r) beginning at or in front of it, and the entry in force is
+// the last such one.  k_plist<false> counts, a scan turns the counts into list offsets, k_plist<true> fills; k_write3 consumes.
+struct PieceEntry { int32_t k_from; uint32_t where, len, pad; };      // where: 16-byte unit of the inline pool, or kOverflowBit | unit of the overflow pool
+template <bool FILL> __global__ void __launch_bounds__(kAsmRows)
+k_plist(PieceCtx a, const uint2* __restrict__ desc, int NT, int nchunks, uint32_t* __restrict__ counts_or_offsets, PieceEntry* __restrict__ plist) {
+  __shared__ uint32_t cur[kMaxTypes][kAsmRows];                 // per (type, lane): entries so far / where the next one goes
+  const int lane = threadIdx.x;
+  const int64_t unit = xcd_aware_unit<1>((int64_t)gridDim.x);
+  const int64_t sub = unit / nchunks;
+  const int ch = (int)(unit % nchunks);
+  const int64_t k0 = sub * kSizeBlock, k1 = min(a.P, k0 + (int64_t)kSizeBlock);
+  const int32_t r = ch * kAsmRows + lane;
+  if (r >= a.nrows) return;
+  uint32_t* const table = counts_or_offsets + ((int64_t)sub * NT) * a.nrows + r;      // [t] at stride nrows
+  for (int t = 0; t < NT; ++t) cur[t][lane] = FILL ? table[(int64_t)t * a.nrows] : 0u;
+  auto emit = [&](uint32_t t, int64_t k_from, uint32_t slot) {
+    if (FILL) {
+      const uint2 d = desc[slot];
+      PieceEntry e;
+      e.k_from = (int32_t)k_from; e.where = d.x; e.len = d.y; e.pad = 0;
+      *reinterpret_cast<uint4*>(&plist[cur[t][lane]]) = *reinterpret_cast<const uint4*>(&e);
+    }
+    ++cur[t][lane];
+  };
+  const int64_t j_begin = a.row_ptr[r], j_end = a.row_ptr[r + 1];
+  const int64_t s0 = a.rec_start[k0];
+  int64_t lo = j_begin, hi = j_end;
+  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a.rm_begin[mid] <= s0) lo = mid + 1; else hi = mid; }
+  int64_t j = lo - 1;
+  bool may_be_stale = j >= j_begin;                              // (as in k_size2: the cell found may begin in front of the window)
+  if (!may_be_stale) j = j_begin;
+  int64_t covered = k0 - 1;                                      // last record of the block that has its entries
+  for (; j < j_end; ++j) {
+    const WalkCell* wp = a.walk + j + r;
+    const uint4 tail = *reinterpret_cast<const uint4*>(&wp->k_lo);
+    const int32_t klo = (int32_t)tail.x, khi = (int32_t)tail.y;
+    if ((tail.w >> 8) != a.epoch) { if (may_be_stale) { may_be_stale = false; continue; } break; }
+    may_be_stale = false;
+    if (klo < 0) continue;
+    if ((int64_t)klo >= k1) break;
+    if ((int64_t)khi < k0) continue;
+    const int64_t ka = max((int64_t)klo, k0), kb = min((int64_t)khi, k1 - 1);
+    if (ka > covered + 1) for (int t = 0; t < NT; ++t) emit((uint32_t)t, covered + 1, (uint32_t)t);   // nothing live: the types' no-call entries
+    if (tail.w & kWalkHeavy) {
+      for (int64_t k = ka; k <= kb; ++k) { const uint32_t t = a.rtype[k]; if (t != kUntabledType) emit(t, k, a.heavy_base + tail.z + (uint32_t)(k - klo)); }
+    } else {
+      uint64_t m = wp->aux;
+      uint32_t sl = a.light_base + tail.z;
+      while (m) { const int t = __builtin_ctzll(m); m &= m - 1; if (t < NT) emit((uint32_t)t, ka, sl); ++sl; }
+    }
+    covered = kb;
+  }
+  if (covered < k1 - 1) for (int t = 0; t < NT; ++t) emit((uint32_t)t, covered + 1, (uint32_t)t);
+  for (int t = 0; t < NT; ++t) emit((uint32_t)t, (int64_t)INT32_MAX, (uint32_t)t);
+  if (!FILL) for (int t = 0; t < NT; ++t) table[(int64_t)t * a.nrows] = cur[t][lane];
+}
+
 // The (record, sample) matrix for k_assemble_write / the BCF kernels, from a PieceWalker per lane: what k_assemble_size leaves, at half
 // its instructions per step (the kernels of this file are bound by the instructions they issue: ~4.4 cycles of a SIMD each) - one
 // compare where nothing changes, no position arithmetic, no incidence look-up, no scan (the sizes come from k_size2).  The descriptor
@@ -1965,6 +2033,179 @@ k_write2(PieceCtx a, const char* __restrict__ pool, const char* __restrict__ poo
         }
         pending = 0;
       }
+      const uint32_t len = cur_len;
+      const uint32_t inc = wave_inclusive_scan_dpp(len);
+      const uint32_t excl = inc - len;
+      const uint32_t total = wave_total(inc);
+      char* const grec = arena + readlane64(my_dst, jj);
+      // The chunk normally fits one LDS image.  Wider chunks (long PL vectors) go out in passes over consecutive lane ranges that
+      // fit; only a single entry larger than the image is copied straight from the pool.  The flush of a pass is put off until the
+      // next one is about to build (the image is about to be overwritten) or, for the last one, until the next record's request is out.
+      uint32_t l0 = 0, base_off = 0;
+      bool built = false;
+      char* f_dst = grec; uint32_t f_al = 0, f_total = 0;
+      while (base_off < total) {                            // uniform
+        if (built) { flush(f_dst, f_al, f_total); built = false; }
+        char* gdst = grec + base_off;
+        const uint32_t al = (uint32_t)((uintptr_t)gdst & 15u);
+        const bool fits = (uint32_t)lane >= l0 && al + (inc - base_off) <= (uint32_t)kWaveLds;
+        const uint64_t fit_mask = __ballot(fits) >> l0;     // inc is non-decreasing: the fitting lanes are a run starting at l0
+        const uint32_t len_l0 = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)(l0 < 64u ? l0 : 63u));
+        if (!(fit_mask & 1ull) || len_l0 > (uint32_t)kCooperativeEntry) {   // a long text (or one that exceeds the image): the whole wavefront copies it
+          const char* big_src = pool_ovf + (size_t)((uint32_t)__builtin_amdgcn_readlane((int)cur_where, (int)l0) & ~kOverflowBit) * 16;   // (only overflow texts are this long)
+          const uint32_t big_len = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)l0);
+          uint32_t head = (16u - al) & 15u;                 // bytes up to the first 16-byte boundary of the destination
+          if (head > big_len) head = big_len;
+          if ((uint32_t)lane < head) gdst[lane] = big_src[lane];
+          const uint32_t nwords = (big_len - head) >> 4;
+          uint4* gw = reinterpret_cast<uint4*>(gdst + head);
+          for (uint32_t wq = lane; wq < nwords; wq += kAsmRows) {   // aligned 16-byte stores, source words assembled from two aligned loads
+            const char* sp = big_src + head + ((size_t)wq << 4);
+            const uint4 lo = *reinterpret_cast<const uint4*>((uintptr_t)sp & ~(uintptr_t)15);
+            const uint4 hi = *reinterpret_cast<const uint4*>(((uintptr_t)sp & ~(uintptr_t)15) + 16);
+            const uint32_t sh = (uint32_t)((uintptr_t)sp & 15u);
+            const uint32_t ww[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            uint32_t o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const uint32_t x = ww[(sh >> 2) + q], y = ww[(sh >> 2) + q + 1 < 8 ? (sh >> 2) + q + 1 : 7];
+              o[q] = __builtin_amdgcn_alignbyte(y, x, sh & 3u);
+            }
+            gw[wq] = make_uint4(o[0], o[1], o[2], o[3]);
+          }
+          const uint32_t tail_at = head + (nwords << 4);
+          if ((uint32_t)lane < big_len - tail_at) gdst[tail_at + lane] = big_src[tail_at + lane];
+          base_off = (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)l0);
+          ++l0;
+          continue;
+        }
+        const uint32_t nfit = fit_mask == ~0ull ? 64u - l0 : (uint32_t)__builtin_ctzll(~fit_mask);
+        const uint32_t l1 = l0 + nfit;
+        const uint32_t pass_total = (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)(l1 - 1)) - base_off;
+        const bool mine = (uint32_t)lane >= l0 && (uint32_t)lane < l1;
+        SlotCopy cp;
+        cp.begin((gdb_lds_char*)lds_buf + al + (excl - base_off), mine ? len : 0u, (gdb_lds_char*)lds_buf + kWaveLds + 16 + 4 * lane);
+        cp.chunk(0, as_uint4(txt.x[0]));
+#pragma unroll
+        for (int q = 1; q < kText2Chunks; ++q) if (__any((int)cp.needs(q))) cp.chunk(q, as_uint4(txt.x[q]));
+        if (__any((int)cp.needs(kText2Chunks))) {           // texts longer than the registers hold: overflow texts
+          const char* cur_src = pool_ovf + (size_t)(cur_where & ~kOverflowBit) * 16;
+          for (uint32_t q = kText2Chunks; __any((int)cp.needs(q)); ++q) cp.chunk(q, load_chunk(cur_src, q, mine ? len : 0u));
+        }
+        cp.finish();
+        // One wavefront per workgroup: the LDS unit runs its instructions in order, so the image only needs a compiler-level
+        // fence (wavefront scope emits no s_waitcnt: outstanding loads and page stores keep flying across records).
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        built = true; f_dst = gdst; f_al = al; f_total = pass_total;
+        l0 = l1;
+        base_off += pass_total;
+      }
+      if (jj + 1 < cnt) request(__builtin_amdgcn_readlane(my_k, jj + 1), (uint32_t)__builtin_amdgcn_readlane((int)my_t, jj + 1));
+      if (built) flush(f_dst, f_al, f_total);
+    }
+  }
+}
+
+// Page assembly from the piece lists (k_plist): k_write2's image / flush loop and its requests ahead; a lane's transition is "take the next entry,
+// ask for the one behind it, ask for the text" - the entry says where the text lies and how long it is, nothing is decided here.
+template <int WAVES, int kWaveLds> __global__ void __launch_bounds__(kAsmRows * WAVES)
+k_write3(PieceCtx a, const PieceEntry* __restrict__ plist, const uint32_t* __restrict__ pofs, int NT, const char* __restrict__ pool, const char* __restrict__ pool_ovf, const int32_t* __restrict__ order, int64_t n, int nchunks, int run,
+         const uint64_t* __restrict__ chunk_off, uint64_t page_base, char* __restrict__ arena, int xcd_aware) {
+  const int dbg = xcd_aware >> 1;                            // timing experiments only (GDBAMD_W2_DBG): 1 = no walk behind a run's first record, 2 = slots are named but not fetched, 32 = no request ahead
+  const int64_t unit = xcd_aware_unit<WAVES>(((n + run - 1) / run) * (int64_t)nchunks, xcd_aware & 1);
+  if (unit < 0) return;
+  const int64_t ib = (unit / nchunks) * run;
+  const int64_t ie = min(n, ib + (int64_t)run);
+  const int ch = (int)(unit % nchunks);
+  const int lane = threadIdx.x & 63;
+  const int32_t r = ch * kAsmRows + lane;
+  const bool has_row = r < a.nrows;
+  __shared__ __attribute__((aligned(16))) char lds_all[WAVES][kWaveLds + 16 + kScrapBytes];
+  char* const lds_buf = &lds_all[threadIdx.x >> 6][0];
+  uint32_t cur_where = 0, cur_len = 0;                      // the tag of the lane's present slot (an inline text is wholly in txt)
+  TextRegs<kText2Chunks> txt;
+#pragma unroll
+  for (int q = 0; q < kText2Chunks; ++q) txt.x[q] = u32x4{0, 0, 0, 0};
+  // the lane's place in its piece list: nx = the next entry (x = first record it holds from, y = where its text lies, z = its length), requested
+  // when the lane took the one in front of it; ent = the entry behind nx
+  const PieceEntry* ent = plist;
+  u32x4 nx = u32x4{(uint32_t)INT32_MAX, 0u, 0u, 0u};
+  uint32_t prev_t = 0xFFFFFFFFu;
+  int32_t prev_sb = -1;
+  uint64_t pending = 0;                                     // lanes that have asked for a slot's line and not looked at it yet
+  // A step has two halves.  REQUEST (record jj): samples whose entry changes there name their slot and ask for its line - nothing
+  // waits.  TAKE + build + flush: the tags are read (here the loads are waited for), the image is built and written.  The request
+  // for record jj + 1 is made between the build and the flush of record jj: the texts of the lanes that change are dead once the
+  // image stands, and the random-access latency of the new ones (what this kernel would otherwise sit out on nearly every
+  // record: ~1.6 us against 2.5 us for everything else in the step) passes while the image is flushed.
+  // (real moves in front of the load, as in PieceWalker::advance: the entry being taken leaves nx before the next one is loaded into it)
+  auto take = [&]() {
+    uint32_t w_, l_;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(w_) : "v"(nx.y));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(l_) : "v"(nx.z));
+    __builtin_amdgcn_sched_barrier(0);
+    nx = *reinterpret_cast<const u32x4*>(ent);
+    ++ent;
+    cur_where = w_; cur_len = l_;
+  };
+  auto request = [&](int32_t k, uint32_t t) {
+    const int32_t sb = k / kSizeBlock;
+    if (t != prev_t || sb != prev_sb) {                     // uniform: the run starts, its records change type or enter the next block of records: another list
+      prev_t = t; prev_sb = sb;
+      if (has_row) {
+        ent = plist + pofs[((int64_t)sb * NT + t) * a.nrows + r];
+        nx = *reinterpret_cast<const u32x4*>(ent);
+        ++ent;
+        asm volatile("; the list's first entry has arrived" : : "v"(nx.x), "v"(nx.w));   // (the wait stays in this rare block)
+      }
+    }
+    const bool need = has_row && k >= (int32_t)nx.x && !((dbg & 2) && cur_len);
+    if (need) {                                             // the sample's entry changes here: take the next one, ask for the one behind it and for the text
+      take();
+      while (k >= (int32_t)nx.x) take();                    // (entries without a record of this run in between: rare, and only these wait)
+      const char* src = (cur_where & kOverflowBit) ? pool_ovf + (size_t)(cur_where & ~kOverflowBit) * 16 : pool + (size_t)cur_where * 16;
+      load16_in_place<0>(txt.x[0], src);
+      load16_in_place<16>(txt.x[1], src);
+      load16_in_place<32>(txt.x[2], src);
+      if (cur_len > 48u) {
+        load16_in_place<48>(txt.x[3], src);
+        load16_in_place<64>(txt.x[4], src);
+        load16_in_place<80>(txt.x[5], src);
+        load16_in_place<96>(txt.x[6], src);
+        load16_in_place<112>(txt.x[7], src);
+      }
+    }
+    pending = __ballot(need);
+  };
+  // the image of one pass (<= kWaveLds bytes of a record's chunk, with the destination's alignment) -> page
+  auto flush = [&](char* gdst, uint32_t al, uint32_t pass_total) {
+    const char* img = lds_buf + al;
+    uint32_t head = (16u - al) & 15u;
+    if (head > pass_total) head = pass_total;
+    const uint32_t nwords = (pass_total - head) >> 4;
+    const uint32_t tail_at = head + (nwords << 4);
+    const uint4* lsrc = reinterpret_cast<const uint4*>(img + head);
+    uint4* gw = reinterpret_cast<uint4*>(gdst + head);
+    for (uint32_t wq = lane; wq < nwords; wq += kAsmRows) gw[wq] = lsrc[wq];
+    {   // the bytes in front of the first and behind the last 16-byte word in ONE store instruction: lanes 0-15 head, 16-31 tail
+      const uint32_t li = (uint32_t)lane & 15u;
+      const bool is_tail = (lane & 16) != 0;
+      const uint32_t at = is_tail ? tail_at + li : li;
+      if (lane < 32 && li < (is_tail ? pass_total - tail_at : head)) gdst[at] = img[at];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  };
+  for (int64_t i0 = ib; i0 < ie; i0 += 64) {                // uniform
+    const int cnt = (int)min((int64_t)64, ie - i0);
+    int32_t my_k = 0; int64_t my_dst = 0; uint32_t my_t = 0;
+    if (lane < cnt) {
+      my_k = order[i0 + lane];
+      my_t = a.rtype[my_k];
+      my_dst = (int64_t)(chunk_off[(int64_t)my_k * nchunks + ch] - page_base) + (ch == 0 ? a.prefix_len[my_k] : 0u);
+    }
+    request(__builtin_amdgcn_readlane(my_k, 0), (uint32_t)__builtin_amdgcn_readlane((int)my_t, 0));
+    for (int jj = 0; jj < cnt; ++jj) {                      // uniform
+      if (pending) { text_arrived(); pending = 0; }        // uniform: the texts asked for during the previous step
       const uint32_t len = cur_len;
       const uint32_t inc = wave_inclusive_scan_dpp(len);
       const uint32_t excl = inc - len;
@@ -3218,6 +3459,7 @@ struct DevicePipeline::Impl {
   DevBuf<unsigned long long> type_hkeys; DevBuf<int32_t> type_hrep, type_rep; DevBuf<uint8_t> type_hid, rtype;
   DevBuf<WalkCell> walk; DevBuf<int64_t> walk_inv;
   DevBuf<int32_t> jhint;
+  DevBuf<uint32_t> pl_cnt, pl_ofs; DevBuf<PieceEntry> plist;     // piece lists (GDBAMD_ASM_PATH=3)
   uint32_t walk_epoch = 0;           // stamp of the interval whose cells the walk list describes (24 bits; 0: none yet)
   // cell-stream staging (append_cells)
   DevBuf<uint8_t> raw_cells; DevBuf<uint64_t> raw_off; DevBuf<int32_t> raw_row_map, raw_qrow; DevBuf<uint32_t> raw_keep, raw_dest, raw_len, raw_voff, raw_mark, raw_mdest;
@@ -3245,7 +3487,7 @@ struct DevicePipeline::Impl {
     std::vector<uint64_t> rec_off;
     IntervalStats stats;
     SiteCtx sx; EntryCtx ex; RowIndex ri; SiteOut so; RecordTable rec; AsmCtx ac; PieceCtx pc2;
-    bool resolved_whole = false, piece_path = false; int asm_path = 0;
+    bool resolved_whole = false, piece_path = false; int asm_path = 0, NT = 0;
     bool bcf = false; int bcf_F = 0; BcfLayout lay{nullptr, nullptr, nullptr, nullptr};
     bool events = false; int evrun = 0; EventBuf eb{nullptr, nullptr, nullptr, 0};
   } iv;
@@ -4949,9 +5191,10 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
 #undef GDB_SLOT_KERNELS
   S.long_texts_seen = long_texts * 16 > NS;    // the wide strip of pass 0 pays when a sixteenth of the texts is long
   S.pool_ovf_need = std::max<uint64_t>(S.pool_ovf_need, shard_need);   // (units per shard)
-  const int asm_path = events_enabled() ? 0 : (pl.bcf_mode && asm_path_wanted() == 1) ? 2 : asm_path_wanted();
-  const bool piece_path = asm_path == 1;   // matrix-free page assembly
-  hipLaunchKernelGGL(k_slot_desc, dim3(blocks_for((int64_t)NS)), dim3(kBlock), 0, st, S.slot_len.p, S.slot_off.p, (int64_t)NS, piece_path ? (uint2*)nullptr : S.slot_desc.p,
+  int asm_path = events_enabled() ? 0 : (pl.bcf_mode && (asm_path_wanted() & 1)) ? 2 : asm_path_wanted();
+  if (asm_path == 3 && UR > 0) asm_path = 0;      // (records of untabled types have a slot per (record, sample): the piece lists do not carry them)
+  const bool piece_path = asm_path == 1 || asm_path == 3;   // matrix-free page assembly
+  hipLaunchKernelGGL(k_slot_desc, dim3(blocks_for((int64_t)NS)), dim3(kBlock), 0, st, S.slot_len.p, S.slot_off.p, (int64_t)NS, asm_path == 1 ? (uint2*)nullptr : S.slot_desc.p,
                      pl.bcf_mode ? (char*)nullptr : S.pool.p, stt.inline_max);
   stats.num_record_types = ntypes;
   stats.num_text_slots = (int64_t)NS;
@@ -5018,6 +5261,17 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
     S.order_iv_valid = true;
   } else if (asm_path != 0) {
     hipLaunchKernelGGL(k_size2, dim3((unsigned)size2_units), dim3(kAsmRows), 0, st, pc2, nchunks, S.chunk_size.p);
+    if (asm_path == 3) {   // piece lists: count, offsets, fill
+      const size_t nlists = (size_t)((P + kSizeBlock - 1) / kSizeBlock) * (size_t)ntypes * (size_t)N;
+      S.pl_cnt.ensure(nlists + 1); S.pl_ofs.ensure(nlists + 1);
+      hipLaunchKernelGGL(k_plist<false>, dim3((unsigned)size2_units), dim3(kAsmRows), 0, st, pc2, (const uint2*)S.slot_desc.p, ntypes, nchunks, S.pl_cnt.p, (PieceEntry*)nullptr);
+      S.excl_scan(S.pl_cnt.p, S.pl_ofs.p, nlists);
+      const int64_t nent = S.read_back_sum(S.pl_ofs.p + (nlists - 1), S.pl_cnt.p + (nlists - 1));
+      if (nent >= (1ll << 32)) throw GenomicsDBDeviceException("more than 2^32 piece-list entries in one interval: split the query interval");
+      S.plist.ensure((size_t)nent + 4);
+      hipLaunchKernelGGL(k_plist<true>, dim3((unsigned)size2_units), dim3(kAsmRows), 0, st, pc2, (const uint2*)S.slot_desc.p, ntypes, nchunks, S.pl_ofs.p, S.plist.p);
+      S.iv.NT = ntypes;
+    }
     if (asm_path == 2 && resolved_whole)
       hipLaunchKernelGGL(k_fill2, dim3(fill_units), dim3(kAsmRows), 0, st, pc2, (const uint2*)S.slot_desc.p, (const int32_t*)S.order.p, P, nchunks, frun, S.resolved.p, (int64_t)0);
   } else
@@ -5148,12 +5402,17 @@ bool DevicePipeline::begin_page(uint64_t arena_bytes, int arena_idx, PageTicket*
     (const int32_t*)S.order.p, np, iv.nchunks, wrun, (const uint64_t*)S.chunk_off.p, page_base, arena, (xcd_aware_numbering() ? 1 : 0) | (w2dbg << 1))
     const int ww = write_waves_per_group(), wl = write_image_kb();
     const int w2dbg = getenv("GDBAMD_W2_DBG") ? atoi(getenv("GDBAMD_W2_DBG")) : 0;
+#define GDB_LAUNCH_WRITE3(W, L) hipLaunchKernelGGL((k_write3<W, L>), dim3((wgrid.x + (W) - 1u) / (W)), dim3(kAsmRows * (W)), 0, st, iv.pc2, (const PieceEntry*)S.plist.p, (const uint32_t*)S.pl_ofs.p, iv.NT, \
+    (const char*)S.pool.p, (const char*)S.pool_ovf.p, (const int32_t*)S.order.p, np, iv.nchunks, wrun, (const uint64_t*)S.chunk_off.p, page_base, arena, (xcd_aware_numbering() ? 1 : 0) | (w2dbg << 1))
+    if (iv.asm_path == 3) { if (wl <= 4) GDB_LAUNCH_WRITE3(1, 4096); else GDB_LAUNCH_WRITE3(1, 8192); }
+    else
     if (ww >= 4 && wl <= 4) GDB_LAUNCH_WRITE2(4, 4096);
     else if (ww >= 4) GDB_LAUNCH_WRITE2(4, 8192);
     else if (wl <= 4) GDB_LAUNCH_WRITE2(1, 4096);
     else if (wl <= 6) GDB_LAUNCH_WRITE2(1, 6144);
     else GDB_LAUNCH_WRITE2(1, 8192);
 #undef GDB_LAUNCH_WRITE2
+#undef GDB_LAUNCH_WRITE3
     HIP_CHECK(hipEventRecord(w[2], st));
     HIP_CHECK(hipMemcpyAsync(&S.hb->page_err[ai], S.err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipEventRecord(w[3], st));

@@ -34,7 +34,7 @@ def _golden(gdb, name, **kw):
     return got, helpers.golden_text(golden)
 
 
-@pytest.mark.parametrize("path", ["1", "2"])
+@pytest.mark.parametrize("path", ["1", "2", "3"])
 def test_goldens_on_every_path(gdb, monkeypatch, path):
     monkeypatch.setenv("GDBAMD_ASM_PATH", path)
     seen = 0
@@ -47,7 +47,7 @@ def test_goldens_on_every_path(gdb, monkeypatch, path):
     assert seen >= 4
 
 
-@pytest.mark.parametrize("path", ["1", "2"])
+@pytest.mark.parametrize("path", ["1", "2", "3"])
 @pytest.mark.parametrize("max_types", ["0", "2"])
 def test_untabled_types_and_tiny_pages(gdb, tmp_path, monkeypatch, path, max_types):
     """record types without table slots take one slot per (record, sample); a page per record restarts every walker at every record"""
@@ -83,7 +83,7 @@ def test_paths_agree_at_1000_samples(gdb, tmp_path, monkeypatch):
     eng.stage_cells(cells)
     eng.set_reference(B, synth.reference(B, L + 2500 + 4096))
     hashes = {}
-    for path in ("0", "1", "2"):
+    for path in ("0", "1", "2", "3"):
         monkeypatch.setenv("GDBAMD_ASM_PATH", path)
         for arena in (4 << 30, 64 << 20):
             got, st = eng.run_interval(B, B + L - 1, arena_bytes=arena)
@@ -97,7 +97,7 @@ def test_paths_agree_at_1000_samples(gdb, tmp_path, monkeypatch):
     eng.close()
 
 
-@pytest.mark.parametrize("path", ["1", "2"])
+@pytest.mark.parametrize("path", ["1", "2", "3"])
 def test_overflow_texts_at_10000_samples(gdb, tmp_path, monkeypatch, path):
     """10 000 samples: most variant entries are longer than an inline slot (overflow pool, texts longer than the registers hold)"""
     from genomicsdb_amd import synth
