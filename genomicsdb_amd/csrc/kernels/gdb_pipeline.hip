@@ -1823,7 +1823,7 @@ k_size2(PieceCtx a, int nchunks, uint64_t* __restrict__ chunk_size) {
 //   * a list ends with an entry that never begins (INT32_MAX).
 // Every record of type t in the block therefore has an entry of list (block, t, r) beginning at or in front of it, and the entry in force is
 // the last such one.  k_plist<false> counts, a scan turns the counts into list offsets, k_plist<true> fills; k_write3 consumes.
-struct PieceEntry { int32_t k_from; uint32_t where, len, pad; };      // where: 16-byte unit of the inline pool, or kOverflowBit | unit of the overflow pool
+struct PieceEntry { int32_t k_from; uint32_t where, len; int32_t k_next; };   // where: 16-byte unit of the inline pool, or kOverflowBit | unit of the overflow pool; k_next: the k_from of the entry behind (a lane decides to move on from the entry it HOLDS - the one behind it is still on its way)
 template <bool FILL> __global__ void __launch_bounds__(kAsmRows)
 k_plist(PieceCtx a, const uint2* __restrict__ desc, int NT, int nchunks, uint32_t* __restrict__ counts_or_offsets, PieceEntry* __restrict__ plist) {
   __shared__ uint32_t cur[kMaxTypes][kAsmRows];                 // per (type, lane): entries so far / where the next one goes
@@ -1840,8 +1840,10 @@ k_plist(PieceCtx a, const uint2* __restrict__ desc, int NT, int nchunks, uint32_
     if (FILL) {
       const uint2 d = desc[slot];
       PieceEntry e;
-      e.k_from = (int32_t)k_from; e.where = d.x; e.len = d.y; e.pad = 0;
-      *reinterpret_cast<uint4*>(&plist[cur[t][lane]]) = *reinterpret_cast<const uint4*>(&e);
+      e.k_from = (int32_t)k_from; e.where = d.x; e.len = d.y; e.k_next = INT32_MAX;
+      const uint32_t at = cur[t][lane];
+      if (at != table[(int64_t)t * a.nrows]) plist[at - 1].k_next = (int32_t)k_from;
+      *reinterpret_cast<uint4*>(&plist[at]) = *reinterpret_cast<const uint4*>(&e);
     }
     ++cur[t][lane];
   };
@@ -1935,6 +1937,22 @@ __device__ __forceinline__ void text_arrived() {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
+// The same wait where `behind` (uniform) page-store instructions have been issued SINCE the loads: gfx9 counts loads and stores in one
+// in-order counter, so "at most `behind` outstanding" = the loads have landed, and the stores - whose acknowledgement nobody needs - keep
+// flying.  (vmcnt(0) here would wait for the acknowledgement of stores issued a moment ago: a full trip to memory on nearly every record,
+// which is exactly what asking for the texts a record ahead is meant to avoid.)  `behind` may be smaller than the truth, never larger.
+__device__ __forceinline__ void texts_arrived_in_front_of(uint32_t behind) {
+  switch (behind) {
+    case 0: asm volatile("s_waitcnt vmcnt(0) ; texts arrived" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1) ; texts arrived" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2) ; texts arrived" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3) ; texts arrived" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4) ; texts arrived" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5) ; texts arrived" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(6) ; texts arrived" ::: "memory"); break;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
 __device__ __forceinline__ uint4 as_uint4(const u32x4& v) { return make_uint4(v.x, v.y, v.z, v.w); }
 // Page assembly without the matrix: k_assemble_write's image / flush loop, fed by a PieceWalker per lane.
 template <int WAVES, int kWaveLds> __global__ void __launch_bounds__(kAsmRows * WAVES)
@@ -1960,6 +1978,7 @@ k_write2(PieceCtx a, const char* __restrict__ pool, const char* __restrict__ poo
   uint64_t below = 0;                                       // record types in front of the run's one (bit mask: a plain cell's slot = its base + how many of them it meets)
   uint32_t prev_t = 0xFFFFFFFFu, nocall_chunks = 0;
   uint64_t pending = 0;                                     // lanes that have asked for a slot's line and not looked at it yet
+  uint32_t behind = 0;                                      // (uniform) page-store instructions issued since the last request
   // A step has two halves.  REQUEST (record jj): samples whose entry changes there name their slot and ask for its line - nothing
   // waits.  TAKE + build + flush: the tags are read (here the loads are waited for), the image is built and written.  The request
   // for record jj + 1 is made between the build and the flush of record jj: the texts of the lanes that change are dead once the
@@ -1991,6 +2010,7 @@ k_write2(PieceCtx a, const char* __restrict__ pool, const char* __restrict__ poo
       }
     }
     pending = __ballot(need);
+    behind = 0;
   };
   // the image of one pass (<= kWaveLds bytes of a record's chunk, with the destination's alignment) -> page
   auto flush = [&](char* gdst, uint32_t al, uint32_t pass_total) {
@@ -2002,11 +2022,14 @@ k_write2(PieceCtx a, const char* __restrict__ pool, const char* __restrict__ poo
     const uint4* lsrc = reinterpret_cast<const uint4*>(img + head);
     uint4* gw = reinterpret_cast<uint4*>(gdst + head);
     for (uint32_t wq = lane; wq < nwords; wq += kAsmRows) gw[wq] = lsrc[wq];
-    {   // the bytes in front of the first and behind the last 16-byte word in ONE store instruction: lanes 0-15 head, 16-31 tail
+    behind += (nwords + (uint32_t)kAsmRows - 1u) / (uint32_t)kAsmRows;   // (one store instruction per trip of the loop)
+    if (head | (pass_total - tail_at)) {   // (uniform, so that the count is exact: one too few and the wait is for the first store of THIS flush)
+      // the bytes in front of the first and behind the last 16-byte word in ONE store instruction: lanes 0-15 head, 16-31 tail
       const uint32_t li = (uint32_t)lane & 15u;
       const bool is_tail = (lane & 16) != 0;
       const uint32_t at = is_tail ? tail_at + li : li;
       if (lane < 32 && li < (is_tail ? pass_total - tail_at : head)) gdst[at] = img[at];
+      ++behind;
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   };
@@ -2021,7 +2044,7 @@ k_write2(PieceCtx a, const char* __restrict__ pool, const char* __restrict__ poo
     request(__builtin_amdgcn_readlane(my_k, 0), (uint32_t)__builtin_amdgcn_readlane((int)my_t, 0));
     for (int jj = 0; jj < cnt; ++jj) {                      // uniform
       if (pending) {                                        // uniform
-        text_arrived();
+        if (dbg & 32) text_arrived(); else texts_arrived_in_front_of(behind);
         if (((pending >> lane) & 1ull) && !((dbg & 64) && cur_len)) {   // take the tag
           cur_where = txt.x[kText2Chunks - 1].z;
           cur_len = txt.x[kText2Chunks - 1].w;
@@ -2110,7 +2133,7 @@ k_write2(PieceCtx a, const char* __restrict__ pool, const char* __restrict__ poo
 // ask for the one behind it, ask for the text" - the entry says where the text lies and how long it is, nothing is decided here.
 template <int WAVES, int kWaveLds> __global__ void __launch_bounds__(kAsmRows * WAVES)
 k_write3(PieceCtx a, const PieceEntry* __restrict__ plist, const uint32_t* __restrict__ pofs, int NT, const char* __restrict__ pool, const char* __restrict__ pool_ovf, const int32_t* __restrict__ order, int64_t n, int nchunks, int run,
-         const uint64_t* __restrict__ chunk_off, uint64_t page_base, char* __restrict__ arena, int xcd_aware) {
+         const uint64_t* __restrict__ chunk_off, uint64_t page_base, char* __restrict__ arena, int xcd_aware, unsigned long long* dbg_counters) {
   const int dbg = xcd_aware >> 1;                            // timing experiments only (GDBAMD_W2_DBG): 1 = no walk behind a run's first record, 2 = slots are named but not fetched, 32 = no request ahead
   const int64_t unit = xcd_aware_unit<WAVES>(((n + run - 1) / run) * (int64_t)nchunks, xcd_aware & 1);
   if (unit < 0) return;
@@ -2129,10 +2152,12 @@ k_write3(PieceCtx a, const PieceEntry* __restrict__ plist, const uint32_t* __res
   // the lane's place in its piece list: nx = the next entry (x = first record it holds from, y = where its text lies, z = its length), requested
   // when the lane took the one in front of it; ent = the entry behind nx
   const PieceEntry* ent = plist;
-  u32x4 nx = u32x4{(uint32_t)INT32_MAX, 0u, 0u, 0u};
+  u32x4 nx = u32x4{(uint32_t)INT32_MAX, 0u, 0u, (uint32_t)INT32_MAX};
+  int32_t cur_until = INT32_MAX;                            // the first record the lane's present entry does not hold any more
   uint32_t prev_t = 0xFFFFFFFFu;
   int32_t prev_sb = -1;
-  uint64_t pending = 0;                                     // lanes that have asked for a slot's line and not looked at it yet
+  uint32_t behind = 0;                                      // (uniform) page-store instructions issued since the last request
+  uint64_t t_wait = 0, n_wait = 0, t_begin = (dbg & 64) ? __builtin_readcyclecounter() : 0;   // (GDBAMD_W2_DBG=64: cycle accounting into the first words of the arena's tail - timing runs only)
   // A step has two halves.  REQUEST (record jj): samples whose entry changes there name their slot and ask for its line - nothing
   // waits.  TAKE + build + flush: the tags are read (here the loads are waited for), the image is built and written.  The request
   // for record jj + 1 is made between the build and the flush of record jj: the texts of the lanes that change are dead once the
@@ -2140,13 +2165,15 @@ k_write3(PieceCtx a, const PieceEntry* __restrict__ plist, const uint32_t* __res
   // record: ~1.6 us against 2.5 us for everything else in the step) passes while the image is flushed.
   // (real moves in front of the load, as in PieceWalker::advance: the entry being taken leaves nx before the next one is loaded into it)
   auto take = [&]() {
-    uint32_t w_, l_;
+    uint32_t w_, l_, u_;
     asm volatile("v_mov_b32 %0, %1" : "=v"(w_) : "v"(nx.y));
     asm volatile("v_mov_b32 %0, %1" : "=v"(l_) : "v"(nx.z));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(u_) : "v"(nx.w));
+    asm volatile("; the entry's first word stays the entry's" : : "v"(nx.x));   // (unused here - but a register the compiler takes for dead while the load into it is under way costs a wait for that load)
     __builtin_amdgcn_sched_barrier(0);
-    nx = *reinterpret_cast<const u32x4*>(ent);
+    load16_in_place<0>(nx, reinterpret_cast<const char*>(ent));   // (in place as well: the compiler would wait for it - and with it for every page store in flight - where the lane next looks at nx)
     ++ent;
-    cur_where = w_; cur_len = l_;
+    cur_where = w_; cur_len = l_; cur_until = (int32_t)u_;
   };
   auto request = [&](int32_t k, uint32_t t) {
     const int32_t sb = k / kSizeBlock;
@@ -2154,15 +2181,16 @@ k_write3(PieceCtx a, const PieceEntry* __restrict__ plist, const uint32_t* __res
       prev_t = t; prev_sb = sb;
       if (has_row) {
         ent = plist + pofs[((int64_t)sb * NT + t) * a.nrows + r];
-        nx = *reinterpret_cast<const u32x4*>(ent);
+        load16_in_place<0>(nx, reinterpret_cast<const char*>(ent));
         ++ent;
-        asm volatile("; the list's first entry has arrived" : : "v"(nx.x), "v"(nx.w));   // (the wait stays in this rare block)
+        text_arrived();                                     // (the wait stays in this rare block)
+        cur_until = INT32_MIN;                              // (every record of the list has an entry at or in front of it: the first one is taken below)
       }
     }
-    const bool need = has_row && k >= (int32_t)nx.x && !((dbg & 2) && cur_len);
+    const bool need = has_row && k >= cur_until;
     if (need) {                                             // the sample's entry changes here: take the next one, ask for the one behind it and for the text
       take();
-      while (k >= (int32_t)nx.x) take();                    // (entries without a record of this run in between: rare, and only these wait)
+      while (k >= cur_until) { text_arrived(); take(); }    // (entries without a record of this run in between: rare, and only these wait for the entry just asked for)
       const char* src = (cur_where & kOverflowBit) ? pool_ovf + (size_t)(cur_where & ~kOverflowBit) * 16 : pool + (size_t)cur_where * 16;
       load16_in_place<0>(txt.x[0], src);
       load16_in_place<16>(txt.x[1], src);
@@ -2175,7 +2203,7 @@ k_write3(PieceCtx a, const PieceEntry* __restrict__ plist, const uint32_t* __res
         load16_in_place<112>(txt.x[7], src);
       }
     }
-    pending = __ballot(need);
+    behind = 0;
   };
   // the image of one pass (<= kWaveLds bytes of a record's chunk, with the destination's alignment) -> page
   auto flush = [&](char* gdst, uint32_t al, uint32_t pass_total) {
@@ -2187,11 +2215,14 @@ k_write3(PieceCtx a, const PieceEntry* __restrict__ plist, const uint32_t* __res
     const uint4* lsrc = reinterpret_cast<const uint4*>(img + head);
     uint4* gw = reinterpret_cast<uint4*>(gdst + head);
     for (uint32_t wq = lane; wq < nwords; wq += kAsmRows) gw[wq] = lsrc[wq];
-    {   // the bytes in front of the first and behind the last 16-byte word in ONE store instruction: lanes 0-15 head, 16-31 tail
+    behind += (nwords + (uint32_t)kAsmRows - 1u) / (uint32_t)kAsmRows;   // (one store instruction per trip of the loop)
+    if (head | (pass_total - tail_at)) {   // (uniform, so that the count is exact: one too few and the wait is for the first store of THIS flush)
+      // the bytes in front of the first and behind the last 16-byte word in ONE store instruction: lanes 0-15 head, 16-31 tail
       const uint32_t li = (uint32_t)lane & 15u;
       const bool is_tail = (lane & 16) != 0;
       const uint32_t at = is_tail ? tail_at + li : li;
       if (lane < 32 && li < (is_tail ? pass_total - tail_at : head)) gdst[at] = img[at];
+      ++behind;
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   };
@@ -2205,7 +2236,10 @@ k_write3(PieceCtx a, const PieceEntry* __restrict__ plist, const uint32_t* __res
     }
     request(__builtin_amdgcn_readlane(my_k, 0), (uint32_t)__builtin_amdgcn_readlane((int)my_t, 0));
     for (int jj = 0; jj < cnt; ++jj) {                      // uniform
-      if (pending) { text_arrived(); pending = 0; }        // uniform: the texts asked for during the previous step
+      // the texts (and the entries) asked for during the previous step: every record waits - where no sample changed, for nothing
+      if (dbg & 64) { const uint64_t t0 = __builtin_readcyclecounter(); texts_arrived_in_front_of(behind); t_wait += __builtin_readcyclecounter() - t0; ++n_wait; }
+      else if (dbg & 32) text_arrived();
+      else texts_arrived_in_front_of(behind);
       const uint32_t len = cur_len;
       const uint32_t inc = wave_inclusive_scan_dpp(len);
       const uint32_t excl = inc - len;
@@ -2276,6 +2310,15 @@ k_write3(PieceCtx a, const PieceEntry* __restrict__ plist, const uint32_t* __res
       if (jj + 1 < cnt) request(__builtin_amdgcn_readlane(my_k, jj + 1), (uint32_t)__builtin_amdgcn_readlane((int)my_t, jj + 1));
       if (built) flush(f_dst, f_al, f_total);
     }
+  }
+  if ((dbg & 64) && lane == 0) {
+    unsigned long long* c = reinterpret_cast<unsigned long long*>(const_cast<uint32_t*>(pofs)) ;   // (the list offsets are not needed any more by this wavefront... other wavefronts still read them: use the tail instead)
+    (void)c;
+    unsigned long long* acc = dbg_counters;
+    atomicAdd(&acc[0], (unsigned long long)(__builtin_readcyclecounter() - t_begin));
+    atomicAdd(&acc[1], (unsigned long long)t_wait);
+    atomicAdd(&acc[2], (unsigned long long)n_wait);
+    atomicAdd(&acc[3], (unsigned long long)(ie - ib));
   }
 }
 
@@ -3459,6 +3502,7 @@ struct DevicePipeline::Impl {
   DevBuf<unsigned long long> type_hkeys; DevBuf<int32_t> type_hrep, type_rep; DevBuf<uint8_t> type_hid, rtype;
   DevBuf<WalkCell> walk; DevBuf<int64_t> walk_inv;
   DevBuf<int32_t> jhint;
+  DevBuf<unsigned long long> dbg_counters;
   DevBuf<uint32_t> pl_cnt, pl_ofs; DevBuf<PieceEntry> plist;     // piece lists (GDBAMD_ASM_PATH=3)
   uint32_t walk_epoch = 0;           // stamp of the interval whose cells the walk list describes (24 bits; 0: none yet)
   // cell-stream staging (append_cells)
@@ -5402,8 +5446,10 @@ bool DevicePipeline::begin_page(uint64_t arena_bytes, int arena_idx, PageTicket*
     (const int32_t*)S.order.p, np, iv.nchunks, wrun, (const uint64_t*)S.chunk_off.p, page_base, arena, (xcd_aware_numbering() ? 1 : 0) | (w2dbg << 1))
     const int ww = write_waves_per_group(), wl = write_image_kb();
     const int w2dbg = getenv("GDBAMD_W2_DBG") ? atoi(getenv("GDBAMD_W2_DBG")) : 0;
+    S.dbg_counters.ensure(8);
+    if (w2dbg & 64) HIP_CHECK(hipMemsetAsync(S.dbg_counters.p, 0, 8 * sizeof(unsigned long long), st));
 #define GDB_LAUNCH_WRITE3(W, L) hipLaunchKernelGGL((k_write3<W, L>), dim3((wgrid.x + (W) - 1u) / (W)), dim3(kAsmRows * (W)), 0, st, iv.pc2, (const PieceEntry*)S.plist.p, (const uint32_t*)S.pl_ofs.p, iv.NT, \
-    (const char*)S.pool.p, (const char*)S.pool_ovf.p, (const int32_t*)S.order.p, np, iv.nchunks, wrun, (const uint64_t*)S.chunk_off.p, page_base, arena, (xcd_aware_numbering() ? 1 : 0) | (w2dbg << 1))
+    (const char*)S.pool.p, (const char*)S.pool_ovf.p, (const int32_t*)S.order.p, np, iv.nchunks, wrun, (const uint64_t*)S.chunk_off.p, page_base, arena, (xcd_aware_numbering() ? 1 : 0) | (w2dbg << 1), S.dbg_counters.p)
     if (iv.asm_path == 3) { if (wl <= 4) GDB_LAUNCH_WRITE3(1, 4096); else GDB_LAUNCH_WRITE3(1, 8192); }
     else
     if (ww >= 4 && wl <= 4) GDB_LAUNCH_WRITE2(4, 4096);
@@ -5413,6 +5459,13 @@ bool DevicePipeline::begin_page(uint64_t arena_bytes, int arena_idx, PageTicket*
     else GDB_LAUNCH_WRITE2(1, 8192);
 #undef GDB_LAUNCH_WRITE2
 #undef GDB_LAUNCH_WRITE3
+    if ((w2dbg & 64) && iv.asm_path == 3) {
+      unsigned long long c[4];
+      HIP_CHECK(hipMemcpyAsync(c, S.dbg_counters.p, sizeof(c), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      fprintf(stderr, "[k_write3] wavefront cycles %.3e, waiting for texts %.3e (%.1f %%), waits %llu, steps %llu: %.0f cycles per step, %.0f per wait\n", (double)c[0], (double)c[1],
+              100.0 * (double)c[1] / (double)std::max<unsigned long long>(1, c[0]), c[2], c[3], (double)c[0] / (double)std::max<unsigned long long>(1, c[3]), (double)c[1] / (double)std::max<unsigned long long>(1, c[2]));
+    }
     HIP_CHECK(hipEventRecord(w[2], st));
     HIP_CHECK(hipMemcpyAsync(&S.hb->page_err[ai], S.err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipEventRecord(w[3], st));

@@ -1,6 +1,7 @@
 """ISA check for k_write2 (tests/tools/isa.sh output): the texts requested ahead are loaded by inline asm into the registers the
 lane's text already lives in, so the compiler does not know they are pending.  Walk the kernel's control-flow graph and make sure no
-instruction reads one of those registers between such a load and the next `s_waitcnt vmcnt(0)`.
+instruction reads one of those registers between such a load and the next `s_waitcnt vmcnt(0)` (or the counted wait of
+texts_arrived_in_front_of, marked "texts arrived": vmcnt(N) behind N page stores issued after the loads).
 usage: python tests/tools/check_inplace_loads.py /tmp/gdb_pipeline.s [kernel-name-substring]"""
 import re, sys
 src = open(sys.argv[1]).read().split('\n')
@@ -21,6 +22,7 @@ blocks, cur, name = {}, [], 'entry'
 order = []
 for l in body:
     marked = 'in-place text' in l
+    counted = 'texts arrived' in l        # s_waitcnt vmcnt(N) behind N page stores issued after the loads (texts_arrived_in_front_of)
     t = l.split(';')[0].rstrip()
     m = re.match(r'^(\.LBB\w+):', t)
     if m:
@@ -28,7 +30,7 @@ for l in body:
         continue
     t = t.strip()
     if not t or t.startswith('.'): continue
-    cur.append(t + (' ;INPLACE' if marked else ''))
+    cur.append(t + (' ;INPLACE' if marked else '') + (' ;ARRIVED' if counted else ''))
 blocks[name] = cur; order.append(name)
 succ = {}
 for i, b in enumerate(order):
@@ -72,7 +74,7 @@ while work:
     b = work.pop()
     pend = set(state_in[b])
     for t in blocks[b]:
-        if t.startswith('s_waitcnt') and 'vmcnt(0)' in t: pend.clear(); continue
+        if t.startswith('s_waitcnt') and ('vmcnt(0)' in t or ';ARRIVED' in t): pend.clear(); continue
         m = inplace.match(t)
         rd = sources(t)
         if rd & pend: bad.append((b, t, sorted(rd & pend)))
