@@ -30,7 +30,8 @@
 #define GDB_MAX_INFO_VECTOR 64       // elements of an element_wise_sum INFO vector
 #define GDB_MAX_ID_TOKENS 16        // distinct ';'-separated ID tokens per output record
 #define GDB_MAX_FILTER_IDS 16       // distinct FILTER ids united in one output record
-#define GDB_MAX_PIPELINES_PER_PROCESS 16   // elements of the __constant__ context array (kernels/gdb_pipeline.hip: c_ex), one per live pipeline
+#define GDB_MAX_PIPELINES_PER_PROCESS 256  // elements of the __constant__ context array (kernels/gdb_pipeline.hip: c_ex), one per live pipeline (on gfx9 the constant
+                                           // address space is ordinary device memory read with scalar loads: nothing limits it to 64 KB)
 #define GDB_MAX_HISTOGRAM_FIELDS 8  // composite (bins, counts) INFO fields reduced with histogram_sum
 
 // htslib / TileDB sentinels (reference include/vcf/vcf.h:59-218)

@@ -3647,7 +3647,7 @@ DevicePipeline::DevicePipeline(const HostPlan& hp, int device) : m_(new Impl) {
     std::lock_guard<std::mutex> g(g_ctx_slot_mutex);
     for (int i = 0; i < kCtxSlots && m_->ctx_slot < 0; ++i) if (!g_ctx_slot_used[i]) { g_ctx_slot_used[i] = true; m_->ctx_slot = i; }
   }
-  if (m_->ctx_slot < 0) { this->~DevicePipeline(); throw GenomicsDBDeviceException("more than 16 device pipelines alive in one process (GDBAMD_MAX_PIPELINES_PER_PROCESS: one per engine or query stream, two for an engine that streams an array in windows)"); }
+  if (m_->ctx_slot < 0) { this->~DevicePipeline(); throw GenomicsDBDeviceException("more than " + std::to_string(kCtxSlots) + " device pipelines alive in one process (GDBAMD_MAX_PIPELINES_PER_PROCESS: one per engine or query stream, two for an engine that streams an array in windows)"); }
 }
 
 DevicePipeline::~DevicePipeline() {

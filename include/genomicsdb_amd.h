@@ -33,8 +33,9 @@
 #define GDBAMD_MAX_ID_TOKENS 16             /* distinct ';'-separated ID tokens united in one record (data) */
 #define GDBAMD_MAX_FILTER_IDS 16            /* distinct FILTER ids united in one record (data) */
 #define GDBAMD_MAX_HISTOGRAM_FIELDS 8       /* (bins, counts) INFO fields reduced with histogram_sum (plan time) */
-#define GDBAMD_MAX_PIPELINES_PER_PROCESS 16 /* device pipelines alive in one process: one per query stream / engine, two for an engine that streams an array through HBM
-                                              * in windows with overlapped staging (each owns a 3.5 KB element of a 64 KB __constant__ array; handles do not serialise) */
+#define GDBAMD_MAX_PIPELINES_PER_PROCESS 256 /* device pipelines alive in one process: one per query stream / engine, two for an engine that streams an array through HBM
+                                              * in windows with overlapped staging (each owns a 3.5 KB element of a __constant__ array - 0.9 MB of device memory read
+                                              * with scalar loads; handles do not serialise on it) */
 
 #ifdef __cplusplus
 extern "C" {

@@ -702,17 +702,34 @@ def test_two_handles_in_two_threads(gdb, tmp_path):
 
 
 def test_pipelines_per_process_limit_is_reported(gdb, tmp_path):
-    """GDBAMD_MAX_PIPELINES_PER_PROCESS = 16 (include/genomicsdb_amd.h): the 17th engine alive at a time is refused with a message
-    that names the limit; closing one makes room again"""
-    q = helpers.synth_query(tmp_path, 5, 10_000_000, 10_000_100)
+    """GDBAMD_MAX_PIPELINES_PER_PROCESS (include/genomicsdb_amd.h; 256 since round 4 - round 3: 16): one engine more than that alive at a
+    time is refused with a message that names the limit, closing one makes room again; engines far beyond the old 16 give the same bytes"""
+    import os, re
+    hdr = open(os.path.join(helpers.ROOT, "include", "genomicsdb_amd.h")).read()
+    cap = int(re.search(r"#define GDBAMD_MAX_PIPELINES_PER_PROCESS (\d+)", hdr).group(1))
+    assert cap >= 256
+    from genomicsdb_amd import synth
+    N, B, L = 5, 10_000_000, 101
+    cells, _ = synth.Generator(N, B, L).chunk_bytes(B + L)
+    q = helpers.synth_query(tmp_path, N, B, B + L - 1)
     engines = []
     try:
-        for i in range(16):
+        for i in range(cap):
             engines.append(gdb.CombineEngine(q))
-        with pytest.raises(gdb.GenomicsDBException, match="16 device pipelines"):
+        with pytest.raises(gdb.GenomicsDBException, match="%d device pipelines" % cap):
             gdb.CombineEngine(q)
         engines.pop().close()
         engines.append(gdb.CombineEngine(q))
+        outs = []
+        for i in (0, 15, 16, 17, cap // 2, cap - 1):
+            e = engines[i]
+            e.stage_cells(cells)
+            e.set_reference(B, synth.reference(B, L + 4096))
+            got, st = e.run_interval(B, B + L - 1, arena_bytes=1 << 20)
+            outs.append(got)
+        assert len(set(outs)) == 1 and len(outs[0]) > 0
+        want, nrec, _ = helpers.oracle_run_synth(q, cells, synth.SEED, with_header=False)
+        assert outs[0] == want
     finally:
         for e in engines:
             e.close()
