@@ -5,6 +5,7 @@
 // reports done, draining the output buffer after each call (the "-p <page>" batched mode when
 // buffer_limit != 0).
 #include "gdb_oracle_combine.hpp"
+#include "gdb_oracle_print.hpp"
 
 #include <chrono>
 #include <cstdio>
@@ -122,6 +123,30 @@ int oracle_run_query_synthetic_reference(const char* query_json_text, const uint
     if (err && errlen) snprintf(err, errlen, "%s", e.what());
     return 1;
   }
+}
+
+// gt_mpi_gather --print-calls (gdb_oracle_print.hpp): the JSON document of the query's cells; *out malloc'ed
+int oracle_print_calls(const char* query_json_text, const uint8_t* cells, uint64_t nbytes, char** out, uint64_t* out_len, char* err, uint64_t errlen) {
+  try {
+    oracle_json::Value q = oracle_json::parse(query_json_text);
+    VidMapper vid;
+    if (q.HasMember("vid_mapping_file")) vid.load_vid(oracle_json::parse_file(q["vid_mapping_file"].GetString()));
+    else if (q.HasMember("vid_mapping")) vid.load_vid(q["vid_mapping"]);
+    else throw OracleException("query JSON needs vid_mapping_file or vid_mapping");
+    if (q.HasMember("callset_mapping_file")) vid.load_callsets(oracle_json::parse_file(q["callset_mapping_file"].GetString()));
+    else if (q.HasMember("callset_mapping") || q.HasMember("callsets")) vid.load_callsets(q);
+    else throw OracleException("query JSON needs callset_mapping_file or callset_mapping");
+    VariantArray array;
+    array.schema = build_array_schema(vid);
+    array.num_rows = (int64_t)vid.row_to_callset.size();
+    array.load(cells, nbytes, 0, INT64_MAX - 1);
+    QueryConfig qc;
+    qc.read_query_json(q, vid, 0);
+    qc.do_query_bookkeeping(array.schema, vid, array.num_rows, 0);
+    std::string o = print_calls(array, qc, vid);
+    *out = (char*)malloc(o.size() + 1); memcpy(*out, o.data(), o.size()); (*out)[o.size()] = 0; *out_len = o.size();
+    return 0;
+  } catch (const std::exception& e) { if (err && errlen) snprintf(err, errlen, "%s", e.what()); return 1; }
 }
 
 void oracle_free(char* p) { free(p); }

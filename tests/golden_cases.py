@@ -76,3 +76,38 @@ CASES = [
 # Goldens of the hot path that are NOT covered yet, with the reason (kept visible on purpose).
 UNCOVERED = {
 }
+
+
+# ---- gt_mpi_gather --print-calls (the reference's "calls" goldens, tests/run.py:184-720) ----------------------------------------
+CALLS_ATTRIBUTES = ["REF", "ALT", "BaseQRankSum", "MQ", "RAW_MQ", "MQ0", "ClippingRankSum", "MQRankSum", "ReadPosRankSum", "DP", "GT", "GQ",
+                    "SB", "AD", "PL", "DP_FORMAT", "MIN_DP", "PID", "PGT"]   # run.py:50 (the query template's "attributes")
+CALLS_ATTRIBUTES_DS_ID = CALLS_ATTRIBUTES + ["DS", "ID"]
+
+
+def _rl(*pairs):
+    return [{"range_list": [{"low": lo, "high": hi} for lo, hi in pairs]}]
+
+
+CALLS_CASES = [
+    # name (= golden file), callsets, vid, query_column_ranges, attributes
+    ("t0_1_2_calls_at_0", "t0_1_2.json", "vid.json", FULL, CALLS_ATTRIBUTES),
+    ("t0_1_2_calls_at_multiple_positions", "t0_1_2.json", "vid.json", [[12000, 12142, 12144, 12160, 12290, 12294, 14000, 17384, 18000]], CALLS_ATTRIBUTES),
+    ("t0_1_2_calls_at_12100", "t0_1_2.json", "vid.json", _rl((12100, 12100)), CALLS_ATTRIBUTES),
+    ("t0_1_2_calls_at_12100_12141", "t0_1_2.json", "vid.json", _rl((12100, 12100), (12141, 12141)), CALLS_ATTRIBUTES),
+    ("t0_1_2_calls_at_12100_12141_12150", "t0_1_2.json", "vid.json", _rl((12100, 12100), (12141, 12141), (12150, 12150)), CALLS_ATTRIBUTES),
+    ("t0_1_2_calls_at_12100_12141_to_12150", "t0_1_2.json", "vid.json", _rl((12100, 12100), (12141, 12150)), CALLS_ATTRIBUTES),
+    ("t0_1_2_calls_at_12100_12141_to_12150_12300_17384", "t0_1_2.json", "vid.json", _rl((12100, 12100), (12141, 12150), (12300, 12300), (17384, 17384)),
+     CALLS_ATTRIBUTES),
+    ("t0_1_2_calls_at_0_with_PL_only", "t0_1_2.json", "vid.json", FULL, ["PL"]),
+    ("t0_1_2_calls_at_12150", "t0_1_2.json", "vid.json", _r(12150), CALLS_ATTRIBUTES),
+    ("t6_7_8_calls_at_0", "t6_7_8.json", "vid.json", FULL, CALLS_ATTRIBUTES),
+    ("t6_7_8_calls_at_8029500", "t6_7_8.json", "vid.json", _r(8029500), CALLS_ATTRIBUTES),
+    ("t0_1_2_calls_at_0_phased_GT", "t0_1_2.json", "vid_phased_GT.json", FULL, CALLS_ATTRIBUTES),
+    ("t0_1_2_calls_at_12150_phased_GT", "t0_1_2.json", "vid_phased_GT.json", _r(12150), CALLS_ATTRIBUTES),
+    ("t6_7_8_calls_at_0_phased_GT", "t6_7_8.json", "vid_phased_GT.json", FULL, CALLS_ATTRIBUTES),
+    ("t6_7_8_calls_at_8029500_phased_GT", "t6_7_8.json", "vid_phased_GT.json", _r(8029500), CALLS_ATTRIBUTES),
+    ("test_new_fields_MLEAC_only.json", "t6_7_8.json", "vid_MLEAC_MLEAF.json", FULL, ["MLEAC"]),
+    ("t0_1_2_DS_ID_calls_at_0", "t0_1_2.json", "vid_DS_ID.json", FULL, CALLS_ATTRIBUTES_DS_ID),
+    ("t0_1_2_DS_ID_calls_at_0_phased_GT", "t0_1_2.json", "vid_DS_ID_phased_GT.json", FULL, CALLS_ATTRIBUTES_DS_ID),
+    ("t0_with_missing_PL_SB_fields_t1_calls.json", "t0_with_missing_PL_SB_fields_t1.json", "vid.json", FULL, CALLS_ATTRIBUTES),
+]
