@@ -204,6 +204,17 @@ class CombineEngine:
     def set_reference(self, begin, bases):
         _check(_lib.lib().gdbamd_engine_set_reference(self._e, begin, bases, len(bases)) == 0, "set_reference")
 
+    def print_calls(self):
+        """`gt_mpi_gather --print-calls`: the JSON document of the cells of the query's column intervals (VariantCallPrintOperator), bytes"""
+        L = _lib.lib()
+        L.gdbamd_engine_print_calls.restype = ctypes.c_int64
+        L.gdbamd_engine_print_calls.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
+        n = L.gdbamd_engine_print_calls(self._e, None, 0)
+        _check(n >= 0, "print_calls")
+        buf = ctypes.create_string_buffer(max(1, n))
+        _check(L.gdbamd_engine_print_calls(self._e, buf, n) == n, "print_calls")
+        return buf.raw[:n]
+
     def column_histogram(self, hist_begin, hist_end, bin_size, counts=None):
         """ColumnHistogramOperator on the device: numpy uint64 counts[(hist_end - hist_begin) // bin_size + 1] of the staged begin-cells by
         begin column (counts given: added to, for arrays streamed in windows)"""

@@ -20,7 +20,7 @@ template <class F, class R> R guarded(F f, R on_error) {
   catch (const std::exception& e) { g_last_error = e.what(); return on_error; }
   catch (...) { g_last_error = "unknown exception"; return on_error; }
 }
-struct EngineHandle { std::unique_ptr<CombineEngine> eng; };
+struct EngineHandle { std::unique_ptr<CombineEngine> eng; std::string calls_text; };
 }  // namespace
 
 extern "C" {
@@ -267,6 +267,20 @@ int gdbamd_engine_split_point(void* engine, int64_t qb, int64_t qe, int64_t max_
 }
 int gdbamd_engine_column_histogram(void* engine, uint64_t hist_begin, uint64_t hist_end, uint64_t bin_size, uint64_t* counts, uint64_t nbins, int accumulate) {
   try { ((EngineHandle*)engine)->eng->pipeline().column_histogram(hist_begin, hist_end, bin_size, counts, nbins, accumulate != 0); return 0; } catch (const std::exception& e) { g_last_error = e.what(); return -1; }
+}
+// gt_mpi_gather --print-calls: the document is produced by the call with dst == NULL (which returns its length) and kept in the handle
+// for the call that copies it
+int64_t gdbamd_engine_print_calls(void* engine, char* dst, uint64_t cap) {
+  try {
+    EngineHandle* h = (EngineHandle*)engine;
+    if (!dst) h->calls_text = h->eng->print_calls();
+    else {
+      if (h->calls_text.empty()) h->calls_text = h->eng->print_calls();
+      if (cap < h->calls_text.size()) { g_last_error = "print_calls: destination too small"; return -1; }
+      memcpy(dst, h->calls_text.data(), h->calls_text.size());
+    }
+    return (int64_t)h->calls_text.size();
+  } catch (const std::exception& e) { g_last_error = e.what(); return -1; }
 }
 // ColumnHistogramOperator::equi_partition_and_print_bins (variant_operations.cc:769-796), the text it prints; returns its length (dst may be NULL), -1 when
 // num_parts >= nbins (the reference prints a complaint and returns false)

@@ -358,6 +358,38 @@ void CombineEngine::column_histogram(uint64_t hist_begin, uint64_t hist_end, uin
   }
 }
 
+std::string CombineEngine::print_calls() {
+  const std::string ip = "    ";
+  std::string o = "{\n" + ip + "\"variant_calls\": [\n";
+  const std::string p0 = ip + ip, p1 = p0 + ip;
+  unsigned printed = 0;
+  std::vector<std::pair<int64_t, int64_t>> ivs;
+  for (unsigned i = 0; i < m_qc.get_num_column_intervals(); ++i) ivs.emplace_back(m_qc.get_column_begin(i), m_qc.get_column_end(i));
+  const bool whole_array = ivs.empty();       // a scan of the whole array has no interval begin to intersect (genomicsdb_iterators.cc:188-190)
+  if (whole_array) ivs.emplace_back(0, INT64_MAX - 1);
+  for (const auto& iv : ivs) {
+    std::string cells;
+    bool first_piece = true;
+    for (int64_t pos = iv.first; pos <= iv.second;) {            // piece by piece when the array passes through HBM in column windows
+      const Coverage cov = cover(pos);
+      const int64_t hi = std::min(cov.hi, iv.second);
+      std::string part = m_pipe->calls_json(pos, hi, 16, first_piece && !whole_array);
+      if (!part.empty()) { if (!cells.empty()) cells += ",\n"; cells += part; }
+      first_piece = false;
+      if (hi >= iv.second || m_src.kind == SRC_NONE || m_window_eof) break;
+      pos = hi + 1;
+    }
+    if (cells.empty()) continue;                                  // (an interval without a cell prints nothing: the header is printed WITH its first cell)
+    if (printed) o += "\n" + p1 + "]\n" + p0 + "},\n";
+    o += p0 + "{\n" + p1 + "\"query_interval\": [ " + std::to_string(iv.first) + ", " + std::to_string(iv.second) + " ],\n" + p1 + "\"variant_calls\": [\n";
+    o += cells;
+    ++printed;
+  }
+  if (printed) o += "\n" + p1 + "]\n" + p0 + "}";
+  o += "\n" + ip + "]\n}\n";
+  return o;
+}
+
 void CombineEngine::set_reference_window(int64_t begin, const std::string& bases) {
   m_user_ref = true; m_user_ref_begin = begin; m_user_ref_bases = bases;
   m_pipe->set_reference_window(begin, bases);

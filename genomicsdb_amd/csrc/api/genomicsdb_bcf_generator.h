@@ -54,6 +54,9 @@ class CombineEngine {
   Coverage cover(int64_t column);                               // stages windows until `column` is covered
   // ColumnHistogramOperator over the whole array source (all its column windows, front to back): counts[(hist_end - hist_begin) / bin_size + 1]
   void column_histogram(uint64_t hist_begin, uint64_t hist_end, uint64_t bin_size, std::vector<uint64_t>& counts);
+  // gt_mpi_gather --print-calls (tools/src/gt_mpi_gather.cc:369-383): the JSON document of the query's cells, interval by interval
+  // (VariantCallPrintOperator, variant_operations.cc:803-843); the cells are selected and formatted on the device (DevicePipeline::calls_json)
+  std::string print_calls();
   uint64_t staging_budget_bytes() const;
   int64_t windows_staged = 0;
   uint64_t pipeline_generation = 0;   // counts the swaps of the two pipelines (overlapped staging): pipeline() is another object afterwards

@@ -120,6 +120,11 @@ class DevicePipeline {
   // ColumnHistogramOperator (variant_operations.cc:732-767) over the staged fragment's begin-cells: counts[(end - begin) / bin_size + 1];
   // accumulate: add to what counts holds (an array streamed in windows is counted window by window)
   void column_histogram(uint64_t hist_begin, uint64_t hist_end, uint64_t bin_size, uint64_t* counts, uint64_t nbins, bool accumulate = false);
+  // gt_mpi_gather --print-calls (VariantCallPrintOperator, variant_operations.cc:803-843): the cells of [qb, qe] in the reference's iterator
+  // order - first the intervals that began before qb and intersect it, then the cells that begin inside - as JSON objects separated by
+  // ",\n", every line indented by `indent` spaces; ncells: how many.  with_intersecting = false: only the cells that begin inside (the
+  // continuation of an interval whose first piece has been printed from an earlier column window)
+  std::string calls_json(int64_t qb, int64_t qe, int indent, bool with_intersecting = true, int64_t* ncells = nullptr);
   bool next_page(uint64_t arena_bytes, const char** dev_ptr, uint64_t* nbytes);
   // the same in two steps (asynchronous page production, two arenas): see gdb_pipeline.hip
   struct PageTicket { int arena = 0; const char* dev = nullptr; uint64_t nbytes = 0; void* done_event = nullptr; };   // done_event: hipEvent_t recorded behind the page's kernels
@@ -135,6 +140,7 @@ class DevicePipeline {
   static int device_count();
   struct Impl;
  private:
+  void classify_fragment();
   Impl* m_;
 };
 

@@ -27,6 +27,7 @@
 
 #include "../core/gdb_stages.hpp"
 #include "../core/gdb_bcf.hpp"
+#include "../core/gdb_calls.hpp"
 #include "gdb_pipeline.h"
 #include "gdb_bgzf.h"
 
@@ -3487,6 +3488,7 @@ struct DevicePipeline::Impl {
   DevBuf<uint32_t> err; DevBuf<int32_t> counters;
   DevBuf<uint32_t> site_key, site_key_sorted; DevBuf<int32_t> site_ord_in, site_ord;
   int ctx_slot = -1;                 // this pipeline's element of c_ex
+  DevBuf<char> calls_names, calls_text; DevBuf<int32_t> calls_name_off; DevBuf<uint64_t> calls_len, calls_off; bool calls_names_ready = false;   // --print-calls
   // persistent events (no create / destroy per interval) and one pinned block for every scalar that comes back to the host
   hipEvent_t ev_prep[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_page[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};   // per arena: start, before / after the page assembly, page done
@@ -4814,25 +4816,14 @@ void DevicePipeline::column_histogram(uint64_t hist_begin, uint64_t hist_end, ui
   HIP_CHECK(hipStreamSynchronize(S.stream));
 }
 
-void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
+// S0 classify + S1 row index + S2 effective END: independent of the query interval, once per staged fragment
+void DevicePipeline::classify_fragment() {
   Impl& S = *m_;
-  S.iv = Impl::IntervalState();
-  S.order_k0 = S.order_n = -1;
-  S.order_iv_valid = false;
-  HIP_CHECK(hipSetDevice(S.device));
   hipStream_t st = S.stream;
   const CombinePlan& pl = S.hp.plan;
   const FragmentView& fr = S.fr;
   const int64_t C = fr.ncells;
   const int32_t N = pl.num_query_rows;
-  IntervalStats& stats = S.iv.stats;
-  stats.num_cells = C;
-  if (C == 0 || N == 0) return;
-  hipEvent_t* ev = S.ev_prep;
-  HIP_CHECK(hipMemsetAsync(S.err.p, 0, sizeof(uint32_t), st));
-  HIP_CHECK(hipMemsetAsync(S.counters.p, 0, (16 + kCountSpread) * sizeof(int32_t), st));
-  HIP_CHECK(hipEventRecord(ev[0], st));
-  // ---- S0 classify + S1 row index (independent of the query interval: once per staged fragment) ---------------------
   S.vmask.ensure(C); S.cflags.ensure(C); S.dpval.ensure(C); S.k_lo.ensure(C); S.k_hi.ensure(C); S.eff_end.ensure(C);
   CellMeta cm{S.vmask.p, S.cflags.p, S.dpval.p, S.eff_end.p, S.k_lo.p, S.k_hi.p};
   S.perm.ensure(C); S.rm_begin.ensure(C); S.row_ptr.ensure((size_t)N + 2);
@@ -4862,6 +4853,102 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
     S.max_span = S.read_back(S.span_max.p);
     S.classified = true;
   }
+}
+
+// ---- gt_mpi_gather --print-calls: the cells of a query column interval as JSON objects (core/gdb_calls.hpp) --------------------------
+// Which cells: the reference's SingleCellTileDBIterator (genomicsdb_iterators.cc:181-301, 425-510) first looks for the intervals that
+// began before the query interval and intersect its begin - per row the first cell at or behind it, if that is an END copy -, hands
+// them out in column-major order of their begins, then traverses [qb, qe].  The staged fragment holds begin cells only, sorted by
+// (begin, row), and every cell's effective END (where the loader's truncated END copy lies): the cells are those with
+// begin < qb <= eff_end, printed with eff_end as their END, followed by those with qb <= begin <= qe - already in the right order.
+// One thread per cell; the emitter runs twice (length, text) around a scan, like the other emitters of this file.
+template <bool WRITE> __global__ void k_calls(FragmentView fr, CombinePlan pl, QueryWindow qw, CallsNames names, const int64_t* __restrict__ eff_end, int64_t c_base, int64_t n,
+                                              int64_t qb, int64_t qe, int indent, int with_intersecting, uint64_t* __restrict__ len_or_off, char* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t c = c_base + i;
+  int64_t end = 0;
+  const bool take = calls_select(fr, eff_end, c, qb, qe, with_intersecting != 0, end);
+  if (!WRITE) {
+    uint64_t l = 0;
+    if (take) { CountSink s; calls_emit_cell(s, fr, pl, qw, names, c, end, indent); l = s.n + 2u; }   // ",\n" in front of every cell (the caller drops the first)
+    len_or_off[i] = l;
+  } else if (take) {
+    ByteSink s(out + len_or_off[i]);
+    s.put(','); s.put('\n');
+    calls_emit_cell(s, fr, pl, qw, names, c, end, indent);
+  }
+}
+
+std::string DevicePipeline::calls_json(int64_t qb, int64_t qe, int indent, bool with_intersecting, int64_t* ncells) {
+  Impl& S = *m_;
+  HIP_CHECK(hipSetDevice(S.device));
+  hipStream_t st = S.stream;
+  const FragmentView& fr = S.fr;
+  const int64_t C = fr.ncells;
+  if (ncells) *ncells = 0;
+  if (C == 0 || S.hp.plan.num_query_rows == 0) return std::string();
+  for (int f = 0; f < S.hp.plan.nfields; ++f)
+    if (S.hp.plan.field[f].ndim == 2) throw GenomicsDBDeviceException("print-calls: 2-dimensional field " + S.hp.field_names[(size_t)f] + " is not printed on the device");
+  HIP_CHECK(hipMemsetAsync(S.err.p, 0, sizeof(uint32_t), st));
+  classify_fragment();
+  if (!S.calls_names_ready) {
+    std::string text; std::vector<int32_t> off;
+    for (const auto& nm : S.hp.field_names) { off.push_back((int32_t)text.size()); text += nm; }
+    off.push_back((int32_t)text.size());
+    S.calls_names.ensure(text.size() + 1); S.calls_name_off.ensure(off.size());
+    HIP_CHECK(hipMemcpy(S.calls_names.p, text.data(), text.size(), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(S.calls_name_off.p, off.data(), off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    S.calls_names_ready = true;
+  }
+  S.cwin.ensure(4);
+  hipLaunchKernelGGL(k_cell_window, dim3(1), dim3(64), 0, st, fr.begin, C, qb > INT64_MIN + S.max_span ? qb - S.max_span : INT64_MIN, qe, S.cwin.p);
+  int64_t cw[2] = {0, 0};
+  S.read_back_many({{cw, S.cwin.p, 2 * sizeof(int64_t)}});
+  const int64_t c_base = cw[0], CW = cw[1] - cw[0];
+  if (CW <= 0) return std::string();
+  QueryWindow qw;
+  memset(&qw, 0, sizeof(qw));
+  qw.qb = qb; qw.qe = qe;
+  qw.contigs = S.contigs.p; qw.ncontigs = (int32_t)S.hp.contigs.size(); qw.contig_names = S.contig_names.p;
+  CallsNames names{S.calls_names.p, S.calls_name_off.p};
+  S.calls_len.ensure((size_t)CW + 1); S.calls_off.ensure((size_t)CW + 1);
+  hipLaunchKernelGGL(k_calls<false>, dim3(blocks_for(CW)), dim3(kBlock), 0, st, fr, S.hp.plan, qw, names, (const int64_t*)S.eff_end.p, c_base, CW, qb, qe, indent, with_intersecting ? 1 : 0, S.calls_len.p, (char*)nullptr);
+  HIP_CHECK(hipMemsetAsync(S.calls_len.p + CW, 0, sizeof(uint64_t), st));
+  S.excl_scan(S.calls_len.p, S.calls_off.p, (size_t)CW + 1);
+  const uint64_t total = S.read_back(S.calls_off.p + CW);
+  if (total == 0) return std::string();
+  S.calls_text.ensure((size_t)total + 16);
+  hipLaunchKernelGGL(k_calls<true>, dim3(blocks_for(CW)), dim3(kBlock), 0, st, fr, S.hp.plan, qw, names, (const int64_t*)S.eff_end.p, c_base, CW, qb, qe, indent, with_intersecting ? 1 : 0, S.calls_off.p, S.calls_text.p);
+  std::string out((size_t)total, '\0');
+  HIP_CHECK(hipMemcpyAsync(&out[0], S.calls_text.p, (size_t)total, hipMemcpyDeviceToHost, st));
+  uint32_t eb = 0;
+  S.read_back_many({{&eb, S.err.p, sizeof(uint32_t)}});
+  if (eb) throw GenomicsDBDeviceException(err_bits_text(eb));
+  if (ncells) { int64_t k = 0; for (size_t q = 0; q + 1 < out.size(); ++q) if (out[q] == ',' && out[q + 1] == '\n' && out.compare(q + 2, (size_t)indent + 2, std::string((size_t)indent, ' ') + "{\n") == 0) ++k; *ncells = k; }
+  return out.substr(2);   // (without the first separator)
+}
+
+void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
+  Impl& S = *m_;
+  S.iv = Impl::IntervalState();
+  S.order_k0 = S.order_n = -1;
+  S.order_iv_valid = false;
+  HIP_CHECK(hipSetDevice(S.device));
+  hipStream_t st = S.stream;
+  const CombinePlan& pl = S.hp.plan;
+  const FragmentView& fr = S.fr;
+  const int64_t C = fr.ncells;
+  const int32_t N = pl.num_query_rows;
+  IntervalStats& stats = S.iv.stats;
+  stats.num_cells = C;
+  if (C == 0 || N == 0) return;
+  hipEvent_t* ev = S.ev_prep;
+  HIP_CHECK(hipMemsetAsync(S.err.p, 0, sizeof(uint32_t), st));
+  HIP_CHECK(hipMemsetAsync(S.counters.p, 0, (16 + kCountSpread) * sizeof(int32_t), st));
+  HIP_CHECK(hipEventRecord(ev[0], st));
+  classify_fragment();
+  CellMeta cm{S.vmask.p, S.cflags.p, S.dpval.p, S.eff_end.p, S.k_lo.p, S.k_hi.p};
   // ---- cells that can reach the window -----------------------------------------------------------------------------
   S.cwin.ensure(4);
   STAGE("k_cell_window");

@@ -143,6 +143,11 @@ int gdbamd_engine_split_point(void* engine, int64_t column_begin, int64_t column
  * the staged begin-cells counted on the device by the bin of their begin column.  nbins must be (hist_end - hist_begin) / bin_size + 1; a cell beginning at or
  * before hist_begin counts for bin 0, one at or behind hist_end for the last bin.  accumulate != 0 adds to what counts holds (arrays streamed in windows). */
 int gdbamd_engine_column_histogram(void* engine, uint64_t hist_begin, uint64_t hist_end, uint64_t bin_size, uint64_t* counts, uint64_t nbins, int accumulate);
+/* VariantCallPrintOperator (src/main/cpp/src/query_operations/variant_operations.cc:803-843; gt_mpi_gather --print-calls, tools/src/gt_mpi_gather.cc:369-383):
+ * the cells of the query's column intervals as the reference's JSON document - per interval first the intervals that began in front of it and
+ * intersect its begin, then the cells that begin inside (SingleCellTileDBIterator, src/main/cpp/src/genomicsdb/genomicsdb_iterators.cc:181-510); selected and
+ * formatted on the device, one thread per cell.  Call with dst == NULL for the length, then with a buffer of at least that size.  -1: error. */
+int64_t gdbamd_engine_print_calls(void* engine, char* dst, uint64_t cap);
 /* "index_output_VCF" (src/main/cpp/src/config/json_config.cc:648, src/main/cpp/src/vcf/vcf_adapter.cc:275-295): the index htslib builds from a finished BGZF
  * file - <path>.tbi for a bgzip'ed VCF (tbx_index_build with the VCF preset), <path>.csi with min_shift 14 for a BGZF BCF2 file (bcf_index_build(.., 14)).
  * The file-writing VCFAdapter and gt_mpi_gather call it when the query JSON says "index_output_VCF": true and the format is "z" / "b". */

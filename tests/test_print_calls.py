@@ -9,6 +9,12 @@ import helpers
 from golden_cases import CALLS_CASES
 
 
+@pytest.fixture()
+def gdb():
+    import genomicsdb_amd
+    return genomicsdb_amd
+
+
 def calls_query(callsets, vid, ranges, attributes):
     return {
         "vid_mapping_file": os.path.join(helpers.GOLDEN, "inputs", vid),
@@ -42,3 +48,98 @@ def test_oracle_prints_the_reference_calls_goldens(case):
     want = helpers.golden_text(name)
     assert json.loads(got) == json.loads(want)      # what the reference's own test accepts (run.py:993-1001)
     assert got == want                              # and the bytes
+
+
+def hostsim_print_calls(q, cells):
+    lib = helpers.hostsim_lib()
+    fn = lib.hostsim_print_calls
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p, ctypes.c_uint64]
+    out, n = ctypes.c_void_p(), ctypes.c_uint64()
+    err = ctypes.create_string_buffer(4096)
+    rc = fn(json.dumps(q).encode(), cells, len(cells), ctypes.byref(out), ctypes.byref(n), err, 4096)
+    assert rc == 0, err.value.decode()
+    text = ctypes.string_at(out.value, n.value)
+    lib.hostsim_free(out)
+    return text
+
+
+@pytest.mark.parametrize("case", CALLS_CASES, ids=[c[0] for c in CALLS_CASES])
+def test_kernel_bodies_print_the_reference_calls_goldens(case):
+    """core/gdb_calls.hpp (the functions the device kernel k_calls runs per cell) compiled by g++ (tests/hostsim)"""
+    name, callsets, vid, ranges, attributes = case
+    cells = helpers.cells_for(callsets, vid)
+    assert hostsim_print_calls(calls_query(callsets, vid, ranges, attributes), cells) == helpers.golden_text(name)
+
+
+def _synth_calls_query(tmp_path, N, ranges):
+    q = dict(helpers.synth_query(tmp_path, N, 10_000_000, 10_000_000))
+    q["query_column_ranges"] = ranges
+    return q
+
+
+def test_oracle_and_kernel_bodies_agree_on_synthetic_cells(tmp_path):
+    """200 synthetic samples, intervals that begin inside reference blocks (every row has an interval intersecting the begin), a single
+    position, an interval without cells"""
+    from genomicsdb_amd import synth
+    N, B, L = 200, 10_000_000, 3000
+    cells, _ = synth.Generator(N, B, L).chunk_bytes(B + L)
+    q = _synth_calls_query(tmp_path, N, [{"range_list": [{"low": B + 700, "high": B + 900}, {"low": B + 1500, "high": B + 1500}, {"low": B + 2000, "high": B + 2600},
+                                                           {"low": B + 50_000, "high": B + 50_010}]}])
+    a = oracle_print_calls(q, cells)
+    b = hostsim_print_calls(q, cells)
+    assert a == b and a.count(b'"row"') > 3 * N
+    doc = json.loads(a)
+    assert [iv["query_interval"] for iv in doc["variant_calls"]] == [[B + 700, B + 900], [B + 1500, B + 1500], [B + 2000, B + 2600]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CALLS_CASES, ids=[c[0] for c in CALLS_CASES])
+def test_device_prints_the_reference_calls_goldens(gdb, case):
+    name, callsets, vid, ranges, attributes = case
+    cells = helpers.cells_for(callsets, vid)
+    eng = gdb.CombineEngine(calls_query(callsets, vid, ranges, attributes))
+    eng.stage_cells(cells)
+    got = eng.print_calls()
+    eng.close()
+    assert got == helpers.golden_text(name)
+
+
+@pytest.mark.gpu
+def test_device_print_calls_at_1000_samples_and_through_column_windows(gdb, tmp_path, monkeypatch):
+    """1 000 samples x 20 kb (190 000 cells, ~100 MB of JSON) against the oracle; the same array streamed through HBM in column windows
+    (intervals cut into pieces: a piece behind the first prints only the cells that begin in it)"""
+    from genomicsdb_amd import synth
+    N, B, L = 1000, 10_000_000, 20_000
+    cells, _ = synth.Generator(N, B, L).chunk_bytes(B + L)
+    q = _synth_calls_query(tmp_path, N, [{"range_list": [{"low": B + 5000, "high": B + 15_000}, {"low": B + 17_000, "high": B + 17_000}]}])
+    want = oracle_print_calls(q, cells)
+    eng = gdb.CombineEngine(q)
+    eng.stage_cells(cells)
+    got = eng.print_calls()
+    eng.close()
+    assert got == want
+    monkeypatch.setenv("GDBAMD_STAGE_BUDGET_BYTES", str(len(cells) // 7))
+    eng = gdb.CombineEngine(q)
+    eng.open_memory_cells(cells)
+    got2 = eng.print_calls()
+    eng.close()
+    assert got2 == want
+
+
+@pytest.mark.gpu
+def test_gt_mpi_gather_print_calls(gdb, tmp_path):
+    """the command line: gt_mpi_gather -j query.json --print-calls (tools/src/gt_mpi_gather.cc:369-383, 602-606)"""
+    import subprocess
+    name, callsets, vid, ranges, attributes = CALLS_CASES[8]       # t0_1_2_calls_at_12150
+    ws = tmp_path / "ws"
+    (ws / "arr").mkdir(parents=True)
+    (ws / "arr" / "cells.bin").write_bytes(helpers.cells_for(callsets, vid))
+    q = calls_query(callsets, vid, ranges, attributes)
+    q["workspace"], q["array"] = str(ws), "arr"
+    qf = tmp_path / "q.json"
+    qf.write_text(json.dumps(q))
+    exe = os.path.join(helpers.ROOT, "genomicsdb_amd", "gt_mpi_gather")
+    r = subprocess.run([exe, "-j", str(qf), "--print-calls"], capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout == helpers.golden_text(name)
