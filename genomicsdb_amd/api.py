@@ -204,16 +204,23 @@ class CombineEngine:
     def set_reference(self, begin, bases):
         _check(_lib.lib().gdbamd_engine_set_reference(self._e, begin, bases, len(bases)) == 0, "set_reference")
 
-    def print_calls(self):
-        """`gt_mpi_gather --print-calls`: the JSON document of the cells of the query's column intervals (VariantCallPrintOperator), bytes"""
+    def print_calls(self, mode=0):
+        """`gt_mpi_gather --print-calls` (mode 0: the JSON document of the cells of the query's column intervals, VariantCallPrintOperator),
+        `--print-csv` (1) or `--print-AC` (2); bytes"""
         L = _lib.lib()
-        L.gdbamd_engine_print_calls.restype = ctypes.c_int64
-        L.gdbamd_engine_print_calls.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
-        n = L.gdbamd_engine_print_calls(self._e, None, 0)
+        L.gdbamd_engine_print_cells.restype = ctypes.c_int64
+        L.gdbamd_engine_print_cells.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64]
+        n = L.gdbamd_engine_print_cells(self._e, mode, None, 0)
         _check(n >= 0, "print_calls")
         buf = ctypes.create_string_buffer(max(1, n))
-        _check(L.gdbamd_engine_print_calls(self._e, buf, n) == n, "print_calls")
+        _check(L.gdbamd_engine_print_cells(self._e, mode, buf, n) == n, "print_calls")
         return buf.raw[:n]
+
+    def print_csv(self):
+        return self.print_calls(1)
+
+    def print_allele_counts(self):
+        return self.print_calls(2)
 
     def column_histogram(self, hist_begin, hist_end, bin_size, counts=None):
         """ColumnHistogramOperator on the device: numpy uint64 counts[(hist_end - hist_begin) // bin_size + 1] of the staged begin-cells by

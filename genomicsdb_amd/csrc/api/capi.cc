@@ -270,12 +270,15 @@ int gdbamd_engine_column_histogram(void* engine, uint64_t hist_begin, uint64_t h
 }
 // gt_mpi_gather --print-calls: the document is produced by the call with dst == NULL (which returns its length) and kept in the handle
 // for the call that copies it
-int64_t gdbamd_engine_print_calls(void* engine, char* dst, uint64_t cap) {
+int64_t gdbamd_engine_print_calls(void* engine, char* dst, uint64_t cap) { return gdbamd_engine_print_cells(engine, 0, dst, cap); }
+// mode 0: --print-calls, 1: --print-csv, 2: --print-AC
+int64_t gdbamd_engine_print_cells(void* engine, int mode, char* dst, uint64_t cap) {
   try {
     EngineHandle* h = (EngineHandle*)engine;
-    if (!dst) h->calls_text = h->eng->print_calls();
+    auto make = [&]() { return mode == 0 ? h->eng->print_calls() : mode == 1 ? h->eng->print_csv() : h->eng->print_allele_counts(); };
+    if (!dst) h->calls_text = make();
     else {
-      if (h->calls_text.empty()) h->calls_text = h->eng->print_calls();
+      if (h->calls_text.empty()) h->calls_text = make();
       if (cap < h->calls_text.size()) { g_last_error = "print_calls: destination too small"; return -1; }
       memcpy(dst, h->calls_text.data(), h->calls_text.size());
     }

@@ -1,4 +1,6 @@
 #include "genomicsdb_bcf_generator.h"
+#include <functional>
+#include <map>
 #include "../kernels/gdb_bgzf.h"
 
 #include <hip/hip_runtime_api.h>
@@ -358,35 +360,65 @@ void CombineEngine::column_histogram(uint64_t hist_begin, uint64_t hist_end, uin
   }
 }
 
-std::string CombineEngine::print_calls() {
-  const std::string ip = "    ";
-  std::string o = "{\n" + ip + "\"variant_calls\": [\n";
-  const std::string p0 = ip + ip, p1 = p0 + ip;
-  unsigned printed = 0;
+// the cells of every query interval through DevicePipeline::cells_text, piece by piece when the array passes through HBM in column windows
+// (a piece behind the first prints only the cells that begin in it)
+void CombineEngine::for_each_interval_text(int mode, int arg, const std::function<void(int64_t, int64_t, const std::string&)>& fn) {
   std::vector<std::pair<int64_t, int64_t>> ivs;
   for (unsigned i = 0; i < m_qc.get_num_column_intervals(); ++i) ivs.emplace_back(m_qc.get_column_begin(i), m_qc.get_column_end(i));
   const bool whole_array = ivs.empty();       // a scan of the whole array has no interval begin to intersect (genomicsdb_iterators.cc:188-190)
   if (whole_array) ivs.emplace_back(0, INT64_MAX - 1);
   for (const auto& iv : ivs) {
-    std::string cells;
+    std::string text;
     bool first_piece = true;
-    for (int64_t pos = iv.first; pos <= iv.second;) {            // piece by piece when the array passes through HBM in column windows
+    for (int64_t pos = iv.first; pos <= iv.second;) {
       const Coverage cov = cover(pos);
       const int64_t hi = std::min(cov.hi, iv.second);
-      std::string part = m_pipe->calls_json(pos, hi, 16, first_piece && !whole_array);
-      if (!part.empty()) { if (!cells.empty()) cells += ",\n"; cells += part; }
+      text += m_pipe->cells_text(pos, hi, mode, arg, first_piece && !whole_array);
       first_piece = false;
-      if (hi >= iv.second || m_src.kind == SRC_NONE || m_window_eof) break;
+      if (hi >= iv.second || m_src.kind == SRC_NONE || m_window_eof || cov.hi >= INT64_MAX - 1) break;
       pos = hi + 1;
     }
-    if (cells.empty()) continue;                                  // (an interval without a cell prints nothing: the header is printed WITH its first cell)
-    if (printed) o += "\n" + p1 + "]\n" + p0 + "},\n";
-    o += p0 + "{\n" + p1 + "\"query_interval\": [ " + std::to_string(iv.first) + ", " + std::to_string(iv.second) + " ],\n" + p1 + "\"variant_calls\": [\n";
-    o += cells;
-    ++printed;
+    fn(iv.first, iv.second, text);
   }
+}
+
+std::string CombineEngine::print_calls() {
+  const std::string ip = "    ";
+  std::string o = "{\n" + ip + "\"variant_calls\": [\n";
+  const std::string p0 = ip + ip, p1 = p0 + ip;
+  unsigned printed = 0;
+  for_each_interval_text(0, 16, [&](int64_t lo, int64_t hi, const std::string& cells) {
+    if (cells.empty()) return;                                    // (an interval without a cell prints nothing: the header is printed WITH its first cell)
+    if (printed) o += "\n" + p1 + "]\n" + p0 + "},\n";
+    o += p0 + "{\n" + p1 + "\"query_interval\": [ " + std::to_string(lo) + ", " + std::to_string(hi) + " ],\n" + p1 + "\"variant_calls\": [\n";
+    o.append(cells, 2, std::string::npos);                        // (every cell comes with ",\n" in front of it)
+    ++printed;
+  });
   if (printed) o += "\n" + p1 + "]\n" + p0 + "}";
   o += "\n" + ip + "]\n}\n";
+  return o;
+}
+
+std::string CombineEngine::print_csv() {
+  std::string o;
+  for_each_interval_text(1, 0, [&](int64_t, int64_t, const std::string& t) { o += t; });
+  return o;
+}
+
+std::string CombineEngine::print_allele_counts() {
+  if (m_hp.plan.f_GT < 0) throw GenomicsDBConfigException("GT field must be queried for AlleleCountOperator");   // (variant_operations.cc:909-911)
+  const int gt_step = m_hp.plan.field[m_hp.plan.f_GT].length == GDB_VL_PP ? 2 : 1;
+  std::string o;
+  for_each_interval_text(2, gt_step, [&](int64_t, int64_t, const std::string& t) {
+    std::map<int64_t, std::map<std::pair<std::string, std::string>, uint64_t>> counts;      // (m_column_to_REF_ALT_to_count_vec's element of this interval)
+    for (size_t b = 0; b < t.size();) {
+      const size_t e = t.find('\n', b), t1 = t.find('\t', b), t2 = t.find('\t', t1 + 1);
+      ++counts[strtoll(t.c_str() + b, nullptr, 10)][std::make_pair(t.substr(t1 + 1, t2 - t1 - 1), t.substr(t2 + 1, e - t2 - 1))];
+      b = e + 1;
+    }
+    for (const auto& col : counts)
+      for (const auto& ra : col.second) o += std::to_string(col.first) + " " + ra.first.first + " " + ra.first.second + " " + std::to_string(ra.second) + "\n";
+  });
   return o;
 }
 

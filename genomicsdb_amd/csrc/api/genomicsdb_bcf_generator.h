@@ -2,6 +2,7 @@
 // GenomicsDBBCFGenerator (reference src/main/cpp/include/vcf/genomicsdb_bcf_generator.h:33-93): header first, then the
 // combined-gVCF body of every query column interval, produced in batches of at most buffer_capacity bytes.
 #pragma once
+#include <functional>
 #include <memory>
 #include <exception>
 #include <string>
@@ -57,6 +58,10 @@ class CombineEngine {
   // gt_mpi_gather --print-calls (tools/src/gt_mpi_gather.cc:369-383): the JSON document of the query's cells, interval by interval
   // (VariantCallPrintOperator, variant_operations.cc:803-843); the cells are selected and formatted on the device (DevicePipeline::calls_json)
   std::string print_calls();
+  // --print-csv (VariantCallPrintCSVOperator, variant_operations.cc:845-903): one line per cell; --print-AC (AlleleCountOperator, :905-1089): per query
+  // interval "column REF ALT count" of the normalised ALT alleles the cells' genotypes name, ordered by column, REF, ALT
+  std::string print_csv();
+  std::string print_allele_counts();
   uint64_t staging_budget_bytes() const;
   int64_t windows_staged = 0;
   uint64_t pipeline_generation = 0;   // counts the swaps of the two pipelines (overlapped staging): pipeline() is another object afterwards
@@ -70,6 +75,7 @@ class CombineEngine {
   bool has_cells = false;
   ~CombineEngine();
  private:
+  void for_each_interval_text(int mode, int arg, const std::function<void(int64_t, int64_t, const std::string&)>& fn);
   VariantQueryConfig m_qc;
   HostPlan m_hp;
   std::unique_ptr<DevicePipeline> m_pipe;       // the pipeline whose fragment is in use

@@ -118,4 +118,72 @@ template <class Sink> GDB_HD void calls_emit_cell(Sink& s, const FragmentView& f
   s.put('\n'); put_spaces(s, indent + 4); put_lit(s, "}\n"); put_spaces(s, indent); s.put('}');
 }
 
+
+// VariantCallPrintCSVOperator::operate_on_columnar_cell -> GenomicsDBColumnarCell::print_csv (variant_cell.cc:167-184): row, begin, end, then every
+// queried attribute behind END through the print_csv of its type (genomicsdb_columnar_field.cc:116-199, 419-424): a list type of variable length
+// starts with its element count (0 and nothing else when the field is not valid), a fixed-length list that is not valid leaves its commas, a single
+// value or a string that is not valid leaves nothing.  (ALT has no special treatment here: the stored string, "|" and "&" included.)
+template <class Sink> GDB_HD void calls_emit_csv(Sink& s, const FragmentView& fr, const CombinePlan& pl, int64_t c, int64_t end) {
+  put_i64(s, (int64_t)fr.row[c]); s.put(','); put_i64(s, fr.begin[c]); s.put(','); put_i64(s, end);
+  for (int f = 0; f < pl.nfields; ++f) {
+    s.put(',');
+    const GdbFieldDesc& fd = pl.field[f];
+    const bool singleton = fd.length == GDB_VL_FIXED && fd.fixed_num == 1;
+    const bool is_var = fd.length != GDB_VL_FIXED;
+    const bool valid = calls_field_valid(fr, pl, f, c);
+    int n;
+    if (fd.elem == GDB_ET_CHAR && !singleton) { const char* p = cell_field<char>(fr, pl, f, c, n); if (valid) s.write(p, n); continue; }
+    if (singleton) {
+      if (!valid) continue;
+      if (fd.elem == GDB_ET_INT) put_i32(s, *cell_field<int32_t>(fr, pl, f, c, n));
+      else if (fd.elem == GDB_ET_FLOAT) put_float_ostream(s, *cell_field<float>(fr, pl, f, c, n));
+      else { const char ch = *cell_field<char>(fr, pl, f, c, n); if (fd.elem == GDB_ET_FLAG) s.put(ch ? '1' : '0'); else s.put(ch); }
+      continue;
+    }
+    const void* p = fd.elem == GDB_ET_INT ? (const void*)cell_field<int32_t>(fr, pl, f, c, n) : fd.elem == GDB_ET_FLOAT ? (const void*)cell_field<float>(fr, pl, f, c, n)
+                                                                                                                          : (const void*)cell_field<char>(fr, pl, f, c, n);
+    if (is_var) put_i64(s, (int64_t)n);
+    if (valid) {
+      if (is_var) s.put(',');
+      for (int i = 0; i < n; ++i) {
+        if (i) s.put(',');
+        if (fd.elem == GDB_ET_INT) put_i32(s, ((const int32_t*)p)[i]);
+        else if (fd.elem == GDB_ET_FLOAT) put_float_ostream(s, ((const float*)p)[i]);
+        else s.put(fd.elem == GDB_ET_FLAG ? (((const char*)p)[i] ? '1' : '0') : ((const char*)p)[i]);
+      }
+    } else if (!is_var) for (int i = 1; i < n; ++i) s.put(',');
+  }
+  s.put('\n');
+}
+
+// AlleleCountOperator::operate_on_columnar_cell (variant_operations.cc:951-1008) + normalize_REF_ALT_pair (:1012-1056): one line
+// "column<TAB>REF<TAB>ALT" per GT element that names an ALT allele; counting equal lines (per query interval, ordered by column, REF, ALT) is
+// print_allele_counts (:1069-1089).  gt_step: 2 when GT carries phase elements (BCF_VL_Phased_Ploidy), else 1.
+template <class Sink> GDB_HD void calls_emit_allele_lines(Sink& s, const FragmentView& fr, const CombinePlan& pl, int64_t c, int gt_step, uint32_t* err) {
+  if (pl.f_GT < 0 || !calls_field_valid(fr, pl, pl.f_REF, c) || !calls_field_valid(fr, pl, pl.f_ALT, c) || !calls_field_valid(fr, pl, pl.f_GT, c)) return;
+  int nref, nalt, ngt;
+  const char* ref = cell_field<char>(fr, pl, pl.f_REF, c, nref);
+  const char* alt = cell_field<char>(fr, pl, pl.f_ALT, c, nalt);
+  const int32_t* gt = cell_field<int32_t>(fr, pl, pl.f_GT, c, ngt);
+  for (int i = 0; i < ngt; i += gt_step) {
+    const int32_t g = gt[i];
+    if (!gdb_int_valid(g) || g <= 0) continue;
+    int b = 0, e = 0, idx = 0;                       // the (g - 1)-th '|' separated piece of ALT (empty pieces count: memchr)
+    for (;;) { e = b; while (e < nalt && alt[e] != '|') ++e; if (idx == g - 1 || e >= nalt) break; b = e + 1; ++idx; }
+    if (idx != g - 1) { *err |= GDB_ERR_INTERNAL; continue; }
+    const char* a = alt + b;
+    int alen = e - b, rlen = nref;
+    if (rlen > 1 && alen > 0) {                      // the cell contains a deletion: bring this allele's pair to its own normal form
+      if (allele_is_symbolic(a, alen)) rlen = 1;
+      else {
+        int suffix = 0;
+        if (alen >= rlen) suffix = rlen - 1;         // SNV / insertion next to a deletion: the last REF length - 1 bases are shared
+        else if (alen > 1) suffix = alen - 1;        // a shorter deletion next to a longer one
+        rlen -= suffix; alen -= suffix;
+      }
+    }
+    put_i64(s, fr.begin[c]); s.put('\t'); s.write(ref, rlen); s.put('\t'); s.write(a, alen); s.put('\n');
+  }
+}
+
 }  // namespace genomicsdb_amd

@@ -125,6 +125,10 @@ class DevicePipeline {
   // ",\n", every line indented by `indent` spaces; ncells: how many.  with_intersecting = false: only the cells that begin inside (the
   // continuation of an interval whose first piece has been printed from an earlier column window)
   std::string calls_json(int64_t qb, int64_t qe, int indent, bool with_intersecting = true, int64_t* ncells = nullptr);
+  // the same selection printed otherwise: mode 1 = the lines of --print-csv (VariantCallPrintCSVOperator, variant_operations.cc:845-903), mode 2 = one line
+  // "column<TAB>REF<TAB>ALT" per GT element naming an ALT allele, REF / ALT normalised (AlleleCountOperator, :951-1056; indent = the GT step);
+  // mode 0 = the JSON objects with ",\n" in front of each
+  std::string cells_text(int64_t qb, int64_t qe, int mode, int indent, bool with_intersecting);
   bool next_page(uint64_t arena_bytes, const char** dev_ptr, uint64_t* nbytes);
   // the same in two steps (asynchronous page production, two arenas): see gdb_pipeline.hip
   struct PageTicket { int arena = 0; const char* dev = nullptr; uint64_t nbytes = 0; void* done_event = nullptr; };   // done_event: hipEvent_t recorded behind the page's kernels

@@ -4863,30 +4863,40 @@ void DevicePipeline::classify_fragment() {
 // begin < qb <= eff_end, printed with eff_end as their END, followed by those with qb <= begin <= qe - already in the right order.
 // One thread per cell; the emitter runs twice (length, text) around a scan, like the other emitters of this file.
 template <bool WRITE> __global__ void k_calls(FragmentView fr, CombinePlan pl, QueryWindow qw, CallsNames names, const int64_t* __restrict__ eff_end, int64_t c_base, int64_t n,
-                                              int64_t qb, int64_t qe, int indent, int with_intersecting, uint64_t* __restrict__ len_or_off, char* __restrict__ out) {
+                                              int64_t qb, int64_t qe, int mode, int indent, int with_intersecting, uint64_t* __restrict__ len_or_off, char* __restrict__ out, uint32_t* err) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int64_t c = c_base + i;
   int64_t end = 0;
   const bool take = calls_select(fr, eff_end, c, qb, qe, with_intersecting != 0, end);
+  uint32_t e = 0;
+  auto emit = [&](auto& s) {
+    if (mode == 0) { s.put(','); s.put('\n'); calls_emit_cell(s, fr, pl, qw, names, c, end, indent); }   // ",\n" in front of every cell (the caller drops the first)
+    else if (mode == 1) calls_emit_csv(s, fr, pl, c, end);
+    else calls_emit_allele_lines(s, fr, pl, c, indent, &e);                                             // (indent: the GT step)
+  };
   if (!WRITE) {
     uint64_t l = 0;
-    if (take) { CountSink s; calls_emit_cell(s, fr, pl, qw, names, c, end, indent); l = s.n + 2u; }   // ",\n" in front of every cell (the caller drops the first)
+    if (take) { CountSink s; emit(s); l = s.n; }
     len_or_off[i] = l;
   } else if (take) {
     ByteSink s(out + len_or_off[i]);
-    s.put(','); s.put('\n');
-    calls_emit_cell(s, fr, pl, qw, names, c, end, indent);
+    emit(s);
   }
+  if (e) atomicOr(err, e);
 }
 
 std::string DevicePipeline::calls_json(int64_t qb, int64_t qe, int indent, bool with_intersecting, int64_t* ncells) {
+  std::string out = cells_text(qb, qe, 0, indent, with_intersecting);
+  if (ncells) { int64_t k = 0; const std::string head = ",\n" + std::string((size_t)indent, ' ') + "{\n"; for (size_t q = out.find(head); q != std::string::npos; q = out.find(head, q + 1)) ++k; *ncells = k; }
+  return out.empty() ? out : out.substr(2);   // (without the first separator)
+}
+std::string DevicePipeline::cells_text(int64_t qb, int64_t qe, int mode, int indent, bool with_intersecting) {
   Impl& S = *m_;
   HIP_CHECK(hipSetDevice(S.device));
   hipStream_t st = S.stream;
   const FragmentView& fr = S.fr;
   const int64_t C = fr.ncells;
-  if (ncells) *ncells = 0;
   if (C == 0 || S.hp.plan.num_query_rows == 0) return std::string();
   for (int f = 0; f < S.hp.plan.nfields; ++f)
     if (S.hp.plan.field[f].ndim == 2) throw GenomicsDBDeviceException("print-calls: 2-dimensional field " + S.hp.field_names[(size_t)f] + " is not printed on the device");
@@ -4913,20 +4923,19 @@ std::string DevicePipeline::calls_json(int64_t qb, int64_t qe, int indent, bool 
   qw.contigs = S.contigs.p; qw.ncontigs = (int32_t)S.hp.contigs.size(); qw.contig_names = S.contig_names.p;
   CallsNames names{S.calls_names.p, S.calls_name_off.p};
   S.calls_len.ensure((size_t)CW + 1); S.calls_off.ensure((size_t)CW + 1);
-  hipLaunchKernelGGL(k_calls<false>, dim3(blocks_for(CW)), dim3(kBlock), 0, st, fr, S.hp.plan, qw, names, (const int64_t*)S.eff_end.p, c_base, CW, qb, qe, indent, with_intersecting ? 1 : 0, S.calls_len.p, (char*)nullptr);
+  hipLaunchKernelGGL(k_calls<false>, dim3(blocks_for(CW)), dim3(kBlock), 0, st, fr, S.hp.plan, qw, names, (const int64_t*)S.eff_end.p, c_base, CW, qb, qe, mode, indent, with_intersecting ? 1 : 0, S.calls_len.p, (char*)nullptr, S.err.p);
   HIP_CHECK(hipMemsetAsync(S.calls_len.p + CW, 0, sizeof(uint64_t), st));
   S.excl_scan(S.calls_len.p, S.calls_off.p, (size_t)CW + 1);
   const uint64_t total = S.read_back(S.calls_off.p + CW);
   if (total == 0) return std::string();
   S.calls_text.ensure((size_t)total + 16);
-  hipLaunchKernelGGL(k_calls<true>, dim3(blocks_for(CW)), dim3(kBlock), 0, st, fr, S.hp.plan, qw, names, (const int64_t*)S.eff_end.p, c_base, CW, qb, qe, indent, with_intersecting ? 1 : 0, S.calls_off.p, S.calls_text.p);
+  hipLaunchKernelGGL(k_calls<true>, dim3(blocks_for(CW)), dim3(kBlock), 0, st, fr, S.hp.plan, qw, names, (const int64_t*)S.eff_end.p, c_base, CW, qb, qe, mode, indent, with_intersecting ? 1 : 0, S.calls_off.p, S.calls_text.p, S.err.p);
   std::string out((size_t)total, '\0');
   HIP_CHECK(hipMemcpyAsync(&out[0], S.calls_text.p, (size_t)total, hipMemcpyDeviceToHost, st));
   uint32_t eb = 0;
   S.read_back_many({{&eb, S.err.p, sizeof(uint32_t)}});
   if (eb) throw GenomicsDBDeviceException(err_bits_text(eb));
-  if (ncells) { int64_t k = 0; for (size_t q = 0; q + 1 < out.size(); ++q) if (out[q] == ',' && out[q + 1] == '\n' && out.compare(q + 2, (size_t)indent + 2, std::string((size_t)indent, ' ') + "{\n") == 0) ++k; *ncells = k; }
-  return out.substr(2);   // (without the first separator)
+  return out;
 }
 
 void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {

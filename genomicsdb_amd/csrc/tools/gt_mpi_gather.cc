@@ -20,7 +20,7 @@
 
 using namespace genomicsdb_amd;
 
-enum { ARGS_IDX_PRODUCE_BROAD_GVCF = 1000, ARGS_IDX_PRODUCE_HISTOGRAM, ARGS_IDX_PRINT_CALLS, ARGS_IDX_VERSION, ARGS_IDX_UNSUPPORTED };
+enum { ARGS_IDX_PRODUCE_BROAD_GVCF = 1000, ARGS_IDX_PRODUCE_HISTOGRAM, ARGS_IDX_PRINT_CALLS, ARGS_IDX_PRINT_CSV, ARGS_IDX_PRINT_AC, ARGS_IDX_VERSION, ARGS_IDX_UNSUPPORTED };
 extern "C" int64_t gdbamd_equi_partition_text(const uint64_t* counts, uint64_t nbins, uint64_t hist_begin, uint64_t bin_size, uint64_t num_parts, char* dst, uint64_t cap);
 
 static int launcher_rank() {
@@ -35,12 +35,13 @@ int main(int argc, char** argv) {
       {"loader-json-config", 1, 0, 'l'}, {"segment-size", 1, 0, 's'}, {"array", 1, 0, 'A'},
       {"produce-Broad-GVCF", 0, 0, ARGS_IDX_PRODUCE_BROAD_GVCF}, {"version", 0, 0, ARGS_IDX_VERSION},
       {"skip-query-on-root", 0, 0, ARGS_IDX_UNSUPPORTED}, {"produce-interesting-positions", 0, 0, ARGS_IDX_UNSUPPORTED},
-      {"produce-histogram", 0, 0, ARGS_IDX_PRODUCE_HISTOGRAM}, {"print-calls", 0, 0, ARGS_IDX_PRINT_CALLS}, {"print-csv", 0, 0, ARGS_IDX_UNSUPPORTED},
-      {"print-AC", 0, 0, ARGS_IDX_UNSUPPORTED}, {0, 0, 0, 0}};
+      {"produce-histogram", 0, 0, ARGS_IDX_PRODUCE_HISTOGRAM}, {"print-calls", 0, 0, ARGS_IDX_PRINT_CALLS}, {"print-csv", 0, 0, ARGS_IDX_PRINT_CSV},
+      {"print-AC", 0, 0, ARGS_IDX_PRINT_AC}, {0, 0, 0, 0}};
   std::string json_config, loader_json, output_format;
   size_t page_size = 0, segment_size = 10u * 1024u * 1024u;
   int rank = launcher_rank();
   bool produce_gvcf = false, produce_histogram = false, print_calls = false;
+  int print_mode = 0;
   int c;
   while ((c = getopt_long(argc, argv, "j:l:w:A:p:O:s:r:", long_options, NULL)) >= 0) {
     switch (c) {
@@ -53,21 +54,23 @@ int main(int argc, char** argv) {
       case 'w': case 'A': std::cerr << "-w / -A: give workspace and array in the JSON files\n"; return -1;
       case ARGS_IDX_PRODUCE_BROAD_GVCF: produce_gvcf = true; break;
       case ARGS_IDX_PRODUCE_HISTOGRAM: produce_histogram = true; break;
-      case ARGS_IDX_PRINT_CALLS: print_calls = true; break;
+      case ARGS_IDX_PRINT_CALLS: print_calls = true; print_mode = 0; break;
+      case ARGS_IDX_PRINT_CSV: print_calls = true; print_mode = 1; break;
+      case ARGS_IDX_PRINT_AC: print_calls = true; print_mode = 2; break;
       case ARGS_IDX_VERSION: std::cout << "genomicsdb_amd (MI355X variant-combine path) for GenomicsDB 0.10.2 query JSON\n"; return 0;
-      case ARGS_IDX_UNSUPPORTED: std::cerr << "this build implements --produce-Broad-GVCF, --produce-histogram and --print-calls only\n"; return -1;
+      case ARGS_IDX_UNSUPPORTED: std::cerr << "this build implements --produce-Broad-GVCF, --produce-histogram, --print-calls, --print-csv and --print-AC only\n"; return -1;
       default: std::cerr << "Unknown command line argument\n"; return -1;
     }
   }
   if (json_config.empty() || !(produce_gvcf || produce_histogram || print_calls)) {
-    std::cerr << "Usage: gt_mpi_gather -j <query.json> [-l <loader.json>] [-r rank] [-p page_size] [-O output_format] --produce-Broad-GVCF | --produce-histogram | --print-calls\n";
+    std::cerr << "Usage: gt_mpi_gather -j <query.json> [-l <loader.json>] [-r rank] [-p page_size] [-O output_format] --produce-Broad-GVCF | --produce-histogram | --print-calls | --print-csv | --print-AC\n";
     return -1;
   }
   if (print_calls) {
     // print_calls, COMMAND_PRINT_CALLS (tools/src/gt_mpi_gather.cc:369-383): the cells of the query intervals as JSON; selected and formatted on the GPU
     try {
       GenomicsDBBCFGenerator gen(loader_json, json_config, "", 0, 0, rank, (size_t)1u << 20, segment_size, "", true, false, true);
-      const std::string doc = gen.engine().print_calls();
+      const std::string doc = print_mode == 0 ? gen.engine().print_calls() : print_mode == 1 ? gen.engine().print_csv() : gen.engine().print_allele_counts();
       fwrite(doc.data(), 1, doc.size(), stdout);
     } catch (const std::exception& e) {
       std::cerr << "gt_mpi_gather: " << e.what() << "\n";

@@ -148,6 +148,11 @@ int gdbamd_engine_column_histogram(void* engine, uint64_t hist_begin, uint64_t h
  * intersect its begin, then the cells that begin inside (SingleCellTileDBIterator, src/main/cpp/src/genomicsdb/genomicsdb_iterators.cc:181-510); selected and
  * formatted on the device, one thread per cell.  Call with dst == NULL for the length, then with a buffer of at least that size.  -1: error. */
 int64_t gdbamd_engine_print_calls(void* engine, char* dst, uint64_t cap);
+/* The other two SingleCellOperatorBase printers over the same cells, same calling convention.  mode 0: --print-calls; 1: --print-csv
+ * (VariantCallPrintCSVOperator, variant_operations.cc:845-903: "row,begin,end,<fields>" per cell); 2: --print-AC (AlleleCountOperator, :905-1089:
+ * "column REF ALT count" per normalised ALT allele named by a genotype, per query interval in the order of column, REF, ALT).  The reference's tests
+ * hold no golden for modes 1 and 2: parity is against the oracle's restatement only. */
+int64_t gdbamd_engine_print_cells(void* engine, int mode, char* dst, uint64_t cap);
 /* "index_output_VCF" (src/main/cpp/src/config/json_config.cc:648, src/main/cpp/src/vcf/vcf_adapter.cc:275-295): the index htslib builds from a finished BGZF
  * file - <path>.tbi for a bgzip'ed VCF (tbx_index_build with the VCF preset), <path>.csi with min_shift 14 for a BGZF BCF2 file (bcf_index_build(.., 14)).
  * The file-writing VCFAdapter and gt_mpi_gather call it when the query JSON says "index_output_VCF": true and the format is "z" / "b". */

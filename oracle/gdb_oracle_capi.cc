@@ -126,7 +126,12 @@ int oracle_run_query_synthetic_reference(const char* query_json_text, const uint
 }
 
 // gt_mpi_gather --print-calls (gdb_oracle_print.hpp): the JSON document of the query's cells; *out malloc'ed
+int oracle_print_cells(const char* query_json_text, const uint8_t* cells, uint64_t nbytes, int mode, char** out, uint64_t* out_len, char* err, uint64_t errlen);
 int oracle_print_calls(const char* query_json_text, const uint8_t* cells, uint64_t nbytes, char** out, uint64_t* out_len, char* err, uint64_t errlen) {
+  return oracle_print_cells(query_json_text, cells, nbytes, 0, out, out_len, err, errlen);
+}
+// mode 0: --print-calls, 1: --print-csv, 2: --print-AC
+int oracle_print_cells(const char* query_json_text, const uint8_t* cells, uint64_t nbytes, int mode, char** out, uint64_t* out_len, char* err, uint64_t errlen) {
   try {
     oracle_json::Value q = oracle_json::parse(query_json_text);
     VidMapper vid;
@@ -143,7 +148,7 @@ int oracle_print_calls(const char* query_json_text, const uint8_t* cells, uint64
     QueryConfig qc;
     qc.read_query_json(q, vid, 0);
     qc.do_query_bookkeeping(array.schema, vid, array.num_rows, 0);
-    std::string o = print_calls(array, qc, vid);
+    std::string o = mode == 0 ? print_calls(array, qc, vid) : mode == 1 ? print_csv(array, qc) : print_allele_counts(array, qc);
     *out = (char*)malloc(o.size() + 1); memcpy(*out, o.data(), o.size()); (*out)[o.size()] = 0; *out_len = o.size();
     return 0;
   } catch (const std::exception& e) { if (err && errlen) snprintf(err, errlen, "%s", e.what()); return 1; }

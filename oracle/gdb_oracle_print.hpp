@@ -111,38 +111,47 @@ inline void print_columnar_cell(std::string& o, const VariantArray& array, const
   o += "\n" + in1 + "}\n" + indent + "}";
 }
 
-// print_calls + VariantCallPrintOperator + the iterator
+// the iterator: the cells of one query interval in the order operator++ hands them out (begin / end after the swap of an END copy)
+struct CellHit { int64_t begin, end; const DiskCell* d; };
+inline std::vector<CellHit> cells_of_interval(const VariantArray& array, const QueryConfig& qc, int64_t b, int64_t e, bool whole_array) {
+  std::vector<CellHit> hits;
+  const size_t from = std::lower_bound(array.cells.begin(), array.cells.end(), b, [](const DiskCell& c, int64_t v) { return c.col < v; }) - array.cells.begin();
+  if (!whole_array) {      // find intersecting intervals: the first cell of every queried row at or behind column b
+    std::set<int64_t> seen;
+    for (size_t i = from; i < array.cells.size() && seen.size() < qc.get_num_rows_to_query(); ++i) {
+      const DiskCell& d = array.cells[i];
+      if (!qc.is_queried_array_row_idx(d.row) || !seen.insert(d.row).second) continue;
+      if (d.END < d.col && d.END < b) hits.push_back({d.END, d.col, &d});      // an END copy of an interval that began before b: swapped
+    }
+    std::sort(hits.begin(), hits.end(), [](const CellHit& x, const CellHit& y) { return x.begin < y.begin || (x.begin == y.begin && x.d->row < y.d->row); });
+  }
+  for (size_t i = from; i < array.cells.size() && array.cells[i].col <= e; ++i) {   // simple traversal
+    const DiskCell& d = array.cells[i];
+    if (d.END < d.col || !qc.is_queried_array_row_idx(d.row)) continue;
+    hits.push_back({d.col, d.END, &d});
+  }
+  return hits;
+}
+inline std::vector<std::pair<int64_t, int64_t>> intervals_of(const QueryConfig& qc, bool& whole_array) {
+  std::vector<std::pair<int64_t, int64_t>> ivs = qc.column_intervals;
+  whole_array = ivs.empty();
+  if (whole_array) ivs.emplace_back(0, INT64_MAX - 1);
+  return ivs;
+}
+
+// print_calls + VariantCallPrintOperator
 inline std::string print_calls(const VariantArray& array, const QueryConfig& qc, const VidMapper& vid) {
   const std::string ip = "    ";
   std::string o = "{\n" + ip + "\"variant_calls\": [\n";
   const std::string p0 = ip + ip, p1 = p0 + ip, p2 = p1 + ip;
   unsigned intervals_printed = 0;
-  std::vector<std::pair<int64_t, int64_t>> ivs = qc.column_intervals;
-  const bool whole_array = ivs.empty();
-  if (whole_array) ivs.emplace_back(0, INT64_MAX - 1);
-  for (const auto& iv : ivs) {
-    const int64_t b = iv.first, e = iv.second;
-    struct Hit { int64_t begin, end; const DiskCell* d; };
-    std::vector<Hit> hits;
-    const size_t from = std::lower_bound(array.cells.begin(), array.cells.end(), b, [](const DiskCell& c, int64_t v) { return c.col < v; }) - array.cells.begin();
-    if (!whole_array) {      // find intersecting intervals: the first cell of every queried row at or behind column b
-      std::set<int64_t> seen;
-      for (size_t i = from; i < array.cells.size() && seen.size() < qc.get_num_rows_to_query(); ++i) {
-        const DiskCell& d = array.cells[i];
-        if (!qc.is_queried_array_row_idx(d.row) || !seen.insert(d.row).second) continue;
-        if (d.END < d.col && d.END < b) hits.push_back({d.END, d.col, &d});      // an END copy of an interval that began before b: swapped
-      }
-      std::sort(hits.begin(), hits.end(), [](const Hit& x, const Hit& y) { return x.begin < y.begin || (x.begin == y.begin && x.d->row < y.d->row); });
-    }
-    for (size_t i = from; i < array.cells.size() && array.cells[i].col <= e; ++i) {   // simple traversal
-      const DiskCell& d = array.cells[i];
-      if (d.END < d.col || !qc.is_queried_array_row_idx(d.row)) continue;
-      hits.push_back({d.col, d.END, &d});
-    }
+  bool whole_array;
+  for (const auto& iv : intervals_of(qc, whole_array)) {
+    const std::vector<CellHit> hits = cells_of_interval(array, qc, iv.first, iv.second, whole_array);
     if (hits.empty()) continue;
     if (intervals_printed) o += "\n" + p1 + "]\n" + p0 + "},\n";
     char bb[96];
-    snprintf(bb, sizeof bb, "\"query_interval\": [ %lld, %lld ],\n", (long long)b, (long long)e);
+    snprintf(bb, sizeof bb, "\"query_interval\": [ %lld, %lld ],\n", (long long)iv.first, (long long)iv.second);
     o += p0 + "{\n" + p1 + bb + p1 + "\"variant_calls\": [\n";
     for (size_t h = 0; h < hits.size(); ++h) {
       if (h) o += ",\n";
@@ -152,6 +161,88 @@ inline std::string print_calls(const VariantArray& array, const QueryConfig& qc,
   }
   if (intervals_printed) o += "\n" + p1 + "]\n" + p0 + "}";
   o += "\n" + ip + "]\n}\n";
+  return o;
+}
+
+// --print-csv: VariantCallPrintCSVOperator::operate_on_columnar_cell (variant_operations.cc:899-903) -> GenomicsDBColumnarCell::print_csv
+// (variant_cell.cc:167-184) -> GenomicsDBColumnarFieldPrintOperator<...>::print_csv (genomicsdb_columnar_field.cc:116-199, 419-424).
+// (No golden in the reference's tests: parity unpinned.)
+inline std::string print_csv(const VariantArray& array, const QueryConfig& qc) {
+  std::string o;
+  bool whole_array;
+  for (const auto& iv : intervals_of(qc, whole_array))
+    for (const CellHit& h : cells_of_interval(array, qc, iv.first, iv.second, whole_array)) {
+      std::vector<CellAttrView> attr;
+      parse_cell_attributes(array.schema, h.d->raw, attr);
+      char b[96];
+      snprintf(b, sizeof b, "%lld,%lld,%lld", (long long)h.d->row, (long long)h.begin, (long long)h.end);
+      o += b;
+      for (unsigned i = 1; i < qc.num_queried_attributes(); ++i) {
+        o += ",";
+        const QueryAttr& qa = qc.attrs[i];
+        const SchemaAttr& sa = array.schema.attrs[qa.schema_idx];
+        const CellAttrView& v = attr[qa.schema_idx];
+        const bool valid = columnar_field_valid(sa, v);
+        ElementType et = sa.et;
+        if (qa.info && qa.info->et == ET_FLAG) et = ET_FLAG;
+        const bool singleton = qa.info ? (qa.info->ld == VL_FIXED && qa.info->num_elements == 1u) : (!sa.var && sa.num == 1u);
+        const bool is_var = qa.info ? qa.info->ld != VL_FIXED : sa.var;
+        auto one = [&](unsigned k) {
+          char t[32];
+          if (et == ET_INT) { int32_t x; memcpy(&x, v.ptr + 4u * k, 4); snprintf(t, sizeof t, "%d", x); o += t; }
+          else if (et == ET_FLOAT) { float x; memcpy(&x, v.ptr + 4u * k, 4); print_float_like_ostream(o, x); }
+          else if (et == ET_FLAG) o += v.ptr[k] ? "1" : "0";
+          else o.push_back((char)v.ptr[k]);
+        };
+        if (et == ET_CHAR && !singleton) { if (valid) o.append((const char*)v.ptr, v.num); continue; }   // string: the bytes
+        if (singleton) { if (valid) one(0); continue; }
+        if (is_var) { snprintf(b, sizeof b, "%u", v.num); o += b; }
+        if (valid) { if (is_var) o += ","; one(0); for (unsigned k = 1; k < v.num; ++k) { o += ","; one(k); } }
+        else if (!is_var) for (unsigned k = 1; k < v.num; ++k) o += ",";
+      }
+      o += "\n";
+    }
+  return o;
+}
+
+// --print-AC: AlleleCountOperator (variant_operations.cc:905-1089) - operate_on_columnar_cell (:951-1008), normalize_REF_ALT_pair (:1012-1056),
+// print_allele_counts (:1069-1089); one map per query interval that has cells.  (No golden in the reference's tests: parity unpinned.)
+inline std::string print_allele_counts(const VariantArray& array, const QueryConfig& qc) {
+  if (!qc.is_defined_query_idx_for_known_field_enum(GVCF_GT_IDX)) throw OracleException("GT field must be queried for AlleleCountOperator");
+  const unsigned gi = qc.get_query_idx_for_known_field_enum(GVCF_GT_IDX), ri = qc.get_query_idx_for_known_field_enum(GVCF_REF_IDX), ai = qc.get_query_idx_for_known_field_enum(GVCF_ALT_IDX);
+  const unsigned step = (qc.attrs[gi].info && qc.attrs[gi].info->ld == VL_PP) ? 2u : 1u;
+  std::string o;
+  bool whole_array;
+  for (const auto& iv : intervals_of(qc, whole_array)) {
+    std::map<int64_t, std::map<std::pair<std::string, std::string>, uint64_t>> counts;
+    for (const CellHit& h : cells_of_interval(array, qc, iv.first, iv.second, whole_array)) {
+      std::vector<CellAttrView> attr;
+      parse_cell_attributes(array.schema, h.d->raw, attr);
+      const CellAttrView& R = attr[qc.attrs[ri].schema_idx]; const CellAttrView& A = attr[qc.attrs[ai].schema_idx]; const CellAttrView& G = attr[qc.attrs[gi].schema_idx];
+      if (!columnar_field_valid(array.schema.attrs[qc.attrs[ri].schema_idx], R) || !columnar_field_valid(array.schema.attrs[qc.attrs[ai].schema_idx], A) ||
+          !columnar_field_valid(array.schema.attrs[qc.attrs[gi].schema_idx], G)) continue;
+      std::vector<std::string> alts;          // memchr on '|': empty pieces count
+      { std::string a((const char*)A.ptr, A.num); size_t s0 = 0; for (;;) { size_t e0 = a.find('|', s0); if (e0 == std::string::npos) { alts.push_back(a.substr(s0)); break; } alts.push_back(a.substr(s0, e0 - s0)); s0 = e0 + 1; } }
+      for (unsigned i = 0; i < G.num; i += step) {
+        int32_t g; memcpy(&g, G.ptr + 4u * i, 4);
+        if (g == bcf_int32_missing || g == bcf_int32_vector_end || g <= 0) continue;
+        ORACLE_VERIFY((size_t)(g - 1) < alts.size());
+        std::pair<std::string, std::string> ra(std::string((const char*)R.ptr, R.num), alts[(size_t)g - 1]);
+        const size_t rl = ra.first.size(), al = ra.second.size();
+        if (rl > 1u && al) {
+          if (VariantUtils::is_symbolic_allele(ra.second)) ra.first.resize(1u);
+          else {
+            size_t suffix = 0;
+            if (al == rl) suffix = rl - 1u; else if (al > rl) suffix = rl - 1u; else if (al > 1u) suffix = al - 1u;
+            ra.first.resize(rl - suffix); ra.second.resize(al - suffix);
+          }
+        }
+        ++counts[h.begin][ra];
+      }
+    }
+    for (const auto& col : counts)
+      for (const auto& e : col.second) o += std::to_string(col.first) + " " + e.first.first + " " + e.first.second + " " + std::to_string(e.second) + "\n";
+  }
   return o;
 }
 

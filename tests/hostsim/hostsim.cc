@@ -17,6 +17,7 @@
 #include "../../genomicsdb_amd/csrc/core/gdb_bcf.hpp"
 #include "../../genomicsdb_amd/csrc/host/combine_plan.h"
 #include "../../genomicsdb_amd/csrc/host/fragment.h"
+#include <map>
 #include "../../genomicsdb_amd/csrc/core/gdb_calls.hpp"
 #include "../../genomicsdb_amd/csrc/host/reference_genome.h"
 #include "../../genomicsdb_amd/csrc/common/gz_text.hpp"
@@ -209,7 +210,12 @@ int hostsim_run_query(const char* query_json_text, const uint8_t* cells, uint64_
 }
 // gt_mpi_gather --print-calls with the kernel bodies on the host (core/gdb_calls.hpp: calls_select + calls_emit_cell; the document frame as
 // CombineEngine::print_calls writes it)
+int hostsim_print_cells(const char* query_json_text, const uint8_t* cells, uint64_t nbytes, int mode, char** out, uint64_t* out_len, char* errmsg, uint64_t errlen);
 int hostsim_print_calls(const char* query_json_text, const uint8_t* cells, uint64_t nbytes, char** out, uint64_t* out_len, char* errmsg, uint64_t errlen) {
+  return hostsim_print_cells(query_json_text, cells, nbytes, 0, out, out_len, errmsg, errlen);
+}
+// mode 1: --print-csv lines, mode 2: --print-AC (the lines of calls_emit_allele_lines counted like CombineEngine::print_allele_counts)
+int hostsim_print_cells(const char* query_json_text, const uint8_t* cells, uint64_t nbytes, int mode, char** out, uint64_t* out_len, char* errmsg, uint64_t errlen) {
   try {
     VariantQueryConfig qc;
     qc.read_from_json(mini_json::parse(query_json_text), 0, "");
@@ -236,7 +242,8 @@ int hostsim_print_calls(const char* query_json_text, const uint8_t* cells, uint6
     memset(&qw, 0, sizeof(qw));
     qw.contigs = hp.contigs.data(); qw.ncontigs = (int32_t)hp.contigs.size(); qw.contig_names = hp.contig_names.data();
     const std::string ip = "    ", p0 = ip + ip, p1 = p0 + ip;
-    std::string o = "{\n" + ip + "\"variant_calls\": [\n";
+    std::string o = mode == 0 ? "{\n" + ip + "\"variant_calls\": [\n" : std::string();
+    const int gt_step = pl.f_GT >= 0 && pl.field[pl.f_GT].length == GDB_VL_PP ? 2 : 1;
     std::vector<std::pair<int64_t, int64_t>> ivs;
     for (unsigned i = 0; i < qc.get_num_column_intervals(); ++i) ivs.emplace_back(qc.get_column_begin(i), qc.get_column_end(i));
     const bool whole = ivs.empty();
@@ -247,19 +254,40 @@ int hostsim_print_calls(const char* query_json_text, const uint8_t* cells, uint6
       for (int64_t c = 0; c < C; ++c) {
         int64_t end;
         if (!calls_select(fr, eff_end.data(), c, iv.first, iv.second, !whole, end)) continue;
+        if (mode != 0) {
+          CountSink cs;
+          if (mode == 1) calls_emit_csv(cs, fr, pl, c, end); else calls_emit_allele_lines(cs, fr, pl, c, gt_step, &err);
+          std::string t((size_t)cs.n, '\0');
+          ByteSink bs(&t[0]);
+          if (mode == 1) calls_emit_csv(bs, fr, pl, c, end); else calls_emit_allele_lines(bs, fr, pl, c, gt_step, &err);
+          body += t;
+          continue;
+        }
         CountSink cs; calls_emit_cell(cs, fr, pl, qw, names, c, end, 16);
         std::string cell((size_t)cs.n, '\0');
         ByteSink bs(&cell[0]); calls_emit_cell(bs, fr, pl, qw, names, c, end, 16);
         if (!body.empty()) body += ",\n";
         body += cell;
       }
+      if (mode == 1) { o += body; continue; }
+      if (mode == 2) {
+        std::map<int64_t, std::map<std::pair<std::string, std::string>, uint64_t>> counts;
+        for (size_t b = 0; b < body.size();) {
+          const size_t e = body.find('\n', b), t1 = body.find('\t', b), t2 = body.find('\t', t1 + 1);
+          ++counts[strtoll(body.c_str() + b, nullptr, 10)][std::make_pair(body.substr(t1 + 1, t2 - t1 - 1), body.substr(t2 + 1, e - t2 - 1))];
+          b = e + 1;
+        }
+        for (const auto& col : counts)
+          for (const auto& ra : col.second) o += std::to_string(col.first) + " " + ra.first.first + " " + ra.first.second + " " + std::to_string(ra.second) + "\n";
+        continue;
+      }
       if (body.empty()) continue;
       if (printed) o += "\n" + p1 + "]\n" + p0 + "},\n";
       o += p0 + "{\n" + p1 + "\"query_interval\": [ " + std::to_string(iv.first) + ", " + std::to_string(iv.second) + " ],\n" + p1 + "\"variant_calls\": [\n" + body;
       ++printed;
     }
-    if (printed) o += "\n" + p1 + "]\n" + p0 + "}";
-    o += "\n" + ip + "]\n}\n";
+    if (mode == 0) { if (printed) o += "\n" + p1 + "]\n" + p0 + "}"; o += "\n" + ip + "]\n}\n"; }
+    if (err) throw std::runtime_error("device error bits " + std::to_string(err));
     *out = (char*)malloc(o.size() + 1); memcpy(*out, o.data(), o.size()); *out_len = o.size();
     return 0;
   } catch (const std::exception& e) { snprintf(errmsg, errlen, "%s", e.what()); return 1; }

@@ -26,14 +26,14 @@ def calls_query(callsets, vid, ranges, attributes):
     }
 
 
-def oracle_print_calls(q, cells):
+def oracle_print_calls(q, cells, mode=0):
     lib = helpers.oracle_lib()
-    fn = lib.oracle_print_calls
+    fn = lib.oracle_print_cells
     fn.restype = ctypes.c_int
-    fn.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p, ctypes.c_uint64]
+    fn.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p, ctypes.c_uint64]
     out, n = ctypes.c_void_p(), ctypes.c_uint64()
     err = ctypes.create_string_buffer(1024)
-    rc = fn(json.dumps(q).encode(), cells, len(cells), ctypes.byref(out), ctypes.byref(n), err, 1024)
+    rc = fn(json.dumps(q).encode(), cells, len(cells), mode, ctypes.byref(out), ctypes.byref(n), err, 1024)
     assert rc == 0, err.value.decode()
     text = ctypes.string_at(out.value, n.value)
     lib.oracle_free(out)
@@ -50,14 +50,14 @@ def test_oracle_prints_the_reference_calls_goldens(case):
     assert got == want                              # and the bytes
 
 
-def hostsim_print_calls(q, cells):
+def hostsim_print_calls(q, cells, mode=0):
     lib = helpers.hostsim_lib()
-    fn = lib.hostsim_print_calls
+    fn = lib.hostsim_print_cells
     fn.restype = ctypes.c_int
-    fn.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p, ctypes.c_uint64]
+    fn.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p, ctypes.c_uint64]
     out, n = ctypes.c_void_p(), ctypes.c_uint64()
     err = ctypes.create_string_buffer(4096)
-    rc = fn(json.dumps(q).encode(), cells, len(cells), ctypes.byref(out), ctypes.byref(n), err, 4096)
+    rc = fn(json.dumps(q).encode(), cells, len(cells), mode, ctypes.byref(out), ctypes.byref(n), err, 4096)
     assert rc == 0, err.value.decode()
     text = ctypes.string_at(out.value, n.value)
     lib.hostsim_free(out)
@@ -143,3 +143,77 @@ def test_gt_mpi_gather_print_calls(gdb, tmp_path):
     r = subprocess.run([exe, "-j", str(qf), "--print-calls"], capture_output=True, timeout=300)
     assert r.returncode == 0, r.stderr.decode()
     assert r.stdout == helpers.golden_text(name)
+
+
+# ---- --print-csv / --print-AC: the reference's tests hold no golden for them (parity unpinned: oracle restatement = kernel bodies = device) ----------
+def test_allele_counts_known_answer_on_t0_1_2():
+    """hand-derived from the reference's golden t0_1_2_calls_at_0 (rows 0 / 1 / 2 at 17384: G -> A 0/1, G -> T 0/1 ... ): every GT element that names
+    an ALT allele counts once under (column, REF, ALT)"""
+    doc = json.loads(helpers.golden_text("t0_1_2_calls_at_0"))
+    want = {}
+    for c in doc["variant_calls"][0]["variant_calls"]:
+        f = c["fields"]
+        if "GT" not in f or "REF" not in f or "ALT" not in f:
+            continue
+        for g in f["GT"]:
+            if g > 0:
+                ref, alt = f["REF"], f["ALT"][g - 1]
+                alt = "&" if alt == "<NON_REF>" else alt
+                assert len(ref) == 1                # (no deletions among the called alleles of this input: nothing to normalise)
+                k = (c["interval"][0], ref, alt)
+                want[k] = want.get(k, 0) + 1
+    lines = "".join("%d %s %s %d\n" % (k[0], k[1], k[2], n) for k, n in sorted(want.items()))
+    case = [c for c in CALLS_CASES if c[0] == "t0_1_2_calls_at_0"][0]
+    name, callsets, vid, ranges, attributes = case
+    cells = helpers.cells_for(callsets, vid)
+    q = calls_query(callsets, vid, ranges, attributes)
+    assert oracle_print_calls(q, cells, 2).decode() == lines and len(want) >= 2
+    assert hostsim_print_calls(q, cells, 2).decode() == lines
+
+
+@pytest.mark.parametrize("case", CALLS_CASES, ids=[c[0] for c in CALLS_CASES])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_csv_and_allele_counts_kernel_bodies_against_the_oracle(case, mode):
+    name, callsets, vid, ranges, attributes = case
+    if mode == 2 and attributes == ["MLEAC"]:
+        pytest.skip("AlleleCountOperator needs GT in the query")
+    cells = helpers.cells_for(callsets, vid)
+    q = calls_query(callsets, vid, ranges, attributes)
+    a = oracle_print_calls(q, cells, mode)
+    assert hostsim_print_calls(q, cells, mode) == a
+    if mode == 1 and b'"row"' in helpers.golden_text(name):
+        assert a.count(b"\n") == helpers.golden_text(name).count(b'"row"')      # one line per cell of the JSON golden
+
+
+def test_csv_and_allele_counts_on_synthetic_cells_with_deletions(tmp_path):
+    from genomicsdb_amd import synth
+    N, B, L = 300, 10_000_000, 4000
+    cells, _ = synth.Generator(N, B, L).chunk_bytes(B + L)
+    q = _synth_calls_query(tmp_path, N, [{"range_list": [{"low": B + 500, "high": B + 2500}, {"low": B + 3000, "high": B + 3000}]}])
+    for mode in (1, 2):
+        a = oracle_print_calls(q, cells, mode)
+        assert hostsim_print_calls(q, cells, mode) == a and len(a) > 1000
+    ac = oracle_print_calls(q, cells, 2).decode().splitlines()
+    assert any(len(l.split()[1]) > 1 for l in ac)        # deletions are there (REF longer than one base after normalisation)
+
+
+@pytest.mark.gpu
+def test_device_csv_and_allele_counts(gdb, tmp_path):
+    from genomicsdb_amd import synth
+    for case in (CALLS_CASES[0], CALLS_CASES[6], CALLS_CASES[11], CALLS_CASES[16]):
+        name, callsets, vid, ranges, attributes = case
+        cells = helpers.cells_for(callsets, vid)
+        q = calls_query(callsets, vid, ranges, attributes)
+        eng = gdb.CombineEngine(q)
+        eng.stage_cells(cells)
+        for mode in (1, 2):
+            assert eng.print_calls(mode) == oracle_print_calls(q, cells, mode), (name, mode)
+        eng.close()
+    N, B, L = 1000, 10_000_000, 20_000
+    cells, _ = synth.Generator(N, B, L).chunk_bytes(B + L)
+    q = _synth_calls_query(tmp_path, N, [{"range_list": [{"low": B + 5000, "high": B + 15_000}, {"low": B + 17_000, "high": B + 17_000}]}])
+    eng = gdb.CombineEngine(q)
+    eng.stage_cells(cells)
+    for mode in (1, 2):
+        assert eng.print_calls(mode) == oracle_print_calls(q, cells, mode)
+    eng.close()
