@@ -367,11 +367,14 @@ void CombineEngine::for_each_interval_text(int mode, int arg, const std::functio
   for (unsigned i = 0; i < m_qc.get_num_column_intervals(); ++i) ivs.emplace_back(m_qc.get_column_begin(i), m_qc.get_column_end(i));
   const bool whole_array = ivs.empty();       // a scan of the whole array has no interval begin to intersect (genomicsdb_iterators.cc:188-190)
   if (whole_array) ivs.emplace_back(0, INT64_MAX - 1);
+  std::vector<int64_t> q2a;                   // (the reference prints the row of the ARRAY; a staged cell knows its query row)
+  { const CellStreamLayout& L = layout(); for (size_t r = 0; r < L.row_map.size(); ++r) { const int32_t q = L.row_map[r]; if (q >= 0) { if ((size_t)q >= q2a.size()) q2a.resize((size_t)q + 1, 0); q2a[(size_t)q] = (int64_t)r; } } }
   for (const auto& iv : ivs) {
     std::string text;
     bool first_piece = true;
     for (int64_t pos = iv.first; pos <= iv.second;) {
       const Coverage cov = cover(pos);
+      m_pipe->set_array_rows(q2a);            // (cover() may have swapped the engine's two pipelines)
       const int64_t hi = std::min(cov.hi, iv.second);
       text += m_pipe->cells_text(pos, hi, mode, arg, first_piece && !whole_array);
       first_piece = false;

@@ -13,7 +13,9 @@ namespace genomicsdb_amd {
 struct CallsNames {            // attribute names of the plan fields (the JSON keys), in device memory
   const char* text;
   const int32_t* off;          // [nfields + 1]
+  const int64_t* array_row;    // query row (what a staged cell carries) -> row of the array (what the reference prints); null: the same
 };
+GDB_HD int64_t calls_array_row(const FragmentView& fr, const CallsNames& names, int64_t c) { return names.array_row ? names.array_row[fr.row[c]] : (int64_t)fr.row[c]; }
 
 template <class Sink> GDB_HD void put_lit(Sink& s, const char* z) { int n = 0; while (z[n]) ++n; s.write(z, n); }
 template <class Sink> GDB_HD void put_spaces(Sink& s, int n) { for (int i = 0; i < n; ++i) s.put(' '); }
@@ -97,7 +99,7 @@ template <class Sink> GDB_HD void calls_emit_cell(Sink& s, const FragmentView& f
                                                   int64_t end, int indent) {
   const int64_t begin = fr.begin[c];
   put_spaces(s, indent); put_lit(s, "{\n");
-  put_spaces(s, indent + 4); put_lit(s, "\"row\": "); put_i64(s, (int64_t)fr.row[c]); put_lit(s, ",\n");
+  put_spaces(s, indent + 4); put_lit(s, "\"row\": "); put_i64(s, calls_array_row(fr, names, c)); put_lit(s, ",\n");
   put_spaces(s, indent + 4); put_lit(s, "\"interval\": [ "); put_i64(s, begin); put_lit(s, ", "); put_i64(s, end); put_lit(s, " ],\n");
   const int ci = find_contig(qw, begin);
   if (ci >= 0) {
@@ -123,8 +125,8 @@ template <class Sink> GDB_HD void calls_emit_cell(Sink& s, const FragmentView& f
 // queried attribute behind END through the print_csv of its type (genomicsdb_columnar_field.cc:116-199, 419-424): a list type of variable length
 // starts with its element count (0 and nothing else when the field is not valid), a fixed-length list that is not valid leaves its commas, a single
 // value or a string that is not valid leaves nothing.  (ALT has no special treatment here: the stored string, "|" and "&" included.)
-template <class Sink> GDB_HD void calls_emit_csv(Sink& s, const FragmentView& fr, const CombinePlan& pl, int64_t c, int64_t end) {
-  put_i64(s, (int64_t)fr.row[c]); s.put(','); put_i64(s, fr.begin[c]); s.put(','); put_i64(s, end);
+template <class Sink> GDB_HD void calls_emit_csv(Sink& s, const FragmentView& fr, const CombinePlan& pl, const CallsNames& names, int64_t c, int64_t end) {
+  put_i64(s, calls_array_row(fr, names, c)); s.put(','); put_i64(s, fr.begin[c]); s.put(','); put_i64(s, end);
   for (int f = 0; f < pl.nfields; ++f) {
     s.put(',');
     const GdbFieldDesc& fd = pl.field[f];

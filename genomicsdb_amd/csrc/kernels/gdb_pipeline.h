@@ -129,6 +129,8 @@ class DevicePipeline {
   // "column<TAB>REF<TAB>ALT" per GT element naming an ALT allele, REF / ALT normalised (AlleleCountOperator, :951-1056; indent = the GT step);
   // mode 0 = the JSON objects with ",\n" in front of each
   std::string cells_text(int64_t qb, int64_t qe, int mode, int indent, bool with_intersecting);
+  // the staged cells carry query rows; the printers above print array rows: the map (empty: identical)
+  void set_array_rows(const std::vector<int64_t>& query_row_to_array_row);
   bool next_page(uint64_t arena_bytes, const char** dev_ptr, uint64_t* nbytes);
   // the same in two steps (asynchronous page production, two arenas): see gdb_pipeline.hip
   struct PageTicket { int arena = 0; const char* dev = nullptr; uint64_t nbytes = 0; void* done_event = nullptr; };   // done_event: hipEvent_t recorded behind the page's kernels

@@ -3488,7 +3488,7 @@ struct DevicePipeline::Impl {
   DevBuf<uint32_t> err; DevBuf<int32_t> counters;
   DevBuf<uint32_t> site_key, site_key_sorted; DevBuf<int32_t> site_ord_in, site_ord;
   int ctx_slot = -1;                 // this pipeline's element of c_ex
-  DevBuf<char> calls_names, calls_text; DevBuf<int32_t> calls_name_off; DevBuf<uint64_t> calls_len, calls_off; bool calls_names_ready = false;   // --print-calls
+  DevBuf<char> calls_names, calls_text; DevBuf<int32_t> calls_name_off; DevBuf<uint64_t> calls_len, calls_off; bool calls_names_ready = false; DevBuf<int64_t> calls_array_row; size_t calls_array_row_n = 0;   // --print-calls
   // persistent events (no create / destroy per interval) and one pinned block for every scalar that comes back to the host
   hipEvent_t ev_prep[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_page[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};   // per arena: start, before / after the page assembly, page done
@@ -4872,7 +4872,7 @@ template <bool WRITE> __global__ void k_calls(FragmentView fr, CombinePlan pl, Q
   uint32_t e = 0;
   auto emit = [&](auto& s) {
     if (mode == 0) { s.put(','); s.put('\n'); calls_emit_cell(s, fr, pl, qw, names, c, end, indent); }   // ",\n" in front of every cell (the caller drops the first)
-    else if (mode == 1) calls_emit_csv(s, fr, pl, c, end);
+    else if (mode == 1) calls_emit_csv(s, fr, pl, names, c, end);
     else calls_emit_allele_lines(s, fr, pl, c, indent, &e);                                             // (indent: the GT step)
   };
   if (!WRITE) {
@@ -4886,6 +4886,14 @@ template <bool WRITE> __global__ void k_calls(FragmentView fr, CombinePlan pl, Q
   if (e) atomicOr(err, e);
 }
 
+void DevicePipeline::set_array_rows(const std::vector<int64_t>& query_row_to_array_row) {
+  Impl& S = *m_;
+  HIP_CHECK(hipSetDevice(S.device));
+  S.calls_array_row_n = query_row_to_array_row.size();
+  if (!S.calls_array_row_n) return;
+  S.calls_array_row.ensure(S.calls_array_row_n);
+  HIP_CHECK(hipMemcpy(S.calls_array_row.p, query_row_to_array_row.data(), S.calls_array_row_n * sizeof(int64_t), hipMemcpyHostToDevice));
+}
 std::string DevicePipeline::calls_json(int64_t qb, int64_t qe, int indent, bool with_intersecting, int64_t* ncells) {
   std::string out = cells_text(qb, qe, 0, indent, with_intersecting);
   if (ncells) { int64_t k = 0; const std::string head = ",\n" + std::string((size_t)indent, ' ') + "{\n"; for (size_t q = out.find(head); q != std::string::npos; q = out.find(head, q + 1)) ++k; *ncells = k; }
@@ -4921,7 +4929,7 @@ std::string DevicePipeline::cells_text(int64_t qb, int64_t qe, int mode, int ind
   memset(&qw, 0, sizeof(qw));
   qw.qb = qb; qw.qe = qe;
   qw.contigs = S.contigs.p; qw.ncontigs = (int32_t)S.hp.contigs.size(); qw.contig_names = S.contig_names.p;
-  CallsNames names{S.calls_names.p, S.calls_name_off.p};
+  CallsNames names{S.calls_names.p, S.calls_name_off.p, S.calls_array_row_n ? S.calls_array_row.p : nullptr};
   S.calls_len.ensure((size_t)CW + 1); S.calls_off.ensure((size_t)CW + 1);
   hipLaunchKernelGGL(k_calls<false>, dim3(blocks_for(CW)), dim3(kBlock), 0, st, fr, S.hp.plan, qw, names, (const int64_t*)S.eff_end.p, c_base, CW, qb, qe, mode, indent, with_intersecting ? 1 : 0, S.calls_len.p, (char*)nullptr, S.err.p);
   HIP_CHECK(hipMemsetAsync(S.calls_len.p + CW, 0, sizeof(uint64_t), st));

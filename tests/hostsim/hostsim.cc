@@ -237,7 +237,9 @@ int hostsim_print_cells(const char* query_json_text, const uint8_t* cells, uint6
     std::string names_text; std::vector<int32_t> names_off;
     for (const auto& nm : hp.field_names) { names_off.push_back((int32_t)names_text.size()); names_text += nm; }
     names_off.push_back((int32_t)names_text.size());
-    CallsNames names{names_text.data(), names_off.data()};
+    std::vector<int64_t> q2a;
+    { CellStreamLayout L(qc, hp); for (size_t r = 0; r < L.row_map.size(); ++r) if (L.row_map[r] >= 0) { if ((size_t)L.row_map[r] >= q2a.size()) q2a.resize((size_t)L.row_map[r] + 1, 0); q2a[(size_t)L.row_map[r]] = (int64_t)r; } }
+    CallsNames names{names_text.data(), names_off.data(), q2a.empty() ? nullptr : q2a.data()};
     QueryWindow qw;
     memset(&qw, 0, sizeof(qw));
     qw.contigs = hp.contigs.data(); qw.ncontigs = (int32_t)hp.contigs.size(); qw.contig_names = hp.contig_names.data();
@@ -256,10 +258,10 @@ int hostsim_print_cells(const char* query_json_text, const uint8_t* cells, uint6
         if (!calls_select(fr, eff_end.data(), c, iv.first, iv.second, !whole, end)) continue;
         if (mode != 0) {
           CountSink cs;
-          if (mode == 1) calls_emit_csv(cs, fr, pl, c, end); else calls_emit_allele_lines(cs, fr, pl, c, gt_step, &err);
+          if (mode == 1) calls_emit_csv(cs, fr, pl, names, c, end); else calls_emit_allele_lines(cs, fr, pl, c, gt_step, &err);
           std::string t((size_t)cs.n, '\0');
           ByteSink bs(&t[0]);
-          if (mode == 1) calls_emit_csv(bs, fr, pl, c, end); else calls_emit_allele_lines(bs, fr, pl, c, gt_step, &err);
+          if (mode == 1) calls_emit_csv(bs, fr, pl, names, c, end); else calls_emit_allele_lines(bs, fr, pl, c, gt_step, &err);
           body += t;
           continue;
         }

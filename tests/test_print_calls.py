@@ -198,6 +198,20 @@ def test_csv_and_allele_counts_on_synthetic_cells_with_deletions(tmp_path):
 
 
 @pytest.mark.gpu
+def test_device_prints_array_rows_for_a_row_subset(gdb):
+    name, callsets, vid, ranges, attributes = CALLS_CASES[8]
+    cells = helpers.cells_for(callsets, vid)
+    for row in (1, 2):
+        q = calls_query(callsets, vid, ranges, attributes)
+        q["query_row_ranges"] = [{"range_list": [{"low": row, "high": row}]}]
+        eng = gdb.CombineEngine(q)
+        eng.stage_cells(cells)
+        for mode in (0, 1, 2):
+            assert eng.print_calls(mode) == oracle_print_calls(q, cells, mode), (row, mode)
+        eng.close()
+
+
+@pytest.mark.gpu
 def test_device_csv_and_allele_counts(gdb, tmp_path):
     from genomicsdb_amd import synth
     for case in (CALLS_CASES[0], CALLS_CASES[6], CALLS_CASES[11], CALLS_CASES[16]):
@@ -217,3 +231,23 @@ def test_device_csv_and_allele_counts(gdb, tmp_path):
     for mode in (1, 2):
         assert eng.print_calls(mode) == oracle_print_calls(q, cells, mode)
     eng.close()
+
+
+def test_row_subsets_and_empty_results():
+    """a query for one row prints that row's cells only (the search for intersecting intervals ends when every QUERIED row has been seen); an
+    interval in front of every cell and a query over no cells at all print the empty document"""
+    name, callsets, vid, ranges, attributes = CALLS_CASES[8]          # t0_1_2_calls_at_12150
+    cells = helpers.cells_for(callsets, vid)
+    full = json.loads(helpers.golden_text(name))
+    for row in (0, 1, 2):
+        q = calls_query(callsets, vid, ranges, attributes)
+        q["query_row_ranges"] = [{"range_list": [{"low": row, "high": row}]}]
+        a = oracle_print_calls(q, cells)
+        assert hostsim_print_calls(q, cells) == a
+        want = [c for c in full["variant_calls"][0]["variant_calls"] if c["row"] == row]
+        assert json.loads(a)["variant_calls"][0]["variant_calls"] == want and want
+    q = calls_query(callsets, vid, [{"range_list": [{"low": 5, "high": 100}]}], attributes)
+    empty = b'{\n    "variant_calls": [\n\n    ]\n}\n'
+    assert oracle_print_calls(q, cells) == empty == hostsim_print_calls(q, cells) == helpers.golden_text("t0_1_2_calls_at_12100")
+    for mode in (1, 2):
+        assert oracle_print_calls(q, cells, mode) == b"" == hostsim_print_calls(q, cells, mode)
