@@ -47,7 +47,7 @@ SYMBOLS = ["gdb_mi355_last_error", "gdb_mi355_device_count", "gdb_mi355_init", "
            "gdbamd_engine_create", "gdbamd_engine_create_format", "gdbamd_engine_destroy", "gdbamd_engine_num_fields", "gdbamd_engine_field_name",
            "gdbamd_engine_field_info", "gdbamd_engine_header", "gdbamd_engine_stage_cells", "gdbamd_engine_stage_cells_begin", "gdbamd_engine_stage_cells_append", "gdbamd_engine_stage_cells_end",
            "gdbamd_engine_adopt_device_fragment", "gdbamd_engine_open_array", "gdbamd_engine_open_memory_cells", "gdbamd_engine_open_cell_callback", "gdbamd_engine_cover", "gdbamd_engine_staged_info", "gdbamd_engine_set_reference", "gdbamd_engine_run_interval", "gdbamd_engine_prepare_interval", "gdbamd_engine_next_page", "gdbamd_engine_split_point", "gdbamd_engine_save_fragment", "gdbamd_engine_save_fragment_compressed", "gdbamd_engine_load_fragment", "gdbamd_column_partition", "gdbamd_import_cells", "gdbamd_free",
-           "gdbamd_engine_column_histogram", "gdbamd_equi_partition_text", "gdbamd_build_output_index", "gdbamd_engine_print_calls", "gdbamd_engine_print_cells"]
+           "gdbamd_engine_column_histogram", "gdbamd_equi_partition_text", "gdbamd_build_output_index", "gdbamd_engine_print_calls", "gdbamd_engine_print_cells", "gdbamd_pin_host_memory", "gdbamd_unpin_host_memory"]
 
 
 def lib():
@@ -115,6 +115,8 @@ def lib():
     L.gdbamd_engine_adopt_device_fragment.argtypes = [c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p, c.c_void_p, c.POINTER(DeviceColumn), c.c_int, c.c_uint64]
     L.gdbamd_engine_open_array.argtypes = [c.c_void_p, c.c_char_p]
     L.gdbamd_engine_open_memory_cells.argtypes = [c.c_void_p, c.c_void_p, c.c_uint64]
+    L.gdbamd_pin_host_memory.argtypes = [c.c_void_p, c.c_uint64]
+    L.gdbamd_unpin_host_memory.argtypes = [c.c_void_p]
     L.gdbamd_engine_open_cell_callback.argtypes = [c.c_void_p, CELL_CHUNK_FN, c.c_void_p]
     L.gdbamd_engine_cover.argtypes = [c.c_void_p, c.c_int64, c.POINTER(c.c_int64), c.POINTER(c.c_int64)]
     L.gdbamd_engine_staged_info.argtypes = [c.c_void_p, c.POINTER(c.c_int64), c.POINTER(c.c_uint64)]

@@ -299,6 +299,15 @@ class CombineEngine:
             pass
 
 
+def pin_host_memory(addr, nbytes):
+    """page-lock the caller's host range so that staging copies out of it are DMA transfers (gdbamd_pin_host_memory)"""
+    _check(_lib.lib().gdbamd_pin_host_memory(addr, nbytes) == 0, "pin_host_memory")
+
+
+def unpin_host_memory(addr):
+    _check(_lib.lib().gdbamd_unpin_host_memory(addr) == 0, "unpin_host_memory")
+
+
 def import_cells(vid_mapping_file, callset_mapping_file, file_root="", treat_deletions_as_intervals=True, column_begin=0, column_end=2**63 - 2):
     """(g)VCFs of a callset mapping -> begin-cells (bytes, reference binary cell layout, column-major) of one column partition:
     the conversion step of the reference's vcf2tiledb (vcf2binary.cc:991-1196).  Host code, no device needed."""

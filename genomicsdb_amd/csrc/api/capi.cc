@@ -185,6 +185,19 @@ int gdbamd_engine_open_array(void* e, const char* dir) { return guarded([&]() ->
 int gdbamd_engine_open_memory_cells(void* e, const uint8_t* cells, uint64_t nbytes) {
   return guarded([&]() -> int { ((EngineHandle*)e)->eng->open_memory_cells(cells, nbytes); return 0; }, 1);
 }
+int gdbamd_pin_host_memory(const void* p, uint64_t nbytes) {
+  return guarded([&]() -> int {
+    if (!p || !nbytes) return 0;
+    if (hipHostRegister(const_cast<void*>(p), (size_t)nbytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); throw GenomicsDBDeviceException("hipHostRegister failed (locked-memory limit?)"); }
+    return 0;
+  }, 1);
+}
+int gdbamd_unpin_host_memory(const void* p) {
+  return guarded([&]() -> int {
+    if (p && hipHostUnregister(const_cast<void*>(p)) != hipSuccess) { (void)hipGetLastError(); throw GenomicsDBDeviceException("hipHostUnregister failed"); }
+    return 0;
+  }, 1);
+}
 int gdbamd_engine_open_cell_callback(void* e, gdbamd_cell_chunk_fn fn, void* user) {
   return guarded([&]() -> int { ((EngineHandle*)e)->eng->open_cell_callback(fn, user); return 0; }, 1);
 }

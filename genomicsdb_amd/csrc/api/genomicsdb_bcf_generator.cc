@@ -228,7 +228,8 @@ void CombineEngine::stage_window(DevicePipeline& dst, DevicePipeline& carry_src,
   } else {
     // the binary cell stream in sub-chunks (whole begin columns each): read -> walk the sizes -> HBM, until the window is full
     const CellStreamLayout& L = layout();
-    const uint64_t sub = std::min<uint64_t>(budget, (uint64_t)256 << 20);
+    static const uint64_t sub_mb = []() { const char* e = getenv("GDBAMD_STAGE_SUB_MB"); return e && *e ? (uint64_t)std::max<long long>(1, std::min<long long>(2048, atoll(e))) : (uint64_t)1024; }();
+    const uint64_t sub = std::min<uint64_t>(budget, sub_mb << 20);
     uint64_t taken = 0;
     std::vector<uint64_t> offs;
     uint64_t want = sub;

@@ -185,6 +185,13 @@ typedef int (*gdbamd_cell_chunk_fn)(void* user, const uint8_t** cells, uint64_t*
 int gdbamd_engine_open_array(void* engine, const char* dir);
 int gdbamd_engine_open_memory_cells(void* engine, const uint8_t* cells, uint64_t nbytes);
 int gdbamd_engine_open_cell_callback(void* engine, gdbamd_cell_chunk_fn fn, void* user);
+/* Page-lock a range of the caller's own host memory (the cells handed to open_memory_cells / stage_cells_append, a chunk buffer of
+ * a cell callback) so that the engine's host -> HBM copies are DMA transfers that overlap the kernels of the window being
+ * computed; copies from pageable memory go through the runtime's bounce buffers on the calling thread and hold up the other
+ * pipeline's launches.  The range stays valid and pinned until gdbamd_unpin_host_memory; 0 on success (on failure the memory is
+ * left as it was: the copies still work, only slower). */
+int gdbamd_pin_host_memory(const void* p, uint64_t nbytes);
+int gdbamd_unpin_host_memory(const void* p);
 int gdbamd_engine_cover(void* engine, int64_t column, int64_t* lo, int64_t* hi);
 /* what is staged: #begin-cells and the sum of their reference binary-cell sizes ("bytes_in" of the byte accounting) */
 int gdbamd_engine_staged_info(void* engine, int64_t* ncells, uint64_t* reference_cell_bytes);

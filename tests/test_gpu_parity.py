@@ -846,6 +846,43 @@ def test_windowed_streaming_equals_resident_bytes(gdb, tmp_path, monkeypatch):
     s.close()
 
 
+def test_pinned_memory_cells_streamed_in_windows(gdb, tmp_path, monkeypatch):
+    """the caller's cells page-locked with gdbamd_pin_host_memory (DMA copies under the kernels of the window in use): the windowed
+    stream from the pinned range equals the resident one and the oracle; pinning twice / unpinning a foreign pointer fail loudly"""
+    import numpy as np
+    from genomicsdb_amd import synth, api
+    N, B, L = 120, 10_000_000, 20_000
+    cells, nc = _synth_cells(N, B, L)
+    q = helpers.synth_query(tmp_path, N, B + 300, B + L - 500)
+    want, nrec, _ = helpers.oracle_run_synth(q, cells, synth.SEED, with_header=False)
+    keep = np.frombuffer(cells, dtype=np.uint8).copy()
+    api.pin_host_memory(keep.ctypes.data, keep.nbytes)
+    try:
+        with pytest.raises(gdb.GenomicsDBException):
+            api.pin_host_memory(keep.ctypes.data, keep.nbytes)          # already registered
+        monkeypatch.setenv("GDBAMD_STAGE_BUDGET_BYTES", str(len(cells) // 7))
+        e = gdb.CombineEngine(q)
+        e.open_memory_cells((keep.ctypes.data, keep.nbytes))
+        e.set_reference(B, synth.reference(B, L + 4096))
+        body = b""
+        pos, qe = B + 300, B + L - 500
+        nwin = 0
+        while pos <= qe:
+            lo, hi = e.cover(pos)
+            b, st = e.run_interval(pos, min(qe, hi), arena_bytes=1 << 20)
+            body += b
+            pos = hi + 1
+            nwin += 1
+        e.close()
+        assert nwin >= 6
+        assert body == want
+    finally:
+        api.unpin_host_memory(keep.ctypes.data)
+    other = np.zeros(4096, dtype=np.uint8)
+    with pytest.raises(gdb.GenomicsDBException):
+        api.unpin_host_memory(other.ctypes.data)
+
+
 def test_stale_or_foreign_fragment_files_are_refused(gdb, tmp_path):
     """a fragment file is checked against the array schema, the callset mapping and its own size before a byte of it reaches a
     kernel: a truncated file, a file written under another callset mapping and a file with a doctored header are errors (or,
