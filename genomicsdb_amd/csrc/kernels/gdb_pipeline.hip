@@ -128,6 +128,10 @@ inline bool events_enabled() { const char* e = getenv("GDBAMD_EVENTS"); return e
 //   2            sizes from pieces (k_size2), the matrix from a piece walker per lane (k_fill2), pages by k_assemble_write / the BCF kernels
 //   3            text only: sizes from pieces (k_size2), piece lists (k_plist), pages by k_write3 (no matrix, no walking in the page pass)
 inline int asm_path_wanted() { const char* e = getenv("GDBAMD_ASM_PATH"); return e && *e ? std::max(0, std::min(3, atoi(e))) : 0; }
+// sizing pass: 3 = k_assemble_size3 in rounds of 8 records (default), 16 = rounds of 16, 0 = k_assemble_size
+inline int size3_rounds() { const char* e = getenv("GDBAMD_SIZE3"); const int v = e && *e ? atoi(e) : 8; return v == 0 ? 0 : v >= 16 ? 16 : 8; }
+inline bool res_chunk_major() { static const bool v = []() { const char* e = getenv("GDBAMD_RES_LAYOUT"); return e && *e == '1'; }(); return v; }   // (measured: no difference; record-major stays)
+inline bool size3_check() { const char* e = getenv("GDBAMD_SIZE3_CHECK"); return e && *e && *e != '0'; }
 inline int fill_run_length() { const char* e = getenv("GDBAMD_RUN_F"); return e && *e ? std::max(1, atoi(e)) : 128; }
 inline int write2_run_length() { const char* e = getenv("GDBAMD_RUN_W2"); return e && *e ? std::max(1, atoi(e)) : 64; }
 // wavefronts (= neighbouring 64-sample chunks) per workgroup of the page assembly: 4 measured best on the store-only model
@@ -1450,10 +1454,14 @@ __device__ __forceinline__ int64_t readlane64(int64_t v, int l) {
   return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
+// Row of (record k_rel, chunk ch) in the resolved matrix.  res_rows == 0: record-major (the 16 chunk rows of a record are neighbours: what the
+// BCF kernels read); res_rows = #records of the matrix: CHUNK-major - the rows a wavefront writes (sizing) and reads (page assembly) along
+// its run of records lie 512 bytes apart instead of 8 KB (GDBAMD_RES_LAYOUT=1; measured on c2: no difference, so record-major is what runs).
+__device__ __forceinline__ int64_t res_row(int64_t k_rel, int ch, int nchunks, int64_t res_rows) { return res_rows ? (int64_t)ch * res_rows + k_rel : k_rel * nchunks + ch; }
 // chunk_size == nullptr: resolve only (per-page matrix when the whole interval's matrix would not fit the budget)
 __global__ void __launch_bounds__(kAsmRows)
 k_assemble_size(AsmCtx a, const int32_t* __restrict__ order, int64_t n, int32_t N, int nchunks, int run, uint64_t* __restrict__ chunk_size,
-                uint2* __restrict__ resolved, int64_t resolved_base) {
+                uint2* __restrict__ resolved, int64_t resolved_base, int64_t res_rows) {
   // chunk is the fast grid dimension: the wavefronts in flight work on the same few records (one 44 KB line is written
   // by its 16 chunk wavefronts at about the same time: DRAM pages, TLB entries and shared boundary lines stay hot)
   const int64_t ib = (int64_t)(blockIdx.x / (unsigned)nchunks) * run;
@@ -1487,12 +1495,129 @@ k_assemble_size(AsmCtx a, const int32_t* __restrict__ order, int64_t n, int32_t 
         d = cur;
       }
       prev_k = k;
-      if (resolved) resolved[((k - resolved_base) * nchunks + ch) * kAsmRows + lane] = d;
+      if (resolved) resolved[res_row(k - resolved_base, ch, nchunks, res_rows) * kAsmRows + lane] = d;
       const uint32_t total = wave_total(wave_inclusive_scan_dpp(d.y));
       if (lane == jj) my_total += total;
     }
     if (chunk_size && lane < cnt) chunk_size[(int64_t)my_k * nchunks + ch] = my_total;
   }
+}
+
+// The same pass, PIECE-WISE (default; GDBAMD_SIZE3=0 selects the kernel above).  k_assemble_size decides record by record whether a
+// sample's entry changes: with 64 samples in a wavefront some lane changes at nearly every record (~1.6 changes per step), so the
+// dear path - walk list, incidence / slot arithmetic, descriptor load: two dependent loads - is executed by 1-2 of 64 lanes on
+// ~80 % of the 64 steps of a run.  Here the records go in rounds of R: in phase 1 EVERY lane names its own pieces of the round (a piece =
+// the records of the round that keep one entry: the lane asks the walker at the piece's first record, exactly as the kernel above
+// does at every record, and finds the piece's end among the round's record starts, held in LDS, by binary search), all lanes busy, a
+// few iterations per round (the most pieces any lane has); phase 2 is 64 cheap steps (is this record the start of my next piece? -
+// one register compare - and the row's coalesced store).  The sizes do not need a scan per record either: every piece adds its length
+// at its first record and takes it away behind its last in a difference array over the batch's 64 records (LDS atomics), one scan per batch.
+// Bit-identical output (GDBAMD_SIZE3_CHECK=1 runs both and compares).
+template <int R> __global__ void __launch_bounds__(kAsmRows)
+k_assemble_size3(AsmCtx a, const int32_t* __restrict__ order, int64_t n, int32_t N, int nchunks, int run, uint64_t* __restrict__ chunk_size,
+                 uint2* __restrict__ resolved, int64_t resolved_base, int64_t res_rows) {
+  __shared__ int64_t ss[kAsmRows];                     // the batch's record starts
+  __shared__ int32_t ks[kAsmRows];                     // ... and record indices
+  __shared__ uint32_t diff[kAsmRows + 1];              // difference array of the chunk sizes over the batch
+  __shared__ uint2 pl_d[R * kAsmRows];                 // the lanes' pieces of one round: entry ...
+  __shared__ uint8_t pl_at[R * kAsmRows];              // ... and first record (index into the batch)
+  const int64_t ib = (int64_t)(blockIdx.x / (unsigned)nchunks) * run;
+  const int64_t ie = min(n, ib + (int64_t)run);
+  const int ch = (int)(blockIdx.x % (unsigned)nchunks);
+  const int lane = threadIdx.x;
+  const int32_t r = ch * kAsmRows + lane;
+  const bool has_row = r < N;
+  SlotWalker w;
+  int64_t prev_k = INT64_MAX;                          // (uniform) the record in front
+  uint32_t cur_slot = kNoSlot;
+  uint2 cur = make_uint2(0, 0);
+  for (int64_t i0 = ib; i0 < ie; i0 += 64) {          // uniform
+    const int cnt = (int)min((int64_t)64, ie - i0);
+    int32_t my_k = 0; int64_t my_s = INT64_MAX; uint32_t my_t = 0; uint64_t my_total = 0;
+    if (lane < cnt) {
+      my_k = order[i0 + lane];
+      my_s = a.rec_start[my_k];
+      my_t = a.rtype[my_k];
+      if (ch == 0) my_total = a.prefix_len[my_k];
+      if (ch == nchunks - 1) my_total += 1;           // '\n'
+    }
+    ss[lane] = my_s; ks[lane] = my_k; diff[lane] = 0u;
+    if (lane == 0) diff[kAsmRows] = 0u;
+    // segments: records of one type in increasing order (a new type, or the next block of the order, starts a new one)
+    const int32_t left_k = __shfl_up(my_k, 1, 64);
+    const uint32_t left_t = (uint32_t)__shfl_up((int)my_t, 1, 64);
+    const uint64_t heads = __ballot(lane < cnt && (lane == 0 || my_k < left_k || my_t != left_t));
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    for (int seg_a = 0; seg_a < cnt;) {                // uniform
+      const uint64_t behind = seg_a + 1 < 64 ? heads >> (seg_a + 1) : 0ull;
+      const int seg_b = behind ? seg_a + 1 + (int)__builtin_ctzll(behind) : cnt;
+      const int64_t k_a = __builtin_amdgcn_readlane(my_k, seg_a);
+      const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)my_t, seg_a);
+      if (k_a < prev_k && has_row) w.init(a, r, readlane64(my_s, seg_a));   // uniform test: a new type restarts at its first record
+      for (int ra = seg_a; ra < seg_b; ra += R) {      // uniform
+        const int rb = min(seg_b, ra + R);
+        // ---- phase 1: the lane's pieces of [ra, rb) ----
+        int pos = ra, np = 0;
+        while (__any((int)(pos < rb))) {
+          if (pos < rb) {
+            uint2 d = make_uint2(0, 0);
+            int e = rb;
+            if (has_row) {
+              const int64_t s = ss[pos];
+              const int64_t k = ks[pos];
+              w.advance(a, s);
+              const uint32_t sl = w.slot(a, k, s, t, r);
+              if (sl != cur_slot) { cur_slot = sl; cur = a.desc[sl]; }
+              d = cur;
+              const bool dead = s > w.cur_end;
+              if (t == kUntabledType || (!dead && w.heavy)) e = pos + 1;     // a slot per record
+              else {
+                // the entry holds while the walker stands (no cell of the row begins) and the cell stays dead / stays live
+                const int64_t x = dead ? w.next_begin - 1 : min(w.cur_end, w.next_begin - 1);
+                int lo = pos + 1, hi = rb;             // first record of the round that starts behind x
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (ss[mid] > x) hi = mid; else lo = mid + 1; }
+                e = lo;
+              }
+            }
+            pl_d[np * kAsmRows + lane] = d;
+            pl_at[np * kAsmRows + lane] = (uint8_t)pos;
+            ++np;
+            if (chunk_size && d.y) { atomicAdd(&diff[pos], d.y); atomicAdd(&diff[e], 0u - d.y); }
+            pos = e;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        // ---- phase 2: the rows ----
+        if (resolved) {
+          int q = 0, nxt = ra;                         // (every lane's first piece begins at ra)
+          uint2 row = make_uint2(0, 0);
+          for (int jj = ra; jj < rb; ++jj) {           // uniform
+            if (jj == nxt) {
+              row = pl_d[q * kAsmRows + lane];
+              ++q;
+              nxt = q < np ? (int)pl_at[q * kAsmRows + lane] : 255;
+            }
+            const int64_t k = __builtin_amdgcn_readlane(my_k, jj);
+            resolved[res_row(k - resolved_base, ch, nchunks, res_rows) * kAsmRows + lane] = row;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      }
+      prev_k = __builtin_amdgcn_readlane(my_k, seg_b - 1);
+      seg_a = seg_b;
+    }
+    if (chunk_size) {
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      const uint32_t incl = wave_inclusive_scan_dpp(diff[lane]);      // bytes of the sample columns of record `lane` in this chunk
+      if (lane < cnt) chunk_size[(int64_t)my_k * nchunks + ch] = my_total + incl;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  }
+}
+// GDBAMD_SIZE3_CHECK: the two sizing kernels' outputs, word for word
+__global__ void k_compare_words(const uint32_t* a, const uint32_t* b, int64_t nwords, unsigned long long* mismatches) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nwords && a[i] != b[i]) atomicAdd(mismatches, 1ull);
 }
 
 constexpr int kTextChunks = 8;       // 16-byte chunks of a slot kept in registers
@@ -1518,7 +1643,7 @@ template <int WAVES> __device__ __forceinline__ int64_t xcd_aware_unit(int64_t t
 template <int WAVES, int kWaveLds> __global__ void __launch_bounds__(kAsmRows * WAVES)
 k_assemble_write(const char* __restrict__ pool, const char* __restrict__ pool_ovf, const uint32_t* __restrict__ prefix_len, const uint2* __restrict__ resolved, int64_t resolved_base,
                  const int32_t* __restrict__ order, int64_t n, int nchunks, int run, const uint64_t* __restrict__ chunk_off, uint64_t page_base,
-                 char* __restrict__ arena, int xcd_aware) {
+                 char* __restrict__ arena, int xcd_aware, int64_t res_rows) {
   const int64_t unit = xcd_aware_unit<WAVES>(((n + run - 1) / run) * (int64_t)nchunks, xcd_aware);
   if (unit < 0) return;
   const int64_t ib = (unit / nchunks) * run;
@@ -1539,10 +1664,10 @@ k_assemble_write(const char* __restrict__ pool, const char* __restrict__ pool_ov
       my_k = order[i0 + lane];
       my_dst = (int64_t)(chunk_off[(int64_t)my_k * nchunks + ch] - page_base) + (ch == 0 ? prefix_len[my_k] : 0u);
     }
-    uint2 d_next = resolved[(((int64_t)__builtin_amdgcn_readlane(my_k, 0) - resolved_base) * nchunks + ch) * kAsmRows + lane];
+    uint2 d_next = resolved[res_row((int64_t)__builtin_amdgcn_readlane(my_k, 0) - resolved_base, ch, nchunks, res_rows) * kAsmRows + lane];
     for (int jj = 0; jj < cnt; ++jj) {                      // uniform
       const uint2 d = d_next;
-      if (jj + 1 < cnt) d_next = resolved[(((int64_t)__builtin_amdgcn_readlane(my_k, jj + 1) - resolved_base) * nchunks + ch) * kAsmRows + lane];
+      if (jj + 1 < cnt) d_next = resolved[res_row((int64_t)__builtin_amdgcn_readlane(my_k, jj + 1) - resolved_base, ch, nchunks, res_rows) * kAsmRows + lane];
       const uint32_t len = d.y;
       if (len && (d.x != cur.x || len != cur.y)) {          // the sample moved to another slot: fetch its text
         cur = d;
@@ -3515,6 +3640,7 @@ struct DevicePipeline::Impl {
   DevBuf<int64_t> walk_cut; DevBuf<unsigned long long> walk_kept_bytes;
   DevBuf<uint8_t> inflate_in, inflate_out, inflate_scratch; DevBuf<uint64_t> inflate_off; DevBuf<uint32_t> inflate_want;   // DEFLATE tiles of a compressed fragment file
   DevBuf<long long> carry_last; DevBuf<uint64_t> carry_keys, carry_sorted; int64_t carried_cells = 0;
+  DevBuf<uint2> chk_resolved; DevBuf<uint64_t> chk_sizes; DevBuf<unsigned long long> chk_count;   // GDBAMD_SIZE3_CHECK
   DevBuf<uint2> resolved;          // (pool offset, length) of every (record, sample): whole interval, or one page when that exceeds the budget
   DevBuf<uint32_t> type_occ;
   DevBuf<uint32_t> untabled, ubase; DevBuf<int32_t> urec, iota, order; DevBuf<uint32_t> order_keys, order_keys_sorted;
@@ -3533,7 +3659,7 @@ struct DevicePipeline::Impl {
     std::vector<uint64_t> rec_off;
     IntervalStats stats;
     SiteCtx sx; EntryCtx ex; RowIndex ri; SiteOut so; RecordTable rec; AsmCtx ac; PieceCtx pc2;
-    bool resolved_whole = false, piece_path = false; int asm_path = 0, NT = 0;
+    bool resolved_whole = false, piece_path = false; int asm_path = 0, NT = 0; int64_t P_rows = 0;
     bool bcf = false; int bcf_F = 0; BcfLayout lay{nullptr, nullptr, nullptr, nullptr};
     bool events = false; int evrun = 0; EventBuf eb{nullptr, nullptr, nullptr, 0};
   } iv;
@@ -4946,6 +5072,29 @@ std::string DevicePipeline::cells_text(int64_t qb, int64_t qe, int mode, int ind
   return out;
 }
 
+// the sizing / resolution pass of `n` records in `order` (piece-wise kernel by default; GDBAMD_SIZE3=0: the record-by-record one).
+// size_slots: elements of chunk_size (the check mode compares them all)
+static void launch_assemble_size(DevicePipeline::Impl& S, hipStream_t st, dim3 grid, const AsmCtx& ac, const int32_t* order, int64_t n, int32_t N, int nchunks, int run,
+                                 uint64_t* chunk_size, size_t size_slots, uint2* resolved, int64_t resolved_base, int64_t res_rows) {
+  const int rounds = size3_rounds();
+  if (rounds == 0 || run > 64 * 1024) { hipLaunchKernelGGL(k_assemble_size, grid, dim3(kAsmRows), 0, st, ac, order, n, N, nchunks, run, chunk_size, resolved, resolved_base, res_rows); return; }
+  if (rounds >= 16) hipLaunchKernelGGL((k_assemble_size3<16>), grid, dim3(kAsmRows), 0, st, ac, order, n, N, nchunks, run, chunk_size, resolved, resolved_base, res_rows);
+  else hipLaunchKernelGGL((k_assemble_size3<8>), grid, dim3(kAsmRows), 0, st, ac, order, n, N, nchunks, run, chunk_size, resolved, resolved_base, res_rows);
+  if (!size3_check()) return;
+  const size_t nres = resolved ? (size_t)n * (size_t)nchunks * kAsmRows : 0;
+  S.chk_count.ensure(1);
+  HIP_CHECK(hipMemsetAsync(S.chk_count.p, 0, sizeof(unsigned long long), st));
+  if (nres) S.chk_resolved.ensure(nres);
+  if (chunk_size) { S.chk_sizes.ensure(size_slots); HIP_CHECK(hipMemcpyAsync(S.chk_sizes.p, chunk_size, size_slots * sizeof(uint64_t), hipMemcpyDeviceToDevice, st)); }   // (records outside `order` keep what they had)
+  hipLaunchKernelGGL(k_assemble_size, grid, dim3(kAsmRows), 0, st, ac, order, n, N, nchunks, run, chunk_size ? S.chk_sizes.p : (uint64_t*)nullptr, nres ? S.chk_resolved.p : (uint2*)nullptr,
+                     resolved_base, res_rows);
+  // (the rows of the records in `order` only: with a base, row (k - base); the launch sites pass records [base, base + n))
+  if (nres) hipLaunchKernelGGL(k_compare_words, dim3(blocks_for((int64_t)nres * 2)), dim3(kBlock), 0, st, (const uint32_t*)resolved, (const uint32_t*)S.chk_resolved.p, (int64_t)nres * 2, S.chk_count.p);
+  if (chunk_size) hipLaunchKernelGGL(k_compare_words, dim3(blocks_for((int64_t)size_slots * 2)), dim3(kBlock), 0, st, (const uint32_t*)chunk_size, (const uint32_t*)S.chk_sizes.p, (int64_t)size_slots * 2, S.chk_count.p);
+  const unsigned long long bad = S.read_back(S.chk_count.p);
+  if (bad) throw GenomicsDBDeviceException("GDBAMD_SIZE3_CHECK: the piece-wise sizing pass differs from the record-by-record one in " + std::to_string(bad) + " words");
+}
+
 void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   Impl& S = *m_;
   S.iv = Impl::IntervalState();
@@ -5383,7 +5532,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
       hipLaunchKernelGGL(k_size2, dim3((unsigned)size2_units), dim3(kAsmRows), 0, st, pc2, nchunks, S.chunk_size.p);
       hipLaunchKernelGGL(k_fill2, dim3(fill_units), dim3(kAsmRows), 0, st, pc2, (const uint2*)S.slot_desc.p, (const int32_t*)S.order.p, P, nchunks, frun, S.resolved.p, (int64_t)0);
     } else
-    hipLaunchKernelGGL(k_assemble_size, dim3(run_blocks * (unsigned)nchunks), dim3(kAsmRows), 0, st, ac, S.order.p, P, N, nchunks, run, (uint64_t*)nullptr, S.resolved.p, (int64_t)0);
+    launch_assemble_size(S, st, dim3(run_blocks * (unsigned)nchunks), ac, S.order.p, P, N, nchunks, run, (uint64_t*)nullptr, 0, S.resolved.p, (int64_t)0, (int64_t)0);
     S.bcf_part.ensure(nchunk_total * (size_t)bcf_F + 1); S.bcf_fmeta.ensure((size_t)P * bcf_F + 1); S.bcf_foff.ensure((size_t)P * bcf_F + 1); S.bcf_lindiv.ensure((size_t)P + 1);
     S.bcf_rec_size.ensure((size_t)P + 2);
     lay = BcfLayout{S.bcf_fmeta.p, S.bcf_foff.p, S.bcf_lindiv.p, S.bcf_rec_size.p};
@@ -5423,8 +5572,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
     if (asm_path == 2 && resolved_whole)
       hipLaunchKernelGGL(k_fill2, dim3(fill_units), dim3(kAsmRows), 0, st, pc2, (const uint2*)S.slot_desc.p, (const int32_t*)S.order.p, P, nchunks, frun, S.resolved.p, (int64_t)0);
   } else
-  hipLaunchKernelGGL(k_assemble_size, dim3(run_blocks * (unsigned)nchunks), dim3(kAsmRows), 0, st, ac, S.order.p, P, N, nchunks, run, S.chunk_size.p,
-                     resolved_whole ? S.resolved.p : nullptr, (int64_t)0);
+  launch_assemble_size(S, st, dim3(run_blocks * (unsigned)nchunks), ac, S.order.p, P, N, nchunks, run, S.chunk_size.p, nchunk_total, resolved_whole ? S.resolved.p : nullptr, (int64_t)0, res_chunk_major() ? P : (int64_t)0);
   HIP_CHECK(hipMemsetAsync(S.chunk_size.p + nchunk_total, 0, sizeof(uint64_t), st));
   S.excl_scan(S.chunk_size.p, S.chunk_off.p, nchunk_total + 1);
   STAGE("k_gather_record_offsets");
@@ -5446,7 +5594,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   if (eb) throw GenomicsDBDeviceException(err_bits_text(eb));
   S.iv.max_record_bytes = totals[1];
   S.iv.P = P; S.iv.nchunks = nchunks; S.iv.kp = 0;
-  S.iv.sx = sx; S.iv.ex = ex; S.iv.ri = ri; S.iv.so = so; S.iv.rec = rec; S.iv.ac = ac; S.iv.pc2 = pc2; S.iv.piece_path = piece_path; S.iv.asm_path = asm_path; S.iv.resolved_whole = resolved_whole;
+  S.iv.sx = sx; S.iv.ex = ex; S.iv.ri = ri; S.iv.so = so; S.iv.rec = rec; S.iv.ac = ac; S.iv.pc2 = pc2; S.iv.piece_path = piece_path; S.iv.asm_path = asm_path; S.iv.resolved_whole = resolved_whole; S.iv.P_rows = P;
   S.iv.bcf = pl.bcf_mode != 0; S.iv.bcf_F = bcf_F; S.iv.lay = lay;
   S.iv.events = use_events; S.iv.evrun = ebuf.run; S.iv.eb = ebuf;
   S.iv.active = true;
@@ -5584,11 +5732,12 @@ bool DevicePipeline::begin_page(uint64_t arena_bytes, int arena_idx, PageTicket*
       hipLaunchKernelGGL(k_fill2, dim3((unsigned)(((np + frun - 1) / frun) * iv.nchunks)), dim3(kAsmRows), 0, st, iv.pc2, (const uint2*)S.slot_desc.p, (const int32_t*)S.order.p, np, iv.nchunks, frun,
                          S.resolved.p, kp);
     } else
-    hipLaunchKernelGGL(k_assemble_size, wgrid, dim3(kAsmRows), 0, st, iv.ac, S.order.p, np, N, iv.nchunks, wrun, (uint64_t*)nullptr, S.resolved.p, kp);
+    launch_assemble_size(S, st, wgrid, iv.ac, S.order.p, np, N, iv.nchunks, wrun, (uint64_t*)nullptr, 0, S.resolved.p, kp, res_chunk_major() && iv.asm_path != 2 ? np : (int64_t)0);
   }
   HIP_CHECK(hipEventRecord(w[1], st));   // [w1, w2] brackets the page-assembly kernel alone (its duration feeds the roofline figure)
 #define GDB_LAUNCH_WRITE(W, L) hipLaunchKernelGGL((k_assemble_write<W, L>), dim3((wgrid.x + (W) - 1u) / (W)), dim3(kAsmRows * (W)), 0, st, (const char*)S.pool.p, (const char*)S.pool_ovf.p, \
-    (const uint32_t*)S.prefix_len.p, (const uint2*)S.resolved.p, iv.resolved_whole ? (int64_t)0 : kp, (const int32_t*)S.order.p, np, iv.nchunks, wrun, (const uint64_t*)S.chunk_off.p, page_base, arena, xcd_aware_numbering() ? 1 : 0)
+    (const uint32_t*)S.prefix_len.p, (const uint2*)S.resolved.p, iv.resolved_whole ? (int64_t)0 : kp, (const int32_t*)S.order.p, np, iv.nchunks, wrun, (const uint64_t*)S.chunk_off.p, page_base, arena, xcd_aware_numbering() ? 1 : 0, \
+    (res_chunk_major() && iv.asm_path != 2) ? (iv.resolved_whole ? (int64_t)iv.P_rows : np) : (int64_t)0)
   {
     const int ww = write_waves_per_group(), wl = write_image_kb();
     if (ww >= 4 && wl <= 4) GDB_LAUNCH_WRITE(4, 4096);
