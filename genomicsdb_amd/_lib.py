@@ -4,7 +4,7 @@ import os
 import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libgenomicsdb_amd.so")
+LIB_PATH = os.environ.get("GDBAMD_LIB_PATH") or os.path.join(PKG, "libgenomicsdb_amd.so")   # (the override: A/B builds of the same sources under build/variants/)
 
 
 class IntervalStats(ctypes.Structure):

@@ -142,15 +142,27 @@ struct LdsSpillSink {
   gdb_lds_char* p;
   uint32_t n, cap;
   int32_t chunk;          // -1: none taken yet, -2: the pool is exhausted
+  uint32_t acc;           // the spilled bytes of the word under way: the pool is written a word at a time (a byte store per spilled
+                          // character, behind a call, made the site pass 3 x slower as soon as a few records in a hundred spilled)
   SpillPool pool;
-  __device__ __forceinline__ LdsSpillSink(gdb_lds_char* q, uint32_t c, const SpillPool& sp) : p(q), n(0), cap(c), chunk(-1), pool(sp) {}
-  // (by value and out of line: the sink itself stays in registers, the rare path costs one call)
-  __device__ __noinline__ static int32_t spill(SpillPool pool, int32_t chunk, uint32_t at, char c) {
+  __device__ __forceinline__ LdsSpillSink(gdb_lds_char* q, uint32_t c, const SpillPool& sp) : p(q), n(0), cap(c), chunk(-1), acc(0), pool(sp) {}
+  // (by value and out of line: the sink itself stays in registers, the rare path costs one call per four bytes)
+  __device__ __noinline__ static int32_t spill(SpillPool pool, int32_t chunk, uint32_t at, uint32_t w) {   // at: byte offset of the word in the chunk
     if (chunk == -1) { const unsigned int i = atomicAdd(pool.next, 1u); chunk = i < pool.nchunks ? (int32_t)i : -2; }
-    if (chunk >= 0 && at < kSpillChunk) pool.buf[(size_t)chunk * kSpillChunk + at] = c;
+    if (chunk >= 0 && at < kSpillChunk) *reinterpret_cast<uint32_t*>(pool.buf + (size_t)chunk * kSpillChunk + at) = w;
     return chunk;
   }
-  __device__ __forceinline__ void put(char c) { if (n < cap) p[n] = c; else chunk = spill(pool, chunk, n - cap, c); ++n; }
+  __device__ __forceinline__ void put(char c) {
+    if (n < cap) p[n] = c;
+    else {
+      const uint32_t at = n - cap;
+      acc |= (uint32_t)(uint8_t)c << (8u * (at & 3u));
+      if ((at & 3u) == 3u) { chunk = spill(pool, chunk, at & ~3u, acc); acc = 0; }
+    }
+    ++n;
+  }
+  // the last, partial word (call once, when the text is complete)
+  __device__ __forceinline__ void flush() { if (n > cap && ((n - cap) & 3u)) { chunk = spill(pool, chunk, (n - cap) & ~3u, acc); acc = 0; } }
   __device__ __forceinline__ void write(const char* s, int len) { for (int i = 0; i < len; ++i) put(s[i]); }
   __device__ __forceinline__ void put_word(uint64_t w, int len) {
     if (n + 8u <= cap) { const uint32_t a = (uint32_t)(uintptr_t)p + n; asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(w) : "memory"); n += (uint32_t)len; }

@@ -836,6 +836,7 @@ __global__ void __launch_bounds__(64) k_site_size(const SiteCtx* __restrict__ sx
   uint32_t* mine = strip + threadIdx.x * kSiteStripWords;
   LdsSpillSink cs((gdb_lds_char*)mine, (uint32_t)kSiteCap, spill);
   site_emit(sx, k, cs, true, &e);
+  cs.flush();
   sx.so.prefix_len[k] = cs.n;
   // longer texts: the tail lies in a chunk of the spill pool (or, when that did not work out, the page pass formats the record again)
   spill_chunk[k] = (cs.n > (uint32_t)kSiteCap && cs.complete()) ? cs.chunk : -1;
@@ -848,15 +849,23 @@ __global__ void __launch_bounds__(64) k_site_size(const SiteCtx* __restrict__ sx
 // per record: lane j assembles the j-th ALIGNED destination word from its own source word and its left neighbour's
 // (v_alignbyte), so the record leaves as one coalesced store; only the two edge words go out bytewise.  Also writes the
 // newline of every record.
-__global__ void __launch_bounds__(256) k_site_copy(const uint32_t* __restrict__ prefix_len, const char* __restrict__ staging, int64_t k_begin, int64_t k_end,
+__global__ void __launch_bounds__(256) k_site_copy(const uint32_t* __restrict__ prefix_len, const char* __restrict__ staging, const char* __restrict__ spill_buf,
+                                                   const int32_t* __restrict__ spill_chunk, int64_t k_begin, int64_t k_end,
                                                    const uint64_t* __restrict__ chunk_off, int nchunks, uint64_t page_base, char* __restrict__ arena) {
   const int64_t k = k_begin + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63u;
   if (k >= k_end) return;
-  const uint32_t n = prefix_len[k];
+  const uint32_t n_all = prefix_len[k];
   char* rec = arena + (chunk_off[k * nchunks] - page_base);
   if (lane == 0) arena[chunk_off[(k + 1) * nchunks] - page_base - 1] = '\n';
-  if (n > (uint32_t)kSiteCap) return;           // k_site_write formats or un-spills these
+  uint32_t n = n_all;
+  if (n_all > (uint32_t)kSiteCap) {             // a longer text: its head is parked like any other, its tail lies in a chunk of the spill pool
+    const int32_t sc = spill_chunk[k];
+    if (sc < 0) return;                         // (no chunk: k_site_write formats the record again)
+    const char* tail = spill_buf + (size_t)sc * kSpillChunk;
+    for (uint32_t i = lane; i < n_all - (uint32_t)kSiteCap; i += 64u) rec[(uint32_t)kSiteCap + i] = tail[i];
+    n = (uint32_t)kSiteCap;
+  }
   const uint32_t a = (uint32_t)((uintptr_t)rec & 3u);
   const uint32_t cur = reinterpret_cast<const uint32_t*>(staging + (size_t)k * kSiteStride)[lane];
   uint32_t prev = (uint32_t)__shfl_up((int)cur, 1);
@@ -883,10 +892,7 @@ __global__ void k_site_write(const SiteCtx* __restrict__ sxp, const char* __rest
   if (n <= (uint32_t)kSiteCap) {
     return;                                     // parked whole in its staging slot: k_site_copy has written it (and the '\n')
   } else if (spill_chunk[k] >= 0) {
-    const char* src = staging + (size_t)k * kSiteStride;
-    for (uint32_t i = 0; i < (uint32_t)kSiteCap; ++i) dst[i] = src[i];
-    const char* tail = spill_buf + (size_t)spill_chunk[k] * kSpillChunk;
-    for (uint32_t i = kSiteCap; i < n; ++i) dst[i] = tail[i - kSiteCap];
+    return;                                     // head parked, tail in the spill pool: k_site_copy has put both in place
   } else {
     ByteSink bs(dst);
     site_emit(sx, k, bs, false, &e);
@@ -1182,7 +1188,13 @@ __global__ void k_slot_cells(const uint32_t* tbase, const uint32_t* nslots, int6
 // for the dearest: pass 0 regroups the 256 slots of a workgroup by type first (counting sort in LDS), which gives each of its four
 // wavefronts one to three types.
 constexpr int kLightBlock = 256;
-template <int PASS, int STRIPW> __global__ void __launch_bounds__(kLightBlock) k_slots_light(SlotTable st, SiteOut so, const int32_t* type_rep, const uint64_t* tmask, const uint32_t* tbase,
+// With the narrow strip the kernel holds 16 wavefronts per CU by LDS (35 KB per workgroup of four) but 133 registers allowed only 12:
+// capped at 128 (amdgpu_waves_per_eu(4), no spills) the c2 sizing phase is 0.4 ms shorter (10.5 -> 10.1 ms, two A/B pairs on one box).
+// The wide strip (67 KB: 8 wavefronts per CU whatever the registers) keeps its registers.
+#ifndef GDBAMD_LIGHT_WAVES
+#define GDBAMD_LIGHT_WAVES 4
+#endif
+template <int PASS, int STRIPW> __global__ void __launch_bounds__(kLightBlock) __attribute__((amdgpu_waves_per_eu(STRIPW <= kStripWords ? GDBAMD_LIGHT_WAVES : 1))) k_slots_light(SlotTable st, SiteOut so, const int32_t* type_rep, const uint64_t* tmask, const uint32_t* tbase,
                                                       const uint32_t* slot_cell, int64_t c_base, int64_t SL, int regroup, uint32_t* err) {
   __shared__ uint32_t strip[kLightBlock * STRIPW];
   __shared__ uint32_t tcount[kMaxTypes + 1], job[kLightBlock];
@@ -5664,7 +5676,8 @@ bool DevicePipeline::begin_page(uint64_t arena_bytes, int arena_idx, PageTicket*
     return true;
   }
   STAGE("k_site_write");
-  hipLaunchKernelGGL(k_site_copy, dim3(blocks_for(np, 4)), dim3(256), 0, st, (const uint32_t*)S.prefix_len.p, (const char*)S.site_staging.p, kp, ke, (const uint64_t*)S.chunk_off.p, iv.nchunks, page_base, arena);
+  hipLaunchKernelGGL(k_site_copy, dim3(blocks_for(np, 4)), dim3(256), 0, st, (const uint32_t*)S.prefix_len.p, (const char*)S.site_staging.p, (const char*)S.spill_buf.p, (const int32_t*)S.spill_chunk.p, kp, ke,
+                     (const uint64_t*)S.chunk_off.p, iv.nchunks, page_base, arena);
   hipLaunchKernelGGL(k_site_write, dim3(blocks_for(np, 64)), dim3(64), 0, st, S.d_sx.p, (const char*)S.site_staging.p, (const char*)S.spill_buf.p, (const int32_t*)S.spill_chunk.p, kp, ke, S.chunk_off.p, iv.nchunks, page_base, arena, S.err.p);
   STAGE("k_assemble_write");
   {
