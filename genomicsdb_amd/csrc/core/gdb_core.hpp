@@ -133,42 +133,36 @@ struct LdsCapSink {  // counts every byte, stores the first `cap` of them in LDS
   __device__ __forceinline__ uint32_t pos() const { return n; }
   __device__ __forceinline__ void patch_u32(uint32_t at, uint32_t v) { for (int i = 0; i < 4; ++i) if (at + i < cap) p[at + i] = (char)((v >> (8 * i)) & 0xFFu); }
 };
-// The same with a second tier for the few long texts (records with very many ALT alleles): what does not fit the LDS strip goes
-// to one fixed-size chunk of a global pool, taken with an atomic when the first byte overflows.  n counts every byte; the text
-// is complete when n <= cap + kSpillChunk and a chunk was available (chunk >= 0).
-constexpr uint32_t kSpillChunk = 2048;
-struct SpillPool { char* buf; unsigned int* next; uint32_t nchunks; };
+// The same with a second tier for the longer texts (fixed columns with long allele lists or many INFO values): what does not fit the
+// LDS strip goes to the RECORD'S OWN tail slot in global memory (kSpillTail bytes per record, written a word at a time: no pool, no
+// atomic - a pool of chunks handed out by one counter made the site pass 3 x slower as soon as a third of the records spilled:
+// ~10^5 atomics on one address, and the records behind the pool's end formatted a second time).  n counts every byte; the text is
+// complete when n <= cap + kSpillTail.
+constexpr uint32_t kSpillTail = 512;
+struct SpillPool { char* buf; };                     // [records][kSpillTail]
 struct LdsSpillSink {
   gdb_lds_char* p;
   uint32_t n, cap;
-  int32_t chunk;          // -1: none taken yet, -2: the pool is exhausted
-  uint32_t acc;           // the spilled bytes of the word under way: the pool is written a word at a time (a byte store per spilled
-                          // character, behind a call, made the site pass 3 x slower as soon as a few records in a hundred spilled)
-  SpillPool pool;
-  __device__ __forceinline__ LdsSpillSink(gdb_lds_char* q, uint32_t c, const SpillPool& sp) : p(q), n(0), cap(c), chunk(-1), acc(0), pool(sp) {}
-  // (by value and out of line: the sink itself stays in registers, the rare path costs one call per four bytes)
-  __device__ __noinline__ static int32_t spill(SpillPool pool, int32_t chunk, uint32_t at, uint32_t w) {   // at: byte offset of the word in the chunk
-    if (chunk == -1) { const unsigned int i = atomicAdd(pool.next, 1u); chunk = i < pool.nchunks ? (int32_t)i : -2; }
-    if (chunk >= 0 && at < kSpillChunk) *reinterpret_cast<uint32_t*>(pool.buf + (size_t)chunk * kSpillChunk + at) = w;
-    return chunk;
-  }
+  uint32_t acc;           // the spilled bytes of the word under way
+  char* tail;             // the record's tail slot
+  __device__ __forceinline__ LdsSpillSink(gdb_lds_char* q, uint32_t c, const SpillPool& sp, int64_t record) : p(q), n(0), cap(c), acc(0), tail(sp.buf + (size_t)record * kSpillTail) {}
   __device__ __forceinline__ void put(char c) {
     if (n < cap) p[n] = c;
     else {
       const uint32_t at = n - cap;
       acc |= (uint32_t)(uint8_t)c << (8u * (at & 3u));
-      if ((at & 3u) == 3u) { chunk = spill(pool, chunk, at & ~3u, acc); acc = 0; }
+      if ((at & 3u) == 3u) { if (at < kSpillTail) *reinterpret_cast<uint32_t*>(tail + (at & ~3u)) = acc; acc = 0; }
     }
     ++n;
   }
   // the last, partial word (call once, when the text is complete)
-  __device__ __forceinline__ void flush() { if (n > cap && ((n - cap) & 3u)) { chunk = spill(pool, chunk, (n - cap) & ~3u, acc); acc = 0; } }
+  __device__ __forceinline__ void flush() { if (n > cap && ((n - cap) & 3u) && n - cap < kSpillTail) { *reinterpret_cast<uint32_t*>(tail + ((n - cap) & ~3u)) = acc; acc = 0; } }
   __device__ __forceinline__ void write(const char* s, int len) { for (int i = 0; i < len; ++i) put(s[i]); }
   __device__ __forceinline__ void put_word(uint64_t w, int len) {
     if (n + 8u <= cap) { const uint32_t a = (uint32_t)(uintptr_t)p + n; asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(w) : "memory"); n += (uint32_t)len; }
     else for (int i = 0; i < len; ++i) { put((char)(w & 0xFFu)); w >>= 8; }
   }
-  __device__ __forceinline__ bool complete() const { return n <= cap || (chunk >= 0 && n - cap <= kSpillChunk); }
+  __device__ __forceinline__ bool complete() const { return n <= cap + kSpillTail; }
   __device__ __forceinline__ uint32_t pos() const { return n; }
   __device__ __forceinline__ void patch_u32(uint32_t at, uint32_t v) { for (int i = 0; i < 4; ++i) if (at + i < cap) p[at + i] = (char)((v >> (8 * i)) & 0xFFu); }   // (only ever the record header)
 };

@@ -807,16 +807,18 @@ __global__ void __launch_bounds__(kHugeBlock) k_site_huge(const SiteCtx* __restr
 // through a capped LDS sink into a lane-private strip and parked in a fixed-stride staging slot.  The page pass then only
 // copies the parked text (records whose fixed columns exceed the slot - long allele lists - are formatted again).
 constexpr int kSiteStride = 256;                   // distance of two records' staging slots
-// bytes of the fixed columns that are parked (the rest goes to the spill pool): this is also the lane's LDS strip, and the site pass is
-// a latency-bound kernel of one wavefront per workgroup.  192 instead of 256 bytes per lane make it 12 instead of 9 wavefronts per CU
-// and the c2 site phase 2.48 instead of 2.76 ms - but the spill path (byte-wise, one thread per record) is a cliff: with 160 bytes the
-// same phase takes 9.1 ms, and c2's fixed columns (~170 bytes at variant sites) are not far below 192.  256 keeps the distance.
+// bytes of the fixed columns that are parked in the lane's LDS strip (the rest goes to the record's tail slot in global memory, word by
+// word: LdsSpillSink).  The site pass is a latency-bound kernel of one wavefront per workgroup, and the strip is what bounds its
+// residency: 256 bytes per lane = 9 wavefronts per CU, 192 = 12 (the register limit at 149), 128 and the registers capped at 128
+// (amdgpu_waves_per_eu(4)) = 16.  c2, site phase, A/B inside one call: 2.79 (256) / 2.48 (192) / 2.53 (128) / 2.37 ms (128, capped).  Until
+// round 4 anything below ~190 bytes was a cliff (160 bytes: 9.1 ms) - c2's fixed columns are ~170 bytes at variant sites, and the tails
+// went byte by byte through a pool of 32 768 chunks handed out by one atomic counter (exhausted after a tenth of the spilling records,
+// the rest formatted a second time by the page pass).  With a tail slot per record there is no counter and no second formatting.
 #ifndef GDBAMD_SITE_CAP
-#define GDBAMD_SITE_CAP 256
+#define GDBAMD_SITE_CAP 128
 #endif
 constexpr int kSiteCap = GDBAMD_SITE_CAP;
 constexpr int kSiteStripWords = kSiteCap / 4 + 1;
-constexpr int kSpillChunks = 32768;                 // spill pool: 64 MB of 2 KB chunks for the tails of longer fixed columns
 // The lanes of a wavefront wait for the record with the most variant calls among their 64: records are dealt out in the order of
 // their call counts (`order`, a radix sort over 8-bit keys), so that a wavefront's records cost about the same.
 __global__ void k_site_order_keys(const int64_t* __restrict__ hbase, int64_t P, uint32_t* __restrict__ key, int32_t* __restrict__ val) {
@@ -826,7 +828,10 @@ __global__ void k_site_order_keys(const int64_t* __restrict__ hbase, int64_t P, 
   key[k] = (uint32_t)(n > 255 ? 255 : n);
   val[k] = (int32_t)k;
 }
-__global__ void __launch_bounds__(64) k_site_size(const SiteCtx* __restrict__ sxp, const int32_t* __restrict__ order, char* __restrict__ staging, SpillPool spill, int32_t* __restrict__ spill_chunk, uint32_t* err) {
+#ifndef GDBAMD_SITE_ATTR
+#define GDBAMD_SITE_ATTR __attribute__((amdgpu_waves_per_eu(4)))
+#endif
+__global__ void __launch_bounds__(64) GDBAMD_SITE_ATTR k_site_size(const SiteCtx* __restrict__ sxp, const int32_t* __restrict__ order, char* __restrict__ staging, SpillPool spill, int32_t* __restrict__ spill_chunk, uint32_t* err) {
   const SiteCtx& sx = *sxp;
   __shared__ uint32_t strip[64 * kSiteStripWords];
   int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -834,12 +839,12 @@ __global__ void __launch_bounds__(64) k_site_size(const SiteCtx* __restrict__ sx
   if (order) k = order[k];
   uint32_t e = 0;
   uint32_t* mine = strip + threadIdx.x * kSiteStripWords;
-  LdsSpillSink cs((gdb_lds_char*)mine, (uint32_t)kSiteCap, spill);
+  LdsSpillSink cs((gdb_lds_char*)mine, (uint32_t)kSiteCap, spill, k);
   site_emit(sx, k, cs, true, &e);
   cs.flush();
   sx.so.prefix_len[k] = cs.n;
   // longer texts: the tail lies in a chunk of the spill pool (or, when that did not work out, the page pass formats the record again)
-  spill_chunk[k] = (cs.n > (uint32_t)kSiteCap && cs.complete()) ? cs.chunk : -1;
+  spill_chunk[k] = (cs.n > (uint32_t)kSiteCap && cs.complete()) ? 0 : -1;    // >= 0: the tail lies in the record's tail slot
   const uint32_t nstaged = min(cs.n, (uint32_t)kSiteCap);
   uint4* dst = reinterpret_cast<uint4*>(staging + (size_t)k * kSiteStride);
   for (uint32_t q = 0; (q << 4) < nstaged; ++q) dst[q] = make_uint4(mine[4 * q], mine[4 * q + 1], mine[4 * q + 2], mine[4 * q + 3]);
@@ -862,7 +867,7 @@ __global__ void __launch_bounds__(256) k_site_copy(const uint32_t* __restrict__ 
   if (n_all > (uint32_t)kSiteCap) {             // a longer text: its head is parked like any other, its tail lies in a chunk of the spill pool
     const int32_t sc = spill_chunk[k];
     if (sc < 0) return;                         // (no chunk: k_site_write formats the record again)
-    const char* tail = spill_buf + (size_t)sc * kSpillChunk;
+    const char* tail = spill_buf + (size_t)k * kSpillTail;
     for (uint32_t i = lane; i < n_all - (uint32_t)kSiteCap; i += 64u) rec[(uint32_t)kSiteCap + i] = tail[i];
     n = (uint32_t)kSiteCap;
   }
@@ -2798,7 +2803,7 @@ __global__ void k_bcf_shared(const SiteCtx* __restrict__ sxp, const char* __rest
   } else if (spill_chunk[k] >= 0) {
     const char* src = staging + (size_t)k * kSiteStride;
     for (uint32_t i = 0; i < (uint32_t)kSiteCap; ++i) dst[i] = src[i];
-    const char* tail = spill_buf + (size_t)spill_chunk[k] * kSpillChunk;
+    const char* tail = spill_buf + (size_t)k * kSpillTail;
     for (uint32_t i = kSiteCap; i < n; ++i) dst[i] = tail[i - kSiteCap];
   } else {
     ByteSink bs(dst);
@@ -3608,7 +3613,7 @@ struct DevicePipeline::Impl {
   DevBuf<int32_t> diff, first_record_at; DevBuf<uint64_t> diff_packed; DevBuf<int64_t> heavy_count, hoff;
   DevBuf<uint64_t> inc_keys, inc_keys_sorted; DevBuf<int64_t> inc_vals, inc_vals_sorted, hbase;
   DevBuf<uint32_t> lut_len, i2m_off; DevBuf<int8_t> i2m, gt_override; DevBuf<uint8_t> iflags;
-  DevBuf<uint8_t> num_alleles, rflags; DevBuf<uint32_t> fmt_mask, prefix_len; DevBuf<char> site_staging, spill_buf; DevBuf<int32_t> spill_chunk; DevBuf<unsigned int> spill_next;
+  DevBuf<uint8_t> num_alleles, rflags; DevBuf<uint32_t> fmt_mask, prefix_len; DevBuf<char> site_staging, spill_buf; DevBuf<int32_t> spill_chunk;
   DevBuf<uint64_t> chunk_size, chunk_off, rec_off; DevBuf<unsigned long long> max_record;
   std::unique_ptr<BgzfDeviceCompressor> bgzf;   // output formats "z" / "b"
   // "z" / "b": the compression of a page is queued right behind the kernels that assemble it (finish_page only collects the size),
@@ -5360,8 +5365,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   HIP_CHECK(hipMemcpyAsync(S.d_sx.p, &sx, sizeof(SiteCtx), hipMemcpyHostToDevice, st));   // (sx outlives the copy: the function synchronises before it returns)
   STAGE("k_site_size");
   S.site_staging.ensure((size_t)P * kSiteStride + 64);
-  S.spill_buf.ensure((size_t)kSpillChunks * kSpillChunk); S.spill_chunk.ensure((size_t)P); S.spill_next.ensure(1);
-  HIP_CHECK(hipMemsetAsync(S.spill_next.p, 0, sizeof(unsigned int), st));
+  S.spill_buf.ensure((size_t)P * kSpillTail); S.spill_chunk.ensure((size_t)P);
   const int32_t* site_order = nullptr;
   {
     static const bool sorted_sites = !(getenv("GDBAMD_SITE_ORDER") && atoi(getenv("GDBAMD_SITE_ORDER")) == 0);
@@ -5372,7 +5376,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
       site_order = S.site_ord.p;
     }
   }
-  hipLaunchKernelGGL(k_site_size, dim3(blocks_for(P, 64)), dim3(64), 0, st, S.d_sx.p, site_order, S.site_staging.p, SpillPool{S.spill_buf.p, S.spill_next.p, (uint32_t)kSpillChunks}, S.spill_chunk.p, S.err.p);
+  hipLaunchKernelGGL(k_site_size, dim3(blocks_for(P, 64)), dim3(64), 0, st, S.d_sx.p, site_order, S.site_staging.p, SpillPool{S.spill_buf.p}, S.spill_chunk.p, S.err.p);
   S.remap_total.ensure(1);
   HIP_CHECK(hipMemsetAsync(S.remap_total.p, 0, sizeof(unsigned long long), st));
   for (int i = 0; i < pl.n_format; ++i)
