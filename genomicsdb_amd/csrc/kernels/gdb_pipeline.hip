@@ -105,7 +105,8 @@ inline bool debug_sync() { static int v = -1; if (v < 0) { const char* e = geten
 // Records one wavefront takes in a row.  Measured on c2 (200 kb windows): the sizing pass, which starts every run with a
 // binary search per sample, is fastest at 64; the page pass (no per-run set-up beyond one 64-lane scalar fetch) at 32 -
 // more, shorter runs balance better across the 256 CUs than longer ones amortise.  GDBAMD_RUN / GDBAMD_RUN_W override.
-inline int size_run_length() { const char* e = getenv("GDBAMD_RUN"); return e && *e ? std::max(1, atoi(e)) : 64; }
+inline int size3_rounds();
+inline int size_run_length() { const char* e = getenv("GDBAMD_RUN"); return e && *e ? std::max(1, atoi(e)) : size3_rounds() ? 128 : 64; }   // (the piece-wise kernel: 128 measured 0.3 ms faster than 64, 256 slower)
 inline int write_run_length() { const char* e = getenv("GDBAMD_RUN_W"); return e && *e ? std::max(1, atoi(e)) : 32; }
 // record types that get text-table slots (GDBAMD_MAX_TYPES < 64 forces the direct path in tests)
 inline int max_tabled_types() {
