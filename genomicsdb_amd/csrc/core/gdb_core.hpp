@@ -232,7 +232,8 @@ template <class Sink> GDB_HD void put_u32(Sink& s, uint32_t v) {
   if (v >= 100000000u) {   // 9 or 10 digits: leading one or two, then exactly eight
     const uint32_t hi = v / 100000000u;
     v -= hi * 100000000u;
-    put_packed(s, gdb_pack_digits(hi, n), n);
+    const uint64_t wh = gdb_pack_digits(hi, n);   // (its own statement: the order in which call arguments are evaluated is unspecified)
+    put_packed(s, wh, n);
     uint64_t w = gdb_pack_digits(v, n);
     for (; n < 8; ++n) w = (w << 8) | (uint64_t)'0';
     put_packed(s, w, 8);
@@ -706,6 +707,105 @@ GDB_HD void gdb_uset_insert_range(GdbUSetOrder& s, const int32_t* p, int count) 
   }
 }
 
+// ---- ID union of a Release build: the iteration order of libstdc++'s std::unordered_set<std::string> -----------------------------
+// merge_ID_field keeps the ';'-separated tokens of the live calls in a std::set only #ifdef DEBUG (the build the goldens come
+// from); every other build - the one GATK ships - uses a std::unordered_set<std::string> and writes the tokens in ITS iteration
+// order (broad_combined_gvcf.cc:730-763).  Restated for libstdc++ on a 64-bit target: std::hash<std::string> = _Hash_bytes
+// (libsupc++ hash_bytes.cc: the 64-bit Murmur-style mix, seed 0xc70f6907), bucket = hash % bucket_count, list / rehash rules as
+// for the FILTER ids above (single inserts: 13 buckets for the first 13 tokens, 29 from the 14th).  Checked token-sequence-for-
+// token-sequence against the library on the host (tests/hostsim: hostsim_id_union_order, tests/test_id_union_order.py).
+GDB_HD uint64_t gdb_libstdcxx_hash_bytes(const char* p, int len) {
+  const uint64_t mul = (((uint64_t)0xc6a4a793UL) << 32) + (uint64_t)0x5bd1e995UL;
+  const int full = len & ~7;
+  uint64_t hash = (uint64_t)0xc70f6907UL ^ ((uint64_t)len * mul);
+  for (int i = 0; i < full; i += 8) {
+    uint64_t w = 0;
+    for (int b = 7; b >= 0; --b) w = (w << 8) | (uint64_t)(unsigned char)p[i + b];     // little-endian unaligned load
+    w *= mul; w ^= w >> 47; w *= mul;
+    hash ^= w; hash *= mul;
+  }
+  if (len & 7) {
+    uint64_t w = 0;
+    for (int b = (len & 7) - 1; b >= 0; --b) w = (w << 8) + (uint64_t)(unsigned char)p[full + b];
+    hash ^= w; hash *= mul;
+  }
+  hash ^= hash >> 47; hash *= mul; hash ^= hash >> 47;
+  return hash;
+}
+struct GdbUSetHashOrder {
+  uint64_t hash[GDB_MAX_ID_TOKENS];  // list order = iteration order
+  int32_t tok[GDB_MAX_ID_TOKENS];    // the caller's token number of each list element
+  int32_t n, nbkt;
+  uint64_t next_resize;
+};
+GDB_HD void gdb_useth_init(GdbUSetHashOrder& s) { s.n = 0; s.nbkt = 1; s.next_resize = 0; }
+GDB_HD void gdb_useth_place(GdbUSetHashOrder& s, int n, uint64_t h, int32_t tok, uint64_t nbkt) {   // n elements in the list
+  const uint64_t b = h % nbkt;
+  int at = 0;
+  for (int i = 0; i < n; ++i) if (s.hash[i] % nbkt == b) { at = i; break; }
+  for (int j = n; j > at; --j) { s.hash[j] = s.hash[j - 1]; s.tok[j] = s.tok[j - 1]; }
+  s.hash[at] = h; s.tok[at] = tok;
+}
+GDB_HD void gdb_useth_insert_new(GdbUSetHashOrder& s, uint64_t h, int32_t tok) {   // a key that is not in the set; s.n < GDB_MAX_ID_TOKENS
+  if ((uint64_t)s.n + 1 > s.next_resize) {        // _Prime_rehash_policy::_M_need_rehash(n_bkt, n_elt, 1)
+    const uint64_t want = (uint64_t)s.n + 1;
+    const uint64_t min_bkts = s.next_resize ? want : (want > 11 ? want : 11);
+    if (min_bkts >= (uint64_t)s.nbkt) {
+      GdbUSetOrder pol;                            // (only its bucket-count policy is used)
+      pol.next_resize = s.next_resize; pol.overflow = false;
+      const uint64_t nb = gdb_uset_next_bkt(pol, (min_bkts + 1 > (uint64_t)s.nbkt * 2) ? min_bkts + 1 : (uint64_t)s.nbkt * 2);
+      s.next_resize = pol.next_resize;
+      uint64_t oh[GDB_MAX_ID_TOKENS]; int32_t ot[GDB_MAX_ID_TOKENS];
+      for (int j = 0; j < s.n; ++j) { oh[j] = s.hash[j]; ot[j] = s.tok[j]; }
+      for (int j = 0; j < s.n; ++j) gdb_useth_place(s, j, oh[j], ot[j], nb);
+      s.nbkt = (int32_t)nb;
+    } else s.next_resize = (uint64_t)s.nbkt;
+  }
+  gdb_useth_place(s, s.n, h, tok, (uint64_t)s.nbkt);
+  ++s.n;
+}
+// Order of the ID tokens of one record.  release_order == 0: sorted (std::set<std::string>, the DEBUG build);
+// != 0: libstdc++'s unordered_set.  tp / tn: the distinct tokens, written in the order they are to be printed.
+GDB_HD void gdb_id_union_add(const char* p, int len, const char** tp, int* tn, int& nt, GdbUSetHashOrder& us, int release_order, uint32_t* err) {
+  if (release_order) {
+    for (int i = 0; i < nt; ++i) {                // (find: a token that is already in the set changes nothing)
+      if (tn[i] != len) continue;
+      bool same = true;
+      for (int j = 0; j < len && same; ++j) same = tp[i][j] == p[j];
+      if (same) return;
+    }
+    if (nt >= GDB_MAX_ID_TOKENS) { *err |= GDB_ERR_TOO_MANY_ID_TOKENS; return; }
+    tp[nt] = p; tn[nt] = len;
+    gdb_useth_insert_new(us, gdb_libstdcxx_hash_bytes(p, len), nt);
+    ++nt;
+    return;
+  }
+  int pos = 0, cmp = 1;                           // insertion point in the sorted token list
+  for (; pos < nt; ++pos) {
+    const int m = len < tn[pos] ? len : tn[pos];
+    cmp = 0;
+    for (int j = 0; j < m && cmp == 0; ++j) cmp = (int)(unsigned char)p[j] - (int)(unsigned char)tp[pos][j];
+    if (cmp == 0) cmp = len - tn[pos];
+    if (cmp <= 0) break;
+  }
+  if (pos == nt || cmp != 0) {
+    if (nt >= GDB_MAX_ID_TOKENS) { *err |= GDB_ERR_TOO_MANY_ID_TOKENS; }
+    else { for (int j = nt; j > pos; --j) { tp[j] = tp[j - 1]; tn[j] = tn[j - 1]; } tp[pos] = p; tn[pos] = len; ++nt; }
+  }
+}
+// the tokens of one ID value (merge_ID_field's loop: a token in front of every ';', and what is left behind the last one)
+GDB_HD void gdb_id_union_value(const char* p, int n, const char** tp, int* tn, int& nt, GdbUSetHashOrder& us, int release_order, uint32_t* err) {
+  int last = 0;
+  for (int i = 0; i <= n; ++i) {
+    if (i < n && p[i] != ';') continue;
+    const int len = i - last;
+    if (i == n && len == 0) break;                // nothing behind a trailing ';'
+    gdb_id_union_add(p + last, len, tp, tn, nt, us, release_order, err);
+    last = i + 1;
+  }
+}
+GDB_HD int gdb_id_union_at(const GdbUSetHashOrder& us, int release_order, int i) { return release_order ? us.tok[i] : i; }
+
 // scratch of the (rare) tied-zero medians: reduce_scalar takes n_valid floats per use; capacity = passes x float median
 // fields x heavy incidences, so it cannot run out
 struct TieScratch {
@@ -822,7 +922,13 @@ template <class T> GDB_HD bool reduce_scalar(const SiteCtx& cx, int64_t k, int f
   }
   if (!nvalid) return false;
   if (op == GDB_OP_SUM) { result = sum; return true; }
-  if (op == GDB_OP_MEAN) { result = sum / (T)nvalid; return true; }
+  if (op == GDB_OP_MEAN) {
+    // get_valid_mean divides the sum by an `unsigned` count (variant_field_handler.cc:596-607): for an int field the usual
+    // arithmetic conversions make the SUM unsigned too, so a negative sum is divided as 2^32 + sum ((-6) / 3 prints 1431655763)
+    if (is_float) result = sum / (T)nvalid;
+    else result = (T)(int32_t)((uint32_t)(int32_t)sum / (uint32_t)nvalid);
+    return true;
+  }
   if (is_float && nneg0 && npos0 && nbelow <= nvalid / 2 && nvalid / 2 < nbelow + nneg0 + npos0) {
     // the median is a zero and both signs are present: which one the reference prints is decided by its nth_element
     const uint64_t at = cx.tie.buf ? GDB_FETCH_ADD_U64(cx.tie.used, (uint64_t)nvalid) : 0;
@@ -1332,39 +1438,23 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
     const uint32_t at_counts = sink.pos();
     bcf_put_u32(sink, (uint32_t)num_merged << 16);          // n_info patched below
     bcf_put_u32(sink, ((uint32_t)n_fmt << 24) | ((uint32_t)pl.bcf_n_sample & 0xFFFFFFu));
-    // ID (same sorted token union as the text flavour)
+    // ID (the same token union as the text flavour)
     {
       const char* tp[GDB_MAX_ID_TOKENS]; int tn[GDB_MAX_ID_TOKENS]; int nt = 0;
+      GdbUSetHashOrder us;
+      gdb_useth_init(us);
       if (pl.f_ID >= 0 && !(hsite && !hsite->any_id))
         for (int64_t t = hb; t < he; ++t) {
           const int64_t c = cx.hl.cell[t];
           if (!field_valid(cx.cm, c, pl.f_ID)) continue;
           int n;
           const char* p = cell_field<char>(cx.fr, pl, pl.f_ID, c, n);
-          int last = 0;
-          for (int i = 0; i <= n; ++i) {
-            if (i < n && p[i] != ';') continue;
-            const int len = i - last;
-            if (i == n && len == 0) break;
-            int pos = 0, cmp = 1;
-            for (; pos < nt; ++pos) {
-              const int m = len < tn[pos] ? len : tn[pos];
-              cmp = 0;
-              for (int j = 0; j < m && cmp == 0; ++j) cmp = (int)(unsigned char)p[last + j] - (int)(unsigned char)tp[pos][j];
-              if (cmp == 0) cmp = len - tn[pos];
-              if (cmp <= 0) break;
-            }
-            if (pos == nt || cmp != 0) {
-              if (nt >= GDB_MAX_ID_TOKENS) { *err |= GDB_ERR_TOO_MANY_ID_TOKENS; }
-              else { for (int j = nt; j > pos; --j) { tp[j] = tp[j - 1]; tn[j] = tn[j - 1]; } tp[pos] = p + last; tn[pos] = len; ++nt; }
-            }
-            last = i + 1;
-          }
+          gdb_id_union_value(p, n, tp, tn, nt, us, pl.id_order_unordered_set, err);
         }
       int total = nt ? nt - 1 : 0;
       for (int i = 0; i < nt; ++i) total += tn[i];
       bcf_enc_size(sink, total, GDB_BT_CHAR);
-      for (int i = 0; i < nt; ++i) { if (i) sink.put(';'); sink.write(tp[i], tn[i]); }
+      for (int i = 0; i < nt; ++i) { const int w = gdb_id_union_at(us, pl.id_order_unordered_set, i); if (i) sink.put(';'); sink.write(tp[w], tn[w]); }
     }
     // alleles
     bcf_enc_size(sink, mref_len, GDB_BT_CHAR);
@@ -1448,38 +1538,24 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
   sink.put('\t');
   put_i64(sink, s_k - ctg.offset + 1);
   sink.put('\t');
-  // ID: union of the ';'-separated tokens of the live calls, in sorted order (merge_ID_field, broad_combined_gvcf.cc:730-763;
-  // the reference's DEBUG build - the one the goldens come from - keeps them in a std::set)
+  // ID: union of the ';'-separated tokens of the live calls (merge_ID_field, broad_combined_gvcf.cc:730-763): sorted in the
+  // reference's DEBUG build - the one the goldens come from - and in the order of a std::unordered_set<std::string> in every other
+  // build (pl.id_order_unordered_set; gdb_id_union_add).  An empty union string (no token, or only the empty token of an ID value
+  // ";") leaves the record's ID alone: '.' (:801-802)
   {
     const char* tp[GDB_MAX_ID_TOKENS]; int tn[GDB_MAX_ID_TOKENS]; int nt = 0;
+    GdbUSetHashOrder us;
+    gdb_useth_init(us);
     if (pl.f_ID >= 0 && !(hsite && !hsite->any_id))
       for (int64_t t = hb; t < he; ++t) {
         const int64_t c = cx.hl.cell[t];
         if (!field_valid(cx.cm, c, pl.f_ID)) continue;
         int n;
         const char* p = cell_field<char>(cx.fr, pl, pl.f_ID, c, n);
-        int last = 0;
-        for (int i = 0; i <= n; ++i) {
-          if (i < n && p[i] != ';') continue;
-          const int len = i - last;
-          if (i == n && len == 0) break;                    // nothing behind a trailing ';'
-          int pos = 0, cmp = 1;                             // insertion point in the sorted token list
-          for (; pos < nt; ++pos) {
-            const int m = len < tn[pos] ? len : tn[pos];
-            cmp = 0;
-            for (int j = 0; j < m && cmp == 0; ++j) cmp = (int)(unsigned char)p[last + j] - (int)(unsigned char)tp[pos][j];
-            if (cmp == 0) cmp = len - tn[pos];
-            if (cmp <= 0) break;
-          }
-          if (pos == nt || cmp != 0) {
-            if (nt >= GDB_MAX_ID_TOKENS) { *err |= GDB_ERR_TOO_MANY_ID_TOKENS; }
-            else { for (int j = nt; j > pos; --j) { tp[j] = tp[j - 1]; tn[j] = tn[j - 1]; } tp[pos] = p + last; tn[pos] = len; ++nt; }
-          }
-          last = i + 1;
-        }
+        gdb_id_union_value(p, n, tp, tn, nt, us, pl.id_order_unordered_set, err);
       }
-    if (nt == 0) sink.put('.');
-    for (int i = 0; i < nt; ++i) { if (i) sink.put(';'); sink.write(tp[i], tn[i]); }
+    if (nt == 0 || (nt == 1 && tn[0] == 0)) sink.put('.');
+    for (int i = 0; i < nt; ++i) { const int w = gdb_id_union_at(us, pl.id_order_unordered_set, i); if (i) sink.put(';'); sink.write(tp[w], tn[w]); }
   }
   sink.put('\t');
   sink.write(mref, mref_len);

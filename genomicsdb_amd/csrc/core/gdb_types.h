@@ -113,6 +113,7 @@ struct CombinePlan {
   // flags
   int32_t produce_GT_field, produce_FILTER_field, sites_only_query, min_PL_GT_for_spanning_deletions;
   int32_t max_diploid_alt_alleles;
+  int32_t id_order_unordered_set;   // ID union in the order of a Release build of the reference (std::unordered_set<std::string>) instead of sorted
   int32_t qual_combine_op;  // GDB_OP_UNKNOWN unless the vid configures one
   int32_t num_query_rows;   // N: sample columns of the output
   // BCF2 ("bu") output: typed binary records instead of text (vcf_adapter.cc:475-509); ids of the header dictionary

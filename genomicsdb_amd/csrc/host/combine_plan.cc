@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <array>
 #include <map>
+#include <unordered_map>
 #include <cstring>
 #include <set>
 
@@ -147,7 +148,11 @@ HostPlan build_combine_plan(const VariantQueryConfig& qc, const std::string& tmp
   const bool sites_only = qc.sites_only_query();
   int dp_info_plan_field = -1;
   std::vector<int> fmt_list;
-  std::map<int, std::array<int, 2>> histogram_pairs;   // composite vid field idx -> plan fields of (bins, counts)
+  // composite vid field idx -> plan fields of (bins, counts).  The reference keeps these pairs in a std::unordered_map<unsigned, ...>
+  // filled in query order (broad_combined_gvcf.h:123, .cc:213-219) and emits the histogram_sum fields in that map's ITERATION order
+  // (.cc:559): the order of two or more such fields is the C++ library's (libstdc++: a key whose bucket is empty goes to the head of
+  // the list, so with few fields the one queried last comes out first).  Same container, same inserts, same order.
+  std::unordered_map<unsigned, std::array<int, 2>> histogram_pairs;
   for (unsigned q = 0; q < qc.get_num_queried_attributes(); ++q) {
     int f = q2f[q];
     if (f < 0) continue;
@@ -167,8 +172,7 @@ HostPlan build_combine_plan(const VariantQueryConfig& qc, const std::string& tmp
       if (fi->m_element_type != GDB_ET_INT && fi->m_element_type != GDB_ET_FLOAT)
         throw BroadCombinedGVCFException("Operation histogram_sum is only supported for tuple elements that are int or float; field " + parent.m_name);
       if (fi->m_num_dimensions != 2) throw UnsupportedOnDeviceException("histogram_sum over a field that is not 2-dimensional: " + parent.m_name);
-      auto it = histogram_pairs.find(fi->m_parent_composite_field_idx);
-      if (it == histogram_pairs.end()) it = histogram_pairs.insert(std::make_pair(fi->m_parent_composite_field_idx, std::array<int, 2>{{-1, -1}})).first;
+      auto it = histogram_pairs.insert(std::make_pair((unsigned)fi->m_parent_composite_field_idx, std::array<int, 2>{{-1, -1}})).first;
       it->second[fi->m_element_index_in_tuple == 0u ? 0 : 1] = f;
       continue;
     }
@@ -200,7 +204,7 @@ HostPlan build_combine_plan(const VariantQueryConfig& qc, const std::string& tmp
   for (auto& kv : histogram_pairs) {
     if (pl.n_histogram >= GDB_MAX_HISTOGRAM_FIELDS) throw UnsupportedOnDeviceException("too many histogram_sum fields");
     if (kv.second[0] < 0 || kv.second[1] < 0)
-      throw BroadCombinedGVCFException("histogram_sum needs both tuple elements of field " + vid.get_field_info((unsigned)kv.first).m_name + " among the queried attributes");
+      throw BroadCombinedGVCFException("histogram_sum needs both tuple elements of field " + vid.get_field_info(kv.first).m_name + " among the queried attributes");
     pl.histogram_bin_field[pl.n_histogram] = kv.second[0];
     pl.histogram_count_field[pl.n_histogram] = kv.second[1];
     ++pl.n_histogram;
@@ -234,6 +238,7 @@ HostPlan build_combine_plan(const VariantQueryConfig& qc, const std::string& tmp
   pl.sites_only_query = sites_only;
   pl.min_PL_GT_for_spanning_deletions = qc.produce_GT_with_min_PL_value_for_spanning_deletions();
   pl.max_diploid_alt_alleles = (int)qc.get_max_diploid_alt_alleles_that_can_be_genotyped();
+  pl.id_order_unordered_set = qc.id_union_order_unordered_set() ? 1 : 0;
   pl.num_query_rows = (int)qc.get_num_rows_to_query();
   // ---- contigs ---------------------------------------------------------------------------------------
   for (unsigned i = 0; i < vid.get_num_contigs(); ++i) {

@@ -229,6 +229,14 @@ void VariantQueryConfig::read_from_json(const mini_json::Value& j, int rank, con
   if (j.HasMember("reference_genome")) m_reference_genome = join_path(base_dir, pick_rank(j["reference_genome"], rank).GetString());
   if (j.HasMember("max_diploid_alt_alleles_that_can_be_genotyped")) m_max_diploid_alt_alleles_that_can_be_genotyped = (unsigned)j["max_diploid_alt_alleles_that_can_be_genotyped"].GetInt64();
   if (j.HasMember("combined_vcf_records_buffer_size_limit")) set_combined_vcf_records_buffer_size_limit((size_t)j["combined_vcf_records_buffer_size_limit"].GetInt64());
+  {
+    std::string order;
+    if (j.HasMember("id_union_order")) order = j["id_union_order"].GetString();
+    else if (const char* e = getenv("GDBAMD_ID_UNION_ORDER")) order = e;
+    if (!order.empty() && order != "sorted" && order != "unordered_set")
+      throw GenomicsDBConfigException("id_union_order must be \"sorted\" or \"unordered_set\", not \"" + order + "\"");
+    m_id_union_order_unordered_set = order == "unordered_set";
+  }
   auto flag = [&](const char* k) { return j.HasMember(k) && j[k].GetBool(); };
   m_produce_GT_field = flag("produce_GT_field");
   m_produce_FILTER_field = flag("produce_FILTER_field");

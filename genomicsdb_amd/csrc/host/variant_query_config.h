@@ -77,6 +77,11 @@ class VariantQueryConfig {
   bool index_output_VCF() const { return m_index_output_VCF; }
   bool produce_GT_with_min_PL_value_for_spanning_deletions() const { return m_produce_GT_with_min_PL_value_for_spanning_deletions; }
   unsigned get_max_diploid_alt_alleles_that_can_be_genotyped() const { return m_max_diploid_alt_alleles_that_can_be_genotyped; }
+  // ID union order: false = sorted (the reference's DEBUG build, the goldens), true = std::unordered_set<std::string> (any other
+  // build of the reference, broad_combined_gvcf.cc:732-737).  Query JSON "id_union_order": "sorted" | "unordered_set"; without the
+  // key the environment variable GDBAMD_ID_UNION_ORDER decides, default sorted.
+  bool id_union_order_unordered_set() const { return m_id_union_order_unordered_set; }
+  void set_id_union_order_unordered_set(bool v) { m_id_union_order_unordered_set = v; }
   void set_max_diploid_alt_alleles_that_can_be_genotyped(unsigned v) { m_max_diploid_alt_alleles_that_can_be_genotyped = v; }
   size_t get_combined_vcf_records_buffer_size_limit() const { return m_combined_vcf_records_buffer_size_limit; }
   void set_combined_vcf_records_buffer_size_limit(size_t v) { m_combined_vcf_records_buffer_size_limit = v ? v : 1; }
@@ -108,6 +113,7 @@ class VariantQueryConfig {
   bool m_produce_GT_field = false, m_produce_FILTER_field = false, m_sites_only_query = false, m_index_output_VCF = false;
   bool m_produce_GT_with_min_PL_value_for_spanning_deletions = false;
   unsigned m_max_diploid_alt_alleles_that_can_be_genotyped = 50;
+  bool m_id_union_order_unordered_set = false;
   size_t m_combined_vcf_records_buffer_size_limit = 1048576u;
   bool m_done_bookkeeping = false;
 };

@@ -22,6 +22,7 @@
 #include <map>
 #include <set>
 #include <sstream>
+#include <unordered_map>
 #include <unordered_set>
 
 #include "gdb_oracle_scan.hpp"
@@ -504,7 +505,9 @@ class BroadCombinedGVCFOperator : public SingleVariantOperatorBase {
   std::vector<unsigned> ploidy_;
   // BroadCombinedGVCFOperator state
   std::vector<FieldTuple> INFO_fields_vec_, FORMAT_fields_vec_;
-  std::map<unsigned, std::pair<unsigned, unsigned>> INFO_histogram_field_map_;   // composite vid field idx -> (query idx of the bins, of the counts)
+  // composite vid field idx -> (query idx of the bins, of the counts).  The reference's container (broad_combined_gvcf.h:123) and
+  // with it the reference's emission order of several histogram_sum fields: the iteration order of libstdc++'s unordered_map
+  std::unordered_map<unsigned, std::pair<unsigned, unsigned>> INFO_histogram_field_map_;
   FieldTuple qual_tuple_{UNDEFINED_IDX, UNDEFINED_IDX, nullptr};
   std::set<std::string> hdr_ids_;
   std::string curr_contig_name_, next_contig_name_;
@@ -619,7 +622,7 @@ class BroadCombinedGVCFOperator : public SingleVariantOperatorBase {
           if (parent.num_elements_in_tuple() != 2u)
             throw OracleException("Operation histogram_sum is only supported for fields whose elements are tuple with 2 constituent elements; field " + parent.name);
           if (fi->et != ET_INT && fi->et != ET_FLOAT) throw OracleException("histogram_sum needs int or float tuple elements; field " + parent.name);
-          auto& pr = INFO_histogram_field_map_[(unsigned)fi->parent_composite_field_idx];
+          auto& pr = INFO_histogram_field_map_.insert(std::make_pair((unsigned)fi->parent_composite_field_idx, std::make_pair(0u, 0u))).first->second;
           if (fi->element_index_in_tuple == 0u) pr.first = i; else pr.second = i;
         }
         else { INFO_fields_vec_.push_back({ke, i, fi}); add_field_to_hdr_if_missing(fi->vcf_name, 1); }
@@ -940,7 +943,7 @@ class BroadCombinedGVCFOperator : public SingleVariantOperatorBase {
           int sum = 0; unsigned n = 0;
           for_each_valid([&](const Field& f) { int v = f.iv[0]; if (is_bcf_valid_value(v)) { sum += v; ++n; } });
           if (!n) return false;
-          if (fi.combine_op == OP_MEAN) sum = sum / (int)n;
+          if (fi.combine_op == OP_MEAN) sum = sum / n;   // int / unsigned, as written in get_valid_mean (:596-607): the sum is converted to unsigned
           res.iv.assign(1, sum); return true;
         }
         throw OracleException("sum/mean on a string field");
@@ -1101,7 +1104,7 @@ class BroadCombinedGVCFOperator : public SingleVariantOperatorBase {
         e.type = res.type; e.iv = res.iv; e.fv = res.fv; e.sv = res.sv;
       }
     }
-    for (auto& kv : INFO_histogram_field_map_) {   // (:562-600) after the other INFO fields, by composite vid field idx
+    for (auto& kv : INFO_histogram_field_map_) {   // (:559-600) after the other INFO fields, in the unordered_map's iteration order
       const unsigned q_bin = kv.second.first, q_count = kv.second.second;
       const FieldInfo& fb = *qc_->attrs[q_bin].info;
       const FieldInfo& fc = *qc_->attrs[q_count].info;
@@ -1227,9 +1230,10 @@ class BroadCombinedGVCFOperator : public SingleVariantOperatorBase {
       if (sum_INFO_DP > 0 && !is_reference_block_only_) { RecInfo& e = rec_.info_slot("DP"); e.type = 0; e.iv.assign(1, sum_INFO_DP); }
     }
   }
-  // merge_ID_field (:730-763), DEBUG-build flavour (sorted) - the goldens come from a DEBUG build
-  void merge_ID_field(const Variant& variant, unsigned q) {
-    std::set<std::string> ids;
+  // merge_ID_field (:730-763): a std::set<std::string> #ifdef DEBUG (the build the goldens come from), a
+  // std::unordered_set<std::string> otherwise - here the library's own container, so the order is libstdc++'s by construction
+  template <class Set> void merge_ID_tokens(const Variant& variant, unsigned q) {
+    Set ids;
     for (const auto& c : variant.calls) {
       if (!c.is_valid) continue;
       const Field& f = c.fields[q];
@@ -1241,6 +1245,10 @@ class BroadCombinedGVCFOperator : public SingleVariantOperatorBase {
     ID_value_.clear();
     for (auto& s : ids) { ID_value_ += s; ID_value_ += ';'; }
     if (!ID_value_.empty()) ID_value_.pop_back();
+  }
+  void merge_ID_field(const Variant& variant, unsigned q) {
+    if (qc_->id_union_order_unordered_set) merge_ID_tokens<std::unordered_set<std::string>>(variant, q);
+    else merge_ID_tokens<std::set<std::string>>(variant, q);
   }
 };
 

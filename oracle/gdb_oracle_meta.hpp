@@ -432,6 +432,7 @@ class QueryConfig {
   unsigned known_to_qidx[GVCF_NUM_KNOWN_FIELDS];
   std::vector<unsigned> qidx_to_known;
   bool produce_GT_field = false, produce_FILTER_field = false, sites_only_query = false;
+  bool id_union_order_unordered_set = false;   // merge_ID_field without DEBUG (broad_combined_gvcf.cc:732-737); same knob as the product's
   bool produce_GT_with_min_PL_value_for_spanning_deletions = false;
   unsigned max_diploid_alt_alleles_that_can_be_genotyped = 50;
   size_t combined_vcf_records_buffer_size_limit = 1048576u;
@@ -570,6 +571,12 @@ class QueryConfig {
     auto flag = [&](const char* k) { return j.HasMember(k) && j[k].GetBool(); };
     produce_GT_field = flag("produce_GT_field");
     produce_FILTER_field = flag("produce_FILTER_field");
+    {
+      std::string order;
+      if (j.HasMember("id_union_order")) order = j["id_union_order"].GetString();
+      else if (const char* e = getenv("GDBAMD_ID_UNION_ORDER")) order = e;
+      id_union_order_unordered_set = order == "unordered_set";
+    }
     sites_only_query = flag("sites_only_query");
     produce_GT_with_min_PL_value_for_spanning_deletions = flag("produce_GT_with_min_PL_value_for_spanning_deletions");
   }

@@ -4,6 +4,7 @@
 // plain serial loops on the CPU, with std::sort / serial scans standing in for the device sorts and scans.
 // Purpose: debug the index arithmetic of the device pipeline in a container without a GPU and keep a CPU
 // regression of it next to the oracle.  The shipped library (libgenomicsdb_amd.so) contains no such path.
+#include <set>
 #include <unordered_set>
 #include <algorithm>
 #include <cstdio>
@@ -350,6 +351,38 @@ int hostsim_uset_order(const int32_t* ids, const int32_t* lens, int nranges, int
   if (us.overflow) return -1;
   for (int i = 0; i < us.n && i < cap; ++i) out_mine[i] = us.key[i];
   return us.n == n ? n : -2;
+}
+
+// gdb_core.hpp's restatement of a Release build's ID union (std::hash<std::string> + the iteration order of libstdc++'s
+// std::unordered_set<std::string>) against the library itself: `ntok` tokens inserted one by one (text = the tokens back to back,
+// lens[i] bytes each).  The two orders come back as token numbers (first occurrence) in out_mine / out_lib; *hash_mismatch = number of
+// tokens whose restated hash differs from std::hash<std::string>.  Returns the set's size, -1 beyond GDB_MAX_ID_TOKENS.
+int hostsim_id_union_order(const char* text, const int32_t* lens, int ntok, int release_order, int32_t* out_mine, int32_t* out_lib, int cap, int32_t* hash_mismatch) {
+  const char* tp[GDB_MAX_ID_TOKENS]; int tn[GDB_MAX_ID_TOKENS]; int nt = 0;
+  GdbUSetHashOrder us;
+  gdb_useth_init(us);
+  std::unordered_set<std::string> lib;
+  std::set<std::string> lib_sorted;
+  std::vector<std::string> first_seen;
+  uint32_t err = 0;
+  *hash_mismatch = 0;
+  const char* p = text;
+  for (int i = 0; i < ntok; ++i) {
+    const std::string tok(p, (size_t)lens[i]);
+    if (gdb_libstdcxx_hash_bytes(p, lens[i]) != (uint64_t)std::hash<std::string>()(tok)) ++*hash_mismatch;
+    gdb_id_union_add(p, lens[i], tp, tn, nt, us, release_order, &err);
+    lib.insert(tok);
+    lib_sorted.insert(tok);
+    if (std::find(first_seen.begin(), first_seen.end(), tok) == first_seen.end()) first_seen.push_back(tok);
+    p += lens[i];
+  }
+  if (err) return -1;
+  auto number_of = [&](const std::string& t) { return (int32_t)(std::find(first_seen.begin(), first_seen.end(), t) - first_seen.begin()); };
+  int n = 0;
+  if (release_order) { for (auto& t : lib) { if (n < cap) out_lib[n] = number_of(t); ++n; } }
+  else { for (auto& t : lib_sorted) { if (n < cap) out_lib[n] = number_of(t); ++n; } }
+  for (int i = 0; i < nt && i < cap; ++i) { const int w = gdb_id_union_at(us, release_order, i); out_mine[i] = number_of(std::string(tp[w], (size_t)tn[w])); }
+  return nt == n ? n : -2;
 }
 
 // gdb_asa.hpp's "%.3f" of a float (exact integer arithmetic on the mantissa) for the formatting test

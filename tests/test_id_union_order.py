@@ -1,0 +1,179 @@
+"""ID union of a record in the order of a Release build of the reference.  merge_ID_field collects the ';'-separated tokens of
+the live calls in a std::set<std::string> only #ifdef DEBUG (the goldens come from such a build: sorted tokens); every other build
+uses a std::unordered_set<std::string> and prints ITS iteration order (broad_combined_gvcf.cc:730-763) - std::hash<std::string>
+plus libstdc++'s bucket list.  The query key "id_union_order": "unordered_set" (or GDBAMD_ID_UNION_ORDER) selects that flavour.
+gdb_core.hpp restates hash and list order for the device; here the restatement is compared with the library itself, and the
+kernel bodies / the device with the oracle, whose container IS the library's."""
+import ctypes
+import random
+
+import pytest
+
+import helpers
+
+
+def _orders(tokens, release=1):
+    lib = helpers.hostsim_lib()
+    lib.hostsim_id_union_order.restype = ctypes.c_int
+    lib.hostsim_id_union_order.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.c_int,
+                                           ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.c_int,
+                                           ctypes.POINTER(ctypes.c_int32)]
+    text = b"".join(tokens)
+    lens = (ctypes.c_int32 * max(1, len(tokens)))(*[len(t) for t in tokens])
+    mine, ref = (ctypes.c_int32 * 64)(), (ctypes.c_int32 * 64)()
+    bad = ctypes.c_int32()
+    n = lib.hostsim_id_union_order(text, lens, len(tokens), release, mine, ref, 64, ctypes.byref(bad))
+    return n, list(mine[:max(n, 0)]), list(ref[:max(n, 0)]), bad.value
+
+
+def test_hash_and_iteration_order_match_the_library_on_random_token_sequences():
+    """tokens of 0 .. 40 bytes (every tail length of the 8-byte hash loop), duplicates, up to the 16 distinct tokens the device keeps
+    (13 buckets for the first 13, 29 from the 14th)"""
+    rnd = random.Random(20260930)
+    sizes = set()
+    for case in range(3000):
+        universe = []
+        for _ in range(rnd.randint(1, 16)):
+            k = rnd.choice([0, 1, 2, 3, 5, 7, 8, 9, 15, 16, 17, 24, 31, 40]) if rnd.random() < 0.5 else rnd.randint(1, 12)
+            universe.append(bytes(rnd.choice(b"abcrsx0123456789_.-") for _ in range(k)))
+        seq = [rnd.choice(universe) for _ in range(rnd.randint(1, 40))]
+        n, mine, ref, bad = _orders(seq)
+        assert bad == 0, seq
+        assert n >= 0 and mine == ref, (seq, mine, ref)
+        sizes.add(n)
+    assert max(sizes) >= 14 and min(sizes) == 1
+
+
+def test_sorted_flavour_is_a_std_set():
+    rnd = random.Random(3)
+    for case in range(300):
+        seq = [bytes(rnd.choice(b"abrs019") for _ in range(rnd.randint(0, 6))) for _ in range(rnd.randint(1, 20))]
+        if len(set(seq)) > 16:
+            continue
+        n, mine, ref, _ = _orders(seq, release=0)
+        assert n == len(set(seq)) and mine == ref
+
+
+def test_more_than_sixteen_tokens_is_reported():
+    n, _, _, _ = _orders([b"t%d" % i for i in range(17)])
+    assert n == -1
+
+
+def _golden_case():
+    from golden_cases import CASES
+    name, callsets, vid, ov, golden, mode = [c for c in CASES if c[0] == "t0_1_2_DS_ID_vcf_at_0"][0]
+    cells = helpers.cells_for(callsets, vid)
+    q, pb = helpers.query_json(callsets, vid, ov, mode)
+    return cells, q, golden
+
+
+def _library_order(tokens):
+    """iteration order of a std::unordered_set<std::string> after inserting `tokens` (through the hostsim hook's library side)"""
+    n, _, ref, _ = _orders(tokens)
+    first_seen = []
+    for t in tokens:
+        if t not in first_seen:
+            first_seen.append(t)
+    return [first_seen[i] for i in ref]
+
+
+def test_release_order_on_the_reference_fixture_with_ids():
+    """golden t0_1_2_DS_ID_vcf_at_0 (DEBUG build): ID = db567;rs1234;rs890 at 1:17385.  The calls carry, in row order, the ID
+    values of t0 / t1 / t2; a Release build inserts their tokens in that order into an unordered_set and prints its iteration
+    order.  Everything else in the output is unchanged."""
+    cells, q, golden = _golden_case()
+    want_sorted = helpers.golden_text(golden)
+    txt, _, _ = helpers.oracle_run(q, cells)
+    assert txt == want_sorted
+    import gzip, os
+    tokens = []
+    for name in ("t0", "t1", "t2"):
+        with gzip.open(os.path.join(helpers.GOLDEN, "inputs", "vcfs", name + ".vcf.gz"), "rt") as f:
+            for l in f:
+                c = l.split("\t")
+                if not l.startswith("#") and c[1] == "17385" and c[2] != ".":
+                    tokens += [t.encode() for t in c[2].split(";")]
+    assert sorted(set(tokens)) == [b"db567", b"rs1234", b"rs890"]
+    release_id = b";".join(_library_order(tokens))
+    q2 = dict(q, id_union_order="unordered_set")
+    want = want_sorted.replace(b"\tdb567;rs1234;rs890\t", b"\t" + release_id + b"\t")
+    txt, _, _ = helpers.oracle_run(q2, cells)
+    assert txt == want
+    got, err = helpers.hostsim_run(q2, cells)
+    assert err == 0 and got == want
+
+
+def _synth_case(tmp_path, N=200, L=1500, seed=11):
+    from genomicsdb_amd import synth
+    B = 10_000_000
+    g = synth.Generator(N, B, L + 2500, seed=seed, id_permille=700, with_id=True)
+    cells, _ = g.chunk_bytes(B + L + 2500)
+    q = helpers.synth_query(tmp_path, N, B + 20, B + L, with_id=True)
+    q["id_union_order"] = "unordered_set"
+    return B, cells, q
+
+
+def test_kernel_bodies_write_release_id_unions_like_the_oracle(tmp_path):
+    B, cells, q = _synth_case(tmp_path)
+    want, nrec, _ = helpers.oracle_run(q, cells, with_header=False)
+    multi = [l.split(b"\t")[2] for l in want.split(b"\n") if l and l.split(b"\t")[2].count(b";") >= 2]
+    assert len(multi) >= 5
+    assert any(m.split(b";") != sorted(m.split(b";")) for m in multi)       # the order really is not the sorted one
+    got, err = helpers.hostsim_run(q, cells, with_header=False, rows_per_chunk=16, records_per_run=5)
+    assert err == 0 and got == want
+    q["id_union_order"] = "sorted"
+    want_sorted, _, _ = helpers.oracle_run(q, cells, with_header=False)
+    assert want_sorted != want
+    got, err = helpers.hostsim_run(q, cells, with_header=False, rows_per_chunk=16, records_per_run=5)
+    assert err == 0 and got == want_sorted
+
+
+def test_an_id_value_of_one_semicolon_leaves_the_record_id_missing():
+    """merge_ID_field inserts the (empty) token in front of every ';' (:747-752); an ID value ";" therefore gives the set {""}, the
+    union string is empty and bcf_update_id is not called (:801-802): the record keeps '.'"""
+    n, mine, ref, _ = _orders([b""], release=1)
+    assert n == 1 and mine == ref
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_samples", [200, 1200])
+def test_device_writes_release_id_unions_like_the_oracle(tmp_path, n_samples):
+    import genomicsdb_amd
+    from genomicsdb_amd import synth
+    L = 1500 if n_samples < 1000 else 300
+    B, cells, q = _synth_case(tmp_path, N=n_samples, L=L, seed=13)
+    want, nrec, _ = helpers.oracle_run_synth(q, cells, 13, with_header=False)
+    assert sum(1 for l in want.split(b"\n") if l and l.split(b"\t")[2].count(b";") >= 2) >= 3
+    e = genomicsdb_amd.CombineEngine(q)
+    e.stage_cells(cells)
+    e.set_reference(B, synth.reference(B, L + 4096, seed=13))
+    body, st = e.run_interval(B + 20, B + L, arena_bytes=1 << 22)
+    e.close()
+    assert st.num_records == nrec and body == want
+    eb = genomicsdb_amd.CombineEngine(q, is_bcf=True)
+    eb.stage_cells(cells)
+    eb.set_reference(B, synth.reference(B, L + 4096, seed=13))
+    bcf, _ = eb.run_interval(B + 20, B + L, arena_bytes=1 << 22)
+    import struct
+    import bcf2text
+    h = bcf2text.Header(eb.header.decode())
+    eb.close()
+    at, lines = 0, []
+    while at < len(bcf):
+        l_shared, l_indiv = struct.unpack_from("<II", bcf, at)
+        lines.append(bcf2text.record_to_text(h, bcf[at:at + 8 + l_shared + l_indiv], helpers.format_float))
+        at += 8 + l_shared + l_indiv
+    assert ("\n".join(lines) + "\n").encode() == want
+
+
+@pytest.mark.gpu
+def test_device_release_order_on_the_reference_fixture(tmp_path):
+    import genomicsdb_amd
+    cells, q, golden = _golden_case()
+    q2 = dict(q, id_union_order="unordered_set")
+    want, _, _ = helpers.oracle_run(q2, cells)
+    assert want != helpers.golden_text(golden)
+    s = genomicsdb_amd.GenomicsDBQueryStream(query_json=q2, cells=cells, buffer_capacity=1 << 20)
+    got = s.read()
+    s.close()
+    assert got == want
