@@ -29,7 +29,7 @@ int bin_first(int l) { return ((1 << (3 * l)) - 1) / 7; }
 struct Chunk { uint64_t beg, end; };
 struct RefIndex {
   std::map<uint32_t, std::vector<Chunk>> bins;
-  std::map<uint32_t, uint64_t> loffset;        // CSI: smallest virtual offset of a record that overlaps the bin's first 16 kb-window ... (see below)
+  std::map<uint32_t, uint64_t> loffset;        // CSI: virtual offset of the first record that overlaps the bin's first 16 kb window (fill_linear)
   std::vector<uint64_t> linear;                // 16 kb windows -> virtual offset of the first record overlapping the window
   uint64_t off_beg = ~0ull, off_end = 0, n_mapped = 0;
   uint32_t last_bin = ~0u;
@@ -92,18 +92,28 @@ void note_record(std::vector<RefIndex>& refs, int tid, int64_t beg, int64_t end,
   const size_t w0 = (size_t)(beg >> kMinShift), w1 = (size_t)((end - 1) >> kMinShift);
   if (r.linear.size() <= w1) r.linear.resize(w1 + 1, 0);
   for (size_t w = w0; w <= w1; ++w) if (r.linear[w] == 0) r.linear[w] = vbeg;
-  // CSI: loffset of every bin on the record's path from its own bin up to the root = smallest offset of a record beginning in / reaching it
-  for (int l = kDepth, s = kMinShift; l >= 0; --l, s += 3) {
-    const uint32_t b = (uint32_t)(bin_first(l) + (int)(beg >> s));
-    auto it = r.loffset.find(b);
-    if (it == r.loffset.end() || vbeg < it->second) r.loffset[b] = vbeg;
-  }
   r.off_beg = std::min(r.off_beg, vbeg);
   r.off_end = std::max(r.off_end, vend);
   ++r.n_mapped;
 }
+// htslib's update_loff (hts.c): windows in front of a contig's first record take the offset of that record, every other window
+// without a record the offset of the window before it; then the loffset of a bin = the linear offset of the bin's FIRST 16 kb
+// window, i.e. the offset of the first record that OVERLAPS that window - not of the first record that begins in the bin (a
+// reference block that begins in the window before and reaches into it comes first in the file, and hts_itr_query drops every
+// chunk that ends at or below the loffset)
+int bin_level(uint32_t bin) { int l = 0; for (uint32_t b = bin; b; b = (b - 1) >> 3) ++l; return l; }
 void fill_linear(std::vector<RefIndex>& refs) {
-  for (RefIndex& r : refs) for (size_t i = 1; i < r.linear.size(); ++i) if (r.linear[i] == 0) r.linear[i] = r.linear[i - 1];
+  for (RefIndex& r : refs) {
+    size_t i = 0;
+    for (; i < r.linear.size() && r.linear[i] == 0; ++i) r.linear[i] = r.n_mapped ? r.off_beg : 0;
+    for (; i < r.linear.size(); ++i) if (r.linear[i] == 0) r.linear[i] = r.linear[i - 1];
+    r.loffset.clear();
+    for (const auto& b : r.bins) {
+      const int l = bin_level(b.first);
+      const uint64_t bot = (uint64_t)(b.first - (uint32_t)bin_first(l)) << ((kDepth - l) * 3);
+      r.loffset[b.first] = bot < r.linear.size() ? r.linear[bot] : 0;
+    }
+  }
 }
 template <class T> void put(std::string& o, T v) { o.append((const char*)&v, sizeof(T)); }
 constexpr uint32_t kMetaBin = ((1u << ((kDepth + 1) * 3)) - 1u) / 7u + 1u;   // 37450: htslib's pseudo-bin with a contig's offsets and record count
@@ -206,6 +216,7 @@ void build_csi_index(const std::string& path) {
     note_record(refs, chrom, pos, (int64_t)pos + std::max(1, rlen), vbeg, vend);
   }
   if ((int)refs.size() < n_ref) refs.resize((size_t)n_ref);
+  fill_linear(refs);
   std::string o;
   o.append("CSI\1", 4);
   put<int32_t>(o, kMinShift); put<int32_t>(o, kDepth); put<int32_t>(o, 0);   // l_aux = 0

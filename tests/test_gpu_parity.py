@@ -1164,6 +1164,96 @@ def test_c2_full_size_two_pagings_agree(gdb, tmp_path):
     eng.close()
 
 
+def test_c2_full_size_interior_windows_match_the_oracle(gdb, tmp_path):
+    """The array bench.py times (BASELINE.json configs[1]: 1 000 samples x 10 Mb, staged in 1 Mb parts exactly like the bench)
+    against the ORACLE at interior positions: 300-bp query windows at seeded random offsets and across the 1 Mb cuts between the
+    bench's steps.  The oracle cannot scan 10 Mb, but a record depends only on the cells that overlap it, and no interval of the
+    generator is longer than 2 000 bp: the cells that begin in [s - 2 100, s + 300) are everything the reference would look at for
+    the query [s, s + 299] (left sweep included).  The generator hands them over as chunks of their own while the array is staged."""
+    import ctypes
+    import random
+    from genomicsdb_amd import synth
+    N, B, L, W, REACH = 1000, 10_000_000, 10_000_000, 300, 2100
+    rnd = random.Random(20260930)
+    spots = [B + k * 1_000_000 - W // 2 for k in (1, 5, 9)]                         # straddle a cut between two bench steps
+    spots += [B + k * 1_000_000 - 1 for k in (3,)] + [B + 7 * 1_000_000]            # end exactly in front of / begin exactly at a cut
+    spots += [B + rnd.randrange(REACH + 10, L - W - 10) for _ in range(6)]          # anywhere
+    spots = sorted(spots)
+    cuts = sorted(set([B + i * 1_000_000 for i in range(1, 11)] + [s - REACH for s in spots] + [s + W for s in spots]))
+    q = helpers.synth_query(tmp_path, N, B, B + L - 1)
+    eng = gdb.CombineEngine(q)
+    g = synth.Generator(N, B, L)
+    eng.stage_cells_begin()
+    kept = []                                   # (first column, end column, bytes) of the chunks some window needs
+    prev = B
+    for col in cuts:
+        ptr, nbytes, nc = g.next_chunk(col)
+        eng.stage_cells_append(ptr, nbytes)
+        if any(s - REACH <= prev and col <= s + W for s in spots):
+            kept.append((prev, col, ctypes.string_at(ptr, nbytes)))
+        prev = col
+    eng.stage_cells_end()
+    g.close()
+    eng.set_reference(B, synth.reference(B, L + 4096))
+    total = 0
+    for i, s in enumerate(spots):
+        cells = b"".join(c for lo, hi, c in kept if s - REACH <= lo and hi <= s + W)
+        assert len(cells) > 1000 * 150
+        d = tmp_path / ("spot%d" % i)
+        d.mkdir()
+        qs = helpers.synth_query(d, N, s, s + W - 1)
+        want, nrec, _ = helpers.oracle_run_synth(qs, cells, synth.SEED, with_header=False)
+        got, st = eng.run_interval(s, s + W - 1, arena_bytes=64 << 20)
+        assert st.num_records == nrec and nrec >= W - 5, (s, nrec, st.num_records)
+        assert got == want, "window at column %d" % s
+        total += nrec
+    assert total > 3000
+    eng.close()
+
+
+def test_c3_width_interior_window_of_a_streamed_array_matches_the_oracle(gdb, tmp_path, monkeypatch):
+    """BASELINE.json configs[2]'s width (10 000 samples) the way the bench's c3 leg runs it - cells streamed through HBM in column
+    windows with the carry-over between them - checked against the oracle on an interior window: 60 kb of cells (880 MB) through a
+    64 MiB staging budget, the query window 120 bp wide two thirds into the array"""
+    import ctypes
+    import numpy as np
+    from genomicsdb_amd import synth, api
+    N, B, L, W, REACH = 10_000, 10_000_000, 60_000, 120, 2100
+    s = B + 41_234
+    g = synth.Generator(N, B, L)
+    parts, spot = [], []
+    prev = B
+    for col in (s - REACH, s + W, B + L):
+        ptr, nbytes, nc = g.next_chunk(col)
+        parts.append(ctypes.string_at(ptr, nbytes))
+        if prev == s - REACH:
+            spot.append(parts[-1])
+        prev = col
+    g.close()
+    cells = b"".join(parts)
+    qs = helpers.synth_query(tmp_path, N, s, s + W - 1)
+    want, nrec, _ = helpers.oracle_run_synth(qs, spot[0], synth.SEED, with_header=False)
+    assert nrec >= W - 5
+    keep = np.frombuffer(cells, dtype=np.uint8)
+    monkeypatch.setenv("GDBAMD_STAGE_BUDGET_BYTES", str(64 << 20))
+    q = helpers.synth_query(tmp_path, N, B, B + L - 1)
+    e = gdb.CombineEngine(q)
+    e.open_memory_cells((keep.ctypes.data, keep.nbytes))
+    e.set_reference(B, synth.reference(B, L + 4096))
+    pos, nwin, body = B, 0, b""
+    while pos <= s + W - 1:                       # walk the windows like the bench's streamed leg; fetch only the spot
+        lo, hi = e.cover(pos)
+        a, b = max(pos, s), min(hi, s + W - 1)
+        if a <= b:
+            part, st = e.run_interval(a, b, arena_bytes=256 << 20)
+            body += part
+        pos = hi + 1
+        nwin += 1
+    e.close()
+    assert body == want
+    assert nwin >= 3                              # the spot lies behind at least two window cuts (carry-over twice)
+
+
 def test_c4_sample_count_100000_rows_matches_oracle(gdb, tmp_path):
     """BASELINE.json configs[3]'s sample count on a narrow window: 100 000 samples (1 563 chunks of 64 sample columns, a first
     record with 100 000 calls starting at the partition begin - allele merge, medians and sums by its workgroup), 24 columns"""

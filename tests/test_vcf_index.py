@@ -114,6 +114,66 @@ def test_index_of_a_file_without_records(tmp_path):
     assert idx.names == [] and idx.refs == []
 
 
+def _bcf_file(records, n_contigs=2):
+    """a minimal BCF2 stream: header text with `n_contigs` contig lines, records of (tid, pos, rlen) with empty ID / REF 'N' / no ALT"""
+    text = b"##fileformat=VCFv4.2\n" + b"".join(b"##contig=<ID=c%d,length=100000000>\n" % i for i in range(n_contigs))
+    text += b"#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n\x00"
+    out = bytearray(b"BCF\x02\x02" + struct.pack("<I", len(text)) + text)
+    recs = []
+    for tid, pos, rlen in records:
+        shared = struct.pack("<iiifII", tid, pos, rlen, 0.0, (1 << 16) | 0, 0) + b"\x07" + b"\x17N" + b"\x00"   # ID, REF, FILTER: typed values
+        rec = struct.pack("<II", len(shared), 0) + shared
+        recs.append(rec)
+        out += rec
+    return bytes(out), recs
+
+
+def _check_bcf(path, recs, meta, regions):
+    idx = tabix_reader.Index(path + ".csi")
+    assert idx.kind == "csi"
+    for tid, beg, end in regions:
+        want = [r for r, (t, p, l) in zip(recs, meta) if t == tid and p < end and p + max(1, l) > beg]
+        assert tabix_reader.fetch_bcf(path, idx, tid, beg, end) == want, (tid, beg, end)
+
+
+def test_csi_loffset_is_the_first_record_overlapping_the_bins_first_window(tmp_path):
+    """A record that begins in the 16 kb window BEFORE a bin's first window and reaches into it comes first in the file; htslib sets a
+    bin's loffset from the overlap-based linear index (update_loff) and hts_itr_query drops chunks that end at or below the loffset of
+    the leaf bin of the region's begin.  With loffset = first record BEGINNING in the bin, the reaching record's chunk was dropped:
+    a gVCF reference block (pos 16 000, 1 000 long) was missed by a query at 16 400 once a second record began at 16 500."""
+    meta = [(0, 16000, 1000), (0, 16500, 10)]
+    data, recs = _bcf_file(meta)
+    p = str(tmp_path / "a.bcf")
+    open(p, "wb").write(_bgzip(data, block=70))
+    _build(p, True)
+    idx = tabix_reader.Index(p + ".csi")
+    leaf = ((1 << 15) - 1) // 7 + (16400 >> 14)
+    vrec0 = [c for b in idx.refs[0]["bins"] if b != idx.meta_bin for c in idx.refs[0]["bins"][b]]
+    assert idx.refs[0]["loffset"][leaf] == min(c[0] for c in vrec0)          # = the reaching record's offset, not the second record's
+    _check_bcf(p, recs, meta, [(0, 16400, 16450), (0, 16384, 16385), (0, 16999, 17000), (0, 17000, 17001), (0, 0, 16000), (1, 0, 10**8)])
+
+
+def test_csi_of_random_intervals_finds_what_a_scan_finds(tmp_path):
+    rnd = random.Random(5)
+    meta, pos = [], {0: 0, 1: 0, 2: 0}
+    for tid in (0, 1, 2):
+        p0 = 0
+        for _ in range(1500):
+            p0 += rnd.choice([1, 1, 3, 40, 700, 9000, 20000, 140000])
+            meta.append((tid, p0, rnd.choice([1, 1, 2, 150, 2000, 17000, 70000, 300000])))
+    data, recs = _bcf_file(meta, n_contigs=4)
+    p = str(tmp_path / "r.bcf")
+    open(p, "wb").write(_bgzip(data, block=900))
+    _build(p, True)
+    regions = []
+    for _ in range(400):
+        t, b, l = meta[rnd.randrange(len(meta))]
+        at = rnd.choice([b, b + l - 1, b + l, max(0, b - 1), b + l // 2])
+        regions.append((t, at, at + rnd.choice([1, 5, 20000])))
+    regions += [(3, 0, 10**8), (0, 0, 10**8)]
+    _check_bcf(p, recs, meta, regions)
+
+
 @pytest.mark.gpu
 def test_gt_mpi_gather_writes_tbi_and_csi(tmp_path):
     """query JSON with "index_output_VCF": true: gt_mpi_gather -O z leaves <file>.tbi, -O b leaves <file>.csi; regions fetched through them

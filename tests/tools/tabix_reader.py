@@ -107,6 +107,17 @@ class Index:
         if self.kind == "tbi" and r["linear"]:
             w = beg >> self.min_shift
             lo = r["linear"][min(w, len(r["linear"]) - 1)] if w < len(r["linear"]) else r["linear"][-1]
+        elif self.kind == "csi":
+            # hts_itr_query's min_off (htslib hts.c): the loffset of the leaf bin of `beg` if the index has it, else of the nearest
+            # bin in front of it on the same level, else of the parent - chunks that end at or below it are dropped
+            b = ((1 << (self.depth * 3)) - 1) // 7 + (beg >> self.min_shift)
+            while b:
+                if b in r["bins"] and b != self.meta_bin:
+                    break
+                parent = (b - 1) >> 3
+                first = (parent << 3) + 1
+                b = b - 1 if b > first else parent
+            lo = r["loffset"].get(b, 0) if b in r["bins"] else 0
         out = []
         for b in reg2bins(beg, end, self.min_shift, self.depth):
             if b == self.meta_bin:
