@@ -20,7 +20,7 @@ template <class F, class R> R guarded(F f, R on_error) {
   catch (const std::exception& e) { g_last_error = e.what(); return on_error; }
   catch (...) { g_last_error = "unknown exception"; return on_error; }
 }
-struct EngineHandle { std::unique_ptr<CombineEngine> eng; std::string calls_text; };
+struct EngineHandle { std::unique_ptr<CombineEngine> eng; std::string calls_text; int calls_text_mode = -1; };   // calls_text: the document of gdbamd_engine_print_cells(mode) between its sizing and its copying call
 }  // namespace
 
 extern "C" {
@@ -288,14 +288,15 @@ int64_t gdbamd_engine_print_calls(void* engine, char* dst, uint64_t cap) { retur
 int64_t gdbamd_engine_print_cells(void* engine, int mode, char* dst, uint64_t cap) {
   try {
     EngineHandle* h = (EngineHandle*)engine;
-    auto make = [&]() { return mode == 0 ? h->eng->print_calls() : mode == 1 ? h->eng->print_csv() : h->eng->print_allele_counts(); };
-    if (!dst) h->calls_text = make();
-    else {
-      if (h->calls_text.empty()) h->calls_text = make();
-      if (cap < h->calls_text.size()) { g_last_error = "print_calls: destination too small"; return -1; }
-      memcpy(dst, h->calls_text.data(), h->calls_text.size());
-    }
-    return (int64_t)h->calls_text.size();
+    auto make = [&]() { h->calls_text_mode = mode; return mode == 0 ? h->eng->print_calls() : mode == 1 ? h->eng->print_csv() : h->eng->print_allele_counts(); };
+    if (!dst) { h->calls_text = make(); return (int64_t)h->calls_text.size(); }
+    if (h->calls_text_mode != mode) h->calls_text = make();     // (nothing kept, or the document of another mode)
+    const size_t n = h->calls_text.size();
+    if (cap < n) { g_last_error = "print_calls: destination too small"; return -1; }
+    memcpy(dst, h->calls_text.data(), n);
+    std::string().swap(h->calls_text);                          // handed over: a multi-GB document does not stay in the handle
+    h->calls_text_mode = -1;
+    return (int64_t)n;
   } catch (const std::exception& e) { g_last_error = e.what(); return -1; }
 }
 // ColumnHistogramOperator::equi_partition_and_print_bins (variant_operations.cc:769-796), the text it prints; returns its length (dst may be NULL), -1 when
@@ -309,7 +310,9 @@ int64_t gdbamd_equi_partition_text(const uint64_t* counts, uint64_t nbins, uint6
   char line[160];
   snprintf(line, sizeof(line), "Total %llu #bins %llu count/bins %.1f\n", total, (unsigned long long)num_parts, per);
   out += line;
-  for (uint64_t i = 0; i < nbins;) {
+  // (no cell at all - an empty array, or query rows without cells: the reference's loop would not advance (its assert(j > i)); the header
+  // line alone is the answer here)
+  for (uint64_t i = 0; i < nbins && total > 0;) {
     uint64_t j = i;
     unsigned long long cur = 0;
     for (; (double)cur < per && j < nbins; cur += counts[j], ++j) {}

@@ -357,6 +357,24 @@ CombineEngine::Coverage CombineEngine::cover(int64_t column) {
 void CombineEngine::column_histogram(uint64_t hist_begin, uint64_t hist_end, uint64_t bin_size, std::vector<uint64_t>& counts) {
   if (bin_size == 0 || hist_end < hist_begin) throw GenomicsDBConfigException("column histogram: empty range or bin size 0");
   counts.assign((size_t)((hist_end - hist_begin) / bin_size + 1), 0);
+  if (m_qc.get_num_column_intervals() > 0) {
+    // the reference hands the operator the cells of the QUERY's column intervals (iterate_over_cells(ad, query_config, op),
+    // tools/src/gt_mpi_gather.cc:404-411): per interval the cells that begin in it and the intervals that reach its begin, the
+    // selection of --print-calls (for_each_interval_text)
+    for (unsigned i = 0; i < m_qc.get_num_column_intervals(); ++i) {
+      const int64_t qb = m_qc.get_column_begin(i), qe = m_qc.get_column_end(i);
+      bool first_piece = true;
+      for (int64_t pos = qb; pos <= qe;) {
+        const Coverage cov = cover(pos);
+        const int64_t piece[2] = {pos, std::min(cov.hi, qe)};
+        m_pipe->column_histogram(hist_begin, hist_end, bin_size, counts.data(), counts.size(), true, piece, first_piece);
+        first_piece = false;
+        if (piece[1] >= qe || m_src.kind == SRC_NONE || m_window_eof || cov.hi >= INT64_MAX - 1) break;
+        pos = piece[1] + 1;
+      }
+    }
+    return;
+  }
   int64_t col = INT64_MIN;
   for (;;) {                                                      // window by window; a window's carried-over cells are not counted again
     const Coverage cov = cover(col);

@@ -119,7 +119,10 @@ class DevicePipeline {
   int64_t split_point(int64_t qb, int64_t qe, int64_t max_columns);
   // ColumnHistogramOperator (variant_operations.cc:732-767) over the staged fragment's begin-cells: counts[(end - begin) / bin_size + 1];
   // accumulate: add to what counts holds (an array streamed in windows is counted window by window)
-  void column_histogram(uint64_t hist_begin, uint64_t hist_end, uint64_t bin_size, uint64_t* counts, uint64_t nbins, bool accumulate = false);
+  // interval != nullptr: only the cells of the query interval [interval[0], interval[1]] (with_intersecting: and the intervals that began in
+  // front of it and reach its begin), carried-over cells included
+  void column_histogram(uint64_t hist_begin, uint64_t hist_end, uint64_t bin_size, uint64_t* counts, uint64_t nbins, bool accumulate = false,
+                        const int64_t* interval = nullptr, bool with_intersecting = false);
   // gt_mpi_gather --print-calls (VariantCallPrintOperator, variant_operations.cc:803-843): the cells of [qb, qe] in the reference's iterator
   // order - first the intervals that began before qb and intersect it, then the cells that begin inside - as JSON objects separated by
   // ",\n", every line indented by `indent` spaces; ncells: how many.  with_intersecting = false: only the cells that begin inside (the

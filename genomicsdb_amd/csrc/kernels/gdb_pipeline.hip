@@ -4927,13 +4927,18 @@ int64_t DevicePipeline::split_point(int64_t qb, int64_t qe, int64_t max_columns)
 // ColumnHistogramOperator on the device (variant_operations.cc:732-767): every staged begin-cell counts for the bin of its begin column,
 // begin <= hist_begin in bin 0, begin >= hist_end in the last one.  One atomic per run of equal bins inside a wavefront (the cells
 // are sorted by begin: neighbouring lanes nearly always share their bin).
-__global__ void k_column_histogram(const int64_t* __restrict__ begin, int64_t C, uint64_t hist_begin, uint64_t hist_end, uint64_t bin_size, uint64_t nbins, unsigned long long* __restrict__ counts) {
+// eff_end != nullptr: only the cells of the query interval [qb, qe] count - the ones the reference's iterate_over_cells hands to the
+// operator (calls_select: cells that begin inside, and with_intersecting the intervals that began in front of qb and reach it)
+__global__ void k_column_histogram(const int64_t* __restrict__ begin, int64_t C, uint64_t hist_begin, uint64_t hist_end, uint64_t bin_size, uint64_t nbins, unsigned long long* __restrict__ counts,
+                                   const int64_t* __restrict__ eff_end, int64_t qb, int64_t qe, int with_intersecting) {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   uint64_t bin = ~0ull;
   if (c < C) {
-    const uint64_t b = (uint64_t)begin[c];
-    bin = b <= hist_begin ? 0ull : b >= hist_end ? nbins - 1 : (b - hist_begin) / bin_size;
+    const int64_t bc = begin[c];
+    const bool take = !eff_end || (bc >= qb && bc <= qe) || (with_intersecting && bc < qb && eff_end[c] >= qb);
+    const uint64_t b = (uint64_t)bc;
+    if (take) bin = b <= hist_begin ? 0ull : b >= hist_end ? nbins - 1 : (b - hist_begin) / bin_size;
   }
   const uint64_t prev = __shfl_up(bin, 1, 64);
   const bool head = lane == 0 || prev != bin;
@@ -4944,10 +4949,23 @@ __global__ void k_column_histogram(const int64_t* __restrict__ begin, int64_t C,
     atomicAdd(&counts[bin], (unsigned long long)run);
   }
 }
-void DevicePipeline::column_histogram(uint64_t hist_begin, uint64_t hist_end, uint64_t bin_size, uint64_t* counts, uint64_t nbins, bool accumulate) {
+void DevicePipeline::column_histogram(uint64_t hist_begin, uint64_t hist_end, uint64_t bin_size, uint64_t* counts, uint64_t nbins, bool accumulate, const int64_t* interval, bool with_intersecting) {
   Impl& S = *m_;
   if (bin_size == 0 || hist_end < hist_begin || nbins != (hist_end - hist_begin) / bin_size + 1) throw GenomicsDBDeviceException("column_histogram: #bins must be (end - begin) / bin_size + 1");
   HIP_CHECK(hipSetDevice(S.device));
+  if (interval) {     // the cells of one query interval (or of the piece of it the staged window serves): every staged cell is looked at
+    if (S.fr.ncells == 0) return;
+    classify_fragment();                                        // (eff_end)
+    DevBuf<unsigned long long> di;
+    di.ensure(nbins);
+    if (accumulate) HIP_CHECK(hipMemcpyAsync(di.p, counts, nbins * sizeof(uint64_t), hipMemcpyHostToDevice, S.stream));
+    else HIP_CHECK(hipMemsetAsync(di.p, 0, nbins * sizeof(uint64_t), S.stream));
+    hipLaunchKernelGGL(k_column_histogram, dim3(blocks_for(S.fr.ncells)), dim3(kBlock), 0, S.stream, S.fr.begin, S.fr.ncells, hist_begin, hist_end, bin_size, nbins, di.p,
+                       (const int64_t*)S.eff_end.p, interval[0], interval[1], with_intersecting ? 1 : 0);
+    HIP_CHECK(hipMemcpyAsync(counts, di.p, nbins * sizeof(uint64_t), hipMemcpyDeviceToHost, S.stream));
+    HIP_CHECK(hipStreamSynchronize(S.stream));
+    return;
+  }
   DevBuf<unsigned long long> d;
   d.ensure(nbins);
   if (accumulate) HIP_CHECK(hipMemcpyAsync(d.p, counts, nbins * sizeof(uint64_t), hipMemcpyHostToDevice, S.stream));
@@ -4955,7 +4973,8 @@ void DevicePipeline::column_histogram(uint64_t hist_begin, uint64_t hist_end, ui
   // (the cells carried over from the previous column window open the fragment: they were counted with their own window)
   const int64_t first = std::min<int64_t>(S.carried_cells, S.fr.ncells), n = S.fr.ncells - first;
   if (n > 0)
-    hipLaunchKernelGGL(k_column_histogram, dim3(blocks_for(n)), dim3(kBlock), 0, S.stream, S.fr.begin + first, n, hist_begin, hist_end, bin_size, nbins, d.p);
+    hipLaunchKernelGGL(k_column_histogram, dim3(blocks_for(n)), dim3(kBlock), 0, S.stream, S.fr.begin + first, n, hist_begin, hist_end, bin_size, nbins, d.p,
+                       (const int64_t*)nullptr, (int64_t)0, (int64_t)0, 0);
   HIP_CHECK(hipMemcpyAsync(counts, d.p, nbins * sizeof(uint64_t), hipMemcpyDeviceToHost, S.stream));
   HIP_CHECK(hipStreamSynchronize(S.stream));
 }

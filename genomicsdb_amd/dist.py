@@ -135,7 +135,51 @@ def balanced_partition(counts, hist_begin, bin_size, rank, world):
     return b + k * w, (e if k == m - 1 else b + (k + 1) * w - 1)
 
 
-def paged_concat(pages, sink, page_bytes, dst=0, ring_slots=3, device=None, stats=None):
+_header_group = None
+
+
+def _headers_group():
+    """A CPU-side ("gloo") process group of all ranks for the 8-byte page headers of paged_concat: a page's size is known on the
+    host, and a header that travels over the GPU backend costs the root a device-to-host synchronisation per page.  Created once
+    (collectively: every rank calls paged_concat) and kept."""
+    global _header_group
+    import torch.distributed as dist
+    if _header_group is None:
+        _header_group = dist.new_group(backend="gloo")
+    return _header_group
+
+
+class _ThreadedWork:
+    """is_completed() for a backend whose receives only make progress inside wait() (gloo): wait() runs in a helper thread.  Lets
+    the polled root of paged_concat - the one "nccl" uses - run under gloo in the CPU tests."""
+
+    def __init__(self, work):
+        import threading
+        self.error = None
+        self._t = threading.Thread(target=self._run, args=(work,), daemon=True)
+        self._t.start()
+
+    def _run(self, work):
+        try:
+            work.wait()
+        except BaseException as e:      # noqa: BLE001 - re-raised by is_completed()
+            self.error = e
+
+    def is_completed(self):
+        if self._t.is_alive():
+            return False
+        if self.error is not None:
+            raise self.error
+        return True
+
+
+def root_ring_slots(world, page_bytes, ring_slots, root_ring_bytes):
+    """receive buffers per sender on the root: as many as the byte budget allows, at least 1, at most ring_slots"""
+    senders = max(1, world - 1)
+    return int(max(1, min(ring_slots, root_ring_bytes // (senders * max(1, page_bytes)))))
+
+
+def paged_concat(pages, sink, page_bytes, dst=0, ring_slots=3, device=None, stats=None, root_ring_bytes=8 << 30, polled=None):
     """Ordered concatenation of the ranks' page streams with BOUNDED memory on every rank: the single-stream view of the P
     per-partition outputs of `mpirun -n P gt_mpi_gather` (gt_mpi_gather.cc:322-366 writes P files; a combined stream is those
     files back to back in rank = column order).
@@ -146,12 +190,21 @@ def paged_concat(pages, sink, page_bytes, dst=0, ring_slots=3, device=None, stat
     sink(t): called on rank `dst` once per page, in rank order and in each rank's page order; `t` is valid during the call only.
 
     A sending rank keeps ring_slots copies of its own pages in flight and stops scanning when they are full.  Rank `dst` receives
-    from ALL ranks at once: every sender has its own ring of ring_slots receive buffers there (world x ring_slots x page_bytes on the
-    root: 24 GiB for 8 ranks, 3 slots, 1 GiB pages), so while rank r is being drained the ranks behind it can park that many pages
-    at the root on top of their own ring instead of stalling after theirs.  Every page travels as an 8-byte header (its size; 0
-    closes the rank's stream) followed by the bytes, point to point; there is no collective and no tensor of the size of a
-    whole body anywhere.  Returns the number of bytes handed to `sink` (root) / sent.  stats (a dict, optional) receives
-    "bytes", "seconds", "blocked_s" (sender: waiting for a free slot; root: waiting for a page of the rank being drained)."""
+    from ALL ranks at once: every sender has its own ring of receive buffers there, so while rank r is being drained the ranks
+    behind it can park pages at the root on top of their own ring instead of stalling after theirs.  The root's rings are sized
+    from a byte budget (`root_ring_bytes`, default 8 GiB over all senders: 1 slot each for 8 ranks and 1 GiB pages, 3 each with
+    256 MiB pages), allocated when first used.  A page travels as an 8-byte header (its size; 0 closes the rank's stream) over a
+    CPU-side gloo group - the size is known on the host, no device synchronisation is paid for it - and the bytes point to point
+    over the data backend; there is no collective and no tensor of the size of a whole body anywhere.
+
+    Root side, two flavours.  polled (the default under "nccl"): ONE thread posts the receives of all senders as their headers
+    arrive and slots are free, polls work.is_completed() and feeds the sink in rank order - ProcessGroupNCCL is never entered from
+    two threads; only the header receives (gloo, host tensors) sit in helper threads.  threaded (the default under "gloo", whose
+    receives only progress inside wait()): a receiver thread per sender.  A sink that raises does not strand the senders: the
+    root keeps receiving and discarding until every rank has closed its stream, then re-raises.
+    Returns the number of bytes handed to `sink` (root) / sent.  stats (a dict, optional) receives "bytes", "seconds", "blocked_s"
+    (sender: waiting for a free slot; root: waiting for a page of the rank being drained)."""
+    import os
     import time
     import torch
     import torch.distributed as dist
@@ -167,20 +220,22 @@ def paged_concat(pages, sink, page_bytes, dst=0, ring_slots=3, device=None, stat
         return total
     world, rank = dist.get_world_size(), dist.get_rank()
     ring_slots = max(2, int(ring_slots))
+    hgroup = _headers_group()
+    if polled is None:
+        env = os.environ.get("GDBAMD_CONCAT_POLLED")
+        polled = (env == "1") if env is not None else dist.get_backend() != "gloo"
     if rank != dst:
-        ring, hdrs, pending, total, k = [], [], [], 0, 0
-        dev = device
+        ring, pending, total, k = [], [], 0, 0
+        hdr_keep = []
         for t in pages:
             n = int(t.numel())
             if n == 0:
                 continue
             if n > page_bytes:
                 raise ValueError("page of %d bytes exceeds page_bytes %d" % (n, page_bytes))
-            dev = t.device
             slot = k % ring_slots
             if len(ring) <= slot:
                 ring.append(torch.empty(page_bytes, dtype=torch.uint8, device=t.device))
-                hdrs.append(torch.zeros(1, dtype=torch.int64, device=t.device))
             elif len(pending) >= ring_slots:          # the slot's previous page must have left
                 t0 = time.time()
                 for w in pending.pop(0):
@@ -189,79 +244,159 @@ def paged_concat(pages, sink, page_bytes, dst=0, ring_slots=3, device=None, stat
             ring[slot][:n].copy_(t)                   # the engine's arena is reused by the next page:
             if t.is_cuda:                             # the copy (torch's stream) must be over before the engine (its own
                 torch.cuda.current_stream(t.device).synchronize()   # stream) is asked for the next one
-            hdrs[slot].fill_(n)
-            pending.append((dist.isend(hdrs[slot], dst=dst), dist.isend(ring[slot][:n], dst=dst)))
+            h = torch.tensor([n], dtype=torch.int64)  # host tensor, gloo group: the root learns the size without touching the device
+            hdr_keep.append(h)
+            pending.append((dist.isend(h, dst=dst, group=hgroup), dist.isend(ring[slot][:n], dst=dst)))
             total += n
             k += 1
         for ws in pending:
             for w in ws:
                 w.wait()
-        end = torch.zeros(1, dtype=torch.int64, device=dev)   # (device=None with no page sent: a host tensor - fine under gloo; GPU backends pass `device`)
-        dist.send(end, dst=dst)
+        dist.send(torch.zeros(1, dtype=torch.int64), dst=dst, group=hgroup)
         if stats is not None:
             stats.update(bytes=total, seconds=time.time() - t_begin, blocked_s=blocked)
         return total
-    # ---- root: one receiver thread per sender, all of them fed concurrently; the sink is served strictly in rank order ----
-    # (threads, not polling: gloo's irecv only completes inside wait(), and a wait with a timeout closes the pair)
+    # ---- root ---------------------------------------------------------------------------------------------------------------
     import queue
     import threading
     dev = device
     total = 0
+    slots = root_ring_slots(world, page_bytes, ring_slots, int(root_ring_bytes))
+    failure = []                                      # first exception of the sink: from then on pages are received and dropped
 
-    def receiver(src, out_q, free):
+    def deliver(t):
+        nonlocal total
+        if failure:
+            return
         try:
-            if dev is not None and getattr(dev, "type", "cpu") == "cuda":
-                torch.cuda.set_device(dev)
-            hdr = torch.zeros(1, dtype=torch.int64, device=dev)
-            ring, k = [], 0
+            sink(t)
+            total += int(t.numel())
+        except BaseException as e:                    # noqa: BLE001 - re-raised when every sender has closed
+            failure.append(e)
+
+    def header_reader(src, out_q):                    # host tensors over gloo: the only receives that run in helper threads
+        try:
+            hdr = torch.zeros(1, dtype=torch.int64)
             while True:
-                free.acquire()                          # a buffer the sink has given back (ring_slots of them)
-                dist.recv(hdr, src=src)
-                n = int(hdr.item())
+                dist.recv(hdr, src=src, group=hgroup)
+                n = int(hdr[0])
+                out_q.put(n)
                 if n == 0:
-                    out_q.put(None)
                     return
-                if n > page_bytes:
-                    raise ValueError("rank %d announced a page of %d bytes, page_bytes is %d" % (src, n, page_bytes))
-                slot = k % ring_slots
-                k += 1
-                if len(ring) <= slot:
-                    ring.append(torch.empty(page_bytes, dtype=torch.uint8, device=dev))
-                view = ring[slot][:n]
-                dist.recv(view, src=src)
-                out_q.put(view)
-        except BaseException as e:                      # noqa: BLE001 - handed to the thread that drains
+        except BaseException as e:                    # noqa: BLE001
             out_q.put(e)
 
-    rx = {}
-    for r in range(world):
-        if r != dst:
-            qr, free = queue.Queue(), threading.Semaphore(ring_slots)
-            th = threading.Thread(target=receiver, args=(r, qr, free), daemon=True)
+    senders = [r for r in range(world) if r != dst]
+    sizes = {r: queue.Queue() for r in senders}
+    for r in senders:
+        threading.Thread(target=header_reader, args=(r, sizes[r]), daemon=True).start()
+
+    def next_size(r, block):
+        try:
+            n = sizes[r].get(block)
+        except queue.Empty:
+            return None
+        if isinstance(n, BaseException):
+            raise n
+        if n > page_bytes:
+            raise ValueError("rank %d announced a page of %d bytes, page_bytes is %d" % (r, n, page_bytes))
+        return n
+
+    if polled:
+        # one thread: receives posted as headers arrive and slots are free, completion polled, the sink fed in rank order
+        wrap = (lambda w: w) if dist.get_backend() != "gloo" else _ThreadedWork
+        ring = {r: [] for r in senders}               # buffers, allocated when first used
+        free = {r: list(range(slots)) for r in senders}
+        inflight = {r: [] for r in senders}           # (work, view, slot) in posting order
+        closed = {r: False for r in senders}          # the closing header has been read
+
+        def post():
+            posted = False
+            for r in senders:
+                while free[r] and not closed[r]:
+                    n = next_size(r, False)
+                    if n is None:
+                        break
+                    if n == 0:
+                        closed[r] = True
+                        break
+                    slot = free[r].pop(0)
+                    while len(ring[r]) <= slot:
+                        ring[r].append(torch.empty(page_bytes, dtype=torch.uint8, device=dev))
+                    view = ring[r][slot][:n]
+                    inflight[r].append((wrap(dist.irecv(view, src=r)), view, slot))
+                    posted = True
+            return posted
+
+        for r in range(world):                        # rank (= column) order, the root's own pages in their place
+            if r == dst:
+                for t in pages:
+                    post()
+                    if int(t.numel()):
+                        deliver(t)
+                continue
+            while True:
+                progressed = post()
+                if inflight[r] and inflight[r][0][0].is_completed():
+                    _, view, slot = inflight[r].pop(0)
+                    deliver(view)
+                    free[r].append(slot)
+                    continue
+                if closed[r] and not inflight[r]:
+                    break
+                if not progressed:
+                    t0 = time.time()
+                    time.sleep(50e-6)
+                    blocked += time.time() - t0
+    else:
+        # a receiver thread per sender (gloo: a receive only progresses inside wait(), and a wait with a timeout closes the pair)
+        def receiver(src, out_q, free_sem):
+            try:
+                ring, k = [], 0
+                while True:
+                    free_sem.acquire()                  # a buffer the sink has given back
+                    n = next_size(src, True)
+                    if n == 0:
+                        out_q.put(None)
+                        return
+                    slot = k % slots
+                    k += 1
+                    if len(ring) <= slot:
+                        ring.append(torch.empty(page_bytes, dtype=torch.uint8, device=dev))
+                    view = ring[slot][:n]
+                    dist.recv(view, src=src)
+                    out_q.put(view)
+            except BaseException as e:                  # noqa: BLE001 - handed to the thread that drains
+                out_q.put(e)
+
+        rx = {}
+        for r in senders:
+            qr, free_sem = queue.Queue(), threading.Semaphore(slots)
+            th = threading.Thread(target=receiver, args=(r, qr, free_sem), daemon=True)
             th.start()
-            rx[r] = (qr, free, th)
-    for r in range(world):                            # rank (= column) order, the root's own pages in their place
-        if r == dst:
-            for t in pages:
-                if int(t.numel()):
-                    sink(t)
-                    total += int(t.numel())
-            continue
-        qr, free, th = rx[r]
-        while True:
-            t0 = time.time()
-            item = qr.get()
-            blocked += time.time() - t0
-            if item is None:
-                break
-            if isinstance(item, BaseException):
-                raise item
-            sink(item)
-            total += int(item.numel())
-            free.release()
-        th.join()
+            rx[r] = (qr, free_sem, th)
+        for r in range(world):
+            if r == dst:
+                for t in pages:
+                    if int(t.numel()):
+                        deliver(t)
+                continue
+            qr, free_sem, th = rx[r]
+            while True:
+                t0 = time.time()
+                item = qr.get()
+                blocked += time.time() - t0
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                deliver(item)
+                free_sem.release()
+            th.join()
     if stats is not None:
-        stats.update(bytes=total, seconds=time.time() - t_begin, blocked_s=blocked)
+        stats.update(bytes=total, seconds=time.time() - t_begin, blocked_s=blocked, root_slots_per_sender=slots, polled=bool(polled))
+    if failure:
+        raise failure[0]
     return total
 
 

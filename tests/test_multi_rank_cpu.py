@@ -134,7 +134,7 @@ def test_two_ranks_import_their_partitions_and_concat():
     assert nc0 + nc1 > ncells_full          # the replayed intervals exist in both partitions
 
 
-def _paged_worker(rank, world, port, q, dst=0):
+def _paged_worker(rank, world, port, q, dst=0, polled=None, root_ring_bytes=8 << 30, fail_at=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -160,9 +160,21 @@ def _paged_worker(rank, world, port, q, dst=0):
         got = []
         live = {"max": 0}
         stats = {}
-        total = gdist.paged_concat(pages(), lambda t: got.append(bytes(t.numpy().tobytes())), page_bytes=1000, dst=dst, ring_slots=3, stats=stats)
+        def sink(t):
+            if fail_at is not None and len(got) == fail_at:
+                raise RuntimeError("sink failed at page %d" % fail_at)
+            got.append(bytes(t.numpy().tobytes()))
+        try:
+            total = gdist.paged_concat(pages(), sink, page_bytes=1000, dst=dst, ring_slots=3, stats=stats, polled=polled, root_ring_bytes=root_ring_bytes)
+        except RuntimeError as e:
+            assert rank == dst and fail_at is not None and "sink failed" in str(e)
+            q.put((rank, mine, got, -1))
+            return
         assert total == sum(len(m) for m in mine) if rank != dst else True
         assert stats["bytes"] == total and stats["seconds"] >= stats["blocked_s"] >= 0.0
+        if rank == dst:
+            assert stats["polled"] == bool(polled)
+            assert stats["root_slots_per_sender"] == gdist.root_ring_slots(world, 1000, 3, root_ring_bytes)
         q.put((rank, mine, got, total))
     finally:
         dist.destroy_process_group()
@@ -186,6 +198,56 @@ def test_paged_concat_is_ordered_and_bounded():
     assert res[0][2] == want and len(want) == 5 + 13
     assert res[0][3] == sum(len(p) for p in want)
     assert res[1][2] == [] and res[2][2] == []
+
+
+def _run_paged(world, **kw):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    dst = kw.pop("dst", 0)
+    procs = [ctx.Process(target=_paged_worker, args=(r, world, port, q, dst), kwargs=kw) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("dst", [0, 1])
+def test_paged_concat_polled_root_is_single_threaded_on_the_data_backend(dst):
+    """The root flavour "nccl" uses: ONE thread posts the receives of all senders as their headers (a gloo side group) arrive,
+    polls work.is_completed() and feeds the sink in rank order.  Under gloo a receive only completes inside wait(), so the work
+    objects are wrapped (dist._ThreadedWork) - the scheduling code is the one that runs over RCCL."""
+    res = _run_paged(3, dst=dst, polled=True)
+    want = [pg for _, mine, _, _ in res for pg in mine]
+    assert res[dst][2] == want and len(want) == 5 + 13
+    assert res[dst][3] == sum(len(p) for p in want)
+    assert all(res[r][2] == [] for r in range(3) if r != dst)
+
+
+@pytest.mark.parametrize("polled", [False, True])
+def test_paged_concat_root_rings_follow_the_byte_budget(polled):
+    """root_ring_bytes = 2 500 with two senders and 1 000-byte pages: one receive buffer per sender instead of ring_slots = 3 - the
+    stream is the same (the worker checks stats["root_slots_per_sender"] against dist.root_ring_slots)"""
+    from genomicsdb_amd import dist as gdist
+    assert gdist.root_ring_slots(3, 1000, 3, 2500) == 1 and gdist.root_ring_slots(3, 1000, 3, 4000) == 2
+    assert gdist.root_ring_slots(8, 1 << 30, 3, 8 << 30) == 1 and gdist.root_ring_slots(8, 256 << 20, 3, 8 << 30) == 3
+    assert gdist.root_ring_slots(8, 1 << 30, 3, 0) == 1          # never below one buffer per sender
+    res = _run_paged(3, polled=polled, root_ring_bytes=2500)
+    want = [pg for _, mine, _, _ in res for pg in mine]
+    assert res[0][2] == want
+
+
+@pytest.mark.parametrize("polled", [False, True])
+def test_paged_concat_a_failing_sink_does_not_strand_the_senders(polled):
+    """the sink raises at its 8th page: the root keeps receiving (and dropping) until every rank has closed its stream, then
+    re-raises; the senders finish normally instead of hanging in wait()"""
+    res = _run_paged(3, polled=polled, fail_at=7)
+    assert res[0][3] == -1 and len(res[0][2]) == 7
+    assert res[1][3] == 0 and res[2][3] == sum(len(p) for p in res[2][1]) > 0
 
 
 def test_paged_concat_to_another_root_keeps_rank_order():
