@@ -14,7 +14,7 @@ class IntervalStats(ctypes.Structure):
                 ("err_bits", ctypes.c_uint32), ("ms_sweep", ctypes.c_float), ("ms_site", ctypes.c_float),
                 ("ms_size", ctypes.c_float), ("ms_write", ctypes.c_float), ("ms_total", ctypes.c_float),
                 ("ms_write_kernel_avg", ctypes.c_float),
-                ("num_record_types", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+                ("num_record_types", ctypes.c_int32), ("resolved_entry_bytes", ctypes.c_int32),
                 ("num_text_slots", ctypes.c_int64), ("text_pool_bytes", ctypes.c_int64),
                 ("num_remap_elements", ctypes.c_uint64), ("bytes_compressed", ctypes.c_uint64), ("ms_compress", ctypes.c_float),
                 ("reserved1", ctypes.c_int32), ("gt_profile_stats", ctypes.c_uint64 * 6)]

@@ -246,7 +246,7 @@ int gdbamd_engine_run_interval(void* e, int64_t qb, int64_t qe, uint64_t arena_b
       out->pages = s.pages; out->write_launches = s.write_launches; out->err_bits = s.err_bits;
       out->ms_sweep = s.ms_sweep; out->ms_site = s.ms_site; out->ms_size = s.ms_size; out->ms_write = s.ms_write; out->ms_total = s.ms_total;
       out->ms_write_kernel_avg = s.ms_write_kernel_avg;
-      out->num_record_types = s.num_record_types; out->reserved0 = 0;
+      out->num_record_types = s.num_record_types; out->resolved_entry_bytes = s.resolved_entry_bytes;
       out->num_text_slots = s.num_text_slots; out->text_pool_bytes = s.text_pool_bytes;
       out->num_remap_elements = s.num_remap_elements;
       out->bytes_compressed = s.bytes_compressed; out->ms_compress = s.ms_compress; out->reserved1 = 0;

@@ -35,6 +35,7 @@ struct IntervalStats {
   int write_launches = 0;
   // entry text table of the interval
   int num_record_types = 0;       // distinct (FORMAT mask, #merged alleles, remap flags)
+  int resolved_entry_bytes = 0;   // bytes per (record, sample) of the resolved matrix: 8, 5 (compact layout) or 0 (matrix-free / event paths)
   int64_t num_text_slots = 0;     // (cell, type) + (record, variant call) + no-call texts
   int64_t text_pool_bytes = 0;
   uint64_t num_remap_elements = 0; // sum over re-indexed records of (calls with PL) x (merged genotypes)

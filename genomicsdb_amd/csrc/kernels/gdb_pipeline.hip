@@ -132,7 +132,12 @@ inline int asm_path_wanted() { const char* e = getenv("GDBAMD_ASM_PATH"); return
 // sizing pass: 3 = k_assemble_size3 in rounds of 8 records (default), 16 = rounds of 16, 0 = k_assemble_size
 inline int size3_rounds() { const char* e = getenv("GDBAMD_SIZE3"); const int v = e && *e ? atoi(e) : 8; return v == 0 ? 0 : v >= 16 ? 16 : 8; }
 inline bool res_chunk_major() { static const bool v = []() { const char* e = getenv("GDBAMD_RES_LAYOUT"); return e && *e == '1'; }(); return v; }   // (measured: no difference; record-major stays)
+// compact resolved matrix (ResMatrix): 1 (default) whenever the interval allows it, 0 never (A/B runs); the check mode of the sizing
+// kernels compares the wide layout word for word, so it keeps that one
+inline bool size3_check();
+inline bool res_compact_wanted();
 inline bool size3_check() { const char* e = getenv("GDBAMD_SIZE3_CHECK"); return e && *e && *e != '0'; }
+inline bool res_compact_wanted() { if (size3_check()) return false; const char* e = getenv("GDBAMD_RES_COMPACT"); return !(e && *e == '0'); }
 inline int fill_run_length() { const char* e = getenv("GDBAMD_RUN_F"); return e && *e ? std::max(1, atoi(e)) : 128; }
 inline int write2_run_length() { const char* e = getenv("GDBAMD_RUN_W2"); return e && *e ? std::max(1, atoi(e)) : 64; }
 // wavefronts (= neighbouring 64-sample chunks) per workgroup of the page assembly: 4 measured best on the store-only model
@@ -1077,6 +1082,7 @@ struct SlotTable {
   // heavy slots are numbered in FILL order (cell by cell, record by record: hoff[cell] + k - k_lo[cell]), so that a walker names the
   // slot of a heavy call from its registers, without the fill-order -> (record, row)-order table of earlier rounds
   const int64_t* hoff; const int32_t* k_lo; int64_t c_base;
+  unsigned int* over255;  // [kBumpShards] set by pass 0 when an entry is longer than 255 bytes (the compact resolved matrix keeps lengths in a byte)
 };
 // PASS 0: ONE run of the field emitters gives the length of the text and, when it fits kSlotStride bytes (nearly always),
 // the text itself: formatted into a lane-private LDS strip, it leaves as 16-byte stores into the lane's inline slot.
@@ -1137,6 +1143,7 @@ template <int STRIPW> __device__ __forceinline__ void slot_place_long(const Slot
   constexpr uint32_t cap = (uint32_t)(STRIPW - 1) * 4u;
   const bool is_long = active && len > st.inline_max;
   if (!__any((int)is_long)) return;                             // uniform
+  if (__any((int)(active && len > 255u)) && (threadIdx.x & 63) == 0) atomicOr(&st.over255[blockIdx.x & (kBumpShards - 1)], 1u);
   const bool fits = is_long && st.bump_cap != 0u && len <= cap;
   const uint32_t units = fits ? (len + 15u) >> 4 : 0u;
   const uint32_t incl = wave_inclusive_scan_dpp(units);
@@ -1476,10 +1483,27 @@ __device__ __forceinline__ int64_t readlane64(int64_t v, int l) {
 // BCF kernels read); res_rows = #records of the matrix: CHUNK-major - the rows a wavefront writes (sizing) and reads (page assembly) along
 // its run of records lie 512 bytes apart instead of 8 KB (GDBAMD_RES_LAYOUT=1; measured on c2: no difference, so record-major is what runs).
 __device__ __forceinline__ int64_t res_row(int64_t k_rel, int ch, int nchunks, int64_t res_rows) { return res_rows ? (int64_t)ch * res_rows + k_rel : k_rel * nchunks + ch; }
+// The resolved matrix in one of two layouts.  wide: (pool offset, length) as a uint2 per (record, sample) - 8 bytes.  compact
+// (text output, chosen per interval when no entry text is longer than 255 bytes - every window of the c2 workload): the pool offsets
+// as a plane of u32 and the lengths as a plane of u8 - 5 bytes per pair: 3 of 8 bytes less written by the sizing pass and read
+// back by the page pass (8.2 -> 5.1 GB per 1 Mb window of 1 000 samples, each way).  BCF2 and the piece / event paths keep the wide one.
+struct ResMatrix {
+  uint2* wide;        // nullptr: compact, or no matrix at all (sizes only)
+  uint32_t* off;      // compact planes (nullptr: wide)
+  uint8_t* len8;
+  __device__ __forceinline__ bool any() const { return wide != nullptr || off != nullptr; }
+  __device__ __forceinline__ void store(int64_t at, uint2 d) const {
+    if (off) { off[at] = d.x; len8[at] = (uint8_t)d.y; } else wide[at] = d;
+  }
+  __device__ __forceinline__ uint2 load(int64_t at) const {
+    if (off) return make_uint2(off[at], (uint32_t)len8[at]);
+    return wide[at];
+  }
+};
 // chunk_size == nullptr: resolve only (per-page matrix when the whole interval's matrix would not fit the budget)
 __global__ void __launch_bounds__(kAsmRows)
 k_assemble_size(AsmCtx a, const int32_t* __restrict__ order, int64_t n, int32_t N, int nchunks, int run, uint64_t* __restrict__ chunk_size,
-                uint2* __restrict__ resolved, int64_t resolved_base, int64_t res_rows) {
+                ResMatrix resolved, int64_t resolved_base, int64_t res_rows) {
   // chunk is the fast grid dimension: the wavefronts in flight work on the same few records (one 44 KB line is written
   // by its 16 chunk wavefronts at about the same time: DRAM pages, TLB entries and shared boundary lines stay hot)
   const int64_t ib = (int64_t)(blockIdx.x / (unsigned)nchunks) * run;
@@ -1513,7 +1537,7 @@ k_assemble_size(AsmCtx a, const int32_t* __restrict__ order, int64_t n, int32_t 
         d = cur;
       }
       prev_k = k;
-      if (resolved) resolved[res_row(k - resolved_base, ch, nchunks, res_rows) * kAsmRows + lane] = d;
+      if (resolved.any()) resolved.store(res_row(k - resolved_base, ch, nchunks, res_rows) * kAsmRows + lane, d);
       const uint32_t total = wave_total(wave_inclusive_scan_dpp(d.y));
       if (lane == jj) my_total += total;
     }
@@ -1533,7 +1557,7 @@ k_assemble_size(AsmCtx a, const int32_t* __restrict__ order, int64_t n, int32_t 
 // Bit-identical output (GDBAMD_SIZE3_CHECK=1 runs both and compares).
 template <int R> __global__ void __launch_bounds__(kAsmRows)
 k_assemble_size3(AsmCtx a, const int32_t* __restrict__ order, int64_t n, int32_t N, int nchunks, int run, uint64_t* __restrict__ chunk_size,
-                 uint2* __restrict__ resolved, int64_t resolved_base, int64_t res_rows) {
+                 ResMatrix resolved, int64_t resolved_base, int64_t res_rows) {
   __shared__ int64_t ss[kAsmRows];                     // the batch's record starts
   __shared__ int32_t ks[kAsmRows];                     // ... and record indices
   __shared__ uint32_t diff[kAsmRows + 1];              // difference array of the chunk sizes over the batch
@@ -1606,7 +1630,7 @@ k_assemble_size3(AsmCtx a, const int32_t* __restrict__ order, int64_t n, int32_t
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         // ---- phase 2: the rows ----
-        if (resolved) {
+        if (resolved.any()) {
           int q = 0, nxt = ra;                         // (every lane's first piece begins at ra)
           uint2 row = make_uint2(0, 0);
           for (int jj = ra; jj < rb; ++jj) {           // uniform
@@ -1616,7 +1640,7 @@ k_assemble_size3(AsmCtx a, const int32_t* __restrict__ order, int64_t n, int32_t
               nxt = q < np ? (int)pl_at[q * kAsmRows + lane] : 255;
             }
             const int64_t k = __builtin_amdgcn_readlane(my_k, jj);
-            resolved[res_row(k - resolved_base, ch, nchunks, res_rows) * kAsmRows + lane] = row;
+            resolved.store(res_row(k - resolved_base, ch, nchunks, res_rows) * kAsmRows + lane, row);
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -1659,7 +1683,7 @@ template <int WAVES> __device__ __forceinline__ int64_t xcd_aware_unit(int64_t t
   return u < total_units ? u : -1;
 }
 template <int WAVES, int kWaveLds> __global__ void __launch_bounds__(kAsmRows * WAVES)
-k_assemble_write(const char* __restrict__ pool, const char* __restrict__ pool_ovf, const uint32_t* __restrict__ prefix_len, const uint2* __restrict__ resolved, int64_t resolved_base,
+k_assemble_write(const char* __restrict__ pool, const char* __restrict__ pool_ovf, const uint32_t* __restrict__ prefix_len, const ResMatrix resolved, int64_t resolved_base,
                  const int32_t* __restrict__ order, int64_t n, int nchunks, int run, const uint64_t* __restrict__ chunk_off, uint64_t page_base,
                  char* __restrict__ arena, int xcd_aware, int64_t res_rows) {
   const int64_t unit = xcd_aware_unit<WAVES>(((n + run - 1) / run) * (int64_t)nchunks, xcd_aware);
@@ -1682,10 +1706,10 @@ k_assemble_write(const char* __restrict__ pool, const char* __restrict__ pool_ov
       my_k = order[i0 + lane];
       my_dst = (int64_t)(chunk_off[(int64_t)my_k * nchunks + ch] - page_base) + (ch == 0 ? prefix_len[my_k] : 0u);
     }
-    uint2 d_next = resolved[res_row((int64_t)__builtin_amdgcn_readlane(my_k, 0) - resolved_base, ch, nchunks, res_rows) * kAsmRows + lane];
+    uint2 d_next = resolved.load(res_row((int64_t)__builtin_amdgcn_readlane(my_k, 0) - resolved_base, ch, nchunks, res_rows) * kAsmRows + lane);
     for (int jj = 0; jj < cnt; ++jj) {                      // uniform
       const uint2 d = d_next;
-      if (jj + 1 < cnt) d_next = resolved[res_row((int64_t)__builtin_amdgcn_readlane(my_k, jj + 1) - resolved_base, ch, nchunks, res_rows) * kAsmRows + lane];
+      if (jj + 1 < cnt) d_next = resolved.load(res_row((int64_t)__builtin_amdgcn_readlane(my_k, jj + 1) - resolved_base, ch, nchunks, res_rows) * kAsmRows + lane);
       const uint32_t len = d.y;
       if (len && (d.x != cur.x || len != cur.y)) {          // the sample moved to another slot: fetch its text
         cur = d;
@@ -3660,6 +3684,8 @@ struct DevicePipeline::Impl {
   DevBuf<long long> carry_last; DevBuf<uint64_t> carry_keys, carry_sorted; int64_t carried_cells = 0;
   DevBuf<uint2> chk_resolved; DevBuf<uint64_t> chk_sizes; DevBuf<unsigned long long> chk_count;   // GDBAMD_SIZE3_CHECK
   DevBuf<uint2> resolved;          // (pool offset, length) of every (record, sample): whole interval, or one page when that exceeds the budget
+  DevBuf<uint32_t> res_off; DevBuf<uint8_t> res_len8;   // the same matrix in its compact layout (ResMatrix): offsets and byte lengths as two planes
+  DevBuf<unsigned int> slot_over;  // [kBumpShards] "an entry text is longer than 255 bytes" (pass 0 of the slot kernels)
   DevBuf<uint32_t> type_occ;
   DevBuf<uint32_t> untabled, ubase; DevBuf<int32_t> urec, iota, order; DevBuf<uint32_t> order_keys, order_keys_sorted;
   DevBuf<uint64_t> tmask; DevBuf<uint32_t> nslots, tbase, slot_len, slot_units, slot_off; DevBuf<uint2> slot_desc; DevBuf<char> pool, pool_ovf;
@@ -3677,7 +3703,7 @@ struct DevicePipeline::Impl {
     std::vector<uint64_t> rec_off;
     IntervalStats stats;
     SiteCtx sx; EntryCtx ex; RowIndex ri; SiteOut so; RecordTable rec; AsmCtx ac; PieceCtx pc2;
-    bool resolved_whole = false, piece_path = false; int asm_path = 0, NT = 0; int64_t P_rows = 0;
+    bool resolved_whole = false, piece_path = false, res_compact = false; int asm_path = 0, NT = 0; int64_t P_rows = 0;
     bool bcf = false; int bcf_F = 0; BcfLayout lay{nullptr, nullptr, nullptr, nullptr};
     bool events = false; int evrun = 0; EventBuf eb{nullptr, nullptr, nullptr, 0};
   } iv;
@@ -5112,21 +5138,21 @@ std::string DevicePipeline::cells_text(int64_t qb, int64_t qe, int mode, int ind
 // the sizing / resolution pass of `n` records in `order` (piece-wise kernel by default; GDBAMD_SIZE3=0: the record-by-record one).
 // size_slots: elements of chunk_size (the check mode compares them all)
 static void launch_assemble_size(DevicePipeline::Impl& S, hipStream_t st, dim3 grid, const AsmCtx& ac, const int32_t* order, int64_t n, int32_t N, int nchunks, int run,
-                                 uint64_t* chunk_size, size_t size_slots, uint2* resolved, int64_t resolved_base, int64_t res_rows) {
+                                 uint64_t* chunk_size, size_t size_slots, ResMatrix resolved, int64_t resolved_base, int64_t res_rows) {
   const int rounds = size3_rounds();
   if (rounds == 0 || run > 64 * 1024) { hipLaunchKernelGGL(k_assemble_size, grid, dim3(kAsmRows), 0, st, ac, order, n, N, nchunks, run, chunk_size, resolved, resolved_base, res_rows); return; }
   if (rounds >= 16) hipLaunchKernelGGL((k_assemble_size3<16>), grid, dim3(kAsmRows), 0, st, ac, order, n, N, nchunks, run, chunk_size, resolved, resolved_base, res_rows);
   else hipLaunchKernelGGL((k_assemble_size3<8>), grid, dim3(kAsmRows), 0, st, ac, order, n, N, nchunks, run, chunk_size, resolved, resolved_base, res_rows);
   if (!size3_check()) return;
-  const size_t nres = resolved ? (size_t)n * (size_t)nchunks * kAsmRows : 0;
+  const size_t nres = resolved.wide ? (size_t)n * (size_t)nchunks * kAsmRows : 0;     // (the check runs with the wide layout: res_compact_wanted())
   S.chk_count.ensure(1);
   HIP_CHECK(hipMemsetAsync(S.chk_count.p, 0, sizeof(unsigned long long), st));
   if (nres) S.chk_resolved.ensure(nres);
   if (chunk_size) { S.chk_sizes.ensure(size_slots); HIP_CHECK(hipMemcpyAsync(S.chk_sizes.p, chunk_size, size_slots * sizeof(uint64_t), hipMemcpyDeviceToDevice, st)); }   // (records outside `order` keep what they had)
-  hipLaunchKernelGGL(k_assemble_size, grid, dim3(kAsmRows), 0, st, ac, order, n, N, nchunks, run, chunk_size ? S.chk_sizes.p : (uint64_t*)nullptr, nres ? S.chk_resolved.p : (uint2*)nullptr,
-                     resolved_base, res_rows);
+  hipLaunchKernelGGL(k_assemble_size, grid, dim3(kAsmRows), 0, st, ac, order, n, N, nchunks, run, chunk_size ? S.chk_sizes.p : (uint64_t*)nullptr,
+                     ResMatrix{nres ? S.chk_resolved.p : (uint2*)nullptr, nullptr, nullptr}, resolved_base, res_rows);
   // (the rows of the records in `order` only: with a base, row (k - base); the launch sites pass records [base, base + n))
-  if (nres) hipLaunchKernelGGL(k_compare_words, dim3(blocks_for((int64_t)nres * 2)), dim3(kBlock), 0, st, (const uint32_t*)resolved, (const uint32_t*)S.chk_resolved.p, (int64_t)nres * 2, S.chk_count.p);
+  if (nres) hipLaunchKernelGGL(k_compare_words, dim3(blocks_for((int64_t)nres * 2)), dim3(kBlock), 0, st, (const uint32_t*)resolved.wide, (const uint32_t*)S.chk_resolved.p, (int64_t)nres * 2, S.chk_count.p);
   if (chunk_size) hipLaunchKernelGGL(k_compare_words, dim3(blocks_for((int64_t)size_slots * 2)), dim3(kBlock), 0, st, (const uint32_t*)chunk_size, (const uint32_t*)S.chk_sizes.p, (int64_t)size_slots * 2, S.chk_count.p);
   const unsigned long long bad = S.read_back(S.chk_count.p);
   if (bad) throw GenomicsDBDeviceException("GDBAMD_SIZE3_CHECK: the piece-wise sizing pass differs from the record-by-record one in " + std::to_string(bad) + " words");
@@ -5453,6 +5479,8 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   // wavefronts) is used once an interval has shown long texts; GDBAMD_SLOT_STRIP = 128 / 256 forces one.
   S.slot_bump.ensure(kBumpShards * 4);
   HIP_CHECK(hipMemsetAsync(S.slot_bump.p, 0, kBumpShards * 4 * sizeof(unsigned int), st));
+  S.slot_over.ensure(kBumpShards);
+  HIP_CHECK(hipMemsetAsync(S.slot_over.p, 0, kBumpShards * sizeof(unsigned int), st));
   bool wide = S.long_texts_seen;
   if (const char* e = getenv("GDBAMD_SLOT_STRIP")) wide = atoi(e) >= 256;
   // the overflow pool in kBumpShards equal parts; a part holds what its shard needed at most so far, and an eighth more
@@ -5460,7 +5488,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   if (wide) S.pool_ovf.ensure(std::max<size_t>((size_t)kBumpShards * ((size_t)S.pool_ovf_need * 16 + ((size_t)S.pool_ovf_need * 16 >> 3)), (size_t)1 << 20) + 64);
   SlotTable stt{S.slot_len.p, S.slot_off.p, S.pool.p, S.pool_ovf.p, (uint32_t)kMaxTypes, (uint32_t)(kMaxTypes + SL), (uint32_t)(kMaxTypes + SL + (uint64_t)T), S.slot_off.p, S.slot_bump.p,
                 wide ? shard_units_of(S.pool_ovf.cap) : 0u, (int32_t)S.ctx_slot, pl.bcf_mode, pl.bcf_mode ? (uint32_t)kSlotStride : (uint32_t)kInlineText,
-                (const int64_t*)S.hoff.p, (const int32_t*)S.k_lo.p, c_base};
+                (const int64_t*)S.hoff.p, (const int32_t*)S.k_lo.p, c_base, S.slot_over.p};
   STAGE("k_slots<0>");
 #define GDB_SLOT_KERNELS(PASSN, W) do { \
   hipLaunchKernelGGL((k_slots_nocall<PASSN, W>), dim3(1), dim3(kMaxTypes), 0, st, stt, so, S.type_rep.p, ntypes, S.err.p); \
@@ -5473,8 +5501,10 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
     hipLaunchKernelGGL(k_slot_cells, dim3(blocks_for(CW)), dim3(kBlock), 0, st, (const uint32_t*)S.tbase.p, (const uint32_t*)S.nslots.p, CW, S.slot_cell.p);
   }
   if (wide) GDB_SLOT_KERNELS(0, kStripWordsWide); else GDB_SLOT_KERNELS(0, kStripWords);
-  unsigned int bump_sh[kBumpShards * 4];
-  S.read_back_many({{bump_sh, S.slot_bump.p, sizeof(bump_sh)}});
+  unsigned int bump_sh[kBumpShards * 4], over_sh[kBumpShards];
+  S.read_back_many({{bump_sh, S.slot_bump.p, sizeof(bump_sh)}, {over_sh, S.slot_over.p, sizeof(over_sh)}});
+  bool any_over255 = false;
+  for (int sh = 0; sh < kBumpShards; ++sh) any_over255 |= over_sh[sh] != 0;
   uint64_t left_texts = 0, long_texts = 0, shard_need = 0, total_units = 0;   // (per shard: units taken - also the ones that ran past its part - plus units still wanted)
   for (int sh = 0; sh < kBumpShards; ++sh) {
     left_texts += bump_sh[sh * 4 + 1]; long_texts += bump_sh[sh * 4 + 3];
@@ -5530,6 +5560,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   hipLaunchKernelGGL(k_slot_desc, dim3(blocks_for((int64_t)NS)), dim3(kBlock), 0, st, S.slot_len.p, S.slot_off.p, (int64_t)NS, asm_path == 1 ? (uint2*)nullptr : S.slot_desc.p,
                      pl.bcf_mode ? (char*)nullptr : S.pool.p, stt.inline_max);
   stats.num_record_types = ntypes;
+  stats.resolved_entry_bytes = (asm_path == 1 || asm_path == 3 || events_enabled()) ? 0 : ((!pl.bcf_mode && asm_path == 0 && !any_over255 && res_compact_wanted()) ? 5 : 8);
   stats.num_text_slots = (int64_t)NS;
   stats.text_pool_bytes = (int64_t)(NS * kSlotStride + pool_units * 16);
   STAGE("k_walk_window");
@@ -5553,7 +5584,13 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   bool use_events = false;
   EventBuf ebuf{nullptr, nullptr, nullptr, 0};
   const bool resolved_whole = !piece_path && (pl.bcf_mode || (resolved_bytes <= resolved_budget_bytes() && !(events_enabled() && ((1 << order_block_log2()) % event_run_length()) == 0)));
-  if (resolved_whole) S.resolved.ensure((size_t)P * nchunks * kAsmRows);
+  // compact layout: text output through the default kernels, no entry longer than a byte can say
+  const bool res_compact = !pl.bcf_mode && asm_path == 0 && !events_enabled() && !any_over255 && res_compact_wanted();
+  if (resolved_whole) {
+    if (res_compact) { S.res_off.ensure((size_t)P * nchunks * kAsmRows); S.res_len8.ensure((size_t)P * nchunks * kAsmRows); }
+    else S.resolved.ensure((size_t)P * nchunks * kAsmRows);
+  }
+  auto res_view = [&S, res_compact]() { return res_compact ? ResMatrix{nullptr, S.res_off.p, S.res_len8.p} : ResMatrix{S.resolved.p, nullptr, nullptr}; };
   S.max_record.ensure(1);
   HIP_CHECK(hipMemsetAsync(S.max_record.p, 0, sizeof(unsigned long long), st));
   BcfLayout lay{nullptr, nullptr, nullptr, nullptr};
@@ -5568,7 +5605,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
       hipLaunchKernelGGL(k_size2, dim3((unsigned)size2_units), dim3(kAsmRows), 0, st, pc2, nchunks, S.chunk_size.p);
       hipLaunchKernelGGL(k_fill2, dim3(fill_units), dim3(kAsmRows), 0, st, pc2, (const uint2*)S.slot_desc.p, (const int32_t*)S.order.p, P, nchunks, frun, S.resolved.p, (int64_t)0);
     } else
-    launch_assemble_size(S, st, dim3(run_blocks * (unsigned)nchunks), ac, S.order.p, P, N, nchunks, run, (uint64_t*)nullptr, 0, S.resolved.p, (int64_t)0, (int64_t)0);
+    launch_assemble_size(S, st, dim3(run_blocks * (unsigned)nchunks), ac, S.order.p, P, N, nchunks, run, (uint64_t*)nullptr, 0, ResMatrix{S.resolved.p, nullptr, nullptr}, (int64_t)0, (int64_t)0);
     S.bcf_part.ensure(nchunk_total * (size_t)bcf_F + 1); S.bcf_fmeta.ensure((size_t)P * bcf_F + 1); S.bcf_foff.ensure((size_t)P * bcf_F + 1); S.bcf_lindiv.ensure((size_t)P + 1);
     S.bcf_rec_size.ensure((size_t)P + 2);
     lay = BcfLayout{S.bcf_fmeta.p, S.bcf_foff.p, S.bcf_lindiv.p, S.bcf_rec_size.p};
@@ -5608,7 +5645,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
     if (asm_path == 2 && resolved_whole)
       hipLaunchKernelGGL(k_fill2, dim3(fill_units), dim3(kAsmRows), 0, st, pc2, (const uint2*)S.slot_desc.p, (const int32_t*)S.order.p, P, nchunks, frun, S.resolved.p, (int64_t)0);
   } else
-  launch_assemble_size(S, st, dim3(run_blocks * (unsigned)nchunks), ac, S.order.p, P, N, nchunks, run, S.chunk_size.p, nchunk_total, resolved_whole ? S.resolved.p : nullptr, (int64_t)0, res_chunk_major() ? P : (int64_t)0);
+  launch_assemble_size(S, st, dim3(run_blocks * (unsigned)nchunks), ac, S.order.p, P, N, nchunks, run, S.chunk_size.p, nchunk_total, resolved_whole ? res_view() : ResMatrix{nullptr, nullptr, nullptr}, (int64_t)0, res_chunk_major() ? P : (int64_t)0);
   HIP_CHECK(hipMemsetAsync(S.chunk_size.p + nchunk_total, 0, sizeof(uint64_t), st));
   S.excl_scan(S.chunk_size.p, S.chunk_off.p, nchunk_total + 1);
   STAGE("k_gather_record_offsets");
@@ -5630,7 +5667,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   if (eb) throw GenomicsDBDeviceException(err_bits_text(eb));
   S.iv.max_record_bytes = totals[1];
   S.iv.P = P; S.iv.nchunks = nchunks; S.iv.kp = 0;
-  S.iv.sx = sx; S.iv.ex = ex; S.iv.ri = ri; S.iv.so = so; S.iv.rec = rec; S.iv.ac = ac; S.iv.pc2 = pc2; S.iv.piece_path = piece_path; S.iv.asm_path = asm_path; S.iv.resolved_whole = resolved_whole; S.iv.P_rows = P;
+  S.iv.sx = sx; S.iv.ex = ex; S.iv.ri = ri; S.iv.so = so; S.iv.rec = rec; S.iv.ac = ac; S.iv.pc2 = pc2; S.iv.piece_path = piece_path; S.iv.asm_path = asm_path; S.iv.resolved_whole = resolved_whole; S.iv.res_compact = res_compact; S.iv.P_rows = P;
   S.iv.bcf = pl.bcf_mode != 0; S.iv.bcf_F = bcf_F; S.iv.lay = lay;
   S.iv.events = use_events; S.iv.evrun = ebuf.run; S.iv.eb = ebuf;
   S.iv.active = true;
@@ -5762,18 +5799,20 @@ bool DevicePipeline::begin_page(uint64_t arena_bytes, int arena_idx, PageTicket*
     ticket->arena = ai; ticket->dev = arena; ticket->nbytes = page_bytes; ticket->done_event = (void*)w[3]; S.queue_compression(ai, arena, page_bytes);
     return true;
   }
+  const auto res_view = [&S, &iv]() { return iv.res_compact ? ResMatrix{nullptr, S.res_off.p, S.res_len8.p} : ResMatrix{S.resolved.p, nullptr, nullptr}; };
   if (!iv.resolved_whole) {   // the interval's matrix exceeded the budget: resolve this page's records now
-    S.resolved.ensure((size_t)np * iv.nchunks * kAsmRows);
+    if (iv.res_compact) { S.res_off.ensure((size_t)np * iv.nchunks * kAsmRows); S.res_len8.ensure((size_t)np * iv.nchunks * kAsmRows); }
+    else S.resolved.ensure((size_t)np * iv.nchunks * kAsmRows);
     if (iv.asm_path == 2) {
       const int frun = fill_run_length();
       hipLaunchKernelGGL(k_fill2, dim3((unsigned)(((np + frun - 1) / frun) * iv.nchunks)), dim3(kAsmRows), 0, st, iv.pc2, (const uint2*)S.slot_desc.p, (const int32_t*)S.order.p, np, iv.nchunks, frun,
                          S.resolved.p, kp);
     } else
-    launch_assemble_size(S, st, wgrid, iv.ac, S.order.p, np, N, iv.nchunks, wrun, (uint64_t*)nullptr, 0, S.resolved.p, kp, res_chunk_major() && iv.asm_path != 2 ? np : (int64_t)0);
+    launch_assemble_size(S, st, wgrid, iv.ac, S.order.p, np, N, iv.nchunks, wrun, (uint64_t*)nullptr, 0, res_view(), kp, res_chunk_major() && iv.asm_path != 2 ? np : (int64_t)0);
   }
   HIP_CHECK(hipEventRecord(w[1], st));   // [w1, w2] brackets the page-assembly kernel alone (its duration feeds the roofline figure)
 #define GDB_LAUNCH_WRITE(W, L) hipLaunchKernelGGL((k_assemble_write<W, L>), dim3((wgrid.x + (W) - 1u) / (W)), dim3(kAsmRows * (W)), 0, st, (const char*)S.pool.p, (const char*)S.pool_ovf.p, \
-    (const uint32_t*)S.prefix_len.p, (const uint2*)S.resolved.p, iv.resolved_whole ? (int64_t)0 : kp, (const int32_t*)S.order.p, np, iv.nchunks, wrun, (const uint64_t*)S.chunk_off.p, page_base, arena, xcd_aware_numbering() ? 1 : 0, \
+    (const uint32_t*)S.prefix_len.p, res_view(), iv.resolved_whole ? (int64_t)0 : kp, (const int32_t*)S.order.p, np, iv.nchunks, wrun, (const uint64_t*)S.chunk_off.p, page_base, arena, xcd_aware_numbering() ? 1 : 0, \
     (res_chunk_major() && iv.asm_path != 2) ? (iv.resolved_whole ? (int64_t)iv.P_rows : np) : (int64_t)0)
   {
     const int ww = write_waves_per_group(), wl = write_image_kb();

@@ -96,7 +96,8 @@ typedef struct gdbamd_interval_stats {
   int32_t pages, write_launches;
   uint32_t err_bits;
   float ms_sweep, ms_site, ms_size, ms_write, ms_total, ms_write_kernel_avg;
-  int32_t num_record_types, reserved0;   /* entry text table: distinct record types, slots, pool bytes */
+  int32_t num_record_types, resolved_entry_bytes;   /* entry text table: distinct record types, slots, pool bytes; bytes per (record, sample) of the
+                                                      * resolved matrix: 8 (offset + length), 5 (compact: no entry longer than 255 bytes), 0 (no matrix) */
   int64_t num_text_slots, text_pool_bytes;
   uint64_t num_remap_elements;           /* sum over re-indexed records of (calls with PL) x (merged genotypes): the PL remap work */
   uint64_t bytes_compressed;             /* output formats "z" / "b": bytes of the pages after BGZF compression (bytes_out: before) */

@@ -97,6 +97,57 @@ def test_paths_agree_at_1000_samples(gdb, tmp_path, monkeypatch):
     eng.close()
 
 
+def test_compact_and_wide_resolved_matrix_give_the_same_bytes(gdb, tmp_path, monkeypatch):
+    """The (record, sample) matrix of the default path in its two layouts: compact (u32 offsets + u8 lengths, 5 bytes per pair; chosen
+    per interval when no entry text is longer than 255 bytes - c2's width) and wide (8 bytes; GDBAMD_RES_COMPACT=0, or forced by a
+    long entry).  Same bytes, whole-interval and page-by-page matrix alike; the first 1 200 columns against the oracle."""
+    from genomicsdb_amd import synth
+    N, B, L = 1000, 10_000_000, 30_000
+    g = synth.Generator(N, B, L + 2500)
+    cells, nc = g.chunk_bytes(B + L + 2500)
+    q = helpers.synth_query(tmp_path, N, B, B + L - 1)
+    eng = gdb.CombineEngine(q)
+    eng.stage_cells(cells)
+    eng.set_reference(B, synth.reference(B, L + 2500 + 4096))
+    seen = {}
+    for compact, want_bytes in (("1", 5), ("0", 8)):
+        monkeypatch.setenv("GDBAMD_RES_COMPACT", compact)
+        for budget in (None, "0"):
+            if budget is None:
+                monkeypatch.delenv("GDBAMD_RESOLVED_MB", raising=False)
+            else:
+                monkeypatch.setenv("GDBAMD_RESOLVED_MB", budget)
+            got, st = eng.run_interval(B, B + L - 1, arena_bytes=64 << 20)
+            assert st.resolved_entry_bytes == want_bytes and st.pages > 5
+            seen[(compact, budget)] = (hashlib.sha256(got).hexdigest(), st.num_records, len(got))
+    assert len(set(seen.values())) == 1, seen
+    monkeypatch.setenv("GDBAMD_RES_COMPACT", "1")
+    monkeypatch.delenv("GDBAMD_RESOLVED_MB", raising=False)
+    q2 = helpers.synth_query(tmp_path, N, B, B + 1199)
+    want, nrec, _ = helpers.oracle_run_synth(q2, cells, synth.SEED, with_header=False)
+    head, st = eng.run_interval(B, B + 1199, arena_bytes=1 << 30)
+    assert st.num_records == nrec and head == want and st.resolved_entry_bytes == 5
+    eng.close()
+
+
+def test_an_entry_longer_than_255_bytes_takes_the_wide_matrix(gdb, tmp_path, monkeypatch):
+    """10 000 samples: variant entries of several hundred bytes - the interval falls back to the 8-byte layout by itself"""
+    from genomicsdb_amd import synth
+    N, B, L = 10_000, 10_000_000, 200
+    g = synth.Generator(N, B, L + 2500)
+    cells, nc = g.chunk_bytes(B + L + 2500)
+    q = helpers.synth_query(tmp_path, N, B, B + L - 1)
+    want, nrec, _ = helpers.oracle_run_synth(q, cells, synth.SEED, with_header=False)
+    assert max(len(c) for l in want.split(b"\n")[:50] for c in l.split(b"\t")[9:]) > 255
+    eng = gdb.CombineEngine(q)
+    eng.stage_cells(cells)
+    eng.set_reference(B, synth.reference(B, L + 2500 + 4096))
+    got, st = eng.run_interval(B, B + L - 1, arena_bytes=64 << 20)
+    assert st.resolved_entry_bytes == 8
+    assert st.num_records == nrec and got == want
+    eng.close()
+
+
 @pytest.mark.parametrize("path", ["1", "2", "3"])
 def test_overflow_texts_at_10000_samples(gdb, tmp_path, monkeypatch, path):
     """10 000 samples: most variant entries are longer than an inline slot (overflow pool, texts longer than the registers hold)"""

@@ -170,3 +170,32 @@ def test_int_mean_and_histogram_order_device(tmp_path, pad, order):
     bcf = s.read()
     s.close()
     assert helpers.bcf_stream_to_text(bcf) == hdr_and_body
+
+
+def test_a_soft_masked_reference_base_becomes_N(tmp_path):
+    """`m_legal_bases` holds A, T, G, C in upper case only (broad_combined_gvcf.cc:51,823-830): a record whose merged REF is the
+    placeholder `N` (nobody starts at its position) takes the FASTA base - unless that base is not a legal one, e.g. the lower-case
+    letter of a soft-masked region.  Golden t0_1_2_vcf_at_0: the record at 1:12278 has REF C from the FASTA; with that base written
+    as `c` the reference prints N."""
+    import gzip as gz
+    from golden_cases import CASES
+    name, callsets, vid, ov, golden, mode = [c for c in CASES if c[0] == "t0_1_2_vcf_at_0"][0]
+    cells = helpers.cells_for(callsets, vid)
+    q, pb = helpers.query_json(callsets, vid, ov, mode)
+    with gz.open(q["reference_genome"], "rt") as f:
+        lines = f.read().split("\n")
+    assert lines[0].startswith(">1")
+    width = len(lines[1])
+    row, col = divmod(12278 - 1, width)
+    assert lines[1 + row][col] == "C"
+    lines[1 + row] = lines[1 + row][:col] + "c" + lines[1 + row][col + 1:]
+    fa = tmp_path / "masked.fasta.gz"
+    with gz.open(fa, "wt") as f:
+        f.write("\n".join(lines))
+    q["reference_genome"] = str(fa)
+    want = helpers.golden_text(golden).replace(b"1\t12278\t.\tC\t<NON_REF>", b"1\t12278\t.\tN\t<NON_REF>")
+    assert want != helpers.golden_text(golden)
+    txt, _, _ = helpers.oracle_run(q, cells)
+    assert txt == want
+    got, err = helpers.hostsim_run(q, cells)
+    assert err == 0 and got == want
