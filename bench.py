@@ -38,6 +38,9 @@ def main():
     ap.add_argument("--interval-bp", type=int, default=10_000_000)
     ap.add_argument("--window-bp", type=int, default=1_000_000, help="columns per step (one batch); 1 Mb = 44.6 GB of VCF text at 1 000 samples")
     ap.add_argument("--arena-mb", type=int, default=49152, help="HBM page for the output text (one page per window at the defaults)")
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("GDBAMD_BENCH_LANES", "1")),
+                    help="windows in flight at a time (gdbamd_engine_run_intervals): lane l takes steps l, l + lanes, ... on a device pipeline of its own over the same "
+                         "staged fragment; the sweep / site / sizing kernels of one window overlap with the page kernel of another.  Needs lanes x (arena + ~12 GB) of HBM")
     ap.add_argument("--bcf", action="store_true", help="pages of BCF2 records (output format \"bu\") instead of VCF text; not the headline configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stream-input", action="store_true",
@@ -125,15 +128,27 @@ def main():
 
     arena = args.arena_mb << 20
     windows = [(B + (i % (need_bp // W)) * W, B + (i % (need_bp // W)) * W + W - 1) for i in range(total_steps)]
-    for i in range(args.warmup):
-        eng.run_interval(windows[i][0], windows[i][1], arena_bytes=arena, fetch=False)
+    lanes = max(1, min(4, args.lanes))
+    if lanes > 1:
+        arena = min(arena, int(os.environ.get("GDBAMD_BENCH_LANE_ARENA_MB", "46080")) << 20)   # (two 48 GiB pages + two entry tables do not fit beside the fragment)
+        if args.warmup:
+            eng.run_intervals(windows[:args.warmup], arena_bytes=arena, lanes=lanes)
+        else:
+            eng.run_intervals(windows[:0], arena_bytes=arena, lanes=lanes)
+    else:
+        for i in range(args.warmup):
+            eng.run_interval(windows[i][0], windows[i][1], arena_bytes=arena, fetch=False)
     barrier()
     t1 = time.time()
     recs = cells_in = bytes_out = bytes_in = 0
     ms = {"sweep": 0.0, "site": 0.0, "size": 0.0, "write": 0.0}
     wk_ms = wk_launches = 0.0
+    lane_stats = eng.run_intervals(windows[args.warmup:total_steps], arena_bytes=arena, lanes=lanes) if lanes > 1 else None
     for i in range(args.warmup, total_steps):
-        _, st = eng.run_interval(windows[i][0], windows[i][1], arena_bytes=arena, fetch=False)
+        if lane_stats is not None:
+            st = lane_stats[i - args.warmup]
+        else:
+            _, st = eng.run_interval(windows[i][0], windows[i][1], arena_bytes=arena, fetch=False)
         recs += st.num_records
         cells_in += st.num_cells_in_window
         bytes_out += st.bytes_out
@@ -191,6 +206,7 @@ def main():
             "bytes_in_per_cell": bi_all / max(1.0, cells_all),
             "whole_path_GBps": (bo_all + bi_all) / dt / 1e9,
             "phase_ms": {k: v / args.steps for k, v in ms.items()},
+            "lanes": lanes,
             "stage_seconds_untimed": t_stage,
             "roofline": {"bound": "hbm", "kernel": "k_bcf_write" if args.bcf else "k_assemble_write", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None if args.bcf else pmc_traffic(N, W, arena),
@@ -365,6 +381,8 @@ def run_streamed(args, rank, world, device_index, backend, source="callback", em
     wk_ms = wk_launches = 0.0
     windows = 0
     t_cover = 0.0
+    t_run = 0.0
+    n_intervals = 0
     pos, qe = B, B + Lbp - 1
     while pos <= qe:
         tc = time.time()
@@ -374,7 +392,10 @@ def run_streamed(args, rank, world, device_index, backend, source="callback", em
         end = min(qe, hi)
         while pos <= end:
             pe = min(end, pos + W - 1)
+            tr = time.time()
             _, st = eng.run_interval(pos, pe, arena_bytes=arena, fetch=False)
+            t_run += time.time() - tr
+            n_intervals += 1
             recs += st.num_records; cells_in += st.num_cells_in_window; bytes_out += st.bytes_out
             dev_ms += st.ms_total
             wk_ms += st.ms_write_kernel_avg * st.write_launches; wk_launches += st.write_launches
@@ -408,6 +429,12 @@ def run_streamed(args, rank, world, device_index, backend, source="callback", em
             "roofline": {"bound": "hbm", "kernel": "k_assemble_write", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_launch": alg, "avg_launch_ms": avg_ms, "launches": int(launches)},
         }
+        # where the wall clock of the timed region went, by name: device time of the intervals (HIP events), the rest of the
+        # run_interval calls (kernel launches, the syncs that fetch sizes and counters, the page hand-over), cover() (waiting for the
+        # window staged ahead, swapping the pipelines; for a callback source also the generator), and the loop around them
+        out["wall_accounting"] = {"wall_s": dt, "device_s": dev_ms * 1e-3, "run_interval_beyond_device_s": t_run - dev_ms * 1e-3, "cover_s": t_cover,
+                                  "loop_and_barrier_s": dt - t_run - t_cover, "intervals": n_intervals,
+                                  "run_interval_beyond_device_us_per_interval": (t_run - dev_ms * 1e-3) / max(1, n_intervals) * 1e6}
         out["config"]["source"] = "host memory (generated before the timed region, %.1f s)" % t_pregen if source == "memory" else "cell callback (generator inside the timed region)"
         if source == "memory":
             out["config"]["source_pinned"] = t_pin is not None

@@ -267,6 +267,29 @@ class CombineEngine:
         _check(rc == 0, "run_interval")
         return None, st
 
+    def run_intervals(self, intervals, arena_bytes=1 << 30, lanes=2, fetch=False, host_cap=1 << 26):
+        """several (begin, end) column intervals of the staged fragment, up to `lanes` in flight at a time on device pipelines that share
+        the fragment (gdbamd_engine_run_intervals).  fetch=False: pages stay in HBM, returns the per-interval statistics in interval
+        order; fetch=True: returns [(body bytes, statistics)]"""
+        L = _lib.lib()
+        n = len(intervals)
+        b = (ctypes.c_int64 * max(1, n))(*[iv[0] for iv in intervals])
+        e = (ctypes.c_int64 * max(1, n))(*[iv[1] for iv in intervals])
+        st = (_lib.IntervalStats * max(1, n))()
+        if not fetch:
+            _check(L.gdbamd_engine_run_intervals(self._e, n, b, e, arena_bytes, lanes, st, None, None, None) == 0, "run_intervals")
+            return [st[i] for i in range(n)]
+        caps = [host_cap] * n
+        while True:
+            bufs = [ctypes.create_string_buffer(c) for c in caps]
+            ptrs = (ctypes.c_char_p * max(1, n))(*[ctypes.cast(x, ctypes.c_char_p) for x in bufs])
+            cap = (ctypes.c_uint64 * max(1, n))(*caps)
+            lens = (ctypes.c_uint64 * max(1, n))()
+            _check(L.gdbamd_engine_run_intervals(self._e, n, b, e, arena_bytes, lanes, st, ptrs, cap, lens) == 0, "run_intervals")
+            if all(lens[i] <= caps[i] for i in range(n)):
+                return [(bufs[i].raw[:lens[i]], st[i]) for i in range(n)]
+            caps = [max(caps[i], lens[i]) for i in range(n)]
+
     def pages(self, begin=0, end=INT64_MAX - 1, arena_bytes=1 << 30):
         """the VCF body of one column interval page by page, left in HBM: yields (device address, nbytes); an address is valid
         until the next page is asked for"""

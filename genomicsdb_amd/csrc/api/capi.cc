@@ -1,6 +1,7 @@
 // capi.cc - extern "C" surface declared in include/genomicsdb_amd.h
 #include "../../../include/genomicsdb_amd.h"
 
+#include <functional>
 #include <hip/hip_runtime_api.h>
 
 #include <cstdlib>
@@ -232,6 +233,18 @@ void copy_page(void* user, const char* dev, uint64_t n) {
 }
 }  // namespace
 
+static void fill_interval_stats(gdbamd_interval_stats* out, const IntervalStats& s, CombineEngine& eng) {
+  out->num_cells = s.num_cells; out->num_cells_in_window = s.num_cells_in_window; out->num_records = s.num_records;
+  out->num_heavy_incidences = s.num_heavy_incidences; out->bytes_out = s.bytes_out; out->bytes_in_reference_cells = eng.reference_cell_bytes;
+  out->pages = s.pages; out->write_launches = s.write_launches; out->err_bits = s.err_bits;
+  out->ms_sweep = s.ms_sweep; out->ms_site = s.ms_site; out->ms_size = s.ms_size; out->ms_write = s.ms_write; out->ms_total = s.ms_total;
+  out->ms_write_kernel_avg = s.ms_write_kernel_avg;
+  out->num_record_types = s.num_record_types; out->resolved_entry_bytes = s.resolved_entry_bytes;
+  out->num_text_slots = s.num_text_slots; out->text_pool_bytes = s.text_pool_bytes;
+  out->num_remap_elements = s.num_remap_elements;
+  out->bytes_compressed = s.bytes_compressed; out->ms_compress = s.ms_compress; out->reserved1 = 0;
+  for (int i = 0; i < GDBAMD_GT_NUM_STATS; ++i) out->gt_profile_stats[i] = s.gt_profile[i];
+}
 int gdbamd_engine_run_interval(void* e, int64_t qb, int64_t qe, uint64_t arena_bytes, char* host_out, uint64_t host_cap, uint64_t* host_len,
                                gdbamd_interval_stats* out) {
   return guarded([&]() -> int {
@@ -240,18 +253,25 @@ int gdbamd_engine_run_interval(void* e, int64_t qb, int64_t qe, uint64_t arena_b
     eng.stage_reference_for(qb, qe);  // no-op unless the query names a reference_genome and cells were staged from host
     IntervalStats s = eng.pipeline().run_interval(qb, qe, arena_bytes, host_out ? copy_page : nullptr, &hc);
     if (host_len) *host_len = host_out ? hc.len : s.bytes_out;
-    if (out) {
-      out->num_cells = s.num_cells; out->num_cells_in_window = s.num_cells_in_window; out->num_records = s.num_records;
-      out->num_heavy_incidences = s.num_heavy_incidences; out->bytes_out = s.bytes_out; out->bytes_in_reference_cells = eng.reference_cell_bytes;
-      out->pages = s.pages; out->write_launches = s.write_launches; out->err_bits = s.err_bits;
-      out->ms_sweep = s.ms_sweep; out->ms_site = s.ms_site; out->ms_size = s.ms_size; out->ms_write = s.ms_write; out->ms_total = s.ms_total;
-      out->ms_write_kernel_avg = s.ms_write_kernel_avg;
-      out->num_record_types = s.num_record_types; out->resolved_entry_bytes = s.resolved_entry_bytes;
-      out->num_text_slots = s.num_text_slots; out->text_pool_bytes = s.text_pool_bytes;
-      out->num_remap_elements = s.num_remap_elements;
-      out->bytes_compressed = s.bytes_compressed; out->ms_compress = s.ms_compress; out->reserved1 = 0;
-      for (int i = 0; i < GDBAMD_GT_NUM_STATS; ++i) out->gt_profile_stats[i] = s.gt_profile[i];
+    if (out) fill_interval_stats(out, s, eng);
+    return 0;
+  }, 1);
+}
+int gdbamd_engine_run_intervals(void* e, int n, const int64_t* begins, const int64_t* ends, uint64_t arena_bytes, int lanes, gdbamd_interval_stats* stats,
+                                char* const* host_out, const uint64_t* host_cap, uint64_t* host_len) {
+  return guarded([&]() -> int {
+    CombineEngine& eng = *((EngineHandle*)e)->eng;
+    std::vector<std::pair<int64_t, int64_t>> ivs;
+    for (int i = 0; i < n; ++i) ivs.emplace_back(begins[i], ends[i]);
+    std::vector<HostCopy> hc;
+    std::function<void(size_t, const char*, uint64_t)> on_page;
+    if (host_out) {      // (interval i's pages go to host_out[i], each interval from one thread only)
+      for (int i = 0; i < n; ++i) hc.push_back(HostCopy{host_out[i], host_cap ? host_cap[i] : 0, 0});
+      on_page = [&hc](size_t i, const char* dev, uint64_t nbytes) { copy_page(&hc[i], dev, nbytes); };
     }
+    const std::vector<IntervalStats> res = eng.run_intervals(ivs, arena_bytes, lanes, on_page);
+    if (host_len) for (int i = 0; i < n; ++i) host_len[i] = host_out ? hc[(size_t)i].len : res[(size_t)i].bytes_out;
+    if (stats) for (int i = 0; i < n; ++i) fill_interval_stats(&stats[i], res[(size_t)i], eng);
     return 0;
   }, 1);
 }

@@ -453,13 +453,54 @@ void CombineEngine::set_reference_window(int64_t begin, const std::string& bases
   m_user_ref = true; m_user_ref_begin = begin; m_user_ref_bases = bases;
   m_pipe->set_reference_window(begin, bases);
   m_pipe_has_user_ref[pipeline_generation & 1] = true; m_pipe_has_user_ref[(pipeline_generation + 1) & 1] = false;
+  for (Lane& L : m_lanes) L.has_user_ref = false;
 }
 
-void CombineEngine::stage_reference_for(int64_t qb, int64_t qe) {
+void CombineEngine::stage_reference_on(DevicePipeline& pipe, int64_t qb, int64_t qe) {
   if (!m_ref.is_initialized() || !has_cells) return;
   int64_t b = std::max(qb, min_begin), e = std::min(qe, max_end);
   if (e < b) return;
-  m_pipe->set_reference_window(b, m_ref.window(m_qc.get_vid_mapper(), b, e - b + 1));
+  pipe.set_reference_window(b, m_ref.window(m_qc.get_vid_mapper(), b, e - b + 1));
+}
+void CombineEngine::stage_reference_for(int64_t qb, int64_t qe) { stage_reference_on(*m_pipe, qb, qe); }
+
+std::vector<IntervalStats> CombineEngine::run_intervals(const std::vector<std::pair<int64_t, int64_t>>& intervals, uint64_t arena_bytes, int lanes,
+                                                        const std::function<void(size_t, const char*, uint64_t)>& on_page) {
+  struct PageCtx { const std::function<void(size_t, const char*, uint64_t)>* fn; size_t index; };
+  const PageCallback relay = [](void* user, const char* dev, uint64_t nbytes) { PageCtx* c = (PageCtx*)user; (*c->fn)(c->index, dev, nbytes); };
+  const size_t n = intervals.size();
+  std::vector<IntervalStats> out(n);
+  if (n == 0) return out;
+  lanes = std::max(1, std::min<int>({lanes, 4, (int)n}));
+  std::vector<DevicePipeline*> pipes((size_t)lanes, nullptr);
+  pipes[0] = m_pipe.get();
+  if ((int)m_lanes.size() < lanes - 1) m_lanes.resize((size_t)lanes - 1);
+  for (int l = 1; l < lanes; ++l) {
+    Lane& L = m_lanes[(size_t)l - 1];
+    if (!L.pipe) L.pipe.reset(new DevicePipeline(m_hp, m_device));
+    if (L.src != m_pipe.get() || L.gen != m_pipe->fragment_generation()) {     // another fragment since the lane last ran: adopt it (the cells stay where they are)
+      L.pipe->adopt_fragment(m_pipe->fragment_view());
+      L.src = m_pipe.get(); L.gen = m_pipe->fragment_generation();
+    }
+    if (m_user_ref && !L.has_user_ref) { L.pipe->set_reference_window(m_user_ref_begin, m_user_ref_bases); L.has_user_ref = true; }
+    pipes[(size_t)l] = L.pipe.get();
+  }
+  std::vector<std::exception_ptr> errors((size_t)lanes);
+  auto work = [&](int l) {
+    try {
+      for (size_t i = (size_t)l; i < n; i += (size_t)lanes) {
+        if (!m_user_ref) stage_reference_on(*pipes[(size_t)l], intervals[i].first, intervals[i].second);
+        PageCtx pc{&on_page, i};
+        out[i] = pipes[(size_t)l]->run_interval(intervals[i].first, intervals[i].second, arena_bytes, on_page ? relay : (PageCallback) nullptr, &pc);
+      }
+    } catch (...) { errors[(size_t)l] = std::current_exception(); }
+  };
+  std::vector<std::thread> th;
+  for (int l = 1; l < lanes; ++l) th.emplace_back(work, l);
+  work(0);
+  for (auto& t : th) t.join();
+  for (auto& e : errors) if (e) std::rethrow_exception(e);
+  return out;
 }
 
 GenomicsDBBCFGenerator::GenomicsDBBCFGenerator(const std::string& loader_config_file, const std::string& query_config_file, const char* chr,

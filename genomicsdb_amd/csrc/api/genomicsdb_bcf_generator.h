@@ -7,6 +7,7 @@
 #include <exception>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "../kernels/gdb_pipeline.h"
@@ -67,6 +68,14 @@ class CombineEngine {
   uint64_t pipeline_generation = 0;   // counts the swaps of the two pipelines (overlapped staging): pipeline() is another object afterwards
   int64_t num_cells = 0;
   void stage_reference_for(int64_t qb, int64_t qe);
+  // Several query intervals of the staged fragment, up to `lanes` of them in flight at a time: lane l takes intervals l, l + lanes, ...
+  // on a device pipeline of its own (own HIP stream, own entry table / matrix / page arenas) that ADOPTS the fragment staged in the
+  // engine's pipeline - the cells are in HBM once.  The sweep / site / sizing kernels of one interval (latency-bound) then overlap
+  // with the page kernel of another (store-bound).  Pages stay in HBM (no callback); per-interval statistics in interval order.
+  // The reference's analogue: nothing - its scan is one thread per partition (tools/src/gt_mpi_gather.cc:322-366).
+  // on_page (optional): called from the lane's thread for every page of interval `index` (device pointer, valid during the call)
+  std::vector<IntervalStats> run_intervals(const std::vector<std::pair<int64_t, int64_t>>& intervals, uint64_t arena_bytes, int lanes,
+                                           const std::function<void(size_t index, const char* dev_ptr, uint64_t nbytes)>& on_page = nullptr);
   // reference bases given by the caller for columns [begin, begin + bases.size()): kept, so that the pipeline a later window is
   // staged into (overlapped staging) sees them too
   void set_reference_window(int64_t begin, const std::string& bases);
@@ -80,6 +89,9 @@ class CombineEngine {
   HostPlan m_hp;
   std::unique_ptr<DevicePipeline> m_pipe;       // the pipeline whose fragment is in use
   std::unique_ptr<DevicePipeline> m_pipe2;      // overlapped staging: the next column window is staged here meanwhile
+  struct Lane { std::unique_ptr<DevicePipeline> pipe; const DevicePipeline* src = nullptr; uint64_t gen = 0; bool has_user_ref = false; };
+  std::vector<Lane> m_lanes;                    // run_intervals: pipelines 1 .. lanes - 1 (lane 0 is m_pipe)
+  void stage_reference_on(DevicePipeline& pipe, int64_t qb, int64_t qe);
   int m_device = 0;
   std::unique_ptr<CellStreamLayout> m_layout;   // attribute order, plan-field map, row map of the binary cell stream
   ReferenceGenomeInfo m_ref;

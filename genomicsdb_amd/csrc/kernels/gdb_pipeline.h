@@ -145,6 +145,10 @@ class DevicePipeline {
   // hip_event (hipEvent_t) marks the consumer's last read of the arena; the next begin_page() into it waits for the event on the compute stream
   void set_arena_release_event(int arena_idx, void* hip_event);
   const IntervalStats& interval_stats() const;
+  // the staged fragment as device pointers (owned by this pipeline: valid until it stages, loads or adopts another one) and a counter
+  // of the fragments held so far - what a second pipeline needs to work on the same fragment (adopt_fragment; CombineEngine::run_intervals)
+  FragmentView fragment_view() const;
+  uint64_t fragment_generation() const;
   // push interface built on the two calls above
   IntervalStats run_interval(int64_t qb, int64_t qe, uint64_t arena_bytes, PageCallback cb, void* user);
   static int device_count();

@@ -144,7 +144,15 @@ inline int write2_run_length() { const char* e = getenv("GDBAMD_RUN_W2"); return
 inline int write_waves_per_group() { const char* e = getenv("GDBAMD_WRITE_WAVES"); return e && *e ? atoi(e) : 1; }
 inline bool slot_regroup() { static const bool v = []() { const char* e = getenv("GDBAMD_SLOT_REGROUP"); return !(e && *e == '0'); }(); return v; }
 inline bool xcd_aware_numbering() { const char* e = getenv("GDBAMD_XCD_AWARE"); return !(e && *e == '0'); }
-inline int write_image_kb() { const char* e = getenv("GDBAMD_WRITE_IMAGE_KB"); return e && *e ? atoi(e) : 8; }
+// LDS image of one (record, 64-sample chunk) of the page kernel.  GDBAMD_WRITE_IMAGE_KB = 4 / 6 / 8 forces one; otherwise by the
+// interval's average chunk: 4 KiB while a chunk (c2: 2.8 KB) and its alignment slack fit - more resident wavefronts per CU, 0.4-0.6 ms
+// of a 12 ms launch, three A/B rounds inside one call (profiles/r5_ab_image.txt) - and 8 KiB for wider entries (c3's width: ~6 KB
+// per chunk would take two passes through a 4 KiB image)
+inline int write_image_kb(uint64_t avg_chunk_bytes = 0) {
+  const char* e = getenv("GDBAMD_WRITE_IMAGE_KB");
+  if (e && *e) return atoi(e);
+  return avg_chunk_bytes && avg_chunk_bytes <= 3400 ? 4 : 8;
+}
 inline int order_block_log2() {
   const char* e = getenv("GDBAMD_ORDER_BLOCK_LOG2");
   return e && *e ? std::max(0, std::min(30, atoi(e))) : 12;
@@ -3690,6 +3698,7 @@ struct DevicePipeline::Impl {
   DevBuf<uint32_t> untabled, ubase; DevBuf<int32_t> urec, iota, order; DevBuf<uint32_t> order_keys, order_keys_sorted;
   DevBuf<uint64_t> tmask; DevBuf<uint32_t> nslots, tbase, slot_len, slot_units, slot_off; DevBuf<uint2> slot_desc; DevBuf<char> pool, pool_ovf;
   bool classified = false;
+  uint64_t fragment_generation = 0;   // counts the fragments this pipeline has held: a pipeline that adopted this one's fragment (CombineEngine lanes) re-adopts when it changes
   struct Part { FragmentView v; std::vector<size_t> data_bytes; std::vector<void*> bufs; };
   std::vector<Part> parts;
   std::vector<int> col_elem_size; std::vector<bool> col_var; std::vector<int> col_fixed_num;
@@ -3698,7 +3707,7 @@ struct DevicePipeline::Impl {
     bool active = false;
     int64_t P = 0, kp = 0;
     int nchunks = 0;
-    uint64_t max_record_bytes = 0;
+    uint64_t max_record_bytes = 0, total_bytes = 0;
     float write_kernel_ms = 0;
     std::vector<uint64_t> rec_off;
     IntervalStats stats;
@@ -3861,7 +3870,7 @@ void DevicePipeline::stage_fragment(const HostFragment& hf) {
   v.marker_begin = (const int64_t*)up(hf.marker_begin.data(), hf.marker_begin.size() * 8);
   m_->fr = v;
   m_->owns_fragment = true;
-  m_->classified = false;
+  m_->classified = false; ++m_->fragment_generation;
 }
 
 void DevicePipeline::begin_staging(int64_t carry_from) { begin_staging_from(*this, carry_from); }
@@ -4251,7 +4260,7 @@ void DevicePipeline::finish_staging() {
   S.free_parts();
   S.fr = v;
   S.owns_fragment = true;
-  S.classified = false;
+  S.classified = false; ++S.fragment_generation;
 }
 
 // ---- columnar fragment file: the staged fragment as it lies in HBM, so that opening an array is file -> HBM copies ------
@@ -4918,7 +4927,7 @@ void DevicePipeline::adopt_fragment(const FragmentView& v) {
   m_->free_owned();
   m_->fr = v;
   m_->owns_fragment = false;
-  m_->classified = false;
+  m_->classified = false; ++m_->fragment_generation;
 }
 
 void DevicePipeline::set_reference_window(int64_t begin, const std::string& bases) {
@@ -5665,7 +5674,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   HIP_CHECK(hipEventElapsedTime(&stats.ms_site, ev[1], ev[2]));
   HIP_CHECK(hipEventElapsedTime(&stats.ms_size, ev[2], ev[3]));
   if (eb) throw GenomicsDBDeviceException(err_bits_text(eb));
-  S.iv.max_record_bytes = totals[1];
+  S.iv.max_record_bytes = totals[1]; S.iv.total_bytes = totals[0];
   S.iv.P = P; S.iv.nchunks = nchunks; S.iv.kp = 0;
   S.iv.sx = sx; S.iv.ex = ex; S.iv.ri = ri; S.iv.so = so; S.iv.rec = rec; S.iv.ac = ac; S.iv.pc2 = pc2; S.iv.piece_path = piece_path; S.iv.asm_path = asm_path; S.iv.resolved_whole = resolved_whole; S.iv.res_compact = res_compact; S.iv.P_rows = P;
   S.iv.bcf = pl.bcf_mode != 0; S.iv.bcf_F = bcf_F; S.iv.lay = lay;
@@ -5770,7 +5779,7 @@ bool DevicePipeline::begin_page(uint64_t arena_bytes, int arena_idx, PageTicket*
     HIP_CHECK(hipEventRecord(w[1], st));
 #define GDB_LAUNCH_WRITE2(W, L) hipLaunchKernelGGL((k_write2<W, L>), dim3((wgrid.x + (W) - 1u) / (W)), dim3(kAsmRows * (W)), 0, st, iv.pc2, (const char*)S.pool.p, (const char*)S.pool_ovf.p, \
     (const int32_t*)S.order.p, np, iv.nchunks, wrun, (const uint64_t*)S.chunk_off.p, page_base, arena, (xcd_aware_numbering() ? 1 : 0) | (w2dbg << 1))
-    const int ww = write_waves_per_group(), wl = write_image_kb();
+    const int ww = write_waves_per_group(), wl = write_image_kb(iv.P > 0 && iv.nchunks > 0 ? iv.total_bytes / ((uint64_t)iv.P * (uint64_t)iv.nchunks) : 0);
     const int w2dbg = getenv("GDBAMD_W2_DBG") ? atoi(getenv("GDBAMD_W2_DBG")) : 0;
     S.dbg_counters.ensure(8);
     if (w2dbg & 64) HIP_CHECK(hipMemsetAsync(S.dbg_counters.p, 0, 8 * sizeof(unsigned long long), st));
@@ -5815,7 +5824,7 @@ bool DevicePipeline::begin_page(uint64_t arena_bytes, int arena_idx, PageTicket*
     (const uint32_t*)S.prefix_len.p, res_view(), iv.resolved_whole ? (int64_t)0 : kp, (const int32_t*)S.order.p, np, iv.nchunks, wrun, (const uint64_t*)S.chunk_off.p, page_base, arena, xcd_aware_numbering() ? 1 : 0, \
     (res_chunk_major() && iv.asm_path != 2) ? (iv.resolved_whole ? (int64_t)iv.P_rows : np) : (int64_t)0)
   {
-    const int ww = write_waves_per_group(), wl = write_image_kb();
+    const int ww = write_waves_per_group(), wl = write_image_kb(iv.P > 0 && iv.nchunks > 0 ? iv.total_bytes / ((uint64_t)iv.P * (uint64_t)iv.nchunks) : 0);
     if (ww >= 4 && wl <= 4) GDB_LAUNCH_WRITE(4, 4096);
     else if (ww >= 4 && wl <= 6) GDB_LAUNCH_WRITE(4, 6144);
     else if (ww >= 4) GDB_LAUNCH_WRITE(4, 8192);
@@ -5870,6 +5879,8 @@ bool DevicePipeline::next_page(uint64_t arena_bytes, const char** dev_ptr, uint6
 }
 
 const IntervalStats& DevicePipeline::interval_stats() const { return m_->iv.stats; }
+FragmentView DevicePipeline::fragment_view() const { return m_->fr; }
+uint64_t DevicePipeline::fragment_generation() const { return m_->fragment_generation; }
 
 IntervalStats DevicePipeline::run_interval(int64_t qb, int64_t qe, uint64_t arena_bytes, PageCallback cb, void* user) {
   prepare_interval(qb, qe);

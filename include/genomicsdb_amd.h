@@ -203,6 +203,16 @@ int gdbamd_engine_set_reference(void* engine, int64_t begin, const char* bases, 
 int gdbamd_engine_run_interval(void* engine, int64_t column_begin, int64_t column_end, uint64_t arena_bytes, char* host_out,
                                uint64_t host_cap, uint64_t* host_len, gdbamd_interval_stats* stats);
 
+/* n query intervals of the staged fragment, up to `lanes` (1 .. 4) of them in flight at a time: lane l takes intervals l, l + lanes, ... on a
+ * device pipeline of its own (own stream, entry table, matrix and page arenas) that works on the SAME staged fragment - the latency-bound
+ * sweep / site / sizing kernels of one interval overlap with the store-bound page kernel of another.  The pages stay in HBM (each lane's
+ * last page is valid until the lane's next interval) unless host_out != NULL: then interval i's body is copied to host_out[i] (at most
+ * host_cap[i] bytes; host_len[i] = its length either way).  stats[i] belongs to interval i.  lanes = 1 is a loop of gdbamd_engine_run_interval.
+ * (The reference scans a partition with one thread: tools/src/gt_mpi_gather.cc:322-366; this is the device's way to keep two batches of
+ * the same partition in flight.) */
+int gdbamd_engine_run_intervals(void* engine, int n, const int64_t* column_begins, const int64_t* column_ends, uint64_t arena_bytes, int lanes,
+                                gdbamd_interval_stats* stats, char* const* host_out, const uint64_t* host_cap, uint64_t* host_len);
+
 /* the same in two steps, for consumers that take the pages where they are (HBM): prepare = sweep, site and sizing passes of
  * the interval; next_page = the next <= arena_bytes of whole records.  *dev_ptr is device memory, valid until the next call
  * on this engine.  next_page returns 1 (a page), 0 (interval exhausted) or -1 (error).

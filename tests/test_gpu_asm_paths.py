@@ -131,20 +131,28 @@ def test_compact_and_wide_resolved_matrix_give_the_same_bytes(gdb, tmp_path, mon
 
 
 def test_an_entry_longer_than_255_bytes_takes_the_wide_matrix(gdb, tmp_path, monkeypatch):
-    """10 000 samples: variant entries of several hundred bytes - the interval falls back to the 8-byte layout by itself"""
+    """a dense high-ALT region (entries of several KB) in front of plain columns: the interval with the long entries falls back to the
+    8-byte layout by itself, a later interval without them is compact again"""
     from genomicsdb_amd import synth
-    N, B, L = 10_000, 10_000_000, 200
-    g = synth.Generator(N, B, L + 2500)
+    N, B, L = 150, 10_000_000, 1500
+    g = synth.Generator(N, B, L + 2500, dense=(B + 100, 200, 50, 64))
     cells, nc = g.chunk_bytes(B + L + 2500)
     q = helpers.synth_query(tmp_path, N, B, B + L - 1)
+    q["max_diploid_alt_alleles_that_can_be_genotyped"] = 64
     want, nrec, _ = helpers.oracle_run_synth(q, cells, synth.SEED, with_header=False)
-    assert max(len(c) for l in want.split(b"\n")[:50] for c in l.split(b"\t")[9:]) > 255
+    assert max(len(c) for l in want.split(b"\n") if l for c in l.split(b"\t")[9:]) > 255
     eng = gdb.CombineEngine(q)
     eng.stage_cells(cells)
     eng.set_reference(B, synth.reference(B, L + 2500 + 4096))
-    got, st = eng.run_interval(B, B + L - 1, arena_bytes=64 << 20)
+    got, st = eng.run_interval(B, B + L - 1, arena_bytes=1 << 20)
     assert st.resolved_entry_bytes == 8
     assert st.num_records == nrec and got == want
+    q2 = helpers.synth_query(tmp_path, N, B + 700, B + L - 1)
+    q2["max_diploid_alt_alleles_that_can_be_genotyped"] = 64
+    want2, nrec2, _ = helpers.oracle_run_synth(q2, cells, synth.SEED, with_header=False)
+    got2, st2 = eng.run_interval(B + 700, B + L - 1, arena_bytes=1 << 20)
+    assert max(len(c) for l in want2.split(b"\n") if l for c in l.split(b"\t")[9:]) <= 255
+    assert st2.resolved_entry_bytes == 5 and st2.num_records == nrec2 and got2 == want2
     eng.close()
 
 

@@ -1254,6 +1254,36 @@ def test_c3_width_interior_window_of_a_streamed_array_matches_the_oracle(gdb, tm
     assert nwin >= 3                              # the spot lies behind at least two window cuts (carry-over twice)
 
 
+@pytest.mark.parametrize("lanes", [2, 3])
+def test_intervals_in_flight_on_lanes_give_the_same_bytes(gdb, tmp_path, lanes):
+    """gdbamd_engine_run_intervals: several windows of one staged fragment in flight at a time, every lane a device pipeline of its own
+    over the SAME fragment (the sizing kernels of one window overlap with the page kernel of another: bench.py --lanes).  The bodies
+    are the bodies of one window after the other, the whole is the oracle's output; restaging is followed (the lanes adopt the new
+    fragment) and a lane count above the interval count is fine."""
+    from genomicsdb_amd import synth
+    N, B, L, W = 300, 10_000_000, 4200, 600
+    eng, q, cells = _c2_engine(gdb, tmp_path, N, B, L)
+    want, nrec, _ = helpers.oracle_run_synth(q, cells, synth.SEED, with_header=False)
+    wins = [(B + i * W, B + (i + 1) * W - 1) for i in range(L // W)]
+    seq = [eng.run_interval(a, b, arena_bytes=1 << 20)[0] for a, b in wins]
+    assert b"".join(seq) == want
+    res = eng.run_intervals(wins, arena_bytes=1 << 20, lanes=lanes, fetch=True)
+    assert [r[0] for r in res] == seq
+    assert sum(r[1].num_records for r in res) == nrec and all(r[1].pages >= 1 for r in res)
+    stats = eng.run_intervals(wins[:2], arena_bytes=8 << 20, lanes=4)                       # pages left in HBM, more lanes than intervals
+    assert [s.num_records for s in stats] == [r[1].num_records for r in res[:2]]
+    # another fragment in the engine: the lanes must follow it
+    g = synth.Generator(N, B, L + 2500, seed=77)
+    cells2, _ = g.chunk_bytes(B + L + 2500)
+    eng.stage_cells(cells2)
+    eng.set_reference(B, synth.reference(B, L + 2500 + 4096, seed=77))
+    want2, nrec2, _ = helpers.oracle_run_synth(q, cells2, 77, with_header=False)
+    assert want2 != want
+    res2 = eng.run_intervals(wins, arena_bytes=1 << 20, lanes=lanes, fetch=True)
+    assert b"".join(r[0] for r in res2) == want2
+    eng.close()
+
+
 def test_c4_sample_count_100000_rows_matches_oracle(gdb, tmp_path):
     """BASELINE.json configs[3]'s sample count on a narrow window: 100 000 samples (1 563 chunks of 64 sample columns, a first
     record with 100 000 calls starting at the partition begin - allele merge, medians and sums by its workgroup), 24 columns"""
