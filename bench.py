@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--interval-bp", type=int, default=10_000_000)
     ap.add_argument("--window-bp", type=int, default=1_000_000, help="columns per step (one batch); 1 Mb = 44.6 GB of VCF text at 1 000 samples")
     ap.add_argument("--arena-mb", type=int, default=49152, help="HBM page for the output text (one page per window at the defaults)")
-    ap.add_argument("--lanes", type=int, default=int(os.environ.get("GDBAMD_BENCH_LANES", "1")),
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("GDBAMD_BENCH_LANES", "3")),
                     help="windows in flight at a time (gdbamd_engine_run_intervals): lane l takes steps l, l + lanes, ... on a device pipeline of its own over the same "
                          "staged fragment; the sweep / site / sizing kernels of one window overlap with the page kernel of another.  Needs lanes x (arena + ~12 GB) of HBM")
     ap.add_argument("--bcf", action="store_true", help="pages of BCF2 records (output format \"bu\") instead of VCF text; not the headline configuration")
@@ -48,6 +48,7 @@ def main():
                          "(GDBAMD_STAGE_BUDGET_MB) with carry-over; one pass over --interval-bp, --steps / --warmup are ignored")
     ap.add_argument("--stream-source", default="callback", help="--stream-input: \"callback\" (the generator inside the timed region) or \"memory\" (generated first)")
     ap.add_argument("--no-stream", action="store_true", help="skip the end-to-end leg through the query stream (gdb_mi355_read)")
+    ap.add_argument("--no-alone-pass", action="store_true", help="lanes > 1: skip the three extra steps that time the page kernel with one window in flight")
     ap.add_argument("--no-c3", action="store_true", help="skip the c3-shape leg (10 000 samples streamed through HBM in column windows)")
     ap.add_argument("--c3-bp", type=int, default=10_000_000, help="columns of the c3-shape leg (10 000 samples: 14.6 GB of cells per Mb, generated into host memory first)")
     ap.add_argument("--cpu-sample-bp", type=int, default=12000, help="columns of the bounded CPU-baseline sample (~15 s of oracle time)")
@@ -131,10 +132,14 @@ def main():
     lanes = max(1, min(4, args.lanes))
     if lanes > 1:
         arena = min(arena, int(os.environ.get("GDBAMD_BENCH_LANE_ARENA_MB", "46080")) << 20)   # (two 48 GiB pages + two entry tables do not fit beside the fragment)
+        # every lane has to have run one full window before the clock starts: its pipeline is created, adopts and classifies the staged
+        # fragment and sizes its grow-only buffers then (one-off work of the kind staging is).  With W >= lanes the W warm-up steps do that;
+        # else the missing ones are run here, untimed and reported as "untimed_lane_preparation_steps".
+        prep = lanes if args.warmup < lanes else 0
+        if prep:
+            eng.run_intervals([windows[i % len(windows)] for i in range(lanes)], arena_bytes=arena, lanes=lanes)
         if args.warmup:
             eng.run_intervals(windows[:args.warmup], arena_bytes=arena, lanes=lanes)
-        else:
-            eng.run_intervals(windows[:0], arena_bytes=arena, lanes=lanes)
     else:
         for i in range(args.warmup):
             eng.run_interval(windows[i][0], windows[i][1], arena_bytes=arena, fetch=False)
@@ -157,6 +162,18 @@ def main():
         wk_launches += st.write_launches
     barrier()
     dt = time.time() - t1
+    # With several windows in flight a launch of the page kernel shares the device with the other lanes' kernels: its duration (what
+    # `roofline` is computed from, as everywhere) says how long it was resident, not how fast it can go.  A short pass of the same
+    # windows one at a time, OUTSIDE the timed region, measures the kernel on its own; it goes into roofline["alone"].
+    alone = None
+    if lanes > 1 and not args.no_alone_pass:
+        a_ms = a_n = 0.0
+        for i in range(args.warmup, min(total_steps, args.warmup + 3)):
+            _, st1 = eng.run_interval(windows[i][0], windows[i][1], arena_bytes=arena, fetch=False)
+            a_ms += st1.ms_write_kernel_avg * st1.write_launches
+            a_n += st1.write_launches
+        if a_n:
+            alone = a_ms / a_n
     # bytes_in: reference binary-cell bytes of the begin-cells consumed (pro rata of the staged total)
     st_total_cells = max(1, ncells)
     bytes_in = int(eng_reference_bytes(eng) * (cells_in / st_total_cells))
@@ -207,11 +224,19 @@ def main():
             "whole_path_GBps": (bo_all + bi_all) / dt / 1e9,
             "phase_ms": {k: v / args.steps for k, v in ms.items()},
             "lanes": lanes,
+            "untimed_lane_preparation_steps": (lanes if args.warmup < lanes else 0) if lanes > 1 else 0,
+            "lanes_note": ("%d windows in flight at a time (gdbamd_engine_run_intervals: lane pipelines over one staged fragment); phase_ms and "
+                           "roofline.avg_launch_ms are device times on each lane's own stream and overlap, so they add up to more than ms_per_step; "
+                           "roofline.alone is the same kernel measured with one window at a time, outside the timed region" % lanes) if lanes > 1 else None,
+            "whole_path_frac_of_hbm_peak": (bo_all + bi_all) / dt / 1e9 / HBM_PEAK_GBS / max(1, world),
             "stage_seconds_untimed": t_stage,
             "roofline": {"bound": "hbm", "kernel": "k_bcf_write" if args.bcf else "k_assemble_write", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None if args.bcf else pmc_traffic(N, W, arena),
                          "alg_bytes_per_launch": alg_bytes_per_launch, "avg_launch_ms": avg_ms, "launches": int(launches)},
         }
+        if alone:
+            out["roofline"]["alone"] = {"avg_launch_ms": alone, "achieved": alg_bytes_per_launch / (alone * 1e-3) / 1e9, "frac": alg_bytes_per_launch / (alone * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "what": "k_assemble_write with one window in flight (3 steps after the timed region)"}
         if concat is not None:
             out["concat"] = concat
         if not args.no_stream and world == 1 and not args.bcf:         # the boundary GATK drives: header + body through gdb_mi355_read
@@ -383,6 +408,9 @@ def run_streamed(args, rank, world, device_index, backend, source="callback", em
     t_cover = 0.0
     t_run = 0.0
     n_intervals = 0
+    lanes = max(1, min(4, int(os.environ.get("GDBAMD_BENCH_C3_LANES", str(getattr(args, "c3_lanes", 1))))))
+    if lanes > 1:
+        arena = min(arena, int(os.environ.get("GDBAMD_BENCH_LANE_ARENA_MB", "46080")) << 20)
     pos, qe = B, B + Lbp - 1
     while pos <= qe:
         tc = time.time()
@@ -390,16 +418,30 @@ def run_streamed(args, rank, world, device_index, backend, source="callback", em
         t_cover += time.time() - tc
         windows += 1
         end = min(qe, hi)
-        while pos <= end:
-            pe = min(end, pos + W - 1)
+        if lanes > 1:
+            # the pieces of this staged window, `lanes` of them in flight at a time (the lanes adopt the window's fragment)
+            ivs = []
+            while pos <= end:
+                pe = min(end, pos + W - 1)
+                ivs.append((pos, pe))
+                pos = pe + 1
             tr = time.time()
-            _, st = eng.run_interval(pos, pe, arena_bytes=arena, fetch=False)
+            sts = eng.run_intervals(ivs, arena_bytes=arena, lanes=lanes)
             t_run += time.time() - tr
+        else:
+            sts = []
+            while pos <= end:
+                pe = min(end, pos + W - 1)
+                tr = time.time()
+                _, st = eng.run_interval(pos, pe, arena_bytes=arena, fetch=False)
+                t_run += time.time() - tr
+                sts.append(st)
+                pos = pe + 1
+        for st in sts:
             n_intervals += 1
             recs += st.num_records; cells_in += st.num_cells_in_window; bytes_out += st.bytes_out
             dev_ms += st.ms_total
             wk_ms += st.ms_write_kernel_avg * st.write_launches; wk_launches += st.write_launches
-            pos = pe + 1
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -421,7 +463,7 @@ def run_streamed(args, rank, world, device_index, backend, source="callback", em
                        "staging_budget_MB": int(os.environ.get("GDBAMD_STAGE_BUDGET_MB", "8192")), "output": "VCF text, bit-exact, pages left in HBM"},
             "cells_per_sec": cells_all / dt,
             "positions_per_sec_excluding_generator": recs / max(1e-9, dt - state["gen_s"]),
-            "positions_per_sec_device_only": recs / max(1e-9, dev_ms * 1e-3),
+            "positions_per_sec_device_only": recs / max(1e-9, dev_ms * 1e-3) if lanes == 1 else None,   # (lanes > 1: the intervals' device times overlap)
             "bytes_out_per_position": bo_all / max(1.0, recs_all), "bytes_in_per_cell": bi_all / max(1.0, state["cells"]),
             "whole_path_GBps": (bo_all + bi_all) / dt / 1e9,
             "input_path": {"cell_bytes": state["bytes"], "cells": state["cells"], "t_generator_s": state["gen_s"], "t_stage_s": t_input,
@@ -432,6 +474,7 @@ def run_streamed(args, rank, world, device_index, backend, source="callback", em
         # where the wall clock of the timed region went, by name: device time of the intervals (HIP events), the rest of the
         # run_interval calls (kernel launches, the syncs that fetch sizes and counters, the page hand-over), cover() (waiting for the
         # window staged ahead, swapping the pipelines; for a callback source also the generator), and the loop around them
+        out["lanes"] = lanes
         out["wall_accounting"] = {"wall_s": dt, "device_s": dev_ms * 1e-3, "run_interval_beyond_device_s": t_run - dev_ms * 1e-3, "cover_s": t_cover,
                                   "loop_and_barrier_s": dt - t_run - t_cover, "intervals": n_intervals,
                                   "run_interval_beyond_device_us_per_interval": (t_run - dev_ms * 1e-3) / max(1, n_intervals) * 1e6}
