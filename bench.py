@@ -240,7 +240,10 @@ def main():
         if concat is not None:
             out["concat"] = concat
         if not args.no_stream and world == 1 and not args.bcf:         # the boundary GATK drives: header + body through gdb_mi355_read
-            eng.close()                                                 # (the timed engine's HBM - fragment, 48 GB arena, tables - is given back first)
+            eng.close()                                                 # (the timed engine's HBM - fragment, the lanes' arenas and tables - is given back first)
+            # an untimed 20 kb stream first: the first stream of a process pays one-off costs (its pinned ring, the first allocations after ~180 GB
+            # were given back: seen once as 3.4 s in front of the first byte on a fresh box) that say nothing about the path
+            stream_end_to_end(N, B, min(20_000, W, Lbp), tmp, expect_body_bytes=None)
             out["stream_end_to_end"] = stream_end_to_end(N, B, min(W, Lbp), tmp, expect_body_bytes=None)
             out["stream_end_to_end_bgzf"] = stream_end_to_end(N, B, min(W, Lbp), tmp, expect_body_bytes=None, output_format="z")
             # BCF2, what GATK4's GenomicsDBFeatureReader decodes: uncompressed ("bu", the JNI's is_bcf stream) and as BGZF blocks ("b")

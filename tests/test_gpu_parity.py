@@ -1284,6 +1284,56 @@ def test_intervals_in_flight_on_lanes_give_the_same_bytes(gdb, tmp_path, lanes):
     eng.close()
 
 
+def test_c5_one_piece_of_2000_columns_at_50000_samples(gdb, tmp_path):
+    """BASELINE.json configs[4] at its stated width, one of the 50 pieces tests/tools/c5_full.py works off: 50 000 samples, 2 000 columns
+    of the dense region (every sample starts an insertion out of a pool of 64 alleles every 50 columns: 40 hot sites of 50 000 calls,
+    ~66 merged alleles, PL vectors of 2 278 genotypes; 5 M cells, ~12 GB of text).  Checked through what does not need the oracle at
+    this size - two pagings and a cut into pieces give the same stream (device-side checksums), one line per record, a hot record
+    has 9 + N columns with G = (A + 1)(A + 2) / 2 PL values - and against the ORACLE on the columns in front of the first hot site."""
+    import ctypes
+    import torch
+    from genomicsdb_amd import synth
+    N, B, L = 50_000, 10_000_000, 2000
+    g = synth.Generator(N, B, L + 3000, dense=(B, L, 50, 64))
+    eng_q = helpers.synth_query(tmp_path, N, B, B + L - 1)
+    eng_q["max_diploid_alt_alleles_that_can_be_genotyped"] = 64
+    eng = gdb.CombineEngine(eng_q)
+    eng.stage_cells_begin()
+    head_cells = b""
+    for col in (B + 45, B + L + 3000):
+        ptr, nbytes, nc = g.next_chunk(col)
+        if col == B + 45:
+            head_cells = ctypes.string_at(ptr, nbytes)
+        eng.stage_cells_append(ptr, nbytes)
+    eng.stage_cells_end()
+    g.close()
+    eng.set_reference(B, synth.reference(B, L + 8000))
+    a = _stream_checksum(eng, B, B + L - 1, 16 << 30)
+    b = _stream_checksum(eng, B, B + L - 1, 1 << 30, split_every=500)
+    assert a[:4] == b[:4] and b[4] > a[4] and a[0] > 8e9
+    # the columns in front of the first hot site: every live interval of them begins in the first chunk
+    d = tmp_path / "head"
+    d.mkdir()
+    qh = helpers.synth_query(d, N, B, B + 39)
+    qh["max_diploid_alt_alleles_that_can_be_genotyped"] = 64
+    want, nrec, _ = helpers.oracle_run_synth(qh, head_cells, synth.SEED, with_header=False)
+    got, st = eng.run_interval(B, B + 39, arena_bytes=1 << 30)
+    assert st.num_records == nrec and got == want
+    # one hot record where it lies in HBM: columns and PL length
+    pages = eng.page_tensors(B + 50, B + 50, arena_bytes=2 << 30)
+    rec = b"".join(bytes(t.cpu().numpy().tobytes()) for t in pages)
+    lines = rec.split(b"\n")
+    assert lines[-1] == b"" and len(lines) == 2
+    cols = lines[0].split(b"\t")
+    assert len(cols) == 9 + N
+    A = len(cols[4].split(b","))                       # ALT alleles incl. <NON_REF>
+    assert A >= 60 and cols[4].endswith(b"<NON_REF>")
+    fmt = cols[8].split(b":")
+    pl = cols[9].split(b":")[fmt.index(b"PL")]
+    assert len(pl.split(b",")) == (A + 1) * (A + 2) // 2
+    eng.close()
+
+
 def test_c4_sample_count_100000_rows_matches_oracle(gdb, tmp_path):
     """BASELINE.json configs[3]'s sample count on a narrow window: 100 000 samples (1 563 chunks of 64 sample columns, a first
     record with 100 000 calls starting at the partition begin - allele merge, medians and sums by its workgroup), 24 columns"""
