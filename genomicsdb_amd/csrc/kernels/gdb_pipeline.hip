@@ -143,6 +143,7 @@ inline int write2_run_length() { const char* e = getenv("GDBAMD_RUN_W2"); return
 // wavefronts (= neighbouring 64-sample chunks) per workgroup of the page assembly: 4 measured best on the store-only model
 inline int write_waves_per_group() { const char* e = getenv("GDBAMD_WRITE_WAVES"); return e && *e ? atoi(e) : 1; }
 inline bool slot_regroup() { static const bool v = []() { const char* e = getenv("GDBAMD_SLOT_REGROUP"); return !(e && *e == '0'); }(); return v; }
+inline bool coop_unroll_wanted() { const char* e = getenv("GDBAMD_COOP_UNROLL"); return !(e && *e == '0'); }   // (A/B: 0 keeps the word-by-word copy of long entries)
 inline bool xcd_aware_numbering() { const char* e = getenv("GDBAMD_XCD_AWARE"); return !(e && *e == '0'); }
 // LDS image of one (record, 64-sample chunk) of the page kernel.  GDBAMD_WRITE_IMAGE_KB = 4 / 6 / 8 forces one; otherwise by the
 // interval's average chunk: 4 KiB while a chunk (c2: 2.8 KB) and its alignment slack fit - more resident wavefronts per CU, 0.4-0.6 ms
@@ -1690,7 +1691,11 @@ template <int WAVES> __device__ __forceinline__ int64_t xcd_aware_unit(int64_t t
   const int64_t u = (int64_t)lb * WAVES + (int64_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform: scalar registers)
   return u < total_units ? u : -1;
 }
-template <int WAVES, int kWaveLds> __global__ void __launch_bounds__(kAsmRows * WAVES)
+// COOP_U: 16-byte words per lane whose source loads are in flight together in the cooperative copy of a long entry (the whole
+// wavefront moves one entry pool -> page).  1 = load, shift, store, word by word: every iteration waits a full memory latency for
+// its two loads - fine where long entries are rare (c2, c3), but c5's hot records are ALL long entries (6 KB of PL text per sample,
+// 550 of 597 GB): 4 there (chosen by the host from the largest record's average entry), at the price of registers.
+template <int WAVES, int kWaveLds, int COOP_U = 1> __global__ void __launch_bounds__(kAsmRows * WAVES)
 k_assemble_write(const char* __restrict__ pool, const char* __restrict__ pool_ovf, const uint32_t* __restrict__ prefix_len, const ResMatrix resolved, int64_t resolved_base,
                  const int32_t* __restrict__ order, int64_t n, int nchunks, int run, const uint64_t* __restrict__ chunk_off, uint64_t page_base,
                  char* __restrict__ arena, int xcd_aware, int64_t res_rows) {
@@ -1747,19 +1752,28 @@ k_assemble_write(const char* __restrict__ pool, const char* __restrict__ pool_ov
           if ((uint32_t)lane < head) gdst[lane] = big_src[lane];
           const uint32_t nwords = (big_len - head) >> 4;
           uint4* gw = reinterpret_cast<uint4*>(gdst + head);
-          for (uint32_t wq = lane; wq < nwords; wq += kAsmRows) {   // aligned 16-byte stores, source words assembled from two aligned loads
-            const char* sp = big_src + head + ((size_t)wq << 4);
-            const uint4 lo = *reinterpret_cast<const uint4*>((uintptr_t)sp & ~(uintptr_t)15);
-            const uint4 hi = *reinterpret_cast<const uint4*>(((uintptr_t)sp & ~(uintptr_t)15) + 16);
-            const uint32_t sh = (uint32_t)((uintptr_t)sp & 15u);
-            const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-            uint32_t o[4];
+          for (uint32_t w0 = lane; w0 < nwords; w0 += kAsmRows * COOP_U) {   // aligned 16-byte stores, source words assembled from two aligned loads
+            uint4 lo[COOP_U], hi[COOP_U];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const uint32_t a = w[(sh >> 2) + q], b = w[(sh >> 2) + q + 1 < 8 ? (sh >> 2) + q + 1 : 7];
-              o[q] = __builtin_amdgcn_alignbyte(b, a, sh & 3u);
+            for (int u = 0; u < COOP_U; ++u) {                    // all loads of the batch first ...
+              const uint32_t wq = w0 + (uint32_t)u * kAsmRows;
+              const char* sp = big_src + head + ((size_t)(wq < nwords ? wq : w0) << 4);
+              lo[u] = *reinterpret_cast<const uint4*>((uintptr_t)sp & ~(uintptr_t)15);
+              hi[u] = *reinterpret_cast<const uint4*>(((uintptr_t)sp & ~(uintptr_t)15) + 16);
             }
-            gw[wq] = make_uint4(o[0], o[1], o[2], o[3]);
+            const uint32_t sh = (uint32_t)((uintptr_t)(big_src + head) & 15u);   // (the same for every word of the entry)
+#pragma unroll
+            for (int u = 0; u < COOP_U; ++u) {                    // ... then shift and store
+              const uint32_t wq = w0 + (uint32_t)u * kAsmRows;
+              const uint32_t w[8] = {lo[u].x, lo[u].y, lo[u].z, lo[u].w, hi[u].x, hi[u].y, hi[u].z, hi[u].w};
+              uint32_t o[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const uint32_t a = w[(sh >> 2) + q], b = w[(sh >> 2) + q + 1 < 8 ? (sh >> 2) + q + 1 : 7];
+                o[q] = __builtin_amdgcn_alignbyte(b, a, sh & 3u);
+              }
+              if (wq < nwords) gw[wq] = make_uint4(o[0], o[1], o[2], o[3]);
+            }
           }
           const uint32_t tail_at = head + (nwords << 4);
           if ((uint32_t)lane < big_len - tail_at) gdst[tail_at + lane] = big_src[tail_at + lane];
@@ -5825,6 +5839,13 @@ bool DevicePipeline::begin_page(uint64_t arena_bytes, int arena_idx, PageTicket*
     (res_chunk_major() && iv.asm_path != 2) ? (iv.resolved_whole ? (int64_t)iv.P_rows : np) : (int64_t)0)
   {
     const int ww = write_waves_per_group(), wl = write_image_kb(iv.P > 0 && iv.nchunks > 0 ? iv.total_bytes / ((uint64_t)iv.P * (uint64_t)iv.nchunks) : 0);
+    // the largest record's average entry is a long one (copied by the whole wavefront): the variant that keeps 4 words per lane in flight
+    const bool long_entries = coop_unroll_wanted() && iv.nchunks > 0 && iv.max_record_bytes / ((uint64_t)iv.nchunks * kAsmRows) > (uint64_t)kCooperativeEntry;
+    if (long_entries && ww == 1) {
+      hipLaunchKernelGGL((k_assemble_write<1, 8192, 4>), dim3(wgrid.x), dim3(kAsmRows), 0, st, (const char*)S.pool.p, (const char*)S.pool_ovf.p,
+        (const uint32_t*)S.prefix_len.p, res_view(), iv.resolved_whole ? (int64_t)0 : kp, (const int32_t*)S.order.p, np, iv.nchunks, wrun, (const uint64_t*)S.chunk_off.p, page_base, arena, xcd_aware_numbering() ? 1 : 0,
+        (res_chunk_major() && iv.asm_path != 2) ? (iv.resolved_whole ? (int64_t)iv.P_rows : np) : (int64_t)0);
+    } else
     if (ww >= 4 && wl <= 4) GDB_LAUNCH_WRITE(4, 4096);
     else if (ww >= 4 && wl <= 6) GDB_LAUNCH_WRITE(4, 6144);
     else if (ww >= 4) GDB_LAUNCH_WRITE(4, 8192);
