@@ -310,13 +310,25 @@ __global__ void k_cell_ranges(FragmentView fr, CombinePlan pl, CellMeta cm, Reco
   const int64_t prev_key = __shfl_up(klo, 1, 64);
   const bool head = lane == 0 || prev_key != klo;
   const uint32_t run_id = wave_inclusive_scan_dpp(head ? 1u : 0u);   // runs of equal klo (dead lanes are runs of their own)
+  // The -words: normally scattered (cells that begin together end apart), one atomic per lane.  At a hot site of BASELINE configs[4]
+  // 50 000 cells begin AND end together: 50 000 x nwords atomics on one address per site (k_cell_ranges 6.0 ms per 2 000-column piece
+  // of c5, two thirds of its sweep).  When most of the wavefront's neighbours share khi as well, the -words are summed per run like
+  // the +words (runs of equal (klo, khi): a subdivision of the klo runs).
+  const int64_t prev_khi = __shfl_up(khi, 1, 64);
+  const bool same_khi = live && lane > 0 && prev_key == klo && prev_khi == khi;
+  const bool runs_end_together = __popcll(__ballot(same_khi)) >= 32;                 // uniform
+  const bool head2 = head || prev_khi != khi;
+  const uint32_t run_id2 = runs_end_together ? wave_inclusive_scan_dpp(head2 ? 1u : 0u) : 0u;
   for (int word = 0; word < pk.nwords; ++word) {           // uniform
     uint64_t acc = 0;
     if (live) acc = word + 1 < pk.nwords ? stage_packed_word(pl, pk, vm, cf, word) : (uint64_t)(int64_t)dp;
     const uint64_t run = wave_run_sum(run_id, acc, lane);
     uint64_t* w = pk.w + (int64_t)word * pk.stride;
     if (live && head && run) atomicAdd((unsigned long long*)(w + klo), (unsigned long long)run);
-    if (live && acc) atomicAdd((unsigned long long*)(w + khi + 1), (unsigned long long)(0 - acc));
+    if (runs_end_together) {
+      const uint64_t run2 = wave_run_sum(run_id2, acc, lane);
+      if (live && head2 && run2) atomicAdd((unsigned long long*)(w + khi + 1), (unsigned long long)(0 - run2));
+    } else if (live && acc) atomicAdd((unsigned long long*)(w + khi + 1), (unsigned long long)(0 - acc));
   }
   // one atomic per wavefront, spread over kCountSpread addresses (same-address atomics serialise in L2: ~10 ns each)
   const uint64_t m = __ballot(live);
@@ -1692,10 +1704,11 @@ template <int WAVES> __device__ __forceinline__ int64_t xcd_aware_unit(int64_t t
   return u < total_units ? u : -1;
 }
 // COOP_U: 16-byte words per lane whose source loads are in flight together in the cooperative copy of a long entry (the whole
-// wavefront moves one entry pool -> page).  1 = load, shift, store, word by word: every iteration waits a full memory latency for
-// its two loads - fine where long entries are rare (c2, c3), but c5's hot records are ALL long entries (6 KB of PL text per sample,
-// 550 of 597 GB): 4 there (chosen by the host from the largest record's average entry), at the price of registers.
-template <int WAVES, int kWaveLds, int COOP_U = 1> __global__ void __launch_bounds__(kAsmRows * WAVES)
+// wavefront moves one entry pool -> page): 2 where long entries are rare (c2, c3); c5's hot records are ALL long entries (6 KB of PL
+// text per sample, 550 of 597 GB): 4 there (chosen by the host from the largest record's average entry), at the price of registers.
+struct __attribute__((packed)) GlobalPackedU128_ { u32x4 v; };
+typedef __attribute__((address_space(1))) GlobalPackedU128_ GlobalPackedU128;   // an unaligned 16-byte word in GLOBAL memory (global_load, not flat_load)
+template <int WAVES, int kWaveLds, int COOP_U = 2> __global__ void __launch_bounds__(kAsmRows * WAVES)
 k_assemble_write(const char* __restrict__ pool, const char* __restrict__ pool_ovf, const uint32_t* __restrict__ prefix_len, const ResMatrix resolved, int64_t resolved_base,
                  const int32_t* __restrict__ order, int64_t n, int nchunks, int run, const uint64_t* __restrict__ chunk_off, uint64_t page_base,
                  char* __restrict__ arena, int xcd_aware, int64_t res_rows) {
@@ -1752,27 +1765,21 @@ k_assemble_write(const char* __restrict__ pool, const char* __restrict__ pool_ov
           if ((uint32_t)lane < head) gdst[lane] = big_src[lane];
           const uint32_t nwords = (big_len - head) >> 4;
           uint4* gw = reinterpret_cast<uint4*>(gdst + head);
-          for (uint32_t w0 = lane; w0 < nwords; w0 += kAsmRows * COOP_U) {   // aligned 16-byte stores, source words assembled from two aligned loads
-            uint4 lo[COOP_U], hi[COOP_U];
+          // aligned 16-byte stores fed by UNALIGNED 16-byte global loads (gfx9 handles the misalignment in the memory pipeline).  Until round 5
+          // every word was assembled from two aligned loads with v_alignbyte and a run-time word offset - which the compiler turns into a
+          // chain of eight v_cndmask per source word: ~150 instructions per 16 bytes, the reason c5's page assembly ran at 0.19.
+          const GlobalPackedU128* gsrc = (const GlobalPackedU128*)(uintptr_t)(big_src + head);
+          for (uint32_t w0 = lane; w0 < nwords; w0 += kAsmRows * COOP_U) {
+            u32x4 v[COOP_U];
 #pragma unroll
             for (int u = 0; u < COOP_U; ++u) {                    // all loads of the batch first ...
               const uint32_t wq = w0 + (uint32_t)u * kAsmRows;
-              const char* sp = big_src + head + ((size_t)(wq < nwords ? wq : w0) << 4);
-              lo[u] = *reinterpret_cast<const uint4*>((uintptr_t)sp & ~(uintptr_t)15);
-              hi[u] = *reinterpret_cast<const uint4*>(((uintptr_t)sp & ~(uintptr_t)15) + 16);
+              v[u] = gsrc[wq < nwords ? wq : w0].v;
             }
-            const uint32_t sh = (uint32_t)((uintptr_t)(big_src + head) & 15u);   // (the same for every word of the entry)
 #pragma unroll
-            for (int u = 0; u < COOP_U; ++u) {                    // ... then shift and store
+            for (int u = 0; u < COOP_U; ++u) {                    // ... then the stores
               const uint32_t wq = w0 + (uint32_t)u * kAsmRows;
-              const uint32_t w[8] = {lo[u].x, lo[u].y, lo[u].z, lo[u].w, hi[u].x, hi[u].y, hi[u].z, hi[u].w};
-              uint32_t o[4];
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const uint32_t a = w[(sh >> 2) + q], b = w[(sh >> 2) + q + 1 < 8 ? (sh >> 2) + q + 1 : 7];
-                o[q] = __builtin_amdgcn_alignbyte(b, a, sh & 3u);
-              }
-              if (wq < nwords) gw[wq] = make_uint4(o[0], o[1], o[2], o[3]);
+              if (wq < nwords) gw[wq] = make_uint4(v[u][0], v[u][1], v[u][2], v[u][3]);
             }
           }
           const uint32_t tail_at = head + (nwords << 4);

@@ -27,21 +27,39 @@ while col < B + L + 3000:
 eng.stage_cells_end()
 eng.set_reference(B, synth.reference(B, L + 8000))
 t_stage = time.time() - t0
-tot = {"records": 0, "bytes": 0, "remap": 0, "ms_sweep": 0.0, "ms_site": 0.0, "ms_size": 0.0, "ms_write": 0.0, "pieces": 0, "heavy": 0}
-t1 = time.time()
-cur, qe = B, B + L - 1
-while cur <= qe:
-    pe = eng.split_point(cur, qe, PIECE)
-    _, st = eng.run_interval(cur, pe, arena_bytes=64 << 30, fetch=False)
-    tot["records"] += st.num_records; tot["bytes"] += st.bytes_out; tot["remap"] += st.num_remap_elements; tot["heavy"] += st.num_heavy_incidences
-    tot["ms_sweep"] += st.ms_sweep; tot["ms_site"] += st.ms_site; tot["ms_size"] += st.ms_size; tot["ms_write"] += st.ms_write; tot["pieces"] += 1
-    cur = pe + 1
-    if time.time() - t1 > 900:
-        print("time limit: stopped at column", cur); break
-dt = time.time() - t1
-dev = (tot["ms_sweep"] + tot["ms_site"] + tot["ms_size"] + tot["ms_write"]) * 1e-3
-print(json.dumps({"what": "c5: %d samples x %d bp dense region, K = %d, %d-column pieces" % (N, L, K, PIECE), "cells": ncells, "cell_bytes": nbytes_all, "stage_s": t_stage,
-                  "covered_bp": cur - B, "pieces": tot["pieces"], "records": tot["records"], "heavy_incidences": tot["heavy"], "bytes_out": tot["bytes"], "wall_s": dt, "device_s": dev,
-                  "phase_ms": {k: tot[k] for k in ("ms_sweep", "ms_site", "ms_size", "ms_write")}, "positions_per_s": tot["records"] / dt, "GBps_out": tot["bytes"] / dt / 1e9,
-                  "remap_elements": tot["remap"], "remap_elements_per_s": tot["remap"] / dt, "remap_elements_per_s_device": tot["remap"] / max(dev, 1e-9),
-                  "site_pass_PL_read_GBps": tot["remap"] * 4 / max(tot["ms_site"] * 1e-3, 1e-9) / 1e9}))
+def run(LANES):
+    tot = {"records": 0, "bytes": 0, "remap": 0, "ms_sweep": 0.0, "ms_site": 0.0, "ms_size": 0.0, "ms_write": 0.0, "pieces": 0, "heavy": 0}
+    def account(st):
+        tot["records"] += st.num_records; tot["bytes"] += st.bytes_out; tot["remap"] += st.num_remap_elements; tot["heavy"] += st.num_heavy_incidences
+        tot["ms_sweep"] += st.ms_sweep; tot["ms_site"] += st.ms_site; tot["ms_size"] += st.ms_size; tot["ms_write"] += st.ms_write; tot["pieces"] += 1
+    cur, qe = B, B + L - 1
+    if LANES > 1:
+        pieces = []
+        while cur <= qe:
+            pe = eng.split_point(cur, qe, PIECE)
+            pieces.append((cur, pe)); cur = pe + 1
+        eng.run_intervals(pieces[:LANES], arena_bytes=16 << 30, lanes=LANES)          # every lane once, untimed: it adopts and classifies the fragment, sizes its buffers
+        t1 = time.time()
+        for st in eng.run_intervals(pieces, arena_bytes=16 << 30, lanes=LANES):
+            account(st)
+    else:
+        t1 = time.time()
+        while cur <= qe:
+            pe = eng.split_point(cur, qe, PIECE)
+            _, st = eng.run_interval(cur, pe, arena_bytes=64 << 30, fetch=False)
+            account(st)
+            cur = pe + 1
+            if time.time() - t1 > 900:
+                print("time limit: stopped at column", cur); break
+    dt = time.time() - t1
+    dev = (tot["ms_sweep"] + tot["ms_site"] + tot["ms_size"] + tot["ms_write"]) * 1e-3
+    print(json.dumps({"what": "c5: %d samples x %d bp dense region, K = %d, %d-column pieces" % (N, L, K, PIECE), "lanes": LANES, "cells": ncells, "cell_bytes": nbytes_all, "stage_s": t_stage,
+                      "covered_bp": cur - B, "pieces": tot["pieces"], "records": tot["records"], "heavy_incidences": tot["heavy"], "bytes_out": tot["bytes"], "wall_s": dt, "device_s": dev,
+                      "phase_ms": {k: tot[k] for k in ("ms_sweep", "ms_site", "ms_size", "ms_write")}, "positions_per_s": tot["records"] / dt, "GBps_out": tot["bytes"] / dt / 1e9,
+                      "remap_elements": tot["remap"], "remap_elements_per_s": tot["remap"] / dt, "remap_elements_per_s_device": tot["remap"] / max(dev, 1e-9),
+                      "site_pass_PL_read_GBps": tot["remap"] * 4 / max(tot["ms_site"] * 1e-3, 1e-9) / 1e9}))
+
+
+# C5_LANES="1,3": the same staged array once per lane count (pieces in flight at a time, gdbamd_engine_run_intervals; > 1: the phase times overlap)
+for lanes in [int(x) for x in os.environ.get("C5_LANES", "1").split(",")]:
+    run(lanes)
