@@ -132,6 +132,12 @@ def main():
     lanes = max(1, min(4, args.lanes))
     if lanes > 1:
         arena = min(arena, int(os.environ.get("GDBAMD_BENCH_LANE_ARENA_MB", "46080")) << 20)   # (two 48 GiB pages + two entry tables do not fit beside the fragment)
+        # a lane needs its page arena and its entry table / matrix / sweep buffers (~14 GB at c2's width; scaled by the window for others):
+        # no more lanes than the free HBM holds
+        free_b, _ = torch.cuda.mem_get_info(device_index)
+        per_lane = min(arena, 45 * N * W + (1 << 30)) + 18 * N * W + (2 << 30)     # (~45 bytes of text and up to ~18 bytes of tables per sample and position)
+        while lanes > 1 and lanes * per_lane + (4 << 30) > free_b:
+            lanes -= 1
         # every lane has to have run one full window before the clock starts: its pipeline is created, adopts and classifies the staged
         # fragment and sizes its grow-only buffers then (one-off work of the kind staging is).  With W >= lanes the W warm-up steps do that;
         # else the missing ones are run here, untimed and reported as "untimed_lane_preparation_steps".
