@@ -252,6 +252,36 @@ def test_gt_mpi_gather_produce_histogram(gdb, tmp_path):
     assert r.stdout.decode() == want
 
 
+@pytest.mark.parametrize("interval,total", [((12150, 12250), 2), ((12144, 17384), 5), ((12300, 17000), 0)])
+def test_produce_histogram_counts_the_cells_of_the_query_intervals(gdb, tmp_path, interval, total):
+    """the reference hands ColumnHistogramOperator the cells of the QUERY's column intervals (iterate_over_cells(ad, query_config, op),
+    tools/src/gt_mpi_gather.cc:404-411): the cells that begin inside an interval and the intervals that began in front of it and reach
+    its begin.  t0 / t1 / t2: reference blocks [12140, 12294] and [12144, 12276], three cells at 17384.  [12150, 12250]: the two blocks
+    reach in (2); [12144, 17384]: four cells begin inside, the block from 12140 reaches in (5); [12300, 17000]: nothing - and the
+    partition lines are then just the header (the reference's loop would not terminate on an empty histogram)."""
+    from golden_cases import CASES
+    case = [c for c in CASES if c[0] == "t0_1_2_vcf_at_0"][0]
+    _, callsets, vid, ov, golden, mode = case
+    cells = helpers.cells_for(callsets, vid)
+    q, _ = helpers.query_json(callsets, vid, ov, mode)
+    ws = tmp_path / "ws"
+    (ws / "t0_1_2").mkdir(parents=True)
+    (ws / "t0_1_2" / "cells.bin").write_bytes(cells)
+    q["workspace"] = str(ws); q["array"] = "t0_1_2"
+    q["query_column_ranges"] = [[[interval[0], interval[1]]]]
+    qf = tmp_path / "query.json"
+    qf.write_text(json.dumps(q))
+    r = subprocess.run([os.path.join(helpers.ROOT, "genomicsdb_amd", "gt_mpi_gather"), "-j", str(qf), "--produce-histogram"], capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    blocks = r.stdout.decode().split("\n\n")
+    first = blocks[0].split("\n")
+    assert first[0] == "Total %d #bins 128 count/bins %.1f" % (total, total / 128.0)
+    if total == 0:
+        assert len(first) == 1
+    else:
+        assert sum(int(l.split(",")[2]) for l in first[1:]) == total
+
+
 def test_rccl_paged_concat_one_rank(gdb, tmp_path):
     """the same concat over the "nccl" backend (= RCCL) with the pages in HBM; one GPU here, so one rank: device buffers and
     the page pull are exercised, ordering across ranks by the gloo runs above and tests/test_multi_rank_cpu.py"""

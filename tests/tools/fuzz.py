@@ -55,6 +55,7 @@ for case in range(ncases):
     cells, nc = g.chunk_bytes(B + off + L + 2500)
     q = helpers.synth_query(tmp, N, qb, qe, with_id=with_id, contigs=contigs)
     q.update(opts)
+    if with_id and rnd.random() < 0.5: q["id_union_order"] = "unordered_set"     # (round 5: the ID union of a Release build of the reference)
     want, nrec, _ = helpers.oracle_run_synth(q, cells, gseed, with_header=False)
     eng = genomicsdb_amd.CombineEngine(q)
     # stage in 1-3 parts
@@ -92,6 +93,14 @@ for case in range(ncases):
             k = next((i for i in range(min(len(j), len(want))) if j[i] != want[i]), -1)
             print("  pieces (max %d columns, %d pieces): got %d bytes, want %d, first difference at %d: %r / %r" % (maxc, len(pieces), len(j), len(want), k, j[max(0, k - 80):k + 40], want[max(0, k - 80):k + 40]))
         ok = ok and b"".join(pieces) == want
+        if ok and len(pieces) > 1 and rnd.random() < 0.6:   # (round 5) the same pieces, 2-3 of them in flight at a time on lane pipelines that share the fragment
+            cur, ivs = qb, []
+            while cur <= qe:
+                pe = eng.split_point(cur, qe, maxc)
+                ivs.append((cur, pe)); cur = pe + 1
+            res = eng.run_intervals(ivs, arena_bytes=max(arena, 1 << 12), lanes=rnd.choice([2, 3]), fetch=True)
+            ok = b"".join(r[0] for r in res) == want
+            if not ok: print("  lanes: %d intervals differ from the one-at-a-time pieces" % len(ivs))
     eng.close()
     if ok and rnd.random() < 0.25:   # the same interval as BGZF blocks deflated on the device: the inflated stream is the text
         import zlib
