@@ -80,43 +80,17 @@ __device__ __forceinline__ void fixed_litlen(uint32_t sym, uint32_t& bits, uint3
   bits = __brev(code) >> (32u - nb);
 }
 
-template <int kBgzfBlockInput>
-__global__ void __launch_bounds__(64) k_bgzf_deflate(const uint8_t* __restrict__ src, uint64_t n_total, uint8_t* __restrict__ slots, uint32_t* __restrict__ csize,
-                                                     uint64_t* __restrict__ bsize, uint32_t* __restrict__ crc_out, const uint32_t* __restrict__ crc_slice,
-                                                     const uint32_t* __restrict__ crc_shift) {
-  const uint64_t blk = blockIdx.x;
-  const uint64_t base = blk * (uint64_t)kBgzfBlockInput;
-  const uint32_t n = (uint32_t)((n_total - base) < (uint64_t)kBgzfBlockInput ? (n_total - base) : (uint64_t)kBgzfBlockInput);
-  const int lane = threadIdx.x;
-  __shared__ uint4 in4[kBgzfBlockInput / 16 + 3];             // 48 bytes of zeros behind the block: the probes read up to 39 bytes past a position
-  constexpr int kHashBits = kBgzfBlockInput > 8192 ? 11 : kBgzfBlockInput > 4096 ? GDBAMD_BGZF_HASH_BITS_8K : 9;
-  constexpr uint32_t kSlotBytes = slot_bytes((uint32_t)kBgzfBlockInput);
-  constexpr int kPieceWords = kBgzfBlockInput / 256 + 1;       // dwords of the block whose CRC a lane takes: an ODD count, so that the lanes' reads fall into different banks
-  __shared__ uint32_t table32[(1 << kHashBits) / 2 + 2];      // (+ a spare slot for the positions behind the block's end)
-  __shared__ uint32_t ring[kRingWords];
-  __shared__ uint32_t tokq[kTokQueue];                        // tokens waiting to be encoded (< 64 before a step, < 128 after it)
-  uint8_t* const in = reinterpret_cast<uint8_t*>(in4);
-  uint16_t* const table = reinterpret_cast<uint16_t*>(table32);
-  // ---- the piece into LDS (zero behind its end: the 8-byte compares read up to 7 bytes past it) -------------------------------------
-  const uint8_t* const blk_src = src + base;
-  for (uint32_t q = lane; q < kBgzfBlockInput / 16 + 3; q += 64) {
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (q * 16u + 16u <= n) v = reinterpret_cast<const uint4*>(blk_src)[q];
-    else if (q * 16u < n) {
-      uint32_t w[4] = {0, 0, 0, 0};
-      for (uint32_t b = q * 16u; b < n; ++b) w[(b & 15u) >> 2] |= (uint32_t)blk_src[b] << (8u * (b & 3u));
-      v = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-    in4[q] = v;
-  }
-  for (uint32_t q = lane; q < (1u << kHashBits) / 2 + 2; q += 64) table32[q] = 0xFFFFFFFFu;
-  for (uint32_t q = lane; q < kRingWords; q += 64) ring[q] = (q == 0) ? 3u : 0u;      // BFINAL = 1, BTYPE = 01 (fixed Huffman)
-  __syncthreads();
-  uint32_t* const out_words = reinterpret_cast<uint32_t*>(slots + blk * (uint64_t)kSlotBytes);
+// One wavefront's share of a block: the positions [begin, end) of the `n` input bytes in LDS, deflated as ONE fixed-Huffman block
+// whose first three bits (BFINAL + BTYPE) are already in ring[0].  `table` is the wavefront's own hash table: empty, or primed with
+// the positions in front of `begin` (its dictionary).  Returns the bit position behind the last token (no end-of-block symbol yet);
+// gave_up: the output has outgrown the input, the whole block will be stored.
+template <int kBgzfBlockInput, int kHashBits>
+__device__ __forceinline__ uint32_t deflate_range(const uint8_t* in, uint32_t n, uint32_t begin, uint32_t end, uint16_t* table, uint32_t* ring, uint32_t* tokq,
+                                                  uint32_t* out_words, int lane, bool& gave_up) {
   uint32_t bitpos = 3, flushed = 0;
-  uint32_t p = 0;
+  uint32_t p = begin;
   int e = 0;
-  bool gave_up = false;
+  gave_up = false;
   uint32_t qhead = 0, qtail = 0;                               // token queue (uniform counters)
   // ---- tokens -> bits: the next `ntok` <= 64 tokens of the queue, one per lane ----------------------------------------------------------
   // (the kernel is bound by the instructions it issues - SQ counters, profiles/r3_*: a step of 64 positions yields ~6 tokens, so
@@ -158,7 +132,7 @@ __global__ void __launch_bounds__(64) k_bgzf_deflate(const uint8_t* __restrict__
     }
     bitpos += total;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    if ((bitpos >> 3) > n) { gave_up = true; return; }        // uniform: the block is not shrinking, it will be stored
+    if ((bitpos >> 3) > end - begin) { gave_up = true; return; }   // uniform: the range is not shrinking, the block will be stored
     while ((bitpos >> 5) - flushed >= (uint32_t)kFlushWords) {   // uniform: full words leave, their ring slots are zeroed for reuse
       for (uint32_t i = lane; i < (uint32_t)kFlushWords; i += 64) {
         const uint32_t slot = (flushed + i) & (kRingWords - 1);
@@ -169,12 +143,12 @@ __global__ void __launch_bounds__(64) k_bgzf_deflate(const uint8_t* __restrict__
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
   };
-  while (p < n) {                                             // uniform
+  while (p < end) {                                           // uniform
     // The body of a step is written without branches on per-lane conditions (every such branch costs exec-mask bookkeeping on
     // the scalar unit, and this kernel is bound by the instructions it issues - SQ counters, profiles/r3_*): positions behind
     // the block's end hash the zero padding into a spare table slot and come out with no candidate.
     const uint32_t q = p + (uint32_t)lane;
-    const bool can_hash = q + 4u <= n;
+    const bool can_hash = q + 4u <= n && q < end;
     // LDS accesses are aligned dwords only: a ds_read_b64 off its natural alignment is replayed at 64 LDS cycles per wave
     // instruction (2 when aligned), and with four of them per step the kernel was bound by the LDS array (SQ_LDS_IDX_ACTIVE at
     // 90 % of the kernel's cycles).  A lane reads the five aligned dwords around its position and funnel-shifts its 16 bytes out
@@ -209,13 +183,13 @@ __global__ void __launch_bounds__(64) k_bgzf_deflate(const uint8_t* __restrict__
       k = x2 ? 8u + ((uint32_t)__builtin_ctz(x2) >> 3) : k;
       k = x1 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3) : k;
       k = x0 ? ((uint32_t)__builtin_ctz(x0) >> 3) : k;
-      const uint32_t room = n > q ? n - q : 0u;               // (the zero padding behind the block never extends a match)
+      const uint32_t room = end > q ? end - q : 0u;           // (a match never runs past the range: behind it lies the other wavefront's share, or the zero padding)
       k = k < room ? k : room;
       L = (has_cand && k >= 4u) ? k : 0u;
     }
     // ---- greedy parse: the chain of token starts through this step's positions (scalar) --------------------------------------------
     // A run of literals up to the next position that has a match is taken in one go (one bit trick on the ballot of the matches).
-    const int lim = (n - p) < 64u ? (int)(n - p) : 64;
+    const int lim = (end - p) < 64u ? (int)(end - p) : 64;
     const uint64_t has_match = __ballot(L != 0u);
     uint64_t sel = 0;
     int cur = e;
@@ -231,7 +205,7 @@ __global__ void __launch_bounds__(64) k_bgzf_deflate(const uint8_t* __restrict__
       uint32_t Lc = (uint32_t)__builtin_amdgcn_readlane((int)L, cur);
       if (Lc == (uint32_t)kProbe) {                              // uniform: the probe ran to its end - how far does the match really go?
         const uint32_t cpos = (uint32_t)__builtin_amdgcn_readlane((int)cand, cur), qpos = p + (uint32_t)cur;
-        const uint32_t mx = (n - qpos) < 258u ? (n - qpos) : 258u;
+        const uint32_t mx = (end - qpos) < 258u ? (end - qpos) : 258u;
         uint32_t k = (uint32_t)kProbe;
         while (k < mx) {
           const uint32_t j = k + (uint32_t)lane;
@@ -264,24 +238,20 @@ __global__ void __launch_bounds__(64) k_bgzf_deflate(const uint8_t* __restrict__
     while (e >= 64) { e -= 64; p += 64; }                     // a match that covers whole steps: nothing to do there
   }
   if (!gave_up && qtail != qhead) emit_tokens(qtail - qhead);
-  uint32_t payload;
-  if (!gave_up) {
-    bitpos += 7;                                              // end of block: symbol 256 = seven zero bits
-    payload = (bitpos + 7u) >> 3;
-    if (payload >= n + 5u) gave_up = true;
-  }
-  if (!gave_up) {
-    const uint32_t nwords = (bitpos + 31u) >> 5;
-    for (uint32_t i = flushed + lane; i < nwords; i += 64) out_words[i] = ring[i & (kRingWords - 1)];
-  } else {
-    // stored block: 0x01 (BFINAL, BTYPE 00, padding), LEN, NLEN, the bytes
-    uint8_t* o = slots + blk * (uint64_t)kSlotBytes;
-    if (lane == 0) { o[0] = 1; o[1] = (uint8_t)(n & 0xFFu); o[2] = (uint8_t)(n >> 8); o[3] = (uint8_t)(~n & 0xFFu); o[4] = (uint8_t)((~n >> 8) & 0xFFu); }
-    for (uint32_t i = lane; i < n; i += 64) o[5 + i] = in[i];
-    payload = n + 5u;
-  }
-  // ---- CRC-32 of the block's input --------------------------------------------------------------------------------------------
-  uint32_t crc;
+  // (what is left in the ring is written by the caller, once the block's end is in it)
+  (void)flushed;
+  return bitpos;
+}
+// full ring words behind `bitpos` that emit_tokens has not flushed: everything from the last multiple of kFlushWords below bitpos / 32
+__device__ __forceinline__ void flush_ring_tail(const uint32_t* ring, uint32_t* out_words, uint32_t bitpos_before_end, uint32_t bitpos, int lane) {
+  const uint32_t flushed = ((bitpos_before_end >> 5) / (uint32_t)kFlushWords) * (uint32_t)kFlushWords;
+  const uint32_t nwords = (bitpos + 31u) >> 5;
+  for (uint32_t i = flushed + lane; i < nwords; i += 64) out_words[i] = ring[i & (kRingWords - 1)];
+}
+// CRC-32 of the n <= kBgzfBlockInput input bytes in LDS, by ONE wavefront (every lane its piece + the GF(2) shift over what follows it)
+template <int kBgzfBlockInput>
+__device__ __forceinline__ uint32_t block_crc(const uint8_t* in, uint32_t n, int lane, const uint32_t* __restrict__ crc_slice, const uint32_t* __restrict__ crc_shift) {
+  constexpr int kPieceWords = kBgzfBlockInput / 256 + 1;       // dwords of the block whose CRC a lane takes: an ODD count, so that the lanes' reads fall into different banks
   const uint32_t* T0 = crc_slice, *T1 = crc_slice + 256, *T2 = crc_slice + 512, *T3 = crc_slice + 768;
   if (n == kBgzfBlockInput) {
     // (pieces of 128 bytes put every lane's dword i into the same LDS bank: a 64-way conflict per read; with 33 dwords per lane
@@ -296,38 +266,162 @@ __global__ void __launch_bounds__(64) k_bgzf_deflate(const uint8_t* __restrict__
     }
     const uint32_t* S = crc_shift + (size_t)lane * 1024;      // this lane's contribution after the bytes behind its piece
     const uint32_t c = S[r & 0xFFu] ^ S[256 + ((r >> 8) & 0xFFu)] ^ S[512 + ((r >> 16) & 0xFFu)] ^ S[768 + (r >> 24)];
-    crc = wave_xor(c) ^ 0xFFFFFFFFu;
-  } else {
-    uint32_t r = 0xFFFFFFFFu;                                  // the short last block of a page: one lane, serially
-    if (lane == 0) {
-      uint32_t i = 0;
-      for (; i + 4 <= n; i += 4) { const uint32_t x = r ^ lds_read_u32(in + i); r = T3[x & 0xFFu] ^ T2[(x >> 8) & 0xFFu] ^ T1[(x >> 16) & 0xFFu] ^ T0[x >> 24]; }
-      for (; i < n; ++i) r = T0[(r ^ in[i]) & 0xFFu] ^ (r >> 8);
-    }
-    crc = r ^ 0xFFFFFFFFu;
+    return wave_xor(c) ^ 0xFFFFFFFFu;
   }
-  if (lane == 0) { csize[blk] = payload; bsize[blk] = (uint64_t)payload + kBgzfHeaderBytes + kBgzfTrailerBytes; crc_out[blk] = crc; }
+  uint32_t r = 0xFFFFFFFFu;                                    // the short last block of a page: one lane, serially
+  if (lane == 0) {
+    uint32_t i = 0;
+    for (; i + 4 <= n; i += 4) { const uint32_t x = r ^ lds_read_u32(in + i); r = T3[x & 0xFFu] ^ T2[(x >> 8) & 0xFFu] ^ T1[(x >> 16) & 0xFFu] ^ T0[x >> 24]; }
+    for (; i < n; ++i) r = T0[(r ^ in[i]) & 0xFFu] ^ (r >> 8);
+  }
+  return r ^ 0xFFFFFFFFu;
+}
+// the block's bytes into LDS (zero behind its end: the probes read up to 39 bytes past a position), by all threads of the workgroup
+template <int kBgzfBlockInput>
+__device__ __forceinline__ void load_block(uint4* in4, const uint8_t* blk_src, uint32_t n, int tid, int nthreads) {
+  for (uint32_t q = tid; q < kBgzfBlockInput / 16 + 3; q += nthreads) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (q * 16u + 16u <= n) v = reinterpret_cast<const uint4*>(blk_src)[q];
+    else if (q * 16u < n) {
+      uint32_t w[4] = {0, 0, 0, 0};
+      for (uint32_t b = q * 16u; b < n; ++b) w[(b & 15u) >> 2] |= (uint32_t)blk_src[b] << (8u * (b & 3u));
+      v = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    in4[q] = v;
+  }
 }
 
-__global__ void __launch_bounds__(64) k_bgzf_pack(const uint8_t* __restrict__ slots, const uint32_t* __restrict__ csize, const uint64_t* __restrict__ boff,
-                                                  const uint32_t* __restrict__ crc, uint64_t n_total, uint8_t* __restrict__ dst, uint32_t kBgzfBlockInput) {
+// csize holds kParts payload sizes per block (the pack kernel lays them behind each other)
+template <int kBgzfBlockInput>
+__global__ void __launch_bounds__(64) k_bgzf_deflate(const uint8_t* __restrict__ src, uint64_t n_total, uint8_t* __restrict__ slots, uint32_t* __restrict__ csize,
+                                                     uint64_t* __restrict__ bsize, uint32_t* __restrict__ crc_out, const uint32_t* __restrict__ crc_slice,
+                                                     const uint32_t* __restrict__ crc_shift) {
   const uint64_t blk = blockIdx.x;
-  const int lane = threadIdx.x;
-  const uint32_t c = csize[blk];
-  uint8_t* o = dst + boff[blk];
   const uint64_t base = blk * (uint64_t)kBgzfBlockInput;
   const uint32_t n = (uint32_t)((n_total - base) < (uint64_t)kBgzfBlockInput ? (n_total - base) : (uint64_t)kBgzfBlockInput);
-  const uint32_t bs = c + kBgzfHeaderBytes + kBgzfTrailerBytes - 1u;      // BSIZE = total block size - 1
-  if (lane < 18) {
-    const uint8_t hdr[18] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, (uint8_t)(bs & 0xFFu), (uint8_t)(bs >> 8)};
-    o[lane] = hdr[lane];
-  } else if (lane < 26) {
-    const uint32_t v = lane < 22 ? crc[blk] : n;
-    o[kBgzfHeaderBytes + c + (uint32_t)(lane - 18)] = (uint8_t)((v >> (8 * ((lane - 18) & 3))) & 0xFFu);
+  const int lane = threadIdx.x;
+  __shared__ uint4 in4[kBgzfBlockInput / 16 + 3];             // 48 bytes of zeros behind the block: the probes read up to 39 bytes past a position
+  constexpr int kHashBits = kBgzfBlockInput > 8192 ? 11 : kBgzfBlockInput > 4096 ? GDBAMD_BGZF_HASH_BITS_8K : 9;
+  constexpr uint32_t kSlotBytes = slot_bytes((uint32_t)kBgzfBlockInput);
+  __shared__ uint32_t table32[(1 << kHashBits) / 2 + 2];      // (+ a spare slot for the positions behind the block's end)
+  __shared__ uint32_t ring[kRingWords];
+  __shared__ uint32_t tokq[kTokQueue];                        // tokens waiting to be encoded (< 64 before a step, < 128 after it)
+  uint8_t* const in = reinterpret_cast<uint8_t*>(in4);
+  load_block<kBgzfBlockInput>(in4, src + base, n, lane, 64);
+  for (uint32_t q = lane; q < (1u << kHashBits) / 2 + 2; q += 64) table32[q] = 0xFFFFFFFFu;
+  for (uint32_t q = lane; q < kRingWords; q += 64) ring[q] = (q == 0) ? 3u : 0u;      // BFINAL = 1, BTYPE = 01 (fixed Huffman)
+  __syncthreads();
+  uint32_t* const out_words = reinterpret_cast<uint32_t*>(slots + blk * (uint64_t)kSlotBytes);
+  bool gave_up;
+  const uint32_t body_bits = deflate_range<kBgzfBlockInput, kHashBits>(in, n, 0u, n, reinterpret_cast<uint16_t*>(table32), ring, tokq, out_words, lane, gave_up);
+  uint32_t payload = 0;
+  if (!gave_up) {
+    const uint32_t bitpos = body_bits + 7u;                   // end of block: symbol 256 = seven zero bits
+    payload = (bitpos + 7u) >> 3;
+    if (payload >= n + 5u) gave_up = true;
+    else flush_ring_tail(ring, out_words, body_bits, bitpos, lane);
   }
-  // payload: aligned words of the destination assembled from two aligned source words (the slot is 16-byte aligned, the destination not)
-  const uint8_t* s = slots + blk * (uint64_t)slot_bytes(kBgzfBlockInput);
-  uint8_t* d = o + kBgzfHeaderBytes;
+  if (gave_up) {
+    // stored block: 0x01 (BFINAL, BTYPE 00, padding), LEN, NLEN, the bytes
+    uint8_t* o = slots + blk * (uint64_t)kSlotBytes;
+    if (lane == 0) { o[0] = 1; o[1] = (uint8_t)(n & 0xFFu); o[2] = (uint8_t)(n >> 8); o[3] = (uint8_t)(~n & 0xFFu); o[4] = (uint8_t)((~n >> 8) & 0xFFu); }
+    for (uint32_t i = lane; i < n; i += 64) o[5 + i] = in[i];
+    payload = n + 5u;
+  }
+  const uint32_t crc = block_crc<kBgzfBlockInput>(in, n, lane, crc_slice, crc_shift);
+  if (lane == 0) { csize[2 * blk] = payload; csize[2 * blk + 1] = 0u; bsize[blk] = (uint64_t)payload + kBgzfHeaderBytes + kBgzfTrailerBytes; crc_out[blk] = crc; }
+}
+
+// TWO wavefronts per block (round 5).  A block's time is a chain of ~128 dependent steps and a wavefront issues an instruction every
+// third cycle (LDS round trips, the scalar parse): more wavefronts per CU and shorter chains are what it runs on.  The two halves of a
+// block go to two wavefronts, pigz's way: wavefront 1 first enters the positions of the FIRST half into its own hash table (hash and
+// store only: ~5 % of a half's work), so that its matches reach back into the first half like a sequential parse's would; each half
+// becomes a DEFLATE block of its own, the first one ends with an empty stored block (3 bits + padding + 00 00 FF FF: zlib's sync flush),
+// which makes the second one start on a byte boundary; the pack kernel puts the two payloads behind each other.  Both wavefronts share
+// the 8 KiB of input in LDS: 14.4 KB per pair = 22 wavefronts per CU instead of 14.  Ratio: a match cannot cross the middle, + 5 bytes.
+template <int kBgzfBlockInput>
+__global__ void __launch_bounds__(128) k_bgzf_deflate2(const uint8_t* __restrict__ src, uint64_t n_total, uint8_t* __restrict__ slots, uint32_t* __restrict__ csize,
+                                                       uint64_t* __restrict__ bsize, uint32_t* __restrict__ crc_out, const uint32_t* __restrict__ crc_slice,
+                                                       const uint32_t* __restrict__ crc_shift) {
+  const uint64_t blk = blockIdx.x;
+  const uint64_t base = blk * (uint64_t)kBgzfBlockInput;
+  const uint32_t n = (uint32_t)((n_total - base) < (uint64_t)kBgzfBlockInput ? (n_total - base) : (uint64_t)kBgzfBlockInput);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);    // (wave-uniform)
+  constexpr uint32_t kHalf = kBgzfBlockInput / 2;
+  __shared__ uint4 in4[kBgzfBlockInput / 16 + 3];
+  constexpr int kHashBits = kBgzfBlockInput > 8192 ? 11 : kBgzfBlockInput > 4096 ? GDBAMD_BGZF_HASH_BITS_8K : 9;
+  constexpr uint32_t kSlotBytes = slot_bytes((uint32_t)kBgzfBlockInput);
+  constexpr uint32_t kTableWords = (1 << kHashBits) / 2 + 2;
+  __shared__ uint32_t table32[2][kTableWords];
+  __shared__ uint32_t ring2[2][kRingWords];
+  __shared__ uint32_t tokq2[2][kTokQueue];
+  __shared__ uint32_t s_payload[2], s_gave_up[2];
+  uint8_t* const in = reinterpret_cast<uint8_t*>(in4);
+  load_block<kBgzfBlockInput>(in4, src + base, n, tid, 128);
+  const bool two = n > kHalf;                                 // (a short last block: the first wavefront alone)
+  uint32_t* const ring = ring2[wv];
+  for (uint32_t q = lane; q < kTableWords; q += 64) table32[wv][q] = 0xFFFFFFFFu;
+  for (uint32_t q = lane; q < kRingWords; q += 64) ring[q] = (q == 0) ? ((wv == 1 || !two) ? 3u : 2u) : 0u;   // BTYPE = 01; BFINAL only on the block's last part
+  if (tid < 2) { s_payload[tid] = 0u; s_gave_up[tid] = 0u; }
+  __syncthreads();
+  uint16_t* const table = reinterpret_cast<uint16_t*>(table32[wv]);
+  const uint32_t begin = wv == 0 ? 0u : kHalf, end = wv == 0 ? (two ? kHalf : n) : n;
+  uint32_t* const out_words = reinterpret_cast<uint32_t*>(slots + blk * (uint64_t)kSlotBytes + (uint64_t)wv * (kSlotBytes / 2));
+  if (wv == 0 || two) {
+    if (wv == 1) {
+      // the dictionary: every position of the first half enters the table (the most recent one of a hash value stays, as in a sequential parse)
+      const uint32_t* const in32 = reinterpret_cast<const uint32_t*>(in);
+      for (uint32_t pp = 0; pp < kHalf; pp += 64) {
+        const uint32_t q = pp + (uint32_t)lane, wq = q >> 2, sh = q & 3u;
+        const uint32_t w0 = __builtin_amdgcn_alignbyte(in32[wq + 1], in32[wq], sh);
+        table[(w0 * 2654435761u) >> (32 - kHashBits)] = (uint16_t)q;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+    bool gave_up;
+    const uint32_t body_bits = deflate_range<kBgzfBlockInput, kHashBits>(in, n, begin, end, table, ring, tokq2[wv], out_words, lane, gave_up);
+    uint32_t payload = 0;
+    if (!gave_up) {
+      uint32_t bitpos = body_bits + 7u;                       // end of block: seven zero bits
+      if (wv == 0 && two) {
+        // an empty stored block behind it: BFINAL = 0, BTYPE = 00 (three zero bits), padding to the byte, LEN = 0000, NLEN = FFFF
+        bitpos = (bitpos + 3u + 7u) & ~7u;
+        if (lane == 0) {                                      // the two FF bytes: bits [bitpos + 16, bitpos + 32)
+          const uint32_t off = bitpos + 16u, w = off >> 5, sh = off & 31u;   // (sh is 0, 8, 16 or 24)
+          atomicOr(&ring[w & (kRingWords - 1)], 0xFFFFu << sh);
+          if (sh > 16u) atomicOr(&ring[(w + 1u) & (kRingWords - 1)], 0xFFFFu >> (32u - sh));
+        }
+        bitpos += 32u;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      }
+      payload = (bitpos + 7u) >> 3;
+      if (payload >= (end - begin) + 16u) gave_up = true;
+      else flush_ring_tail(ring, out_words, body_bits, bitpos, lane);
+    }
+    if (lane == 0) { s_payload[wv] = payload; s_gave_up[wv] = gave_up ? 1u : 0u; }
+  }
+  __syncthreads();
+  const uint32_t total = s_payload[0] + s_payload[1];
+  const bool store = s_gave_up[0] || s_gave_up[1] || total >= n + 5u;
+  if (store) {
+    uint8_t* o = slots + blk * (uint64_t)kSlotBytes;          // (the stored block spans both wavefronts' parts of the slot)
+    if (tid == 0) { o[0] = 1; o[1] = (uint8_t)(n & 0xFFu); o[2] = (uint8_t)(n >> 8); o[3] = (uint8_t)(~n & 0xFFu); o[4] = (uint8_t)((~n >> 8) & 0xFFu); }
+    for (uint32_t i = tid; i < n; i += 128) o[5 + i] = in[i];
+  }
+  if (wv == 0) {
+    const uint32_t crc = block_crc<kBgzfBlockInput>(in, n, lane, crc_slice, crc_shift);
+    if (lane == 0) {
+      const uint32_t p0 = store ? n + 5u : s_payload[0], p1 = store ? 0u : s_payload[1];
+      csize[2 * blk] = p0; csize[2 * blk + 1] = p1;
+      bsize[blk] = (uint64_t)(p0 + p1) + kBgzfHeaderBytes + kBgzfTrailerBytes; crc_out[blk] = crc;
+    }
+  }
+}
+
+// `len` bytes from the 4-byte aligned `s` to the arbitrary `d`, by one wavefront: aligned words of the destination assembled from two aligned source words
+__device__ __forceinline__ void pack_copy(const uint8_t* s, uint8_t* d, uint32_t c, int lane) {
+  if (c == 0u) return;
   const uint32_t head = (uint32_t)((4u - ((uintptr_t)d & 3u)) & 3u) < c ? (uint32_t)((4u - ((uintptr_t)d & 3u)) & 3u) : c;
   if ((uint32_t)lane < head) d[lane] = s[lane];
   const uint32_t nw = (c - head) >> 2;
@@ -339,6 +433,26 @@ __global__ void __launch_bounds__(64) k_bgzf_pack(const uint8_t* __restrict__ sl
   }
   const uint32_t tail_at = head + (nw << 2);
   if ((uint32_t)lane < c - tail_at) d[tail_at + lane] = s[tail_at + lane];
+}
+__global__ void __launch_bounds__(64) k_bgzf_pack(const uint8_t* __restrict__ slots, const uint32_t* __restrict__ csize, const uint64_t* __restrict__ boff,
+                                                  const uint32_t* __restrict__ crc, uint64_t n_total, uint8_t* __restrict__ dst, uint32_t kBgzfBlockInput) {
+  const uint64_t blk = blockIdx.x;
+  const int lane = threadIdx.x;
+  const uint32_t c0 = csize[2 * blk], c1 = csize[2 * blk + 1], c = c0 + c1;       // the block's payload: one part, or the two wavefronts' parts
+  uint8_t* o = dst + boff[blk];
+  const uint64_t base = blk * (uint64_t)kBgzfBlockInput;
+  const uint32_t n = (uint32_t)((n_total - base) < (uint64_t)kBgzfBlockInput ? (n_total - base) : (uint64_t)kBgzfBlockInput);
+  const uint32_t bs = c + kBgzfHeaderBytes + kBgzfTrailerBytes - 1u;      // BSIZE = total block size - 1
+  if (lane < 18) {
+    const uint8_t hdr[18] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, (uint8_t)(bs & 0xFFu), (uint8_t)(bs >> 8)};
+    o[lane] = hdr[lane];
+  } else if (lane < 26) {
+    const uint32_t v = lane < 22 ? crc[blk] : n;
+    o[kBgzfHeaderBytes + c + (uint32_t)(lane - 18)] = (uint8_t)((v >> (8 * ((lane - 18) & 3))) & 0xFFu);
+  }
+  const uint8_t* s = slots + blk * (uint64_t)slot_bytes(kBgzfBlockInput);
+  pack_copy(s, o + kBgzfHeaderBytes, c0, lane);
+  pack_copy(s + slot_bytes(kBgzfBlockInput) / 2, o + kBgzfHeaderBytes + c0, c1, lane);
 }
 
 // ---- CRC-32 tables (reflected polynomial 0xEDB88320, the gzip CRC) -------------------------------------------------------------
@@ -370,6 +484,9 @@ uint32_t bgzf_block_input() {
   static const uint32_t v = []() { const char* e = getenv("GDBAMD_BGZF_BLOCK"); const int v = e ? atoi(e) : 0; return v == 16384 ? 16384u : v == 4096 ? 4096u : v == 6144 ? 6144u : 8192u; }();
   return v;
 }
+
+// wavefronts per 8 KiB block: 2 (default: k_bgzf_deflate2) or 1 (GDBAMD_BGZF_WAVES=1: the kernel of rounds 3-4, for A/B runs)
+static int bgzf_waves_per_block() { static const int v = []() { const char* e = getenv("GDBAMD_BGZF_WAVES"); return e && *e == '1' ? 1 : 2; }(); return v; }
 
 std::string bgzf_compress_host(const std::string& bytes) {
   std::string out;
@@ -447,7 +564,7 @@ void BgzfDeviceCompressor::enqueue(int slot, const char* dev_src, uint64_t n, ch
     BGZF_HIP(hipStreamSynchronize(st));
     for (void* p : {(void*)S.csize, (void*)S.crc, (void*)S.bsize, (void*)S.boff}) if (p) (void)hipFree(p);
     const size_t cap = (size_t)nblocks + (size_t)(nblocks >> 3) + 64;
-    BGZF_HIP(hipMalloc((void**)&S.csize, cap * 4)); BGZF_HIP(hipMalloc((void**)&S.crc, cap * 4));
+    BGZF_HIP(hipMalloc((void**)&S.csize, cap * 8)); BGZF_HIP(hipMalloc((void**)&S.crc, cap * 4));   // (two payload parts per block)
     BGZF_HIP(hipMalloc((void**)&S.bsize, cap * 8)); BGZF_HIP(hipMalloc((void**)&S.boff, cap * 8));
     S.blocks_cap = cap;
   }
@@ -477,6 +594,9 @@ void BgzfDeviceCompressor::enqueue(int slot, const char* dev_src, uint64_t n, ch
                        (const uint32_t*)S.d_shift);
   else if (kBgzfBlockInput == 4096u)
     hipLaunchKernelGGL(k_bgzf_deflate<4096>, dim3((unsigned)nblocks), dim3(64), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.bsize, S.crc, (const uint32_t*)S.d_slice,
+                       (const uint32_t*)S.d_shift);
+  else if (bgzf_waves_per_block() >= 2)
+    hipLaunchKernelGGL(k_bgzf_deflate2<8192>, dim3((unsigned)nblocks), dim3(128), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.bsize, S.crc, (const uint32_t*)S.d_slice,
                        (const uint32_t*)S.d_shift);
   else
     hipLaunchKernelGGL(k_bgzf_deflate<8192>, dim3((unsigned)nblocks), dim3(64), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.bsize, S.crc, (const uint32_t*)S.d_slice,
