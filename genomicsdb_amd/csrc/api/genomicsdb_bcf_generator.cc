@@ -485,6 +485,7 @@ std::vector<IntervalStats> CombineEngine::run_intervals(const std::vector<std::p
     if (m_user_ref && !L.has_user_ref) { L.pipe->set_reference_window(m_user_ref_begin, m_user_ref_bases); L.has_user_ref = true; }
     pipes[(size_t)l] = L.pipe.get();
   }
+  for (DevicePipeline* p : pipes) p->set_page_priority(lanes > 1);
   std::vector<std::exception_ptr> errors((size_t)lanes);
   auto work = [&](int l) {
     try {

@@ -149,6 +149,9 @@ class DevicePipeline {
   // of the fragments held so far - what a second pipeline needs to work on the same fragment (adopt_fragment; CombineEngine::run_intervals)
   FragmentView fragment_view() const;
   uint64_t fragment_generation() const;
+  // several pipelines at work on one device (CombineEngine::run_intervals): launch the page kernel on a high-priority stream, so that it is
+  // not slowed down by the other lanes' sweeps and sizing passes (the step time is the same; the kernel runs at its stand-alone duration)
+  void set_page_priority(bool on);
   // push interface built on the two calls above
   IntervalStats run_interval(int64_t qb, int64_t qe, uint64_t arena_bytes, PageCallback cb, void* user);
   static int device_count();

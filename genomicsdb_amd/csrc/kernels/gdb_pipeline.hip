@@ -143,6 +143,8 @@ inline int write2_run_length() { const char* e = getenv("GDBAMD_RUN_W2"); return
 // wavefronts (= neighbouring 64-sample chunks) per workgroup of the page assembly: 4 measured best on the store-only model
 inline int write_waves_per_group() { const char* e = getenv("GDBAMD_WRITE_WAVES"); return e && *e ? atoi(e) : 1; }
 inline bool slot_regroup() { static const bool v = []() { const char* e = getenv("GDBAMD_SLOT_REGROUP"); return !(e && *e == '0'); }(); return v; }
+// the page kernel on a high-priority stream: GDBAMD_PAGE_PRIORITY=0 / 1 overrides what the engine asked for (set_page_priority)
+inline int page_priority_env() { const char* e = getenv("GDBAMD_PAGE_PRIORITY"); return e && (*e == '0' || *e == '1') ? *e - '0' : -1; }
 inline bool coop_unroll_wanted() { const char* e = getenv("GDBAMD_COOP_UNROLL"); return !(e && *e == '0'); }   // (A/B: 0 keeps the word-by-word copy of long entries)
 inline bool xcd_aware_numbering() { const char* e = getenv("GDBAMD_XCD_AWARE"); return !(e && *e == '0'); }
 // LDS image of one (record, 64-sample chunk) of the page kernel.  GDBAMD_WRITE_IMAGE_KB = 4 / 6 / 8 forces one; otherwise by the
@@ -1434,6 +1436,11 @@ struct SlotWalker {
   }
 };
 
+// s_waitcnt vmcnt(0): behind loads issued under a per-lane condition.  The compiler cannot tell whether such a load is still in flight on
+// the paths that skipped its use, and waits for it (vmcnt(0): for every store issued since, too) wherever one of its registers is written
+// next - in k_bcf_write that was in the middle of every group pass and between the image's store sets.  Placed where nothing the
+// kernel wants in flight is in flight.
+__device__ __forceinline__ void settle_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 // Copy n bytes of a 16-byte aligned pool slot to an arbitrary LDS byte address, executed by all lanes of a wavefront
 // with per-lane n (0: idle lane).  Destination words are funnel-shifted out of consecutive source words (v_alignbyte).
 // The last, partial word is stored whole: it spills at most 3 bytes past the entry, and every spilled byte is a HEAD byte
@@ -2755,9 +2762,11 @@ __device__ __forceinline__ uint32_t bcf_pair_reduce(uint32_t v) {
   }
   return v;
 }
-// part[(record, chunk)][pair word]: a lane's entry rarely changes from one record to the next (a call spans many records), so the
-// summary words stay in registers and only the lanes whose entry changed go to memory.
-__global__ void __launch_bounds__(kAsmRows) k_bcf_field_meta(const uint2* __restrict__ resolved, const char* __restrict__ pool, const char* __restrict__ pool_ovf,
+// part[chunk][record][pair word]: a lane's entry rarely changes from one record to the next (a call spans many records), so the
+// summary words stay in registers and only the lanes whose entry changed go to memory.  The resolved rows of kMetaBatch records are
+// fetched together and then the entry heads those rows name (a load per record made every step wait two memory latencies in a row).
+constexpr int kMetaBatch = 4;
+__global__ void __launch_bounds__(kAsmRows) k_bcf_field_meta(const ResMatrix resolved, const char* __restrict__ pool, const char* __restrict__ pool_ovf,
                                                            const uint32_t* __restrict__ fmt_mask, const int32_t* __restrict__ order, int64_t P, int nchunks, int F, uint32_t* __restrict__ part) {
   const int64_t unit = xcd_aware_unit<1>(((P + kBcfRun - 1) / kBcfRun) * (int64_t)nchunks);
   if (unit < 0) return;
@@ -2770,33 +2779,53 @@ __global__ void __launch_bounds__(kAsmRows) k_bcf_field_meta(const uint2* __rest
   uint32_t prev_key = 0xFFFFFFFFu, mine = 0;
   int prev_words = -1;
   // records in (block, type) order (`order`, like the text assembly): along a run the samples keep their entries
-  int32_t my_k = 0;
-  for (int64_t i = k0; i < k1; ++i) {                    // uniform
-    if (((i - k0) & 63) == 0) my_k = (i + lane < k1) ? order[i + lane] : 0;
-    const int64_t k = __builtin_amdgcn_readlane(my_k, (int)((i - k0) & 63));
-    const int64_t rc = k * nchunks + ch;
-    const uint2 d = resolved[rc * kAsmRows + lane];
-    const char* src = ((d.x & kOverflowBit) ? pool_ovf : pool) + (size_t)(d.x & ~kOverflowBit) * 16;
-    const int words = (__popc(fmt_mask[k]) + 1) >> 1;
-    // a record whose 64 samples all keep the entries of the record before it (a third of the steps along a type run) has its
-    // summary maxima too: the reductions below are skipped
-    const uint32_t key = d.y ? d.x : 0xFFFFFFFEu;
-    const bool same = words == prev_words && !__any((int)(key != prev_key));
-    prev_key = key; prev_words = words;
-    if (same) { if (lane < words) part[rc * W + lane] = mine; continue; }
-    if (d.y && d.x != held) { h = *reinterpret_cast<const u32x4*>(src); held = d.x; }   // (entries are 16-byte aligned and padded)
-    mine = 0;
-    for (int w0 = 0; w0 < words; w0 += 4) {               // uniform
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (d.y) v = w0 == 0 ? h : *reinterpret_cast<const u32x4*>(src + 4 * w0);
+  int32_t my_k = 0; uint32_t my_mask = 0;
+  for (int64_t i0 = k0; i0 < k1; i0 += kMetaBatch) {       // uniform
+    if (((i0 - k0) & 63) == 0) { my_k = (i0 + lane < k1) ? order[i0 + lane] : 0; my_mask = (i0 + lane < k1) ? fmt_mask[my_k] : 0u; }
+    uint2 t[kMetaBatch]; u32x4 hd[kMetaBatch]; bool ld[kMetaBatch];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        if (w0 + c >= words) break;
-        const uint32_t r = bcf_pair_reduce(v[c]);
-        if (lane == w0 + c) mine = r;
-      }
+    for (int b = 0; b < kMetaBatch; ++b) {
+      const int64_t i = i0 + b < k1 ? i0 + b : k1 - 1;
+      const int64_t k = __builtin_amdgcn_readlane(my_k, (int)((i - k0) & 63));
+      t[b] = resolved.load((k * nchunks + ch) * kAsmRows + lane);
     }
-    if (lane < words) part[rc * W + lane] = mine;
+    uint32_t will_hold = held;
+#pragma unroll
+    for (int b = 0; b < kMetaBatch; ++b) {
+      ld[b] = t[b].y && t[b].x != will_hold;
+      hd[b] = u32x4{0u, 0u, 0u, 0u};
+      if (ld[b]) { hd[b] = *reinterpret_cast<const u32x4*>(((t[b].x & kOverflowBit) ? pool_ovf : pool) + (size_t)(t[b].x & ~kOverflowBit) * 16); will_hold = t[b].x; }   // (entries are 16-byte aligned and padded)
+    }
+#pragma unroll
+    for (int b = 0; b < kMetaBatch; ++b) {
+      const int64_t i = i0 + b;
+      if (i >= k1) break;                                   // uniform
+      const int64_t k = __builtin_amdgcn_readlane(my_k, (int)((i - k0) & 63));
+      const uint2 d = t[b];
+      if (ld[b]) { h = hd[b]; held = d.x; }
+      const int words = (__popc((uint32_t)__builtin_amdgcn_readlane((int)my_mask, (int)((i - k0) & 63))) + 1) >> 1;
+      uint32_t* const out = part + ((int64_t)ch * P + k) * W;
+      // a record whose 64 samples all keep the entries of the record before it (a third of the steps along a type run) has its
+      // summary maxima too: the reductions below are skipped
+      const uint32_t key = d.y ? d.x : 0xFFFFFFFEu;
+      const bool same = words == prev_words && !__any((int)(key != prev_key));
+      prev_key = key; prev_words = words;
+      if (!same) {
+        mine = 0;
+        const char* src = ((d.x & kOverflowBit) ? pool_ovf : pool) + (size_t)(d.x & ~kOverflowBit) * 16;
+        for (int w0 = 0; w0 < words; w0 += 4) {               // uniform
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (d.y) v = w0 == 0 ? h : *reinterpret_cast<const u32x4*>(src + 4 * w0);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (w0 + c >= words) break;
+            const uint32_t r = bcf_pair_reduce(v[c]);
+            if (lane == w0 + c) mine = r;
+          }
+        }
+      }
+      if (lane < words) out[lane] = mine;
+    }
   }
 }
 struct BcfLayout {            // per record
@@ -2817,7 +2846,7 @@ __global__ void k_bcf_layout(CombinePlan pl, const uint32_t* __restrict__ part, 
   for (int i = 0; i < pl.n_format; ++i) {
     if (!((mask >> i) & 1u)) continue;
     uint32_t sum = 0;
-    for (int ch = 0; ch < nchunks; ++ch) sum = bcf_summary_max(sum, (part[(k * nchunks + ch) * W + (q >> 1)] >> (16 * (q & 1))) & 0xFFFFu);
+    for (int ch = 0; ch < nchunks; ++ch) sum = bcf_summary_max(sum, (part[((int64_t)ch * P + k) * W + (q >> 1)] >> (16 * (q & 1))) & 0xFFFFu);
     const int t = bcf_field_type(pl, i, sum);
     const uint32_t cnt = bcf_summary_n(sum) ? bcf_summary_n(sum) : 1u;   // (a field in the mask has a value somewhere; 1 keeps the layout sane otherwise)
     const int f = pl.format_field[i];
@@ -2881,7 +2910,10 @@ __global__ void k_bcf_shared(const SiteCtx* __restrict__ sxp, const char* __rest
 // (collect_and_extend_fields, variant_field_handler.cc:846-866) into an LDS image of the 64 samples' values, and the wavefront
 // moves the image to the record with aligned 16-byte stores.
 struct __attribute__((packed)) PackedU16 { uint16_t v; };
-constexpr int kBcfEntryCap = 96;     // bytes of an entry kept in the lane's LDS slot (the rest is read from the pool)
+#ifndef GDB_BCF_ENTRY_CAP
+#define GDB_BCF_ENTRY_CAP 96
+#endif
+constexpr int kBcfEntryCap = GDB_BCF_ENTRY_CAP;     // bytes of an entry kept in the lane's LDS slot (the rest is read from the pool)
 constexpr int kBcfImageSample = 32;  // bytes per sample and field that go through the LDS image (longer vectors: direct stores)
 // one sample's cnt values of a field of BCF type t, from its entry (n elements at `in`) to `out`.  first / rest: what stands where
 // the call has no element (the first position of an empty vector, every other one).  The two pointers are LDS or global by
@@ -2917,6 +2949,19 @@ __global__ void k_bcf_same_layout(const int32_t* __restrict__ order, const uint3
   }
   same[idx] = eq ? 1 : 0;
 }
+// GDB_BCF_PROF (a variant build, tests/tools/build_variant.sh): cycles per section of k_bcf_write's step, summed over the wavefronts
+#ifdef GDB_BCF_PROF
+#define BCF_PROF_PARAM , unsigned long long* prof
+#define BCF_PROF_ARG , bcf_prof_buffer()
+#define BCF_STAMP(n) { const uint64_t now_ = __builtin_amdgcn_s_memtime(); prof_acc[n] += now_ - prof_t; prof_t = now_; }
+#define BCF_COUNT(n) { ++prof_acc[n]; }
+static unsigned long long* bcf_prof_buffer() { static unsigned long long* p = nullptr; if (!p) { (void)hipMalloc((void**)&p, 128); (void)hipMemset(p, 0, 128); } return p; }
+#else
+#define BCF_PROF_PARAM
+#define BCF_PROF_ARG
+#define BCF_STAMP(n)
+#define BCF_COUNT(n)
+#endif
 struct __attribute__((packed)) PackedU128 { u32x4 v; };
 constexpr int kBcfImageBytes = 3072;     // LDS image of the FORMAT values of one (record, 64-sample chunk), every field a 16-byte aligned region
 constexpr int kBcfImageSets = kBcfImageBytes / (16 * kAsmRows);
@@ -2934,10 +2979,13 @@ constexpr int kBcfBatch = 4;             // records whose resolved rows are fetc
 // most 128 registers (amdgpu_waves_per_eu) make it 14 per CU instead of 11 - 18.1 -> 14.3 ms on the c2 window.  (With 129 registers
 // the register file allowed 12, which is why smaller slots alone changed nothing in round 2; a 2 KiB image sends c2's records down
 // the slow path, 2 instead of 4 rows per batch costs more than the 15th wavefront brings.)
-__global__ void __launch_bounds__(kAsmRows) __attribute__((amdgpu_waves_per_eu(4))) k_bcf_write(CombinePlan pl, const uint2* __restrict__ resolved, const char* __restrict__ pool, const char* __restrict__ pool_ovf,
+__global__ void __launch_bounds__(kAsmRows) __attribute__((amdgpu_waves_per_eu(4))) k_bcf_write(CombinePlan pl, const ResMatrix resolved, const char* __restrict__ pool, const char* __restrict__ pool_ovf,
                                                       const uint32_t* __restrict__ fmt_mask, const int32_t* __restrict__ order, const uint8_t* __restrict__ same_layout, int64_t np, int nchunks,
-                                                      int F, int32_t N, BcfLayout lay, const uint64_t* __restrict__ rec_off, uint64_t page_base, char* __restrict__ arena) {
+                                                      int F, int32_t N, BcfLayout lay, const uint64_t* __restrict__ rec_off, uint64_t page_base, char* __restrict__ arena BCF_PROF_PARAM) {
   __shared__ __attribute__((aligned(16))) char s_entry[kAsmRows * kBcfEntryCap];
+#ifdef GDB_BCF_PROF
+  uint64_t prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint64_t prof_t = __builtin_amdgcn_s_memtime();
+#endif
   __shared__ __attribute__((aligned(16))) char s_image[kBcfImageBytes + 16];
   __shared__ uint2 s_rows[kBcfBatch][kAsmRows];
   __shared__ uint8_t s_changed[kAsmRows];     // the lanes (samples) whose entry changed at this record, in lane order
@@ -3000,7 +3048,7 @@ __global__ void __launch_bounds__(kAsmRows) __attribute__((amdgpu_waves_per_eu(4
       for (int b = 0; b < kBcfBatch; ++b) {
         const int jb = j + b < cnt_run ? j + b : cnt_run - 1;
         const int64_t kk = __builtin_amdgcn_readlane(my_k, jb);
-        t[b] = resolved[(kk * nchunks + ch) * kAsmRows + lane];
+        t[b] = resolved.load((kk * nchunks + ch) * kAsmRows + lane);
       }
 #pragma unroll
       for (int b = 0; b < kBcfBatch; ++b) s_rows[b][lane] = t[b];
@@ -3010,7 +3058,9 @@ __global__ void __launch_bounds__(kAsmRows) __attribute__((amdgpu_waves_per_eu(4
     const uint32_t mask = (uint32_t)__builtin_amdgcn_readlane((int)my_mask, j);
     char* rec = arena + (readlane64((int64_t)my_roff, j) - (int64_t)page_base);
     const char* src = ((d.x & kOverflowBit) ? pool_ovf : pool) + (size_t)(d.x & ~kOverflowBit) * 16;
-    if (d.y && d.x != slot_key) {                         // all 16-byte pieces in flight at once, then into the slot: one exposed latency
+    const bool fetch = d.y && d.x != slot_key;
+    if (__any((int)fetch)) {                              // uniform: a step in which no sample changes its entry has no wait for memory at all
+    if (fetch) {                                          // all 16-byte pieces in flight at once, then into the slot: one exposed latency
       const uint32_t take = d.y < (uint32_t)kBcfEntryCap ? d.y : (uint32_t)kBcfEntryCap;
       u32x4 piece[kBcfEntryCap / 16];
 #pragma unroll
@@ -3019,9 +3069,12 @@ __global__ void __launch_bounds__(kAsmRows) __attribute__((amdgpu_waves_per_eu(4
       for (int o = 0; o < kBcfEntryCap / 16; ++o) if ((uint32_t)o * 16u < take) *reinterpret_cast<u32x4*>(s_entry + lane * kBcfEntryCap + o * 16) = piece[o];
       slot_key = d.x;
     }
+    settle_loads();        // the step's one wait for memory: the entry fetch and the stores of the steps before
+    }
     const uint32_t key = d.y ? d.x : 0xFFFFFFFEu;
     const bool whole = !__any((int)(live && d.y > (uint32_t)kBcfEntryCap));   // every live lane's entry is in its slot
     const int nf = __popc(mask);
+    BCF_STAMP(0) BCF_COUNT(8)
     // ---- layout: unchanged from the previous record? ------------------------------------------------------------------------------
     const bool same = img_valid && __builtin_amdgcn_readlane((int)my_same, j) != 0;
     bool fits = true;
@@ -3086,47 +3139,28 @@ __global__ void __launch_bounds__(kAsmRows) __attribute__((amdgpu_waves_per_eu(4
         }
       }
     }
+    BCF_STAMP(1)
     if (fits) {
       // ---- format the lanes whose entry changed (all of them after a layout change) -------------------------------------------------
       const bool need = live && (!same || key != img_key);
-      const uint64_t need_mask = __ballot(need);
-      if (need_mask && same && n_elems && whole) {
-        // Few samples changed (a few lanes per step): a group of lanes per changed sample, lane l of the group = its l-th output
-        // element; 64 >> g_shift samples per pass.  The offset of the element's field inside the sample's entry comes from a walk
-        // over the entry's summary (4-byte fields are 4-byte aligned), then every lane fetches, converts and stores its own element.
-        if (need) s_changed[__popcll(need_mask & ((1ull << lane) - 1ull))] = (uint8_t)lane;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        const int n_changed = __popcll(need_mask);
-        const int per_pass = 64 >> g_shift;
-        for (int p0 = 0; p0 < n_changed; p0 += per_pass) {        // uniform
-          const int r = p0 + (lane >> g_shift);
-          const bool act = g_ok && r < n_changed;
-          const int L = act ? (int)s_changed[r] : lane;
-          const uint32_t dyL = (uint32_t)__shfl((int)d.y, L, 64);
-          const char* const slotL = s_entry + L * kBcfEntryCap;
-          uint32_t b = bcf_summary_bytes(nf), body = 0, n = 0;
-          for (int q = 0; q < nf; ++q) {                           // uniform
-            const uint32_t es = (uint32_t)__builtin_amdgcn_readlane((int)q_es, q);
-            const uint32_t nq = dyL ? bcf_summary_n(reinterpret_cast<const uint16_t*>(slotL)[q]) : 0u;
-            if (es == 4u) b = (b + 3u) & ~3u;
-            if ((uint32_t)q == g_q) { body = b; n = nq; }
-            b += nq * es;
-          }
-          if (act) {
-            char* const out = s_image + g_dst + (uint32_t)L * g_per;
-            if (g_t == GDB_BT_CHAR) {
-              out[0] = g_j < n ? slotL[body + g_j] : (char)(g_j == 0 ? g_first : g_rest);
-            } else {
-              const uint32_t v = g_j < n ? *reinterpret_cast<const uint32_t*>(slotL + body + 4u * g_j) : (g_j == 0 ? g_first : g_rest);
-              if (g_t == GDB_BT_INT8) out[0] = (int32_t)v == GDB_BCF_INT32_MISSING ? (char)0x80 : (int32_t)v == GDB_BCF_INT32_VECTOR_END ? (char)0x81 : (char)v;
-              else if (g_t == GDB_BT_INT16)
-                *reinterpret_cast<uint16_t*>(out) = (int32_t)v == GDB_BCF_INT32_MISSING ? (uint16_t)0x8000u : (int32_t)v == GDB_BCF_INT32_VECTOR_END ? (uint16_t)0x8001u : (uint16_t)v;
-              else *reinterpret_cast<uint32_t*>(out) = v;
-            }
-          }
+      // the summaries (vector length per field) of an entry: 2 bytes per field at its start - up to 8 fields arrive with ONE 16-byte LDS read
+      // and are shifted out field by field (a read per field is an LDS round trip per field in every pass below)
+      const bool packed = nf <= 8;
+      // Who formats what.  The layout has at most 64 elements per sample (n_elems): the samples whose entry changed go through the
+      // group passes below, a group of lanes per sample; after a layout change every sample is due, and the lanes format their own
+      // sample (lanes-are-samples) - except those whose entry is longer than its LDS slot, which take the group passes too (a lane
+      // that walks a long entry in the pool waits a memory latency per element: 15 and more in a row).  More than 64 elements per
+      // sample: lanes-are-samples for all, from the pool when some entry is longer than its slot.
+      const bool big = d.y > (uint32_t)kBcfEntryCap;
+      const bool grp = need && n_elems && (same || big);
+      const bool lanes_pass = need && !grp;
+      const bool from_slot = n_elems ? true : whole;
+      if (__any((int)lanes_pass)) {
+        uint64_t lo = 0, hi = 0;
+        if (packed && d.y) {
+          const u32x4 sm = *reinterpret_cast<const u32x4*>(s_entry + lane * kBcfEntryCap);
+          lo = (uint64_t)sm[0] | ((uint64_t)sm[1] << 32); hi = (uint64_t)sm[2] | ((uint64_t)sm[3] << 32);
         }
-        if (need) img_key = key;
-      } else if (need_mask) {
         uint32_t body = bcf_summary_bytes(nf);
         for (int q = 0; q < nf; ++q) {                   // uniform
           const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)my_meta, q);
@@ -3134,16 +3168,92 @@ __global__ void __launch_bounds__(kAsmRows) __attribute__((amdgpu_waves_per_eu(4
           const uint32_t per = (uint32_t)__builtin_amdgcn_readlane((int)q_per, q), ro = (uint32_t)__builtin_amdgcn_readlane((int)q_reg, q);
           const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)q_first, q), rest = (uint32_t)__builtin_amdgcn_readlane((int)q_rest, q);
           const uint32_t es = (uint32_t)__builtin_amdgcn_readlane((int)q_es, q);
-          const uint32_t n = d.y ? bcf_summary_n(reinterpret_cast<const uint16_t*>(s_entry + lane * kBcfEntryCap)[q]) : 0u;
+          uint32_t n;
+          if (packed) { n = bcf_summary_n((uint32_t)lo & 0xFFFFu); lo = (lo >> 16) | (hi << 48); hi >>= 16; }
+          else n = d.y ? bcf_summary_n(reinterpret_cast<const uint16_t*>(s_entry + lane * kBcfEntryCap)[q]) : 0u;
           if (es == 4u) body = (body + 3u) & ~3u;
-          if (need) {
-            if (whole) bcf_sample_values(s_image + ro + (uint32_t)lane * per, s_entry + lane * kBcfEntryCap + body, n, cnt, t, first, rest);
+          if (lanes_pass) {
+            if (from_slot) bcf_sample_values(s_image + ro + (uint32_t)lane * per, s_entry + lane * kBcfEntryCap + body, n, cnt, t, first, rest);
             else bcf_sample_values(s_image + ro + (uint32_t)lane * per, src + body, n, cnt, t, first, rest);
           }
           body += n * es;
         }
-        if (need) img_key = key;
+        if (!from_slot) settle_loads();
       }
+      BCF_STAMP(2)
+      const uint64_t grp_mask = __ballot(grp);
+      if (grp_mask) BCF_COUNT(9)
+      if (grp_mask) {
+        // A group of lanes per sample, lane l of the group = the sample's l-th output element; 64 >> g_shift samples per pass.  The
+        // offset of the element's field inside the sample's entry comes from a walk over the entry's summary (4-byte fields are
+        // 4-byte aligned), then every lane fetches, converts and stores its own element: from the sample's slot, or from the pool
+        // where a long entry reaches beyond its slot (one load per lane, all in flight together).
+        if (grp) s_changed[__popcll(grp_mask & ((1ull << lane) - 1ull))] = (uint8_t)(lane | (d.y ? 0x80 : 0));
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        const int n_changed = __popcll(grp_mask);
+        const int per_pass = 64 >> g_shift;
+        // (two instances: the one that may go to the pool has a wait for memory in every pass)
+        const auto passes = [&](auto with_pool) {
+          for (int p0 = 0; p0 < n_changed; p0 += per_pass) {        // uniform
+            const int r = p0 + (lane >> g_shift);
+            const bool act = g_ok && r < n_changed;
+            const uint32_t cL = act ? (uint32_t)s_changed[r] : (uint32_t)lane;
+            const int L = (int)(cL & 63u);
+            const bool hasL = (cL & 0x80u) != 0u;
+            const char* const slotL = s_entry + L * kBcfEntryCap;
+            const char* srcL = nullptr;
+            if constexpr (decltype(with_pool)::value) {
+              const uint32_t xL = (uint32_t)__shfl((int)d.x, L, 64);
+              srcL = ((xL & kOverflowBit) ? pool_ovf : pool) + (size_t)(xL & ~kOverflowBit) * 16;
+            }
+            uint32_t b = bcf_summary_bytes(nf), body = 0, n = 0;
+            if (packed) {
+              const u32x4 sm = *reinterpret_cast<const u32x4*>(slotL);
+              uint64_t lo = hasL ? ((uint64_t)sm[0] | ((uint64_t)sm[1] << 32)) : 0ull, hi = hasL ? ((uint64_t)sm[2] | ((uint64_t)sm[3] << 32)) : 0ull;
+              for (int q = 0; q < nf; ++q) {                         // uniform
+                const uint32_t es = (uint32_t)__builtin_amdgcn_readlane((int)q_es, q);
+                const uint32_t nq = bcf_summary_n((uint32_t)lo & 0xFFFFu);
+                lo = (lo >> 16) | (hi << 48); hi >>= 16;
+                if (es == 4u) b = (b + 3u) & ~3u;
+                if ((uint32_t)q == g_q) { body = b; n = nq; }
+                b += nq * es;
+              }
+            } else {
+              for (int q = 0; q < nf; ++q) {                         // uniform
+                const uint32_t es = (uint32_t)__builtin_amdgcn_readlane((int)q_es, q);
+                const uint32_t nq = hasL ? bcf_summary_n(reinterpret_cast<const uint16_t*>(slotL)[q]) : 0u;
+                if (es == 4u) b = (b + 3u) & ~3u;
+                if ((uint32_t)q == g_q) { body = b; n = nq; }
+                b += nq * es;
+              }
+            }
+            const bool have = act && g_j < n;
+            const bool is_char = g_t == GDB_BT_CHAR;
+            const uint32_t at = body + (is_char ? g_j : 4u * g_j);
+            uint32_t v = g_j == 0 ? g_first : g_rest;
+            bool in_slot = true;
+            if constexpr (decltype(with_pool)::value) {
+              in_slot = at + (is_char ? 1u : 4u) <= (uint32_t)kBcfEntryCap;
+              uint32_t pv = 0;
+              if (have && !in_slot) pv = is_char ? (uint32_t)(uint8_t)srcL[at] : *reinterpret_cast<const uint32_t*>(srcL + at);
+              settle_loads();
+              if (have && !in_slot) v = pv;
+            }
+            if (have && in_slot) v = is_char ? (uint32_t)(uint8_t)slotL[at] : *reinterpret_cast<const uint32_t*>(slotL + at);
+            if (act) {
+              char* const out = s_image + g_dst + (uint32_t)L * g_per;
+              if (is_char) out[0] = (char)v;
+              else if (g_t == GDB_BT_INT8) out[0] = (int32_t)v == GDB_BCF_INT32_MISSING ? (char)0x80 : (int32_t)v == GDB_BCF_INT32_VECTOR_END ? (char)0x81 : (char)v;
+              else if (g_t == GDB_BT_INT16)
+                *reinterpret_cast<uint16_t*>(out) = (int32_t)v == GDB_BCF_INT32_MISSING ? (uint16_t)0x8000u : (int32_t)v == GDB_BCF_INT32_VECTOR_END ? (uint16_t)0x8001u : (uint16_t)v;
+              else *reinterpret_cast<uint32_t*>(out) = v;
+            }
+          }
+        };
+        if (__ballot(grp && big) != 0ull) passes(std::true_type{}); else passes(std::false_type{});
+      }
+      if (need) img_key = key;
+      BCF_STAMP(3)
       img_valid = true;
       // ---- flush: every lane its words of the image ----------------------------------------------------------------------------------
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -3166,6 +3276,7 @@ __global__ void __launch_bounds__(kAsmRows) __attribute__((amdgpu_waves_per_eu(4
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      BCF_STAMP(4)
       continue;
     }
     // ---- slow path: field by field --------------------------------------------------------------------------------------------------
@@ -3215,7 +3326,11 @@ __global__ void __launch_bounds__(kAsmRows) __attribute__((amdgpu_waves_per_eu(4
       body += n * (uint32_t)es;
       ++q;
     }
+    BCF_STAMP(5)
   }
+#ifdef GDB_BCF_PROF
+  if (lane == 0) for (int c = 0; c < 12; ++c) atomicAdd(prof + c, (unsigned long long)prof_acc[c]);
+#endif
 }
 
 // SURVEY 8(d) "remap elements": per record that needs re-indexing, (calls with a valid genotype-length field) x (merged genotypes) -
@@ -3629,6 +3744,9 @@ struct DevicePipeline::Impl {
   HostPlan hp;
   int device = 0;
   hipStream_t stream = nullptr;        // the stream in use: stream_compute, or stream_stage between begin_staging_from() and finish_staging()
+  hipStream_t stream_page = nullptr;   // the page kernel on a high-priority stream of its own (several windows in flight: it is dispatched ahead of the other lanes' kernels and runs at its stand-alone duration)
+  bool page_priority = false;
+  hipEvent_t ev_page_fork = nullptr, ev_page_join = nullptr;
   hipStream_t stream_compute = nullptr, stream_stage = nullptr;
   // A window staged ahead (overlapped staging) shares the GPU with the other pipeline's page assembly, whose kernels fill every CU
   // for milliseconds: the short staging kernels (1 ms per 270 MB chunk) run on a stream of higher priority so that the staging
@@ -3864,6 +3982,7 @@ DevicePipeline::~DevicePipeline() {
   if (m_->ctx_slot >= 0) { std::lock_guard<std::mutex> g(g_ctx_slot_mutex); g_ctx_slot_used[m_->ctx_slot] = false; }
   if (m_->stream_compute) (void)hipStreamDestroy(m_->stream_compute);
   if (m_->stream_stage) (void)hipStreamDestroy(m_->stream_stage);
+  if (m_->stream_page) { (void)hipStreamDestroy(m_->stream_page); (void)hipEventDestroy(m_->ev_page_fork); (void)hipEventDestroy(m_->ev_page_join); }
   delete m_;
   m_ = nullptr;
 }
@@ -5590,7 +5709,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   hipLaunchKernelGGL(k_slot_desc, dim3(blocks_for((int64_t)NS)), dim3(kBlock), 0, st, S.slot_len.p, S.slot_off.p, (int64_t)NS, asm_path == 1 ? (uint2*)nullptr : S.slot_desc.p,
                      pl.bcf_mode ? (char*)nullptr : S.pool.p, stt.inline_max);
   stats.num_record_types = ntypes;
-  stats.resolved_entry_bytes = (asm_path == 1 || asm_path == 3 || events_enabled()) ? 0 : ((!pl.bcf_mode && asm_path == 0 && !any_over255 && res_compact_wanted()) ? 5 : 8);
+  stats.resolved_entry_bytes = (asm_path == 1 || asm_path == 3 || events_enabled()) ? 0 : ((asm_path == 0 && !any_over255 && res_compact_wanted()) ? 5 : 8);
   stats.num_text_slots = (int64_t)NS;
   stats.text_pool_bytes = (int64_t)(NS * kSlotStride + pool_units * 16);
   STAGE("k_walk_window");
@@ -5614,8 +5733,8 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   bool use_events = false;
   EventBuf ebuf{nullptr, nullptr, nullptr, 0};
   const bool resolved_whole = !piece_path && (pl.bcf_mode || (resolved_bytes <= resolved_budget_bytes() && !(events_enabled() && ((1 << order_block_log2()) % event_run_length()) == 0)));
-  // compact layout: text output through the default kernels, no entry longer than a byte can say
-  const bool res_compact = !pl.bcf_mode && asm_path == 0 && !events_enabled() && !any_over255 && res_compact_wanted();
+  // compact layout: the default kernels (text and BCF2), no entry longer than a byte can say
+  const bool res_compact = asm_path == 0 && !events_enabled() && !any_over255 && res_compact_wanted() && (!pl.bcf_mode || resolved_whole);
   if (resolved_whole) {
     if (res_compact) { S.res_off.ensure((size_t)P * nchunks * kAsmRows); S.res_len8.ensure((size_t)P * nchunks * kAsmRows); }
     else S.resolved.ensure((size_t)P * nchunks * kAsmRows);
@@ -5635,12 +5754,12 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
       hipLaunchKernelGGL(k_size2, dim3((unsigned)size2_units), dim3(kAsmRows), 0, st, pc2, nchunks, S.chunk_size.p);
       hipLaunchKernelGGL(k_fill2, dim3(fill_units), dim3(kAsmRows), 0, st, pc2, (const uint2*)S.slot_desc.p, (const int32_t*)S.order.p, P, nchunks, frun, S.resolved.p, (int64_t)0);
     } else
-    launch_assemble_size(S, st, dim3(run_blocks * (unsigned)nchunks), ac, S.order.p, P, N, nchunks, run, (uint64_t*)nullptr, 0, ResMatrix{S.resolved.p, nullptr, nullptr}, (int64_t)0, (int64_t)0);
+    launch_assemble_size(S, st, dim3(run_blocks * (unsigned)nchunks), ac, S.order.p, P, N, nchunks, run, (uint64_t*)nullptr, 0, res_view(), (int64_t)0, (int64_t)0);
     S.bcf_part.ensure(nchunk_total * (size_t)bcf_F + 1); S.bcf_fmeta.ensure((size_t)P * bcf_F + 1); S.bcf_foff.ensure((size_t)P * bcf_F + 1); S.bcf_lindiv.ensure((size_t)P + 1);
     S.bcf_rec_size.ensure((size_t)P + 2);
     lay = BcfLayout{S.bcf_fmeta.p, S.bcf_foff.p, S.bcf_lindiv.p, S.bcf_rec_size.p};
     STAGE("k_bcf_field_meta");
-    hipLaunchKernelGGL(k_bcf_field_meta, dim3((unsigned)(((P + kBcfRun - 1) / kBcfRun) * nchunks)), dim3(kAsmRows), 0, st, (const uint2*)S.resolved.p, (const char*)S.pool.p,
+    hipLaunchKernelGGL(k_bcf_field_meta, dim3((unsigned)(((P + kBcfRun - 1) / kBcfRun) * nchunks)), dim3(kAsmRows), 0, st, res_view(), (const char*)S.pool.p,
                        (const char*)S.pool_ovf.p, (const uint32_t*)S.fmt_mask.p, (const int32_t*)S.order.p, P, nchunks, bcf_F, S.bcf_part.p);
     hipLaunchKernelGGL(k_bcf_layout, dim3(blocks_for(P)), dim3(kBlock), 0, st, pl, (const uint32_t*)S.bcf_part.p, (const uint32_t*)S.fmt_mask.p, (const uint32_t*)S.prefix_len.p, P,
                        nchunks, bcf_F, lay);
@@ -5747,19 +5866,41 @@ bool DevicePipeline::begin_page(uint64_t arena_bytes, int arena_idx, PageTicket*
   const int64_t np = ke - kp;
   hipEvent_t* w = S.ev_page[ai];
   HIP_CHECK(hipEventRecord(w[0], st));
+  // the stream of the page kernel: the compute stream, or (several windows in flight) a high-priority one forked from it and joined behind the kernel
+  const auto fork_page_stream = [&S, st]() -> hipStream_t {
+    if (!(page_priority_env() >= 0 ? page_priority_env() == 1 : S.page_priority)) return st;
+    if (!S.stream_page) {
+      int least = 0, greatest = 0;
+      HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      HIP_CHECK(hipStreamCreateWithPriority(&S.stream_page, hipStreamNonBlocking, greatest));
+      HIP_CHECK(hipEventCreateWithFlags(&S.ev_page_fork, hipEventDisableTiming));
+      HIP_CHECK(hipEventCreateWithFlags(&S.ev_page_join, hipEventDisableTiming));
+    }
+    HIP_CHECK(hipEventRecord(S.ev_page_fork, st));
+    HIP_CHECK(hipStreamWaitEvent(S.stream_page, S.ev_page_fork, 0));
+    return S.stream_page;
+  };
+  const auto join_page_stream = [&S, st](hipStream_t st_w) { if (st_w != st) { HIP_CHECK(hipEventRecord(S.ev_page_join, st_w)); HIP_CHECK(hipStreamWaitEvent(st, S.ev_page_join, 0)); } };
   if (iv.bcf) {
     STAGE("k_bcf_shared");
     hipLaunchKernelGGL(k_bcf_shared, dim3(blocks_for(np, 64)), dim3(64), 0, st, S.d_sx.p, (const char*)S.site_staging.p, (const char*)S.spill_buf.p, (const int32_t*)S.spill_chunk.p, kp, ke,
                        (const uint64_t*)S.rec_off.p, page_base, iv.lay, iv.bcf_F, arena, S.err.p);
-    HIP_CHECK(hipEventRecord(w[1], st));
     STAGE("k_bcf_write");
     S.order_by_type(kp, np);
     S.bcf_same.ensure((size_t)np + 1);
     hipLaunchKernelGGL(k_bcf_same_layout, dim3(blocks_for(np)), dim3(kBlock), 0, st, (const int32_t*)S.order.p, (const uint32_t*)S.fmt_mask.p, (const uint32_t*)iv.lay.fmeta, np, iv.bcf_F, S.bcf_same.p);
+    const hipStream_t st_w = fork_page_stream();
+    HIP_CHECK(hipEventRecord(w[1], st_w));   // [w1, w2]: the values kernel alone
     if (S.hp.plan.n_format > 0 && !S.hp.plan.sites_only_query)
-      hipLaunchKernelGGL(k_bcf_write, dim3((unsigned)(((np + kBcfRun - 1) / kBcfRun) * iv.nchunks)), dim3(kAsmRows), 0, st, S.hp.plan, (const uint2*)S.resolved.p, (const char*)S.pool.p,
-                         (const char*)S.pool_ovf.p, (const uint32_t*)S.fmt_mask.p, (const int32_t*)S.order.p, (const uint8_t*)S.bcf_same.p, np, iv.nchunks, iv.bcf_F, N, iv.lay, (const uint64_t*)S.rec_off.p, page_base, arena);
-    HIP_CHECK(hipEventRecord(w[2], st));
+      hipLaunchKernelGGL(k_bcf_write, dim3((unsigned)(((np + kBcfRun - 1) / kBcfRun) * iv.nchunks)), dim3(kAsmRows), 0, st_w, S.hp.plan, iv.res_compact ? ResMatrix{nullptr, S.res_off.p, S.res_len8.p} : ResMatrix{S.resolved.p, nullptr, nullptr}, (const char*)S.pool.p,
+                         (const char*)S.pool_ovf.p, (const uint32_t*)S.fmt_mask.p, (const int32_t*)S.order.p, (const uint8_t*)S.bcf_same.p, np, iv.nchunks, iv.bcf_F, N, iv.lay, (const uint64_t*)S.rec_off.p, page_base, arena BCF_PROF_ARG);
+#ifdef GDB_BCF_PROF
+    { unsigned long long h[12]; HIP_CHECK(hipStreamSynchronize(st_w)); HIP_CHECK(hipMemcpy(h, bcf_prof_buffer(), sizeof h, hipMemcpyDeviceToHost)); HIP_CHECK(hipMemset(bcf_prof_buffer(), 0, sizeof h));
+      fprintf(stderr, "k_bcf_write cycles per step (100 MHz ticks x wavefronts / steps): top %.1f layout %.1f lanes-pass %.1f groups %.1f flush %.1f slow %.1f; steps %llu, with group passes %llu\n", (double)h[0] / h[8], (double)h[1] / h[8],
+              (double)h[2] / h[8], (double)h[3] / h[8], (double)h[4] / h[8], (double)h[5] / h[8], h[8], h[9]); }
+#endif
+    HIP_CHECK(hipEventRecord(w[2], st_w));
+    join_page_stream(st_w);
     HIP_CHECK(hipMemcpyAsync(&S.hb->page_err[ai], S.err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipEventRecord(w[3], st));
     iv.kp = ke;
@@ -5840,8 +5981,9 @@ bool DevicePipeline::begin_page(uint64_t arena_bytes, int arena_idx, PageTicket*
     } else
     launch_assemble_size(S, st, wgrid, iv.ac, S.order.p, np, N, iv.nchunks, wrun, (uint64_t*)nullptr, 0, res_view(), kp, res_chunk_major() && iv.asm_path != 2 ? np : (int64_t)0);
   }
-  HIP_CHECK(hipEventRecord(w[1], st));   // [w1, w2] brackets the page-assembly kernel alone (its duration feeds the roofline figure)
-#define GDB_LAUNCH_WRITE(W, L) hipLaunchKernelGGL((k_assemble_write<W, L>), dim3((wgrid.x + (W) - 1u) / (W)), dim3(kAsmRows * (W)), 0, st, (const char*)S.pool.p, (const char*)S.pool_ovf.p, \
+  const hipStream_t st_w = fork_page_stream();
+  HIP_CHECK(hipEventRecord(w[1], st_w));   // [w1, w2] brackets the page-assembly kernel alone (its duration feeds the roofline figure)
+#define GDB_LAUNCH_WRITE(W, L) hipLaunchKernelGGL((k_assemble_write<W, L>), dim3((wgrid.x + (W) - 1u) / (W)), dim3(kAsmRows * (W)), 0, st_w, (const char*)S.pool.p, (const char*)S.pool_ovf.p, \
     (const uint32_t*)S.prefix_len.p, res_view(), iv.resolved_whole ? (int64_t)0 : kp, (const int32_t*)S.order.p, np, iv.nchunks, wrun, (const uint64_t*)S.chunk_off.p, page_base, arena, xcd_aware_numbering() ? 1 : 0, \
     (res_chunk_major() && iv.asm_path != 2) ? (iv.resolved_whole ? (int64_t)iv.P_rows : np) : (int64_t)0)
   {
@@ -5849,7 +5991,7 @@ bool DevicePipeline::begin_page(uint64_t arena_bytes, int arena_idx, PageTicket*
     // the largest record's average entry is a long one (copied by the whole wavefront): the variant that keeps 4 words per lane in flight
     const bool long_entries = coop_unroll_wanted() && iv.nchunks > 0 && iv.max_record_bytes / ((uint64_t)iv.nchunks * kAsmRows) > (uint64_t)kCooperativeEntry;
     if (long_entries && ww == 1) {
-      hipLaunchKernelGGL((k_assemble_write<1, 8192, 4>), dim3(wgrid.x), dim3(kAsmRows), 0, st, (const char*)S.pool.p, (const char*)S.pool_ovf.p,
+      hipLaunchKernelGGL((k_assemble_write<1, 8192, 4>), dim3(wgrid.x), dim3(kAsmRows), 0, st_w, (const char*)S.pool.p, (const char*)S.pool_ovf.p,
         (const uint32_t*)S.prefix_len.p, res_view(), iv.resolved_whole ? (int64_t)0 : kp, (const int32_t*)S.order.p, np, iv.nchunks, wrun, (const uint64_t*)S.chunk_off.p, page_base, arena, xcd_aware_numbering() ? 1 : 0,
         (res_chunk_major() && iv.asm_path != 2) ? (iv.resolved_whole ? (int64_t)iv.P_rows : np) : (int64_t)0);
     } else
@@ -5862,7 +6004,8 @@ bool DevicePipeline::begin_page(uint64_t arena_bytes, int arena_idx, PageTicket*
     else GDB_LAUNCH_WRITE(1, 8192);
   }
 #undef GDB_LAUNCH_WRITE
-  HIP_CHECK(hipEventRecord(w[2], st));
+  HIP_CHECK(hipEventRecord(w[2], st_w));
+  join_page_stream(st_w);
   HIP_CHECK(hipMemcpyAsync(&S.hb->page_err[ai], S.err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipEventRecord(w[3], st));
   iv.kp = ke;
@@ -5909,6 +6052,7 @@ bool DevicePipeline::next_page(uint64_t arena_bytes, const char** dev_ptr, uint6
 const IntervalStats& DevicePipeline::interval_stats() const { return m_->iv.stats; }
 FragmentView DevicePipeline::fragment_view() const { return m_->fr; }
 uint64_t DevicePipeline::fragment_generation() const { return m_->fragment_generation; }
+void DevicePipeline::set_page_priority(bool on) { m_->page_priority = on; }
 
 IntervalStats DevicePipeline::run_interval(int64_t qb, int64_t qe, uint64_t arena_bytes, PageCallback cb, void* user) {
   prepare_interval(qb, qe);

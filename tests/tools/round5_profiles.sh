@@ -11,6 +11,8 @@ bash tests/tools/prof_stats.sh r5p/stats --no-stream --no-c3 > $o/stats.log 2>&1
 bash tests/tools/prof_stats.sh r5p/stats_lanes1 --lanes 1 --no-stream --no-c3 > $o/stats_lanes1.log 2>&1; head -4 $o/stats_lanes1.log
 sleep 30
 bash tests/tools/prof_traffic.sh r5p/traffic --steps 2 --warmup 1 --lanes 1 --no-stream --no-c3 > $o/traffic.log 2>&1
+bash tests/tools/prof_stats.sh r5p/stats_bcf --bcf --lanes 1 --steps 5 --warmup 1 --no-stream --no-c3 > $o/stats_bcf.log 2>&1; head -4 $o/stats_bcf.log
+bash tests/tools/prof_traffic.sh r5p/traffic_bcf --bcf --steps 2 --warmup 1 --lanes 1 --no-stream --no-c3 --no-alone-pass > $o/traffic_bcf.log 2>&1
 python bench.py --bcf --steps 6 --warmup 3 --no-cpu-baseline --no-c3 > $o/bench_bcf.json 2>/dev/null; cut -c1-300 $o/bench_bcf.json
 python bench.py --bcf --lanes 1 --steps 5 --warmup 1 --no-cpu-baseline --no-c3 --no-stream > $o/bench_bcf_lanes1.json 2>/dev/null; cut -c1-300 $o/bench_bcf_lanes1.json
 C5_LANES=1,2 timeout 900 python tests/tools/c5_full.py > $o/c5_full.json 2> $o/c5_full.err; cut -c1-400 $o/c5_full.json

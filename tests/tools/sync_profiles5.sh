@@ -12,6 +12,8 @@ python3 tests/tools/short_stats.py ${p}_kernel_stats_rocprofv3.csv > ${p}_kernel
 cp $r/stats_lanes1/p_kernel_stats.csv ${p}_kernel_stats_lanes1_rocprofv3.csv
 python3 tests/tools/short_stats.py ${p}_kernel_stats_lanes1_rocprofv3.csv > ${p}_kernel_stats_lanes1_short.txt
 cp $r/traffic/traffic_by_kernel.json ${p}_pmc_traffic_by_kernel.json
+if [ -f $r/stats_bcf/p_kernel_stats.csv ]; then python3 tests/tools/short_stats.py $r/stats_bcf/p_kernel_stats.csv > ${p}_bcf_kernel_stats_lanes1_short.txt; fi
+if [ -f $r/traffic_bcf/traffic_by_kernel.json ]; then cp $r/traffic_bcf/traffic_by_kernel.json ${p}_bcf_pmc_traffic_by_kernel.json; fi
 grep "^{" $r/c5_full.json > ${p}_c5_full_50000x100kb.json
 ( [ -f $r/gpu_tests.log ] && grep -n "passed\|failed" $r/gpu_tests.log; tail -1 $r/smoke.log ) > ${p}_gpu_tests_and_smoke.txt
 [ -f $r/gpu_tests_size3_check.log ] && grep -n "passed\|failed" $r/gpu_tests_size3_check.log > ${p}_gpu_tests_size3_check.txt
