@@ -994,6 +994,60 @@ template <class Sink> GDB_HD void put_elem(Sink& s, float v, uint32_t* err) {
   else put_float(s, v);
 }
 
+// The elements of one call's INFO vector as the reducers below see them: as stored (mode 0), or - a record whose alleles were
+// merged - through the call's allele LUT like the reference's remapped variant: R / A length in merged-allele order (modes 1 / 2,
+// remap_data_based_on_alleles, variant_field_handler.cc:104-132), G length in merged-genotype order (mode 3,
+// remap_data_based_on_genotype, :134-297: haploid by allele, diploid through bcf_alleles2gt(input j, input k) - in this argument order -
+// any other ploidy by enumeration).  A merged allele the call does not have reads its <NON_REF>; no such input: missing.
+// fn(i, v) -> false stops the walk.
+template <class T, class Fn> GDB_HD void info_for_each_element(const T* p, int n_in, int mode, const int8_t* lut, int nal, int num_merged, bool non_ref_exists, int ploidy,
+                                                             uint32_t* err, Fn&& fn) {
+  if (mode == 0) { for (int i = 0; i < n_in; ++i) if (!fn(i, p[i])) return; return; }
+  int nr_in = -1;
+  if (non_ref_exists) for (int a = 0; a < nal; ++a) if (lut[a] == num_merged - 1) nr_in = a;
+  const auto look = [&](int aj) -> int { for (int a = 0; a < nal; ++a) if (lut[a] == aj) return a; return nr_in; };
+  T miss; elem_set_missing(miss);
+  if (mode == 1 || mode == 2) {
+    const bool alt_only = mode == 2;
+    const int n = alt_only ? num_merged - 1 : num_merged;
+    for (int i = 0; i < n; ++i) {
+      const int in = look(alt_only ? i + 1 : i);
+      const int idx = alt_only ? in - 1 : in;
+      if (!fn(i, (in >= 0 && idx >= 0 && idx < n_in) ? p[idx] : miss)) return;
+    }
+    return;
+  }
+  if (ploidy == 1) {
+    for (int j = 0; j < num_merged; ++j) { const int in = look(j); if (!fn(j, (in >= 0 && in < n_in) ? p[in] : miss)) return; }
+  } else if (ploidy == 2) {
+    int i = 0;
+    for (int kk = 0; kk < num_merged; ++kk) {
+      const int in_k = look(kk);
+      for (int j = 0; j <= kk; ++j, ++i) {
+        const int in_j = look(j);
+        const bool both = in_j >= 0 && in_k >= 0;
+        const int gi = both ? gdb_alleles2gt(in_j, in_k) : 0;
+        if (!fn(i, (both && gi < n_in) ? p[gi] : miss)) return;
+      }
+    }
+  } else if (ploidy >= 3 && ploidy <= GDB_MAX_PLOIDY) {
+    int g[GDB_MAX_PLOIDY], in[GDB_MAX_PLOIDY];
+    for (int q = 0; q < ploidy; ++q) g[q] = 0;
+    int i = 0;
+    do {
+      bool missing = false;
+      for (int q = 0; q < ploidy; ++q) { in[q] = look(g[q]); if (in[q] < 0) missing = true; }
+      T v = miss;
+      if (!missing) { const int64_t gi = gdb_genotype_index(in, ploidy); if (gi < n_in) v = p[gi]; }
+      if (!fn(i++, v)) return;
+    } while (gdb_next_genotype(g, ploidy, num_merged));
+  } else *err |= GDB_ERR_UNSUPPORTED_PLOIDY;      // (no GT in the call: the reference sizes the vector for ploidy 0; not on the device path)
+}
+GDB_HD int info_element_mode(const GdbFieldDesc& fd, bool remapping_needed) {
+  if (!remapping_needed) return 0;
+  return fd.length == GDB_VL_R ? 1 : fd.length == GDB_VL_A ? 2 : fd.length == GDB_VL_G ? 3 : 0;
+}
+
 // element_wise_sum / concatenate INFO combiners (handle_VCF_field_combine_operation, broad_combined_gvcf.cc:374-429;
 // compute_valid_element_wise_sum, variant_field_handler.cc:618-664).  Allele-dependent fields (A / R length) are read
 // through the call's allele LUT, i.e. in merged-allele order with the <NON_REF> fallback, like the reference reads them from
@@ -1004,8 +1058,7 @@ template <class T, class Sink> GDB_HD bool info_vector_combine(const SiteCtx& cx
   const GdbFieldDesc& fd = pl.field[f];
   const int64_t b = cx.hl.base[k], e = cx.hl.base[k + 1];
   const int64_t s_k = cx.rec.start[k];
-  const bool allele_dep = remapping_needed && (fd.length == GDB_VL_A || fd.length == GDB_VL_R);
-  const bool alt_only = fd.length == GDB_VL_A;
+  const int mode = info_element_mode(fd, remapping_needed);
   T r[GDB_MAX_INFO_VECTOR];
   int num_valid = 0, nconcat = 0;
   bool name_written = false;
@@ -1015,24 +1068,9 @@ template <class T, class Sink> GDB_HD bool info_vector_combine(const SiteCtx& cx
     if (!field_valid(cx.cm, c, f)) continue;
     int n_in;
     const T* p = cell_field<T>(cx.fr, pl, f, c, n_in);
-    int n = n_in;
-    const int8_t* lut = cx.hl.i2m + cx.hl.i2m_off[t];
-    const int nal = (int)GDB_CF_NALT(cx.cm.cflags[c]) + 1;
-    int nr_in = -1;
-    if (allele_dep) {
-      n = alt_only ? num_merged - 1 : num_merged;
-      if (non_ref_exists) for (int a = 0; a < nal; ++a) if (lut[a] == num_merged - 1) nr_in = a;
-    }
-    for (int i = 0; i < n; ++i) {
-      T v;
-      if (allele_dep) {
-        const int aj = alt_only ? i + 1 : i;
-        int in = -1;
-        for (int a = 0; a < nal; ++a) if (lut[a] == aj) { in = a; break; }
-        if (in < 0) in = nr_in;
-        const int idx = alt_only ? in - 1 : in;
-        if (in >= 0 && idx >= 0 && idx < n_in) v = p[idx]; else elem_set_missing(v);
-      } else v = p[i];
+    bool stop = false;
+    info_for_each_element<T>(p, n_in, mode, cx.hl.i2m + cx.hl.i2m_off[t], (int)GDB_CF_NALT(cx.cm.cflags[c]) + 1, num_merged, non_ref_exists, (int)GDB_CF_PLOIDY(cx.cm.cflags[c]), err,
+                             [&](int i, T v) -> bool {
       if (op == GDB_OP_CONCATENATE) {
         if (!name_written) {
           if (any) sink.put(';');
@@ -1040,16 +1078,18 @@ template <class T, class Sink> GDB_HD bool info_vector_combine(const SiteCtx& cx
           sink.put('=');
           name_written = true; any = true;
         }
-        if (elem_is_vector_end(v)) return true;           // htslib stops printing a vector at vector_end
+        if (elem_is_vector_end(v)) { stop = true; return false; }           // htslib stops printing a vector at vector_end
         if (nconcat++) sink.put(',');
         put_elem(sink, v, err);
-        continue;
+        return true;
       }
-      if (elem_is_missing(v) || elem_is_vector_end(v)) continue;
-      if (i >= GDB_MAX_INFO_VECTOR) { *err |= GDB_ERR_INFO_VECTOR_TOO_LONG; break; }
+      if (elem_is_missing(v) || elem_is_vector_end(v)) return true;
+      if (i >= GDB_MAX_INFO_VECTOR) { *err |= GDB_ERR_INFO_VECTOR_TOO_LONG; return false; }
       if (i < num_valid && !elem_is_missing(r[i])) r[i] += v;
       else { r[i] = v; if (i >= num_valid) { for (int j = num_valid; j < i; ++j) elem_set_missing(r[j]); num_valid = i + 1; } }
-    }
+      return true;
+    });
+    if (stop) return true;
   }
   if (op == GDB_OP_CONCATENATE) return name_written;
   if (num_valid == 0) return false;
@@ -1137,8 +1177,7 @@ template <class T, class Sink> GDB_HD bool info_vector_combine_bcf(const SiteCtx
   const GdbFieldDesc& fd = pl.field[f];
   const int64_t b = cx.hl.base[k], e = cx.hl.base[k + 1];
   const int64_t s_k = cx.rec.start[k];
-  const bool allele_dep = remapping_needed && (fd.length == GDB_VL_A || fd.length == GDB_VL_R);
-  const bool alt_only = fd.length == GDB_VL_A;
+  const int mode = info_element_mode(fd, remapping_needed);
   const bool is_float = fd.elem == GDB_ET_FLOAT;
   T r[GDB_MAX_INFO_VECTOR];
   int num_valid = 0;
@@ -1160,37 +1199,22 @@ template <class T, class Sink> GDB_HD bool info_vector_combine_bcf(const SiteCtx
       if (!field_valid(cx.cm, c, f)) continue;
       int n_in;
       const T* p = cell_field<T>(cx.fr, pl, f, c, n_in);
-      int n = n_in;
-      const int8_t* lut = cx.hl.i2m + cx.hl.i2m_off[t];
-      const int nal = (int)GDB_CF_NALT(cx.cm.cflags[c]) + 1;
-      int nr_in = -1;
-      if (allele_dep) {
-        n = alt_only ? num_merged - 1 : num_merged;
-        if (non_ref_exists) for (int a = 0; a < nal; ++a) if (lut[a] == num_merged - 1) nr_in = a;
-      }
-      for (int i = 0; i < n; ++i) {
-        T v;
-        if (allele_dep) {
-          const int aj = alt_only ? i + 1 : i;
-          int in = -1;
-          for (int a = 0; a < nal; ++a) if (lut[a] == aj) { in = a; break; }
-          if (in < 0) in = nr_in;
-          const int idx = alt_only ? in - 1 : in;
-          if (in >= 0 && idx >= 0 && idx < n_in) v = p[idx]; else elem_set_missing(v);
-        } else v = p[i];
+      info_for_each_element<T>(p, n_in, mode, cx.hl.i2m + cx.hl.i2m_off[t], (int)GDB_CF_NALT(cx.cm.cflags[c]) + 1, num_merged, non_ref_exists, (int)GDB_CF_PLOIDY(cx.cm.cflags[c]), err,
+                               [&](int i, T v) -> bool {
         if (op == GDB_OP_CONCATENATE) {
           if (pass == 0) {
             ++n_total;
             if (!is_float && !elem_is_missing(v) && !elem_is_vector_end(v)) { const int32_t iv = (int32_t)v; if (iv < mn) mn = iv; if (iv > mx) mx = iv; }
           } else if (is_float) { union { T t; uint32_t u; } x; x.u = 0; x.t = v; bcf_put_u32(sink, x.u); }
           else bcf_put_int(sink, (int32_t)v, type);
-          continue;
+          return true;
         }
-        if (elem_is_missing(v) || elem_is_vector_end(v)) continue;
-        if (i >= GDB_MAX_INFO_VECTOR) { *err |= GDB_ERR_INFO_VECTOR_TOO_LONG; break; }
+        if (elem_is_missing(v) || elem_is_vector_end(v)) return true;
+        if (i >= GDB_MAX_INFO_VECTOR) { *err |= GDB_ERR_INFO_VECTOR_TOO_LONG; return false; }
         if (i < num_valid && !elem_is_missing(r[i])) r[i] += v;
         else { r[i] = v; if (i >= num_valid) { for (int j = num_valid; j < i; ++j) elem_set_missing(r[j]); num_valid = i + 1; } }
-      }
+        return true;
+      });
     }
   }
   if (op == GDB_OP_CONCATENATE) return true;
@@ -1501,6 +1525,7 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
     for (int i = 0; i < pl.n_info; ++i) {
       const int f = pl.info_field[i];
       const GdbFieldDesc& fd = pl.field[f];
+      if (fd.length == GDB_VL_G && (num_merged - 1) > pl.max_diploid_alt_alleles) continue;   // (handle_VCF_field_combine_operation, broad_combined_gvcf.cc:380-385)
       if (fd.ndim == 2) { bool any2 = false; if (info_asa_sum(cx, k, f, num_merged, non_ref_exists, !ref_block_only, true, sink, any2, err)) ++n_info; continue; }
       if (fd.combine_op == GDB_OP_ELEMENT_WISE_SUM || fd.combine_op == GDB_OP_CONCATENATE) {
         bool found;
@@ -1613,6 +1638,7 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
     for (int i = 0; i < pl.n_info; ++i) {
       int f = pl.info_field[i];
       const GdbFieldDesc& fd = pl.field[f];
+      if (fd.length == GDB_VL_G && (num_merged - 1) > pl.max_diploid_alt_alleles) continue;
       if (fd.ndim == 2) { info_asa_sum(cx, k, f, num_merged, non_ref_exists, !ref_block_only, false, sink, any, err); continue; }
       if (fd.combine_op == GDB_OP_ELEMENT_WISE_SUM || fd.combine_op == GDB_OP_CONCATENATE) {
         if (fd.elem == GDB_ET_FLOAT) info_vector_combine<float>(cx, k, f, fd.combine_op, num_merged, non_ref_exists, !ref_block_only, sink, any, err);

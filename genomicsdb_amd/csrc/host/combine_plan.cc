@@ -181,8 +181,6 @@ HostPlan build_combine_plan(const VariantQueryConfig& qc, const std::string& tmp
         throw UnsupportedOnDeviceException("INFO combine operation of field " + fi->m_name + " is not on the device path");
       if (fi->m_num_dimensions == 2 && op != GDB_OP_ELEMENT_WISE_SUM)
         throw UnsupportedOnDeviceException("2-dimensional INFO field " + fi->m_name + ": only element_wise_sum and histogram_sum are defined for it");
-      if ((op == GDB_OP_ELEMENT_WISE_SUM || op == GDB_OP_CONCATENATE) && fi->m_length_descriptor == GDB_VL_G)
-        throw UnsupportedOnDeviceException("genotype-length INFO vector " + fi->m_name + " is not on the device path yet");
       if (fi->m_element_type != GDB_ET_INT && fi->m_element_type != GDB_ET_FLOAT)
         throw UnsupportedOnDeviceException("INFO reducer on non-numeric field " + fi->m_name);
       if (pl.n_info >= GDB_MAX_INFO_FIELDS) throw UnsupportedOnDeviceException("too many INFO fields");
