@@ -2753,14 +2753,21 @@ constexpr int kBcfRun = 256;       // records one wavefront of the BCF kernels t
   // (every run begins with a full format of its 64 samples and two dependent fetches of per-record data: with runs of 32 that start
   // was most of the kernel)
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-// maximum over the wavefront of a pair of 16-bit summaries (vector length: maximum; class bits: OR)
+// maximum over the wavefront of a pair of 16-bit summaries (vector length: maximum; class bits: OR), the same value in every lane.
+// A scan-shaped reduction through the DPP network (row shifts, then the row broadcasts of gfx9) instead of six ds_bpermute round trips
+// per word: lanes a shift does not reach read 0, the identity of both operations.
+__device__ __forceinline__ uint32_t bcf_pair_combine(uint32_t v, uint32_t o) {
+  const u16x2 n = __builtin_elementwise_max(__builtin_bit_cast(u16x2, v & 0x3FFF3FFFu), __builtin_bit_cast(u16x2, o & 0x3FFF3FFFu));
+  return __builtin_bit_cast(uint32_t, n) | ((v | o) & 0xC000C000u);
+}
 __device__ __forceinline__ uint32_t bcf_pair_reduce(uint32_t v) {
-  for (int off = 32; off > 0; off >>= 1) {
-    const uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
-    const u16x2 n = __builtin_elementwise_max(__builtin_bit_cast(u16x2, v & 0x3FFF3FFFu), __builtin_bit_cast(u16x2, o & 0x3FFF3FFFu));
-    v = __builtin_bit_cast(uint32_t, n) | ((v | o) & 0xC000C000u);
-  }
-  return v;
+  v = bcf_pair_combine(v, dpp_row_shr(v, 1));
+  v = bcf_pair_combine(v, dpp_row_shr(v, 2));
+  v = bcf_pair_combine(v, dpp_row_shr(v, 4));
+  v = bcf_pair_combine(v, dpp_row_shr(v, 8));
+  v = bcf_pair_combine(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1 and 3
+  v = bcf_pair_combine(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));   // row_bcast:31 into rows 2 and 3
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 // part[chunk][record][pair word]: a lane's entry rarely changes from one record to the next (a call spans many records), so the
 // summary words stay in registers and only the lanes whose entry changed go to memory.  The resolved rows of kMetaBatch records are
