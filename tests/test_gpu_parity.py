@@ -1284,6 +1284,48 @@ def test_intervals_in_flight_on_lanes_give_the_same_bytes(gdb, tmp_path, lanes):
     eng.close()
 
 
+@pytest.mark.parametrize("fmt", ["bu", "z"])
+def test_lanes_give_the_same_bytes_in_the_other_output_formats(gdb, tmp_path, fmt):
+    """the same through the BCF2 page assembly (k_bcf_write on the lanes' high-priority stream) and the on-device BGZF compressor:
+    three windows in flight against one window after the other; the BCF2 records decode to the oracle's text"""
+    import struct
+    import zlib
+    from genomicsdb_amd import synth
+    import bcf2text
+    N, B, L, W = 300, 10_000_000, 3600, 600
+    g = synth.Generator(N, B, L + 2500)
+    cells, _ = g.chunk_bytes(B + L + 2500)
+    q = helpers.synth_query(tmp_path, N, B, B + L - 1)
+    want, nrec, _ = helpers.oracle_run_synth(q, cells, synth.SEED, with_header=False)
+    eng = gdb.CombineEngine(q, output_format=fmt)
+    eng.stage_cells(cells)
+    eng.set_reference(B, synth.reference(B, L + 2500 + 4096))
+    wins = [(B + i * W, B + (i + 1) * W - 1) for i in range(L // W)]
+    seq = [eng.run_interval(a, b, arena_bytes=1 << 20)[0] for a, b in wins]
+    res = eng.run_intervals(wins, arena_bytes=1 << 20, lanes=3, fetch=True)
+    assert [r[0] for r in res] == seq
+    assert sum(r[1].num_records for r in res) == nrec
+    body = b"".join(seq)
+    if fmt == "bu":
+        et = gdb.CombineEngine(q)
+        h = bcf2text.Header(et.header.decode())
+        et.close()
+        at, lines = 0, []
+        while at < len(body):
+            l_shared, l_indiv = struct.unpack_from("<II", body, at)
+            lines.append(bcf2text.record_to_text(h, body[at:at + 8 + l_shared + l_indiv], helpers.format_float))
+            at += 8 + l_shared + l_indiv
+        assert ("\n".join(lines) + "\n").encode() == want
+    else:
+        out, at = [], 0
+        while at < len(body):                                   # BGZF: a series of gzip members
+            d = zlib.decompressobj(31)
+            out.append(d.decompress(body[at:]))
+            at = len(body) - len(d.unused_data)
+        assert b"".join(out) == want
+    eng.close()
+
+
 def test_c5_one_piece_of_2000_columns_at_50000_samples(gdb, tmp_path):
     """BASELINE.json configs[4] at its stated width, one of the 50 pieces tests/tools/c5_full.py works off: 50 000 samples, 2 000 columns
     of the dense region (every sample starts an insertion out of a pool of 64 alleles every 50 columns: 40 hot sites of 50 000 calls,
