@@ -95,6 +95,19 @@ def test_genotype_length_info_vectors_oracle_and_kernel_bodies(tmp_path):
     assert err == 0 and got == want
 
 
+def test_above_the_alt_allele_limit_the_vector_is_dropped_like_PL(tmp_path):
+    """handle_VCF_field_combine_operation returns early for a genotype-length field when the record has more ALT alleles than
+    max_diploid_alt_alleles_that_can_be_genotyped (broad_combined_gvcf.cc:380-385), the same rule that drops PL from FORMAT: with a
+    limit of 2 the record at 1:17385 (3 merged ALT alleles) loses GLS and PL, the other INFO fields stay"""
+    cells, q = _make_inputs(tmp_path)
+    q["max_diploid_alt_alleles_that_can_be_genotyped"] = 2
+    txt, nrec, _ = helpers.oracle_run(q, cells, with_header=False)
+    rec = [l for l in txt.decode().splitlines() if l.split("\t")[1] == "17385"][0].split("\t")
+    assert rec[4] == "A,T,<NON_REF>" and "GLS=" not in rec[7] and "MQ0=3" in rec[7] and "PL" not in rec[8].split(":")
+    got, err = helpers.hostsim_run(q, cells, with_header=False)
+    assert err == 0 and got == txt
+
+
 @pytest.mark.gpu
 def test_genotype_length_info_vectors_device(tmp_path):
     import genomicsdb_amd
