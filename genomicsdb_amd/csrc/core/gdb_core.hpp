@@ -868,7 +868,13 @@ GDB_HD bool inc_is_spanning(const SiteCtx& cx, int64_t t, int64_t s_k) {
 // the value call t of record k contributes to scalar field f, false when it does not count (field absent, value missing,
 // spanning deletion unless keep_spanning).  With the gathered table (ScalarPre) this is one load from a contiguous array;
 // without it (CPU harness) the cell is consulted.
-template <class T> GDB_HD bool scalar_at(const SiteCtx& cx, const uint32_t* pre, int64_t t, int64_t s_k, int f, bool keep_spanning, bool is_float, T& v) {
+// `alt_merged` > 0: an A-length field of a record whose alleles were merged (alt_merged = merged alleles).  The reference's scalar reducers
+// read element 0 of the REMAPPED vector (handle_VCF_field_combine_operation picks m_remapped_variant for allele-dependent fields,
+// broad_combined_gvcf.cc:386-390; get_valid_sum / median read ptr->get()[0], variant_field_handler.cc:529-607): the call's value for the
+// FIRST MERGED ALT allele - its own allele of that name, else its <NON_REF>, else missing.  (Element 0 of an R- or G-length vector is the
+// REF allele / the all-REF genotype in both orders.)
+template <class T> GDB_HD bool scalar_at(const SiteCtx& cx, const uint32_t* pre, int64_t t, int64_t s_k, int f, bool keep_spanning, bool is_float, T& v,
+                                         int alt_merged = 0, bool non_ref_exists = false) {
   if (pre) {
     union { uint32_t u; T v; } x;
     x.u = pre[t];
@@ -880,10 +886,23 @@ template <class T> GDB_HD bool scalar_at(const SiteCtx& cx, const uint32_t* pre,
   const int64_t c = cx.hl.cell[t];
   if (!field_valid(cx.cm, c, f)) return false;
   int n;
-  v = cell_field<T>(cx.fr, cx.pl, f, c, n)[0];
+  const T* p = cell_field<T>(cx.fr, cx.pl, f, c, n);
+  int idx = 0;
+  if (alt_merged > 0) {
+    const int8_t* lut = cx.hl.i2m + cx.hl.i2m_off[t];
+    const int nal = (int)GDB_CF_NALT(cx.cm.cflags[c]) + 1;
+    int in = -1;
+    for (int a = 0; a < nal; ++a) if (lut[a] == 1) { in = a; break; }
+    if (in < 0 && non_ref_exists) for (int a = 0; a < nal; ++a) if (lut[a] == alt_merged - 1) in = a;
+    idx = in - 1;
+    if (in < 0 || idx < 0 || idx >= n) return false;
+  }
+  v = p[idx];
   return is_float ? gdb_float_valid((float)v) : gdb_int_valid((int32_t)v);
 }
-template <class T> GDB_HD bool reduce_scalar(const SiteCtx& cx, int64_t k, int f, int op, bool keep_spanning, T& result, uint32_t* err) {
+template <class T> GDB_HD bool reduce_scalar(const SiteCtx& cx, int64_t k, int f, int op, bool keep_spanning, T& result, uint32_t* err, int num_merged = 0,
+                                             bool non_ref_exists = false, bool remapping_needed = false) {
+  const int alt_merged = (remapping_needed && cx.pl.field[f].length == GDB_VL_A) ? num_merged : 0;   // (such fields have none of the precomputed helpers: combine_plan / prepare_interval)
   const int64_t b = cx.hl.base[k], e = cx.hl.base[k + 1];
   if (op == GDB_OP_MEDIAN && cx.big.enabled && cx.big.slot[f] >= 0 && cx.big.index[k] >= 0) {
     const int64_t at = (int64_t)cx.big.slot[f] * cx.big.stride + cx.big.index[k];
@@ -910,7 +929,7 @@ template <class T> GDB_HD bool reduce_scalar(const SiteCtx& cx, int64_t k, int f
   } else
   for (int64_t t = b; t < e; ++t) {
     T v;
-    if (!scalar_at<T>(cx, pre, t, s_k, f, keep_spanning, is_float, v)) continue;
+    if (!scalar_at<T>(cx, pre, t, s_k, f, keep_spanning, is_float, v, alt_merged, non_ref_exists)) continue;
     sum += v;
     ++nvalid;
     if (is_float) {
@@ -937,7 +956,7 @@ template <class T> GDB_HD bool reduce_scalar(const SiteCtx& cx, int64_t k, int f
     int64_t m = 0;
     for (int64_t t = b; t < e; ++t) {
       T v;
-      if (scalar_at<T>(cx, pre, t, s_k, f, keep_spanning, is_float, v)) a[m++] = (float)v;
+      if (scalar_at<T>(cx, pre, t, s_k, f, keep_spanning, is_float, v, alt_merged, non_ref_exists)) a[m++] = (float)v;
     }
     result = (T)gdb_nth_element_libstdcxx(a, m, m / 2);
     return true;
@@ -959,11 +978,11 @@ template <class T> GDB_HD bool reduce_scalar(const SiteCtx& cx, int64_t k, int f
   int64_t mid = nvalid / 2;
   for (int64_t t = b; t < e; ++t) {
     T v;
-    if (!scalar_at<T>(cx, pre, t, s_k, f, keep_spanning, is_float, v)) continue;
+    if (!scalar_at<T>(cx, pre, t, s_k, f, keep_spanning, is_float, v, alt_merged, non_ref_exists)) continue;
     int64_t less = 0, leq = 0;
     for (int64_t u = b; u < e; ++u) {
       T w;
-      if (!scalar_at<T>(cx, pre, u, s_k, f, keep_spanning, is_float, w)) continue;
+      if (!scalar_at<T>(cx, pre, u, s_k, f, keep_spanning, is_float, w, alt_merged, non_ref_exists)) continue;
       if (w < v) ++less;
       if (w <= v) ++leq;
     }
@@ -1536,13 +1555,13 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
       }
       if (fd.elem == GDB_ET_FLOAT) {
         float v;
-        if (!reduce_scalar<float>(cx, k, f, fd.combine_op, false, v, err)) continue;
+        if (!reduce_scalar<float>(cx, k, f, fd.combine_op, false, v, err, num_merged, non_ref_exists, !ref_block_only)) continue;
         bcf_enc_int1(sink, pl.bcf_id[f]);
         sink.put((char)((1 << 4) | GDB_BT_FLOAT));
         bcf_put_u32(sink, gdb_f2u(v));
       } else {
         int32_t v;
-        if (!reduce_scalar<int32_t>(cx, k, f, fd.combine_op, false, v, err)) continue;
+        if (!reduce_scalar<int32_t>(cx, k, f, fd.combine_op, false, v, err, num_merged, non_ref_exists, !ref_block_only)) continue;
         bcf_enc_int1(sink, pl.bcf_id[f]);
         bcf_enc_int1(sink, v);
       }
@@ -1647,14 +1666,14 @@ template <class Sink> GDB_HD void site_emit(const SiteCtx& cx, int64_t k, Sink& 
       }
       if (fd.elem == GDB_ET_FLOAT) {
         float v;
-        if (!reduce_scalar<float>(cx, k, f, fd.combine_op, false, v, err)) continue;
+        if (!reduce_scalar<float>(cx, k, f, fd.combine_op, false, v, err, num_merged, non_ref_exists, !ref_block_only)) continue;
         if (any) sink.put(';');
         sink.write(cx.names.text + cx.names.field_name_off[f], cx.names.field_name_len[f]);
         sink.put('=');
         put_float(sink, v);
       } else {
         int32_t v;
-        if (!reduce_scalar<int32_t>(cx, k, f, fd.combine_op, false, v, err)) continue;
+        if (!reduce_scalar<int32_t>(cx, k, f, fd.combine_op, false, v, err, num_merged, non_ref_exists, !ref_block_only)) continue;
         if (any) sink.put(';');
         sink.write(cx.names.text + cx.names.field_name_off[f], cx.names.field_name_len[f]);
         sink.put('=');

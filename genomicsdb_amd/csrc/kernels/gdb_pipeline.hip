@@ -5477,7 +5477,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   for (int f = 0; f < GDB_MAX_FIELDS; ++f) med.slot[f] = -1;
   if (T > (int64_t)kSortedMedianThreshold * P || getenv("GDBAMD_SORTED_MEDIAN")) {
     std::vector<std::pair<int, int>> fields;   // (plan field, keep_spanning)
-    for (int i = 0; i < pl.n_info; ++i) if (pl.field[pl.info_field[i]].combine_op == GDB_OP_MEDIAN) fields.push_back(std::make_pair(pl.info_field[i], 0));
+    for (int i = 0; i < pl.n_info; ++i) if (pl.field[pl.info_field[i]].combine_op == GDB_OP_MEDIAN && pl.field[pl.info_field[i]].length != GDB_VL_A) fields.push_back(std::make_pair(pl.info_field[i], 0));   // (A-length: element 0 of the REMAPPED vector, known only behind the allele merge - scalar_at)
     if (pl.qual_combine_op == GDB_OP_MEDIAN && pl.f_QUAL >= 0) fields.push_back(std::make_pair(pl.f_QUAL, 1));
     if (!fields.empty() && T > 0 && P < (1ll << 31)) {
       S.med_keys.ensure((size_t)T); S.med_idx.ensure((size_t)T);
@@ -5498,7 +5498,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   for (int f = 0; f < GDB_MAX_FIELDS; ++f) big.slot[f] = -1;
   if (!med.enabled && T > 0) {
     std::vector<std::pair<int, int>> fields;
-    for (int i = 0; i < pl.n_info; ++i) if (pl.field[pl.info_field[i]].combine_op == GDB_OP_MEDIAN) fields.push_back(std::make_pair(pl.info_field[i], 0));
+    for (int i = 0; i < pl.n_info; ++i) if (pl.field[pl.info_field[i]].combine_op == GDB_OP_MEDIAN && pl.field[pl.info_field[i]].length != GDB_VL_A) fields.push_back(std::make_pair(pl.info_field[i], 0));   // (A-length: element 0 of the REMAPPED vector, known only behind the allele merge - scalar_at)
     if (pl.qual_combine_op == GDB_OP_MEDIAN && pl.f_QUAL >= 0) fields.push_back(std::make_pair(pl.f_QUAL, 1));
     if (!fields.empty()) {
       S.big_index.ensure((size_t)P); S.big_list.ensure(kMaxBigRecords); S.big_value.ensure(fields.size() * (size_t)kMaxBigRecords); S.big_ok.ensure(fields.size() * (size_t)kMaxBigRecords);
@@ -5531,7 +5531,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
     std::vector<std::pair<int, int>> fields;   // (plan field, keep_spanning)
     for (int i = 0; i < pl.n_info; ++i) {
       const GdbFieldDesc& fd = pl.field[pl.info_field[i]];
-      if ((fd.combine_op == GDB_OP_MEDIAN || fd.combine_op == GDB_OP_SUM || fd.combine_op == GDB_OP_MEAN) && (fd.elem == GDB_ET_FLOAT || fd.elem == GDB_ET_INT))
+      if ((fd.combine_op == GDB_OP_MEDIAN || fd.combine_op == GDB_OP_SUM || fd.combine_op == GDB_OP_MEAN) && (fd.elem == GDB_ET_FLOAT || fd.elem == GDB_ET_INT) && fd.length != GDB_VL_A)
         fields.push_back(std::make_pair(pl.info_field[i], 0));
     }
     if (pl.qual_combine_op != GDB_OP_UNKNOWN && pl.f_QUAL >= 0) fields.push_back(std::make_pair(pl.f_QUAL, 1));
