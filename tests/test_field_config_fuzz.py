@@ -45,3 +45,47 @@ def test_random_field_configurations_device(tmp_path, cls, seeds):
         bcf = s.read()
         s.close()
         assert helpers.bcf_stream_to_text(bcf) == want, (seed, what)
+
+
+def _fixture_cases():
+    from golden_cases import CASES
+    return [c for c in CASES if c[5] == "load" and not c[3] and "as_array" not in c[0]]
+
+
+def _fixture_inputs(seed, tmp_path):
+    loads = _fixture_cases()
+    name, callsets, vid_name, ov, golden, mode = loads[seed % len(loads)]
+    d = tmp_path / ("s%d" % seed)
+    d.mkdir()
+    cells, vp, cp, what = field_fuzz.inputs_on_fixture(seed, callsets, vid_name, str(d))
+    q, _ = helpers.query_json(callsets, vid_name, ov, mode)
+    q["vid_mapping_file"] = vp
+    q["callset_mapping_file"] = cp
+    return cells, q, name + ": " + what
+
+
+def test_an_extra_field_on_every_fixture_oracle_and_kernel_bodies(tmp_path):
+    """haploid / triploid calls, spanning deletions, overlapping intervals, files of several samples: three random field configurations
+    per callset fixture of the reference"""
+    assert len(_fixture_cases()) >= 12
+    for seed in range(3 * len(_fixture_cases())):
+        cells, q, what = _fixture_inputs(seed, tmp_path)
+        txt, nrec, _ = helpers.oracle_run(q, cells)
+        got, err = helpers.hostsim_run(q, cells)
+        assert err == 0 and got == txt, (seed, what)
+
+
+@pytest.mark.gpu
+def test_an_extra_field_on_every_fixture_device(tmp_path):
+    import genomicsdb_amd
+    for seed in range(200, 200 + 2 * len(_fixture_cases())):
+        cells, q, what = _fixture_inputs(seed, tmp_path)
+        want, _, _ = helpers.oracle_run(q, cells)
+        s = genomicsdb_amd.GenomicsDBQueryStream(query_json=q, cells=cells, buffer_capacity=1 << 20)
+        got = s.read()
+        s.close()
+        assert got == want, (seed, what)
+        s = genomicsdb_amd.GenomicsDBQueryStream(query_json=q, cells=cells, buffer_capacity=1 << 20, is_bcf=True)
+        bcf = s.read()
+        s.close()
+        assert helpers.bcf_stream_to_text(bcf) == want, (seed, what)

@@ -72,6 +72,68 @@ def inputs(seed, cls, tmp):
     return cells, q, "%s length %s %s %s" % (cls, length, typ, op or "")
 
 
+def inputs_on_fixture(seed, callsets, vid_name, tmp):
+    """the same on ANY of the reference's callset fixtures (haploid / triploid calls, spanning deletions, overlapping intervals, several
+    samples per file): one extra INFO or FORMAT field per record and sample, G-length vectors sized by the sample's ploidy; INFO fields
+    also with move_to_FORMAT.  -> (cells, vid path, callsets path, description)"""
+    import math
+    rnd = random.Random(seed)
+    cls = rnd.choice(["INFO", "FORMAT"])
+    length = rnd.choice(["A", "R", "G", 1, 2, "VAR"])
+    typ = rnd.choice(["int", "float"])
+    desc = {"vcf_field_class": [cls], "type": typ, "length": length}
+    if cls == "INFO":
+        desc["VCF_field_combine_operation"] = rnd.choice(["sum", "mean", "median", "element_wise_sum", "move_to_FORMAT"] + (["concatenate"] if length == "VAR" else []))
+    with open(os.path.join(helpers.GOLDEN, "inputs", vid_name)) as f:
+        vid = json.load(f)
+    vid["fields"]["XF"] = desc
+    vp = os.path.join(tmp, "vid.json")
+    with open(vp, "w") as f:
+        json.dump(vid, f)
+    with open(os.path.join(helpers.GOLDEN, "inputs", "callsets", callsets)) as f:
+        cs = json.load(f)
+    out_cs = {"callsets": {}}
+    files = {}
+    for sample, info in sorted(cs["callsets"].items(), key=lambda kv: kv[1]["row_idx"]):
+        fn = info["filename"]
+        if fn not in files:
+            with gzip.open(os.path.join(helpers.GOLDEN, fn), "rt") as f:
+                lines = f.read().splitlines()
+            out = []
+            for l in lines:
+                if l.startswith("#CHROM"):
+                    out.append('##%s=<ID=XF,Number=%s,Type=%s,Description="x">' % (cls, "." if length == "VAR" else str(length), "Integer" if typ == "int" else "Float"))
+                if not l.startswith("#"):
+                    c = l.split("\t")
+                    nal = 1 + len(c[4].split(","))
+
+                    def vals(ploidy):
+                        n = {"A": nal - 1, "R": nal, "G": math.comb(ploidy + nal - 1, nal - 1), "VAR": rnd.randint(1, 4)}.get(length, length)
+                        return ",".join("." if rnd.random() < 0.1 else (str(rnd.randint(-20, 200)) if typ == "int" else "%.2f" % rnd.uniform(-3, 40)) for _ in range(n))
+                    fmt = c[8].split(":")
+                    gts = [s.split(":")[fmt.index("GT")].replace("|", "/").split("/") if "GT" in fmt else ["0", "0"] for s in c[9:]]
+                    if rnd.random() < 0.85:
+                        if cls == "INFO":
+                            e = "XF=" + vals(len(gts[0]))
+                            c[7] = e if c[7] in (".", "") else c[7] + ";" + e
+                        else:
+                            c[8] += ":XF"
+                            for i in range(len(c) - 9):
+                                c[9 + i] += ":" + vals(len(gts[i]))
+                    l = "\t".join(c)
+                out.append(l)
+            p = os.path.join(tmp, "f%d.vcf.gz" % len(files))
+            with gzip.open(p, "wt") as f:
+                f.write("\n".join(out) + "\n")
+            files[fn] = p
+        out_cs["callsets"][sample] = dict(info, filename=files[fn])
+    cp = os.path.join(tmp, "callsets.json")
+    with open(cp, "w") as f:
+        json.dump(out_cs, f)
+    cells = b"".join(c[3] for c in vcf2cells.build_cells(cp, vp, lambda fn: fn))
+    return cells, vp, cp, "%s length %s %s %s" % (cls, length, typ, desc.get("VCF_field_combine_operation", ""))
+
+
 if __name__ == "__main__":
     import tempfile
     bad = 0
