@@ -46,7 +46,7 @@ SYMBOLS = ["gdb_mi355_last_error", "gdb_mi355_device_count", "gdb_mi355_init", "
            "gdb_mi355_get_num_bytes_available", "gdb_mi355_read_next_byte", "gdb_mi355_read", "gdb_mi355_skip", "gdb_mi355_peek", "gdb_mi355_get_stream_stats",
            "gdbamd_engine_create", "gdbamd_engine_create_format", "gdbamd_engine_destroy", "gdbamd_engine_num_fields", "gdbamd_engine_field_name",
            "gdbamd_engine_field_info", "gdbamd_engine_header", "gdbamd_engine_stage_cells", "gdbamd_engine_stage_cells_begin", "gdbamd_engine_stage_cells_append", "gdbamd_engine_stage_cells_end",
-           "gdbamd_engine_adopt_device_fragment", "gdbamd_engine_open_array", "gdbamd_engine_open_memory_cells", "gdbamd_engine_open_cell_callback", "gdbamd_engine_cover", "gdbamd_engine_staged_info", "gdbamd_engine_set_reference", "gdbamd_engine_run_interval", "gdbamd_engine_run_intervals", "gdbamd_engine_prepare_interval", "gdbamd_engine_next_page", "gdbamd_engine_split_point", "gdbamd_engine_save_fragment", "gdbamd_engine_save_fragment_compressed", "gdbamd_engine_load_fragment", "gdbamd_column_partition", "gdbamd_import_cells", "gdbamd_free",
+           "gdbamd_engine_adopt_device_fragment", "gdbamd_engine_open_array", "gdbamd_engine_open_memory_cells", "gdbamd_engine_open_cell_callback", "gdbamd_engine_cover", "gdbamd_engine_staged_info", "gdbamd_engine_set_reference", "gdbamd_engine_run_interval", "gdbamd_engine_run_intervals", "gdbamd_engine_lane_footprint", "gdbamd_engine_release_lanes", "gdbamd_engine_prepare_interval", "gdbamd_engine_next_page", "gdbamd_engine_split_point", "gdbamd_engine_save_fragment", "gdbamd_engine_save_fragment_compressed", "gdbamd_engine_load_fragment", "gdbamd_column_partition", "gdbamd_import_cells", "gdbamd_free",
            "gdbamd_engine_column_histogram", "gdbamd_equi_partition_text", "gdbamd_build_output_index", "gdbamd_engine_print_calls", "gdbamd_engine_print_cells", "gdbamd_pin_host_memory", "gdbamd_unpin_host_memory"]
 
 
@@ -124,6 +124,8 @@ def lib():
     L.gdbamd_engine_run_interval.argtypes = [c.c_void_p, c.c_int64, c.c_int64, c.c_uint64, c.c_void_p, c.c_uint64, c.POINTER(c.c_uint64), c.POINTER(IntervalStats)]
     L.gdbamd_engine_run_intervals.argtypes = [c.c_void_p, c.c_int, c.POINTER(c.c_int64), c.POINTER(c.c_int64), c.c_uint64, c.c_int, c.POINTER(IntervalStats),
                                               c.POINTER(c.c_char_p), c.POINTER(c.c_uint64), c.POINTER(c.c_uint64)]
+    L.gdbamd_engine_lane_footprint.argtypes = [c.c_void_p, c.c_int64, c.c_uint64, c.POINTER(c.c_uint64)]
+    L.gdbamd_engine_release_lanes.argtypes = [c.c_void_p]
     L.gdbamd_engine_split_point.argtypes = [c.c_void_p, c.c_int64, c.c_int64, c.c_int64, c.POINTER(c.c_int64)]
     L.gdbamd_engine_save_fragment.argtypes = [c.c_void_p, c.c_char_p]
     L.gdbamd_engine_save_fragment_compressed.argtypes = [c.c_void_p, c.c_char_p]

@@ -290,6 +290,16 @@ class CombineEngine:
                 return [(bufs[i].raw[:lens[i]], st[i]) for i in range(n)]
             caps = [max(caps[i], lens[i]) for i in range(n)]
 
+    def lane_footprint(self, interval_columns, arena_bytes=1 << 30):
+        """HBM bytes a new lane pipeline of run_intervals takes at this query's sample count (gdbamd_engine_lane_footprint)"""
+        n = ctypes.c_uint64(0)
+        _check(_lib.lib().gdbamd_engine_lane_footprint(self._e, interval_columns, arena_bytes, ctypes.byref(n)) == 0, "lane_footprint")
+        return n.value
+
+    def release_lanes(self):
+        """frees the lane pipelines run_intervals created (their HBM comes back; the next call creates them again)"""
+        _check(_lib.lib().gdbamd_engine_release_lanes(self._e) == 0, "release_lanes")
+
     def pages(self, begin=0, end=INT64_MAX - 1, arena_bytes=1 << 30):
         """the VCF body of one column interval page by page, left in HBM: yields (device address, nbytes); an address is valid
         until the next page is asked for"""

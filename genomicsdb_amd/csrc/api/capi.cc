@@ -276,6 +276,13 @@ int gdbamd_engine_run_intervals(void* e, int n, const int64_t* begins, const int
   }, 1);
 }
 
+int gdbamd_engine_lane_footprint(void* e, int64_t interval_columns, uint64_t arena_bytes, uint64_t* bytes) {
+  return guarded([&]() -> int { *bytes = ((EngineHandle*)e)->eng->lane_footprint_bytes(interval_columns, arena_bytes); return 0; }, -1);
+}
+int gdbamd_engine_release_lanes(void* e) {
+  return guarded([&]() -> int { ((EngineHandle*)e)->eng->release_lanes(); return 0; }, -1);
+}
+
 int gdbamd_engine_prepare_interval(void* e, int64_t qb, int64_t qe) {
   return guarded([&]() -> int {
     CombineEngine& eng = *((EngineHandle*)e)->eng;

@@ -472,6 +472,23 @@ std::vector<IntervalStats> CombineEngine::run_intervals(const std::vector<std::p
   std::vector<IntervalStats> out(n);
   if (n == 0) return out;
   lanes = std::max(1, std::min<int>({lanes, 4, (int)n}));
+  // A lane pipeline that does not exist yet will allocate its own page arenas, entry table, matrix and sweep buffers (grow-only): no more
+  // NEW lanes than the free HBM holds (lane_footprint_bytes: the estimate bench.py used to make on the caller's side), else the run would
+  // end in a hipMalloc failure half-way through.  Lanes that exist keep what they hold.
+  {
+    int64_t widest = 1;
+    for (const auto& iv : intervals) widest = std::max<int64_t>(widest, iv.second - iv.first + 1);
+    const uint64_t per_lane = lane_footprint_bytes(widest, arena_bytes);
+    int existing = 0;
+    for (const Lane& L : m_lanes) if (L.pipe) ++existing;
+    size_t free_b = 0, total_b = 0;
+    if (lanes - 1 > existing && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      const int asked = lanes;
+      while (lanes - 1 > existing && (uint64_t)(lanes - 1 - existing) * per_lane + (4ull << 30) > (uint64_t)free_b) --lanes;
+      if (lanes < asked)
+        fprintf(stderr, "genomicsdb_amd: run_intervals: %d lanes asked, %d used (%.1f GB free, ~%.1f GB per new lane)\n", asked, lanes, free_b / 1e9, per_lane / 1e9);
+    }
+  }
   std::vector<DevicePipeline*> pipes((size_t)lanes, nullptr);
   pipes[0] = m_pipe.get();
   if ((int)m_lanes.size() < lanes - 1) m_lanes.resize((size_t)lanes - 1);
@@ -486,6 +503,8 @@ std::vector<IntervalStats> CombineEngine::run_intervals(const std::vector<std::p
     pipes[(size_t)l] = L.pipe.get();
   }
   for (DevicePipeline* p : pipes) p->set_page_priority(lanes > 1);
+  // (the priority stream is for pipelines that share the device: a later run_interval on the engine's own pipeline is alone again)
+  struct PriorityReset { std::vector<DevicePipeline*>& v; ~PriorityReset() { for (DevicePipeline* p : v) p->set_page_priority(false); } } priority_reset{pipes};
   std::vector<std::exception_ptr> errors((size_t)lanes);
   auto work = [&](int l) {
     try {
@@ -503,6 +522,16 @@ std::vector<IntervalStats> CombineEngine::run_intervals(const std::vector<std::p
   for (auto& e : errors) if (e) std::rethrow_exception(e);
   return out;
 }
+
+uint64_t CombineEngine::lane_footprint_bytes(int64_t interval_columns, uint64_t arena_bytes) const {
+  // ~45 bytes of output and up to ~18 bytes of tables (entry slots, resolved matrix, chunk sizes, sweep buffers) per sample and position of
+  // the interval, measured at the widths of BASELINE configs[1] and [2]; the page arena is capped by arena_bytes (two of them alternate, but
+  // the second is only allocated when a page overflows into it: counted once here like the first)
+  const uint64_t cells = std::max<uint64_t>(1, m_qc.get_num_rows_to_query()) * (uint64_t)std::max<int64_t>(1, interval_columns);
+  return std::min<uint64_t>(arena_bytes, 45ull * cells + (1ull << 30)) + 18ull * cells + (2ull << 30);
+}
+
+void CombineEngine::release_lanes() { m_lanes.clear(); }
 
 GenomicsDBBCFGenerator::GenomicsDBBCFGenerator(const std::string& loader_config_file, const std::string& query_config_file, const char* chr,
                                                const int start, const int end, int my_rank, size_t buffer_capacity, size_t, const char* output_format,

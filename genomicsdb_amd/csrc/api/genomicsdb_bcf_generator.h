@@ -76,6 +76,11 @@ class CombineEngine {
   // on_page (optional): called from the lane's thread for every page of interval `index` (device pointer, valid during the call)
   std::vector<IntervalStats> run_intervals(const std::vector<std::pair<int64_t, int64_t>>& intervals, uint64_t arena_bytes, int lanes,
                                            const std::function<void(size_t index, const char* dev_ptr, uint64_t nbytes)>& on_page = nullptr);
+  // HBM a NEW lane pipeline takes for intervals of `interval_columns` positions at this query's sample count (an estimate, see the
+  // definition): run_intervals uses no more new lanes than hipMemGetInfo's free bytes hold (4 GiB kept spare) and says so on stderr.
+  uint64_t lane_footprint_bytes(int64_t interval_columns, uint64_t arena_bytes) const;
+  // frees the lane pipelines (and their HBM); the next run_intervals creates them again
+  void release_lanes();
   // reference bases given by the caller for columns [begin, begin + bases.size()): kept, so that the pipeline a later window is
   // staged into (overlapped staging) sees them too
   void set_reference_window(int64_t begin, const std::string& bases);

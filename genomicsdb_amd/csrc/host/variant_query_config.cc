@@ -231,8 +231,7 @@ void VariantQueryConfig::read_from_json(const mini_json::Value& j, int rank, con
   if (j.HasMember("combined_vcf_records_buffer_size_limit")) set_combined_vcf_records_buffer_size_limit((size_t)j["combined_vcf_records_buffer_size_limit"].GetInt64());
   {
     std::string order;
-    if (j.HasMember("id_union_order")) order = j["id_union_order"].GetString();
-    else if (const char* e = getenv("GDBAMD_ID_UNION_ORDER")) order = e;
+    if (j.HasMember("id_union_order")) order = j["id_union_order"].GetString();   // (the query key only: no environment fallback - an ambient variable must not change output bytes)
     if (!order.empty() && order != "sorted" && order != "unordered_set")
       throw GenomicsDBConfigException("id_union_order must be \"sorted\" or \"unordered_set\", not \"" + order + "\"");
     m_id_union_order_unordered_set = order == "unordered_set";

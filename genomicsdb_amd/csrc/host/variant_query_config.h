@@ -78,8 +78,8 @@ class VariantQueryConfig {
   bool produce_GT_with_min_PL_value_for_spanning_deletions() const { return m_produce_GT_with_min_PL_value_for_spanning_deletions; }
   unsigned get_max_diploid_alt_alleles_that_can_be_genotyped() const { return m_max_diploid_alt_alleles_that_can_be_genotyped; }
   // ID union order: false = sorted (the reference's DEBUG build, the goldens), true = std::unordered_set<std::string> (any other
-  // build of the reference, broad_combined_gvcf.cc:732-737).  Query JSON "id_union_order": "sorted" | "unordered_set"; without the
-  // key the environment variable GDBAMD_ID_UNION_ORDER decides, default sorted.
+  // build of the reference, broad_combined_gvcf.cc:732-737: what a drop-in for a Release libtiledbgenomicsdb.so sets).  Query JSON
+  // "id_union_order": "sorted" | "unordered_set", or the setter below; default sorted.  The library reads no environment variable for it.
   bool id_union_order_unordered_set() const { return m_id_union_order_unordered_set; }
   void set_id_union_order_unordered_set(bool v) { m_id_union_order_unordered_set = v; }
   void set_max_diploid_alt_alleles_that_can_be_genotyped(unsigned v) { m_max_diploid_alt_alleles_that_can_be_genotyped = v; }

@@ -96,8 +96,13 @@ void note_record(std::vector<RefIndex>& refs, int tid, int64_t beg, int64_t end,
   r.off_end = std::max(r.off_end, vend);
   ++r.n_mapped;
 }
-// htslib's update_loff (hts.c): windows in front of a contig's first record take the offset of that record, every other window
-// without a record the offset of the window before it; then the loffset of a bin = the linear offset of the bin's FIRST 16 kb
+// htslib's update_loff (hts.c) AS IT WAS IN THE 1.x RELEASES OF THE REFERENCE'S TIME (its dependencies/htslib is a 2016-17 fork whose
+// pinned commit cannot be read here: SURVEY 8(c)): windows in front of a contig's first record take the offset of that record, every
+// other window without a record the offset of the window BEFORE it.  htslib 1.10 and later fill an empty window from the window BEHIND
+// it ("the last entry is always valid").  Both are lower bounds of the first overlapping record's offset, so every reader finds the same
+// records with either; only the stored values of empty windows (and of bins that begin in one) differ - byte identity with a given
+// htslib build's .tbi / .csi is therefore NOT claimed for files with empty 16 kb windows, query equivalence is (tests/test_vcf_index.py).
+// Then the loffset of a bin = the linear offset of the bin's FIRST 16 kb
 // window, i.e. the offset of the first record that OVERLAPS that window - not of the first record that begins in the bin (a
 // reference block that begins in the window before and reaches into it comes first in the file, and hts_itr_query drops every
 // chunk that ends at or below the loffset)

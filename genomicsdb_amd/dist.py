@@ -226,7 +226,6 @@ def paged_concat(pages, sink, page_bytes, dst=0, ring_slots=3, device=None, stat
         polled = (env == "1") if env is not None else dist.get_backend() != "gloo"
     if rank != dst:
         ring, pending, total, k = [], [], 0, 0
-        hdr_keep = []
         for t in pages:
             n = int(t.numel())
             if n == 0:
@@ -238,19 +237,18 @@ def paged_concat(pages, sink, page_bytes, dst=0, ring_slots=3, device=None, stat
                 ring.append(torch.empty(page_bytes, dtype=torch.uint8, device=t.device))
             elif len(pending) >= ring_slots:          # the slot's previous page must have left
                 t0 = time.time()
-                for w in pending.pop(0):
+                for w in pending.pop(0)[:2]:
                     w.wait()
                 blocked += time.time() - t0
             ring[slot][:n].copy_(t)                   # the engine's arena is reused by the next page:
             if t.is_cuda:                             # the copy (torch's stream) must be over before the engine (its own
                 torch.cuda.current_stream(t.device).synchronize()   # stream) is asked for the next one
             h = torch.tensor([n], dtype=torch.int64)  # host tensor, gloo group: the root learns the size without touching the device
-            hdr_keep.append(h)
-            pending.append((dist.isend(h, dst=dst, group=hgroup), dist.isend(ring[slot][:n], dst=dst)))
+            pending.append((dist.isend(h, dst=dst, group=hgroup), dist.isend(ring[slot][:n], dst=dst), h))   # (h lives as long as its send: dropped with the slot)
             total += n
             k += 1
         for ws in pending:
-            for w in ws:
+            for w in ws[:2]:
                 w.wait()
         dist.send(torch.zeros(1, dtype=torch.int64), dst=dst, group=hgroup)
         if stats is not None:
@@ -298,8 +296,10 @@ def paged_concat(pages, sink, page_bytes, dst=0, ring_slots=3, device=None, stat
             return None
         if isinstance(n, BaseException):
             raise n
-        if n > page_bytes:
-            raise ValueError("rank %d announced a page of %d bytes, page_bytes is %d" % (r, n, page_bytes))
+        if n > page_bytes and not failure:
+            # a sender that breaks the contract must not strand the others: the page is received into a buffer of its own and dropped,
+            # every stream is drained to its closing header, then the error is raised (like a failing sink)
+            failure.append(ValueError("rank %d announced a page of %d bytes, page_bytes is %d" % (r, n, page_bytes)))
         return n
 
     if polled:
@@ -323,7 +323,7 @@ def paged_concat(pages, sink, page_bytes, dst=0, ring_slots=3, device=None, stat
                     slot = free[r].pop(0)
                     while len(ring[r]) <= slot:
                         ring[r].append(torch.empty(page_bytes, dtype=torch.uint8, device=dev))
-                    view = ring[r][slot][:n]
+                    view = ring[r][slot][:n] if n <= page_bytes else torch.empty(n, dtype=torch.uint8, device=dev)   # (oversize: dropped, see next_size)
                     inflight[r].append((wrap(dist.irecv(view, src=r)), view, slot))
                     posted = True
             return posted
@@ -363,7 +363,7 @@ def paged_concat(pages, sink, page_bytes, dst=0, ring_slots=3, device=None, stat
                     k += 1
                     if len(ring) <= slot:
                         ring.append(torch.empty(page_bytes, dtype=torch.uint8, device=dev))
-                    view = ring[slot][:n]
+                    view = ring[slot][:n] if n <= page_bytes else torch.empty(n, dtype=torch.uint8, device=dev)       # (oversize: dropped, see next_size)
                     dist.recv(view, src=src)
                     out_q.put(view)
             except BaseException as e:                  # noqa: BLE001 - handed to the thread that drains

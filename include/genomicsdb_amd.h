@@ -213,6 +213,13 @@ int gdbamd_engine_run_interval(void* engine, int64_t column_begin, int64_t colum
 int gdbamd_engine_run_intervals(void* engine, int n, const int64_t* column_begins, const int64_t* column_ends, uint64_t arena_bytes, int lanes,
                                 gdbamd_interval_stats* stats, char* const* host_out, const uint64_t* host_cap, uint64_t* host_len);
 
+/* HBM a NEW lane pipeline takes for intervals of `interval_columns` positions at the query's sample count (~45 bytes of page and ~18 bytes
+ * of tables per sample and position, the page capped by arena_bytes, + 2 GiB).  gdbamd_engine_run_intervals creates no more new lanes than
+ * the device's free memory holds (4 GiB kept spare) and reports the clamp on stderr; lane pipelines stay allocated (grow-only) until
+ * gdbamd_engine_release_lanes or the engine's destruction. */
+int gdbamd_engine_lane_footprint(void* engine, int64_t interval_columns, uint64_t arena_bytes, uint64_t* bytes);
+int gdbamd_engine_release_lanes(void* engine);
+
 /* the same in two steps, for consumers that take the pages where they are (HBM): prepare = sweep, site and sizing passes of
  * the interval; next_page = the next <= arena_bytes of whole records.  *dev_ptr is device memory, valid until the next call
  * on this engine.  next_page returns 1 (a page), 0 (interval exhausted) or -1 (error).

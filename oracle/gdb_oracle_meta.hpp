@@ -574,7 +574,6 @@ class QueryConfig {
     {
       std::string order;
       if (j.HasMember("id_union_order")) order = j["id_union_order"].GetString();
-      else if (const char* e = getenv("GDBAMD_ID_UNION_ORDER")) order = e;
       id_union_order_unordered_set = order == "unordered_set";
     }
     sites_only_query = flag("sites_only_query");

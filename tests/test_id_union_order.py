@@ -1,7 +1,7 @@
 """ID union of a record in the order of a Release build of the reference.  merge_ID_field collects the ';'-separated tokens of
 the live calls in a std::set<std::string> only #ifdef DEBUG (the goldens come from such a build: sorted tokens); every other build
 uses a std::unordered_set<std::string> and prints ITS iteration order (broad_combined_gvcf.cc:730-763) - std::hash<std::string>
-plus libstdc++'s bucket list.  The query key "id_union_order": "unordered_set" (or GDBAMD_ID_UNION_ORDER) selects that flavour.
+plus libstdc++'s bucket list.  The query key "id_union_order": "unordered_set" selects that flavour (the query key only: no environment fallback).
 gdb_core.hpp restates hash and list order for the device; here the restatement is compared with the library itself, and the
 kernel bodies / the device with the oracle, whose container IS the library's."""
 import ctypes

@@ -134,7 +134,7 @@ def test_two_ranks_import_their_partitions_and_concat():
     assert nc0 + nc1 > ncells_full          # the replayed intervals exist in both partitions
 
 
-def _paged_worker(rank, world, port, q, dst=0, polled=None, root_ring_bytes=8 << 30, fail_at=None):
+def _paged_worker(rank, world, port, q, dst=0, polled=None, root_ring_bytes=8 << 30, fail_at=None, root_page_bytes=1000):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -165,7 +165,12 @@ def _paged_worker(rank, world, port, q, dst=0, polled=None, root_ring_bytes=8 <<
                 raise RuntimeError("sink failed at page %d" % fail_at)
             got.append(bytes(t.numpy().tobytes()))
         try:
-            total = gdist.paged_concat(pages(), sink, page_bytes=1000, dst=dst, ring_slots=3, stats=stats, polled=polled, root_ring_bytes=root_ring_bytes)
+            total = gdist.paged_concat(pages(), sink, page_bytes=root_page_bytes if rank == dst else 1000, dst=dst, ring_slots=3, stats=stats, polled=polled,
+                                       root_ring_bytes=root_ring_bytes)
+        except ValueError as e:
+            assert rank == dst and root_page_bytes < 1000 and "announced a page" in str(e)
+            q.put((rank, mine, got, -2))
+            return
         except RuntimeError as e:
             assert rank == dst and fail_at is not None and "sink failed" in str(e)
             q.put((rank, mine, got, -1))
@@ -247,6 +252,16 @@ def test_paged_concat_a_failing_sink_does_not_strand_the_senders(polled):
     re-raises; the senders finish normally instead of hanging in wait()"""
     res = _run_paged(3, polled=polled, fail_at=7)
     assert res[0][3] == -1 and len(res[0][2]) == 7
+    assert res[1][3] == 0 and res[2][3] == sum(len(p) for p in res[2][1]) > 0
+
+
+@pytest.mark.parametrize("polled", [False, True])
+def test_paged_concat_an_oversize_page_header_does_not_strand_the_senders(polled):
+    """the root was given a smaller page_bytes (400) than the senders use (1 000): the first header above it is an error of the
+    ROOT's call, but the root keeps receiving - the oversize pages into buffers of their own - and dropping until every rank has closed
+    its stream; the senders finish normally, then the root raises"""
+    res = _run_paged(3, polled=polled, root_page_bytes=400)
+    assert res[0][3] == -2
     assert res[1][3] == 0 and res[2][3] == sum(len(p) for p in res[2][1]) > 0
 
 
