@@ -42,7 +42,7 @@ _lib = None
 
 # every symbol include/genomicsdb_amd.h declares
 SYMBOLS = ["gdb_mi355_last_error", "gdb_mi355_device_count", "gdb_mi355_init", "gdb_mi355_init_output_format", "gdb_mi355_init_from_memory_output_format",
-           "gdbamd_engine_create_output_format", "gdbamd_bgzf_compress", "gdbamd_bgzf_bound", "gdb_mi355_init_from_memory", "gdb_mi355_init_from_memory_format", "gdb_mi355_close",
+           "gdbamd_engine_create_output_format", "gdbamd_bgzf_compress", "gdbamd_bgzf_compress_mode", "gdbamd_bgzf_bound", "gdb_mi355_init_from_memory", "gdb_mi355_init_from_memory_format", "gdb_mi355_close",
            "gdb_mi355_get_num_bytes_available", "gdb_mi355_read_next_byte", "gdb_mi355_read", "gdb_mi355_skip", "gdb_mi355_peek", "gdb_mi355_get_stream_stats",
            "gdbamd_engine_create", "gdbamd_engine_create_format", "gdbamd_engine_destroy", "gdbamd_engine_num_fields", "gdbamd_engine_field_name",
            "gdbamd_engine_field_info", "gdbamd_engine_header", "gdbamd_engine_stage_cells", "gdbamd_engine_stage_cells_begin", "gdbamd_engine_stage_cells_append", "gdbamd_engine_stage_cells_end",
@@ -83,6 +83,7 @@ def lib():
     L.gdbamd_engine_create_output_format.restype = c.c_void_p
     L.gdbamd_engine_create_output_format.argtypes = [c.c_char_p, c.c_int, c.c_char_p, c.c_int]
     L.gdbamd_bgzf_compress.argtypes = [c.c_char_p, c.c_uint64, c.c_char_p, c.c_uint64, c.POINTER(c.c_uint64), c.POINTER(c.c_float)]
+    L.gdbamd_bgzf_compress_mode.argtypes = [c.c_char_p, c.c_uint64, c.c_char_p, c.c_uint64, c.POINTER(c.c_uint64), c.POINTER(c.c_float), c.c_int]
     L.gdbamd_bgzf_bound.restype = c.c_uint64
     L.gdbamd_bgzf_bound.argtypes = [c.c_uint64]
     L.gdbamd_engine_create_format.restype = c.c_void_p

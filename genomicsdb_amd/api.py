@@ -357,15 +357,16 @@ def import_cells(vid_mapping_file, callset_mapping_file, file_root="", treat_del
         L.gdbamd_free(p)
 
 
-def bgzf_compress(data):
-    """BGZF blocks (no EOF block) of `data`, deflated by the device kernels (kernels/gdb_bgzf.hip); returns (bytes, kernel ms)"""
+def bgzf_compress(data, vcf_text=False):
+    """BGZF blocks (no EOF block) of `data`, deflated by the device kernels (kernels/gdb_bgzf.hip); returns (bytes, kernel ms).
+    vcf_text: the anchored kernel of the "z" stream (matches begin at tabs / newlines) instead of the byte-level one"""
     L = _lib.lib()
     data = bytes(data)
     cap = L.gdbamd_bgzf_bound(len(data))
     dst = ctypes.create_string_buffer(cap)
     n = ctypes.c_uint64()
     ms = ctypes.c_float()
-    _check(L.gdbamd_bgzf_compress(data, len(data), dst, cap, ctypes.byref(n), ctypes.byref(ms)) == 0, "bgzf_compress")
+    _check(L.gdbamd_bgzf_compress_mode(data, len(data), dst, cap, ctypes.byref(n), ctypes.byref(ms), 1 if vcf_text else 0) == 0, "bgzf_compress")
     return dst.raw[:n.value], ms.value
 
 

@@ -117,6 +117,9 @@ void* gdbamd_engine_create_output_format(const char* query_json_text, int device
 }
 // BGZF blocks of n host bytes, compressed by the device kernels (a utility and the test hook of kernels/gdb_bgzf.hip)
 int gdbamd_bgzf_compress(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t dst_cap, uint64_t* dst_len, float* ms_kernels) {
+  return gdbamd_bgzf_compress_mode(src, n, dst, dst_cap, dst_len, ms_kernels, 0);
+}
+int gdbamd_bgzf_compress_mode(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t dst_cap, uint64_t* dst_len, float* ms_kernels, int vcf_text) {
   return guarded([&]() -> int {
     if (DevicePipeline::device_count() <= 0) throw GenomicsDBDeviceException("no HIP device visible");
     const uint64_t bound = bgzf_bound(n);
@@ -126,6 +129,7 @@ int gdbamd_bgzf_compress(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t 
     try {
       if (n && hipMemcpy(d, src, (size_t)n, hipMemcpyHostToDevice) != hipSuccess) throw GenomicsDBDeviceException("copy to the device failed");
       BgzfDeviceCompressor c;
+      c.set_text(vcf_text != 0);
       got = c.compress(d, n, d, nullptr, ms_kernels);
       if (got > dst_cap) throw GenomicsDBDeviceException("destination too small: " + std::to_string(got) + " bytes needed");
       if (got && hipMemcpy(dst, d, (size_t)got, hipMemcpyDeviceToHost) != hipSuccess) throw GenomicsDBDeviceException("copy from the device failed");

@@ -127,7 +127,8 @@ GDB_HD int bcf_field_elem_size(const CombinePlan& pl, int fmt_i) {
 template <class Sink> GDB_HD Sink entry_emit_bin(const EntryCtx& cx, const RecordInfo& ri, int64_t c, Sink s, uint32_t* err) {
   const CombinePlan& pl = cx.pl;
   EntryMaps em;
-  build_entry_maps(cx, ri, c, em, err);
+  int8_t m2i_store[GDB_MAX_MERGED_ALLELES];
+  build_entry_maps(cx, ri, c, em, m2i_store, err);
   int nf = 0;
   for (uint32_t m = ri.fmt_mask; m; m &= m - 1) ++nf;
   const uint32_t hdr_at = s.pos();

@@ -1728,8 +1728,10 @@ template <class Sink> GDB_HD void put_int_or_missing(Sink& s, bool has, int32_t 
 }
 
 // Allele maps of one live call inside one record (built once per entry, handed to the field emitters by reference)
+// (m2i is a pointer to an array of the CALLER, not a member: with the array inside, the variable-length fill of build_entry_maps kept the
+//  whole struct in scratch memory on the device - every `em.remap` / `em.cf` in front of a field was a trip to memory, ~60 per entry)
 struct EntryMaps {
-  int8_t m2i[GDB_MAX_MERGED_ALLELES];  // merged allele -> input allele of this call (-1: none)
+  int8_t* m2i;                         // [GDB_MAX_MERGED_ALLELES] merged allele -> input allele of this call (-1: none); only filled for heavy calls
   const int8_t* i2m;                   // input -> merged (heavy calls), null for plain reference blocks
   int nr_in;                           // input idx of <NON_REF> in this call, -1 if it has none
   int n_in;                            // #input alleles incl. REF
@@ -1895,7 +1897,8 @@ template <class Sink, class T> GDB_FIELD_FN Sink emit_remap_genotypes(Sink s, co
   return s;
 }
 
-GDB_FIELD_FN void build_entry_maps(const EntryCtx& cx, const RecordInfo& ri, int64_t c, EntryMaps& em, uint32_t* err) {
+GDB_FIELD_FN void build_entry_maps(const EntryCtx& cx, const RecordInfo& ri, int64_t c, EntryMaps& em, int8_t* m2i_store, uint32_t* err) {
+  em.m2i = m2i_store;
   em.remap = (ri.rflags & GDB_RF_REMAPPING_NEEDED) != 0;
   em.nr_exists = (ri.rflags & GDB_RF_NON_REF_EXISTS) != 0;
   em.nr_in = -1; em.i2m = nullptr; em.n_in = 0; em.iflag = 0; em.inc = -1; em.cf = 0; em.light = false;
@@ -1959,7 +1962,8 @@ template <class Sink> GDB_HD Sink emit_field(Sink s, const EntryCtx& cx, const R
 template <class Sink> GDB_HD Sink entry_emit(const EntryCtx& cx, const RecordInfo& ri, int64_t c, Sink s, uint32_t* err) {
   const CombinePlan& pl = cx.pl;
   EntryMaps em;
-  build_entry_maps(cx, ri, c, em, err);
+  int8_t m2i_store[GDB_MAX_MERGED_ALLELES];
+  build_entry_maps(cx, ri, c, em, m2i_store, err);
   bool first = true;
   for (int i = 0; i < pl.n_format; ++i) {
     if ((ri.fmt_mask >> i) & 1) {

@@ -44,6 +44,10 @@ class BgzfDeviceCompressor {
   // enqueue() only queues work on the stream (n > 0), finish() waits for it and returns the size.  Two jobs (slot 0 / 1) may be
   // queued behind each other on ONE stream; cancel() forgets a queued job whose result nobody will ask for.
   void enqueue(int slot, const char* dev_src, uint64_t n, char* dev_dst, void* hip_stream);
+  // The pages are VCF TEXT (output format "z"): matches are looked for where a column begins (tabs, newlines) instead of at every byte -
+  // k_bgzf_deflate_text, about a third of the instructions per block at ~5 % of the ratio.  Any bytes still give a valid stream (the anchors
+  // only decide how much is found), but binary pages (BCF2, "b") compress far better with the byte-level kernel, which stays the default.
+  void set_text(bool pages_are_vcf_text);
   uint64_t finish(int slot, float* ms_kernels = nullptr);
   void cancel(int slot);
   struct Impl;

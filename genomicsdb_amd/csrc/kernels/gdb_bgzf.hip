@@ -291,9 +291,10 @@ __device__ __forceinline__ void load_block(uint4* in4, const uint8_t* blk_src, u
   }
 }
 
-// csize holds kParts payload sizes per block (the pack kernel lays them behind each other)
+// csize / coff hold kParts payload sizes / offsets inside the block's slot (the pack kernel lays the parts behind each other)
+constexpr int kParts = 4;
 template <int kBgzfBlockInput>
-__global__ void __launch_bounds__(64) k_bgzf_deflate(const uint8_t* __restrict__ src, uint64_t n_total, uint8_t* __restrict__ slots, uint32_t* __restrict__ csize,
+__global__ void __launch_bounds__(64) k_bgzf_deflate(const uint8_t* __restrict__ src, uint64_t n_total, uint8_t* __restrict__ slots, uint32_t* __restrict__ csize, uint32_t* __restrict__ coff,
                                                      uint64_t* __restrict__ bsize, uint32_t* __restrict__ crc_out, const uint32_t* __restrict__ crc_slice,
                                                      const uint32_t* __restrict__ crc_shift) {
   const uint64_t blk = blockIdx.x;
@@ -329,7 +330,8 @@ __global__ void __launch_bounds__(64) k_bgzf_deflate(const uint8_t* __restrict__
     payload = n + 5u;
   }
   const uint32_t crc = block_crc<kBgzfBlockInput>(in, n, lane, crc_slice, crc_shift);
-  if (lane == 0) { csize[2 * blk] = payload; csize[2 * blk + 1] = 0u; bsize[blk] = (uint64_t)payload + kBgzfHeaderBytes + kBgzfTrailerBytes; crc_out[blk] = crc; }
+  if (lane < kParts) { csize[kParts * blk + lane] = lane ? 0u : payload; coff[kParts * blk + lane] = 0u; }
+  if (lane == 0) { bsize[blk] = (uint64_t)payload + kBgzfHeaderBytes + kBgzfTrailerBytes; crc_out[blk] = crc; }
 }
 
 // TWO wavefronts per block (round 5).  A block's time is a chain of ~128 dependent steps and a wavefront issues an instruction every
@@ -340,7 +342,7 @@ __global__ void __launch_bounds__(64) k_bgzf_deflate(const uint8_t* __restrict__
 // which makes the second one start on a byte boundary; the pack kernel puts the two payloads behind each other.  Both wavefronts share
 // the 8 KiB of input in LDS: 14.4 KB per pair = 22 wavefronts per CU instead of 14.  Ratio: a match cannot cross the middle, + 5 bytes.
 template <int kBgzfBlockInput>
-__global__ void __launch_bounds__(128) k_bgzf_deflate2(const uint8_t* __restrict__ src, uint64_t n_total, uint8_t* __restrict__ slots, uint32_t* __restrict__ csize,
+__global__ void __launch_bounds__(128) k_bgzf_deflate2(const uint8_t* __restrict__ src, uint64_t n_total, uint8_t* __restrict__ slots, uint32_t* __restrict__ csize, uint32_t* __restrict__ coff,
                                                        uint64_t* __restrict__ bsize, uint32_t* __restrict__ crc_out, const uint32_t* __restrict__ crc_slice,
                                                        const uint32_t* __restrict__ crc_shift) {
   const uint64_t blk = blockIdx.x;
@@ -413,9 +415,308 @@ __global__ void __launch_bounds__(128) k_bgzf_deflate2(const uint8_t* __restrict
     const uint32_t crc = block_crc<kBgzfBlockInput>(in, n, lane, crc_slice, crc_shift);
     if (lane == 0) {
       const uint32_t p0 = store ? n + 5u : s_payload[0], p1 = store ? 0u : s_payload[1];
-      csize[2 * blk] = p0; csize[2 * blk + 1] = p1;
+      csize[kParts * blk] = p0; csize[kParts * blk + 1] = p1; csize[kParts * blk + 2] = 0u; csize[kParts * blk + 3] = 0u;
+      coff[kParts * blk] = 0u; coff[kParts * blk + 1] = kSlotBytes / 2; coff[kParts * blk + 2] = 0u; coff[kParts * blk + 3] = 0u;
       bsize[blk] = (uint64_t)(p0 + p1) + kBgzfHeaderBytes + kBgzfTrailerBytes; crc_out[blk] = crc;
     }
+  }
+}
+
+
+// ---- VCF TEXT: matches only where an entry begins ("anchored" LZ77, round 6) --------------------------------------------------------------
+// The byte-level kernels above hash and probe all 64 positions of a step although the greedy parse visits ~6 of them (every position
+// inside a match is wasted work): 13.3 K vector instructions per 8 KiB block, and the kernel is bound by the instructions it issues.
+// VCF text says where matches begin: a sample column ("\t./.:99:.:.:0,297,4455,...") repeats the column of some earlier sample with
+// the same leading fields.  So a lane here is not a byte position but an ANCHOR - a tab or newline (where 64 bytes go by without one:
+// the first ':' or ',' of a 32-byte chunk, else the chunk's first byte; at most one anchor per 8 bytes, so a block has <= 1 024 and a
+// segment - the bytes from an anchor to the next - is at most 95 bytes long):
+//   * hash of the anchor's first 8 bytes -> the most recent earlier anchor with that hash (a table per wavefront, entered sixteen lanes at a
+//     time so that an anchor finds candidates among the lanes in front of it; the three lanes right in front are compared directly);
+//   * ONE match per anchor, measured to its end but never beyond the next anchor, then the rest of the segment as literals: no lane
+//     depends on another lane's match, there is no parse chain;
+//   * every lane knows its bit count (length / distance codes by arithmetic, 8 or 9 bits per literal), a wavefront scan places the lanes,
+//     and each lane ORs its own tokens - the match, then its literals three at a time - into the ring of output words.
+// FOUR wavefronts share a block (its 8 KiB of input sit in LDS once): the anchors are found by all 256 threads, each wavefront takes a
+// quarter of them, primes its table with the anchors in front of its quarter, and writes a DEFLATE block of its own that ends with an
+// empty stored block (zlib's sync flush: the next one starts on a byte boundary), like k_bgzf_deflate2's halves.  The CRC-32 is taken
+// by all four.  A block that does not shrink is stored.  ANY set of anchors gives a valid stream - they only decide how much is found -
+// so binary pages (BCF2) keep the byte-level kernel and the text kernel is chosen by the producer of the page (gdb_bgzf.h).
+constexpr int kTW = 4;                          // wavefronts per block
+constexpr int kTThreads = 64 * kTW;
+constexpr int kTMaxAnch = 1024;                 // (one per 8 bytes of an 8 KiB block)
+constexpr int kTHashBits = 9;
+constexpr int kTRing = 256, kTFlush = 64;       // ring of output words per wavefront: < 64 words wait, a pass adds < 192
+constexpr uint32_t kTPassBits = 6000;           // bits the lanes of one pass may add (a lane: at most 31 + 95 x 9)
+constexpr uint32_t kTNoCand = 0xFFFFu;
+
+// 0x80 in every byte of v that equals the byte repeated in pat (exact, no carries between bytes)
+__device__ __forceinline__ uint32_t eq_bytes(uint32_t v, uint32_t pat) {
+  const uint32_t x = v ^ pat;
+  return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+}
+__device__ __forceinline__ uint32_t marks_to_nibble(uint32_t z) { return ((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u); }
+// the four bytes at byte position q of the block (aligned LDS dwords, funnel-shifted)
+__device__ __forceinline__ uint32_t ld4u(const uint32_t* in32, uint32_t q) {
+  const uint32_t wq = q >> 2;
+  return __builtin_amdgcn_alignbyte(in32[wq + 1], in32[wq], q & 3u);
+}
+__device__ __forceinline__ void ring_or(uint32_t* ring, uint32_t bitoff, uint32_t bits, uint32_t nb) {   // nb <= 32, bits < 2^nb
+  const uint32_t w = bitoff >> 5, sh = bitoff & 31u;
+  atomicOr(&ring[w & (kTRing - 1)], bits << sh);
+  if (sh + nb > 32u) atomicOr(&ring[(w + 1u) & (kTRing - 1)], bits >> (32u - sh));
+}
+
+template <int kBgzfBlockInput>
+__global__ void __launch_bounds__(kTThreads) k_bgzf_deflate_text(const uint8_t* __restrict__ src, uint64_t n_total, uint8_t* __restrict__ slots, uint32_t* __restrict__ csize,
+                                                                 uint32_t* __restrict__ coff, uint64_t* __restrict__ bsize, uint32_t* __restrict__ crc_out,
+                                                                 const uint32_t* __restrict__ crc_slice, const uint32_t* __restrict__ crc_shift256) {
+  static_assert(kBgzfBlockInput == 8192, "256 threads x 32 bytes");
+  const uint64_t blk = blockIdx.x;
+  const uint64_t base = blk * (uint64_t)kBgzfBlockInput;
+  const uint32_t n = (uint32_t)((n_total - base) < (uint64_t)kBgzfBlockInput ? (n_total - base) : (uint64_t)kBgzfBlockInput);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr uint32_t kSlotBytes = slot_bytes((uint32_t)kBgzfBlockInput);
+  __shared__ uint4 in4[kBgzfBlockInput / 16 + 3];
+  __shared__ uint16_t anch[kTMaxAnch + 2];
+  __shared__ uint16_t table_all[kTW][(1 << kTHashBits) + 2];
+  __shared__ uint32_t ring_all[kTW][kTRing];
+  __shared__ uint32_t s_cnt[kTW], s_payload[kTW], s_gave_up[kTW], s_crc[kTW], s_off[kTW];
+  __shared__ uint8_t s_has_tab[kTThreads];
+  uint8_t* const in = reinterpret_cast<uint8_t*>(in4);
+  const uint32_t* const in32 = reinterpret_cast<const uint32_t*>(in4);
+  load_block<kBgzfBlockInput>(in4, src + base, n, tid, kTThreads);
+  uint16_t* const table = table_all[wv];
+  uint32_t* const ring = ring_all[wv];
+  for (uint32_t q = lane; q < (1u << kTHashBits) + 2u; q += 64) table[q] = (uint16_t)kTNoCand;
+  for (uint32_t q = lane; q < (uint32_t)kTRing; q += 64) ring[q] = 0u;
+  if (tid < kTW) { s_payload[tid] = 0u; s_gave_up[tid] = 0u; s_off[tid] = 0u; }
+  __syncthreads();
+  // ---- anchors: thread t looks at the 32 bytes [32 t, 32 t + 32) ----------------------------------------------------------------------
+  const uint32_t chunk = 32u * (uint32_t)tid;
+  uint32_t mt = 0, ms = 0;                                     // bit b: byte chunk + b is a tab / newline, a ':' / ','
+  {
+    const uint4 q0 = in4[2 * tid], q1 = in4[2 * tid + 1];
+    const uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      mt |= marks_to_nibble(eq_bytes(w[k], 0x09090909u) | eq_bytes(w[k], 0x0A0A0A0Au)) << (4 * k);
+      ms |= marks_to_nibble(eq_bytes(w[k], 0x3A3A3A3Au) | eq_bytes(w[k], 0x2C2C2C2Cu)) << (4 * k);
+    }
+  }
+  const uint32_t valid = chunk >= n ? 0u : (n - chunk >= 32u ? ~0u : ((1u << (n - chunk)) - 1u));
+  mt &= valid; ms &= valid;
+  s_has_tab[tid] = mt ? 1 : 0;
+  __syncthreads();
+  uint32_t m = mt;
+  if (!mt && valid && tid > 0 && !s_has_tab[tid - 1]) m = ms ? (ms & (0u - ms)) : 1u;   // 32 .. 63 bytes without a tab in front: a secondary anchor
+  if (tid == 0 && n) m |= 1u;                                                             // the block's first byte
+  {                                                                                       // at most one anchor per 8 bytes: the first of each octet
+    uint32_t t = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const uint32_t b = (m >> (8 * k)) & 0xFFu; t |= (b & (0u - b)) << (8 * k); }
+    m = t;
+  }
+  const uint32_t cnt = (uint32_t)__popc(m);
+  const uint32_t incl_c = wave_incl_scan(cnt);
+  if (lane == 63) s_cnt[wv] = incl_c;
+  __syncthreads();
+  uint32_t A = 0, before = 0;
+#pragma unroll
+  for (int k = 0; k < kTW; ++k) { const uint32_t c = s_cnt[k]; if (k < wv) before += c; A += c; }
+  {
+    uint32_t pos = before + incl_c - cnt;
+    while (m) { const uint32_t b = (uint32_t)__builtin_ctz(m); anch[pos++] = (uint16_t)(chunk + b); m &= m - 1u; }
+  }
+  if (tid == 0) anch[A] = (uint16_t)n;                          // (A <= 1 024; n <= 8 192 fits)
+  __syncthreads();
+  // ---- this wavefront's quarter of the anchors ---------------------------------------------------------------------------------------------
+  const uint32_t per = A ? (A + kTW - 1) / kTW : 1u;
+  const uint32_t lo = (uint32_t)wv * per < A ? (uint32_t)wv * per : A, hi = lo + per < A ? lo + per : A;
+  const uint32_t last_wave = A ? (A - 1u) / per : 0u;
+  const bool working = lo < hi;
+  uint32_t payload = 0;
+  bool gave_up = false;
+  if (working) {                                                 // (uniform)
+    const uint32_t begin = anch[lo], end = anch[hi], share = end - begin;
+    const uint32_t off = ((begin + 3u) & ~3u) + 32u * (uint32_t)wv;      // the part's place in the slot: its output never grows past share + 25 bytes
+    uint32_t* const out_words = reinterpret_cast<uint32_t*>(slots + blk * (uint64_t)kSlotBytes + off);
+    if (lane == 0) { ring[0] = (uint32_t)wv == last_wave ? 3u : 2u; s_off[wv] = off; }     // BFINAL on the block's last part, BTYPE = 01
+    // the dictionary: the anchors in front of the quarter enter the table (which of two lanes with one hash stays is not defined: either is a candidate)
+    for (uint32_t j0 = 0; j0 < lo; j0 += 64) {
+      const uint32_t j = j0 + (uint32_t)lane;
+      if (j < lo) {
+        const uint32_t a = anch[j];
+        const uint32_t h = ((ld4u(in32, a) * 2654435761u) ^ (ld4u(in32, a + 4u) * 2246822519u)) >> (32 - kTHashBits);
+        table[h] = (uint16_t)a;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    uint32_t bitpos = 3, flushed = 0;
+    for (uint32_t s0 = lo; s0 < hi && !gave_up; s0 += 64) {      // uniform
+      const uint32_t j = s0 + (uint32_t)lane;
+      const bool act = j < hi;
+      const uint32_t a = act ? anch[j] : 0u, e = act ? anch[j + 1] : 0u;
+      const uint32_t w0 = ld4u(in32, a), w1 = ld4u(in32, a + 4u);
+      const uint32_t h = act ? ((w0 * 2654435761u) ^ (w1 * 2246822519u)) >> (32 - kTHashBits) : (1u << kTHashBits);
+      int32_t cand = -1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {                              // sixteen lanes at a time: read the table, then enter it
+        if ((lane >> 4) == q) { const uint32_t c = table[h]; cand = c == kTNoCand ? -1 : (int32_t)c; }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if ((lane >> 4) == q) table[h] = (uint16_t)a;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      }
+#pragma unroll
+      for (int k = 3; k >= 1; --k) {                             // the three anchors right in front (more recent than anything in the table)
+        const uint32_t nw0 = (uint32_t)__shfl_up((int)w0, k, 64), nw1 = (uint32_t)__shfl_up((int)w1, k, 64);
+        const int32_t na = __shfl_up((int)a, k, 64);
+        if (act && lane >= k && nw0 == w0 && nw1 == w1 && na > cand) cand = na;
+      }
+      // the match: cand's bytes against the anchor's, to the first difference, the segment's end or 258
+      const uint32_t seg = e - a;
+      const uint32_t maxL = seg < 258u ? seg : 258u;
+      uint32_t L = 0;
+      {
+        bool go = act && cand >= 0;
+        const uint32_t cpos = go ? (uint32_t)cand : 0u;
+        while (__any((int)go)) {
+          const uint32_t x = ld4u(in32, a + L) ^ ld4u(in32, cpos + L);
+          if (go) {
+            L += x ? ((uint32_t)__builtin_ctz(x) >> 3) : 4u;
+            if (x || L >= maxL) go = false;
+          }
+        }
+        L = L < maxL ? L : maxL;
+        if (L < 4u) L = 0;
+      }
+      const uint32_t d = (a - (uint32_t)(cand >= 0 ? cand : 0)) - 1u;      // distance - 1
+      // the match's code: length symbol + extra bits, 5-bit distance symbol + extra bits (as in emit_tokens above)
+      uint32_t mb = 0, mn = 0;
+      if (L) {
+        const uint32_t l = L - 3u;
+        const uint32_t leb = l < 8u ? 0u : (31u - (uint32_t)__clz(l | 8u)) - 2u;
+        uint32_t lsym = l < 8u ? 257u + l : 261u + 4u * leb + ((l >> leb) & 3u);
+        uint32_t lextra = l & ((1u << leb) - 1u), lextra_bits = leb;
+        if (L == 258u) { lsym = 285u; lextra = 0; lextra_bits = 0; }
+        uint32_t sb, sn;
+        fixed_litlen(lsym, sb, sn);
+        const uint32_t deb = d < 4u ? 0u : (31u - (uint32_t)__clz(d | 4u)) - 1u;
+        const uint32_t dsym = d < 4u ? d : 2u * deb + 2u + ((d >> deb) & 1u);
+        const uint32_t dextra = d & ((1u << deb) - 1u);
+        mb = sb | (lextra << sn); mn = sn + lextra_bits;
+        mb |= (__brev(dsym) >> 27) << mn; mn += 5u;
+        mb |= dextra << mn; mn += deb;
+      }
+      // the literals behind it: 8 bits each, 9 for the bytes from 144 up
+      const uint32_t ls = a + L, nl = act ? seg - L : 0u;
+      uint32_t nhigh = 0;
+      for (uint32_t t = 0; __any((int)(t < nl)); t += 4) {
+        if (t < nl) {
+          const uint32_t v = ld4u(in32, ls + t);
+          const uint32_t keep = nl - t >= 4u ? ~0u : ((1u << (8u * (nl - t))) - 1u);
+          nhigh += (uint32_t)__popc(v & ((v & 0x70707070u) + 0x70707070u) & 0x80808080u & keep);
+        }
+      }
+      const uint32_t B = mn + 8u * nl + nhigh;
+      const uint32_t incl = wave_incl_scan(B);
+      for (uint32_t i0 = 0; i0 < 64u;) {                         // uniform: passes over consecutive lanes whose bits fit the ring
+        const uint32_t before_bits = i0 ? (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)i0 - 1) : 0u;
+        const bool fits = (uint32_t)lane >= i0 && incl - before_bits <= kTPassBits;
+        const uint64_t fm = __ballot(fits) >> i0;                // (incl does not decrease: the fitting lanes are a run starting at i0)
+        const uint32_t nfit = fm == ~0ull ? 64u - i0 : (uint32_t)__builtin_ctzll(~fm);
+        const uint32_t i1 = i0 + nfit;
+        const uint32_t pass_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)i1 - 1) - before_bits;
+        if (((bitpos + pass_bits) >> 3) > share + 16u) { gave_up = true; break; }      // uniform: the part is not shrinking, the whole block will be stored
+        const bool mine = (uint32_t)lane >= i0 && (uint32_t)lane < i1;
+        uint32_t o = bitpos + (incl - B) - before_bits;
+        if (mine && mn) ring_or(ring, o, mb, mn);
+        o += mn;
+        for (uint32_t t = 0; __any((int)(mine && t < nl)); t += 3) {
+          if (mine && t < nl) {
+            const uint32_t v = ld4u(in32, ls + t);
+            const uint32_t k = nl - t < 3u ? nl - t : 3u;
+            uint32_t bits = 0, nb = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < 3u; ++q) {
+              uint32_t sb, sn;
+              fixed_litlen((v >> (8u * q)) & 0xFFu, sb, sn);
+              if (q < k) { bits |= sb << nb; nb += sn; }
+            }
+            ring_or(ring, o, bits, nb);
+            o += nb;
+          }
+        }
+        bitpos += pass_bits;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        while ((bitpos >> 5) - flushed >= (uint32_t)kTFlush) {   // uniform: full words leave, their ring slots are zeroed for reuse
+          const uint32_t slot = (flushed + (uint32_t)lane) & (kTRing - 1);
+          out_words[flushed + lane] = ring[slot];
+          ring[slot] = 0;
+          flushed += kTFlush;
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
+        i0 = i1;
+      }
+    }
+    if (!gave_up) {
+      bitpos += 7u;                                              // end of block: seven zero bits
+      if ((uint32_t)wv != last_wave) {                           // an empty stored block: the next part starts on a byte boundary
+        bitpos = (bitpos + 3u + 7u) & ~7u;
+        if (lane == 0) ring_or(ring, bitpos + 16u, 0xFFFFu, 16u);
+        bitpos += 32u;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      }
+      payload = (bitpos + 7u) >> 3;
+      if (payload > share + 25u) gave_up = true;
+      else for (uint32_t i = flushed + lane; i < ((bitpos + 31u) >> 5); i += 64) out_words[i] = ring[i & (kTRing - 1)];
+    }
+    if (lane == 0) { s_payload[wv] = payload; s_gave_up[wv] = gave_up ? 1u : 0u; }
+  }
+  // ---- CRC-32 of the block: every thread its nine dwords + the GF(2) shift over what follows them ---------------------------------------
+  {
+    const uint32_t* T0 = crc_slice, *T1 = crc_slice + 256, *T2 = crc_slice + 512, *T3 = crc_slice + 768;
+    uint32_t c = 0;
+    if (n == (uint32_t)kBgzfBlockInput) {
+      constexpr uint32_t kPiece = kBgzfBlockInput / 4 / kTThreads + 1;      // 9: an odd count (the threads' reads fall into different banks)
+      uint32_t r = tid == 0 ? 0xFFFFFFFFu : 0u;
+      const uint32_t w_begin = kPiece * (uint32_t)tid;
+      const uint32_t w_end = w_begin + kPiece < (uint32_t)(kBgzfBlockInput / 4) ? w_begin + kPiece : (uint32_t)(kBgzfBlockInput / 4);
+      for (uint32_t i = w_begin; i < w_end; ++i) {
+        const uint32_t x = r ^ in32[i];
+        r = T3[x & 0xFFu] ^ T2[(x >> 8) & 0xFFu] ^ T1[(x >> 16) & 0xFFu] ^ T0[x >> 24];
+      }
+      const uint32_t* S = crc_shift256 + (size_t)tid * 1024;
+      c = S[r & 0xFFu] ^ S[256 + ((r >> 8) & 0xFFu)] ^ S[512 + ((r >> 16) & 0xFFu)] ^ S[768 + (r >> 24)];
+      c = wave_xor(c);
+    } else if (tid == 0) {                                        // the short last block of a page: one thread, serially
+      uint32_t r = 0xFFFFFFFFu, i = 0;
+      for (; i + 4 <= n; i += 4) { const uint32_t x = r ^ lds_read_u32(in + i); r = T3[x & 0xFFu] ^ T2[(x >> 8) & 0xFFu] ^ T1[(x >> 16) & 0xFFu] ^ T0[x >> 24]; }
+      for (; i < n; ++i) r = T0[(r ^ in[i]) & 0xFFu] ^ (r >> 8);
+      c = r;
+    }
+    if (lane == 0) s_crc[wv] = c;
+  }
+  __syncthreads();
+  uint32_t total = 0;
+  bool store = false;
+#pragma unroll
+  for (int k = 0; k < kTW; ++k) { total += s_payload[k]; store = store || s_gave_up[k]; }
+  store = store || total >= n + 5u || n == 0u;
+  if (store) {
+    uint8_t* o = slots + blk * (uint64_t)kSlotBytes;             // (the stored block spans the parts of the slot)
+    if (tid == 0) { o[0] = 1; o[1] = (uint8_t)(n & 0xFFu); o[2] = (uint8_t)(n >> 8); o[3] = (uint8_t)(~n & 0xFFu); o[4] = (uint8_t)((~n >> 8) & 0xFFu); }
+    for (uint32_t i = tid; i < n; i += kTThreads) o[5 + i] = in[i];
+  }
+  if (tid == 0) {
+    const uint32_t crc = (s_crc[0] ^ s_crc[1] ^ s_crc[2] ^ s_crc[3]) ^ 0xFFFFFFFFu;
+    uint32_t sum = 0;
+    for (int k = 0; k < kTW; ++k) {
+      const uint32_t pk = store ? (k ? 0u : n + 5u) : s_payload[k];
+      csize[kParts * blk + k] = pk; coff[kParts * blk + k] = store ? 0u : s_off[k];
+      sum += pk;
+    }
+    bsize[blk] = (uint64_t)sum + kBgzfHeaderBytes + kBgzfTrailerBytes; crc_out[blk] = crc;
   }
 }
 
@@ -434,11 +735,12 @@ __device__ __forceinline__ void pack_copy(const uint8_t* s, uint8_t* d, uint32_t
   const uint32_t tail_at = head + (nw << 2);
   if ((uint32_t)lane < c - tail_at) d[tail_at + lane] = s[tail_at + lane];
 }
-__global__ void __launch_bounds__(64) k_bgzf_pack(const uint8_t* __restrict__ slots, const uint32_t* __restrict__ csize, const uint64_t* __restrict__ boff,
+__global__ void __launch_bounds__(64) k_bgzf_pack(const uint8_t* __restrict__ slots, const uint32_t* __restrict__ csize, const uint32_t* __restrict__ coff, const uint64_t* __restrict__ boff,
                                                   const uint32_t* __restrict__ crc, uint64_t n_total, uint8_t* __restrict__ dst, uint32_t kBgzfBlockInput) {
   const uint64_t blk = blockIdx.x;
   const int lane = threadIdx.x;
-  const uint32_t c0 = csize[2 * blk], c1 = csize[2 * blk + 1], c = c0 + c1;       // the block's payload: one part, or the two wavefronts' parts
+  uint32_t c = 0;                                                               // the block's payload: up to kParts pieces of the slot
+  for (int k = 0; k < kParts; ++k) c += csize[kParts * blk + k];
   uint8_t* o = dst + boff[blk];
   const uint64_t base = blk * (uint64_t)kBgzfBlockInput;
   const uint32_t n = (uint32_t)((n_total - base) < (uint64_t)kBgzfBlockInput ? (n_total - base) : (uint64_t)kBgzfBlockInput);
@@ -451,12 +753,16 @@ __global__ void __launch_bounds__(64) k_bgzf_pack(const uint8_t* __restrict__ sl
     o[kBgzfHeaderBytes + c + (uint32_t)(lane - 18)] = (uint8_t)((v >> (8 * ((lane - 18) & 3))) & 0xFFu);
   }
   const uint8_t* s = slots + blk * (uint64_t)slot_bytes(kBgzfBlockInput);
-  pack_copy(s, o + kBgzfHeaderBytes, c0, lane);
-  pack_copy(s + slot_bytes(kBgzfBlockInput) / 2, o + kBgzfHeaderBytes + c0, c1, lane);
+  uint32_t at = 0;
+  for (int k = 0; k < kParts; ++k) {                                            // (uniform)
+    const uint32_t ck = csize[kParts * blk + k];
+    pack_copy(s + coff[kParts * blk + k], o + kBgzfHeaderBytes + at, ck, lane);   // (part offsets are multiples of 4)
+    at += ck;
+  }
 }
 
 // ---- CRC-32 tables (reflected polynomial 0xEDB88320, the gzip CRC) -------------------------------------------------------------
-void build_crc_tables(std::vector<uint32_t>& slice, std::vector<uint32_t>& shift, int block_bytes) {
+void build_crc_tables(std::vector<uint32_t>& slice, std::vector<uint32_t>& shift, int block_bytes, int lanes = 64) {
   slice.assign(4 * 256, 0);
   for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1; slice[i] = c; }
   for (uint32_t i = 0; i < 256; ++i) for (int t = 1; t < 4; ++t) { const uint32_t prev = slice[(t - 1) * 256 + i]; slice[t * 256 + i] = (prev >> 8) ^ slice[prev & 0xFFu]; }
@@ -464,15 +770,15 @@ void build_crc_tables(std::vector<uint32_t>& slice, std::vector<uint32_t>& shift
   // behind(i) bytes: its register has to be advanced over that many zero bytes.  cols = the images of the 32 unit vectors under
   // "advance over k zero bytes", stepped from k = 0 upwards; a lane's table is written when k reaches its count.
   auto zero_byte = [&](uint32_t r) { return slice[r & 0xFFu] ^ (r >> 8); };
-  const int nw = block_bytes / 4, pw = nw / 64 + 1;
-  std::vector<int> behind(64);
-  for (int lane = 0; lane < 64; ++lane) { const int end = std::min((lane + 1) * pw, nw), begin = std::min(lane * pw, nw); behind[lane] = begin < end ? 4 * (nw - end) : -1; }
-  shift.assign((size_t)64 * 1024, 0);      // (a lane without dwords contributes nothing: its register stays 0, any table will do)
+  const int nw = block_bytes / 4, pw = nw / lanes + 1;
+  std::vector<int> behind(lanes);
+  for (int lane = 0; lane < lanes; ++lane) { const int end = std::min((lane + 1) * pw, nw), begin = std::min(lane * pw, nw); behind[lane] = begin < end ? 4 * (nw - end) : -1; }
+  shift.assign((size_t)lanes * 1024, 0);   // (a lane without dwords contributes nothing: its register stays 0, any table will do)
   uint32_t cols[32];
   for (int j = 0; j < 32; ++j) cols[j] = 1u << j;
   auto apply = [&](uint32_t v) { uint32_t o = 0; for (int j = 0; j < 32; ++j) if ((v >> j) & 1u) o ^= cols[j]; return o; };
   for (int k = 0; k <= block_bytes; ++k) {
-    for (int lane = 0; lane < 64; ++lane) if (behind[lane] == k)
+    for (int lane = 0; lane < lanes; ++lane) if (behind[lane] == k)
       for (int t = 0; t < 4; ++t) for (uint32_t b = 0; b < 256; ++b) shift[(size_t)lane * 1024 + t * 256 + b] = apply(b << (8 * t));
     for (int j = 0; j < 32; ++j) cols[j] = zero_byte(cols[j]);
   }
@@ -486,6 +792,8 @@ uint32_t bgzf_block_input() {
 }
 
 // wavefronts per 8 KiB block: 2 (default: k_bgzf_deflate2) or 1 (GDBAMD_BGZF_WAVES=1: the kernel of rounds 3-4, for A/B runs)
+// pages of VCF text through the anchored kernel (k_bgzf_deflate_text, 8 KiB blocks only); GDBAMD_BGZF_TEXT=0: the byte-level kernel for everything (A/B runs)
+static bool bgzf_text_kernel() { static const bool v = []() { const char* e = getenv("GDBAMD_BGZF_TEXT"); return !(e && *e == '0'); }(); return v; }
 static int bgzf_waves_per_block() { static const int v = []() { const char* e = getenv("GDBAMD_BGZF_WAVES"); return e && *e == '1' ? 1 : 2; }(); return v; }
 
 std::string bgzf_compress_host(const std::string& bytes) {
@@ -516,7 +824,9 @@ std::string bgzf_compress_host(const std::string& bytes) {
 }
 
 struct BgzfDeviceCompressor::Impl {
-  uint32_t* d_slice = nullptr; uint32_t* d_shift = nullptr; uint32_t block = 0;
+  uint32_t* d_slice = nullptr; uint32_t* d_shift = nullptr; uint32_t* d_shift256 = nullptr; uint32_t block = 0;
+  uint32_t* coff = nullptr;
+  bool text = false;
   uint8_t* slots = nullptr; size_t slots_cap = 0;
   uint32_t* csize = nullptr; uint32_t* crc = nullptr; uint64_t* bsize = nullptr; uint64_t* boff = nullptr; size_t blocks_cap = 0;
   void* temp = nullptr; size_t temp_cap = 0;
@@ -525,7 +835,7 @@ struct BgzfDeviceCompressor::Impl {
   struct Job { hipEvent_t ev0 = nullptr, ev1 = nullptr, done = nullptr; bool pending = false; } job[2];
   uint64_t* h_total = nullptr;          // pinned, [2]
   void release() {
-    for (void* p : {(void*)d_slice, (void*)d_shift, (void*)slots, (void*)csize, (void*)crc, (void*)bsize, (void*)boff, temp}) if (p) (void)hipFree(p);
+    for (void* p : {(void*)d_slice, (void*)d_shift, (void*)d_shift256, (void*)slots, (void*)csize, (void*)coff, (void*)crc, (void*)bsize, (void*)boff, temp}) if (p) (void)hipFree(p);
     for (Job& j : job) for (hipEvent_t e : {j.ev0, j.ev1, j.done}) if (e) (void)hipEventDestroy(e);
     if (h_total) (void)hipHostFree(h_total);
   }
@@ -549,6 +859,11 @@ void BgzfDeviceCompressor::enqueue(int slot, const char* dev_src, uint64_t n, ch
     BGZF_HIP(hipMalloc((void**)&S.d_shift, shift.size() * 4));
     BGZF_HIP(hipMemcpy(S.d_slice, slice.data(), slice.size() * 4, hipMemcpyHostToDevice));
     BGZF_HIP(hipMemcpy(S.d_shift, shift.data(), shift.size() * 4, hipMemcpyHostToDevice));
+    if (S.block == 8192u) {                                     // the text kernel's CRC: 256 threads x 9 dwords
+      build_crc_tables(slice, shift, 8192, kTThreads);
+      BGZF_HIP(hipMalloc((void**)&S.d_shift256, shift.size() * 4));
+      BGZF_HIP(hipMemcpy(S.d_shift256, shift.data(), shift.size() * 4, hipMemcpyHostToDevice));
+    }
     for (Impl::Job& j : S.job) {
       BGZF_HIP(hipEventCreate(&j.ev0));
       BGZF_HIP(hipEventCreate(&j.ev1));
@@ -562,9 +877,9 @@ void BgzfDeviceCompressor::enqueue(int slot, const char* dev_src, uint64_t n, ch
   // (growing a scratch buffer frees memory the other queued job may still use: the stream has to be idle for that)
   if (S.blocks_cap < nblocks + 1) {
     BGZF_HIP(hipStreamSynchronize(st));
-    for (void* p : {(void*)S.csize, (void*)S.crc, (void*)S.bsize, (void*)S.boff}) if (p) (void)hipFree(p);
+    for (void* p : {(void*)S.csize, (void*)S.coff, (void*)S.crc, (void*)S.bsize, (void*)S.boff}) if (p) (void)hipFree(p);
     const size_t cap = (size_t)nblocks + (size_t)(nblocks >> 3) + 64;
-    BGZF_HIP(hipMalloc((void**)&S.csize, cap * 8)); BGZF_HIP(hipMalloc((void**)&S.crc, cap * 4));   // (two payload parts per block)
+    BGZF_HIP(hipMalloc((void**)&S.csize, cap * 4 * kParts)); BGZF_HIP(hipMalloc((void**)&S.coff, cap * 4 * kParts)); BGZF_HIP(hipMalloc((void**)&S.crc, cap * 4));   // (kParts payload parts per block)
     BGZF_HIP(hipMalloc((void**)&S.bsize, cap * 8)); BGZF_HIP(hipMalloc((void**)&S.boff, cap * 8));
     S.blocks_cap = cap;
   }
@@ -587,29 +902,34 @@ void BgzfDeviceCompressor::enqueue(int slot, const char* dev_src, uint64_t n, ch
   Impl::Job& J = S.job[slot];
   BGZF_HIP(hipEventRecord(J.ev0, st));
   if (kBgzfBlockInput == 16384u)
-    hipLaunchKernelGGL(k_bgzf_deflate<16384>, dim3((unsigned)nblocks), dim3(64), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.bsize, S.crc, (const uint32_t*)S.d_slice,
+    hipLaunchKernelGGL(k_bgzf_deflate<16384>, dim3((unsigned)nblocks), dim3(64), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.coff, S.bsize, S.crc, (const uint32_t*)S.d_slice,
                        (const uint32_t*)S.d_shift);
   else if (kBgzfBlockInput == 6144u)
-    hipLaunchKernelGGL(k_bgzf_deflate<6144>, dim3((unsigned)nblocks), dim3(64), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.bsize, S.crc, (const uint32_t*)S.d_slice,
+    hipLaunchKernelGGL(k_bgzf_deflate<6144>, dim3((unsigned)nblocks), dim3(64), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.coff, S.bsize, S.crc, (const uint32_t*)S.d_slice,
                        (const uint32_t*)S.d_shift);
   else if (kBgzfBlockInput == 4096u)
-    hipLaunchKernelGGL(k_bgzf_deflate<4096>, dim3((unsigned)nblocks), dim3(64), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.bsize, S.crc, (const uint32_t*)S.d_slice,
+    hipLaunchKernelGGL(k_bgzf_deflate<4096>, dim3((unsigned)nblocks), dim3(64), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.coff, S.bsize, S.crc, (const uint32_t*)S.d_slice,
                        (const uint32_t*)S.d_shift);
+  else if (S.text && bgzf_text_kernel())
+    hipLaunchKernelGGL(k_bgzf_deflate_text<8192>, dim3((unsigned)nblocks), dim3(kTThreads), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.coff, S.bsize, S.crc, (const uint32_t*)S.d_slice,
+                       (const uint32_t*)S.d_shift256);
   else if (bgzf_waves_per_block() >= 2)
-    hipLaunchKernelGGL(k_bgzf_deflate2<8192>, dim3((unsigned)nblocks), dim3(128), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.bsize, S.crc, (const uint32_t*)S.d_slice,
+    hipLaunchKernelGGL(k_bgzf_deflate2<8192>, dim3((unsigned)nblocks), dim3(128), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.coff, S.bsize, S.crc, (const uint32_t*)S.d_slice,
                        (const uint32_t*)S.d_shift);
   else
-    hipLaunchKernelGGL(k_bgzf_deflate<8192>, dim3((unsigned)nblocks), dim3(64), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.bsize, S.crc, (const uint32_t*)S.d_slice,
+    hipLaunchKernelGGL(k_bgzf_deflate<8192>, dim3((unsigned)nblocks), dim3(64), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.coff, S.bsize, S.crc, (const uint32_t*)S.d_slice,
                        (const uint32_t*)S.d_shift);
   BGZF_HIP(hipMemsetAsync(S.bsize + nblocks, 0, sizeof(uint64_t), st));
   BGZF_HIP(rocprim::exclusive_scan(S.temp, bytes, S.bsize, S.boff, (uint64_t)0, (size_t)nblocks + 1, rocprim::plus<uint64_t>(), st));
-  hipLaunchKernelGGL(k_bgzf_pack, dim3((unsigned)nblocks), dim3(64), 0, st, (const uint8_t*)S.slots, (const uint32_t*)S.csize, (const uint64_t*)S.boff, (const uint32_t*)S.crc, n,
+  hipLaunchKernelGGL(k_bgzf_pack, dim3((unsigned)nblocks), dim3(64), 0, st, (const uint8_t*)S.slots, (const uint32_t*)S.csize, (const uint32_t*)S.coff, (const uint64_t*)S.boff, (const uint32_t*)S.crc, n,
                      (uint8_t*)dev_dst, kBgzfBlockInput);
   BGZF_HIP(hipEventRecord(J.ev1, st));
   BGZF_HIP(hipMemcpyAsync(S.h_total + slot, S.boff + nblocks, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   BGZF_HIP(hipEventRecord(J.done, st));
   J.pending = true;
 }
+
+void BgzfDeviceCompressor::set_text(bool pages_are_vcf_text) { m_->text = pages_are_vcf_text; }
 
 uint64_t BgzfDeviceCompressor::finish(int slot, float* ms_kernels) {
   slot &= 1;

@@ -3799,7 +3799,7 @@ struct DevicePipeline::Impl {
   // so the device works on page k + 1 - assembly and compression - while the host hands out page k
   void queue_compression(int ai, char* arena, uint64_t page_bytes) {
     if (!hp.bgzf || page_bytes == 0) return;
-    if (!bgzf) bgzf.reset(new BgzfDeviceCompressor);
+    if (!bgzf) { bgzf.reset(new BgzfDeviceCompressor); bgzf->set_text(!hp.plan.bcf_mode); }   // ("z": pages of VCF text through the anchored kernel; "b": BCF2 records through the byte-level one)
     bgzf->enqueue(ai, arena, page_bytes, arena, (void*)stream);
   }
   DevBuf<unsigned int> slot_bump;               // pass 0's bump allocator of the overflow text pool: next unit, texts it could not place

@@ -121,6 +121,9 @@ void* gdbamd_engine_create_format(const char* query_json_text, int device, int i
 void* gdbamd_engine_create_output_format(const char* query_json_text, int device, const char* output_format, int use_missing_values_only_not_vector_end);  /* "", "bu", "z", "b": with "z" / "b" the pages hold BGZF blocks (no header, no EOF block) */
 /* n host bytes as BGZF blocks (no EOF block), compressed by the device kernels; gdbamd_bgzf_bound(n) bytes of dst always suffice */
 int gdbamd_bgzf_compress(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t dst_cap, uint64_t* dst_len, float* ms_kernels);
+/* the same with the kernel chosen: vcf_text != 0 = the anchored kernel the "z" stream uses for its pages of VCF text (matches begin at tabs /
+ * newlines; any bytes give a valid stream), 0 = the byte-level kernel ("b", and what gdbamd_bgzf_compress runs) */
+int gdbamd_bgzf_compress_mode(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t dst_cap, uint64_t* dst_len, float* ms_kernels, int vcf_text);
 uint64_t gdbamd_bgzf_bound(uint64_t n);
 void gdbamd_engine_destroy(void* engine);
 int gdbamd_engine_num_fields(void* engine);                                     /* plan fields = staged attribute columns */

@@ -317,6 +317,8 @@ int hostsim_nth_element_same(const float* values, int64_t n, int64_t nth, int de
 int hostsim_genotype_map(const int32_t* m2i, int num_merged, int nr_in, int ploidy, int64_t* out, int cap) {
   EntryMaps em;
   memset(&em, 0, sizeof(em));
+  int8_t m2i_store[GDB_MAX_MERGED_ALLELES];
+  em.m2i = m2i_store;
   for (int k = 0; k < GDB_MAX_MERGED_ALLELES; ++k) em.m2i[k] = (int8_t)(k < num_merged ? m2i[k] : -1);
   em.nr_in = nr_in; em.light = false; em.remap = true;
   std::vector<int32_t> data(100000);

@@ -21,5 +21,8 @@ case "$1" in
            run none_l1 GDBAMD_SLOT_STORE=2 GDBAMD_BENCH_LANES=1
            for i in 1 2; do run coop_l3_$i GDBAMD_SLOT_STORE=1; run lane_l3_$i GDBAMD_SLOT_STORE=0; done ;;
   slotdbg) for i in 1 2; do run base_$i GDBAMD_BENCH_LANES=1; run onecell_$i GDBAMD_SLOT_DBG=8 GDBAMD_BENCH_LANES=1; run noemit_$i GDBAMD_SLOT_DBG=16 GDBAMD_BENCH_LANES=1; done ;;
-  *) echo "usage: round6_ab.sh warm|store|slotdbg" ;;
+  variant) # $2 = name under build/variants (the build before a change): the in-tree library against it
+           for i in 1 2 3; do run new_l1_$i GDBAMD_BENCH_LANES=1; run old_l1_$i GDBAMD_LIB_PATH=$GRAFT_REPO_ROOT/build/variants/$2/libgenomicsdb_amd.so GDBAMD_BENCH_LANES=1; done
+           for i in 1 2; do run new_l3_$i A=1; run old_l3_$i GDBAMD_LIB_PATH=$GRAFT_REPO_ROOT/build/variants/$2/libgenomicsdb_amd.so; done ;;
+  *) echo "usage: round6_ab.sh warm|store|slotdbg|variant NAME" ;;
 esac 2>&1 | tee $o/result.txt
