@@ -36,7 +36,7 @@ FLAGS = ["--offload-arch=gfx950", "-gline-tables-only", "-O3", "-std=c++17", "-f
 def _headers():
     out = []
     for d, _, fs in os.walk(CSRC):
-        out += [os.path.join(d, f) for f in fs if f.endswith((".h", ".hpp"))]
+        out += [os.path.join(d, f) for f in fs if f.endswith((".h", ".hpp", ".inc"))]
     out.append(os.path.join(ROOT, "include", "genomicsdb_amd.h"))
     return out
 

@@ -423,31 +423,34 @@ __global__ void __launch_bounds__(128) k_bgzf_deflate2(const uint8_t* __restrict
 }
 
 
-// ---- VCF TEXT: matches only where an entry begins ("anchored" LZ77, round 6) --------------------------------------------------------------
+// ---- VCF TEXT: matches only where an entry begins ("anchored" LZ77) + a Huffman code made for VCF text (round 6) -----------------------
 // The byte-level kernels above hash and probe all 64 positions of a step although the greedy parse visits ~6 of them (every position
 // inside a match is wasted work): 13.3 K vector instructions per 8 KiB block, and the kernel is bound by the instructions it issues.
 // VCF text says where matches begin: a sample column ("\t./.:99:.:.:0,297,4455,...") repeats the column of some earlier sample with
 // the same leading fields.  So a lane here is not a byte position but an ANCHOR - a tab or newline (where 64 bytes go by without one:
 // the first ':' or ',' of a 32-byte chunk, else the chunk's first byte; at most one anchor per 8 bytes, so a block has <= 1 024 and a
-// segment - the bytes from an anchor to the next - is at most 95 bytes long):
+// segment - the bytes from an anchor to the next - is at most 102 bytes long):
 //   * hash of the anchor's first 8 bytes -> the most recent earlier anchor with that hash (a table per wavefront, entered sixteen lanes at a
 //     time so that an anchor finds candidates among the lanes in front of it; the three lanes right in front are compared directly);
 //   * ONE match per anchor, measured to its end but never beyond the next anchor, then the rest of the segment as literals: no lane
-//     depends on another lane's match, there is no parse chain;
-//   * every lane knows its bit count (length / distance codes by arithmetic, 8 or 9 bits per literal), a wavefront scan places the lanes,
-//     and each lane ORs its own tokens - the match, then its literals three at a time - into the ring of output words.
+//     depends on another lane's match, there is no parse chain.
 // FOUR wavefronts share a block (its 8 KiB of input sit in LDS once): the anchors are found by all 256 threads, each wavefront takes a
-// quarter of them, primes its table with the anchors in front of its quarter, and writes a DEFLATE block of its own that ends with an
-// empty stored block (zlib's sync flush: the next one starts on a byte boundary), like k_bgzf_deflate2's halves.  The CRC-32 is taken
-// by all four.  A block that does not shrink is stored.  ANY set of anchors gives a valid stream - they only decide how much is found -
-// so binary pages (BCF2) keep the byte-level kernel and the text kernel is chosen by the producer of the page (gdb_bgzf.h).
+// quarter of them and primes its table with the anchors in front of its quarter.  PASS 1 finds the matches and counts every anchor's
+// bits (kept in LDS: length, distance, bit count); after a barrier every lane knows where its bits go in the block's ONE bit string;
+// PASS 2 ORs them - the match, then the literals four at a time - into an LDS image of the payload, which leaves as coalesced stores.
+// The block is ONE DEFLATE block of BTYPE = 10 whose Huffman code is the same in every block (gdb_bgzf_text_code.inc, generated by
+// tests/tools/bgzf_text_code.py from VCF text: digits 4 bits, ':' 3, ',' 5, tab 8, every other byte 8 - 12; the 67-byte header that
+// describes the code is a constant bit string): a literal of this text costs 4.2 bits instead of the fixed code's 8.
+// The CRC-32 is taken by all four wavefronts.  A block that does not shrink is stored.  ANY set of anchors gives a valid stream - they
+// only decide how much is found - so binary pages (BCF2) keep the byte-level kernel and the producer of the page says which one runs.
+#include "gdb_bgzf_text_code.inc"
 constexpr int kTW = 4;                          // wavefronts per block
 constexpr int kTThreads = 64 * kTW;
 constexpr int kTMaxAnch = 1024;                 // (one per 8 bytes of an 8 KiB block)
-constexpr int kTHashBits = 9;
-constexpr int kTRing = 256, kTFlush = 64;       // ring of output words per wavefront: < 64 words wait, a pass adds < 192
-constexpr uint32_t kTPassBits = 6000;           // bits the lanes of one pass may add (a lane: at most 31 + 95 x 9)
+constexpr int kTHashBits = 8;
 constexpr uint32_t kTNoCand = 0xFFFFu;
+constexpr int kTCodeWords = 192;                // the code as the kernels read it: u16 (bits << 12 | reversed code) x 286 literal / length + 30 distance symbols, header words behind
+constexpr int kTHeaderAt = 160;                 // word index of the header in that table: [nbits][words ...]
 
 // 0x80 in every byte of v that equals the byte repeated in pat (exact, no carries between bytes)
 __device__ __forceinline__ uint32_t eq_bytes(uint32_t v, uint32_t pat) {
@@ -460,16 +463,27 @@ __device__ __forceinline__ uint32_t ld4u(const uint32_t* in32, uint32_t q) {
   const uint32_t wq = q >> 2;
   return __builtin_amdgcn_alignbyte(in32[wq + 1], in32[wq], q & 3u);
 }
-__device__ __forceinline__ void ring_or(uint32_t* ring, uint32_t bitoff, uint32_t bits, uint32_t nb) {   // nb <= 32, bits < 2^nb
+__device__ __forceinline__ void image_or(uint32_t* image, uint32_t bitoff, uint32_t bits, uint32_t nb) {   // nb <= 32, bits < 2^nb
   const uint32_t w = bitoff >> 5, sh = bitoff & 31u;
-  atomicOr(&ring[w & (kTRing - 1)], bits << sh);
-  if (sh + nb > 32u) atomicOr(&ring[(w + 1u) & (kTRing - 1)], bits >> (32u - sh));
+  atomicOr(&image[w], bits << sh);
+  if (sh + nb > 32u) atomicOr(&image[w + 1u], bits >> (32u - sh));
+}
+// length / distance symbols of a match of L bytes at distance d + 1 (RFC 1951 3.2.5): symbol, extra bits, their count
+__device__ __forceinline__ void match_symbols(uint32_t L, uint32_t d, uint32_t& lsym, uint32_t& lextra, uint32_t& lnb, uint32_t& dsym, uint32_t& dextra, uint32_t& dnb) {
+  const uint32_t l = L - 3u;
+  lnb = l < 8u ? 0u : (31u - (uint32_t)__clz(l | 8u)) - 2u;
+  lsym = l < 8u ? 257u + l : 261u + 4u * lnb + ((l >> lnb) & 3u);
+  lextra = l & ((1u << lnb) - 1u);
+  if (L == 258u) { lsym = 285u; lextra = 0; lnb = 0; }
+  dnb = d < 4u ? 0u : (31u - (uint32_t)__clz(d | 4u)) - 1u;
+  dsym = d < 4u ? d : 2u * dnb + 2u + ((d >> dnb) & 1u);
+  dextra = d & ((1u << dnb) - 1u);
 }
 
 template <int kBgzfBlockInput>
 __global__ void __launch_bounds__(kTThreads) k_bgzf_deflate_text(const uint8_t* __restrict__ src, uint64_t n_total, uint8_t* __restrict__ slots, uint32_t* __restrict__ csize,
                                                                  uint32_t* __restrict__ coff, uint64_t* __restrict__ bsize, uint32_t* __restrict__ crc_out,
-                                                                 const uint32_t* __restrict__ crc_slice, const uint32_t* __restrict__ crc_shift256) {
+                                                                 const uint32_t* __restrict__ crc_slice, const uint32_t* __restrict__ crc_shift256, const uint32_t* __restrict__ text_code) {
   static_assert(kBgzfBlockInput == 8192, "256 threads x 32 bytes");
   const uint64_t blk = blockIdx.x;
   const uint64_t base = blk * (uint64_t)kBgzfBlockInput;
@@ -477,20 +491,24 @@ __global__ void __launch_bounds__(kTThreads) k_bgzf_deflate_text(const uint8_t* 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr uint32_t kSlotBytes = slot_bytes((uint32_t)kBgzfBlockInput);
+  constexpr int kImageWords = kBgzfBlockInput / 4 + 32;            // the payload while it is put together: never more than the input (else the block is stored)
   __shared__ uint4 in4[kBgzfBlockInput / 16 + 3];
+  __shared__ uint32_t image[kImageWords];
+  __shared__ uint32_t minfo[kTMaxAnch];                            // per anchor: match length (7 bits: a segment has <= 102 bytes) | (distance - 1) << 7 (13 bits) | bits of its tokens << 20 (<= 31 + 102 x 12)
   __shared__ uint16_t anch[kTMaxAnch + 2];
   __shared__ uint16_t table_all[kTW][(1 << kTHashBits) + 2];
-  __shared__ uint32_t ring_all[kTW][kTRing];
-  __shared__ uint32_t s_cnt[kTW], s_payload[kTW], s_gave_up[kTW], s_crc[kTW], s_off[kTW];
+  __shared__ uint32_t code_w[kTCodeWords];
+  __shared__ uint32_t s_cnt[kTW], s_crc[kTW], s_step_bits[kTW * 4];
   __shared__ uint8_t s_has_tab[kTThreads];
   uint8_t* const in = reinterpret_cast<uint8_t*>(in4);
   const uint32_t* const in32 = reinterpret_cast<const uint32_t*>(in4);
+  const uint16_t* const code = reinterpret_cast<const uint16_t*>(code_w);       // [0, 286): literals / lengths, [288, 318): distances
   load_block<kBgzfBlockInput>(in4, src + base, n, tid, kTThreads);
   uint16_t* const table = table_all[wv];
-  uint32_t* const ring = ring_all[wv];
   for (uint32_t q = lane; q < (1u << kTHashBits) + 2u; q += 64) table[q] = (uint16_t)kTNoCand;
-  for (uint32_t q = lane; q < (uint32_t)kTRing; q += 64) ring[q] = 0u;
-  if (tid < kTW) { s_payload[tid] = 0u; s_gave_up[tid] = 0u; s_off[tid] = 0u; }
+  for (uint32_t q = tid; q < (uint32_t)kImageWords; q += kTThreads) image[q] = 0u;
+  if (tid < kTCodeWords) code_w[tid] = text_code[tid];
+  if (tid < kTW * 4) s_step_bits[tid] = 0u;
   __syncthreads();
   // ---- anchors: thread t looks at the 32 bytes [32 t, 32 t + 32) ----------------------------------------------------------------------
   const uint32_t chunk = 32u * (uint32_t)tid;
@@ -530,30 +548,22 @@ __global__ void __launch_bounds__(kTThreads) k_bgzf_deflate_text(const uint8_t* 
   }
   if (tid == 0) anch[A] = (uint16_t)n;                          // (A <= 1 024; n <= 8 192 fits)
   __syncthreads();
-  // ---- this wavefront's quarter of the anchors ---------------------------------------------------------------------------------------------
-  const uint32_t per = A ? (A + kTW - 1) / kTW : 1u;
+  // ---- PASS 1: this wavefront's quarter of the anchors: matches and bit counts --------------------------------------------------------------
+  const uint32_t per = A ? (A + kTW - 1) / kTW : 1u;           // (<= 256: at most four steps of 64 per wavefront)
   const uint32_t lo = (uint32_t)wv * per < A ? (uint32_t)wv * per : A, hi = lo + per < A ? lo + per : A;
-  const uint32_t last_wave = A ? (A - 1u) / per : 0u;
-  const bool working = lo < hi;
-  uint32_t payload = 0;
-  bool gave_up = false;
-  if (working) {                                                 // (uniform)
-    const uint32_t begin = anch[lo], end = anch[hi], share = end - begin;
-    const uint32_t off = ((begin + 3u) & ~3u) + 32u * (uint32_t)wv;      // the part's place in the slot: its output never grows past share + 25 bytes
-    uint32_t* const out_words = reinterpret_cast<uint32_t*>(slots + blk * (uint64_t)kSlotBytes + off);
-    if (lane == 0) { ring[0] = (uint32_t)wv == last_wave ? 3u : 2u; s_off[wv] = off; }     // BFINAL on the block's last part, BTYPE = 01
-    // the dictionary: the anchors in front of the quarter enter the table (which of two lanes with one hash stays is not defined: either is a candidate)
-    for (uint32_t j0 = 0; j0 < lo; j0 += 64) {
-      const uint32_t j = j0 + (uint32_t)lane;
-      if (j < lo) {
-        const uint32_t a = anch[j];
-        const uint32_t h = ((ld4u(in32, a) * 2654435761u) ^ (ld4u(in32, a + 4u) * 2246822519u)) >> (32 - kTHashBits);
-        table[h] = (uint16_t)a;
-      }
+  // the dictionary: the anchors in front of the quarter enter the table (which of two lanes with one hash stays is not defined: either is a candidate)
+  for (uint32_t j0 = 0; j0 < lo; j0 += 64) {
+    const uint32_t j = j0 + (uint32_t)lane;
+    if (j < lo) {
+      const uint32_t a = anch[j];
+      const uint32_t h = ((ld4u(in32, a) * 2654435761u) ^ (ld4u(in32, a + 4u) * 2246822519u)) >> (32 - kTHashBits);
+      table[h] = (uint16_t)a;
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    uint32_t bitpos = 3, flushed = 0;
-    for (uint32_t s0 = lo; s0 < hi && !gave_up; s0 += 64) {      // uniform
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  {
+    int step = 0;
+    for (uint32_t s0 = lo; s0 < hi; s0 += 64, ++step) {         // uniform
       const uint32_t j = s0 + (uint32_t)lane;
       const bool act = j < hi;
       const uint32_t a = act ? anch[j] : 0u, e = act ? anch[j + 1] : 0u;
@@ -567,6 +577,7 @@ __global__ void __launch_bounds__(kTThreads) k_bgzf_deflate_text(const uint8_t* 
         if ((lane >> 4) == q) table[h] = (uint16_t)a;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       }
+      if (!act) cand = -1;
 #pragma unroll
       for (int k = 3; k >= 1; --k) {                             // the three anchors right in front (more recent than anything in the table)
         const uint32_t nw0 = (uint32_t)__shfl_up((int)w0, k, 64), nw1 = (uint32_t)__shfl_up((int)w1, k, 64);
@@ -578,7 +589,7 @@ __global__ void __launch_bounds__(kTThreads) k_bgzf_deflate_text(const uint8_t* 
       const uint32_t maxL = seg < 258u ? seg : 258u;
       uint32_t L = 0;
       {
-        bool go = act && cand >= 0;
+        bool go = cand >= 0;
         const uint32_t cpos = go ? (uint32_t)cand : 0u;
         while (__any((int)go)) {
           const uint32_t x = ld4u(in32, a + L) ^ ld4u(in32, cpos + L);
@@ -590,88 +601,27 @@ __global__ void __launch_bounds__(kTThreads) k_bgzf_deflate_text(const uint8_t* 
         L = L < maxL ? L : maxL;
         if (L < 4u) L = 0;
       }
-      const uint32_t d = (a - (uint32_t)(cand >= 0 ? cand : 0)) - 1u;      // distance - 1
-      // the match's code: length symbol + extra bits, 5-bit distance symbol + extra bits (as in emit_tokens above)
-      uint32_t mb = 0, mn = 0;
+      const uint32_t d = L ? (a - (uint32_t)cand) - 1u : 0u;      // distance - 1
+      uint32_t B = 0;
       if (L) {
-        const uint32_t l = L - 3u;
-        const uint32_t leb = l < 8u ? 0u : (31u - (uint32_t)__clz(l | 8u)) - 2u;
-        uint32_t lsym = l < 8u ? 257u + l : 261u + 4u * leb + ((l >> leb) & 3u);
-        uint32_t lextra = l & ((1u << leb) - 1u), lextra_bits = leb;
-        if (L == 258u) { lsym = 285u; lextra = 0; lextra_bits = 0; }
-        uint32_t sb, sn;
-        fixed_litlen(lsym, sb, sn);
-        const uint32_t deb = d < 4u ? 0u : (31u - (uint32_t)__clz(d | 4u)) - 1u;
-        const uint32_t dsym = d < 4u ? d : 2u * deb + 2u + ((d >> deb) & 1u);
-        const uint32_t dextra = d & ((1u << deb) - 1u);
-        mb = sb | (lextra << sn); mn = sn + lextra_bits;
-        mb |= (__brev(dsym) >> 27) << mn; mn += 5u;
-        mb |= dextra << mn; mn += deb;
+        uint32_t lsym, lextra, lnb, dsym, dextra, dnb;
+        match_symbols(L, d, lsym, lextra, lnb, dsym, dextra, dnb);
+        B = (uint32_t)(code[lsym] >> 12) + lnb + (uint32_t)(code[288u + dsym] >> 12) + dnb;
       }
-      // the literals behind it: 8 bits each, 9 for the bytes from 144 up
+      // the literals behind it: their codes' lengths
       const uint32_t ls = a + L, nl = act ? seg - L : 0u;
-      uint32_t nhigh = 0;
       for (uint32_t t = 0; __any((int)(t < nl)); t += 4) {
         if (t < nl) {
           const uint32_t v = ld4u(in32, ls + t);
-          const uint32_t keep = nl - t >= 4u ? ~0u : ((1u << (8u * (nl - t))) - 1u);
-          nhigh += (uint32_t)__popc(v & ((v & 0x70707070u) + 0x70707070u) & 0x80808080u & keep);
-        }
-      }
-      const uint32_t B = mn + 8u * nl + nhigh;
-      const uint32_t incl = wave_incl_scan(B);
-      for (uint32_t i0 = 0; i0 < 64u;) {                         // uniform: passes over consecutive lanes whose bits fit the ring
-        const uint32_t before_bits = i0 ? (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)i0 - 1) : 0u;
-        const bool fits = (uint32_t)lane >= i0 && incl - before_bits <= kTPassBits;
-        const uint64_t fm = __ballot(fits) >> i0;                // (incl does not decrease: the fitting lanes are a run starting at i0)
-        const uint32_t nfit = fm == ~0ull ? 64u - i0 : (uint32_t)__builtin_ctzll(~fm);
-        const uint32_t i1 = i0 + nfit;
-        const uint32_t pass_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)i1 - 1) - before_bits;
-        if (((bitpos + pass_bits) >> 3) > share + 16u) { gave_up = true; break; }      // uniform: the part is not shrinking, the whole block will be stored
-        const bool mine = (uint32_t)lane >= i0 && (uint32_t)lane < i1;
-        uint32_t o = bitpos + (incl - B) - before_bits;
-        if (mine && mn) ring_or(ring, o, mb, mn);
-        o += mn;
-        for (uint32_t t = 0; __any((int)(mine && t < nl)); t += 3) {
-          if (mine && t < nl) {
-            const uint32_t v = ld4u(in32, ls + t);
-            const uint32_t k = nl - t < 3u ? nl - t : 3u;
-            uint32_t bits = 0, nb = 0;
+          const uint32_t k = nl - t < 4u ? nl - t : 4u;
 #pragma unroll
-            for (uint32_t q = 0; q < 3u; ++q) {
-              uint32_t sb, sn;
-              fixed_litlen((v >> (8u * q)) & 0xFFu, sb, sn);
-              if (q < k) { bits |= sb << nb; nb += sn; }
-            }
-            ring_or(ring, o, bits, nb);
-            o += nb;
-          }
+          for (uint32_t q = 0; q < 4u; ++q) if (q < k) B += (uint32_t)(code[(v >> (8u * q)) & 0xFFu] >> 12);
         }
-        bitpos += pass_bits;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        while ((bitpos >> 5) - flushed >= (uint32_t)kTFlush) {   // uniform: full words leave, their ring slots are zeroed for reuse
-          const uint32_t slot = (flushed + (uint32_t)lane) & (kTRing - 1);
-          out_words[flushed + lane] = ring[slot];
-          ring[slot] = 0;
-          flushed += kTFlush;
-          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        }
-        i0 = i1;
       }
+      if (act) minfo[j] = L | (d << 7) | (B << 20);
+      const uint32_t incl = wave_incl_scan(B);
+      if (lane == 63) s_step_bits[wv * 4 + step] = incl;
     }
-    if (!gave_up) {
-      bitpos += 7u;                                              // end of block: seven zero bits
-      if ((uint32_t)wv != last_wave) {                           // an empty stored block: the next part starts on a byte boundary
-        bitpos = (bitpos + 3u + 7u) & ~7u;
-        if (lane == 0) ring_or(ring, bitpos + 16u, 0xFFFFu, 16u);
-        bitpos += 32u;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      }
-      payload = (bitpos + 7u) >> 3;
-      if (payload > share + 25u) gave_up = true;
-      else for (uint32_t i = flushed + lane; i < ((bitpos + 31u) >> 5); i += 64) out_words[i] = ring[i & (kTRing - 1)];
-    }
-    if (lane == 0) { s_payload[wv] = payload; s_gave_up[wv] = gave_up ? 1u : 0u; }
   }
   // ---- CRC-32 of the block: every thread its nine dwords + the GF(2) shift over what follows them ---------------------------------------
   {
@@ -698,25 +648,74 @@ __global__ void __launch_bounds__(kTThreads) k_bgzf_deflate_text(const uint8_t* 
     if (lane == 0) s_crc[wv] = c;
   }
   __syncthreads();
-  uint32_t total = 0;
-  bool store = false;
+  // ---- where everybody's bits go: [3 bits BFINAL / BTYPE][header][steps in anchor order][end of block] ------------------------------------
+  const uint32_t hdr_bits = code_w[kTHeaderAt];
+  uint32_t total_bits = 3u + hdr_bits, my_base = 0;
 #pragma unroll
-  for (int k = 0; k < kTW; ++k) { total += s_payload[k]; store = store || s_gave_up[k]; }
-  store = store || total >= n + 5u || n == 0u;
+  for (int k = 0; k < kTW * 4; ++k) { if (k == wv * 4) my_base = total_bits; total_bits += s_step_bits[k]; }
+  const uint32_t eob_bits = (uint32_t)(code[256] >> 12);
+  const uint32_t payload = (total_bits + eob_bits + 7u) >> 3;
+  const bool store = payload >= n + 5u || n == 0u;              // uniform over the block
+  uint8_t* const o = slots + blk * (uint64_t)kSlotBytes;
+  if (!store) {
+    // ---- PASS 2: the tokens into the image ---------------------------------------------------------------------------------------------
+    if (wv == 0) {
+      if (lane == 0) { atomicOr(&image[0], 5u); image_or(image, total_bits, (uint32_t)code[256] & 0xFFFu, eob_bits); }      // BFINAL = 1, BTYPE = 10; end of block
+      for (uint32_t w = lane; w * 32u < hdr_bits; w += 64) {
+        const uint32_t nb = hdr_bits - w * 32u < 32u ? hdr_bits - w * 32u : 32u;
+        image_or(image, 3u + w * 32u, code_w[kTHeaderAt + 1 + w], nb);
+      }
+    }
+    uint32_t step_base = my_base;
+    int step = 0;
+    for (uint32_t s0 = lo; s0 < hi; s0 += 64, ++step) {         // uniform
+      const uint32_t j = s0 + (uint32_t)lane;
+      const bool act = j < hi;
+      const uint32_t a = act ? anch[j] : 0u, e = act ? anch[j + 1] : 0u;
+      const uint32_t info = act ? minfo[j] : 0u;
+      const uint32_t L = info & 127u, d = (info >> 7) & 8191u, B = info >> 20;
+      const uint32_t incl = wave_incl_scan(B);
+      uint32_t ob = step_base + incl - B;
+      if (L) {
+        uint32_t lsym, lextra, lnb, dsym, dextra, dnb;
+        match_symbols(L, d, lsym, lextra, lnb, dsym, dextra, dnb);
+        const uint32_t lc = code[lsym], dc = code[288u + dsym];
+        const uint32_t ln = lc >> 12, dn = dc >> 12;
+        image_or(image, ob, (lc & 0xFFFu) | (lextra << ln), ln + lnb);                // <= 12 + 5 bits
+        image_or(image, ob + ln + lnb, (dc & 0xFFFu) | (dextra << dn), dn + dnb);     // <= 12 + 13 bits
+        ob += ln + lnb + dn + dnb;
+      }
+      const uint32_t ls = a + L, nl = act ? (e - a) - L : 0u;
+      for (uint32_t t = 0; __any((int)(t < nl)); t += 4) {
+        if (t < nl) {
+          const uint32_t v = ld4u(in32, ls + t);
+          const uint32_t k = nl - t < 4u ? nl - t : 4u;
+          uint32_t b01 = 0, n01 = 0, b23 = 0, n23 = 0;           // two literals per word: <= 24 bits
+          { const uint32_t c0 = code[v & 0xFFu]; b01 = c0 & 0xFFFu; n01 = c0 >> 12; }
+          if (k > 1u) { const uint32_t c1 = code[(v >> 8) & 0xFFu]; b01 |= (c1 & 0xFFFu) << n01; n01 += c1 >> 12; }
+          if (k > 2u) { const uint32_t c2 = code[(v >> 16) & 0xFFu]; b23 = c2 & 0xFFFu; n23 = c2 >> 12; }
+          if (k > 3u) { const uint32_t c3 = code[v >> 24]; b23 |= (c3 & 0xFFFu) << n23; n23 += c3 >> 12; }
+          image_or(image, ob, b01, n01);
+          if (n23) image_or(image, ob + n01, b23, n23);
+          ob += n01 + n23;
+        }
+      }
+      step_base += s_step_bits[wv * 4 + step];
+    }
+  }
+  __syncthreads();
   if (store) {
-    uint8_t* o = slots + blk * (uint64_t)kSlotBytes;             // (the stored block spans the parts of the slot)
     if (tid == 0) { o[0] = 1; o[1] = (uint8_t)(n & 0xFFu); o[2] = (uint8_t)(n >> 8); o[3] = (uint8_t)(~n & 0xFFu); o[4] = (uint8_t)((~n >> 8) & 0xFFu); }
     for (uint32_t i = tid; i < n; i += kTThreads) o[5 + i] = in[i];
+  } else {
+    uint32_t* const ow = reinterpret_cast<uint32_t*>(o);
+    for (uint32_t i = tid; i < (payload + 3u) >> 2; i += kTThreads) ow[i] = image[i];
   }
   if (tid == 0) {
     const uint32_t crc = (s_crc[0] ^ s_crc[1] ^ s_crc[2] ^ s_crc[3]) ^ 0xFFFFFFFFu;
-    uint32_t sum = 0;
-    for (int k = 0; k < kTW; ++k) {
-      const uint32_t pk = store ? (k ? 0u : n + 5u) : s_payload[k];
-      csize[kParts * blk + k] = pk; coff[kParts * blk + k] = store ? 0u : s_off[k];
-      sum += pk;
-    }
-    bsize[blk] = (uint64_t)sum + kBgzfHeaderBytes + kBgzfTrailerBytes; crc_out[blk] = crc;
+    const uint32_t p0 = store ? n + 5u : payload;
+    for (int k = 0; k < kParts; ++k) { csize[kParts * blk + k] = k ? 0u : p0; coff[kParts * blk + k] = 0u; }
+    bsize[blk] = (uint64_t)p0 + kBgzfHeaderBytes + kBgzfTrailerBytes; crc_out[blk] = crc;
   }
 }
 
@@ -762,6 +761,36 @@ __global__ void __launch_bounds__(64) k_bgzf_pack(const uint8_t* __restrict__ sl
 }
 
 // ---- CRC-32 tables (reflected polynomial 0xEDB88320, the gzip CRC) -------------------------------------------------------------
+// the text kernel's code as it reads it: u16 (bits << 12 | code, bit-reversed for the LSB-first stream) for the 286 literal / length symbols at
+// [0, 286) and the 30 distance symbols at [288, 318), then at word kTHeaderAt the header: its bit count and its bits.  The canonical codes follow
+// from the lengths (RFC 1951 3.2.2); a set of lengths that is not a complete prefix code (Kraft sum != 1) would make every stream unreadable: refused.
+std::vector<uint32_t> build_text_code() {
+  std::vector<uint32_t> words(kTCodeWords, 0u);
+  uint16_t* c16 = reinterpret_cast<uint16_t*>(words.data());
+  auto canonical = [&](const uint8_t* bits, int nsym, int at) {
+    uint32_t count[16] = {0}, next[16] = {0};
+    uint64_t kraft = 0;
+    for (int i = 0; i < nsym; ++i) { if (bits[i] > 12) throw std::runtime_error("BGZF: text code longer than 12 bits"); if (bits[i]) { ++count[bits[i]]; kraft += 1ull << (12 - bits[i]); } }
+    if (kraft != (1ull << 12)) throw std::runtime_error("BGZF: the text code's lengths are not a complete prefix code");
+    uint32_t code = 0;
+    for (int b = 1; b <= 12; ++b) { code = (code + count[b - 1]) << 1; next[b] = code; }
+    for (int i = 0; i < nsym; ++i) {
+      const uint32_t len = bits[i];
+      if (!len) { c16[at + i] = 0; continue; }
+      const uint32_t cw = next[len]++;
+      uint32_t rev = 0;
+      for (uint32_t k = 0; k < len; ++k) rev |= ((cw >> k) & 1u) << (len - 1 - k);
+      c16[at + i] = (uint16_t)((len << 12) | rev);
+    }
+  };
+  canonical(kTextLitLenBits, 286, 0);
+  canonical(kTextDistBits, 30, 288);
+  if ((kTextHeaderNBits + 31) / 32 + kTHeaderAt + 1 > (uint32_t)kTCodeWords) throw std::runtime_error("BGZF: text code header too long");
+  words[kTHeaderAt] = kTextHeaderNBits;
+  for (uint32_t i = 0; i < sizeof(kTextHeader); ++i) words[kTHeaderAt + 1 + i / 4] |= (uint32_t)kTextHeader[i] << (8 * (i & 3));
+  return words;
+}
+
 void build_crc_tables(std::vector<uint32_t>& slice, std::vector<uint32_t>& shift, int block_bytes, int lanes = 64) {
   slice.assign(4 * 256, 0);
   for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1; slice[i] = c; }
@@ -825,7 +854,7 @@ std::string bgzf_compress_host(const std::string& bytes) {
 
 struct BgzfDeviceCompressor::Impl {
   uint32_t* d_slice = nullptr; uint32_t* d_shift = nullptr; uint32_t* d_shift256 = nullptr; uint32_t block = 0;
-  uint32_t* coff = nullptr;
+  uint32_t* coff = nullptr; uint32_t* d_text_code = nullptr;
   bool text = false;
   uint8_t* slots = nullptr; size_t slots_cap = 0;
   uint32_t* csize = nullptr; uint32_t* crc = nullptr; uint64_t* bsize = nullptr; uint64_t* boff = nullptr; size_t blocks_cap = 0;
@@ -835,7 +864,7 @@ struct BgzfDeviceCompressor::Impl {
   struct Job { hipEvent_t ev0 = nullptr, ev1 = nullptr, done = nullptr; bool pending = false; } job[2];
   uint64_t* h_total = nullptr;          // pinned, [2]
   void release() {
-    for (void* p : {(void*)d_slice, (void*)d_shift, (void*)d_shift256, (void*)slots, (void*)csize, (void*)coff, (void*)crc, (void*)bsize, (void*)boff, temp}) if (p) (void)hipFree(p);
+    for (void* p : {(void*)d_slice, (void*)d_shift, (void*)d_shift256, (void*)d_text_code, (void*)slots, (void*)csize, (void*)coff, (void*)crc, (void*)bsize, (void*)boff, temp}) if (p) (void)hipFree(p);
     for (Job& j : job) for (hipEvent_t e : {j.ev0, j.ev1, j.done}) if (e) (void)hipEventDestroy(e);
     if (h_total) (void)hipHostFree(h_total);
   }
@@ -863,6 +892,9 @@ void BgzfDeviceCompressor::enqueue(int slot, const char* dev_src, uint64_t n, ch
       build_crc_tables(slice, shift, 8192, kTThreads);
       BGZF_HIP(hipMalloc((void**)&S.d_shift256, shift.size() * 4));
       BGZF_HIP(hipMemcpy(S.d_shift256, shift.data(), shift.size() * 4, hipMemcpyHostToDevice));
+      const std::vector<uint32_t> tc = build_text_code();
+      BGZF_HIP(hipMalloc((void**)&S.d_text_code, tc.size() * 4));
+      BGZF_HIP(hipMemcpy(S.d_text_code, tc.data(), tc.size() * 4, hipMemcpyHostToDevice));
     }
     for (Impl::Job& j : S.job) {
       BGZF_HIP(hipEventCreate(&j.ev0));
@@ -912,7 +944,7 @@ void BgzfDeviceCompressor::enqueue(int slot, const char* dev_src, uint64_t n, ch
                        (const uint32_t*)S.d_shift);
   else if (S.text && bgzf_text_kernel())
     hipLaunchKernelGGL(k_bgzf_deflate_text<8192>, dim3((unsigned)nblocks), dim3(kTThreads), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.coff, S.bsize, S.crc, (const uint32_t*)S.d_slice,
-                       (const uint32_t*)S.d_shift256);
+                       (const uint32_t*)S.d_shift256, (const uint32_t*)S.d_text_code);
   else if (bgzf_waves_per_block() >= 2)
     hipLaunchKernelGGL(k_bgzf_deflate2<8192>, dim3((unsigned)nblocks), dim3(128), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.coff, S.bsize, S.crc, (const uint32_t*)S.d_slice,
                        (const uint32_t*)S.d_shift);
