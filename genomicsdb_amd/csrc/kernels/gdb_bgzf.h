@@ -50,6 +50,8 @@ class BgzfDeviceCompressor {
   void set_text(bool pages_are_vcf_text);
   uint64_t finish(int slot, float* ms_kernels = nullptr);
   void cancel(int slot);
+  // the hipEvent_t recorded behind the slot's last job (nullptr: none yet): for a producer that reuses the job's buffers from ANOTHER stream
+  void* done_event(int slot) const;
   struct Impl;
  private:
   Impl* m_;

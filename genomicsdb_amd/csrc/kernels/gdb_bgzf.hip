@@ -449,6 +449,13 @@ constexpr int kTThreads = 64 * kTW;
 constexpr int kTMaxAnch = 1024;                 // (one per 8 bytes of an 8 KiB block)
 constexpr int kTHashBits = 8;
 constexpr uint32_t kTNoCand = 0xFFFFu;
+#ifndef GDBAMD_BGZF_MERGE
+#define GDBAMD_BGZF_MERGE 1          // 0: every anchor's match is a token of its own (variant builds: what merging costs and brings)
+#endif
+#ifndef GDBAMD_BGZF_CONTINUE_FROM
+#define GDBAMD_BGZF_CONTINUE_FROM 12
+#endif
+constexpr int kTContinueFrom = GDBAMD_BGZF_CONTINUE_FROM;   // secondary anchors a step of 64 must have before its lanes try to continue the lane in front
 constexpr int kTCodeWords = 192;                // the code as the kernels read it: u16 (bits << 12 | reversed code) x 286 literal / length + 30 distance symbols, header words behind
 constexpr int kTHeaderAt = 160;                 // word index of the header in that table: [nbits][words ...]
 
@@ -480,6 +487,39 @@ __device__ __forceinline__ void match_symbols(uint32_t L, uint32_t d, uint32_t& 
   dextra = d & ((1u << dnb) - 1u);
 }
 
+// Matches of consecutive anchors that continue each other (the lane in front matched its whole segment, and this lane's match lies at the
+// same distance) are ONE match: `cont` marks the lanes that continue the lane in front.  Returns, for the first lane of every run, the
+// run's length (<= 258: runs are cut where the sum would pass it); `cont` comes back with the cuts made.
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v) {        // (values >= 0: the 0 the DPP moves fill in is the identity)
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));   // row_shr:1
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));   // row_shr:2
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true));   // row_shr:4
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true));   // row_shr:8
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));  // row_bcast:15
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));  // row_bcast:31
+  return v;
+}
+__device__ __forceinline__ uint32_t merged_run_length(uint32_t L, bool& cont, int lane) {
+  const uint32_t P = wave_incl_scan(L);                         // sums of L up to and including the lane
+  const uint32_t E = P - L;
+  uint32_t S = 0, head = 0, cut_guard = 0;
+  for (;;) {                                                     // uniform: as many rounds as a run has to be cut (nearly always one)
+    head = wave_incl_max(cont ? 0u : (uint32_t)lane + 1u) - 1u;  // the run's first lane (lane 0 never continues anything)
+    S = P - (uint32_t)__shfl((int)E, (int)head, 64);             // the run's length up to and including the lane
+    const bool over = cont && S > 258u;
+    if (!__any((int)over)) break;
+    if (++cut_guard > 8u) { cont = false; continue; }            // (never seen: give up merging in this step - the next round then finds nothing over)
+    const int prev_over = __shfl_up((int)over, 1, 64);
+    if (over && !(lane > 0 && prev_over)) cont = false;         // the first lane of a run that passes 258 starts a run of its own
+  }
+  // the last lane of a run hands the sum to the run's first lane (a push through the LDS crossbar, no memory: every other lane pushes to the lane
+  // behind it, which continues it and has no use for what it receives - so no two lanes push to the same place)
+  const int next_cont = __shfl_down((int)cont, 1, 64);
+  const bool last = lane == 63 || !next_cont;
+  const uint32_t total = (uint32_t)__builtin_amdgcn_ds_permute((int)((last ? head : (uint32_t)lane + 1u) << 2), (int)S);
+  return cont ? 0u : total;
+}
+
 template <int kBgzfBlockInput>
 __global__ void __launch_bounds__(kTThreads) k_bgzf_deflate_text(const uint8_t* __restrict__ src, uint64_t n_total, uint8_t* __restrict__ slots, uint32_t* __restrict__ csize,
                                                                  uint32_t* __restrict__ coff, uint64_t* __restrict__ bsize, uint32_t* __restrict__ crc_out,
@@ -494,7 +534,7 @@ __global__ void __launch_bounds__(kTThreads) k_bgzf_deflate_text(const uint8_t* 
   constexpr int kImageWords = kBgzfBlockInput / 4 + 32;            // the payload while it is put together: never more than the input (else the block is stored)
   __shared__ uint4 in4[kBgzfBlockInput / 16 + 3];
   __shared__ uint32_t image[kImageWords];
-  __shared__ uint32_t minfo[kTMaxAnch];                            // per anchor: match length (7 bits: a segment has <= 102 bytes) | (distance - 1) << 7 (13 bits) | bits of its tokens << 20 (<= 31 + 102 x 12)
+  __shared__ uint32_t minfo[kTMaxAnch];                            // per anchor: match length inside its segment (7 bits: <= 102) | continues the anchor in front << 7 | (distance - 1) << 8 (13 bits) | bits of its tokens << 21 (<= 31 + 102 x 12)
   __shared__ uint16_t anch[kTMaxAnch + 2];
   __shared__ uint16_t table_all[kTW][(1 << kTHashBits) + 2];
   __shared__ uint32_t code_w[kTCodeWords];
@@ -601,11 +641,45 @@ __global__ void __launch_bounds__(kTThreads) k_bgzf_deflate_text(const uint8_t* 
         L = L < maxL ? L : maxL;
         if (L < 4u) L = 0;
       }
+      // A column longer than two chunks has secondary anchors inside it (wide cohorts: PL vectors of 20 and more values).  Such an anchor
+      // first tries to CONTINUE the anchor in front: if that one matched its whole segment at some candidate, the bytes behind the candidate
+      // are the obvious place to look - and the two matches then merge into one token (below).  A few rounds: a continuation adopted by
+      // lane j is what lane j + 1 continues.  Steps with few secondary anchors (c2's columns of ~40 bytes: the occasional variant call) skip
+      // the rounds: there they cost a sixth of the kernel's speed for 4 % of ratio (profiles/r6_ab_bgzf_text_kernel.txt).
+      const bool sec = act && a != 0u && in[a] != (uint8_t)'\t' && in[a] != (uint8_t)'\n';
+      if (__popcll(__ballot(sec)) >= kTContinueFrom) {           // uniform
+        for (int round = 0; round < 4; ++round) {
+          const uint32_t pL = (uint32_t)__shfl_up((int)L, 1, 64), pa = (uint32_t)__shfl_up((int)a, 1, 64);
+          const int32_t pcand = __shfl_up(cand, 1, 64);
+          const int32_t cc = pcand + (int32_t)(a - pa);
+          const bool tryit = sec && lane > 0 && pL > 0u && pL == a - pa && pcand >= 0 && cc != cand;
+          if (!__any((int)tryit)) break;
+          uint32_t L2 = 0;
+          bool go = tryit;
+          const uint32_t cpos = go ? (uint32_t)cc : 0u;
+          while (__any((int)go)) {
+            const uint32_t x = ld4u(in32, a + L2) ^ ld4u(in32, cpos + L2);
+            if (go) {
+              L2 += x ? ((uint32_t)__builtin_ctz(x) >> 3) : 4u;
+              if (x || L2 >= maxL) go = false;
+            }
+          }
+          L2 = L2 < maxL ? L2 : maxL;
+          if (tryit && L2 >= 4u && L2 >= L) { cand = cc; L = L2; }
+        }
+      }
       const uint32_t d = L ? (a - (uint32_t)cand) - 1u : 0u;      // distance - 1
+      bool cont = false;
+      uint32_t T = L;                                            // length of the match token this lane emits (0: none, or merged into the lane in front)
+      {
+        const uint32_t pL = (uint32_t)__shfl_up((int)L, 1, 64), pa = (uint32_t)__shfl_up((int)a, 1, 64), pd = (uint32_t)__shfl_up((int)d, 1, 64);
+        cont = GDBAMD_BGZF_MERGE && act && lane > 0 && L > 0u && pL > 0u && pL == a - pa && pd == d;
+        if (__any((int)cont)) T = merged_run_length(L, cont, lane);      // uniform
+      }
       uint32_t B = 0;
-      if (L) {
+      if (T) {
         uint32_t lsym, lextra, lnb, dsym, dextra, dnb;
-        match_symbols(L, d, lsym, lextra, lnb, dsym, dextra, dnb);
+        match_symbols(T, d, lsym, lextra, lnb, dsym, dextra, dnb);
         B = (uint32_t)(code[lsym] >> 12) + lnb + (uint32_t)(code[288u + dsym] >> 12) + dnb;
       }
       // the literals behind it: their codes' lengths
@@ -618,7 +692,7 @@ __global__ void __launch_bounds__(kTThreads) k_bgzf_deflate_text(const uint8_t* 
           for (uint32_t q = 0; q < 4u; ++q) if (q < k) B += (uint32_t)(code[(v >> (8u * q)) & 0xFFu] >> 12);
         }
       }
-      if (act) minfo[j] = L | (d << 7) | (B << 20);
+      if (act) minfo[j] = L | ((cont ? 1u : 0u) << 7) | (d << 8) | (B << 21);
       const uint32_t incl = wave_incl_scan(B);
       if (lane == 63) s_step_bits[wv * 4 + step] = incl;
     }
@@ -673,12 +747,15 @@ __global__ void __launch_bounds__(kTThreads) k_bgzf_deflate_text(const uint8_t* 
       const bool act = j < hi;
       const uint32_t a = act ? anch[j] : 0u, e = act ? anch[j + 1] : 0u;
       const uint32_t info = act ? minfo[j] : 0u;
-      const uint32_t L = info & 127u, d = (info >> 7) & 8191u, B = info >> 20;
+      const uint32_t L = info & 127u, d = (info >> 8) & 8191u, B = info >> 21;
+      bool cont = ((info >> 7) & 1u) != 0u;
+      uint32_t T = L;
+      if (__any((int)cont)) T = merged_run_length(L, cont, lane);      // (the same runs as in pass 1: nothing is cut a second time)
       const uint32_t incl = wave_incl_scan(B);
       uint32_t ob = step_base + incl - B;
-      if (L) {
+      if (T) {
         uint32_t lsym, lextra, lnb, dsym, dextra, dnb;
-        match_symbols(L, d, lsym, lextra, lnb, dsym, dextra, dnb);
+        match_symbols(T, d, lsym, lextra, lnb, dsym, dextra, dnb);
         const uint32_t lc = code[lsym], dc = code[288u + dsym];
         const uint32_t ln = lc >> 12, dn = dc >> 12;
         image_or(image, ob, (lc & 0xFFFu) | (lextra << ln), ln + lnb);                // <= 12 + 5 bits
@@ -861,7 +938,7 @@ struct BgzfDeviceCompressor::Impl {
   void* temp = nullptr; size_t temp_cap = 0;
   // two jobs may be queued behind each other on one stream (the stream's two page arenas); they share the scratch buffers -
   // stream order keeps them apart - and have their own events and their own pinned word for the size of the result
-  struct Job { hipEvent_t ev0 = nullptr, ev1 = nullptr, done = nullptr; bool pending = false; } job[2];
+  struct Job { hipEvent_t ev0 = nullptr, ev1 = nullptr, done = nullptr; bool pending = false, used = false; } job[2];
   uint64_t* h_total = nullptr;          // pinned, [2]
   void release() {
     for (void* p : {(void*)d_slice, (void*)d_shift, (void*)d_shift256, (void*)d_text_code, (void*)slots, (void*)csize, (void*)coff, (void*)crc, (void*)bsize, (void*)boff, temp}) if (p) (void)hipFree(p);
@@ -958,7 +1035,7 @@ void BgzfDeviceCompressor::enqueue(int slot, const char* dev_src, uint64_t n, ch
   BGZF_HIP(hipEventRecord(J.ev1, st));
   BGZF_HIP(hipMemcpyAsync(S.h_total + slot, S.boff + nblocks, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   BGZF_HIP(hipEventRecord(J.done, st));
-  J.pending = true;
+  J.pending = true; J.used = true;
 }
 
 void BgzfDeviceCompressor::set_text(bool pages_are_vcf_text) { m_->text = pages_are_vcf_text; }
@@ -975,6 +1052,7 @@ uint64_t BgzfDeviceCompressor::finish(int slot, float* ms_kernels) {
 }
 
 void BgzfDeviceCompressor::cancel(int slot) { m_->job[slot & 1].pending = false; }
+void* BgzfDeviceCompressor::done_event(int slot) const { return m_->job[slot & 1].used ? (void*)m_->job[slot & 1].done : nullptr; }
 
 uint64_t BgzfDeviceCompressor::compress(const char* dev_src, uint64_t n, char* dev_dst, void* hip_stream, float* ms_kernels) {
   if (ms_kernels) *ms_kernels = 0;

@@ -3796,7 +3796,9 @@ struct DevicePipeline::Impl {
   DevBuf<uint64_t> chunk_size, chunk_off, rec_off; DevBuf<unsigned long long> max_record;
   std::unique_ptr<BgzfDeviceCompressor> bgzf;   // output formats "z" / "b"
   // "z" / "b": the compression of a page is queued right behind the kernels that assemble it (finish_page only collects the size),
-  // so the device works on page k + 1 - assembly and compression - while the host hands out page k
+  // so the device works on page k + 1 - assembly and compression - while the host hands out page k.  (Round 6 measured the compression on a
+  // stream of its own, beside the assembly of the next page: slower - 5.2-5.4 against 5.7-5.9 M positions/s for "z" - the two compete for the
+  // CUs instead of taking turns: profiles/r6_ab_bgzf_own_stream.txt.)
   void queue_compression(int ai, char* arena, uint64_t page_bytes) {
     if (!hp.bgzf || page_bytes == 0) return;
     if (!bgzf) { bgzf.reset(new BgzfDeviceCompressor); bgzf->set_text(!hp.plan.bcf_mode); }   // ("z": pages of VCF text through the anchored kernel; "b": BCF2 records through the byte-level one)

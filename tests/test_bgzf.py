@@ -131,12 +131,16 @@ def test_device_deflate_text_kernel_on_hostile_inputs(gdb):
         "high bytes in columns": b"".join(b"\t" + bytes(rnd.choice([200, 250, 255, 144, 143, 65]) for _ in range(rnd.randint(0, 40))) for _ in range(4_000)),
         "repeated column": b"\t./.:99:.:.:0,297,4455,297,4455,4455:34:55" * 3_000,
         "columns of 95+ bytes": (b"\t" + b"q" * 300) * 200,
+        # wide-cohort columns: secondary anchors inside a column continue the anchor in front, the matches merge into one token and
+        # runs are cut where they would pass 258 bytes
+        "long PL columns repeated": b"".join((b"\t./.:99:.:.:" + b",".join(b"%d" % (37 * k % 5000) for k in range(g)) + b":34:55") * 3 for g in (21, 28, 36, 45, 66, 120)) * 40,
+        "long PL columns, one value changed": b"".join(b"\t./.:99:.:.:" + b",".join(b"%d" % ((37 * k + (i == k) * 7) % 5000) for k in range(45)) + b":34:55" for i in range(300)),
         "period 255": bytes(range(255)) * 300,
         "8189 + 3": b"q" * 8189 + b"x\tz" + b"r" * 8189 + b"u\tw",
     }
     for name, data in cases.items():
         comp, _ = _check_roundtrip(gdb, data, vcf_text=True)
-        if name in ("vcf records", "vcf records, blocks cut anywhere", "repeated column"):
+        if name in ("vcf records", "vcf records, blocks cut anywhere", "repeated column", "long PL columns repeated", "long PL columns, one value changed"):
             assert len(comp) * 3 < len(data), (name, len(comp), len(data))
         if name in ("random", "one block exactly"):
             assert len(comp) <= len(data) + 31 * ((len(data) + 8191) // 8192), name            # stored blocks: framing only
