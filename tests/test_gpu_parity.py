@@ -1281,6 +1281,15 @@ def test_intervals_in_flight_on_lanes_give_the_same_bytes(gdb, tmp_path, lanes):
     assert want2 != want
     res2 = eng.run_intervals(wins, arena_bytes=1 << 20, lanes=lanes, fetch=True)
     assert b"".join(r[0] for r in res2) == want2
+    # round 6: what a new lane costs (the estimate run_intervals clamps new lanes with against the device's free memory), lanes given back,
+    # and a single interval on the engine's own pipeline afterwards (the lanes' page-priority stream is switched off again behind a run)
+    fp = eng.lane_footprint(W, arena_bytes=1 << 20)
+    assert fp >= (1 << 20) + 18 * N * W and fp < (8 << 30)
+    assert eng.lane_footprint(1_000_000, arena_bytes=64 << 30) > 45 * N * 1_000_000
+    eng.release_lanes()
+    assert eng.run_interval(wins[0][0], wins[0][1], arena_bytes=1 << 20)[0] == res2[0][0]
+    res3 = eng.run_intervals(wins, arena_bytes=1 << 20, lanes=lanes, fetch=True)             # the lanes are created again
+    assert b"".join(r[0] for r in res3) == want2
     eng.close()
 
 
