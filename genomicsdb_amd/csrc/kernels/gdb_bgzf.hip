@@ -899,7 +899,7 @@ uint32_t bgzf_block_input() {
 
 // wavefronts per 8 KiB block: 2 (default: k_bgzf_deflate2) or 1 (GDBAMD_BGZF_WAVES=1: the kernel of rounds 3-4, for A/B runs)
 // pages of VCF text through the anchored kernel (k_bgzf_deflate_text, 8 KiB blocks only); GDBAMD_BGZF_TEXT=0: the byte-level kernel for everything (A/B runs)
-static int bgzf_text_kernel() { static const int v = []() { const char* e = getenv("GDBAMD_BGZF_TEXT"); return e ? atoi(e) : 1; }(); return v; }   // (2: the text kernel for BCF2 pages too - an experiment)
+static bool bgzf_text_kernel() { static const bool v = []() { const char* e = getenv("GDBAMD_BGZF_TEXT"); return !(e && *e == '0'); }(); return v; }
 static int bgzf_waves_per_block() { static const int v = []() { const char* e = getenv("GDBAMD_BGZF_WAVES"); return e && *e == '1' ? 1 : 2; }(); return v; }
 
 std::string bgzf_compress_host(const std::string& bytes) {
@@ -1019,7 +1019,7 @@ void BgzfDeviceCompressor::enqueue(int slot, const char* dev_src, uint64_t n, ch
   else if (kBgzfBlockInput == 4096u)
     hipLaunchKernelGGL(k_bgzf_deflate<4096>, dim3((unsigned)nblocks), dim3(64), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.coff, S.bsize, S.crc, (const uint32_t*)S.d_slice,
                        (const uint32_t*)S.d_shift);
-  else if ((S.text && bgzf_text_kernel()) || bgzf_text_kernel() == 2)
+  else if (S.text && bgzf_text_kernel())
     hipLaunchKernelGGL(k_bgzf_deflate_text<8192>, dim3((unsigned)nblocks), dim3(kTThreads), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.coff, S.bsize, S.crc, (const uint32_t*)S.d_slice,
                        (const uint32_t*)S.d_shift256, (const uint32_t*)S.d_text_code);
   else if (bgzf_waves_per_block() >= 2)

@@ -153,6 +153,51 @@ def test_device_deflate_text_kernel_on_hostile_inputs(gdb):
 
 
 @pytest.mark.gpu
+def test_device_deflate_text_kernel_random_mixtures(gdb):
+    """differential fuzz of the anchored kernel: 150 buffers of random length put together from random pieces - VCF columns that repeat with
+    small changes, runs of one byte, random bytes, delimiters at random densities, long comma-separated vectors repeated exactly (matches that
+    continue each other and merge, cut at 258) - each must inflate to itself through both kernels, and the compressed bytes of the text
+    kernel must be the same on a second run (four wavefronts OR into one LDS image: the order they arrive in must not matter)"""
+    rnd = random.Random(20260930)
+    def piece():
+        k = rnd.randrange(8)
+        if k == 0:
+            gq = rnd.choice([0, 20, 50, 99])
+            return b"".join(b"\t./.:%d:.:.:0,%d,%d:%d:%d" % (gq, 3 * gq, 45 * gq, rnd.randint(10, 60), rnd.randint(10, 60)) for _ in range(rnd.randint(1, 400)))
+        if k == 1:
+            return bytes([rnd.randrange(256)]) * rnd.randint(1, 3000)
+        if k == 2:
+            return bytes(rnd.getrandbits(8) for _ in range(rnd.randint(1, 2000)))
+        if k == 3:
+            dens = rnd.choice([0.5, 0.1, 0.02, 0.005])
+            return bytes(rnd.choice(b"\t\n:,") if rnd.random() < dens else rnd.choice(b"0123456789ACGT./|") for _ in range(rnd.randint(1, 5000)))
+        if k == 4:
+            col = b"\t0/1:" + b",".join(b"%d" % rnd.randint(0, 9999) for _ in range(rnd.randint(3, 150)))
+            return col * rnd.randint(2, 12)
+        if k == 5:
+            col = bytearray(b"\t1|1:" + b",".join(b"%d" % rnd.randint(0, 9999) for _ in range(rnd.randint(10, 80))))
+            out = bytearray()
+            for _ in range(rnd.randint(2, 10)):
+                col[rnd.randrange(len(col))] = rnd.choice(b"0123456789")
+                out += col
+            return bytes(out)
+        if k == 6:
+            return b"1\t%d\t.\tA\tC,<NON_REF>\t.\t.\tDP=%d;END=%d\tGT:AD:DP:GQ:PL\n" % (rnd.randint(1, 10**8), rnd.randint(0, 10**5), rnd.randint(1, 10**8))
+        return bytes(rnd.choice([9, 10, 58, 44, 200, 255, 143, 144, 0]) for _ in range(rnd.randint(1, 300)))
+    for it in range(150):
+        want = rnd.randint(1, 40000)
+        data = bytearray()
+        while len(data) < want:
+            data += piece()
+        data = bytes(data[:want])
+        comp, _ = _check_roundtrip(gdb, data, vcf_text=True)
+        if it % 5 == 0:
+            comp2, _ = gdb.bgzf_compress(data, vcf_text=True)
+            assert comp2 == comp, "the text kernel's output depends on timing"
+            _check_roundtrip(gdb, data, vcf_text=False)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", [c for c in CASES if c[0] in ("t0_1_2_vcf_at_0", "t6_7_8_vcf_at_0", "t0_1_2_all_asa_loading", "info_ops1.vcf", "t0_overlapping")],
                          ids=lambda c: c[0])
 def test_golden_streams_as_bgzf(gdb, case):

@@ -24,5 +24,6 @@ case "$1" in
   variant) # $2 = name under build/variants (the build before a change): the in-tree library against it
            for i in 1 2 3; do run new_l1_$i GDBAMD_BENCH_LANES=1; run old_l1_$i GDBAMD_LIB_PATH=$GRAFT_REPO_ROOT/build/variants/$2/libgenomicsdb_amd.so GDBAMD_BENCH_LANES=1; done
            for i in 1 2; do run new_l3_$i A=1; run old_l3_$i GDBAMD_LIB_PATH=$GRAFT_REPO_ROOT/build/variants/$2/libgenomicsdb_amd.so; done ;;
-  *) echo "usage: round6_ab.sh warm|store|slotdbg|variant NAME" ;;
+  lanes4)  for i in 1 2; do run l3_full_$i GDBAMD_BENCH_LANES=3; run l4_half_$i GDBAMD_BENCH_LANES=4 GDBAMD_BENCH_LANE_ARENA_MB=23040; run l3_half_$i GDBAMD_BENCH_LANES=3 GDBAMD_BENCH_LANE_ARENA_MB=23040; run l4_third_$i GDBAMD_BENCH_LANES=4 GDBAMD_BENCH_LANE_ARENA_MB=15360; done ;;
+  *) echo "usage: round6_ab.sh warm|store|slotdbg|variant NAME|lanes4" ;;
 esac 2>&1 | tee $o/result.txt
