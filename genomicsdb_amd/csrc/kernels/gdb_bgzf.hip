@@ -47,8 +47,11 @@ constexpr int kRingWords = 128, kFlushWords = 64;  // (64 tokens x 31 bits = 62 
 __host__ __device__ constexpr uint32_t slot_bytes(uint32_t block_input) { return block_input + 1024u; }
 constexpr uint32_t kNoCand = 0xFFFFu;
 constexpr uint32_t kTokQueue = 128;
+// hash bits of the byte-level kernels' tables at 8 KiB blocks.  Round 6: 9 instead of 10 - the kernel runs on residency, and 2 KB less LDS per pair
+// of wavefronts are 13 instead of 11 workgroups per CU: BCF2 pages 235 -> 261 GB/s at the same ratio (4.09; 8 bits: 285 GB/s, but text-like input
+// loses 2-3 % of ratio); profiles/r6_ab_bgzf_hash_bits.txt
 #ifndef GDBAMD_BGZF_HASH_BITS_8K
-#define GDBAMD_BGZF_HASH_BITS_8K 10
+#define GDBAMD_BGZF_HASH_BITS_8K 9
 #endif
 
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
