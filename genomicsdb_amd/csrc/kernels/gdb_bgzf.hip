@@ -431,8 +431,8 @@ __global__ void __launch_bounds__(128) k_bgzf_deflate2(const uint8_t* __restrict
 // inside a match is wasted work): 13.3 K vector instructions per 8 KiB block, and the kernel is bound by the instructions it issues.
 // VCF text says where matches begin: a sample column ("\t./.:99:.:.:0,297,4455,...") repeats the column of some earlier sample with
 // the same leading fields.  So a lane here is not a byte position but an ANCHOR - a tab or newline (where 64 bytes go by without one:
-// the first ':' or ',' of a 32-byte chunk, else the chunk's first byte; at most one anchor per 8 bytes, so a block has <= 1 024 and a
-// segment - the bytes from an anchor to the next - is at most 102 bytes long):
+// the first ':' or ',' of a 32-byte chunk, else the chunk's first byte; at most one anchor per 16 bytes, so a block has <= 512 and a
+// segment - the bytes from an anchor to the next - is at most 110 bytes long):
 //   * hash of the anchor's first 8 bytes -> the most recent earlier anchor with that hash (a table per wavefront, entered sixteen lanes at a
 //     time so that an anchor finds candidates among the lanes in front of it; the three lanes right in front are compared directly);
 //   * ONE match per anchor, measured to its end but never beyond the next anchor, then the rest of the segment as literals: no lane
@@ -449,7 +449,7 @@ __global__ void __launch_bounds__(128) k_bgzf_deflate2(const uint8_t* __restrict
 #include "gdb_bgzf_text_code.inc"
 constexpr int kTW = 4;                          // wavefronts per block
 constexpr int kTThreads = 64 * kTW;
-constexpr int kTMaxAnch = 1024;                 // (one per 8 bytes of an 8 KiB block)
+constexpr int kTMaxAnch = 512;                  // (one per 16 bytes of an 8 KiB block)
 constexpr int kTHashBits = 8;
 constexpr uint32_t kTNoCand = 0xFFFFu;
 #ifndef GDBAMD_BGZF_MERGE
@@ -524,7 +524,7 @@ __device__ __forceinline__ uint32_t merged_run_length(uint32_t L, bool& cont, in
 }
 
 template <int kBgzfBlockInput>
-__global__ void __launch_bounds__(kTThreads) k_bgzf_deflate_text(const uint8_t* __restrict__ src, uint64_t n_total, uint8_t* __restrict__ slots, uint32_t* __restrict__ csize,
+__global__ void __launch_bounds__(kTThreads) __attribute__((amdgpu_waves_per_eu(7))) k_bgzf_deflate_text(const uint8_t* __restrict__ src, uint64_t n_total, uint8_t* __restrict__ slots, uint32_t* __restrict__ csize,
                                                                  uint32_t* __restrict__ coff, uint64_t* __restrict__ bsize, uint32_t* __restrict__ crc_out,
                                                                  const uint32_t* __restrict__ crc_slice, const uint32_t* __restrict__ crc_shift256, const uint32_t* __restrict__ text_code) {
   static_assert(kBgzfBlockInput == 8192, "256 threads x 32 bytes");
@@ -537,7 +537,7 @@ __global__ void __launch_bounds__(kTThreads) k_bgzf_deflate_text(const uint8_t* 
   constexpr int kImageWords = kBgzfBlockInput / 4 + 32;            // the payload while it is put together: never more than the input (else the block is stored)
   __shared__ uint4 in4[kBgzfBlockInput / 16 + 3];
   __shared__ uint32_t image[kImageWords];
-  __shared__ uint32_t minfo[kTMaxAnch];                            // per anchor: match length inside its segment (7 bits: <= 102) | continues the anchor in front << 7 | (distance - 1) << 8 (13 bits) | bits of its tokens << 21 (<= 31 + 102 x 12)
+  __shared__ uint32_t minfo[kTMaxAnch];                            // per anchor: match length inside its segment (7 bits: <= 110) | continues the anchor in front << 7 | (distance - 1) << 8 (13 bits) | bits of its tokens << 21 (<= 31 + 110 x 12)
   __shared__ uint16_t anch[kTMaxAnch + 2];
   __shared__ uint16_t table_all[kTW][(1 << kTHashBits) + 2];
   __shared__ uint32_t code_w[kTCodeWords];
@@ -572,11 +572,9 @@ __global__ void __launch_bounds__(kTThreads) k_bgzf_deflate_text(const uint8_t* 
   uint32_t m = mt;
   if (!mt && valid && tid > 0 && !s_has_tab[tid - 1]) m = ms ? (ms & (0u - ms)) : 1u;   // 32 .. 63 bytes without a tab in front: a secondary anchor
   if (tid == 0 && n) m |= 1u;                                                             // the block's first byte
-  {                                                                                       // at most one anchor per 8 bytes: the first of each octet
-    uint32_t t = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { const uint32_t b = (m >> (8 * k)) & 0xFFu; t |= (b & (0u - b)) << (8 * k); }
-    m = t;
+  {                                                                                       // at most one anchor per 16 bytes: the first of each half of the chunk
+    const uint32_t lo16 = m & 0xFFFFu, hi16 = m >> 16;
+    m = (lo16 & (0u - lo16)) | ((hi16 & (0u - hi16)) << 16);
   }
   const uint32_t cnt = (uint32_t)__popc(m);
   const uint32_t incl_c = wave_incl_scan(cnt);
@@ -589,10 +587,10 @@ __global__ void __launch_bounds__(kTThreads) k_bgzf_deflate_text(const uint8_t* 
     uint32_t pos = before + incl_c - cnt;
     while (m) { const uint32_t b = (uint32_t)__builtin_ctz(m); anch[pos++] = (uint16_t)(chunk + b); m &= m - 1u; }
   }
-  if (tid == 0) anch[A] = (uint16_t)n;                          // (A <= 1 024; n <= 8 192 fits)
+  if (tid == 0) anch[A] = (uint16_t)n;                          // (A <= 512; n <= 8 192 fits)
   __syncthreads();
   // ---- PASS 1: this wavefront's quarter of the anchors: matches and bit counts --------------------------------------------------------------
-  const uint32_t per = A ? (A + kTW - 1) / kTW : 1u;           // (<= 256: at most four steps of 64 per wavefront)
+  const uint32_t per = A ? (A + kTW - 1) / kTW : 1u;           // (<= 128: at most two steps of 64 per wavefront)
   const uint32_t lo = (uint32_t)wv * per < A ? (uint32_t)wv * per : A, hi = lo + per < A ? lo + per : A;
   // the dictionary: the anchors in front of the quarter enter the table (which of two lanes with one hash stays is not defined: either is a candidate)
   for (uint32_t j0 = 0; j0 < lo; j0 += 64) {
