@@ -1223,17 +1223,28 @@ __global__ void k_slot_cells(const uint32_t* tbase, const uint32_t* nslots, int6
 // types (reference-only records: three genotypes) with dear ones (PL re-indexed to 6 - 10 genotypes, AD, SB) and every lane waits
 // for the dearest: pass 0 regroups the 256 slots of a workgroup by type first (counting sort in LDS), which gives each of its four
 // wavefronts one to three types.
-constexpr int kLightBlock = 256;
+#ifndef GDBAMD_LIGHT_BLOCK
+#define GDBAMD_LIGHT_BLOCK 256
+#endif
+#ifndef GDBAMD_LIGHT_BLOCK_WIDE
+#define GDBAMD_LIGHT_BLOCK_WIDE 192
+#endif
+constexpr int kLightBlock = GDBAMD_LIGHT_BLOCK;              // threads per workgroup with the narrow strip ...
+constexpr int kLightBlockWide = GDBAMD_LIGHT_BLOCK_WIDE;     // ... and with the wide one: 192 threads = 51 KB of strips = three workgroups = 9 wavefronts per CU (256: two workgroups = 8); 10 000 samples,
+                                                             // device-only 1.59-1.62 -> 1.64 M positions/s (profiles/r6_ab_micro_variants.txt; the same file: the sizing pass at 64 registers and the
+                                                             // narrow-strip kernel at 192 threads x 5 wavefronts per SIMD change nothing / lose)
+template <int STRIPW> constexpr int light_block() { return STRIPW <= kSlotStride / 4 + 1 ? kLightBlock : kLightBlockWide; }
 // With the narrow strip the kernel holds 16 wavefronts per CU by LDS (35 KB per workgroup of four) but 133 registers allowed only 12:
 // capped at 128 (amdgpu_waves_per_eu(4), no spills) the c2 sizing phase is 0.4 ms shorter (10.5 -> 10.1 ms, two A/B pairs on one box).
 // The wide strip (67 KB: 8 wavefronts per CU whatever the registers) keeps its registers.
 #ifndef GDBAMD_LIGHT_WAVES
 #define GDBAMD_LIGHT_WAVES 4
 #endif
-template <int PASS, int STRIPW> __global__ void __launch_bounds__(kLightBlock) __attribute__((amdgpu_waves_per_eu(STRIPW <= kStripWords ? GDBAMD_LIGHT_WAVES : 1))) k_slots_light(SlotTable st, SiteOut so, const int32_t* type_rep, const uint64_t* tmask, const uint32_t* tbase,
+template <int PASS, int STRIPW> __global__ void __launch_bounds__(light_block<STRIPW>()) __attribute__((amdgpu_waves_per_eu(STRIPW <= kStripWords ? GDBAMD_LIGHT_WAVES : 1))) k_slots_light(SlotTable st, SiteOut so, const int32_t* type_rep, const uint64_t* tmask, const uint32_t* tbase,
                                                       const uint32_t* slot_cell, int64_t c_base, int64_t SL, int regroup, uint32_t* err) {
-  __shared__ uint32_t strip[kLightBlock * STRIPW];
-  __shared__ uint32_t tcount[kMaxTypes + 1], job[kLightBlock];
+  constexpr int kThreads = light_block<STRIPW>();
+  __shared__ uint32_t strip[kThreads * STRIPW];
+  __shared__ uint32_t tcount[kMaxTypes + 1], job[kThreads];
   uint32_t* mine = strip + threadIdx.x * STRIPW;
   int64_t sidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool live = sidx < SL;
@@ -1583,7 +1594,12 @@ k_assemble_size(AsmCtx a, const int32_t* __restrict__ order, int64_t n, int32_t 
 // one register compare - and the row's coalesced store).  The sizes do not need a scan per record either: every piece adds its length
 // at its first record and takes it away behind its last in a difference array over the batch's 64 records (LDS atomics), one scan per batch.
 // Bit-identical output (GDBAMD_SIZE3_CHECK=1 runs both and compares).
-template <int R> __global__ void __launch_bounds__(kAsmRows)
+#ifdef GDBAMD_SIZE3_WAVES               // (variant builds: 8 = at most 64 registers)
+#define GDBAMD_SIZE3_ATTR __attribute__((amdgpu_waves_per_eu(GDBAMD_SIZE3_WAVES)))
+#else
+#define GDBAMD_SIZE3_ATTR
+#endif
+template <int R> __global__ void __launch_bounds__(kAsmRows) GDBAMD_SIZE3_ATTR
 k_assemble_size3(AsmCtx a, const int32_t* __restrict__ order, int64_t n, int32_t N, int nchunks, int run, uint64_t* __restrict__ chunk_size,
                  ResMatrix resolved, int64_t resolved_base, int64_t res_rows) {
   __shared__ int64_t ss[kAsmRows];                     // the batch's record starts
@@ -5650,7 +5666,7 @@ void DevicePipeline::prepare_interval(int64_t qb, int64_t qe) {
   STAGE("k_slots<0>");
 #define GDB_SLOT_KERNELS(PASSN, W) do { \
   hipLaunchKernelGGL((k_slots_nocall<PASSN, W>), dim3(1), dim3(kMaxTypes), 0, st, stt, so, S.type_rep.p, ntypes, S.err.p); \
-  if (SL > 0) hipLaunchKernelGGL((k_slots_light<PASSN, W>), dim3(blocks_for((int64_t)SL, kLightBlock)), dim3(kLightBlock), 0, st, stt, so, S.type_rep.p, S.tmask.p, S.tbase.p, (const uint32_t*)S.slot_cell.p, c_base, (int64_t)SL, slot_regroup() ? 1 : 0, S.err.p); \
+  if (SL > 0) hipLaunchKernelGGL((k_slots_light<PASSN, W>), dim3(blocks_for((int64_t)SL, light_block<W>())), dim3(light_block<W>()), 0, st, stt, so, S.type_rep.p, S.tmask.p, S.tbase.p, (const uint32_t*)S.slot_cell.p, c_base, (int64_t)SL, slot_regroup() ? 1 : 0, S.err.p); \
   if (T > 0) hipLaunchKernelGGL((k_slots_heavy<PASSN, W>), dim3(blocks_for(T, 64)), dim3(64), 0, st, stt, so, S.inc_keys_sorted.p, S.inc_vals_sorted.p, T, (int64_t)N, S.err.p); \
   if (UR > 0) hipLaunchKernelGGL((k_slots_untabled<PASSN, W>), dim3(blocks_for(UR * N, 64)), dim3(64), 0, st, stt, so, ri, rec, S.urec.p, UR, N, S.err.p); \
 } while (0)
