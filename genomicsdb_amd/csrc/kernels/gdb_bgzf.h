@@ -48,6 +48,9 @@ class BgzfDeviceCompressor {
   // k_bgzf_deflate_text, about a third of the instructions per block at ~5 % of the ratio.  Any bytes still give a valid stream (the anchors
   // only decide how much is found), but binary pages (BCF2, "b") compress far better with the byte-level kernel, which stays the default.
   void set_text(bool pages_are_vcf_text);
+  // The pages are BCF2 records ("b"): the byte-level kernel with smaller hash tables (more resident workgroups: 285 against 261 GB/s at the same
+  // ratio on BCF2; text-like bytes would lose 2-3 % of ratio, which is why it is not the default for arbitrary input)
+  void set_bcf2(bool pages_are_bcf2_records);
   uint64_t finish(int slot, float* ms_kernels = nullptr);
   void cancel(int slot);
   // the hipEvent_t recorded behind the slot's last job (nullptr: none yet): for a producer that reuses the job's buffers from ANOTHER stream

@@ -48,8 +48,9 @@ __host__ __device__ constexpr uint32_t slot_bytes(uint32_t block_input) { return
 constexpr uint32_t kNoCand = 0xFFFFu;
 constexpr uint32_t kTokQueue = 128;
 // hash bits of the byte-level kernels' tables at 8 KiB blocks.  Round 6: 9 instead of 10 - the kernel runs on residency, and 2 KB less LDS per pair
-// of wavefronts are 13 instead of 11 workgroups per CU: BCF2 pages 235 -> 261 GB/s at the same ratio (4.09; 8 bits: 285 GB/s, but text-like input
-// loses 2-3 % of ratio); profiles/r6_ab_bgzf_hash_bits.txt
+// of wavefronts are 13 instead of 11 workgroups per CU: BCF2 pages 235 -> 261 GB/s at the same ratio (4.09).  8 bits: 285 GB/s on BCF2 pages at the
+// same ratio again, but text-like input loses 2-3 % - so 8 only where the producer says the pages are BCF2 records (BgzfDeviceCompressor::set_bcf2);
+// profiles/r6_ab_bgzf_hash_bits.txt
 #ifndef GDBAMD_BGZF_HASH_BITS_8K
 #define GDBAMD_BGZF_HASH_BITS_8K 9
 #endif
@@ -344,7 +345,7 @@ __global__ void __launch_bounds__(64) k_bgzf_deflate(const uint8_t* __restrict__
 // becomes a DEFLATE block of its own, the first one ends with an empty stored block (3 bits + padding + 00 00 FF FF: zlib's sync flush),
 // which makes the second one start on a byte boundary; the pack kernel puts the two payloads behind each other.  Both wavefronts share
 // the 8 KiB of input in LDS: 14.4 KB per pair = 22 wavefronts per CU instead of 14.  Ratio: a match cannot cross the middle, + 5 bytes.
-template <int kBgzfBlockInput>
+template <int kBgzfBlockInput, int kHashBitsAt8K = GDBAMD_BGZF_HASH_BITS_8K>
 __global__ void __launch_bounds__(128) k_bgzf_deflate2(const uint8_t* __restrict__ src, uint64_t n_total, uint8_t* __restrict__ slots, uint32_t* __restrict__ csize, uint32_t* __restrict__ coff,
                                                        uint64_t* __restrict__ bsize, uint32_t* __restrict__ crc_out, const uint32_t* __restrict__ crc_slice,
                                                        const uint32_t* __restrict__ crc_shift) {
@@ -355,7 +356,7 @@ __global__ void __launch_bounds__(128) k_bgzf_deflate2(const uint8_t* __restrict
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);    // (wave-uniform)
   constexpr uint32_t kHalf = kBgzfBlockInput / 2;
   __shared__ uint4 in4[kBgzfBlockInput / 16 + 3];
-  constexpr int kHashBits = kBgzfBlockInput > 8192 ? 11 : kBgzfBlockInput > 4096 ? GDBAMD_BGZF_HASH_BITS_8K : 9;
+  constexpr int kHashBits = kBgzfBlockInput > 8192 ? 11 : kBgzfBlockInput > 4096 ? kHashBitsAt8K : 9;
   constexpr uint32_t kSlotBytes = slot_bytes((uint32_t)kBgzfBlockInput);
   constexpr uint32_t kTableWords = (1 << kHashBits) / 2 + 2;
   __shared__ uint32_t table32[2][kTableWords];
@@ -933,7 +934,7 @@ std::string bgzf_compress_host(const std::string& bytes) {
 struct BgzfDeviceCompressor::Impl {
   uint32_t* d_slice = nullptr; uint32_t* d_shift = nullptr; uint32_t* d_shift256 = nullptr; uint32_t block = 0;
   uint32_t* coff = nullptr; uint32_t* d_text_code = nullptr;
-  bool text = false;
+  bool text = false, bcf2 = false;
   uint8_t* slots = nullptr; size_t slots_cap = 0;
   uint32_t* csize = nullptr; uint32_t* crc = nullptr; uint64_t* bsize = nullptr; uint64_t* boff = nullptr; size_t blocks_cap = 0;
   void* temp = nullptr; size_t temp_cap = 0;
@@ -1023,6 +1024,9 @@ void BgzfDeviceCompressor::enqueue(int slot, const char* dev_src, uint64_t n, ch
   else if (S.text && bgzf_text_kernel())
     hipLaunchKernelGGL(k_bgzf_deflate_text<8192>, dim3((unsigned)nblocks), dim3(kTThreads), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.coff, S.bsize, S.crc, (const uint32_t*)S.d_slice,
                        (const uint32_t*)S.d_shift256, (const uint32_t*)S.d_text_code);
+  else if (bgzf_waves_per_block() >= 2 && S.bcf2)
+    hipLaunchKernelGGL((k_bgzf_deflate2<8192, 8>), dim3((unsigned)nblocks), dim3(128), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.coff, S.bsize, S.crc, (const uint32_t*)S.d_slice,
+                       (const uint32_t*)S.d_shift);
   else if (bgzf_waves_per_block() >= 2)
     hipLaunchKernelGGL(k_bgzf_deflate2<8192>, dim3((unsigned)nblocks), dim3(128), 0, st, (const uint8_t*)dev_src, n, S.slots, S.csize, S.coff, S.bsize, S.crc, (const uint32_t*)S.d_slice,
                        (const uint32_t*)S.d_shift);
@@ -1040,6 +1044,7 @@ void BgzfDeviceCompressor::enqueue(int slot, const char* dev_src, uint64_t n, ch
 }
 
 void BgzfDeviceCompressor::set_text(bool pages_are_vcf_text) { m_->text = pages_are_vcf_text; }
+void BgzfDeviceCompressor::set_bcf2(bool pages_are_bcf2_records) { m_->bcf2 = pages_are_bcf2_records; }
 
 uint64_t BgzfDeviceCompressor::finish(int slot, float* ms_kernels) {
   slot &= 1;

@@ -3817,7 +3817,7 @@ struct DevicePipeline::Impl {
   // CUs instead of taking turns: profiles/r6_ab_bgzf_own_stream.txt.)
   void queue_compression(int ai, char* arena, uint64_t page_bytes) {
     if (!hp.bgzf || page_bytes == 0) return;
-    if (!bgzf) { bgzf.reset(new BgzfDeviceCompressor); bgzf->set_text(!hp.plan.bcf_mode); }   // ("z": pages of VCF text through the anchored kernel; "b": BCF2 records through the byte-level one)
+    if (!bgzf) { bgzf.reset(new BgzfDeviceCompressor); bgzf->set_text(!hp.plan.bcf_mode); bgzf->set_bcf2(hp.plan.bcf_mode != 0); }   // ("z": pages of VCF text through the anchored kernel; "b": BCF2 records through the byte-level one)
     bgzf->enqueue(ai, arena, page_bytes, arena, (void*)stream);
   }
   DevBuf<unsigned int> slot_bump;               // pass 0's bump allocator of the overflow text pool: next unit, texts it could not place
